@@ -1,0 +1,92 @@
+// Shared helpers for the MRN gfx950 kernel library (libmrn_hip.so).
+// Everything here is internal; the exported surface is include/mrn_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define MRN_EXPORT extern "C" __attribute__((visibility("default")))
+
+// error codes returned across the C ABI (0 = ok, >0 = hipError_t, <0 = library code)
+enum {
+  MRN_OK = 0,
+  MRN_ERR_BAD_ARG = -1,
+  MRN_ERR_UNSUPPORTED = -2,
+  MRN_ERR_WORKSPACE = -3,
+};
+
+void mrn_set_error(const char* fmt, ...);
+
+#define MRN_CHECK_ARG(cond, ...)          \
+  do {                                    \
+    if (!(cond)) {                        \
+      mrn_set_error(__VA_ARGS__);         \
+      return MRN_ERR_BAD_ARG;             \
+    }                                     \
+  } while (0)
+
+// check the launch that just happened (asynchronous errors surface later, as in any HIP code)
+#define MRN_LAUNCH_CHECK(name)                                              \
+  do {                                                                      \
+    hipError_t e__ = hipGetLastError();                                     \
+    if (e__ != hipSuccess) {                                                \
+      mrn_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return (int)e__;                                                      \
+    }                                                                       \
+  } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// XCD-aware remap of a linear workgroup id so that consecutive logical tiles share one XCD's L2
+// (block b is dispatched to XCD b % 8 on gfx950; bijective for any grid size).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int nx = 8;
+  int q = nwg / nx, r = nwg % nx;
+  int xcd = bid % nx, idx = bid / nx;
+  int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// block-wide sum for blocks of NT threads (NT multiple of 64); scratch must hold NT/64 floats
+template <int NT>
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) scratch[w] = v;
+  __syncthreads();
+  float r = 0.f;
+#pragma unroll
+  for (int i = 0; i < NT / 64; ++i) r += scratch[i];
+  return r;
+}
+template <int NT>
+__device__ __forceinline__ float block_max(float v, float* scratch) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) scratch[w] = v;
+  __syncthreads();
+  float r = scratch[0];
+#pragma unroll
+  for (int i = 1; i < NT / 64; ++i) r = fmaxf(r, scratch[i]);
+  return r;
+}
+
+__device__ __forceinline__ float sigmoidf_acc(float x) { return 1.f / (1.f + expf(-x)); }

@@ -1,0 +1,392 @@
+// fp32 MFMA GEMM / implicit-GEMM convolution for gfx950.
+//
+//   C[b][m][n] = act( sum_k A[b][m][k] * W[b][n][k] + bias )      (+ optional per-column sum / sumsq partials)
+//
+// A is either a strided matrix (any of the two dims may be the contiguous one) or an NHWC activation
+// gathered on the fly (implicit im2col: m = (img, oy, ox), k = (ky, kx, ci)).  The math is
+// v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate -- bitwise a k-ordered fmaf chain -- so
+// results stay inside the reference's 1e-4 fp32 parity band (north star).
+//
+// Replaces the reference's conv2d / linear / bmm op sites:
+//   modules/feature_extraction.py:19-44,214-294   modules/transformation.py:60-87
+//   modules/sequence_modeling.py:10  modules/prediction.py:104-107  modules/dm_router.py:41-46
+//   modules/model.py:151,437-438
+//
+// Tiling: block = WM x WN waves (64 lanes each), each wave owns TM x TN tiles of 32x32; BK = 16.
+// LDS image is k-major ([k][row], row contiguous) so the MFMA operand read (lane -> row = lane&31,
+// k = lane>>5) is a conflict-free ds_read_b32 of 32 consecutive floats per half-wave.
+#include "common.hpp"
+#include "gemm.hpp"
+
+namespace {
+
+constexpr int BK = 16;
+
+// floats staged per thread for a ROWS x BK tile (at least one float4)
+constexpr int stage_regs(int rows, int nt) { return rows * BK / nt < 4 ? 4 : rows * BK / nt; }
+
+// ---- strided operand: element (row, k) at base[row*sr + k*sk] --------------------------------
+// mode 0: scalar, k fastest    1: scalar, row fastest    2: float4 along k    3: float4 along row
+template <int ROWS, int NT>
+struct Stage {
+  static constexpr int NP2 = ROWS / (NT / 4) > 0 ? ROWS / (NT / 4) : 1;    // passes, float4 along k
+  static constexpr int RQ = ROWS / 4;                                      // row quads per k
+  static constexpr int KPP3 = (NT / RQ) < BK ? (NT / RQ) : BK;
+  static constexpr int NP3 = BK / KPP3;
+  static constexpr int NP0 = ROWS / (NT / 16) > 0 ? ROWS / (NT / 16) : 1;
+  static constexpr int KPP1 = (NT / ROWS) < BK ? (NT / ROWS) : BK;
+  static constexpr int NP1 = BK / KPP1;
+  static constexpr int LD = ROWS + 4;
+};
+
+template <int ROWS, int NT>
+__device__ __forceinline__ void load_strided(float (&r)[stage_regs(ROWS, NT)], const float* __restrict__ base,
+                                             long sr, long sk, int row0, int k0, int nrows, int K, int mode) {
+  using S = Stage<ROWS, NT>;
+  const int t = threadIdx.x;
+  if (mode == 2) {
+    const int k = k0 + (t & 3) * 4;
+#pragma unroll
+    for (int p = 0; p < S::NP2; ++p) {
+      const int rl = (t >> 2) + p * (NT / 4);
+      const int row = row0 + rl;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (rl < ROWS && row < nrows && k < K) v = *reinterpret_cast<const f32x4*>(base + (long)row * sr + k);
+      r[p * 4 + 0] = v[0]; r[p * 4 + 1] = v[1]; r[p * 4 + 2] = v[2]; r[p * 4 + 3] = v[3];
+    }
+  } else if (mode == 3) {
+    const int rq = t % S::RQ, kk = t / S::RQ;
+    const int row = row0 + rq * 4;
+#pragma unroll
+    for (int p = 0; p < S::NP3; ++p) {
+      const int k = k0 + kk + p * S::KPP3;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (kk < S::KPP3 && row < nrows && k < K) v = *reinterpret_cast<const f32x4*>(base + (long)k * sk + row);
+      r[p * 4 + 0] = v[0]; r[p * 4 + 1] = v[1]; r[p * 4 + 2] = v[2]; r[p * 4 + 3] = v[3];
+    }
+  } else if (mode == 0) {
+    const int k = k0 + (t & 15);
+#pragma unroll
+    for (int p = 0; p < S::NP0; ++p) {
+      const int rl = (t >> 4) + p * (NT / 16);
+      const int row = row0 + rl;
+      r[p] = (rl < ROWS && row < nrows && k < K) ? base[(long)row * sr + (long)k * sk] : 0.f;
+    }
+  } else {
+    const int rr = t % ROWS, kk = t / ROWS;
+    const int row = row0 + rr;
+#pragma unroll
+    for (int p = 0; p < S::NP1; ++p) {
+      const int k = k0 + kk + p * S::KPP1;
+      r[p] = (kk < S::KPP1 && row < nrows && k < K) ? base[(long)row * sr + (long)k * sk] : 0.f;
+    }
+  }
+}
+
+template <int ROWS, int NT>
+__device__ __forceinline__ void store_lds(const float (&r)[stage_regs(ROWS, NT)], float* __restrict__ s, int mode) {
+  using S = Stage<ROWS, NT>;
+  constexpr int LD = S::LD;
+  const int t = threadIdx.x;
+  if (mode == 2) {
+    const int kq = (t & 3) * 4;
+#pragma unroll
+    for (int p = 0; p < S::NP2; ++p) {
+      const int rl = (t >> 2) + p * (NT / 4);
+      if (rl < ROWS) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[(kq + j) * LD + rl] = r[p * 4 + j];
+      }
+    }
+  } else if (mode == 3) {
+    const int rq = t % S::RQ, kk = t / S::RQ;
+#pragma unroll
+    for (int p = 0; p < S::NP3; ++p) {
+      if (kk < S::KPP3) {
+        f32x4 v = {r[p * 4 + 0], r[p * 4 + 1], r[p * 4 + 2], r[p * 4 + 3]};
+        *reinterpret_cast<f32x4*>(s + (kk + p * S::KPP3) * LD + rq * 4) = v;
+      }
+    }
+  } else if (mode == 0) {
+    const int kk = t & 15;
+#pragma unroll
+    for (int p = 0; p < S::NP0; ++p) {
+      const int rl = (t >> 4) + p * (NT / 16);
+      if (rl < ROWS) s[kk * LD + rl] = r[p];
+    }
+  } else {
+    const int rr = t % ROWS, kk = t / ROWS;
+#pragma unroll
+    for (int p = 0; p < S::NP1; ++p)
+      if (kk < S::KPP1) s[(kk + p * S::KPP1) * LD + rr] = r[p];
+  }
+}
+
+// ---- implicit-GEMM gather from an NHWC activation (Cin % 4 == 0) -------------------------------
+struct ConvRow {
+  long base;  // element offset of image b
+  int iy0, ix0;
+  bool ok;
+};
+
+template <int ROWS, int NT>
+__device__ __forceinline__ void load_conv(float (&r)[stage_regs(ROWS, NT)], const GemmParams& p,
+                                          const ConvRow (&rows)[Stage<ROWS, NT>::NP2], int k0) {
+  const int t = threadIdx.x;
+  const int k = k0 + (t & 3) * 4;
+  const bool kok = k < p.K;
+  const int tap = k / p.Cin;
+  const int ci = k - tap * p.Cin;
+  const int ky = tap / p.kw;
+  const int kx = tap - ky * p.kw;
+#pragma unroll
+  for (int q = 0; q < Stage<ROWS, NT>::NP2; ++q) {
+    const int iy = rows[q].iy0 + ky, ix = rows[q].ix0 + kx;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (kok && rows[q].ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.Wd)
+      v = *reinterpret_cast<const f32x4*>(p.A + rows[q].base + ((long)iy * p.Wd + ix) * p.Cin + ci);
+    r[q * 4 + 0] = v[0]; r[q * 4 + 1] = v[1]; r[q * 4 + 2] = v[2]; r[q * 4 + 3] = v[3];
+  }
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == 1) return fmaxf(v, 0.f);
+  if (act == 2) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+  return v;
+}
+
+template <int WM, int WN, int TM, int TN, bool CONV>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_f32_kernel(const GemmParams p) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int LDA = BM + 4, LDB = BN + 4;
+  constexpr int PA = stage_regs(BM, NT), PB = stage_regs(BN, NT);
+  constexpr int NPA = Stage<BM, NT>::NP2;
+  __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA + LDB)];
+  float* const As = smem;                 // two buffers of BK*LDA
+  float* const Bs = smem + 2 * BK * LDA;  // two buffers of BK*LDB
+
+  const int tilesN = (p.N + BN - 1) / BN;
+  const int nwg = gridDim.x;
+  const int lid = xcd_remap(blockIdx.x, nwg);
+  const int tile_m = lid / tilesN, tile_n = lid - tile_m * tilesN;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int bz = blockIdx.z;
+
+  const float* A = p.A + (CONV ? 0 : (long)bz * p.sAb);
+  const float* W = p.W + (long)bz * p.sWb;
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+
+  ConvRow crow[NPA];
+  if (CONV) {
+#pragma unroll
+    for (int q = 0; q < NPA; ++q) {
+      const int rl = (t >> 2) + q * (NT / 4);
+      const int m = m0 + rl;
+      const bool ok = rl < BM && m < p.M;
+      const int mm = ok ? m : 0;
+      const int hw = p.Ho * p.Wo;
+      const int b = mm / hw;
+      const int rem = mm - b * hw;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      crow[q].base = (long)b * p.H * p.Wd * p.Cin;
+      crow[q].iy0 = oy * p.sh - p.ph;
+      crow[q].ix0 = ox * p.sw - p.pw;
+      crow[q].ok = ok;
+    }
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  float ra[PA], rb[PB];
+  const int nk = (p.K + BK - 1) / BK;
+
+  if (CONV) load_conv<BM, NT>(ra, p, crow, 0);
+  else load_strided<BM, NT>(ra, A, p.sAm, p.sAk, m0, 0, p.M, p.K, p.amode);
+  load_strided<BN, NT>(rb, W, p.sWn, p.sWk, n0, 0, p.N, p.K, p.wmode);
+  store_lds<BM, NT>(ra, As, CONV ? 2 : p.amode);
+  store_lds<BN, NT>(rb, Bs, p.wmode);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      if (CONV) load_conv<BM, NT>(ra, p, crow, (kt + 1) * BK);
+      else load_strided<BM, NT>(ra, A, p.sAm, p.sAk, m0, (kt + 1) * BK, p.M, p.K, p.amode);
+      load_strided<BN, NT>(rb, W, p.sWn, p.sWk, n0, (kt + 1) * BK, p.N, p.K, p.wmode);
+    }
+    const float* as = As + cur * BK * LDA + wm * TM * 32 + (lane & 31) + (lane >> 5) * LDA;
+    const float* bs = Bs + cur * BK * LDB + wn * TN * 32 + (lane & 31) + (lane >> 5) * LDB;
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = as[kk * 2 * LDA + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = bs[kk * 2 * LDB + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      store_lds<BM, NT>(ra, As + (cur ^ 1) * BK * LDA, CONV ? 2 : p.amode);
+      store_lds<BN, NT>(rb, Bs + (cur ^ 1) * BK * LDB, p.wmode);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias, activation, store, optional per-column statistics ------------------------
+  float* C = p.C + (long)bz * p.sCb;
+  const float* R = p.res ? p.res + (long)bz * p.sCb : nullptr;
+  const float* bias = p.bias ? p.bias + (long)bz * p.sBiasB : nullptr;
+  float csum[TN], csq[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
+
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * TN * 32 + j * 32 + (lane & 31);
+    const bool nok = n < p.N;
+    const float bn = (bias && p.bias_axis == 0 && nok) ? bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (m < p.M && nok) {
+          float v = acc[i][j][e] * p.alpha + bn;
+          if (bias && p.bias_axis == 1) v += bias[m];
+          if (R) v += R[(long)m * p.sCm + (long)n * p.sCn];
+          csum[j] += v;
+          csq[j] += v * v;
+          v = apply_act(v, p.act);
+          float* dst = C + (long)m * p.sCm + (long)n * p.sCn;
+          if (p.accumulate) v += *dst;
+          *dst = v;
+        }
+      }
+    }
+  }
+
+  if (p.stats) {
+    // rows of this block: combine the two half-waves, then the WM waves through LDS (deterministic)
+    __syncthreads();
+    float* red = smem;  // [WM][2][BN]
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float s = csum[j] + __shfl_xor(csum[j], 32);
+      float q = csq[j] + __shfl_xor(csq[j], 32);
+      if (lane < 32) {
+        const int c = wn * TN * 32 + j * 32 + lane;
+        red[(wm * 2 + 0) * BN + c] = s;
+        red[(wm * 2 + 1) * BN + c] = q;
+      }
+    }
+    __syncthreads();
+    for (int c = t; c < BN; c += NT) {
+      const int n = n0 + c;
+      if (n < p.N) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) { s += red[(w * 2 + 0) * BN + c]; q += red[(w * 2 + 1) * BN + c]; }
+        float* st = p.stats;
+        st[((long)tile_m * 2 + 0) * p.N + n] = s;
+        st[((long)tile_m * 2 + 1) * p.N + n] = q;
+      }
+    }
+  }
+}
+
+template <int WM, int WN, int TM, int TN>
+int launch_cfg(const GemmParams& p, bool conv, hipStream_t st) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
+  dim3 grid(tiles, 1, p.batch), block(WM * WN * 64);
+  if (conv) hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, true>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, false>), grid, block, 0, st, p);
+  MRN_LAUNCH_CHECK("gemm_f32");
+  return MRN_OK;
+}
+
+}  // namespace
+
+int mrn_gemm_tile_m(int M, int N) {
+  (void)M;
+  (void)N;
+  return 128;
+}
+
+int mrn_gemm_launch(const GemmParams& p, bool conv, hipStream_t st) {
+  if (p.M <= 0 || p.N <= 0 || p.batch <= 0) return MRN_OK;
+  // every configuration keeps BM = 128 so the statistics workspace is always ceil(M/128) row blocks
+  if (p.N <= 32) return launch_cfg<4, 1, 1, 1>(p, conv, st);
+  if (p.N <= 64) return launch_cfg<4, 1, 1, 2>(p, conv, st);
+  return launch_cfg<2, 2, 2, 2>(p, conv, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+static int pick_mode(const void* ptr, long sb, long sr, long sk, int nrows, int K) {
+  const bool al = ((uintptr_t)ptr % 16 == 0) && (sb % 4 == 0);
+  if (sk == 1 && al && sr % 4 == 0 && K % 4 == 0) return 2;
+  if (sr == 1 && al && sk % 4 == 0 && nrows % 4 == 0) return 3;
+  if (sr == 1 && sk != 1) return 1;
+  return 0;
+}
+
+MRN_EXPORT int mrn_gemm_f32(const float* A, const float* W, const float* bias, const float* residual, float* C,
+                            int M, int N, int K,
+                            int batch, int64_t sAb, int64_t sAm, int64_t sAk, int64_t sWb, int64_t sWn,
+                            int64_t sWk, int64_t sCb, int64_t sCm, int64_t sCn, int64_t sBiasB, int bias_axis,
+                            int act, int accumulate, float alpha, void* stream) {
+  MRN_CHECK_ARG(A && W && C, "mrn_gemm_f32: null operand");
+  MRN_CHECK_ARG(M >= 0 && N >= 0 && K > 0 && batch >= 0, "mrn_gemm_f32: bad shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
+  MRN_CHECK_ARG(act >= 0 && act <= 2 && (bias_axis == 0 || bias_axis == 1), "mrn_gemm_f32: bad act/bias_axis");
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.A = A; p.W = W; p.bias = bias; p.res = residual; p.C = C;
+  p.M = M; p.N = N; p.K = K; p.batch = batch;
+  p.sAb = sAb; p.sAm = sAm; p.sAk = sAk;
+  p.sWb = sWb; p.sWn = sWn; p.sWk = sWk;
+  p.sCb = sCb; p.sCm = sCm; p.sCn = sCn;
+  p.sBiasB = sBiasB; p.bias_axis = bias_axis;
+  p.amode = pick_mode(A, sAb, sAm, sAk, M, K);
+  p.wmode = pick_mode(W, sWb, sWn, sWk, N, K);
+  p.act = act; p.accumulate = accumulate; p.alpha = alpha;
+  return mrn_gemm_launch(p, false, (hipStream_t)stream);
+}
+
+MRN_EXPORT int64_t mrn_conv2d_stats_floats(int B, int Ho, int Wo, int Cout) {
+  return (int64_t)ceil_div((long)B * Ho * Wo, 128) * 2 * Cout;
+}
+
+MRN_EXPORT int mrn_conv2d_nhwc_f32(const float* x, const float* w_ohwi, const float* bias, float* y, float* stats,
+                                   int B, int H, int Wd, int Cin, int Cout, int kh, int kw, int sh, int sw,
+                                   int ph, int pw, int act, void* stream) {
+  MRN_CHECK_ARG(x && w_ohwi && y, "mrn_conv2d_nhwc_f32: null operand");
+  MRN_CHECK_ARG(Cin % 4 == 0, "mrn_conv2d_nhwc_f32: Cin=%d must be a multiple of 4", Cin);
+  MRN_CHECK_ARG(((uintptr_t)x % 16 == 0) && ((uintptr_t)w_ohwi % 16 == 0), "mrn_conv2d_nhwc_f32: operands must be 16-byte aligned");
+  const int Ho = (H + 2 * ph - kh) / sh + 1, Wo = (Wd + 2 * pw - kw) / sw + 1;
+  MRN_CHECK_ARG(Ho > 0 && Wo > 0 && B >= 0, "mrn_conv2d_nhwc_f32: empty output");
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.A = x; p.W = w_ohwi; p.bias = bias; p.C = y; p.stats = stats;
+  p.M = B * Ho * Wo; p.N = Cout; p.K = kh * kw * Cin; p.batch = 1;
+  p.sWn = p.K; p.sWk = 1; p.wmode = 2;
+  p.sCm = Cout; p.sCn = 1;
+  p.H = H; p.Wd = Wd; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo;
+  p.kh = kh; p.kw = kw; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw;
+  p.act = act; p.alpha = 1.f;
+  return mrn_gemm_launch(p, true, (hipStream_t)stream);
+}

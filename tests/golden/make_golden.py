@@ -1,0 +1,254 @@
+"""Generate golden vectors by running the REFERENCE implementation (simplify23/MRN at /root/reference) on CPU.
+
+Run in the build container only (the reference never travels to the GPU box):
+    python tests/golden/make_golden.py
+Writes tests/golden/*.npz.  Inputs and weights are NOT stored: they come from the deterministic generator
+mrn_amd/tools/weights.py (value = f(name, shape, seed)), applied here to the reference modules' state_dict and,
+in the tests, to the oracle / HIP-backed modules.  Only outputs of the reference are stored (large tensors as a
+fixed strided subsample plus moments).
+
+Harness shims: `timm` is absent -> stub `timm.models.layers.trunc_normal_`.
+The optimiser step of loop B is driven with the same torch calls the reference learner makes
+(il_modules/mrn.py:338-371: CrossEntropyLoss / CTCLoss, clip_grad_norm_, Adam, OneCycleLR(total=2*num_iter)).
+"""
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+sys.path.insert(0, REF)
+
+timm = types.ModuleType("timm")
+timm.models = types.ModuleType("timm.models")
+timm.models.layers = types.ModuleType("timm.models.layers")
+timm.models.layers.trunc_normal_ = torch.nn.init.trunc_normal_
+sys.modules.update({"timm": timm, "timm.models": timm.models, "timm.models.layers": timm.models.layers})
+
+from modules.model import MRNNet  # noqa: E402  (reference)
+from tools.utils import AttnLabelConverter, CTCLabelConverter  # noqa: E402  (reference)
+
+from mrn_amd.tools import weights as W  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+
+def sub(t, n=4096):
+    """fixed strided subsample + moments of a tensor"""
+    a = t.detach().cpu().double().numpy().reshape(-1)
+    step = max(1, a.size // n)
+    return {"sub": a[::step][:n].astype(np.float32), "mean": np.float64(a.mean()), "absmean": np.float64(np.abs(a).mean()),
+            "shape": np.array(t.shape, dtype=np.int64)}
+
+
+def put(d, name, t, full=False):
+    if full:
+        d[name] = t.detach().cpu().numpy().copy()
+    else:
+        for k, v in sub(t).items():
+            d[f"{name}/{k}"] = v
+
+
+def make_opt(kind):
+    o = types.SimpleNamespace(num_fiducial=20, imgH=32, imgW=256, input_channel=4, output_channel=512, hidden_size=256,
+                              batch_max_length=25)
+    if kind == "crnn":
+        o.Transformation, o.FeatureExtraction, o.SequenceModeling, o.Prediction = "None", "VGG", "BiLSTM", "CTC"
+    else:
+        o.Transformation, o.FeatureExtraction, o.SequenceModeling, o.Prediction = "TPS", "ResNet", "BiLSTM", "Attn"
+    return o
+
+
+def words_for(B, nchar, seed):
+    """synthetic labels over a character set 'chr(0x4e00+i)'; returns (words, character string)"""
+    chars = "".join(chr(0x4E00 + i) for i in range(nchar))
+    lens = W.randint("label_len", (B,), 1, 26, seed)
+    out = []
+    for b in range(B):
+        ids = W.randint(f"label_{b}", (int(lens[b]),), 0, nchar, seed)
+        out.append("".join(chars[i] for i in ids))
+    return out, chars
+
+
+def build(kind, classes, seed):
+    opt = make_opt(kind)
+    net = MRNNet(opt)
+    for c in classes:
+        net.update_fc(opt.hidden_size, c)
+        net.build_prediction(opt, c)
+    W.fill_state_dict(net.state_dict(), seed)
+    return opt, net
+
+
+def run(kind, classes, B, seed):
+    d = {}
+    opt, net = build(kind, classes, seed)
+    I = len(classes)
+    sd0 = net.state_dict()
+    d["sd_keys"] = np.array(sorted(sd0.keys()))                      # pins the reference's state_dict layout
+    d["sd_shapes"] = np.array([",".join(map(str, sd0[k].shape)) for k in sorted(sd0.keys())])
+    image = torch.from_numpy(W.uniform("input:image", (B, 4, 32, 256), -1, 1, seed))
+    nspecial = 4 if kind == "crnn" else 5
+    words, chars = words_for(B, classes[-1] - nspecial, seed)
+    conv = CTCLabelConverter(chars) if kind == "crnn" else AttnLabelConverter(chars)
+    labels_index, labels_length = conv.encode(words, batch_max_length=25)
+    d["labels_index"] = labels_index.numpy()
+    d["labels_length"] = labels_length.numpy()
+    text = None if kind == "crnn" else labels_index[:, :-1]
+    domain = torch.from_numpy(W.randint("domain", (B,), 0, 2, seed))
+
+    # ---- per-stage outputs of expert 0, train-mode BN (batch statistics) --------------------------------
+    net.train()
+    m0 = net.model[0]
+    with torch.no_grad():
+        x = image
+        if kind == "trba":
+            tps = m0.model.Transformation
+            cp = tps.LocalizationNetwork(x)
+            put(d, "e0/tps_cprime", cp, full=True)
+            put(d, "tps/inv_delta_C", tps.GridGenerator.inv_delta_C, full=True)
+            put(d, "tps/P_hat", tps.GridGenerator.P_hat)
+            x = tps(image)          # second pass also moves the BN running stats a second time; restore below
+            put(d, "e0/tps_out", x)
+        fm = m0.model.FeatureExtraction(x)
+        put(d, "e0/featmap", fm)
+    # reset weights/buffers (running stats were touched) and run the real forward paths
+    W.fill_state_dict(net.state_dict(), seed)
+    with torch.no_grad():
+        o = m0(image, text, True)
+        put(d, "e0/feature", o["feature"])
+        put(d, "e0/predict", o["predict"])
+        put(d, "e0/bn_running_mean_after", _first_bn(net, "running_mean"), full=True)
+        put(d, "e0/bn_running_var_after", _first_bn(net, "running_var"), full=True)
+    W.fill_state_dict(net.state_dict(), seed)
+
+    # ---- eval-mode expert forward (running statistics; Attn decodes greedily) ---------------------------
+    net.eval()
+    with torch.no_grad():
+        sos = None if kind == "crnn" else torch.LongTensor(B).fill_(2)   # test.py:186-189
+        o = m0(image, sos, False)
+        put(d, "e0_eval/feature", o["feature"])
+        put(d, "e0_eval/predict", o["predict"])
+        d["e0_eval/argmax"] = o["predict"].max(2)[1].numpy()
+        oe = net(image, True, sos, False)      # cross_forward_expert
+        d["eval/index"] = oe["index"].numpy()
+        put(d, "eval/logits", oe["logits"])
+        d["eval/argmax"] = oe["logits"].max(2)[1].numpy()
+        if kind == "crnn":
+            am = oe["logits"].max(2)[1]
+            d["eval/ctc_strings"] = np.array(conv.decode(am.numpy(), [am.shape[1]] * B))
+
+    # ---- loop B (il_modules/mrn.py:323-371): experts in train mode, router trained ---------------------
+    net.train()
+    for i in range(I):
+        for p in net.model[i].parameters():
+            p.requires_grad = False
+    params = [p for p in net.parameters() if p.requires_grad]
+    names = [n for n, p in net.named_parameters() if p.requires_grad]
+    d["router_param_names"] = np.array(names)
+    opt_ = torch.optim.Adam(params, lr=0.0005)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt_, max_lr=0.0005, cycle_momentum=False, div_factor=20,
+                                                final_div_factor=1000, total_steps=20 * 2)
+    taski_crit = torch.nn.CrossEntropyLoss(reduction="mean")
+    if kind == "crnn":
+        crit = torch.nn.CTCLoss(reduction="mean", zero_infinity=True)
+    else:
+        crit = torch.nn.CrossEntropyLoss(reduction="mean", ignore_index=conv.dict["[PAD]"])
+    before = {n: p.detach().clone() for n, p in zip(names, params)}
+    for it in range(2):
+        if kind == "crnn":
+            out = net(image, True)
+            preds = out["logits"]
+            taski = taski_crit(out["index"], domain)
+            preds_size = torch.IntTensor([preds.size(1)] * B)
+            clf = crit(preds.log_softmax(2).permute(1, 0, 2), labels_index, preds_size, labels_length)
+        else:
+            out = net(image, cross=True, text=labels_index[:, :-1], is_train=True)
+            preds = out["logits"]
+            taski = taski_crit(out["index"], domain)
+            target = labels_index[:, 1:]
+            clf = crit(preds.view(-1, preds.shape[-1]), target.contiguous().view(-1))
+        loss = 15 * clf + taski
+        net.zero_grad()
+        loss.backward()
+        total_norm = torch.nn.utils.clip_grad_norm_(net.parameters(), 5)
+        if it == 0:
+            put(d, "stepB/weights", out["index"], full=True)
+            put(d, "stepB/logits", preds)
+            d["stepB/loss_clf"] = np.float64(clf.item())
+            d["stepB/loss_taski"] = np.float64(taski.item())
+            d["stepB/grad_norm"] = np.float64(total_norm.item())
+            for n, p in zip(names, params):     # grads AFTER clipping, as the optimiser sees them
+                put(d, f"stepB/grad/{n}", p.grad)
+        opt_.step()
+        sched.step()
+        d[f"stepB/lr_after_{it}"] = np.float64(opt_.param_groups[0]["lr"])
+    for n, p in zip(names, params):
+        put(d, f"stepB/delta2/{n}", p.detach() - before[n])
+    d["stepB/loss_clf_1"] = np.float64(clf.item())
+    d["stepB/loss_taski_1"] = np.float64(taski.item())
+
+    # ---- loop A forward + loss on the newest expert (il_modules/mrn.py:247-258), no update ---------------
+    W.fill_state_dict(net.state_dict(), seed)
+    net.train()
+    with torch.no_grad():
+        if kind == "crnn":
+            preds = net(image, False)["logits"]
+            lossA = crit(preds.log_softmax(2).permute(1, 0, 2), labels_index, torch.IntTensor([preds.size(1)] * B), labels_length)
+        else:
+            preds = net(image, False, labels_index[:, :-1])["logits"]
+            lossA = crit(preds.view(-1, preds.shape[-1]), labels_index[:, 1:].contiguous().view(-1))
+        put(d, "stepA/logits", preds)
+        d["stepA/loss"] = np.float64(lossA.item())
+    return d
+
+
+def _first_bn(net, leaf):
+    for k, v in net.state_dict().items():
+        if k.startswith("model.0.") and k.endswith(leaf):
+            return v
+    raise KeyError(leaf)
+
+
+def converters():
+    d = {}
+    chars = "abcdefghij klmno"   # includes a space duplicate, as real dictionaries may
+    words = ["hello", "", "a b", "zzz", "abcdefghijklmnoabcdefghij", "jjjj"]
+    c = CTCLabelConverter(chars)
+    idx, ln = c.encode(words, 25)
+    d["ctc/encode_idx"], d["ctc/encode_len"] = idx.numpy(), ln.numpy()
+    seq = np.array([[0, 5, 5, 0, 5, 6, 6, 1, 0, 2, 3, 3, 3, 0, 0, 7], [4, 4, 4, 4, 0, 0, 0, 0, 9, 9, 8, 8, 0, 1, 1, 2]])
+    d["ctc/decode_in"] = seq
+    d["ctc/decode_out"] = np.array(c.decode(seq, [16, 16]))
+    a = AttnLabelConverter(chars)
+    idx, ln = a.encode(words, 25)
+    d["attn/encode_idx"], d["attn/encode_len"] = idx.numpy(), ln.numpy()
+    d["attn/decode_out"] = np.array(a.decode(idx.numpy()[:, 1:], ln.numpy()))
+    d["words"] = np.array(words)
+    d["chars"] = np.array(chars)
+    return d
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    jobs = {
+        "crnn_mrn3": lambda: run("crnn", (40, 70, 97), 2, 1),
+        "trba_mrn3": lambda: run("trba", (41, 71, 98), 2, 2),
+        "converters": converters,
+    }
+    for name, fn in jobs.items():
+        if args.only and args.only != name:
+            continue
+        d = fn()
+        path = os.path.join(OUT, name + ".npz")
+        np.savez_compressed(path, **d)
+        print(name, "->", path, f"{os.path.getsize(path) / 1024:.0f} KiB")

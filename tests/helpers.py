@@ -1,0 +1,66 @@
+"""Shared helpers for the parity tests (CPU and GPU)."""
+import os
+
+import numpy as np
+import torch
+
+from mrn_amd.tools import weights as W
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+def golden_state_dict(g, seed):
+    """Rebuild the reference model's state_dict (key layout from the fixture, values from the generator)."""
+    sd = {}
+    for k, shp in zip(g["sd_keys"], g["sd_shapes"]):
+        k = str(k)
+        shape = tuple(int(v) for v in str(shp).split(",")) if str(shp) else ()
+        sd[k] = torch.from_numpy(np.array(W.det_param(W.canonical_key(k), shape, seed)))
+    return sd
+
+
+def sub(t, n=4096):
+    a = t.detach().cpu().double().numpy().reshape(-1)
+    step = max(1, a.size // n)
+    return a[::step][:n].astype(np.float32), a.mean(), np.abs(a).mean()
+
+
+def assert_sub_close(g, name, t, atol=1e-4, rtol=1e-4):
+    """Compare a tensor with a stored strided subsample + moments."""
+    assert tuple(g[name + "/shape"]) == tuple(t.shape), (name, tuple(g[name + "/shape"]), tuple(t.shape))
+    s, mean, absmean = sub(t)
+    ref = g[name + "/sub"]
+    err = np.abs(s - ref).max()
+    tol = atol + rtol * np.abs(ref).max()
+    assert err <= tol, f"{name}: max abs err {err:.3e} > tol {tol:.3e}"
+    assert abs(mean - float(g[name + "/mean"])) <= atol + rtol * abs(float(g[name + "/absmean"])), name
+    return err
+
+
+def assert_close(name, a, b, atol=1e-4, rtol=1e-4):
+    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
+    b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    err = np.abs(a - b).max() if a.size else 0.0
+    tol = atol + rtol * (np.abs(b).max() if b.size else 0.0)
+    assert err <= tol, f"{name}: max abs err {err:.3e} > tol {tol:.3e}"
+    return err
+
+
+def det_inputs(kind, classes, B, seed):
+    """Same synthetic batch the golden generator used (tests/golden/make_golden.py: run())."""
+    image = torch.from_numpy(W.uniform("input:image", (B, 4, 32, 256), -1, 1, seed))
+    nspecial = 4 if kind == "crnn" else 5
+    nchar = classes[-1] - nspecial
+    chars = "".join(chr(0x4E00 + i) for i in range(nchar))
+    lens = W.randint("label_len", (B,), 1, 26, seed)
+    words = []
+    for b in range(B):
+        ids = W.randint(f"label_{b}", (int(lens[b]),), 0, nchar, seed)
+        words.append("".join(chars[i] for i in ids))
+    domain = torch.from_numpy(W.randint("domain", (B,), 0, 2, seed))
+    return image, words, chars, domain

@@ -1,0 +1,146 @@
+"""Pin the CPU oracle (oracle/mrn_oracle.py) against golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mrn_oracle as O
+from tests.helpers import assert_close, assert_sub_close, det_inputs, golden_state_dict, load_golden
+
+CASES = {"crnn_mrn3": ("crnn", (40, 70, 97), 2, 1), "trba_mrn3": ("trba", (41, 71, 98), 2, 2)}
+
+
+def cfg_for(kind):
+    if kind == "crnn":
+        return O.Cfg("None", "VGG", "BiLSTM", "CTC")
+    return O.Cfg("TPS", "ResNet", "BiLSTM", "Attn")
+
+
+def test_converters_match_reference():
+    g = load_golden("converters")
+    words = [str(w) for w in g["words"]]
+    chars = str(g["chars"])
+    c = O.CTCConverter(chars)
+    idx, ln = c.encode(words, 25)
+    assert np.array_equal(idx.numpy(), g["ctc/encode_idx"]) and np.array_equal(ln.numpy(), g["ctc/encode_len"])
+    assert c.decode(g["ctc/decode_in"], [16, 16]) == [str(s) for s in g["ctc/decode_out"]]
+    a = O.AttnConverter(chars)
+    idx, ln = a.encode(words, 25)
+    assert np.array_equal(idx.numpy(), g["attn/encode_idx"]) and np.array_equal(ln.numpy(), g["attn/encode_len"])
+    assert a.decode(idx.numpy()[:, 1:], ln.numpy()) == [str(s) for s in g["attn/decode_out"]]
+
+
+def test_tps_constants_match_reference():
+    g = load_golden("trba_mrn3")
+    inv, ph = O.tps_constants(20, (32, 256))
+    assert_close("inv_delta_C", inv, g["tps/inv_delta_C"], atol=1e-6, rtol=1e-6)
+    assert_sub_close(g, "tps/P_hat", ph, atol=1e-6, rtol=1e-6)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_expert_forward_train_and_eval(name):
+    kind, classes, B, seed = CASES[name]
+    g = load_golden(name)
+    cfg = cfg_for(kind)
+    image, words, chars, _ = det_inputs(kind, classes, B, seed)
+    conv = O.CTCConverter(chars) if kind == "crnn" else O.AttnConverter(chars)
+    labels_index, labels_length = conv.encode(words, 25)
+    assert np.array_equal(labels_index.numpy(), g["labels_index"])
+    assert np.array_equal(labels_length.numpy(), g["labels_length"])
+    text = None if kind == "crnn" else labels_index[:, :-1]
+
+    torch.set_grad_enabled(False)
+    try:
+        sd = golden_state_dict(g, seed)
+        if kind == "trba":
+            out, cp, _ = O.tps_forward(sd, "model.0.model.Transformation.", image, True, return_aux=True)
+            assert_close("cprime", cp, g["e0/tps_cprime"], atol=1e-5)
+            assert_sub_close(g, "e0/tps_out", out, atol=1e-5)
+            fm = O.resnet_forward(sd, "model.0.model.FeatureExtraction.", out, True)
+        else:
+            fm = O.vgg_forward(sd, "model.0.model.FeatureExtraction.", image, True)
+        assert_sub_close(g, "e0/featmap", fm, atol=2e-5)
+
+        sd = golden_state_dict(g, seed)
+        o = O.model_forward(sd, "model.0.", cfg, image, text, True, training=True)
+        assert_sub_close(g, "e0/feature", o["feature"], atol=2e-5)
+        assert_sub_close(g, "e0/predict", o["predict"], atol=2e-5)
+        first_rm = sorted(k for k in sd if k.startswith("model.0.") and k.endswith("running_mean"))
+        # the fixture stores the first BN (state_dict order) -- locate it by matching the stored shape
+        rm = [sd[k] for k in first_rm if tuple(sd[k].shape) == g["e0/bn_running_mean_after"].shape]
+        assert any(np.abs(r.numpy() - g["e0/bn_running_mean_after"]).max() < 1e-5 for r in rm)
+
+        sd = golden_state_dict(g, seed)
+        sos = None if kind == "crnn" else torch.LongTensor(B).fill_(2)
+        o = O.model_forward(sd, "model.0.", cfg, image, sos, False, training=False)
+        assert_sub_close(g, "e0_eval/feature", o["feature"], atol=2e-5)
+        assert_sub_close(g, "e0_eval/predict", o["predict"], atol=2e-5)
+        assert np.array_equal(o["predict"].max(2)[1].numpy(), g["e0_eval/argmax"])
+        oe = O.mrn_forward(sd, cfg, len(classes), image, True, sos, False, training=False)
+        assert np.array_equal(oe["index"].numpy(), g["eval/index"])
+        assert_sub_close(g, "eval/logits", oe["logits"], atol=2e-5)
+        assert np.array_equal(oe["logits"].max(2)[1].numpy(), g["eval/argmax"])
+        if kind == "crnn":
+            am = oe["logits"].max(2)[1].numpy()
+            assert conv.decode(am, [am.shape[1]] * B) == [str(s) for s in g["eval/ctc_strings"]]
+    finally:
+        torch.set_grad_enabled(True)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_loop_b_two_steps(name):
+    """loss values, clipped grads and the 2-step parameter delta of the router (il_modules/mrn.py:323-371)."""
+    kind, classes, B, seed = CASES[name]
+    g = load_golden(name)
+    cfg = cfg_for(kind)
+    image, words, chars, domain = det_inputs(kind, classes, B, seed)
+    conv = O.CTCConverter(chars) if kind == "crnn" else O.AttnConverter(chars)
+    labels_index, labels_length = conv.encode(words, 25)
+    text = None if kind == "crnn" else labels_index[:, :-1]
+    sd = golden_state_dict(g, seed)
+    names = [str(n) for n in g["router_param_names"]]
+    params = [sd[n].requires_grad_(True) for n in names]
+    before = [p.detach().clone() for p in params]
+    state = [{"m": torch.zeros_like(p), "v": torch.zeros_like(p)} for p in params]
+    for it in range(2):
+        out = O.mrn_forward(sd, cfg, len(classes), image, True, text, True, training=True)
+        loss, clf, taski = O.mrn_step_loss(out, labels_index, labels_length, domain, cfg.Prediction)
+        grads = torch.autograd.grad(loss, params)
+        lr = O.one_cycle_lr(it, 40, 0.0005)
+        with torch.no_grad():
+            if it == 0:
+                assert_close("weights", out["index"], g["stepB/weights"], atol=1e-5)
+                assert_sub_close(g, "stepB/logits", out["logits"], atol=2e-5)
+                assert abs(clf.item() - float(g["stepB/loss_clf"])) < 1e-5 * max(1, abs(float(g["stepB/loss_clf"])))
+                assert abs(taski.item() - float(g["stepB/loss_taski"])) < 1e-5
+            total = O.clip_and_adam(params, grads, state, lr, it + 1)
+            if it == 0:
+                assert abs(total.item() - float(g["stepB/grad_norm"])) <= 1e-4 * float(g["stepB/grad_norm"])
+                coef = min(1.0, 5.0 / (total.item() + 1e-6))
+                for n, gr in zip(names, grads):
+                    assert_sub_close(g, f"stepB/grad/{n}", gr * coef, atol=1e-6, rtol=1e-3)
+            lr_after = O.one_cycle_lr(it + 1, 40, 0.0005)
+            assert abs(lr_after - float(g[f"stepB/lr_after_{it}"])) < 1e-12
+    assert abs(clf.item() - float(g["stepB/loss_clf_1"])) < 1e-4 * max(1, abs(float(g["stepB/loss_clf_1"])))
+    with torch.no_grad():
+        for n, p, b in zip(names, params, before):
+            if float(g[f"stepB/grad/{n}/absmean"]) < 1e-6:
+                continue  # route.bias: softmax is shift invariant, its gradient is round-off noise that Adam renormalises
+            assert_sub_close(g, f"stepB/delta2/{n}", p - b, atol=2e-6, rtol=2e-2)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_loop_a_forward_loss(name):
+    kind, classes, B, seed = CASES[name]
+    g = load_golden(name)
+    cfg = cfg_for(kind)
+    image, words, chars, _ = det_inputs(kind, classes, B, seed)
+    conv = O.CTCConverter(chars) if kind == "crnn" else O.AttnConverter(chars)
+    labels_index, labels_length = conv.encode(words, 25)
+    with torch.no_grad():
+        sd = golden_state_dict(g, seed)
+        text = None if kind == "crnn" else labels_index[:, :-1]
+        out = O.mrn_forward(sd, cfg, len(classes), image, False, text, True, training=True)
+        assert_sub_close(g, "stepA/logits", out["logits"], atol=2e-5)
+        loss = O.ctc_loss(out["logits"], labels_index, labels_length) if kind == "crnn" else O.attn_ce_loss(out["logits"], labels_index)
+        assert abs(loss.item() - float(g["stepA/loss"])) < 1e-5 * max(1, abs(float(g["stepA/loss"])))
