@@ -85,25 +85,100 @@ int mrn_tps_grid_sample_f32(const float* img_nhwc, const float* cprime, const fl
 
 /* ---- recurrent ------------------------------------------------------------------------------------------ */
 
-/* One (bi)directional LSTM layer given xproj = x W_ih^T + b_ih + b_hh laid out [B][T][ndir*4*hidden]
- * (gate order i,f,g,o), w_hh [ndir][4*hidden][hidden]; out [B][T][ndir*hidden].
+/* One (bi)directional LSTM layer given xproj = x W_ih^T + b_ih laid out [B][T][ndir*4*hidden]
+ * (gate order i,f,g,o), w_hh [ndir][4*hidden][hidden], b_hh [ndir*4*hidden] or NULL; out [B][T][ndir*hidden].
  * modules/sequence_modeling.py:7-21 (nn.LSTM(bidirectional=True, batch_first=True)). */
-int mrn_lstm_layer_fwd_f32(const float* xproj, const float* w_hh, float* out, int B, int T, int hidden,
-                           int ndir, void* stream);
+int mrn_lstm_layer_fwd_f32(const float* xproj, const float* w_hh, const float* b_hh, float* out, int B, int T,
+                           int hidden, int ndir, void* stream);
 
 /* Attention decoder, S steps in one launch (modules/prediction.py:58-68 teacher forced; :78-86 greedy when
  * called with S = 1 and carried h_state/c_state).  Hb [B][T][D], Hproj = i2h(Hb) [B][T][hidden],
- * eproj = W_ih[:, D:] emb + b_ih + b_hh (strided [B][S][4*hidden]), w_ih [4*hidden][ld_wih] (context part =
+ * eproj = W_ih[:, D:] emb + b_ih (strided [B][S][4*hidden]), b_hh [4*hidden] or NULL, w_ih [4*hidden][ld_wih] (context part =
  * first D columns), hid out (strided [B][S][hidden]); alpha_out optional [B][S][T]. */
 int mrn_attn_decoder_fwd_f32(const float* Hb, const float* Hproj, const float* eproj, int64_t eproj_stride_b,
                              int64_t eproj_stride_s, const float* w_h2h, const float* b_h2h,
                              const float* w_score, const float* w_ih, int64_t ld_wih, const float* w_hh,
-                             float* hid, int64_t hid_stride_b, int64_t hid_stride_s, float* h_state,
+                             const float* b_hh, float* hid, int64_t hid_stride_b, int64_t hid_stride_s, float* h_state,
                              float* c_state, float* alpha_out, int B, int T, int D, int S, int hidden,
                              void* stream);
 /* out[b][s][:] = table[cut_unknown(idx[b][s])][:]  (modules/prediction.py:35-36,61) */
 int mrn_embed_gather_f32(const int64_t* idx, int64_t idx_stride, const float* table, float* out, int B, int S,
                          int E, int num_class, void* stream);
+
+/* ---- row-wise operators of the DM-Router (modules/dm_router.py) ------------------------------------------- */
+
+/* LayerNorm over the contiguous dim of strided rows (nn.LayerNorm(channel), dm_router.py:8,40; eps 1e-5);
+ * mean / rstd [rows] are saved for the backward. C % 4 == 0, C <= 1024. */
+int mrn_layernorm_fwd_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy,
+                          float* mean, float* rstd, int64_t rows, int C, float eps, void* stream);
+int64_t mrn_layernorm_bwd_blocks(int64_t rows);
+/* dx (+)= LayerNorm backward; partials [blocks][2][C] receive per-block sums of (dgamma, dbeta) */
+int mrn_layernorm_bwd_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+                          const float* mean, const float* rstd, float* dx, int64_t lddx, int accumulate,
+                          float* partials, int64_t rows, int C, void* stream);
+/* LayerNorm over the P axis of x[B][P][Wd] for every (b, w) column -- ChannelDomainGating's LayerNorm(patch) on
+ * the 'b (d c) p' rearrangement (dm_router.py:23,29,63) without the transpose; mean / rstd are [B][Wd]. */
+int mrn_colnorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                        int B, int P, int Wd, float eps, void* stream);
+/* partials [B*ceil(Wd/256)][2][P] */
+int mrn_colnorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                        float* dx, int accumulate, float* partials, int B, int P, int Wd, void* stream);
+/* elementwise on strided rows: op 0 y=gelu(a) (dm_router.py:42), 1 y=b*gelu'(a), 2 y=a*b (:17,:33), 3 y=a+b */
+int mrn_ew_rows_f32(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy, int64_t rows,
+                    int C, int op, void* stream);
+/* out[c] (+)= sum_r in[r][c] (bias / affine gradients, split-K combine); workspace: chunks*C floats */
+int64_t mrn_colsum_chunks(int64_t rows, int C);
+int mrn_colsum_f32(const float* in, int64_t ld, float* out, float* workspace, int64_t rows, int C, int accumulate,
+                   void* stream);
+/* out[i][j] = in[row_idx[i]][col_idx[j]] (NULL index = identity), columns [C, ld_out) zero-filled */
+int mrn_gather2d_f32(const float* in, int64_t ld_in, const int* row_idx, const int* col_idx, float* out,
+                     int64_t ld_out, int R, int C, void* stream);
+/* first index of the row maximum (preds.max(2), test.py:211; greedy decode prediction.py:84) */
+int mrn_argmax_f32(const float* x, int64_t ld, int64_t* out, int64_t rows, int C, void* stream);
+
+/* ---- MRN fan-in and gate tail (modules/model.py:361-423) --------------------------------------------------- */
+
+/* out[b][t][c] = sum_i w[b][i] * (c < C_i ? L_i[b][t][c] : 1)  -- pad-with-ones + stack + weight + sum in one pass.
+ * logits / lds / classes are HOST arrays of length I (device pointers, row strides (multiples of 4), class counts). */
+int mrn_fanin_fwd_f32(const void* const* logits, const int64_t* lds, const int* classes, int I, const float* w,
+                      float* out, int64_t ldo, int B, int T, int C, void* stream);
+/* dw[b][i] = sum_{t,c} dout[b][t][c] * Lpad_i[b][t][c]; workspace B*T*I floats */
+int mrn_fanin_bwd_f32(const void* const* logits, const int64_t* lds, const int* classes, int I, const float* dout,
+                      int64_t ldd, float* dw, float* workspace, int B, int T, int C, void* stream);
+/* eval hard routing (model.py:377,393): out[b] = Lpad_{index[b]}[b] */
+int mrn_select_expert_f32(const void* const* logits, const int64_t* lds, const int* classes, int I,
+                          const int64_t* index, float* out, int64_t ldo, int B, int T, int C, void* stream);
+/* s = route(r) over the patch axis of r[B][P][I], w = softmax(beta*s) (model.py:405-406); argmax for eval (:377) */
+int mrn_gate_tail_fwd_f32(const float* r, const float* w_route, const float* b_route, float beta, float* s_out,
+                          float* w_out, int64_t* argmax_out, int B, int P, int I, void* stream);
+int mrn_gate_tail_bwd_f32(const float* w, const float* dw, const float* r, const float* w_route, float beta,
+                          float* ds, float* dr, float* d_w_route, float* d_b_route, int B, int P, int I, void* stream);
+
+/* ---- losses -------------------------------------------------------------------------------------------------- */
+
+/* CrossEntropyLoss(mean, ignore_index) over strided rows (il_modules/base.py:134, mrn.py:150-152,254-258,342) */
+int mrn_ce_loss_fwd_f32(const float* logits, int64_t ld, const int64_t* target, int64_t ignore_index, int64_t rows,
+                        int C, float* lse, float* loss_rows, float* loss, float* inv_count, void* stream);
+int mrn_ce_loss_bwd_f32(const float* logits, int64_t ld, const int64_t* target, int64_t ignore_index,
+                        const float* lse, const float* upstream, const float* inv_count, float* dlogits, int64_t ldd,
+                        int64_t rows, int C, void* stream);
+/* log_softmax + CTCLoss(blank, mean, zero_infinity=True), all input lengths = T (base.py:131, mrn.py:250-252) */
+int64_t mrn_ctc_occ_floats(int B, int T);
+int mrn_ctc_loss_fwd_f32(const float* logits, int64_t ld, const int64_t* targets, int64_t tstride,
+                         const int* target_len, int max_target_len, float* lse, float* nll, float* occ, float* loss,
+                         int B, int T, int C, int blank, void* stream);
+int mrn_ctc_loss_bwd_f32(const float* logits, int64_t ld, const float* lse, const float* occ, const int64_t* targets,
+                         int64_t tstride, const int* target_len, const float* nll, const float* upstream,
+                         float* dlogits, int64_t ldd, int B, int T, int C, int blank, void* stream);
+
+/* ---- optimiser (il_modules/base.py:85,255-262) ------------------------------------------------------------------ */
+
+int64_t mrn_grad_norm_workspace_floats(int64_t n);
+/* norm_coef[0] = ||g||_2, norm_coef[1] = min(1, max_norm/(norm+1e-6))  (clip_grad_norm_) */
+int mrn_grad_norm_clip_f32(const float* g, int64_t n, float max_norm, float* workspace, float* norm_coef, void* stream);
+/* g *= coef (in place), then torch.optim.Adam's update; step_size = lr/(1-beta1^t), bc2_sqrt = sqrt(1-beta2^t) */
+int mrn_adam_step_f32(float* p, float* g, float* m, float* v, int64_t n, const float* norm_coef, float step_size,
+                      float beta1, float beta2, float bc2_sqrt, float eps, void* stream);
 
 #ifdef __cplusplus
 }

@@ -23,6 +23,7 @@ _CTYPES = {
     "const int*": ctypes.c_void_p,
     "int*": ctypes.c_void_p,
     "const void*": ctypes.c_void_p,
+    "const void* const*": ctypes.c_void_p,
     "const char*": ctypes.c_char_p,
 }
 

@@ -47,7 +47,8 @@ __device__ __forceinline__ void mma_rows(f32x4 (&acc)[NG][4], const float* __res
 // grid = (ceil(B/16), ndir); out[b][t][dir*H + j].
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void lstm_layer_kernel(const float* __restrict__ xproj, const float* __restrict__ w_hh,
-                                                         float* __restrict__ out, int B, int T, int ndir) {
+                                                         const float* __restrict__ b_hh, float* __restrict__ out,
+                                                         int B, int T, int ndir) {
   __shared__ __attribute__((aligned(16))) float h_lds[2][BT * HLD];
   const int dir = blockIdx.y;
   const int b0 = blockIdx.x * BT;
@@ -56,11 +57,16 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(const float* __restrict
   const int col = lane & 15, rbase = (lane >> 4) * 4;
 
   for (int i = t_; i < BT * HLD; i += 256) h_lds[0][i] = 0.f;
-  float c[4][4];
+  float c[4][4], bh[4][4];   // cell state; recurrent bias of this lane's units, per gate
 #pragma unroll
   for (int s = 0; s < 4; ++s)
 #pragma unroll
     for (int r = 0; r < 4; ++r) c[s][r] = 0.f;
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      bh[g][s] = b_hh ? b_hh[dir * 4 * HID + g * HID + wave * 64 + s * 16 + col] : 0.f;
   __syncthreads();
 
   for (int step = 0; step < T; ++step) {
@@ -83,10 +89,10 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(const float* __restrict
         float hv = 0.f;
         if (b < B) {
           const float* xp = xproj + ((long)b * T + t) * (ndir * 4 * HID) + dir * 4 * HID + j;
-          const float gi = acc[0][s][r] + xp[0];
-          const float gf = acc[1][s][r] + xp[HID];
-          const float gg = acc[2][s][r] + xp[2 * HID];
-          const float go = acc[3][s][r] + xp[3 * HID];
+          const float gi = acc[0][s][r] + xp[0] + bh[0][s];
+          const float gf = acc[1][s][r] + xp[HID] + bh[1][s];
+          const float gg = acc[2][s][r] + xp[2 * HID] + bh[2][s];
+          const float go = acc[3][s][r] + xp[3 * HID] + bh[3][s];
           const float ig = sigmoidf_acc(gi), fg = sigmoidf_acc(gf), og = sigmoidf_acc(go);
           const float cg = tanhf(gg);
           const float cn = fg * c[s][r] + ig * cg;
@@ -117,6 +123,7 @@ struct AttnDecParams {
   const float* w_h2h; const float* b_h2h; const float* w_score;
   const float* w_ih; long ld_wih;   // LSTMCell weight_ih [4H][D+E], context part = first D columns
   const float* w_hh;                // [4H][HID]
+  const float* b_hh;                // optional [4H] (eproj already carries b_ih)
   float* hid;
   float* h_state; float* c_state;   // optional [B][HID] carried state (nullptr: start from zero, do not store)
   float* alpha_out;                 // optional [B][S][T]
@@ -150,6 +157,11 @@ __global__ __launch_bounds__(256) void attn_decoder_kernel(const AttnDecParams p
     h_lds[i] = (p.h_state && b < p.B && j < HID) ? p.h_state[(long)b * HID + j] : 0.f;
   }
   for (int i = t_; i < HID; i += 256) sw_lds[i] = p.w_score[i];
+  float bh[4][4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) bh[g][s] = p.b_hh ? p.b_hh[g * HID + wave * 64 + s * 16 + col] : 0.f;
   float c[4][4];
 #pragma unroll
   for (int s = 0; s < 4; ++s)
@@ -251,10 +263,10 @@ __global__ __launch_bounds__(256) void attn_decoder_kernel(const AttnDecParams p
           float hv = 0.f;
           if (b < p.B) {
             const float* ep = p.eproj + (long)b * p.eproj_stride_b + (long)step * p.eproj_stride_s + j;
-            const float gi = acc[0][s][r] + ep[0];
-            const float gf = acc[1][s][r] + ep[HID];
-            const float gg = acc[2][s][r] + ep[2 * HID];
-            const float go = acc[3][s][r] + ep[3 * HID];
+            const float gi = acc[0][s][r] + ep[0] + bh[0][s];
+            const float gf = acc[1][s][r] + ep[HID] + bh[1][s];
+            const float gg = acc[2][s][r] + ep[2 * HID] + bh[2][s];
+            const float go = acc[3][s][r] + ep[3 * HID] + bh[3][s];
             const float ig = sigmoidf_acc(gi), fg = sigmoidf_acc(gf), og = sigmoidf_acc(go);
             const float cn = fg * c[s][r] + ig * tanhf(gg);
             c[s][r] = cn;
@@ -296,14 +308,14 @@ __global__ void embed_gather_kernel(const long* __restrict__ idx, const float* _
 
 }  // namespace
 
-MRN_EXPORT int mrn_lstm_layer_fwd_f32(const float* xproj, const float* w_hh, float* out, int B, int T, int hidden,
-                                      int ndir, void* stream) {
+MRN_EXPORT int mrn_lstm_layer_fwd_f32(const float* xproj, const float* w_hh, const float* b_hh, float* out, int B, int T,
+                                      int hidden, int ndir, void* stream) {
   MRN_CHECK_ARG(xproj && w_hh && out, "mrn_lstm_layer_fwd_f32: null operand");
   MRN_CHECK_ARG(hidden == HID, "mrn_lstm_layer_fwd_f32: hidden=%d unsupported (library is built for %d)", hidden, HID);
   MRN_CHECK_ARG(ndir == 1 || ndir == 2, "mrn_lstm_layer_fwd_f32: ndir=%d", ndir);
   if (B == 0 || T == 0) return MRN_OK;
-  hipLaunchKernelGGL(lstm_layer_kernel, dim3(ceil_div(B, BT), ndir), dim3(256), 0, (hipStream_t)stream, xproj, w_hh, out,
-                     B, T, ndir);
+  hipLaunchKernelGGL(lstm_layer_kernel, dim3(ceil_div(B, BT), ndir), dim3(256), 0, (hipStream_t)stream, xproj, w_hh, b_hh,
+                     out, B, T, ndir);
   MRN_LAUNCH_CHECK("lstm_layer");
   return MRN_OK;
 }
@@ -311,7 +323,7 @@ MRN_EXPORT int mrn_lstm_layer_fwd_f32(const float* xproj, const float* w_hh, flo
 MRN_EXPORT int mrn_attn_decoder_fwd_f32(const float* Hb, const float* Hproj, const float* eproj, int64_t eproj_stride_b,
                                         int64_t eproj_stride_s, const float* w_h2h, const float* b_h2h,
                                         const float* w_score, const float* w_ih, int64_t ld_wih, const float* w_hh,
-                                        float* hid, int64_t hid_stride_b, int64_t hid_stride_s, float* h_state,
+                                        const float* b_hh, float* hid, int64_t hid_stride_b, int64_t hid_stride_s, float* h_state,
                                         float* c_state, float* alpha_out, int B, int T, int D, int S, int hidden,
                                         void* stream) {
   MRN_CHECK_ARG(Hb && Hproj && eproj && w_h2h && b_h2h && w_score && w_ih && w_hh && hid, "mrn_attn_decoder_fwd_f32: null operand");
@@ -321,7 +333,7 @@ MRN_EXPORT int mrn_attn_decoder_fwd_f32(const float* Hb, const float* Hproj, con
   if (B == 0 || S == 0) return MRN_OK;
   AttnDecParams p;
   p.Hb = Hb; p.Hproj = Hproj; p.eproj = eproj; p.w_h2h = w_h2h; p.b_h2h = b_h2h; p.w_score = w_score;
-  p.w_ih = w_ih; p.ld_wih = ld_wih; p.w_hh = w_hh; p.hid = hid; p.h_state = h_state; p.c_state = c_state;
+  p.w_ih = w_ih; p.ld_wih = ld_wih; p.w_hh = w_hh; p.b_hh = b_hh; p.hid = hid; p.h_state = h_state; p.c_state = c_state;
   p.alpha_out = alpha_out; p.B = B; p.T = T; p.D = D; p.S = S;
   p.eproj_stride_b = eproj_stride_b; p.eproj_stride_s = eproj_stride_s;
   p.hid_stride_b = hid_stride_b; p.hid_stride_s = hid_stride_s;

@@ -1,0 +1,414 @@
+// Row-wise HBM-bound operators used by the DM-Router and the heads: LayerNorm (over the contiguous dim and
+// over a strided "patch" dim), GELU, gating products, column sums (bias / affine gradients, split-K combine),
+// index gathers and argmax.  Rows have a contiguous last dim and an arbitrary row stride (ld), so chunk()/
+// rearrange() views of the reference (modules/dm_router.py:12,58-65) never need a copy.
+//
+// Reference op sites: nn.LayerNorm modules/dm_router.py:8,23,40 (eps 1e-5); nn.GELU :42; u*v :17, x*v :33.
+#include "common.hpp"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over the contiguous dim: one wave per row, C <= 1024 (C % 4 == 0), two-pass in registers.
+// ---------------------------------------------------------------------------------------------
+constexpr int LN_MAXV = 4;  // float4 per lane -> C <= 64*4*4 = 1024
+
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, long ldx,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ y, long ldy, float* __restrict__ mean_out,
+                                                            float* __restrict__ rstd_out, long rows, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int C4 = C >> 2;
+  f32x4 v[LN_MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c4 = lane + i * 64;
+    v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c4 < C4) v[i] = reinterpret_cast<const f32x4*>(x + row * ldx)[c4];
+    s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c4 = lane + i * 64;
+    if (c4 < C4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q += d * d; }
+    }
+  }
+  const float rstd = 1.f / sqrtf(wave_sum(q) / (float)C + eps);
+  if (lane == 0) {
+    if (mean_out) mean_out[row] = mean;
+    if (rstd_out) rstd_out[row] = rstd;
+  }
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c4 = lane + i * 64;
+    if (c4 < C4) {
+      const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[c4];
+      const f32x4 b = reinterpret_cast<const f32x4*>(beta)[c4];
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
+      reinterpret_cast<f32x4*>(y + row * ldy)[c4] = o;
+    }
+  }
+}
+
+// dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)); per-block partial sums of dgamma / dbeta.
+// Each block walks ROWS_PER_BLOCK rows, one wave per row at a time; partials land in part[blk][2][C].
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, long lddy,
+                                                            const float* __restrict__ x, long ldx,
+                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, float* __restrict__ dx, long lddx,
+                                                            int accumulate, float* __restrict__ part, long rows, int C,
+                                                            int rows_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4][2][C]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C4 = C >> 2;
+  f32x4 dg[LN_MAXV], db[LN_MAXV];
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) { dg[i] = f32x4{0.f, 0.f, 0.f, 0.f}; db[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  const long r1 = min(rows, r0 + rows_per_block);
+  for (long row = r0 + wave; row < r1; row += 4) {
+    const float mu = mean[row], rs = rstd[row];
+    f32x4 xh[LN_MAXV], gy[LN_MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c4 = lane + i * 64;
+      xh[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      gy[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c4 < C4) {
+        const f32x4 xv = reinterpret_cast<const f32x4*>(x + row * ldx)[c4];
+        const f32x4 dv = reinterpret_cast<const f32x4*>(dy + row * lddy)[c4];
+        const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[c4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          xh[i][j] = (xv[j] - mu) * rs;
+          gy[i][j] = dv[j] * g[j];
+          s1 += gy[i][j];
+          s2 += gy[i][j] * xh[i][j];
+          dg[i][j] += dv[j] * xh[i][j];
+          db[i][j] += dv[j];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)C;
+    s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c4 = lane + i * 64;
+      if (c4 < C4) {
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = rs * (gy[i][j] - s1 - xh[i][j] * s2);
+        f32x4* dst = reinterpret_cast<f32x4*>(dx + row * lddx) + c4;
+        if (accumulate) {
+          const f32x4 old = *dst;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] += old[j];
+        }
+        *dst = o;
+      }
+    }
+  }
+  if (!part) return;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c4 = lane + i * 64;
+    if (c4 < C4) {
+      reinterpret_cast<f32x4*>(red + (wave * 2 + 0) * C)[c4] = dg[i];
+      reinterpret_cast<f32x4*>(red + (wave * 2 + 1) * C)[c4] = db[i];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * C; c += 256) {
+    const int which = c / C, cc = c - which * C;
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) s += red[(w * 2 + which) * C + cc];
+    part[((long)blockIdx.x * 2 + which) * C + cc] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over a strided axis: x[b][p][w] (w contiguous, W columns), normalise every (b, w) column over
+// the P entries; affine parameters are indexed by p.  This is ChannelDomainGating's LayerNorm(patch) applied
+// to the 'b (d c) p' rearrangement (modules/dm_router.py:23,29,63) without materialising the transpose.
+// One thread per column; loads are coalesced across w.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ y,
+                                                          float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                          int P, int Wd, float eps) {
+  const int b = blockIdx.y;
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  if (w >= Wd) return;
+  const float* xb = x + (long)b * P * Wd + w;
+  float s = 0.f;
+  for (int p = 0; p < P; ++p) s += xb[(long)p * Wd];
+  const float mean = s / (float)P;
+  float q = 0.f;
+  for (int p = 0; p < P; ++p) { const float d = xb[(long)p * Wd] - mean; q += d * d; }
+  const float rstd = 1.f / sqrtf(q / (float)P + eps);
+  mean_out[(long)b * Wd + w] = mean;
+  rstd_out[(long)b * Wd + w] = rstd;
+  float* yb = y + (long)b * P * Wd + w;
+  for (int p = 0; p < P; ++p) yb[(long)p * Wd] = (xb[(long)p * Wd] - mean) * rstd * gamma[p] + beta[p];
+}
+
+// backward of colnorm; per-block partial sums of dgamma[p], dbeta[p] into part[blk][2][P]
+__global__ __launch_bounds__(256) void colnorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, float* __restrict__ dx,
+                                                          int accumulate, float* __restrict__ part, int P, int Wd) {
+  __shared__ float scratch[4];
+  const int b = blockIdx.y;
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  const bool ok = w < Wd;
+  const long base = (long)b * P * Wd + (ok ? w : 0);
+  const float mu = ok ? mean[(long)b * Wd + w] : 0.f, rs = ok ? rstd[(long)b * Wd + w] : 0.f;
+  float s1 = 0.f, s2 = 0.f;
+  if (ok) {
+    for (int p = 0; p < P; ++p) {
+      const float xh = (x[base + (long)p * Wd] - mu) * rs;
+      const float gy = dy[base + (long)p * Wd] * gamma[p];
+      s1 += gy;
+      s2 += gy * xh;
+    }
+  }
+  s1 /= (float)P;
+  s2 /= (float)P;
+  const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+  for (int p = 0; p < P; ++p) {
+    float dgp = 0.f, dbp = 0.f;
+    if (ok) {
+      const float xh = (x[base + (long)p * Wd] - mu) * rs;
+      const float d = dy[base + (long)p * Wd];
+      float o = rs * (d * gamma[p] - s1 - xh * s2);
+      if (accumulate) o += dx[base + (long)p * Wd];
+      dx[base + (long)p * Wd] = o;
+      dgp = d * xh;
+      dbp = d;
+    }
+    const float tg = block_sum<256>(dgp, scratch);
+    const float tb = block_sum<256>(dbp, scratch);
+    if (threadIdx.x == 0) {
+      part[((long)blk * 2 + 0) * P + p] = tg;
+      part[((long)blk * 2 + 1) * P + p] = tb;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// elementwise over strided rows (C % 4 == 0)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float v) {
+  const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * expf(-0.5f * v * v);
+  return cdf + v * pdf;
+}
+
+// op 0: y = gelu(a)   1: y = b * gelu'(a)   2: y = a * b   3: y = a + b
+__global__ __launch_bounds__(256) void ew_rows_kernel(const float* __restrict__ a, long lda, const float* __restrict__ b,
+                                                      long ldb, float* __restrict__ y, long ldy, long rows, int C4, int op) {
+  const long n = rows * C4;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long r = i / C4;
+    const int c4 = (int)(i - r * C4);
+    const f32x4 av = reinterpret_cast<const f32x4*>(a + r * lda)[c4];
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (b) bv = reinterpret_cast<const f32x4*>(b + r * ldb)[c4];
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (op == 0) o[j] = gelu_f(av[j]);
+      else if (op == 1) o[j] = bv[j] * gelu_grad_f(av[j]);
+      else if (op == 2) o[j] = av[j] * bv[j];
+      else o[j] = av[j] + bv[j];
+    }
+    reinterpret_cast<f32x4*>(y + r * ldy)[c4] = o;
+  }
+}
+
+// out[c] (+)= sum_r in[r*ld + c]; two-stage: grid (colblocks, rowchunks) -> part, then a final pass when chunks > 1
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, long ld, float* __restrict__ out,
+                                                     long rows, int C, long rows_per_chunk, int accumulate, int direct) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const long r0 = blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  long r = r0;
+  for (; r + 3 < r1; r += 4) {
+    s0 += in[r * ld + c];
+    s1 += in[(r + 1) * ld + c];
+    s2 += in[(r + 2) * ld + c];
+    s3 += in[(r + 3) * ld + c];
+  }
+  for (; r < r1; ++r) s0 += in[r * ld + c];
+  const float s = (s0 + s1) + (s2 + s3);
+  if (direct) out[c] = accumulate ? out[c] + s : s;
+  else out[(long)blockIdx.y * C + c] = s;
+}
+
+// out[i][j] = in[ridx[i]][cidx[j]] (index arrays may be null = identity); out row stride ld_out, padding cols zeroed
+__global__ void gather2d_kernel(const float* __restrict__ in, long ld_in, const int* __restrict__ ridx,
+                                const int* __restrict__ cidx, float* __restrict__ out, long ld_out, int R, int C, int Cpad) {
+  const long n = (long)R * Cpad;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / Cpad), c = (int)(i - (long)r * Cpad);
+    float v = 0.f;
+    if (c < C) v = in[(long)(ridx ? ridx[r] : r) * ld_in + (cidx ? cidx[c] : c)];
+    out[(long)r * ld_out + c] = v;
+  }
+}
+
+// first index of the maximum along the last dim (torch.max semantics), one wave per row
+__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ x, long ld, int64_t* __restrict__ out,
+                                                     long rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int c = lane; c < C; c += 64) {
+    const float v = x[row * ld + c];
+    if (v > best || (v != v && best == best)) { best = v; bi = c; }  // NaN propagates like torch
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o);
+    const int oi = __shfl_xor(bi, o);
+    const bool take = (ov > best) || (ov == best && oi < bi) || (ov != ov && best == best);
+    if (take) { best = ov; bi = oi; }
+  }
+  if (lane == 0) out[row] = bi;
+}
+
+}  // namespace
+
+static inline int ew_grid(long n, int per_block) {
+  long g = (n + per_block - 1) / per_block;
+  if (g > 256 * 16) g = 256 * 16;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+MRN_EXPORT int mrn_layernorm_fwd_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y,
+                                     int64_t ldy, float* mean, float* rstd, int64_t rows, int C, float eps, void* stream) {
+  MRN_CHECK_ARG(x && gamma && beta && y, "mrn_layernorm_fwd_f32: null operand");
+  MRN_CHECK_ARG(C % 4 == 0 && C <= 1024 && ldx % 4 == 0 && ldy % 4 == 0, "mrn_layernorm_fwd_f32: C=%d must be a multiple of 4, <= 1024", C);
+  if (rows == 0) return MRN_OK;
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, (long)ldx,
+                     gamma, beta, y, (long)ldy, mean, rstd, (long)rows, C, eps);
+  MRN_LAUNCH_CHECK("layernorm_fwd");
+  return MRN_OK;
+}
+
+MRN_EXPORT int64_t mrn_layernorm_bwd_blocks(int64_t rows) {
+  int64_t b = (rows + 63) / 64;
+  if (b > 1024) b = 1024;
+  return b < 1 ? 1 : b;
+}
+
+MRN_EXPORT int mrn_layernorm_bwd_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+                                     const float* mean, const float* rstd, float* dx, int64_t lddx, int accumulate,
+                                     float* partials, int64_t rows, int C, void* stream) {
+  MRN_CHECK_ARG(dy && x && gamma && mean && rstd && dx, "mrn_layernorm_bwd_f32: null operand");
+  MRN_CHECK_ARG(C % 4 == 0 && C <= 1024, "mrn_layernorm_bwd_f32: C=%d", C);
+  if (rows == 0) return MRN_OK;
+  const long nblk = mrn_layernorm_bwd_blocks(rows);
+  const int rpb = (int)((rows + nblk - 1) / nblk);
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)nblk), dim3(256), sizeof(float) * 8 * C, (hipStream_t)stream, dy,
+                     (long)lddy, x, (long)ldx, gamma, mean, rstd, dx, (long)lddx, accumulate, partials, (long)rows, C, rpb);
+  MRN_LAUNCH_CHECK("layernorm_bwd");
+  return MRN_OK;
+}
+
+MRN_EXPORT int mrn_colnorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                                   float* rstd, int B, int P, int Wd, float eps, void* stream) {
+  MRN_CHECK_ARG(x && gamma && beta && y && mean && rstd, "mrn_colnorm_fwd_f32: null operand");
+  if (B == 0) return MRN_OK;
+  hipLaunchKernelGGL(colnorm_fwd_kernel, dim3(ceil_div(Wd, 256), B), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y,
+                     mean, rstd, P, Wd, eps);
+  MRN_LAUNCH_CHECK("colnorm_fwd");
+  return MRN_OK;
+}
+
+MRN_EXPORT int mrn_colnorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean,
+                                   const float* rstd, float* dx, int accumulate, float* partials, int B, int P, int Wd,
+                                   void* stream) {
+  MRN_CHECK_ARG(dy && x && gamma && mean && rstd && dx && partials, "mrn_colnorm_bwd_f32: null operand");
+  if (B == 0) return MRN_OK;
+  hipLaunchKernelGGL(colnorm_bwd_kernel, dim3(ceil_div(Wd, 256), B), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean,
+                     rstd, dx, accumulate, partials, P, Wd);
+  MRN_LAUNCH_CHECK("colnorm_bwd");
+  return MRN_OK;
+}
+
+MRN_EXPORT int mrn_ew_rows_f32(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy,
+                               int64_t rows, int C, int op, void* stream) {
+  MRN_CHECK_ARG(a && y && op >= 0 && op <= 3 && (op == 0 || b), "mrn_ew_rows_f32: bad operands for op %d", op);
+  MRN_CHECK_ARG(C % 4 == 0 && lda % 4 == 0 && ldy % 4 == 0 && ldb % 4 == 0, "mrn_ew_rows_f32: C and row strides must be multiples of 4");
+  if (rows == 0) return MRN_OK;
+  hipLaunchKernelGGL(ew_rows_kernel, dim3(ew_grid(rows * (C / 4), 1024)), dim3(256), 0, (hipStream_t)stream, a, (long)lda, b,
+                     (long)ldb, y, (long)ldy, (long)rows, C / 4, op);
+  MRN_LAUNCH_CHECK("ew_rows");
+  return MRN_OK;
+}
+
+MRN_EXPORT int64_t mrn_colsum_chunks(int64_t rows, int C) {
+  const int64_t colblocks = (C + 255) / 256;
+  int64_t chunks = 1024 / colblocks;
+  if (chunks > (rows + 63) / 64) chunks = (rows + 63) / 64;
+  return chunks < 1 ? 1 : chunks;
+}
+
+// out[c] (+)= sum over rows; workspace must hold mrn_colsum_chunks(rows, C) * C floats (unused when chunks == 1)
+MRN_EXPORT int mrn_colsum_f32(const float* in, int64_t ld, float* out, float* workspace, int64_t rows, int C,
+                              int accumulate, void* stream) {
+  MRN_CHECK_ARG(in && out, "mrn_colsum_f32: null operand");
+  if (C == 0) return MRN_OK;
+  const long chunks = mrn_colsum_chunks(rows, C);
+  const int cb = ceil_div(C, 256);
+  if (chunks == 1) {
+    hipLaunchKernelGGL(colsum_kernel, dim3(cb, 1), dim3(256), 0, (hipStream_t)stream, in, (long)ld, out, (long)rows, C,
+                       (long)rows, accumulate, 1);
+  } else {
+    MRN_CHECK_ARG(workspace, "mrn_colsum_f32: workspace required for %ld chunks", chunks);
+    const long rpc = (rows + chunks - 1) / chunks;
+    hipLaunchKernelGGL(colsum_kernel, dim3(cb, (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, in, (long)ld, workspace,
+                       (long)rows, C, rpc, 0, 0);
+    hipLaunchKernelGGL(colsum_kernel, dim3(cb, 1), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, (long)C, out,
+                       chunks, C, chunks, accumulate, 1);
+  }
+  MRN_LAUNCH_CHECK("colsum");
+  return MRN_OK;
+}
+
+MRN_EXPORT int mrn_gather2d_f32(const float* in, int64_t ld_in, const int* row_idx, const int* col_idx, float* out,
+                                int64_t ld_out, int R, int C, void* stream) {
+  MRN_CHECK_ARG(in && out && ld_out >= C, "mrn_gather2d_f32: bad operands");
+  const long n = (long)R * ld_out;
+  if (n == 0) return MRN_OK;
+  hipLaunchKernelGGL(gather2d_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, in, (long)ld_in, row_idx,
+                     col_idx, out, (long)ld_out, R, C, (int)ld_out);
+  MRN_LAUNCH_CHECK("gather2d");
+  return MRN_OK;
+}
+
+MRN_EXPORT int mrn_argmax_f32(const float* x, int64_t ld, int64_t* out, int64_t rows, int C, void* stream) {
+  MRN_CHECK_ARG(x && out && C > 0, "mrn_argmax_f32: bad operands");
+  if (rows == 0) return MRN_OK;
+  hipLaunchKernelGGL(argmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, (long)ld, out,
+                     (long)rows, C);
+  MRN_LAUNCH_CHECK("argmax");
+  return MRN_OK;
+}

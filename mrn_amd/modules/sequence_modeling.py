@@ -1,0 +1,42 @@
+"""SequenceModeling stage operator: BidirectionalLSTM on the HIP path (reference modules/sequence_modeling.py:4-22).
+
+nn.LSTM / nn.Linear are parameter containers (state_dict keys rnn.weight_ih_l0[_reverse] ... linear.weight).
+Forward = one GEMM for both directions' input projections, one persistent recurrent launch, one output GEMM.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ._nn import require_no_grad
+
+
+class BidirectionalLSTM(nn.Module):
+    def __init__(self, input_size, hidden_size, output_size):
+        super().__init__()
+        self.rnn = nn.LSTM(input_size, hidden_size, bidirectional=True, batch_first=True)
+        self.linear = nn.Linear(hidden_size * 2, output_size)
+        self.hidden_size = hidden_size
+
+    def _packed(self):
+        r = self.rnn
+        ps = (r.weight_ih_l0, r.weight_ih_l0_reverse, r.weight_hh_l0, r.weight_hh_l0_reverse, r.bias_ih_l0,
+              r.bias_hh_l0, r.bias_ih_l0_reverse, r.bias_hh_l0_reverse)
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        cache = getattr(self, "_mrn_packed", None)
+        if cache is None or cache[0] != key:
+            with torch.no_grad():
+                w_ih = torch.cat([ps[0], ps[1]], 0).contiguous()            # [2*4H, in]
+                w_hh = torch.stack([ps[2], ps[3]], 0).contiguous()          # [2, 4H, H]
+                b_ih = torch.cat([ps[4], ps[6]], 0).contiguous()
+                b_hh = torch.cat([ps[5], ps[7]], 0).contiguous()
+            cache = (key, (w_ih, w_hh, b_ih, b_hh))
+            self._mrn_packed = cache
+        return cache[1]
+
+    def forward(self, input, out=None):
+        """input [B,T,in] -> [B,T,out]; `out` may be a strided [B,T,out] view (zero-copy expert stacking)."""
+        require_no_grad(self, "BidirectionalLSTM")
+        w_ih, w_hh, b_ih, b_hh = self._packed()
+        xproj = ops.linear(input, w_ih, b_ih)
+        rec = ops.lstm_layer(xproj, w_hh, b_hh, self.hidden_size, 2)
+        return ops.linear(rec, self.linear.weight, self.linear.bias, out=out)

@@ -41,22 +41,42 @@ def gemm_raw(A, W, C, M, N, K, batch=1, sA=(0, 0, 1), sW=(0, 0, 1), sC=(0, 0, 1)
     return C
 
 
+def rows2d(t):
+    """View [..., K] (contiguous last dim, uniformly strided leading dims) as a 2-D [rows, K] strided tensor."""
+    if t.dim() == 2:
+        assert t.stride(1) == 1 or t.shape[1] == 1
+        return t
+    if t.is_contiguous():
+        return t.view(-1, t.shape[-1])
+    assert t.stride(-1) == 1 or t.shape[-1] == 1, "last dim must be contiguous"
+    rs, n = None, 1
+    for d in range(t.dim() - 2, -1, -1):        # every leading dim (size > 1) must continue the same row stride
+        if t.shape[d] == 1:
+            continue
+        if rs is None:
+            rs = t.stride(d)
+        else:
+            assert t.stride(d) == rs * n, f"non-uniform row stride {t.stride()} for shape {tuple(t.shape)}"
+        n *= t.shape[d]
+    if rs is None:
+        rs = t.shape[-1]
+    return t.as_strided((n, t.shape[-1]), (rs, 1))
+
+
 def linear(x, weight, bias=None, act=ACT_NONE, residual=None, out=None):
-    """y = act(x @ weight.T + bias (+ residual)); x [..., K] with contiguous last dim and uniform row stride."""
+    """y = act(x @ weight.T + bias (+ residual)); x [..., K], weight [N, K] (row stride free), out may be strided."""
     K = x.shape[-1]
     N = weight.shape[0]
-    x2 = x.reshape(-1, K) if x.is_contiguous() else x
-    if x2.dim() != 2:
-        x2 = x.contiguous().view(-1, K)
+    x2 = rows2d(x)
     M = x2.shape[0]
     if out is None:
         out = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
-    o2 = out.view(-1, N) if out.is_contiguous() else out
-    assert o2.dim() == 2 and o2.stride(1) == 1 and x2.stride(1) == 1 and weight.stride(1) == 1
+    o2 = rows2d(out)
+    assert o2.shape == (M, N) and weight.stride(1) == 1
     r2 = None
     if residual is not None:
-        r2 = residual.view(-1, N) if residual.is_contiguous() else residual
-        assert r2.stride() == o2.stride()
+        r2 = rows2d(residual)
+        assert r2.stride() == o2.stride(), "residual must share the output's layout"
     gemm_raw(x2, weight, o2, M, N, K, 1, (0, x2.stride(0), 1), (0, weight.stride(0), 1), (0, o2.stride(0), 1),
              bias=bias, residual=r2, act=act)
     return out
@@ -167,12 +187,12 @@ def tps_grid_sample(img_nhwc, cprime, inv_delta_c, p_hat, out_hw, want_grid=Fals
 # ---------------------------------------------------------------------------------------------------------
 # recurrent
 # ---------------------------------------------------------------------------------------------------------
-def lstm_layer(xproj, w_hh, hidden, ndir):
-    """xproj [B,T,ndir*4H] (already includes both biases), w_hh [ndir,4H,H] -> [B,T,ndir*H]"""
-    _chk(xproj, w_hh)
+def lstm_layer(xproj, w_hh, b_hh, hidden, ndir):
+    """xproj [B,T,ndir*4H] (= x W_ih^T + b_ih), w_hh [ndir,4H,H], b_hh [ndir*4H] or None -> [B,T,ndir*H]"""
+    _chk(xproj, w_hh, b_hh)
     B, T, _ = xproj.shape
     out = torch.empty(B, T, ndir * hidden, device=xproj.device, dtype=torch.float32)
-    call("mrn_lstm_layer_fwd_f32", _p(xproj), _p(w_hh), _p(out), B, T, hidden, ndir, _stream())
+    call("mrn_lstm_layer_fwd_f32", _p(xproj), _p(w_hh), _p(b_hh), _p(out), B, T, hidden, ndir, _stream())
     return out
 
 
@@ -186,9 +206,9 @@ def embed_gather(idx, table, num_class):
     return out
 
 
-def attn_decoder(Hb, Hproj, eproj, w_h2h, b_h2h, w_score, w_ih, w_hh, hidden, hid=None, h_state=None, c_state=None,
-                 want_alpha=False):
-    _chk(Hb, Hproj, eproj, w_h2h, b_h2h, w_score, w_ih, w_hh)
+def attn_decoder(Hb, Hproj, eproj, w_h2h, b_h2h, w_score, w_ih, w_hh, b_hh, hidden, hid=None, h_state=None,
+                 c_state=None, want_alpha=False):
+    _chk(Hb, Hproj, eproj, w_h2h, b_h2h, w_score, w_ih, w_hh, b_hh)
     B, T, D = Hb.shape
     S = eproj.shape[1]
     if hid is None:
@@ -196,6 +216,253 @@ def attn_decoder(Hb, Hproj, eproj, w_h2h, b_h2h, w_score, w_ih, w_hh, hidden, hi
     alpha = torch.empty(B, S, T, device=Hb.device, dtype=torch.float32) if want_alpha else None
     assert eproj.stride(2) == 1 and hid.stride(2) == 1 and w_ih.stride(1) == 1
     call("mrn_attn_decoder_fwd_f32", _p(Hb), _p(Hproj), _p(eproj), eproj.stride(0), eproj.stride(1), _p(w_h2h),
-         _p(b_h2h), _p(w_score), _p(w_ih), w_ih.stride(0), _p(w_hh), _p(hid), hid.stride(0), hid.stride(1),
+         _p(b_h2h), _p(w_score), _p(w_ih), w_ih.stride(0), _p(w_hh), _p(b_hh), _p(hid), hid.stride(0), hid.stride(1),
          _p(h_state), _p(c_state), _p(alpha), B, T, D, S, hidden, _stream())
     return (hid, alpha) if want_alpha else hid
+
+
+# ---------------------------------------------------------------------------------------------------------
+# row-wise operators (DM-Router)
+# ---------------------------------------------------------------------------------------------------------
+def argmax_lastdim(x):
+    x2 = rows2d(x)
+    out = torch.empty(x2.shape[0], device=x.device, dtype=torch.int64)
+    call("mrn_argmax_f32", _p(x2), x2.stride(0), _p(out), x2.shape[0], x2.shape[1], _stream())
+    return out.view(x.shape[:-1])
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-5, out=None):
+    """LayerNorm over the last dim of (strided) rows -> (y, mean, rstd)"""
+    x2 = rows2d(x)
+    rows, C = x2.shape
+    if out is None:
+        out = torch.empty(*x.shape, device=x.device, dtype=torch.float32)
+    o2 = rows2d(out)
+    mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+    rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+    call("mrn_layernorm_fwd_f32", _p(x2), x2.stride(0), _p(gamma), _p(beta), _p(o2), o2.stride(0), _p(mean), _p(rstd),
+         rows, C, float(eps), _stream())
+    return out, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx=None, accumulate=False):
+    """-> (dx, dgamma, dbeta)"""
+    dy2, x2 = rows2d(dy), rows2d(x)
+    rows, C = x2.shape
+    if dx is None:
+        dx = torch.empty(*x.shape, device=x.device, dtype=torch.float32)
+        accumulate = False
+    dx2 = rows2d(dx)
+    nblk = call("mrn_layernorm_bwd_blocks", rows)
+    part = torch.empty(nblk, 2 * C, device=x.device, dtype=torch.float32)
+    call("mrn_layernorm_bwd_f32", _p(dy2), dy2.stride(0), _p(x2), x2.stride(0), _p(gamma), _p(mean), _p(rstd), _p(dx2),
+         dx2.stride(0), int(accumulate), _p(part), rows, C, _stream())
+    dgb = colsum(part)
+    return dx, dgb[:C], dgb[C:]
+
+
+def colnorm_fwd(x, gamma, beta, eps=1e-5):
+    """x [B,P,W] contiguous: LayerNorm over P for every (b, w) -> (y, mean[B,W], rstd[B,W])"""
+    B, P, Wd = x.shape
+    assert x.is_contiguous()
+    y = torch.empty_like(x)
+    mean = torch.empty(B, Wd, device=x.device, dtype=torch.float32)
+    rstd = torch.empty(B, Wd, device=x.device, dtype=torch.float32)
+    call("mrn_colnorm_fwd_f32", _p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), B, P, Wd, float(eps), _stream())
+    return y, mean, rstd
+
+
+def colnorm_bwd(dy, x, gamma, mean, rstd, dx=None, accumulate=False):
+    B, P, Wd = x.shape
+    assert x.is_contiguous() and dy.is_contiguous()
+    if dx is None:
+        dx = torch.empty_like(x)
+        accumulate = False
+    nblk = B * ((Wd + 255) // 256)
+    part = torch.empty(nblk, 2 * P, device=x.device, dtype=torch.float32)
+    call("mrn_colnorm_bwd_f32", _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), int(accumulate), _p(part), B, P, Wd,
+         _stream())
+    dgb = colsum(part)
+    return dx, dgb[:P], dgb[P:]
+
+
+EW_GELU, EW_GELU_BWD, EW_MUL, EW_ADD = 0, 1, 2, 3
+
+
+def ew_rows(op, a, b=None, out=None):
+    a2 = rows2d(a)
+    rows, C = a2.shape
+    if out is None:
+        out = torch.empty(*a.shape, device=a.device, dtype=torch.float32)
+    o2 = rows2d(out)
+    b2 = rows2d(b) if b is not None else None
+    call("mrn_ew_rows_f32", _p(a2), a2.stride(0), _p(b2), b2.stride(0) if b2 is not None else 0, _p(o2), o2.stride(0),
+         rows, C, op, _stream())
+    return out
+
+
+def colsum(x, out=None, accumulate=False):
+    """sum over rows of a (strided) 2-D view -> [C]"""
+    x2 = rows2d(x)
+    rows, C = x2.shape
+    if out is None:
+        out = torch.empty(C, device=x.device, dtype=torch.float32)
+        accumulate = False
+    chunks = call("mrn_colsum_chunks", rows, C)
+    ws = torch.empty(chunks * C, device=x.device, dtype=torch.float32) if chunks > 1 else None
+    call("mrn_colsum_f32", _p(x2), x2.stride(0), _p(out), _p(ws), rows, C, int(accumulate), _stream())
+    return out
+
+
+def gather2d(x, row_idx, col_idx, ld_out=None):
+    """out[i,j] = x[row_idx[i], col_idx[j]] (int32 device index tensors or None); out has row stride ld_out (zero padded)"""
+    R = x.shape[0] if row_idx is None else row_idx.numel()
+    C = x.shape[1] if col_idx is None else col_idx.numel()
+    ld_out = C if ld_out is None else ld_out
+    out = torch.empty(R, ld_out, device=x.device, dtype=torch.float32)
+    call("mrn_gather2d_f32", _p(x), x.stride(0), _p(row_idx), _p(col_idx), _p(out), ld_out, R, C, _stream())
+    return out[:, :C]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# fan-in / gate tail
+# ---------------------------------------------------------------------------------------------------------
+import ctypes as _ct  # noqa: E402
+
+
+def _fanin_args(logits):
+    I = len(logits)
+    ptrs = (_ct.c_void_p * I)(*[l.data_ptr() for l in logits])
+    lds = (_ct.c_int64 * I)(*[l.stride(-2) for l in logits])
+    cls = (_ct.c_int * I)(*[l.shape[-1] for l in logits])
+    for l in logits:
+        assert l.dim() == 3 and l.stride(2) == 1 and l.stride(0) == l.shape[1] * l.stride(1)
+    return I, ptrs, lds, cls
+
+
+def padded_rows(B, T, C, device):
+    """[B,T,C] view of a buffer whose rows are padded to a multiple of 4 floats (16-byte aligned rows)."""
+    ld = (C + 3) // 4 * 4
+    return torch.empty(B, T, ld, device=device, dtype=torch.float32)[:, :, :C]
+
+
+def fanin_fwd(logits, w):
+    I, ptrs, lds, cls = _fanin_args(logits)
+    B, T, C = logits[-1].shape
+    out = padded_rows(B, T, C, w.device)
+    call("mrn_fanin_fwd_f32", ptrs, lds, cls, I, _p(w), _p(out), out.stride(1), B, T, C, _stream())
+    return out
+
+
+def fanin_bwd(logits, dout):
+    I, ptrs, lds, cls = _fanin_args(logits)
+    B, T, C = logits[-1].shape
+    assert dout.stride(2) == 1 and dout.stride(0) == T * dout.stride(1)
+    dw = torch.empty(B, I, device=dout.device, dtype=torch.float32)
+    ws = torch.empty(B * T * I, device=dout.device, dtype=torch.float32)
+    call("mrn_fanin_bwd_f32", ptrs, lds, cls, I, _p(dout), dout.stride(1), _p(dw), _p(ws), B, T, C, _stream())
+    return dw
+
+
+def select_expert(logits, index):
+    I, ptrs, lds, cls = _fanin_args(logits)
+    B, T, C = logits[-1].shape
+    out = torch.empty(B, T, C, device=index.device, dtype=torch.float32)
+    call("mrn_select_expert_f32", ptrs, lds, cls, I, _p(index), _p(out), C, B, T, C, _stream())
+    return out
+
+
+def gate_tail_fwd(r, w_route, b_route, beta=1.0, hard=False):
+    """r [B,P,I] -> (s, w) or (s, argmax)"""
+    B, P, I = r.shape
+    s = torch.empty(B, I, device=r.device, dtype=torch.float32)
+    if hard:
+        am = torch.empty(B, device=r.device, dtype=torch.int64)
+        call("mrn_gate_tail_fwd_f32", _p(r), _p(w_route), _p(b_route), float(beta), _p(s), None, _p(am), B, P, I, _stream())
+        return s, am
+    w = torch.empty(B, I, device=r.device, dtype=torch.float32)
+    call("mrn_gate_tail_fwd_f32", _p(r), _p(w_route), _p(b_route), float(beta), _p(s), _p(w), None, B, P, I, _stream())
+    return s, w
+
+
+def gate_tail_bwd(w, dw, r, w_route, beta=1.0):
+    B, P, I = r.shape
+    ds = torch.empty(B, I, device=r.device, dtype=torch.float32)
+    dr = torch.empty(B, P, I, device=r.device, dtype=torch.float32)
+    dW = torch.empty(P, device=r.device, dtype=torch.float32)
+    db = torch.empty(1, device=r.device, dtype=torch.float32)
+    call("mrn_gate_tail_bwd_f32", _p(w), _p(dw.contiguous()), _p(r), _p(w_route), float(beta), _p(ds), _p(dr), _p(dW), _p(db),
+         B, P, I, _stream())
+    return dr, dW, db
+
+
+# ---------------------------------------------------------------------------------------------------------
+# losses
+# ---------------------------------------------------------------------------------------------------------
+def ce_loss_fwd(logits, target, ignore_index=-100):
+    """logits [..., C] (strided rows), target [...] int64 -> (loss scalar tensor, ctx)"""
+    l2 = rows2d(logits)
+    rows, C = l2.shape
+    t = target.reshape(-1).contiguous()
+    dev = logits.device
+    lse = torch.empty(rows, device=dev, dtype=torch.float32)
+    lrow = torch.empty(rows, device=dev, dtype=torch.float32)
+    loss = torch.empty(1, device=dev, dtype=torch.float32)
+    inv = torch.empty(1, device=dev, dtype=torch.float32)
+    call("mrn_ce_loss_fwd_f32", _p(l2), l2.stride(0), _p(t), ignore_index, rows, C, _p(lse), _p(lrow), _p(loss), _p(inv),
+         _stream())
+    return loss, (l2, t, ignore_index, lse, inv)
+
+
+def ce_loss_bwd(ctx, upstream, like):
+    l2, t, ignore_index, lse, inv = ctx
+    rows, C = l2.shape
+    d = torch.empty_strided(like.shape, like.stride(), device=like.device, dtype=torch.float32)
+    d2 = rows2d(d)
+    call("mrn_ce_loss_bwd_f32", _p(l2), l2.stride(0), _p(t), ignore_index, _p(lse), _p(upstream), _p(inv), _p(d2),
+         d2.stride(0), rows, C, _stream())
+    return d
+
+
+def ctc_loss_fwd(logits, targets, target_len, blank=0):
+    """logits [B,T,C] (strided rows), targets [B,L] int64, target_len [B] int32 -> (loss, ctx)"""
+    B, T, C = logits.shape
+    assert logits.stride(2) == 1 and logits.stride(0) == T * logits.stride(1)
+    dev = logits.device
+    targets = targets.contiguous()
+    target_len = target_len.to(torch.int32).contiguous()
+    lse = torch.empty(B * T, device=dev, dtype=torch.float32)
+    nll = torch.empty(B, device=dev, dtype=torch.float32)
+    occ = torch.empty(call("mrn_ctc_occ_floats", B, T), device=dev, dtype=torch.float32)
+    loss = torch.empty(1, device=dev, dtype=torch.float32)
+    call("mrn_ctc_loss_fwd_f32", _p(logits), logits.stride(1), _p(targets), targets.stride(0), _p(target_len),
+         targets.shape[1], _p(lse), _p(nll), _p(occ), _p(loss), B, T, C, blank, _stream())
+    return loss, (logits, targets, target_len, lse, nll, occ, blank)
+
+
+def ctc_loss_bwd(ctx, upstream):
+    logits, targets, target_len, lse, nll, occ, blank = ctx
+    B, T, C = logits.shape
+    d = torch.empty_strided(logits.shape, logits.stride(), device=logits.device, dtype=torch.float32)
+    call("mrn_ctc_loss_bwd_f32", _p(logits), logits.stride(1), _p(lse), _p(occ), _p(targets), targets.stride(0),
+         _p(target_len), _p(nll), _p(upstream), _p(d), d.stride(1), B, T, C, blank, _stream())
+    return d
+
+
+# ---------------------------------------------------------------------------------------------------------
+# optimiser
+# ---------------------------------------------------------------------------------------------------------
+def grad_norm_clip(gflat, max_norm):
+    """-> device tensor [norm, clip_coef]"""
+    n = gflat.numel()
+    ws = torch.empty(call("mrn_grad_norm_workspace_floats", n), device=gflat.device, dtype=torch.float32)
+    nc = torch.empty(2, device=gflat.device, dtype=torch.float32)
+    call("mrn_grad_norm_clip_f32", _p(gflat), n, float(max_norm), _p(ws), _p(nc), _stream())
+    return nc
+
+
+def adam_step(p, g, m, v, norm_coef, lr, step, betas=(0.9, 0.999), eps=1e-8):
+    bc1 = 1.0 - betas[0] ** step
+    bc2 = 1.0 - betas[1] ** step
+    call("mrn_adam_step_f32", _p(p), _p(g), _p(m), _p(v), p.numel(), _p(norm_coef), float(lr / bc1), float(betas[0]),
+         float(betas[1]), float(bc2 ** 0.5), float(eps), _stream())

@@ -1,0 +1,316 @@
+"""Kernel-level parity on the GPU: every C-ABI entry point against the fp32 torch-CPU op it replaces
+(these CPU ops are exactly what the oracle restatement is composed of).  Tolerance: 1e-4 (north star), tighter
+where the op is a plain reduction."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.helpers import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from mrn_amd import ops as o
+    from mrn_amd._lib import LIB
+    LIB.load()
+    return o
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def cu(t):
+    return t.cuda()
+
+
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(257, 130, 64), (128, 128, 16), (65, 33, 390), (1000, 512, 260), (3, 5, 7), (300, 40, 512)])
+def test_linear_shapes(ops, M, N, K):
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)
+    for act, ref_act in ((0, lambda v: v), (1, F.relu), (2, F.gelu)):
+        y = ops.linear(cu(x), cu(w), cu(b), act=act)
+        assert_close(f"linear act{act}", y, ref_act(F.linear(x, w, b)), atol=1e-5 * K ** 0.5, rtol=1e-5)
+
+
+def test_gemm_all_staging_modes(ops):
+    """operands contiguous along k or along the row dim, vectorisable or not; batch + bias per row + residual"""
+    Bz = 3
+    for (M, N, K) in [(132, 72, 100), (65, 390, 390), (256, 64, 63)]:
+        A = rnd(Bz, M, K, seed=4)
+        W = rnd(Bz, N, K, seed=5)
+        bias = rnd(M, seed=6)
+        res = rnd(Bz, M, N, seed=7)
+        ref = torch.einsum("bmk,bnk->bmn", A, W) + bias[None, :, None] + res
+        for a_t in (False, True):
+            for w_t in (False, True):
+                Ad = cu(A.transpose(1, 2).contiguous()) if a_t else cu(A)      # [B,K,M] or [B,M,K]
+                Wd = cu(W.transpose(1, 2).contiguous()) if w_t else cu(W)
+                sA = (M * K, 1, M) if a_t else (M * K, K, 1)
+                sW = (N * K, 1, N) if w_t else (N * K, K, 1)
+                C = torch.empty(Bz, M, N, device="cuda")
+                ops.gemm_raw(Ad, Wd, C, M, N, K, Bz, sA, sW, (M * N, N, 1), bias=cu(bias), bias_axis=1, residual=cu(res))
+                assert_close(f"gemm {M}x{N}x{K} aT={a_t} wT={w_t}", C, ref, atol=2e-5 * K ** 0.5, rtol=1e-5)
+    # accumulate + alpha + strided output (transposed store)
+    M, N, K = 70, 50, 36
+    A, W, C0 = rnd(M, K, seed=8), rnd(N, K, seed=9), rnd(N, M, seed=10)
+    Cd = cu(C0.clone())
+    ops.gemm_raw(cu(A), cu(W), Cd, M, N, K, 1, (0, K, 1), (0, K, 1), (0, 1, M), accumulate=True, alpha=0.5)
+    assert_close("gemm accumulate/alpha/transposed C", Cd, C0 + 0.5 * (A @ W.t()).t(), atol=1e-5)
+
+
+CONVS = [
+    # B, H, W, Cin, Cout, k, s, p
+    (2, 32, 256, 4, 32, (3, 3), (1, 1), (1, 1)),
+    (3, 16, 128, 32, 64, (3, 3), (1, 1), (1, 1)),
+    (2, 8, 64, 64, 128, (1, 1), (1, 1), (0, 0)),
+    (2, 4, 65, 512, 512, (3, 3), (1, 1), (1, 1)),
+    (2, 4, 65, 256, 512, (2, 2), (2, 1), (0, 1)),
+    (2, 2, 66, 128, 512, (2, 2), (1, 1), (0, 0)),
+    (1, 5, 7, 8, 40, (3, 3), (1, 1), (1, 1)),
+]
+
+
+@pytest.mark.parametrize("cfg", CONVS)
+def test_conv2d_and_batch_stats(ops, cfg):
+    B, H, W, Cin, Cout, k, s, p = cfg
+    x = rnd(B, Cin, H, W, seed=11)
+    w = rnd(Cout, Cin, *k, seed=12, scale=(2.0 / (Cin * k[0] * k[1])) ** 0.5)
+    b = rnd(Cout, seed=13)
+    ref = F.conv2d(x, w, b, s, p)
+    xn = ops.nchw_to_nhwc(cu(x))
+    assert_close("nchw_to_nhwc", xn, x.permute(0, 2, 3, 1))
+    wp = ops.pack_conv_weight(cu(w))
+    y, stats = ops.conv2d_nhwc(xn, wp, cu(b), s, p, act=0, want_stats=True)
+    assert_close("conv", y.permute(0, 3, 1, 2), ref, atol=2e-5, rtol=1e-5)
+    yr, _ = ops.conv2d_nhwc(xn, wp, cu(b), s, p, act=1)
+    assert_close("conv+relu", yr.permute(0, 3, 1, 2), F.relu(ref), atol=2e-5, rtol=1e-5)
+    # BatchNorm (training): statistics from the conv epilogue, running-stat update, apply + residual + relu
+    gamma, beta = rnd(Cout, seed=14) + 1.5, rnd(Cout, seed=15)
+    rm, rv = rnd(Cout, seed=16) * 0.1, rnd(Cout, seed=17) * 0.2 + 1.0
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    res = rnd(*ref.shape, seed=18)
+    bn_ref = F.relu(F.batch_norm(ref, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5) + res)
+    rm_d, rv_d = cu(rm), cu(rv)
+    count = ref.shape[0] * ref.shape[2] * ref.shape[3]
+    scale, shift, mean, invstd = ops.bn_finalize(stats, Cout, count, cu(gamma), cu(beta), rm_d, rv_d, 0.1, 1e-5, save=True)
+    out = ops.scale_shift_act(y.clone(), scale, shift, relu=True, residual=cu(res.permute(0, 2, 3, 1).contiguous()))
+    assert_close("bn train apply", out.permute(0, 3, 1, 2), bn_ref, atol=5e-5, rtol=1e-5)
+    assert_close("running_mean", rm_d, rm_ref, atol=1e-6, rtol=1e-5)
+    assert_close("running_var", rv_d, rv_ref, atol=1e-6, rtol=1e-5)
+    assert_close("save_mean", mean, ref.mean((0, 2, 3)), atol=1e-6, rtol=1e-5)
+    # eval-mode BN
+    sc, sh = ops.bn_eval_affine(cu(gamma), cu(beta), cu(rm), cu(rv), 1e-5)
+    out = ops.scale_shift_act(y.clone(), sc, sh, relu=False)
+    assert_close("bn eval", out.permute(0, 3, 1, 2), F.batch_norm(ref, rm, rv, gamma, beta, False, 0.1, 1e-5), atol=5e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("k,s,p", [((2, 2), (2, 2), (0, 0)), ((2, 1), (2, 1), (0, 0)), ((2, 2), (2, 1), (0, 1))])
+def test_maxpool_and_avgpool(ops, k, s, p):
+    x = rnd(3, 16, 8, 33, seed=19)
+    xn = cu(x.permute(0, 2, 3, 1).contiguous())
+    y = ops.maxpool_nhwc(xn, k, s, p)
+    assert_close("maxpool", y.permute(0, 3, 1, 2), F.max_pool2d(x, k, s, p), atol=0, rtol=0)
+    sc, sh = rnd(16, seed=20), rnd(16, seed=21)
+    y = ops.maxpool_nhwc(xn, k, s, p, scale=cu(sc), shift=cu(sh), relu=True)
+    ref = F.max_pool2d(F.relu(x * sc[None, :, None, None] + sh[None, :, None, None]), k, s, p)
+    assert_close("fused affine+relu+maxpool", y.permute(0, 3, 1, 2), ref, atol=1e-6)
+    assert_close("avgpool", ops.avgpool_nhwc(xn), x.mean((2, 3)), atol=1e-6)
+
+
+def test_tps_grid_sample(ops):
+    from oracle.mrn_oracle import tps_constants
+    from mrn_amd.tools.weights import fiducial_bias
+    B, H, W = 3, 32, 256
+    img = rnd(B, 4, H, W, seed=22)
+    cp = torch.from_numpy(fiducial_bias(20)).view(1, 20, 2) + rnd(B, 20, 2, seed=23) * 0.15
+    inv, ph = tps_constants(20, (H, W))
+    cz = torch.cat([cp, torch.zeros(B, 3, 2)], 1)
+    grid = torch.bmm(ph.repeat(B, 1, 1), torch.bmm(inv.repeat(B, 1, 1), cz)).reshape(B, H, W, 2)
+    ref = F.grid_sample(img, grid, padding_mode="border", align_corners=True)
+    out, g = ops.tps_grid_sample(ops.nchw_to_nhwc(cu(img)), cu(cp), cu(inv), cu(ph), (H, W), want_grid=True)
+    assert_close("tps grid", g.view(B, H, W, 2), grid, atol=2e-5)
+    assert_close("tps sample", out.permute(0, 3, 1, 2), ref, atol=2e-4)   # bilinear weights amplify 1e-5 grid noise by W/2
+
+
+def test_bilstm_layer(ops):
+    from oracle.mrn_oracle import _lstm_dir
+    B, T, IN, Hd = 19, 13, 64, 256
+    x = rnd(B, T, IN, seed=24)
+    k = 1 / 16.0
+    P = {n: rnd(*s, seed=25 + i, scale=k) for i, (n, s) in enumerate(
+        [("wi", (4 * Hd, IN)), ("wh", (4 * Hd, Hd)), ("bi", (4 * Hd,)), ("bh", (4 * Hd,)),
+         ("wi_r", (4 * Hd, IN)), ("wh_r", (4 * Hd, Hd)), ("bi_r", (4 * Hd,)), ("bh_r", (4 * Hd,))])}
+    ref = torch.cat([_lstm_dir(x, P["wi"], P["wh"], P["bi"], P["bh"], False),
+                     _lstm_dir(x, P["wi_r"], P["wh_r"], P["bi_r"], P["bh_r"], True)], 2)
+    w_ih = cu(torch.cat([P["wi"], P["wi_r"]], 0))
+    xproj = ops.linear(cu(x), w_ih, cu(torch.cat([P["bi"], P["bi_r"]])))
+    out = ops.lstm_layer(xproj, cu(torch.stack([P["wh"], P["wh_r"]])), cu(torch.cat([P["bh"], P["bh_r"]])), Hd, 2)
+    assert_close("bilstm", out, ref, atol=2e-5)
+
+
+@pytest.mark.parametrize("is_train", [True, False])
+def test_attention_decoder(ops, is_train):
+    from oracle import mrn_oracle as O
+    from mrn_amd.modules.prediction import Attention
+    import torch.nn as nn
+    B, T, D, Hd, C = 21, 65, 256, 256, 97
+    fc = nn.Linear(Hd, C)
+    att = Attention(D, Hd, C, fc)
+    sd = {k: rnd(*v.shape, seed=40 + i, scale=0.08) for i, (k, v) in enumerate(att.state_dict().items())}
+    sd["char_embeddings.weight"] = rnd(C, 256, seed=77)
+    att.load_state_dict(sd)
+    Hb = rnd(B, T, D, seed=41)
+    text = torch.randint(0, C + 3, (B, 26), generator=torch.Generator().manual_seed(5))   # includes ids >= C (cut_unknown)
+    text[:, 0] = 2
+    tin = text if is_train else torch.LongTensor(B).fill_(2)
+    osd = {"P." + k: v for k, v in sd.items()}
+    ref = O.attention_forward(osd, "P.", Hb, tin, is_train, 25, sd["generator.weight"], sd["generator.bias"])
+    att = att.cuda()
+    with torch.no_grad():
+        out = att(cu(Hb), cu(tin), is_train, 25)
+    assert_close("attn decoder", out, ref, atol=1e-4)
+    assert np.array_equal(out.argmax(2).cpu().numpy(), ref.argmax(2).numpy())
+
+
+def test_rowops(ops):
+    R, C = 1000, 256
+    x = rnd(R, 2 * C, seed=50)
+    g, b = rnd(C, seed=51) + 1.2, rnd(C, seed=52)
+    xd = cu(x)
+    v = xd[:, C:]                                   # strided rows (chunk view)
+    y, mean, rstd = ops.layernorm_fwd(v, cu(g), cu(b))
+    xr = x[:, C:].clone().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (C,), gr, br)
+    assert_close("layernorm", y, ref, atol=1e-5)
+    dy = rnd(R, C, seed=53)
+    ref.backward(dy)
+    dx, dg, db = ops.layernorm_bwd(cu(dy), v, cu(g), mean, rstd)
+    assert_close("layernorm dx", dx, xr.grad, atol=1e-5)
+    assert_close("layernorm dgamma", dg, gr.grad, atol=1e-4, rtol=1e-5)
+    assert_close("layernorm dbeta", db, br.grad, atol=1e-4, rtol=1e-5)
+    # colnorm: LayerNorm over P of [B,P,W]
+    B, P, Wd = 5, 65, 768
+    x = rnd(B, P, Wd, seed=54)
+    g, b = rnd(P, seed=55) + 1.2, rnd(P, seed=56)
+    xr = x.clone().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.layer_norm(xr.permute(0, 2, 1), (P,), gr, br).permute(0, 2, 1)
+    y, mean, rstd = ops.colnorm_fwd(cu(x), cu(g), cu(b))
+    assert_close("colnorm", y, ref, atol=1e-5)
+    dy = rnd(B, P, Wd, seed=57)
+    ref.backward(dy)
+    dx, dg, db = ops.colnorm_bwd(cu(dy), cu(x), cu(g), mean, rstd)
+    assert_close("colnorm dx", dx, xr.grad, atol=1e-5)
+    assert_close("colnorm dgamma", dg, gr.grad, atol=1e-4, rtol=1e-5)
+    assert_close("colnorm dbeta", db, br.grad, atol=1e-4, rtol=1e-5)
+    # elementwise + colsum + gather + argmax
+    a, bb = rnd(300, 512, seed=58) * 3, rnd(300, 512, seed=59)
+    ar = a.clone().requires_grad_(True)
+    F.gelu(ar).backward(bb)
+    assert_close("gelu", ops.ew_rows(ops.EW_GELU, cu(a)), F.gelu(a), atol=1e-6)
+    assert_close("gelu bwd", ops.ew_rows(ops.EW_GELU_BWD, cu(a), cu(bb)), ar.grad, atol=1e-6)
+    assert_close("mul", ops.ew_rows(ops.EW_MUL, cu(a)[:, :256], cu(bb)[:, 256:]), a[:, :256] * bb[:, 256:], atol=0)
+    big = rnd(100000, 40, seed=60)
+    assert_close("colsum", ops.colsum(cu(big)), big.sum(0), atol=2e-3, rtol=1e-5)
+    m = rnd(30, 30, seed=61)
+    perm = torch.randperm(30, generator=torch.Generator().manual_seed(1)).int()
+    gat = ops.gather2d(cu(m), cu(perm), cu(perm), ld_out=32)
+    assert_close("gather2d", gat, m[perm.long()][:, perm.long()], atol=0)
+    lg = rnd(77, 5374, seed=62)
+    assert np.array_equal(ops.argmax_lastdim(cu(lg)).cpu().numpy(), lg.argmax(1).numpy())
+
+
+def test_fanin_gate_tail(ops):
+    from oracle import mrn_oracle as O
+    B, T = 9, 26
+    classes = (41, 71, 98)
+    logits = [rnd(B, T, c, seed=70 + i) for i, c in enumerate(classes)]
+    w = torch.softmax(rnd(B, 3, seed=73), 1).requires_grad_(True)
+    ref = O.fanin(logits, w)
+    dl = []
+    for l in logits:                      # padded-row device copies
+        d = ops.padded_rows(B, T, l.shape[2], "cuda")
+        d.copy_(l)
+        dl.append(d)
+    out = ops.fanin_fwd(dl, cu(w.detach()))
+    assert_close("fanin", out, ref, atol=1e-6)
+    dout = rnd(B, T, classes[-1], seed=74)
+    ref.backward(dout)
+    dd = ops.padded_rows(B, T, classes[-1], "cuda")
+    dd.copy_(dout)
+    assert_close("fanin dw", ops.fanin_bwd(dl, dd), w.grad, atol=1e-4, rtol=1e-5)
+    idx = torch.tensor([0, 1, 2, 2, 1, 0, 0, 2, 1])
+    assert_close("select_expert", ops.select_expert(dl, cu(idx)), O.select_expert(logits, idx), atol=0)
+    # gate tail
+    P, I = 65, 3
+    r = rnd(B, P, I, seed=75).requires_grad_(True)
+    Wr, br = (rnd(1, P, seed=76) * 0.3).requires_grad_(True), rnd(1, seed=77).requires_grad_(True)
+    s_ref = F.linear(r.permute(0, 2, 1).contiguous(), Wr, br).squeeze(-1)
+    w_ref = F.softmax(s_ref, -1)
+    s, wt = ops.gate_tail_fwd(cu(r.detach()), cu(Wr.detach().view(-1)), cu(br.detach()))
+    assert_close("gate w", wt, w_ref, atol=1e-6)
+    dw = rnd(B, I, seed=78)
+    w_ref.backward(dw)
+    dr, dW, db = ops.gate_tail_bwd(wt, cu(dw), cu(r.detach()), cu(Wr.detach().view(-1)))
+    assert_close("gate dr", dr, r.grad, atol=1e-6)
+    assert_close("gate dW", dW, Wr.grad.view(-1), atol=1e-5)
+    _, am = ops.gate_tail_fwd(cu(r.detach()), cu(Wr.detach().view(-1)), cu(br.detach()), hard=True)
+    assert np.array_equal(am.cpu().numpy(), s_ref.argmax(1).numpy())
+
+
+def test_ce_and_ctc_losses(ops):
+    B, S, C = 12, 26, 98
+    logits = (rnd(B, S, C, seed=80) * 4).requires_grad_(True)
+    target = torch.randint(0, C, (B, S), generator=torch.Generator().manual_seed(2))
+    target[:, 10:] = 1                                           # [PAD] -> ignored
+    ref = F.cross_entropy(logits.view(-1, C), target.view(-1), ignore_index=1)
+    (15 * ref).backward()
+    d = ops.padded_rows(B, S, C, "cuda")
+    d.copy_(logits.detach())
+    loss, ctx = ops.ce_loss_fwd(d, cu(target), ignore_index=1)
+    assert_close("ce loss", loss, ref.detach().view(1), atol=1e-5)
+    dl = ops.ce_loss_bwd(ctx, torch.tensor([15.0], device="cuda"), d)
+    assert_close("ce grad", dl, logits.grad, atol=1e-6, rtol=1e-4)
+    # CTC: varied lengths incl. repeats, empty target, and an infeasible one (len 25 with repeats can exceed T)
+    B, T, C = 7, 20, 40
+    logits = (rnd(B, T, C, seed=81) * 3).requires_grad_(True)
+    tl = torch.tensor([5, 1, 0, 12, 20, 3, 9], dtype=torch.int32)
+    targets = torch.randint(2, C, (B, 25), generator=torch.Generator().manual_seed(3))
+    targets[3, :12] = 7                                          # all repeats: needs 2*12-1 = 23 > T frames -> inf
+    targets[5, :3] = torch.tensor([4, 4, 9])
+    for b in range(B):
+        targets[b, tl[b]:] = 1
+    lp = logits.log_softmax(2).permute(1, 0, 2)
+    ref = F.ctc_loss(lp, targets, torch.IntTensor([T] * B), tl, blank=0, reduction="mean", zero_infinity=True)
+    (15 * ref).backward()
+    d = ops.padded_rows(B, T, C, "cuda")
+    d.copy_(logits.detach())
+    loss, ctx = ops.ctc_loss_fwd(d, cu(targets), cu(tl))
+    assert_close("ctc loss", loss, ref.detach().view(1), atol=1e-5, rtol=1e-5)
+    dl = ops.ctc_loss_bwd(ctx, torch.tensor([15.0], device="cuda"))
+    assert_close("ctc grad", dl, logits.grad, atol=2e-6, rtol=1e-4)
+
+
+def test_clip_and_adam(ops):
+    from oracle.mrn_oracle import clip_and_adam
+    n = 100003
+    p, g = rnd(n, seed=90), rnd(n, seed=91) * 0.1
+    pr, st = [p.clone()], [{"m": torch.zeros(n), "v": torch.zeros(n)}]
+    pd, gd = cu(p), cu(g)
+    md, vd = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    for step in (1, 2, 3):
+        gg = g * step
+        total = clip_and_adam(pr, [gg], st, 5e-4, step)
+        gd.copy_(gg)
+        nc = ops.grad_norm_clip(gd, 5.0)
+        ops.adam_step(pd, gd, md, vd, nc, 5e-4, step)
+        assert_close("grad norm", nc[0:1], total.view(1), atol=1e-4, rtol=1e-5)
+    assert_close("adam params", pd, pr[0], atol=1e-6, rtol=1e-5)
+    assert_close("adam m", md, st[0]["m"], atol=1e-7, rtol=1e-4)
