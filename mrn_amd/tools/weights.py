@@ -24,6 +24,24 @@ def randint(name, shape, lo, hi, seed=0):
     return np.minimum((lo + np.floor(u * (hi - lo))).astype(np.int64), hi - 1)
 
 
+def smooth_image(name, shape, seed=0, terms=6):
+    """[B,C,H,W] low-frequency field in [-1,1] (sum of a few cosines).  Parity inputs use this instead of white
+    noise because the TPS grid P_hat.(inv_delta_C.C') is ill-conditioned in fp32 (~1e-5 absolute in the grid, i.e.
+    ~2e-3 pixel): on white noise that alone moves the reference's own features by 6e-3 relative between two
+    summation orders, which says nothing about an implementation.  Text crops are smooth at that scale."""
+    B, C, H, W = shape
+    r = _rng(name, seed)
+    amp = r.random((B, C, terms)) + 0.2
+    fx = r.random((B, C, terms)) * 4.0
+    fy = r.random((B, C, terms)) * 1.5
+    ph = r.random((B, C, terms)) * 2 * np.pi
+    y = (np.arange(H) / H)[None, None, None, :, None]
+    x = (np.arange(W) / W)[None, None, None, None, :]
+    f = (amp[..., None, None] * np.cos(2 * np.pi * (fx[..., None, None] * x + fy[..., None, None] * y) + ph[..., None, None])).sum(2)
+    f = f / amp.sum(2)[..., None, None]
+    return f.astype(np.float32)
+
+
 def fiducial_bias(num_fid):
     """The RARE initial fiducial layout (top row y: 0..-1, bottom row y: 1..0), flattened [F*2]."""
     half = num_fid // 2

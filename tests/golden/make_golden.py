@@ -94,7 +94,7 @@ def run(kind, classes, B, seed):
     sd0 = net.state_dict()
     d["sd_keys"] = np.array(sorted(sd0.keys()))                      # pins the reference's state_dict layout
     d["sd_shapes"] = np.array([",".join(map(str, sd0[k].shape)) for k in sorted(sd0.keys())])
-    image = torch.from_numpy(W.uniform("input:image", (B, 4, 32, 256), -1, 1, seed))
+    image = torch.from_numpy(W.smooth_image("input:image", (B, 4, 32, 256), seed))
     nspecial = 4 if kind == "crnn" else 5
     words, chars = words_for(B, classes[-1] - nspecial, seed)
     conv = CTCLabelConverter(chars) if kind == "crnn" else AttnLabelConverter(chars)

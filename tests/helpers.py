@@ -53,7 +53,7 @@ def assert_close(name, a, b, atol=1e-4, rtol=1e-4):
 
 def det_inputs(kind, classes, B, seed):
     """Same synthetic batch the golden generator used (tests/golden/make_golden.py: run())."""
-    image = torch.from_numpy(W.uniform("input:image", (B, 4, 32, 256), -1, 1, seed))
+    image = torch.from_numpy(W.smooth_image("input:image", (B, 4, 32, 256), seed))
     nspecial = 4 if kind == "crnn" else 5
     nchar = classes[-1] - nspecial
     chars = "".join(chr(0x4E00 + i) for i in range(nchar))
