@@ -1,0 +1,252 @@
+"""Differentiable building blocks of the trainable (router) region, each a torch.autograd.Function whose forward
+and backward are HIP kernel launches (mrn_amd.ops).  torch.autograd only sequences them.
+
+Everything here works on the router-internal layout L2 = [B, P, I, C] ('b w h c'): expert i's contextual
+features are written straight into slice [:, :, i, :], the reference's three rearranges
+(modules/dm_router.py:58,61,63,65 and modules/model.py:402) disappear, and the only token-order dependence --
+the spatial-gating weight over the (domain, patch) axis -- is absorbed by permuting that small weight.
+"""
+import torch
+
+from . import ops
+
+
+# ---------------------------------------------------------------------------------------------------------
+# GEMM helpers for backward passes
+# ---------------------------------------------------------------------------------------------------------
+def linear_dgrad(dy, weight, out=None, accumulate=False):
+    """dx = dy @ weight ; dy rows [R, N], weight [N, K] -> [R, K]"""
+    dy2 = ops.rows2d(dy)
+    R, N = dy2.shape
+    K = weight.shape[1]
+    if out is None:
+        out = torch.empty(R, K, device=dy.device, dtype=torch.float32)
+        accumulate = False
+    o2 = ops.rows2d(out)
+    # C[r][k] = sum_n dy[r][n] * W[n][k]  ->  "W operand"[k][n] = weight[n][k]
+    ops.gemm_raw(dy2, weight, o2, R, K, N, 1, (0, dy2.stride(0), 1), (0, 1, weight.stride(0)), (0, o2.stride(0), 1),
+                 accumulate=accumulate)
+    return out
+
+
+def _pick_split(R, tiles, target=1024, min_rows=128):
+    want = max(1, min(target // max(tiles, 1), R // min_rows))
+    for s in range(want, 0, -1):
+        if R % s == 0:
+            return s
+    return 1
+
+
+def linear_wgrad(dy, x):
+    """dW[n][k] = sum_r dy[r][n] * x[r][k] with split-K over r (partials reduced by a column-sum pass)."""
+    dy2, x2 = ops.rows2d(dy), ops.rows2d(x)
+    R, N = dy2.shape
+    K = x2.shape[1]
+    tiles = ((N + 127) // 128) * ((K + 127) // 128)
+    S = _pick_split(R, tiles)
+    Rc = R // S
+    part = torch.empty(S, N, K, device=dy.device, dtype=torch.float32)
+    ops.gemm_raw(dy2, x2, part, N, K, Rc, S, (Rc * dy2.stride(0), 1, dy2.stride(0)), (Rc * x2.stride(0), 1, x2.stride(0)),
+                 (N * K, K, 1))
+    if S == 1:
+        return part[0]
+    return ops.colsum(part.view(S, N * K)).view(N, K)
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b over (strided) rows."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return ops.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = linear_dgrad(dy, weight).view(x.shape) if ctx.needs_input_grad[0] else None
+        dw = linear_wgrad(dy, x) if ctx.needs_input_grad[1] else None
+        db = ops.colsum(dy) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+# ---------------------------------------------------------------------------------------------------------
+# DM-Router block in L2 layout
+# ---------------------------------------------------------------------------------------------------------
+def token_permutation(P, I, device):
+    """perm[p*I + d] = d*P + p : L2 token position -> reference '(d p)' token index; and its inverse."""
+    idx = torch.arange(P * I, device=device, dtype=torch.int32)
+    perm = (idx % I) * P + idx // I
+    inv = torch.empty_like(perm)
+    inv[perm.long()] = idx
+    return perm, inv
+
+
+class DMRouterFn(torch.autograd.Function):
+    """DM_Router.forward (reference modules/dm_router.py:50-67) on x [B,P,I,C]; returns the same layout."""
+
+    @staticmethod
+    def forward(ctx, x, n_w, n_b, w1, b1, sn_w, sn_b, wsp, bsp, w2, b2, cn_w, cn_b, wch, bch, w3, b3):
+        B, P, I, C = x.shape
+        R, N = B * P * I, P * I
+        x = x.contiguous()
+        X = x.view(R, C)
+        xn, mu1, rs1 = ops.layernorm_fwd(X, n_w, n_b)
+        hpre = ops.linear(xn, w1, b1)
+        h = ops.ew_rows(ops.EW_GELU, hpre)
+        u, v = h[:, :C], h[:, C:]
+        vn, mu2, rs2 = ops.layernorm_fwd(v, sn_w, sn_b)
+        perm, inv = token_permutation(P, I, x.device)
+        ldw = (N + 3) // 4 * 4
+        wsp_p = ops.gather2d(wsp, perm, perm, ld_out=ldw)                    # [N, N] view, row stride ldw
+        bsp_p = ops.gather2d(bsp.view(1, N), None, perm).view(N)
+        vp = torch.empty(R, C, device=x.device, dtype=torch.float32)
+        # vp[b] = Wsp' . vn[b] + bsp'[:, None]
+        ops.gemm_raw(wsp_p, vn, vp, N, C, N, B, (0, ldw, 1), (N * C, 1, C), (N * C, C, 1), bias=bsp_p, bias_axis=1)
+        g = ops.ew_rows(ops.EW_MUL, u, vp)
+        y = ops.linear(g, w2, b2, residual=X)
+        y3 = y.view(B, P, I * C)
+        zn, mu3, rs3 = ops.colnorm_fwd(y3, cn_w, cn_b)
+        zp = ops.linear(zn.view(B * P, I * C), wch, bch).view(R, C)
+        z2 = ops.ew_rows(ops.EW_MUL, y, zp)
+        out = ops.linear(z2, w3, b3, residual=X)
+        ctx.save_for_backward(X, n_w, w1, sn_w, w2, cn_w, wch, w3, mu1, rs1, xn, hpre, h, mu2, rs2, vn, wsp_p, vp, g, y,
+                              mu3, rs3, zn, zp, z2, inv)
+        ctx.dims = (B, P, I, C, ldw)
+        return out.view(B, P, I, C)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (X, n_w, w1, sn_w, w2, cn_w, wch, w3, mu1, rs1, xn, hpre, h, mu2, rs2, vn, wsp_p, vp, g, y, mu3, rs3, zn, zp, z2,
+         inv) = ctx.saved_tensors
+        B, P, I, C, ldw = ctx.dims
+        R, N = B * P * I, P * I
+        need_x = ctx.needs_input_grad[0]
+        dout = dout.contiguous().view(R, C)
+        dev = dout.device
+        # out = z2 W3^T + b3 + X
+        dw3, db3 = linear_wgrad(dout, z2), ops.colsum(dout)
+        dz2 = linear_dgrad(dout, w3)
+        # z2 = y * zp
+        dy = ops.ew_rows(ops.EW_MUL, dz2, zp)
+        dzp = ops.ew_rows(ops.EW_MUL, dz2, y)
+        # zp = zn Wch^T + bch over rows [B*P, I*C]
+        dzp2, zn2 = dzp.view(B * P, I * C), zn.view(B * P, I * C)
+        dwch, dbch = linear_wgrad(dzp2, zn2), ops.colsum(dzp2)
+        dzn = linear_dgrad(dzp2, wch)
+        # zn = LayerNorm_P(y)
+        _, dcn_w, dcn_b = ops.colnorm_bwd(dzn.view(B, P, I * C), y.view(B, P, I * C), cn_w, mu3, rs3,
+                                          dx=dy.view(B, P, I * C), accumulate=True)
+        # y = g W2^T + b2 + X
+        dw2, db2 = linear_wgrad(dy, g), ops.colsum(dy)
+        dg = linear_dgrad(dy, w2)
+        # g = u * vp
+        u, v = h[:, :C], h[:, C:]
+        dh = torch.empty(R, 2 * C, device=dev, dtype=torch.float32)
+        ops.ew_rows(ops.EW_MUL, dg, vp, out=dh[:, :C])                      # du
+        dvp = ops.ew_rows(ops.EW_MUL, dg, u)
+        # vp[b] = Wsp' vn[b] + bsp'
+        part = torch.empty(B, N, N, device=dev, dtype=torch.float32)
+        ops.gemm_raw(dvp, vn, part, N, N, C, B, (N * C, C, 1), (N * C, C, 1), (N * N, N, 1))
+        dwsp_p = ops.colsum(part.view(B, N * N)).view(N, N) if B > 1 else part[0]
+        dwsp = ops.gather2d(dwsp_p, inv, inv)
+        ones = torch.ones(1, C, device=dev, dtype=torch.float32)
+        rowsum = ops.linear(dvp, ones)                                        # [R,1] = sum_c dvp
+        dbsp_p = ops.colsum(rowsum.view(B, N)) if B > 1 else rowsum.view(N)
+        dbsp = ops.gather2d(dbsp_p.view(1, N), None, inv).view(N)
+        dvn = torch.empty(R, C, device=dev, dtype=torch.float32)
+        # dvn[b] = Wsp'^T dvp[b]
+        ops.gemm_raw(wsp_p, dvp, dvn, N, C, N, B, (0, 1, ldw), (N * C, 1, C), (N * C, C, 1))
+        # vn = LayerNorm(v)
+        _, dsn_w, dsn_b = ops.layernorm_bwd(dvn, v, sn_w, mu2, rs2, dx=dh[:, C:])
+        # h = gelu(hpre)
+        dhpre = ops.ew_rows(ops.EW_GELU_BWD, hpre, dh)
+        dw1, db1 = linear_wgrad(dhpre, xn), ops.colsum(dhpre)
+        dxn = linear_dgrad(dhpre, w1)
+        # xn = LayerNorm(X)
+        dx_ln, dn_w, dn_b = ops.layernorm_bwd(dxn, X, n_w, mu1, rs1)
+        dx = None
+        if need_x:
+            dx = ops.ew_rows(ops.EW_ADD, dx_ln, dout)
+            dx = ops.ew_rows(ops.EW_ADD, dx, dy, out=dx).view(B, P, I, C)
+        return (dx, dn_w, dn_b, dw1, db1, dsn_w, dsn_b, dwsp, dbsp, dw2, db2, dcn_w, dcn_b, dwch, dbch, dw3, db3)
+
+
+class GateTailFn(torch.autograd.Function):
+    """route Linear(P->1) over the patch axis + squeeze + softmax(beta * s)  (modules/model.py:405-406,495-496)"""
+
+    @staticmethod
+    def forward(ctx, r, w_route, b_route, beta):
+        r = r.contiguous()
+        _, w = ops.gate_tail_fwd(r, w_route.view(-1), b_route, beta)
+        ctx.save_for_backward(r, w_route, w)
+        ctx.beta = beta
+        return w
+
+    @staticmethod
+    def backward(ctx, dw):
+        r, w_route, w = ctx.saved_tensors
+        dr, dW, db = ops.gate_tail_bwd(w, dw, r, w_route.view(-1), ctx.beta)
+        return dr, dW.view_as(w_route), db, None
+
+
+class FaninFn(torch.autograd.Function):
+    """out = sum_i w[:, i] * pad_ones(L_i)   (modules/model.py:410-423); experts' logits carry no gradient here."""
+
+    @staticmethod
+    def forward(ctx, w, *logits):
+        ctx.logits = logits
+        ctx.save_for_backward(w)
+        return ops.fanin_fwd(list(logits), w.contiguous())
+
+    @staticmethod
+    def backward(ctx, dout):
+        if any(ctx.needs_input_grad[1:]):
+            raise NotImplementedError("gradient of the fan-in with respect to expert logits is not implemented "
+                                      "(experts are frozen in MRN's router phase)")
+        if dout.stride(2) != 1 or dout.stride(1) % 4 != 0 or dout.stride(0) != dout.shape[1] * dout.stride(1):
+            d = ops.padded_rows(*dout.shape, dout.device)
+            d.copy_(dout)
+            dout = d
+        dw = ops.fanin_bwd(list(ctx.logits), dout)
+        return (dw,) + (None,) * len(ctx.logits)
+
+
+class CrossEntropyFn(torch.autograd.Function):
+    """torch.nn.CrossEntropyLoss(reduction='mean', ignore_index=...) on (strided) rows of logits."""
+
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index):
+        loss, c = ops.ce_loss_fwd(logits, target, ignore_index)
+        ctx.c = c
+        ctx.like = logits
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        d = ops.ce_loss_bwd(ctx.c, g.contiguous().view(1), ctx.like)
+        return d, None, None
+
+
+class CTCLossFn(torch.autograd.Function):
+    """preds.log_softmax(2).permute(1,0,2) -> CTCLoss(blank=0, mean, zero_infinity=True) with input lengths = T."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, target_len):
+        loss, c = ops.ctc_loss_fwd(logits, targets, target_len, 0)
+        ctx.c = c
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.ctc_loss_bwd(ctx.c, g.contiguous().view(1)), None, None
+
+
+def cross_entropy(logits, target, ignore_index=-100):
+    return CrossEntropyFn.apply(logits, target, ignore_index)
+
+
+def ctc_loss(logits, targets, target_len):
+    return CTCLossFn.apply(logits, targets, target_len)

@@ -1,0 +1,236 @@
+"""Model containers with the reference's four-stage operator API (modules/model.py): Model_Extractor (:17-101),
+Model (:105-199), MRNNet (:314-496).  Same constructor arguments (`opt`), attribute names, forward signatures,
+return conventions and state_dict keys; the math runs on the HIP path.
+
+MI355X-first differences that do not change results:
+  * experts write their contextual features straight into one [B, P, I, C] buffer and their logits into
+    16-byte-aligned padded rows, so torch.stack / pad-with-ones / permute / contiguous / sum of
+    MRNNet.cross_forward (:399-423) collapse into the DM-Router kernels plus one fan-in pass;
+  * the input image is converted to NHWC once and shared by all experts.
+"""
+import copy
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..functional import FaninFn, GateTailFn, LinearFn
+from ._nn import to_nhwc
+from .dm_router import DM_Router
+from .feature_extraction import ResNet_FeatureExtractor, VGG_FeatureExtractor
+from .prediction import Attention
+from .sequence_modeling import BidirectionalLSTM
+from .transformation import TPS_SpatialTransformerNetwork
+
+
+class Model_Extractor(nn.Module):
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        self.stages = {"Trans": opt.Transformation, "Feat": opt.FeatureExtraction, "Seq": opt.SequenceModeling,
+                       "Pred": opt.Prediction}
+        if opt.Transformation == "TPS":
+            self.Transformation = TPS_SpatialTransformerNetwork(
+                F=opt.num_fiducial, I_size=(opt.imgH, opt.imgW), I_r_size=(opt.imgH, opt.imgW),
+                I_channel_num=opt.input_channel)
+        else:
+            print("No Transformation module specified")
+        if opt.FeatureExtraction == "VGG":
+            self.FeatureExtraction = VGG_FeatureExtractor(opt.input_channel, opt.output_channel)
+        elif opt.FeatureExtraction == "ResNet":
+            self.FeatureExtraction = ResNet_FeatureExtractor(opt.input_channel, opt.output_channel)
+        elif opt.FeatureExtraction == "SVTR":
+            from .svtr import SVTR_FeatureExtractor
+            self.FeatureExtraction = SVTR_FeatureExtractor(opt.input_channel, opt.output_channel)
+        else:
+            raise Exception("No FeatureExtraction module specified")
+        self.FeatureExtraction_output = opt.output_channel
+        self.AdaptiveAvgPool = nn.AdaptiveAvgPool2d((None, 1))
+        if opt.SequenceModeling == "BiLSTM":
+            self.SequenceModeling = nn.Sequential(
+                BidirectionalLSTM(self.FeatureExtraction_output, opt.hidden_size, opt.hidden_size),
+                BidirectionalLSTM(opt.hidden_size, opt.hidden_size, opt.hidden_size))
+        else:
+            self.SequenceModeling = nn.Sequential(nn.Linear(self.FeatureExtraction_output, opt.hidden_size))
+            print("No SequenceModeling module specified")
+        self.SequenceModeling_output = opt.hidden_size
+
+    def forward(self, image, out=None):
+        """image [B,C,H,W] -> contextual feature [B,T,hidden]; `out` = optional (strided) destination."""
+        if not self.stages["Trans"] == "None":
+            image = self.Transformation(image)
+        fmap = self.FeatureExtraction(image)                 # logical [B,C,H,W], NHWC memory
+        B, C, H, W = fmap.shape
+        if H != 1:
+            raise NotImplementedError("HIP path expects a height-1 feature map (32x256 inputs); got H=%d" % H)
+        # permute(0,3,1,2) + AdaptiveAvgPool((None,1)) + squeeze(3) of the reference is the identity on [B,1,W,C]
+        visual = to_nhwc(fmap).view(B, W, C)
+        if self.stages["Seq"] == "BiLSTM":
+            x = self.SequenceModeling[0](visual)
+            return self.SequenceModeling[1](x, out=out)
+        lin = self.SequenceModeling[0]
+        return ops.linear(visual, lin.weight, lin.bias, out=out)
+
+
+class Model(nn.Module):
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        self.model = Model_Extractor(opt)
+        self.SequenceModeling_output = self.model.SequenceModeling_output
+        self.stages = {"Pred": opt.Prediction}
+        self.fc = None
+        self.Prediction = None
+
+    def reset_class(self, opt, device):
+        if opt.Prediction == "CTC":
+            self.Prediction = nn.Linear(self.SequenceModeling_output, opt.num_class)
+        elif opt.Prediction == "Attn":
+            self.Prediction = Attention(self.SequenceModeling_output, opt.hidden_size, opt.num_class,
+                                        nn.Linear(opt.hidden_size, opt.num_class))
+        else:
+            raise Exception("Prediction is neither CTC or Attn")
+        self.Prediction.to(device)
+
+    def forward(self, image, text=None, is_train=True, feature_out=None, predict_out=None):
+        feat = self.model(image, out=feature_out)
+        if self.stages["Pred"] == "CTC":
+            pred = ops.linear(feat, self.Prediction.weight, self.Prediction.bias, out=predict_out)
+        else:
+            pred = self.Prediction(feat, text, is_train, batch_max_length=self.opt.batch_max_length, out=predict_out)
+        return {"predict": pred, "feature": feat}
+
+    def update_fc(self, hidden_size, nb_classes, device=None):
+        fc = nn.Linear(hidden_size, nb_classes)
+        if self.fc is not None:
+            nb_output = self.fc.out_features
+            fc = fc.to(self.fc.weight.device)
+            fc.weight.data[:nb_output] = self.fc.weight.data
+            fc.bias.data[:nb_output] = self.fc.bias.data
+        self.fc = fc
+
+    def new_fc(self, hidden_size, nb_classes):
+        self.fc = nn.Linear(hidden_size, nb_classes)
+
+    def weight_align(self, increment):
+        weights = self.fc.weight.data
+        newnorm = torch.norm(weights[-increment:, :], p=2, dim=1)
+        oldnorm = torch.norm(weights[:-increment, :], p=2, dim=1)
+        gamma = torch.mean(oldnorm) / torch.mean(newnorm)
+        print("alignweights,gamma=", gamma)
+        self.fc.weight.data[-increment:, :] *= gamma
+
+    def build_prediction(self, opt, num_class):
+        if opt.Prediction == "CTC":
+            self.Prediction = self.fc
+        elif opt.Prediction == "Attn":
+            self.Prediction = Attention(self.SequenceModeling_output, opt.hidden_size, num_class, self.fc)
+        else:
+            raise Exception("Prediction is neither CTC or Attn")
+
+    def copy(self):
+        return copy.deepcopy(self)
+
+    def freeze(self):
+        for p in self.parameters():
+            p.requires_grad = False
+        self.eval()
+        return self
+
+
+class MRNNet(nn.Module):
+    def __init__(self, opt):
+        super().__init__()
+        self.model = nn.ModuleList()
+        self.out_dim = None
+        self.fc = None
+        self.opt = opt
+        self.task_sizes = []
+        self.patch = {"VGG": 63, "SVTR": 64, "ResNet": 65}[opt.FeatureExtraction]
+        self.router = "dm-router"
+        self.layer_num = 1
+        self.beta = 1
+
+    @property
+    def feature_dim(self):
+        return 0 if self.out_dim is None else self.out_dim * len(self.model)
+
+    def forward(self, image, cross=True, text=None, is_train=True):
+        if cross == False:  # noqa: E712  (learners pass cross positionally, exactly as in the reference)
+            features, index = self.model[-1](image, text, is_train)["predict"], None
+        elif is_train == False:  # noqa: E712
+            features, index = self.cross_forward_expert(image, text, is_train)
+        else:
+            features, index = self.cross_forward(image, text, is_train)
+        return {"logits": features, "index": index, "aux_logits": None}
+
+    # -- shared by both routed paths -------------------------------------------------------------------
+    def _experts_and_gate(self, image, text, is_train):
+        I = len(self.model)
+        B = image.shape[0]
+        dev = image.device
+        image = to_nhwc(image).permute(0, 3, 1, 2)          # one NHWC conversion shared by all experts
+        T_pred = self.patch if self.opt.Prediction == "CTC" else self.opt.batch_max_length + 1
+        feats = torch.empty(B, self.patch, I, self.out_dim, device=dev, dtype=torch.float32)
+        logits = []
+        with torch.no_grad():
+            for i, expert in enumerate(self.model):
+                lg = ops.padded_rows(B, T_pred, expert.fc.out_features, dev)
+                expert(image, text, is_train, feature_out=feats[:, :, i, :], predict_out=lg)
+                logits.append(lg)
+        r = self.dm_router[0].forward_l2(feats)               # [B,P,I,C]
+        r = LinearFn.apply(r.view(B * self.patch, I * self.out_dim), self.channel_route.weight, self.channel_route.bias)
+        return logits, r.view(B, self.patch, I)
+
+    def cross_forward(self, image, text=None, is_train=True):
+        for expert in self.model:
+            if torch.is_grad_enabled() and any(p.requires_grad for p in expert.parameters()):
+                raise NotImplementedError("cross_forward trains the router over FROZEN experts (il_modules/mrn.py:154-157,"
+                                          "285-286); unfreeze is not supported on the HIP path")
+        logits, r = self._experts_and_gate(image, text, is_train)
+        w = GateTailFn.apply(r, self.route.weight, self.route.bias, float(self.beta))
+        return FaninFn.apply(w, *logits), w
+
+    def cross_forward_expert(self, image, text=None, is_train=True):
+        with torch.no_grad():
+            logits, r = self._experts_and_gate(image, text, is_train)
+            _, index = ops.gate_tail_fwd(r.contiguous(), self.route.weight.view(-1), self.route.bias, float(self.beta), hard=True)
+            return ops.select_expert(logits, index), index
+
+    def build_fc(self, hidden_size, nb_classes):
+        self.update_fc(hidden_size, nb_classes)
+
+    def update_fc(self, hidden_size, nb_classes):
+        dev = next(self.parameters()).device if len(self.model) else None
+        self.model.append(Model(self.opt))
+        self.model[-1].new_fc(hidden_size, nb_classes)
+        if self.out_dim is None:
+            self.out_dim = self.model[-1].SequenceModeling_output
+        # the whole router is re-created for the new expert count (reference :437-452)
+        self.route = nn.Linear(self.patch, 1)
+        self.channel_route = nn.Linear(self.feature_dim, len(self.model))
+        block = DM_Router(self.out_dim, self.out_dim * 2, self.patch, len(self.model))
+        print("mlp {} has {} layers".format(block, self.layer_num))
+        self.dm_router = nn.Sequential(*[block for _ in range(self.layer_num)])
+        if dev is not None:
+            self.to(dev)
+
+    def build_prediction(self, opt, num_class):
+        if opt.Prediction == "CTC" or opt.Prediction == "Attn":
+            self.model[-1].build_prediction(opt, num_class)
+            if len(self.model) > 1:
+                self.model[-1].to(next(self.model[0].parameters()).device)
+        else:
+            raise Exception("Prediction is neither CTC or Attn")
+
+    def copy(self):
+        return copy.deepcopy(self)
+
+    def freeze(self):
+        for p in self.parameters():
+            p.requires_grad = False
+        self.eval()
+        return self
+
+    def softargmax1d(self, input, beta=5):
+        raise NotImplementedError("fused into mrn_gate_tail_fwd_f32 (softmax(beta * route(x)))")

@@ -1,0 +1,92 @@
+"""Label converters and the loss averager (reference tools/utils.py:10-166) -- the integer label path.
+Same class names, constructor arguments, dict layouts and return types; tensors go to the current device."""
+import torch
+
+device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+
+
+class CTCLabelConverter(object):
+    """index 0 = CTC blank; then [PAD]=1, [UNK]=2, ' '=3, then the characters in order."""
+
+    def __init__(self, character):
+        tokens = ["[PAD]", "[UNK]", " "] + list(character)
+        self.dict = {}
+        for pos, ch in enumerate(tokens, start=1):      # a repeated character keeps its LAST index
+            self.dict[ch] = pos
+        self.character = ["[CTCblank]"] + tokens
+        print(f"# characters dict has: {len(self.character)}")
+
+    def encode(self, word_string, batch_max_length=25):
+        lengths = [len(w) for w in word_string]
+        pad, unk = self.dict["[PAD]"], self.dict["[UNK]"]
+        index = torch.full((len(word_string), batch_max_length), pad, dtype=torch.long)
+        for row, word in enumerate(word_string):
+            if word:
+                index[row, :len(word)] = torch.tensor([self.dict.get(ch, unk) for ch in word], dtype=torch.long)
+        return index.to(device), torch.IntTensor(lengths).to(device)
+
+    def decode(self, word_index, word_length):
+        """greedy CTC collapse: drop blanks (0) and merge repeats"""
+        texts = []
+        for row, n in zip(word_index, word_length):
+            prev, chars = None, []
+            for k in list(row[:int(n)]):
+                k = int(k)
+                if k != 0 and k != prev:
+                    chars.append(self.character[k])
+                prev = k
+            texts.append("".join(chars))
+        return texts
+
+
+class AttnLabelConverter(object):
+    """[UNK]=0 [PAD]=1 [SOS]=2 [EOS]=3 ' '=4, then the characters."""
+
+    def __init__(self, character):
+        self.character = ["[UNK]", "[PAD]", "[SOS]", "[EOS]", " "] + list(character)
+        self.dict = {}
+        for pos, ch in enumerate(self.character):
+            self.dict[ch] = pos
+        print(f"# of tokens and characters: {len(self.character)}")
+
+    def encode(self, word_string, batch_max_length=25):
+        lengths = [len(w) + 1 for w in word_string]          # + [EOS]
+        width = batch_max_length + 2                         # [SOS] + text + [EOS]
+        index = torch.full((len(word_string), width), self.dict["[PAD]"], dtype=torch.long)
+        index[:, 0] = self.dict["[SOS]"]
+        unk, eos = self.dict["[UNK]"], self.dict["[EOS]"]
+        for row, word in enumerate(word_string):
+            ids = [self.dict.get(ch, unk) for ch in word] + [eos]
+            index[row, 1:1 + len(ids)] = torch.tensor(ids, dtype=torch.long)
+        return index.to(device), torch.IntTensor(lengths).to(device)
+
+    def decode(self, word_index, word_length):
+        return ["".join(self.character[int(k)] for k in row[:int(n)]) for row, n in zip(word_index, word_length)]
+
+
+class Averager(object):
+    """running mean of loss tensors"""
+
+    def __init__(self):
+        self.reset()
+
+    def add(self, v):
+        self.n_count += v.data.numel()
+        self.sum += v.data.sum()
+
+    def reset(self):
+        self.n_count = 0
+        self.sum = 0
+
+    def val(self):
+        return self.sum / float(self.n_count) if self.n_count != 0 else 0
+
+
+def adjust_learning_rate(optimizer, iteration, opt):
+    """stepwise decay used when opt.schedule is a list of milestones (fractions of num_iter)"""
+    lr = opt.lr
+    for milestone in opt.schedule:
+        if iteration >= float(milestone) * opt.num_iter:
+            lr *= opt.lr_drop_rate
+    for group in optimizer.param_groups:
+        group["lr"] = lr

@@ -1,0 +1,157 @@
+"""Model-level parity on the GPU: the HIP-backed containers (mrn_amd.modules.model) against
+ (a) golden vectors produced by the reference itself and (b) the CPU oracle on the same inputs.
+Tolerance 1e-4 on features / logits / losses (north star); integer outputs (argmax, routing index, CTC strings)
+bit-exact."""
+import contextlib
+import io
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import assert_close, assert_sub_close, det_inputs, golden_state_dict, load_golden
+
+pytestmark = pytest.mark.gpu
+
+CASES = {"crnn_mrn3": ("crnn", (40, 70, 97), 2, 1), "trba_mrn3": ("trba", (41, 71, 98), 2, 2)}
+
+
+def make_opt(kind):
+    o = types.SimpleNamespace(num_fiducial=20, imgH=32, imgW=256, input_channel=4, output_channel=512, hidden_size=256,
+                              batch_max_length=25)
+    if kind == "crnn":
+        o.Transformation, o.FeatureExtraction, o.SequenceModeling, o.Prediction = "None", "VGG", "BiLSTM", "CTC"
+    else:
+        o.Transformation, o.FeatureExtraction, o.SequenceModeling, o.Prediction = "TPS", "ResNet", "BiLSTM", "Attn"
+    return o
+
+
+def build_net(kind, classes, g, seed):
+    from mrn_amd.modules.model import MRNNet
+    opt = make_opt(kind)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = MRNNet(opt)
+        for c in classes:
+            net.update_fc(opt.hidden_size, c)
+            net.build_prediction(opt, c)
+    net.load_state_dict(golden_state_dict(g, seed), strict=True)
+    return opt, net.cuda()
+
+
+def reload(net, g, seed):
+    net.load_state_dict(golden_state_dict(g, seed), strict=True)
+
+
+def labels_for(kind, words, chars):
+    from mrn_amd.tools.utils import AttnLabelConverter, CTCLabelConverter
+    with contextlib.redirect_stdout(io.StringIO()):
+        conv = CTCLabelConverter(chars) if kind == "crnn" else AttnLabelConverter(chars)
+    idx, ln = conv.encode(words, batch_max_length=25)
+    return conv, idx, ln
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_expert_forward_vs_golden(name):
+    kind, classes, B, seed = CASES[name]
+    g = load_golden(name)
+    opt, net = build_net(kind, classes, g, seed)
+    image, words, chars, _ = det_inputs(kind, classes, B, seed)
+    conv, labels_index, labels_length = labels_for(kind, words, chars)
+    assert np.array_equal(labels_index.cpu().numpy(), g["labels_index"])
+    image = image.cuda()
+    text = None if kind == "crnn" else labels_index[:, :-1].cuda()
+    m0 = net.model[0]
+    with torch.no_grad():
+        net.train()
+        if kind == "trba":
+            out, cp, _ = m0.model.Transformation(image, return_aux=True)
+            assert_close("cprime", cp, g["e0/tps_cprime"], atol=2e-5)
+            assert_sub_close(g, "e0/tps_out", out, atol=5e-4)      # fp32 conditioning of the TPS grid, see weights.smooth_image
+            reload(net, g, seed)
+        o = m0(image, text, True)
+        assert_sub_close(g, "e0/feature", o["feature"], atol=1e-4)
+        assert_sub_close(g, "e0/predict", o["predict"], atol=1e-4)
+        # BatchNorm running statistics moved exactly like the reference's
+        sd = net.state_dict()
+        rm = [v for k, v in sd.items() if k.startswith("model.0.") and k.endswith("running_mean")
+              and tuple(v.shape) == g["e0/bn_running_mean_after"].shape]
+        assert any(np.abs(r.cpu().numpy() - g["e0/bn_running_mean_after"]).max() < 1e-5 for r in rm)
+        reload(net, g, seed)
+        net.eval()
+        sos = None if kind == "crnn" else torch.LongTensor(B).fill_(2).cuda()
+        o = m0(image, sos, False)
+        assert_sub_close(g, "e0_eval/feature", o["feature"], atol=1e-4)
+        assert_sub_close(g, "e0_eval/predict", o["predict"], atol=1e-4)
+        assert np.array_equal(o["predict"].max(2)[1].cpu().numpy(), g["e0_eval/argmax"])
+        oe = net(image, True, sos, False)
+        assert np.array_equal(oe["index"].cpu().numpy(), g["eval/index"])
+        assert_sub_close(g, "eval/logits", oe["logits"], atol=1e-4)
+        am = oe["logits"].max(2)[1].cpu().numpy()
+        assert np.array_equal(am, g["eval/argmax"])
+        if kind == "crnn":
+            assert conv.decode(am, [am.shape[1]] * B) == [str(s) for s in g["eval/ctc_strings"]]
+        # loop A forward + loss
+        reload(net, g, seed)
+        net.train()
+        from mrn_amd import functional as Fn
+        if kind == "crnn":
+            preds = net(image, False)["logits"]
+            loss = Fn.ctc_loss(preds.contiguous(), labels_index.cuda(), labels_length.cuda())
+        else:
+            preds = net(image, False, labels_index[:, :-1].cuda())["logits"]
+            loss = Fn.cross_entropy(preds, labels_index[:, 1:].cuda(), 1)
+        assert_sub_close(g, "stepA/logits", preds, atol=1e-4)
+        assert abs(loss.item() - float(g["stepA/loss"])) < 1e-4 * max(1.0, abs(float(g["stepA/loss"])))
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_loop_b_two_steps_vs_golden(name):
+    """il_modules/mrn.py:323-371 -- weights, fused logits, losses, clipped gradients, 2-step Adam deltas"""
+    from mrn_amd import functional as Fn
+    from mrn_amd.optim import FlatAdam, OneCycle
+    kind, classes, B, seed = CASES[name]
+    g = load_golden(name)
+    opt, net = build_net(kind, classes, g, seed)
+    image, words, chars, domain = det_inputs(kind, classes, B, seed)
+    conv, labels_index, labels_length = labels_for(kind, words, chars)
+    image, domain, labels_index, labels_length = image.cuda(), domain.cuda(), labels_index.cuda(), labels_length.cuda()
+    net.train()
+    for i in range(len(classes)):
+        for p in net.model[i].parameters():
+            p.requires_grad = False
+    names = [n for n, p in net.named_parameters() if p.requires_grad]
+    assert names == [str(n) for n in g["router_param_names"]]
+    params = [p for p in net.parameters() if p.requires_grad]
+    before = [p.detach().clone() for p in params]
+    adam = FlatAdam(params, lr=0.0005)
+    sched = OneCycle(0.0005, 40)
+    for it in range(2):
+        if kind == "crnn":
+            out = net(image, True)
+            clf = Fn.ctc_loss(out["logits"], labels_index, labels_length)
+        else:
+            out = net(image, cross=True, text=labels_index[:, :-1], is_train=True)
+            clf = Fn.cross_entropy(out["logits"], labels_index[:, 1:], 1)
+        taski = Fn.cross_entropy(out["index"], domain, -100)
+        loss = 15 * clf + taski
+        adam.zero_grad()
+        loss.backward()
+        nc = adam.step(lr=sched.lr_at(it), max_norm=5.0)
+        if it == 0:
+            assert_close("weights", out["index"], g["stepB/weights"], atol=1e-5)
+            assert_sub_close(g, "stepB/logits", out["logits"], atol=1e-4)
+            assert abs(clf.item() - float(g["stepB/loss_clf"])) < 1e-4 * max(1.0, abs(float(g["stepB/loss_clf"])))
+            assert abs(taski.item() - float(g["stepB/loss_taski"])) < 1e-4
+            assert abs(nc[0].item() - float(g["stepB/grad_norm"])) <= 1e-3 * float(g["stepB/grad_norm"])
+            for n, p in zip(names, params):
+                if float(g[f"stepB/grad/{n}/absmean"]) < 1e-6:
+                    continue
+                assert_sub_close(g, f"stepB/grad/{n}", p.grad, atol=1e-6, rtol=2e-3)
+    assert abs(clf.item() - float(g["stepB/loss_clf_1"])) < 1e-4 * max(1.0, abs(float(g["stepB/loss_clf_1"])))
+    for n, p, b in zip(names, params, before):
+        if float(g[f"stepB/grad/{n}/absmean"]) < 1e-6:
+            continue          # route.bias: shift-invariant under softmax, gradient is round-off noise
+        # two Adam steps move every element by <= ~5e-5 (2 x lr); where a gradient element is near zero the
+        # normalised update m/sqrt(v) amplifies 1e-7 gradient noise, hence an absolute band of ~10% of one step
+        assert_sub_close(g, f"stepB/delta2/{n}", p.detach() - b, atol=6e-6, rtol=3e-2)
