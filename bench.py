@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- MRN loop B (router phase, il_modules/mrn.py:323-371) on synthetic 32x256 crops.
+
+One "step" = one routing_step of the MRN learner on a per-GPU batch of 256 crops: forward of all frozen experts
+(train-mode BatchNorm, as in the reference's step 1), DM-Router forward, fused fan-in, losses, backward through the
+router, gradient all-reduce (N > 1), global-norm clip + Adam.  Default workload = BASELINE.json's metric
+configuration: TRBA (TPS+ResNet+BiLSTM+Attn) x 6 experts.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import contextlib
+import io
+import json
+import os
+import sys
+import time
+import types
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CLASSES_MLT19 = (2086, 220, 1728, 1160, 73, 102)      # README.md:103, per-task class counts
+FP32_MFMA_PEAK_TFLOPS = 157.3                          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def make_opt(model, batch):
+    o = types.SimpleNamespace(
+        exp_name="bench", il="mrn", memory="random", memory_num=2000, batch_max_length=25, imgH=32, imgW=256,
+        manual_seed=111, start_task=0, num_fiducial=20, input_channel=4, output_channel=512, hidden_size=256,
+        schedule="super", optimizer="adam", lr=0.0005, batch_size=batch, num_iter=10000, val_interval=5000, grad_clip=5,
+        lan_list=["Chinese", "Latin", "Japanese", "Korean", "Arabic", "Bangla"], NED=True, workers=0)
+    if model == "trba":
+        o.Transformation, o.FeatureExtraction, o.SequenceModeling, o.Prediction = "TPS", "ResNet", "BiLSTM", "Attn"
+    elif model == "crnn":
+        o.Transformation, o.FeatureExtraction, o.SequenceModeling, o.Prediction = "None", "VGG", "BiLSTM", "CTC"
+    else:
+        raise SystemExit(f"unknown model {model}")
+    return o
+
+
+def build_learner(opt, n_experts, quiet=True):
+    from mrn_amd.data.synthetic import synthetic_characters
+    from mrn_amd.il_modules.mrn import MRN
+    sink = io.StringIO() if quiet else sys.stdout
+    with contextlib.redirect_stdout(sink):
+        learner = MRN(opt)
+        total = 0
+        for taski in range(n_experts):
+            total += CLASSES_MLT19[taski]
+            learner.character = synthetic_characters(total)
+            learner.converter = learner.build_converter()
+            if taski == 0:
+                learner.criterion = learner.build_criterion()
+                learner.build_model()
+            else:
+                learner.change_model()
+        learner.freeze_experts(n_experts)
+        learner.model.train()       # reference: every "frozen" expert runs train-mode BatchNorm through step 1 (mrn.py:107,401)
+        learner.prepare_routing(total_steps=10 ** 9)
+    return learner
+
+
+def cpu_baseline(learner, opt, n_experts, batch=16, iters=2):
+    """The CPU oracle (oracle/mrn_oracle.py, validated against the reference by tests/test_oracle_golden.py) on a bounded
+    sample of the same workload: loop B at a smaller batch, all host threads."""
+    from oracle import mrn_oracle as O
+    from mrn_amd.data.synthetic import SyntheticTextLines
+    torch.set_num_threads(os.cpu_count() or 1)
+    sd = {k[len("module."):]: v.detach().cpu().clone() for k, v in learner.model.state_dict().items()}
+    cfg = O.Cfg(opt.Transformation, opt.FeatureExtraction, opt.SequenceModeling, opt.Prediction)
+    names = [n for n, p in learner.model.module.named_parameters() if p.requires_grad]
+    params = [sd[n].requires_grad_(True) for n in names]
+    state = [{"m": torch.zeros_like(p), "v": torch.zeros_like(p)} for p in params]
+    o2 = types.SimpleNamespace(**vars(opt))
+    o2.batch_size = batch
+    data = SyntheticTextLines(o2, device=torch.device("cpu"))
+    data.set_characters(learner.character)
+    conv = O.CTCConverter(learner.character) if opt.Prediction == "CTC" else O.AttnConverter(learner.character)
+    times = []
+    for it in range(iters + 1):
+        image, labels, idx = data.get_batch2()
+        domain = torch.LongTensor(idx).squeeze()
+        li, ll = conv.encode(labels, 25)
+        t0 = time.time()
+        text = None if opt.Prediction == "CTC" else li[:, :-1]
+        out = O.mrn_forward(sd, cfg, n_experts, image, True, text, True, training=True)
+        loss, _, _ = O.mrn_step_loss(out, li, ll, domain, opt.Prediction)
+        grads = torch.autograd.grad(loss, params)
+        with torch.no_grad():
+            O.clip_and_adam(params, grads, state, 2.5e-5, it + 1)
+        if it > 0:
+            times.append(time.time() - t0)
+    sec = sum(times) / len(times)
+    return {"value": batch / sec, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{iters} timed iterations (+1 warm-up) of the same loop B at batch {batch}, fp32, torch-CPU oracle"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--model", default="trba", choices=["trba", "crnn"])
+    ap.add_argument("--experts", type=int, default=6)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (reference default 256)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--verbose", action="store_true")
+    args = ap.parse_args()
+
+    from mrn_amd import ops, parallel
+    from mrn_amd.data.synthetic import SyntheticTextLines
+    rank, world, local = parallel.init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
+    torch.cuda.set_device(local)
+    torch.manual_seed(111)
+
+    opt = make_opt(args.model, args.batch)
+    learner = build_learner(opt, args.experts, quiet=not args.verbose)
+    data = SyntheticTextLines(opt, seed=111 + rank)
+    data.set_characters(learner.character)
+    dev = learner.device
+
+    def step():
+        image, labels, idx = data.get_batch2()
+        indexs = torch.LongTensor(idx).squeeze().to(dev)
+        return learner.routing_step(image, labels, indexs)
+
+    for _ in range(args.warmup):
+        step()
+    if not args.no_kernel_timer:
+        ops.CONV_TIMER = ops.KernelTimer()
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss_clf, loss_t = step()
+    torch.cuda.synchronize()
+    parallel.barrier()
+    elapsed = time.perf_counter() - t0
+    timer = ops.CONV_TIMER
+    ops.CONV_TIMER = None
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        res = {
+            "metric": "text-line images/sec (fwd+bwd) at 32x256, TRBA+MRN 6 experts" if (args.model, args.experts) == ("trba", 6)
+            else f"text-line images/sec (fwd+bwd) at 32x256, {args.model.upper()}+MRN {args.experts} experts",
+            "value": world * args.batch * args.steps / elapsed,
+            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"MRN loop B (router phase): {args.model.upper()} x {args.experts} frozen experts "
+                                   f"(train-mode BN) + DM-Router fwd/bwd + clip + Adam, 32x256x4 crops, random-init weights",
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "classes": [sum(CLASSES_MLT19[:i + 1]) + (4 if args.model == "crnn" else 5) for i in range(args.experts)],
+                       "loss_clf": float(loss_clf), "loss_taski": float(loss_t)},
+        }
+        if timer is not None and timer.spans:
+            s = timer.summary()
+            per_launch_flops = s["total_flops"] / s["launches"]
+            avg_ms = s["total_ms"] / s["launches"]
+            ach = per_launch_flops / (avg_ms * 1e-3) / 1e12
+            res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                               "kernel": "gemm_f32_kernel<2,2,2,2,true> (128x128 implicit-GEMM conv, fp32 MFMA)",
+                               "launches_per_step": s["launches"] / args.steps, "avg_launch_ms": avg_ms,
+                               "algorithmic_gflop_per_launch": per_launch_flops / 1e9,
+                               "kernel_share_of_step": s["total_ms"] / (elapsed * 1e3)}
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(learner, opt, args.experts)
+        print(json.dumps(res))
+    parallel.barrier()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,116 @@
+"""MRN learner (reference il_modules/mrn.py:32-515): per task, step 0 trains the newest expert (loop A,
+`_init_train(cross=False)`), the expert is frozen, step 1 trains the DM-Router over all frozen experts (loop B,
+`_update_representation`, loss = 15 * loss_clf + CE(softmax weights, domain)).
+
+`routing_step()` is one iteration of loop B -- the north-star hot path -- and is what bench.py times."""
+import time
+
+import torch
+
+from .. import functional as Fn
+from .. import parallel
+from ..modules.model import MRNNet
+from ..tools.utils import Averager
+from .base import BaseLearner
+
+
+class MRN(BaseLearner):
+    def __init__(self, opt):
+        super().__init__(opt)
+        self.model = MRNNet(opt)
+
+    def after_task(self):
+        self.model = self.model.module
+        self._known_classes = self._total_classes
+        self._old_network = self.model.copy().freeze()
+
+    def change_model(self):
+        if isinstance(self.model, parallel.ReplicaDataParallel):
+            self.model = self.model.module
+        self.model.update_fc(self.opt.hidden_size, self._total_classes)
+        self.model.build_prediction(self.opt, self._total_classes)
+        self.model = parallel.ReplicaDataParallel(self.model).to(self.device)
+        self.model.train()
+
+    def build_model(self):
+        self.model.build_fc(self.opt.hidden_size, self._total_classes)
+        self.model.build_prediction(self.opt, self._total_classes)
+        self._reference_init()
+        self.model = parallel.ReplicaDataParallel(self.model).to(self.device)
+        self.model.train()
+
+    def freeze_experts(self, upto):
+        for i in range(upto):
+            for p in self.model.module.model[i].parameters():
+                p.requires_grad = False
+
+    def incremental_train(self, taski, character, train_loader, valid_loader):
+        self.character = character
+        self.converter = self.build_converter()
+        if taski > 0:
+            self.change_model()
+        else:
+            self.criterion = self.build_criterion()
+            self.build_model()
+        self.freeze_experts(taski)
+        self.build_optimizer(self.count_param())
+        self._train(0, taski, train_loader, valid_loader, step=0)
+        if taski > 0:
+            self._train(0, taski, train_loader, valid_loader, step=1)
+
+    def _train(self, start_iter, taski, train_loader, valid_loader, step=0):
+        print("Task {} start training for model ------{}------".format(taski, self.opt.exp_name))
+        if taski == 0:
+            self._init_train(start_iter, taski, train_loader, valid_loader.create_dataset(), cross=False)
+        elif step == 0:
+            train_loader.get_dataset(taski, memory=None)
+            self.update_step1(start_iter, taski, train_loader, valid_loader.create_dataset())
+        else:
+            train_loader.get_dataset(taski, memory=self.opt.memory, index_list=self.memory_index)
+            self._update_representation(start_iter, taski, train_loader, valid_loader.create_list_dataset())
+
+    def _forward_train(self, image, text):
+        return self.model(image, False, text)["logits"]          # cross=False: newest expert only (mrn.py:248,254)
+
+    def update_step1(self, start_iter, taski, train_loader, valid_loader):
+        self._init_train(start_iter, taski, train_loader, valid_loader, cross=False)
+        for p in self.model.module.model[-1].parameters():
+            p.requires_grad = False
+        self.model.module.model[-1].eval()
+
+    # -- loop B ------------------------------------------------------------------------------------------
+    def prepare_routing(self, total_steps=None):
+        """optimiser of step 1: Adam over the router parameters, OneCycle(total = 2 * num_iter) (mrn.py:308-312)"""
+        self.criterion = self.build_criterion()
+        self.build_optimizer(self.count_param(), scale=1.0, total_steps=total_steps or self.opt.num_iter * 2)
+
+    def routing_step(self, image, labels, indexs, pi=15):
+        """one iteration of mrn.py:329-371"""
+        labels_index, labels_length = self.converter.encode(labels, batch_max_length=self.opt.batch_max_length)
+        if "CTC" in self.opt.Prediction:
+            output = self.model(image, True)
+        else:
+            output = self.model(image, True, labels_index[:, :-1], True)
+        taski_loss = Fn.cross_entropy(output["index"], indexs, -100)     # CE on the already-softmaxed weights
+        loss_clf = self.criterion(output["logits"], labels_index, labels_length)
+        loss = pi * loss_clf + taski_loss
+        self.optimizer_step(loss)
+        return loss_clf, taski_loss
+
+    def _update_representation(self, start_iter, taski, train_loader, valid_loader, pi=15):
+        train_loss_avg, train_taski_loss_avg = Averager(), Averager()
+        self.prepare_routing()
+        start_time = time.time()
+        best_score = -1
+        n_iter = int(self.opt.num_iter // 2)
+        for iteration in range(start_iter + 1, n_iter + 1):
+            image_tensors, labels, indexs = train_loader.get_batch2()
+            indexs = torch.LongTensor(indexs).squeeze().to(self.device)
+            loss_clf, taski_loss = self.routing_step(image_tensors.to(self.device), labels, indexs, pi)
+            train_loss_avg.add(loss_clf.detach())
+            train_taski_loss_avg.add(taski_loss.detach())
+            if iteration % max(self.opt.val_interval // 5, 1) == 0 or iteration == n_iter or iteration == 1:
+                self.val(valid_loader, self.opt, best_score, start_time, iteration, train_loss_avg, train_taski_loss_avg,
+                         taski, step=1, val_choose="TF")
+                train_loss_avg.reset()
+                train_taski_loss_avg.reset()

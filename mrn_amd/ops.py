@@ -10,6 +10,33 @@ from ._lib import call
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 
 
+class KernelTimer:
+    """Optional HIP-event bracket around the dominant kernel (the 128x128 implicit-GEMM conv) so bench.py can report
+    achieved FLOP/s per launch, measured on the stream the kernel runs on."""
+
+    def __init__(self):
+        self.spans = []          # (start_event, end_event, flops)
+
+    def begin(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def end(self, start, flops):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.spans.append((start, e, flops))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        ms = sum(s.elapsed_time(e) for s, e, _ in self.spans)
+        flops = sum(f for _, _, f in self.spans)
+        return {"launches": len(self.spans), "total_ms": ms, "total_flops": flops}
+
+
+CONV_TIMER = None            # set to a KernelTimer by bench.py
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -118,8 +145,12 @@ def conv2d_nhwc(x, w_ohwi, bias=None, stride=(1, 1), padding=(0, 0), act=ACT_NON
     if want_stats:
         n = call("mrn_conv2d_stats_floats", B, Ho, Wo, Cout)
         stats = torch.empty(n, device=x.device, dtype=torch.float32)
+    timed = CONV_TIMER is not None and Cout > 64          # the 128x128-tile instantiation (gemm.hip: mrn_gemm_launch)
+    t0 = CONV_TIMER.begin() if timed else None
     call("mrn_conv2d_nhwc_f32", _p(x), _p(w_ohwi), _p(bias), _p(y), _p(stats), B, H, W, Cin, Cout, kh, kw,
          stride[0], stride[1], padding[0], padding[1], act, _stream())
+    if timed:
+        CONV_TIMER.end(t0, 2.0 * B * Ho * Wo * Cout * kh * kw * Cin)
     return y, stats
 
 
