@@ -7,6 +7,10 @@ import ctypes
 import os
 import re
 
+import torch  # noqa: F401  -- must come first: torch's bundled libamdhip64 has to be the process's HIP runtime before
+#                              libmrn_hip.so (NEEDED libamdhip64.so.7) is dlopen'ed, otherwise a second runtime
+#                              without a device gets bound ("no ROCm-capable device is detected")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmrn_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mrn_hip.h")

@@ -16,7 +16,7 @@ LIB = os.path.join(CSRC, "libmrn_hip.so")
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fvisibility=hidden", "-fno-gpu-rdc",
-         "-Wno-unused-result", "-I", CSRC]
+         "-Wno-unused-result"]
 
 
 def sources():
@@ -42,7 +42,7 @@ def _compile(src):
     dig = _digest(path)
     if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
         return obj, False
-    cmd = [HIPCC, "-x", "hip", *FLAGS, "-c", path, "-o", obj]
+    cmd = [HIPCC, "-x", "hip", *FLAGS, "-I", CSRC, "-c", path, "-o", obj]   # (absolute paths stay out of the digest)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
