@@ -1,0 +1,129 @@
+"""CPU-only checks of the host side: C-ABI surface, converters, LR schedule, state_dict layout, data-parallel helpers
+(gloo, world_size 2).  No kernel is launched here."""
+import contextlib
+import ctypes
+import io
+import os
+import subprocess
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from mrn_amd import _lib
+    from mrn_amd.build import build_library
+    build_library(verbose=False)
+    protos = _lib.parse_header()
+    assert len(protos) >= 39
+    dll = ctypes.CDLL(_lib.LIB_PATH)
+    for name in protos:
+        assert hasattr(dll, name), f"{name} declared in include/mrn_hip.h but not exported"
+    _lib.LIB.load()
+    assert _lib.LIB._dll.mrn_version() == 100
+
+
+def test_ops_refuse_cpu_tensors():
+    from mrn_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.linear(torch.zeros(4, 8), torch.zeros(3, 8))
+
+
+def test_product_converters_match_reference():
+    from mrn_amd.tools.utils import AttnLabelConverter, CTCLabelConverter
+    g = load_golden("converters")
+    words = [str(w) for w in g["words"]]
+    chars = str(g["chars"])
+    with contextlib.redirect_stdout(io.StringIO()):
+        c, a = CTCLabelConverter(chars), AttnLabelConverter(chars)
+    idx, ln = c.encode(words, 25)
+    assert np.array_equal(idx.cpu().numpy(), g["ctc/encode_idx"]) and np.array_equal(ln.cpu().numpy(), g["ctc/encode_len"])
+    assert c.decode(g["ctc/decode_in"], [16, 16]) == [str(s) for s in g["ctc/decode_out"]]
+    idx, ln = a.encode(words, 25)
+    assert np.array_equal(idx.cpu().numpy(), g["attn/encode_idx"]) and np.array_equal(ln.cpu().numpy(), g["attn/encode_len"])
+    assert a.decode(idx.cpu().numpy()[:, 1:], ln.cpu().numpy()) == [str(s) for s in g["attn/decode_out"]]
+
+
+def test_one_cycle_matches_torch_scheduler():
+    from mrn_amd.optim import OneCycle
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=0.0005)
+    sch = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=0.0005, cycle_momentum=False, div_factor=20,
+                                              final_div_factor=1000, total_steps=200)
+    mine = OneCycle(0.0005, 200)
+    for step in range(200):
+        assert abs(opt.param_groups[0]["lr"] - mine.lr_at(step)) < 1e-15, step
+        opt.step()
+        if step < 199:
+            sch.step()
+    with pytest.raises(ValueError):
+        mine.lr_at(200)
+
+
+@pytest.mark.parametrize("name,kind,classes", [("crnn_mrn3", "crnn", (40, 70, 97)), ("trba_mrn3", "trba", (41, 71, 98))])
+def test_state_dict_layout_matches_reference(name, kind, classes):
+    from mrn_amd.modules.model import MRNNet
+    from mrn_amd.parallel import ReplicaDataParallel
+    o = types.SimpleNamespace(num_fiducial=20, imgH=32, imgW=256, input_channel=4, output_channel=512, hidden_size=256,
+                              batch_max_length=25)
+    if kind == "crnn":
+        o.Transformation, o.FeatureExtraction, o.SequenceModeling, o.Prediction = "None", "VGG", "BiLSTM", "CTC"
+    else:
+        o.Transformation, o.FeatureExtraction, o.SequenceModeling, o.Prediction = "TPS", "ResNet", "BiLSTM", "Attn"
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = MRNNet(o)
+        for c in classes:
+            net.update_fc(256, c)
+            net.build_prediction(o, c)
+    g = load_golden(name)
+    ref = {str(k): str(s) for k, s in zip(g["sd_keys"], g["sd_shapes"])}
+    mine = {k: ",".join(map(str, v.shape)) for k, v in net.state_dict().items()}
+    assert mine == ref
+    # the learners' checkpoints carry the DataParallel prefix (il_modules/base.py:323-332)
+    assert all(k.startswith("module.") for k in ReplicaDataParallel(net).state_dict())
+    # fc and Prediction[.generator] alias one tensor, as in the reference (model.py:181,185-187)
+    m = net.model[0]
+    head = m.Prediction if kind == "crnn" else m.Prediction.generator
+    assert head.weight.data_ptr() == m.fc.weight.data_ptr()
+
+
+WORKER = r"""
+import os, sys, torch
+sys.path.insert(0, os.environ["MRN_ROOT"])
+from mrn_amd import parallel
+rank, world, local = parallel.init_distributed(backend="gloo")
+assert world == 2 and parallel.world_size() == 2
+g = torch.full((1001,), float(rank + 1))
+parallel.average_gradients(g)
+assert torch.allclose(g, torch.full((1001,), 1.5)), g[:4]
+p = torch.arange(10, dtype=torch.float32) * (rank + 1)
+parallel.broadcast_parameters(p)
+assert torch.equal(p, torch.arange(10, dtype=torch.float32))
+# per-rank shards differ, the averaged gradient and therefore the replicas stay identical
+torch.manual_seed(rank)
+shard_grad = torch.randn(64)
+parallel.average_gradients(shard_grad)
+gathered = [torch.zeros(64) for _ in range(2)]
+torch.distributed.all_gather(gathered, shard_grad)
+assert torch.equal(gathered[0], gathered[1])
+parallel.barrier()
+print("rank", rank, "ok")
+"""
+
+
+def test_data_parallel_helpers_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MRN_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
