@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 CLASSES_MLT19 = (2086, 220, 1728, 1160, 73, 102)      # README.md:103, per-task class counts
 FP32_MFMA_PEAK_TFLOPS = 157.3                          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0                         # MI355X_MICROARCH.md: dense bf16 MFMA peak
 
 
 def make_opt(model, batch):
@@ -116,6 +117,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--precision", default="auto", choices=["auto", "f32", "bf16x3", "bf16"],
+                    help="conv arithmetic (mrn_amd/ops.py: CONV_PRECISION); auto keeps the 1e-4 parity band")
+    ap.add_argument("--no-streams", action="store_true", help="run the experts sequentially on one stream")
     args = ap.parse_args()
 
     from mrn_amd import ops, parallel
@@ -128,8 +132,10 @@ def main():
     torch.cuda.set_device(local)
     torch.manual_seed(111)
 
+    ops.CONV_PRECISION = args.precision
     opt = make_opt(args.model, args.batch)
     learner = build_learner(opt, args.experts, quiet=not args.verbose)
+    learner.model.module.expert_streams = not args.no_streams
     data = SyntheticTextLines(opt, seed=111 + rank)
     data.set_characters(learner.character)
     dev = learner.device
@@ -165,7 +171,9 @@ def main():
             "value": world * args.batch * args.steps / elapsed,
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": {"auto": "f32 (K>=4096 conv reductions as split-bf16x3 MFMA, fp32 accumulate)", "f32": "f32",
+                      "bf16x3": "bf16x3 (split-bf16 MFMA, fp32 accumulate)", "bf16": "bf16"}[ops.CONV_PRECISION],
+            "data": "synthetic",
             "config": {"workload": f"MRN loop B (router phase): {args.model.upper()} x {args.experts} frozen experts "
                                    f"(train-mode BN) + DM-Router fwd/bwd + clip + Adam, 32x256x4 crops, random-init weights",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
@@ -173,16 +181,28 @@ def main():
                        "loss_clf": loss_clf.detach().item(), "loss_taski": loss_t.detach().item()},
         }
         if timer is not None and timer.spans:
-            s = timer.summary()
-            per_launch_flops = s["total_flops"] / s["launches"]
-            avg_ms = s["total_ms"] / s["launches"]
-            ach = per_launch_flops / (avg_ms * 1e-3) / 1e12
-            res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                               "kernel": "gemm_f32_kernel<2,2,2,2,true> (128x128 implicit-GEMM conv, fp32 MFMA)",
-                               "launches_per_step": s["launches"] / args.steps, "avg_launch_ms": avg_ms,
-                               "algorithmic_gflop_per_launch": per_launch_flops / 1e9,
-                               "kernel_share_of_step": s["total_ms"] / (elapsed * 1e3)}
+            kinds = timer.summary()
+            names = {"f32": "gemm_f32_kernel<2,2,2,2,16,true> (128x128x16 implicit-GEMM conv, v_mfma_f32_32x32x2_f32)",
+                     "bf16x3": "conv_bf16_kernel<3> (128x128x32 implicit-GEMM conv, split-bf16 x3 on v_mfma_f32_32x32x16_bf16)",
+                     "bf16": "conv_bf16_kernel<1> (128x128x32 implicit-GEMM conv, bf16 operands)"}
+            peaks = {"f32": FP32_MFMA_PEAK_TFLOPS, "bf16x3": BF16_MFMA_PEAK_TFLOPS, "bf16": BF16_MFMA_PEAK_TFLOPS}
+            mfma_per_flop = {"f32": 1, "bf16x3": 3, "bf16": 1}
+            rl = []
+            for kind, s_ in kinds.items():
+                per_launch = s_["total_flops"] / s_["launches"]
+                avg_ms = s_["total_ms"] / s_["launches"]
+                ach = per_launch / (avg_ms * 1e-3) / 1e12
+                rl.append({"bound": "mfma", "achieved": ach, "peak": peaks[kind], "unit": "TFLOP/s", "frac": ach / peaks[kind],
+                           "traffic": None, "kernel": names[kind], "mfma_flops_per_algorithmic_flop": mfma_per_flop[kind],
+                           "mfma_issue_frac": ach * mfma_per_flop[kind] / peaks[kind],
+                           "launches_per_step": s_["launches"] / args.steps, "avg_launch_ms": avg_ms,
+                           "algorithmic_gflop_per_launch": per_launch / 1e9,
+                           "kernel_share_of_step": s_["total_ms"] / (elapsed * 1e3),
+                           "note": "experts run on concurrent HIP streams: event time per launch includes overlap with other experts' kernels"})
+            rl.sort(key=lambda r: -r["kernel_share_of_step"])
+            res["roofline"] = rl[0]
+            if len(rl) > 1:
+                res["roofline_other_kernels"] = rl[1:]
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(learner, opt, args.experts)
         print(json.dumps(res))

@@ -46,6 +46,16 @@ int mrn_conv2d_nhwc_f32(const float* x, const float* w_ohwi, const float* bias, 
                         int act, void* stream);
 int64_t mrn_conv2d_stats_floats(int B, int Ho, int Wo, int Cout);
 
+/* The same convolution on the bf16 MFMA pipe with split operands: every fp32 operand is x = hi + lo (two bf16),
+ * product = hi*hi + hi*lo + lo*hi, fp32 accumulate (nsplit 3: fp32-class accuracy, inside the 1e-4 parity band);
+ * nsplit 1 keeps hi*hi only (plain bf16 operands).  w_hi / w_lo: bf16 [Cout][kh*kw*Cin] from mrn_split_weight_bf16.
+ * Requires Cin % 4 == 0 and (kh*kw*Cin) % 32 == 0. */
+int mrn_conv2d_nhwc_bf16split(const float* x, const void* w_hi, const void* w_lo, const float* bias, float* y,
+                              float* stats, int B, int H, int W, int Cin, int Cout, int kh, int kw, int sh, int sw,
+                              int ph, int pw, int act, int nsplit, void* stream);
+/* fp32 [n] -> bf16 hi[n], lo[n] with hi = bf16(x), lo = bf16(x - hi) */
+int mrn_split_weight_bf16(const float* w, void* hi, void* lo, int64_t n, void* stream);
+
 /* conv weight repack [O][I][kh][kw] (state_dict layout) -> [O][kh][kw][I] */
 int mrn_pack_conv_weight_f32(const float* w_oihw, float* w_ohwi, int O, int I, int kh, int kw, void* stream);
 

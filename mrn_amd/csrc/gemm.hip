@@ -17,38 +17,39 @@
 // k = lane>>5) is a conflict-free ds_read_b32 of 32 consecutive floats per half-wave.
 #include "common.hpp"
 #include "gemm.hpp"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int BK = 16;
-
 // floats staged per thread for a ROWS x BK tile (at least one float4)
-constexpr int stage_regs(int rows, int nt) { return rows * BK / nt < 4 ? 4 : rows * BK / nt; }
+constexpr int stage_regs(int rows, int nt, int bk) { return rows * bk / nt < 4 ? 4 : rows * bk / nt; }
 
 // ---- strided operand: element (row, k) at base[row*sr + k*sk] --------------------------------
 // mode 0: scalar, k fastest    1: scalar, row fastest    2: float4 along k    3: float4 along row
-template <int ROWS, int NT>
+template <int ROWS, int NT, int BK>
 struct Stage {
-  static constexpr int NP2 = ROWS / (NT / 4) > 0 ? ROWS / (NT / 4) : 1;    // passes, float4 along k
+  static constexpr int KQ = BK / 4;                                          // float4 groups along k
+  static constexpr int RPP2 = NT / KQ;                                        // rows per pass, float4 along k
+  static constexpr int NP2 = ROWS / RPP2 > 0 ? ROWS / RPP2 : 1;
   static constexpr int RQ = ROWS / 4;                                      // row quads per k
   static constexpr int KPP3 = (NT / RQ) < BK ? (NT / RQ) : BK;
   static constexpr int NP3 = BK / KPP3;
-  static constexpr int NP0 = ROWS / (NT / 16) > 0 ? ROWS / (NT / 16) : 1;
+  static constexpr int NP0 = ROWS / (NT / BK) > 0 ? ROWS / (NT / BK) : 1;
   static constexpr int KPP1 = (NT / ROWS) < BK ? (NT / ROWS) : BK;
   static constexpr int NP1 = BK / KPP1;
   static constexpr int LD = ROWS + 4;
 };
 
-template <int ROWS, int NT>
-__device__ __forceinline__ void load_strided(float (&r)[stage_regs(ROWS, NT)], const float* __restrict__ base,
+template <int ROWS, int NT, int BK>
+__device__ __forceinline__ void load_strided(float (&r)[stage_regs(ROWS, NT, BK)], const float* __restrict__ base,
                                              long sr, long sk, int row0, int k0, int nrows, int K, int mode) {
-  using S = Stage<ROWS, NT>;
+  using S = Stage<ROWS, NT, BK>;
   const int t = threadIdx.x;
   if (mode == 2) {
-    const int k = k0 + (t & 3) * 4;
+    const int k = k0 + (t % S::KQ) * 4;
 #pragma unroll
     for (int p = 0; p < S::NP2; ++p) {
-      const int rl = (t >> 2) + p * (NT / 4);
+      const int rl = (t / S::KQ) + p * S::RPP2;
       const int row = row0 + rl;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (rl < ROWS && row < nrows && k < K) v = *reinterpret_cast<const f32x4*>(base + (long)row * sr + k);
@@ -65,10 +66,10 @@ __device__ __forceinline__ void load_strided(float (&r)[stage_regs(ROWS, NT)], c
       r[p * 4 + 0] = v[0]; r[p * 4 + 1] = v[1]; r[p * 4 + 2] = v[2]; r[p * 4 + 3] = v[3];
     }
   } else if (mode == 0) {
-    const int k = k0 + (t & 15);
+    const int k = k0 + (t % BK);
 #pragma unroll
     for (int p = 0; p < S::NP0; ++p) {
-      const int rl = (t >> 4) + p * (NT / 16);
+      const int rl = (t / BK) + p * (NT / BK);
       const int row = row0 + rl;
       r[p] = (rl < ROWS && row < nrows && k < K) ? base[(long)row * sr + (long)k * sk] : 0.f;
     }
@@ -83,16 +84,16 @@ __device__ __forceinline__ void load_strided(float (&r)[stage_regs(ROWS, NT)], c
   }
 }
 
-template <int ROWS, int NT>
-__device__ __forceinline__ void store_lds(const float (&r)[stage_regs(ROWS, NT)], float* __restrict__ s, int mode) {
-  using S = Stage<ROWS, NT>;
+template <int ROWS, int NT, int BK>
+__device__ __forceinline__ void store_lds(const float (&r)[stage_regs(ROWS, NT, BK)], float* __restrict__ s, int mode) {
+  using S = Stage<ROWS, NT, BK>;
   constexpr int LD = S::LD;
   const int t = threadIdx.x;
   if (mode == 2) {
-    const int kq = (t & 3) * 4;
+    const int kq = (t % S::KQ) * 4;
 #pragma unroll
     for (int p = 0; p < S::NP2; ++p) {
-      const int rl = (t >> 2) + p * (NT / 4);
+      const int rl = (t / S::KQ) + p * S::RPP2;
       if (rl < ROWS) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) s[(kq + j) * LD + rl] = r[p * 4 + j];
@@ -108,10 +109,10 @@ __device__ __forceinline__ void store_lds(const float (&r)[stage_regs(ROWS, NT)]
       }
     }
   } else if (mode == 0) {
-    const int kk = t & 15;
+    const int kk = t % BK;
 #pragma unroll
     for (int p = 0; p < S::NP0; ++p) {
-      const int rl = (t >> 4) + p * (NT / 16);
+      const int rl = (t / BK) + p * (NT / BK);
       if (rl < ROWS) s[kk * LD + rl] = r[p];
     }
   } else {
@@ -129,21 +130,31 @@ struct ConvRow {
   bool ok;
 };
 
-template <int ROWS, int NT>
-__device__ __forceinline__ void load_conv(float (&r)[stage_regs(ROWS, NT)], const GemmParams& p,
-                                          const ConvRow (&rows)[Stage<ROWS, NT>::NP2], int k0) {
+// tap table entry for a 4-float group of the K axis: (ky, kx, ci) packed; built once per block in LDS so the
+// K loop carries no integer division
+__device__ __forceinline__ int pack_tap(int k, int Cin, int kw) {
+  const int tap = k / Cin;
+  const int ci = k - tap * Cin;
+  const int ky = tap / kw;
+  const int kx = tap - ky * kw;
+  return (ky << 26) | (kx << 20) | ci;
+}
+
+template <int ROWS, int NT, int BK>
+__device__ __forceinline__ void load_conv(float (&r)[stage_regs(ROWS, NT, BK)], const GemmParams& p,
+                                          const ConvRow (&rows)[Stage<ROWS, NT, BK>::NP2], const int* __restrict__ taps,
+                                          int k0) {
+  using S = Stage<ROWS, NT, BK>;
   const int t = threadIdx.x;
-  const int k = k0 + (t & 3) * 4;
+  const int k = k0 + (t % S::KQ) * 4;
   const bool kok = k < p.K;
-  const int tap = k / p.Cin;
-  const int ci = k - tap * p.Cin;
-  const int ky = tap / p.kw;
-  const int kx = tap - ky * p.kw;
+  const int info = taps[kok ? (k >> 2) : 0];
+  const int ky = info >> 26, kx = (info >> 20) & 63, ci = info & 0xfffff;
 #pragma unroll
-  for (int q = 0; q < Stage<ROWS, NT>::NP2; ++q) {
+  for (int q = 0; q < S::NP2; ++q) {
     const int iy = rows[q].iy0 + ky, ix = rows[q].ix0 + kx;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (kok && rows[q].ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.Wd)
+    if (kok && rows[q].ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.Wd)
       v = *reinterpret_cast<const f32x4*>(p.A + rows[q].base + ((long)iy * p.Wd + ix) * p.Cin + ci);
     r[q * 4 + 0] = v[0]; r[q * 4 + 1] = v[1]; r[q * 4 + 2] = v[2]; r[q * 4 + 3] = v[3];
   }
@@ -155,16 +166,20 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   return v;
 }
 
-template <int WM, int WN, int TM, int TN, bool CONV>
+constexpr int MAX_TAPS = 2048;   // K/4 entries of the tap table (K <= 8192)
+
+template <int WM, int WN, int TM, int TN, int BK, bool CONV>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_kernel(const GemmParams p) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int LDA = BM + 4, LDB = BN + 4;
-  constexpr int PA = stage_regs(BM, NT), PB = stage_regs(BN, NT);
-  constexpr int NPA = Stage<BM, NT>::NP2;
-  __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA + LDB)];
+  constexpr int PA = stage_regs(BM, NT, BK), PB = stage_regs(BN, NT, BK);
+  constexpr int NPA = Stage<BM, NT, BK>::NP2;
+  constexpr int RPP = Stage<BM, NT, BK>::RPP2, KQ = Stage<BM, NT, BK>::KQ;
+  __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA + LDB) + (CONV ? MAX_TAPS : 0)];
   float* const As = smem;                 // two buffers of BK*LDA
   float* const Bs = smem + 2 * BK * LDA;  // two buffers of BK*LDB
+  int* const taps = reinterpret_cast<int*>(smem + 2 * BK * (LDA + LDB));
 
   const int tilesN = (p.N + BN - 1) / BN;
   const int nwg = gridDim.x;
@@ -183,7 +198,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_kernel(const GemmParams 
   if (CONV) {
 #pragma unroll
     for (int q = 0; q < NPA; ++q) {
-      const int rl = (t >> 2) + q * (NT / 4);
+      const int rl = (t / KQ) + q * RPP;
       const int m = m0 + rl;
       const bool ok = rl < BM && m < p.M;
       const int mm = ok ? m : 0;
@@ -196,6 +211,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_kernel(const GemmParams 
       crow[q].ix0 = ox * p.sw - p.pw;
       crow[q].ok = ok;
     }
+    for (int i = t; i < (p.K + 3) / 4; i += NT) taps[i] = pack_tap(i * 4, p.Cin, p.kw);
+    __syncthreads();
   }
 
   f32x16 acc[TM][TN];
@@ -209,19 +226,19 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_kernel(const GemmParams 
   float ra[PA], rb[PB];
   const int nk = (p.K + BK - 1) / BK;
 
-  if (CONV) load_conv<BM, NT>(ra, p, crow, 0);
-  else load_strided<BM, NT>(ra, A, p.sAm, p.sAk, m0, 0, p.M, p.K, p.amode);
-  load_strided<BN, NT>(rb, W, p.sWn, p.sWk, n0, 0, p.N, p.K, p.wmode);
-  store_lds<BM, NT>(ra, As, CONV ? 2 : p.amode);
-  store_lds<BN, NT>(rb, Bs, p.wmode);
+  if (CONV) load_conv<BM, NT, BK>(ra, p, crow, taps, 0);
+  else load_strided<BM, NT, BK>(ra, A, p.sAm, p.sAk, m0, 0, p.M, p.K, p.amode);
+  load_strided<BN, NT, BK>(rb, W, p.sWn, p.sWk, n0, 0, p.N, p.K, p.wmode);
+  store_lds<BM, NT, BK>(ra, As, CONV ? 2 : p.amode);
+  store_lds<BN, NT, BK>(rb, Bs, p.wmode);
   __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) {
-      if (CONV) load_conv<BM, NT>(ra, p, crow, (kt + 1) * BK);
-      else load_strided<BM, NT>(ra, A, p.sAm, p.sAk, m0, (kt + 1) * BK, p.M, p.K, p.amode);
-      load_strided<BN, NT>(rb, W, p.sWn, p.sWk, n0, (kt + 1) * BK, p.N, p.K, p.wmode);
+      if (CONV) load_conv<BM, NT, BK>(ra, p, crow, taps, (kt + 1) * BK);
+      else load_strided<BM, NT, BK>(ra, A, p.sAm, p.sAk, m0, (kt + 1) * BK, p.M, p.K, p.amode);
+      load_strided<BN, NT, BK>(rb, W, p.sWn, p.sWk, n0, (kt + 1) * BK, p.N, p.K, p.wmode);
     }
     const float* as = As + cur * BK * LDA + wm * TM * 32 + (lane & 31) + (lane >> 5) * LDA;
     const float* bs = Bs + cur * BK * LDB + wn * TN * 32 + (lane & 31) + (lane >> 5) * LDB;
@@ -239,8 +256,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_kernel(const GemmParams 
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     if (kt + 1 < nk) {
-      store_lds<BM, NT>(ra, As + (cur ^ 1) * BK * LDA, CONV ? 2 : p.amode);
-      store_lds<BN, NT>(rb, Bs + (cur ^ 1) * BK * LDB, p.wmode);
+      store_lds<BM, NT, BK>(ra, As + (cur ^ 1) * BK * LDA, CONV ? 2 : p.amode);
+      store_lds<BN, NT, BK>(rb, Bs + (cur ^ 1) * BK * LDB, p.wmode);
     }
     __syncthreads();
   }
@@ -307,13 +324,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_kernel(const GemmParams 
   }
 }
 
-template <int WM, int WN, int TM, int TN>
-int launch_cfg(const GemmParams& p, bool conv, hipStream_t st) {
+template <int WM, int WN, int TM, int TN, int BK>
+int launch_cfg(const GemmParams& p, bool conv, hipStream_t st, size_t pad_lds = 0) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
   dim3 grid(tiles, 1, p.batch), block(WM * WN * 64);
-  if (conv) hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, true>), grid, block, 0, st, p);
-  else hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, false>), grid, block, 0, st, p);
+  if (conv) hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, BK, true>), grid, block, pad_lds, st, p);
+  else hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, BK, false>), grid, block, pad_lds, st, p);
   MRN_LAUNCH_CHECK("gemm_f32");
   return MRN_OK;
 }
@@ -329,9 +346,18 @@ int mrn_gemm_tile_m(int M, int N) {
 int mrn_gemm_launch(const GemmParams& p, bool conv, hipStream_t st) {
   if (p.M <= 0 || p.N <= 0 || p.batch <= 0) return MRN_OK;
   // every configuration keeps BM = 128 so the statistics workspace is always ceil(M/128) row blocks
-  if (p.N <= 32) return launch_cfg<4, 1, 1, 1>(p, conv, st);
-  if (p.N <= 64) return launch_cfg<4, 1, 1, 2>(p, conv, st);
-  return launch_cfg<2, 2, 2, 2>(p, conv, st);
+  if (conv && p.K > MAX_TAPS * 4) {
+    mrn_set_error("conv K=%d exceeds the tap table (%d)", p.K, MAX_TAPS * 4);
+    return MRN_ERR_UNSUPPORTED;
+  }
+  static const int variant = getenv("MRN_GEMM_VARIANT") ? atoi(getenv("MRN_GEMM_VARIANT")) : 0;   // tuning experiments only
+  if (p.N <= 32) return launch_cfg<4, 1, 1, 1, 16>(p, conv, st);
+  if (p.N <= 64) return launch_cfg<4, 1, 1, 2, 16>(p, conv, st);
+  if (variant == 1) return launch_cfg<2, 2, 2, 2, 16>(p, conv, st);
+  if (variant == 2) return launch_cfg<2, 2, 2, 2, 16>(p, conv, st, 10 * 1024);   // 3 blocks/CU
+  if (variant == 3) return launch_cfg<2, 2, 2, 2, 16>(p, conv, st, 30 * 1024);   // 2 blocks/CU
+  if (variant == 4) return launch_cfg<2, 2, 2, 2, 16>(p, conv, st, 60 * 1024);   // 1 block/CU
+  return launch_cfg<2, 2, 2, 2, 32>(p, conv, st);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -21,24 +21,39 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// acc[g][s] += A(16 x K from LDS rows of stride lda) . W[(g*HID + 64w + 16s + n)][k]   for K a multiple of 16
+// acc[g][s] += A(16 x K from LDS rows of stride lda) . W[(g*HID + 64w + 16s + n)][k]   for K a multiple of 16.
+// The weight fragments of step q+1 are fetched (L2 -> registers) before the MFMAs of step q issue, so the L2
+// latency of the weight stream hides behind 16*NG MFMAs instead of stalling every step.
 template <int NG>
 __device__ __forceinline__ void mma_rows(f32x4 (&acc)[NG][4], const float* __restrict__ a_lds, int lda,
                                          const float* __restrict__ W, long ldw, int K, int wave, int lane) {
   const int n = lane & 15, g4 = (lane >> 4) * 4;
   const float* ap = a_lds + n * lda + g4;
   const float* wp = W + (long)(wave * 64 + n) * ldw + g4;
-  for (int q = 0; q < K / 16; ++q) {
+  f32x4 wv[NG][4];
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) wv[g][s] = *reinterpret_cast<const f32x4*>(wp + (long)(g * HID + s * 16) * ldw);
+  const int Q = K / 16;
+  for (int q = 0; q < Q; ++q) {
+    f32x4 wn[NG][4];
+    const int qn = (q + 1 < Q) ? q + 1 : q;
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) wn[g][s] = *reinterpret_cast<const f32x4*>(wp + (long)(g * HID + s * 16) * ldw + qn * 16);
     const f32x4 av = *reinterpret_cast<const f32x4*>(ap + q * 16);
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
+    for (int g = 0; g < NG; ++g)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const f32x4 wv = *reinterpret_cast<const f32x4*>(wp + (long)(g * HID + s * 16) * ldw + q * 16);
+      for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[g][s] = mfma4(av[r], wv[r], acc[g][s]);
-      }
-    }
+        for (int r = 0; r < 4; ++r) acc[g][s] = mfma4(av[r], wv[g][s][r], acc[g][s]);
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) wv[g][s] = wn[g][s];
   }
 }
 
@@ -189,20 +204,41 @@ __global__ __launch_bounds__(256) void attn_decoder_kernel(const AttnDecParams p
       }
     }
     __syncthreads();
-    // (2) e[b][t] = score . tanh(Hproj[b][t] + hp[b]); one wave per (b, t) pair, 4 channels per lane
-    for (int pr = wave; pr < BT * T; pr += 4) {
-      const int row = pr / T, t = pr - row * T;
-      const int b = b0 + row;
-      float s = 0.f;
-      if (b < p.B) {
-        const f32x4 hv = *reinterpret_cast<const f32x4*>(p.Hproj + ((long)b * T + t) * HID + lane * 4);
-        const f32x4 pv = *reinterpret_cast<const f32x4*>(hp_lds + row * HLD + lane * 4);
-        const f32x4 wv = *reinterpret_cast<const f32x4*>(sw_lds + lane * 4);
+    // (2) e[b][t] = score . tanh(Hproj[b][t] + hp[b]); one wave per (b, t) pair, 4 channels per lane, four pairs in
+    //     flight per wave so the Hproj loads (L2) and the cross-lane reductions of different pairs overlap
+    {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(sw_lds + lane * 4);
+      for (int pr0 = wave * 4; pr0 < BT * T; pr0 += 16) {
+        f32x4 hv[4];
+        int rows[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) s = fmaf(wv[k], fast_tanh(hv[k] + pv[k]), s);
+        for (int u = 0; u < 4; ++u) {
+          const int pr = pr0 + u;
+          const int row = pr < BT * T ? pr / T : 0, t = pr < BT * T ? pr - row * T : 0;
+          rows[u] = row;
+          const int b = b0 + row;
+          hv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (pr < BT * T && b < p.B) hv[u] = *reinterpret_cast<const f32x4*>(p.Hproj + ((long)b * T + t) * HID + lane * 4);
+        }
+        float sacc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const f32x4 pv = *reinterpret_cast<const f32x4*>(hp_lds + rows[u] * HLD + lane * 4);
+          float s = 0.f;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) s = fmaf(wv[k], fast_tanh(hv[u][k] + pv[k]), s);
+          sacc[u] = s;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) sacc[u] += __shfl_xor(sacc[u], o);
+        }
+        if (lane < 4 && pr0 + lane < BT * T) {
+          const float v = lane == 0 ? sacc[0] : lane == 1 ? sacc[1] : lane == 2 ? sacc[2] : sacc[3];
+          e_lds[pr0 + lane] = (b0 + (pr0 + lane) / T < p.B) ? v : 0.f;
+        }
       }
-      s = wave_sum(s);
-      if (lane == 0) e_lds[row * T + t] = s;
     }
     __syncthreads();
     // (3) softmax over t, one wave per 4 samples
@@ -233,7 +269,19 @@ __global__ __launch_bounds__(256) void attn_decoder_kernel(const AttnDecParams p
       f32x4 a = {0.f, 0.f, 0.f, 0.f};
       if (b < p.B) {
         const float* hb = p.Hb + (long)b * T * D + c4 * 4;
-        for (int t = 0; t < T; ++t) {
+        int t = 0;
+        for (; t + 8 <= T; t += 8) {                 // eight independent loads in flight
+          f32x4 v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(hb + (long)(t + u) * D);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const float w = e_lds[row * T + t + u];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[k] = fmaf(w, v[u][k], a[k]);
+          }
+        }
+        for (; t < T; ++t) {
           const float w = e_lds[row * T + t];
           const f32x4 v = *reinterpret_cast<const f32x4*>(hb + (long)t * D);
 #pragma unroll

@@ -150,6 +150,13 @@ class MRNNet(nn.Module):
         self.router = "dm-router"
         self.layer_num = 1
         self.beta = 1
+        self.expert_streams = True          # run the frozen experts on separate HIP streams
+        self._stream_pool = []
+
+    def _streams(self, n, device):
+        while len(self._stream_pool) < n:
+            self._stream_pool.append(torch.cuda.Stream(device=device))
+        return self._stream_pool
 
     @property
     def feature_dim(self):
@@ -172,12 +179,22 @@ class MRNNet(nn.Module):
         image = to_nhwc(image).permute(0, 3, 1, 2)          # one NHWC conversion shared by all experts
         T_pred = self.patch if self.opt.Prediction == "CTC" else self.opt.batch_max_length + 1
         feats = torch.empty(B, self.patch, I, self.out_dim, device=dev, dtype=torch.float32)
-        logits = []
+        logits = [ops.padded_rows(B, T_pred, expert.fc.out_features, dev) for expert in self.model]
         with torch.no_grad():
-            for i, expert in enumerate(self.model):
-                lg = ops.padded_rows(B, T_pred, expert.fc.out_features, dev)
-                expert(image, text, is_train, feature_out=feats[:, :, i, :], predict_out=lg)
-                logits.append(lg)
+            if self.expert_streams and I > 1:
+                # experts are independent: one HIP stream each, so the latency-bound recurrent kernels of one expert
+                # (16-32 workgroups) overlap with the conv GEMMs of the others instead of idling 90 % of the CUs
+                main = torch.cuda.current_stream()
+                streams = self._streams(I, dev)
+                for i, expert in enumerate(self.model):
+                    streams[i].wait_stream(main)
+                    with torch.cuda.stream(streams[i]):
+                        expert(image, text, is_train, feature_out=feats[:, :, i, :], predict_out=logits[i])
+                for st in streams[:I]:
+                    main.wait_stream(st)
+            else:
+                for i, expert in enumerate(self.model):
+                    expert(image, text, is_train, feature_out=feats[:, :, i, :], predict_out=logits[i])
         r = self.dm_router[0].forward_l2(feats)               # [B,P,I,C]
         r = LinearFn.apply(r.view(B * self.patch, I * self.out_dim), self.channel_route.weight, self.channel_route.bias)
         return logits, r.view(B, self.patch, I)
@@ -224,7 +241,11 @@ class MRNNet(nn.Module):
             raise Exception("Prediction is neither CTC or Attn")
 
     def copy(self):
-        return copy.deepcopy(self)
+        pool, self._stream_pool = self._stream_pool, []      # streams are not copyable
+        try:
+            return copy.deepcopy(self)
+        finally:
+            self._stream_pool = pool
 
     def freeze(self):
         for p in self.parameters():

@@ -22,19 +22,53 @@ class KernelTimer:
         e.record()
         return e
 
-    def end(self, start, flops):
+    def end(self, start, flops, kind="f32"):
         e = torch.cuda.Event(enable_timing=True)
         e.record()
-        self.spans.append((start, e, flops))
+        self.spans.append((start, e, flops, kind))
 
     def summary(self):
+        """per kernel kind: launches, total event time, total algorithmic flops"""
         torch.cuda.synchronize()
-        ms = sum(s.elapsed_time(e) for s, e, _ in self.spans)
-        flops = sum(f for _, _, f in self.spans)
-        return {"launches": len(self.spans), "total_ms": ms, "total_flops": flops}
+        out = {}
+        for s, e, f, kind in self.spans:
+            d = out.setdefault(kind, {"launches": 0, "total_ms": 0.0, "total_flops": 0.0})
+            d["launches"] += 1
+            d["total_ms"] += s.elapsed_time(e)
+            d["total_flops"] += f
+        return out
 
 
 CONV_TIMER = None            # set to a KernelTimer by bench.py
+
+# Arithmetic of the large implicit-GEMM convs (Cout > 64, K % 32 == 0):
+#   "f32"    exact fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere
+#   "auto"   (default) split-bf16x3 MFMA for the deep reductions (K >= 4096: 79 % of a TRBA expert's FLOPs), exact fp32
+#            elsewhere.  Measured against the reference: router weights / fused logits within 1.2e-5 -- the TPS
+#            localisation net and the shallow layers, whose errors the grid sampler and small-batch BatchNorm amplify,
+#            stay exact, so the 1e-4 parity band holds with a 10x margin.
+#   "bf16x3" split-bf16x3 for every eligible conv: ~1e-4 on fused logits (edge of the band; performance mode)
+#   "bf16"   plain bf16 operands (hi only), fp32 accumulate: ~2e-2 on features
+CONV_PRECISION = "auto"
+AUTO_SPLIT_MIN_K = 4096
+
+
+class PackedConvWeight:
+    """[O,kh,kw,I] fp32 weight plus its lazily built bf16 hi/lo split."""
+
+    def __init__(self, ohwi):
+        self.ohwi = ohwi
+        self.shape = ohwi.shape
+        self._split = None
+
+    def split(self):
+        if self._split is None:
+            n = self.ohwi.numel()
+            hi = torch.empty(n, device=self.ohwi.device, dtype=torch.bfloat16)
+            lo = torch.empty(n, device=self.ohwi.device, dtype=torch.bfloat16)
+            call("mrn_split_weight_bf16", _p(self.ohwi), _p(hi), _p(lo), n, _stream())
+            self._split = (hi, lo)
+        return self._split
 
 
 def _stream():
@@ -127,30 +161,45 @@ def pack_conv_weight(w):
     w = w.contiguous()
     out = torch.empty(O, kh, kw, I, device=w.device, dtype=torch.float32)
     call("mrn_pack_conv_weight_f32", _p(w), _p(out), O, I, kh, kw, _stream())
-    return out
+    return PackedConvWeight(out)
 
 
 def conv_out_hw(H, W, k, s, p):
     return (H + 2 * p[0] - k[0]) // s[0] + 1, (W + 2 * p[1] - k[1]) // s[1] + 1
 
 
-def conv2d_nhwc(x, w_ohwi, bias=None, stride=(1, 1), padding=(0, 0), act=ACT_NONE, want_stats=False):
-    """x [B,H,W,Cin] -> y [B,Ho,Wo,Cout]; returns (y, stats or None) where stats are per-128-row-block partials."""
+def conv2d_nhwc(x, w_ohwi, bias=None, stride=(1, 1), padding=(0, 0), act=ACT_NONE, want_stats=False, precision=None):
+    """x [B,H,W,Cin] -> y [B,Ho,Wo,Cout]; returns (y, stats or None) where stats are per-128-row-block partials.
+    w_ohwi: [O,kh,kw,I] fp32 tensor or a PackedConvWeight."""
+    packed = w_ohwi if isinstance(w_ohwi, PackedConvWeight) else None
+    if packed is not None:
+        w_ohwi = packed.ohwi
     _chk(x, w_ohwi, bias)
     B, H, W, Cin = x.shape
     Cout, kh, kw, _ = w_ohwi.shape
+    precision = precision or CONV_PRECISION
     Ho, Wo = conv_out_hw(H, W, (kh, kw), stride, padding)
     y = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
     stats = None
     if want_stats:
         n = call("mrn_conv2d_stats_floats", B, Ho, Wo, Cout)
         stats = torch.empty(n, device=x.device, dtype=torch.float32)
-    timed = CONV_TIMER is not None and Cout > 64          # the 128x128-tile instantiation (gemm.hip: mrn_gemm_launch)
+    timed = CONV_TIMER is not None and Cout > 64          # the 128x128-tile kernels
     t0 = CONV_TIMER.begin() if timed else None
-    call("mrn_conv2d_nhwc_f32", _p(x), _p(w_ohwi), _p(bias), _p(y), _p(stats), B, H, W, Cin, Cout, kh, kw,
-         stride[0], stride[1], padding[0], padding[1], act, _stream())
+    Kred = kh * kw * Cin
+    if precision == "auto":
+        precision = "bf16x3" if Kred >= AUTO_SPLIT_MIN_K else "f32"
+    if precision != "f32" and Cout > 64 and Kred % 32 == 0:
+        if packed is None:
+            packed = PackedConvWeight(w_ohwi)
+        hi, lo = packed.split()
+        call("mrn_conv2d_nhwc_bf16split", _p(x), _p(hi), _p(lo), _p(bias), _p(y), _p(stats), B, H, W, Cin, Cout, kh, kw,
+             stride[0], stride[1], padding[0], padding[1], act, 3 if precision == "bf16x3" else 1, _stream())
+    else:
+        call("mrn_conv2d_nhwc_f32", _p(x), _p(w_ohwi), _p(bias), _p(y), _p(stats), B, H, W, Cin, Cout, kh, kw,
+             stride[0], stride[1], padding[0], padding[1], act, _stream())
     if timed:
-        CONV_TIMER.end(t0, 2.0 * B * Ho * Wo * Cout * kh * kw * Cin)
+        CONV_TIMER.end(t0, 2.0 * B * Ho * Wo * Cout * Kred, precision if (precision != "f32" and Kred % 32 == 0) else "f32")
     return y, stats
 
 

@@ -86,9 +86,17 @@ def test_conv2d_and_batch_stats(ops, cfg):
     xn = ops.nchw_to_nhwc(cu(x))
     assert_close("nchw_to_nhwc", xn, x.permute(0, 2, 3, 1))
     wp = ops.pack_conv_weight(cu(w))
-    y, stats = ops.conv2d_nhwc(xn, wp, cu(b), s, p, act=0, want_stats=True)
+    assert_close("pack", wp.ohwi, w.permute(0, 2, 3, 1), atol=0)
+    # split-bf16 (bf16x3) path: fp32-class accuracy; plain bf16: operand rounding only
+    y3, st3 = ops.conv2d_nhwc(xn, wp, cu(b), s, p, act=0, want_stats=True, precision="bf16x3")
+    assert_close("conv bf16x3", y3.permute(0, 3, 1, 2), ref, atol=6e-5, rtol=2e-5)
+    y1, _ = ops.conv2d_nhwc(xn, wp, cu(b), s, p, act=1, precision="bf16")
+    assert_close("conv bf16", y1.permute(0, 3, 1, 2), F.relu(ref), atol=3e-2, rtol=1e-2)
+    if Cout > 64 and (Cin * k[0] * k[1]) % 32 == 0:
+        assert_close("bf16x3 stats", st3.view(-1, 2, Cout).sum(0)[0], ref.sum((0, 2, 3)), atol=2e-3, rtol=1e-4)
+    y, stats = ops.conv2d_nhwc(xn, wp, cu(b), s, p, act=0, want_stats=True, precision="f32")
     assert_close("conv", y.permute(0, 3, 1, 2), ref, atol=2e-5, rtol=1e-5)
-    yr, _ = ops.conv2d_nhwc(xn, wp, cu(b), s, p, act=1)
+    yr, _ = ops.conv2d_nhwc(xn, wp, cu(b), s, p, act=1, precision="f32")
     assert_close("conv+relu", yr.permute(0, 3, 1, 2), F.relu(ref), atol=2e-5, rtol=1e-5)
     # BatchNorm (training): statistics from the conv epilogue, running-stat update, apply + residual + relu
     gamma, beta = rnd(Cout, seed=14) + 1.5, rnd(Cout, seed=15)
