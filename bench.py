@@ -171,7 +171,7 @@ def main():
             "value": world * args.batch * args.steps / elapsed,
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"auto": "f32 (K>=4096 conv reductions as split-bf16x3 MFMA, fp32 accumulate)", "f32": "f32",
+            "dtype": {"auto": "f32 (backbone conv reductions with K>=2304 as split-bf16x3 MFMA, fp32 accumulate)", "f32": "f32",
                       "bf16x3": "bf16x3 (split-bf16 MFMA, fp32 accumulate)", "bf16": "bf16"}[ops.CONV_PRECISION],
             "data": "synthetic",
             "config": {"workload": f"MRN loop B (router phase): {args.model.upper()} x {args.experts} frozen experts "
@@ -198,7 +198,7 @@ def main():
                            "launches_per_step": s_["launches"] / args.steps, "avg_launch_ms": avg_ms,
                            "algorithmic_gflop_per_launch": per_launch / 1e9,
                            "kernel_share_of_step": s_["total_ms"] / (elapsed * 1e3),
-                           "note": "experts run on concurrent HIP streams: event time per launch includes overlap with other experts' kernels"})
+                           })
             rl.sort(key=lambda r: -r["kernel_share_of_step"])
             res["roofline"] = rl[0]
             if len(rl) > 1:

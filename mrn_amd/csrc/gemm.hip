@@ -353,11 +353,8 @@ int mrn_gemm_launch(const GemmParams& p, bool conv, hipStream_t st) {
   static const int variant = getenv("MRN_GEMM_VARIANT") ? atoi(getenv("MRN_GEMM_VARIANT")) : 0;   // tuning experiments only
   if (p.N <= 32) return launch_cfg<4, 1, 1, 1, 16>(p, conv, st);
   if (p.N <= 64) return launch_cfg<4, 1, 1, 2, 16>(p, conv, st);
-  if (variant == 1) return launch_cfg<2, 2, 2, 2, 16>(p, conv, st);
-  if (variant == 2) return launch_cfg<2, 2, 2, 2, 16>(p, conv, st, 10 * 1024);   // 3 blocks/CU
-  if (variant == 3) return launch_cfg<2, 2, 2, 2, 16>(p, conv, st, 30 * 1024);   // 2 blocks/CU
-  if (variant == 4) return launch_cfg<2, 2, 2, 2, 16>(p, conv, st, 60 * 1024);   // 1 block/CU
-  return launch_cfg<2, 2, 2, 2, 32>(p, conv, st);
+  if (variant == 1) return launch_cfg<2, 2, 2, 2, 32>(p, conv, st);   // measured slower (4-way LDS store conflicts, 2 blocks/CU)
+  return launch_cfg<2, 2, 2, 2, 16>(p, conv, st);
 }
 
 // ---------------------------------------------------------------------------------------------

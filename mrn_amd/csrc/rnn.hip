@@ -16,52 +16,62 @@ namespace {
 constexpr int HID = 256;       // hidden size (reference configs: hidden_size=256)
 constexpr int BT = 16;         // samples per workgroup
 constexpr int HLD = HID + 4;   // padded LDS row
+constexpr int NW = 16;         // waves per workgroup: wave w owns hidden units [16w, 16w+16) of every gate
+constexpr int NTH = NW * 64;   // 1024 threads -- many waves in flight hide the L2 latency of the weight stream
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// acc[g][s] += A(16 x K from LDS rows of stride lda) . W[(g*HID + 64w + 16s + n)][k]   for K a multiple of 16.
-// The weight fragments of step q+1 are fetched (L2 -> registers) before the MFMAs of step q issue, so the L2
-// latency of the weight stream hides behind 16*NG MFMAs instead of stalling every step.
+// acc[g] += A(16 x K from LDS rows of stride lda) . W[(g*HID + 16*wave + n)][k]   for K a multiple of 16.
+// Weight fragments of step q+1 are fetched before the MFMAs of step q issue; consecutive MFMAs target different
+// accumulators (the 16x16x4 f32 MFMA has a 40-cycle dependent latency vs 32-cycle issue).
 template <int NG>
-__device__ __forceinline__ void mma_rows(f32x4 (&acc)[NG][4], const float* __restrict__ a_lds, int lda,
+__device__ __forceinline__ void mma_rows(f32x4 (&acc)[NG], const float* __restrict__ a_lds, int lda,
                                          const float* __restrict__ W, long ldw, int K, int wave, int lane) {
   const int n = lane & 15, g4 = (lane >> 4) * 4;
   const float* ap = a_lds + n * lda + g4;
-  const float* wp = W + (long)(wave * 64 + n) * ldw + g4;
-  f32x4 wv[NG][4];
+  const float* wp = W + (long)(wave * 16 + n) * ldw + g4;
+  f32x4 wv[NG];
 #pragma unroll
-  for (int g = 0; g < NG; ++g)
-#pragma unroll
-    for (int s = 0; s < 4; ++s) wv[g][s] = *reinterpret_cast<const f32x4*>(wp + (long)(g * HID + s * 16) * ldw);
+  for (int g = 0; g < NG; ++g) wv[g] = *reinterpret_cast<const f32x4*>(wp + (long)(g * HID) * ldw);
   const int Q = K / 16;
+#pragma unroll 1   // keep the one-step-ahead register pipeline; full unrolling hoists every load and spills
   for (int q = 0; q < Q; ++q) {
-    f32x4 wn[NG][4];
+    f32x4 wn[NG];
     const int qn = (q + 1 < Q) ? q + 1 : q;
 #pragma unroll
-    for (int g = 0; g < NG; ++g)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) wn[g][s] = *reinterpret_cast<const f32x4*>(wp + (long)(g * HID + s * 16) * ldw + qn * 16);
+    for (int g = 0; g < NG; ++g) wn[g] = *reinterpret_cast<const f32x4*>(wp + (long)(g * HID) * ldw + qn * 16);
     const f32x4 av = *reinterpret_cast<const f32x4*>(ap + q * 16);
 #pragma unroll
-    for (int g = 0; g < NG; ++g)
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+      for (int g = 0; g < NG; ++g) acc[g] = mfma4(av[r], wv[g][r], acc[g]);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[g][s] = mfma4(av[r], wv[g][s][r], acc[g][s]);
+    for (int g = 0; g < NG; ++g) wv[g] = wn[g];
+  }
+}
+
+__device__ __forceinline__ void lstm_pointwise(const f32x4 (&acc)[4], const float (&xg)[4][4], const float (&bh)[4],
+                                               float (&c)[4], float (&h)[4]) {
 #pragma unroll
-    for (int g = 0; g < NG; ++g)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) wv[g][s] = wn[g][s];
+  for (int r = 0; r < 4; ++r) {
+    const float gi = acc[0][r] + xg[0][r] + bh[0];
+    const float gf = acc[1][r] + xg[1][r] + bh[1];
+    const float gg = acc[2][r] + xg[2][r] + bh[2];
+    const float go = acc[3][r] + xg[3][r] + bh[3];
+    const float ig = sigmoidf_acc(gi), fg = sigmoidf_acc(gf), og = sigmoidf_acc(go);
+    const float cn = fg * c[r] + ig * tanhf(gg);
+    c[r] = cn;
+    h[r] = og * tanhf(cn);
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Bidirectional LSTM layer.  xproj[b][t][dir*4H + gate*H + j] already holds W_ih x + b_ih + b_hh.
+// Bidirectional LSTM layer.  xproj[b][t][dir*4H + gate*H + j] holds W_ih x + b_ih.
 // grid = (ceil(B/16), ndir); out[b][t][dir*H + j].
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void lstm_layer_kernel(const float* __restrict__ xproj, const float* __restrict__ w_hh,
+__global__ __launch_bounds__(NTH) void lstm_layer_kernel(const float* __restrict__ xproj, const float* __restrict__ w_hh,
                                                          const float* __restrict__ b_hh, float* __restrict__ out,
                                                          int B, int T, int ndir) {
   __shared__ __attribute__((aligned(16))) float h_lds[2][BT * HLD];
@@ -70,53 +80,37 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(const float* __restrict
   const int t_ = threadIdx.x, lane = t_ & 63, wave = t_ >> 6;
   const float* W = w_hh + (long)dir * 4 * HID * HID;
   const int col = lane & 15, rbase = (lane >> 4) * 4;
+  const int j = wave * 16 + col;               // this lane's hidden unit
 
-  for (int i = t_; i < BT * HLD; i += 256) h_lds[0][i] = 0.f;
-  float c[4][4], bh[4][4];   // cell state; recurrent bias of this lane's units, per gate
+  for (int i = t_; i < BT * HLD; i += NTH) h_lds[0][i] = 0.f;
+  float c[4] = {0.f, 0.f, 0.f, 0.f}, bh[4];
 #pragma unroll
-  for (int s = 0; s < 4; ++s)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) c[s][r] = 0.f;
-#pragma unroll
-  for (int g = 0; g < 4; ++g)
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-      bh[g][s] = b_hh ? b_hh[dir * 4 * HID + g * HID + wave * 64 + s * 16 + col] : 0.f;
+  for (int g = 0; g < 4; ++g) bh[g] = b_hh ? b_hh[dir * 4 * HID + g * HID + j] : 0.f;
   __syncthreads();
 
   for (int step = 0; step < T; ++step) {
     const int t = dir == 0 ? step : T - 1 - step;
     const int cur = step & 1;
-    f32x4 acc[4][4];
+    // input projections of this step: issued first, they land while the recurrent product runs
+    float xg[4][4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int r = 0; r < 4; ++r) {
+      const int b = b0 + rbase + r;
+      const float* xp = xproj + ((long)(b < B ? b : 0) * T + t) * (ndir * 4 * HID) + dir * 4 * HID + j;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) acc[g][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int g = 0; g < 4; ++g) xg[g][r] = xp[g * HID];
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
     mma_rows<4>(acc, h_lds[cur], HLD, W, HID, HID, wave, lane);
-
+    float h[4];
+    lstm_pointwise(acc, xg, bh, c, h);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int j = wave * 64 + s * 16 + col;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = rbase + r;
-        const int b = b0 + row;
-        float hv = 0.f;
-        if (b < B) {
-          const float* xp = xproj + ((long)b * T + t) * (ndir * 4 * HID) + dir * 4 * HID + j;
-          const float gi = acc[0][s][r] + xp[0] + bh[0][s];
-          const float gf = acc[1][s][r] + xp[HID] + bh[1][s];
-          const float gg = acc[2][s][r] + xp[2 * HID] + bh[2][s];
-          const float go = acc[3][s][r] + xp[3 * HID] + bh[3][s];
-          const float ig = sigmoidf_acc(gi), fg = sigmoidf_acc(gf), og = sigmoidf_acc(go);
-          const float cg = tanhf(gg);
-          const float cn = fg * c[s][r] + ig * cg;
-          c[s][r] = cn;
-          hv = og * tanhf(cn);
-          out[((long)b * T + t) * (ndir * HID) + dir * HID + j] = hv;
-        }
-        h_lds[cur ^ 1][row * HLD + j] = hv;
-      }
+    for (int r = 0; r < 4; ++r) {
+      const int row = rbase + r, b = b0 + row;
+      if (b < B) out[((long)b * T + t) * (ndir * HID) + dir * HID + j] = h[r];
+      h_lds[cur ^ 1][row * HLD + j] = b < B ? h[r] : 0.f;
     }
     __syncthreads();
   }
@@ -128,7 +122,7 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(const float* __restrict
 // into GEMMs by the caller).
 //   Hb     [B][T][D]      encoder states (D multiple of 16)
 //   Hproj  [B][T][HID]    i2h(Hb)
-//   eproj  [B][S][4*HID]  W_ih[:, D:] . emb(text) + b_ih + b_hh       (teacher forced)
+//   eproj  [B][S][4*HID]  W_ih[:, D:] . emb(text) + b_ih       (teacher forced)
 //   hid    [B][S][HID]    decoder hidden states (generator GEMM is applied afterwards)
 // Greedy mode (tokens fed back through argmax of the generator) uses the same kernel one step at a time:
 //   steps = 1, state carried in h_state / c_state.
@@ -152,7 +146,7 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return 1.f - 2.f / (e + 1.f);
 }
 
-__global__ __launch_bounds__(256) void attn_decoder_kernel(const AttnDecParams p) {
+__global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int D = p.D, T = p.T;
   const int CLD = D + 4;
@@ -165,50 +159,48 @@ __global__ __launch_bounds__(256) void attn_decoder_kernel(const AttnDecParams p
   const int b0 = blockIdx.x * BT;
   const int t_ = threadIdx.x, lane = t_ & 63, wave = t_ >> 6;
   const int col = lane & 15, rbase = (lane >> 4) * 4;
+  const int j = wave * 16 + col;
 
-  for (int i = t_; i < BT * HLD; i += 256) {
-    const int row = i / HLD, j = i - row * HLD;
+  for (int i = t_; i < BT * HLD; i += NTH) {
+    const int row = i / HLD, jj = i - row * HLD;
     const int b = b0 + row;
-    h_lds[i] = (p.h_state && b < p.B && j < HID) ? p.h_state[(long)b * HID + j] : 0.f;
+    h_lds[i] = (p.h_state && b < p.B && jj < HID) ? p.h_state[(long)b * HID + jj] : 0.f;
   }
-  for (int i = t_; i < HID; i += 256) sw_lds[i] = p.w_score[i];
-  float bh[4][4];
+  for (int i = t_; i < HID; i += NTH) sw_lds[i] = p.w_score[i];
+  float bh[4], c[4];
 #pragma unroll
-  for (int g = 0; g < 4; ++g)
+  for (int g = 0; g < 4; ++g) bh[g] = p.b_hh ? p.b_hh[g * HID + j] : 0.f;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) bh[g][s] = p.b_hh ? p.b_hh[g * HID + wave * 64 + s * 16 + col] : 0.f;
-  float c[4][4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int b = b0 + rbase + r;
-      const int j = wave * 64 + s * 16 + col;
-      c[s][r] = (p.c_state && b < p.B) ? p.c_state[(long)b * HID + j] : 0.f;
-    }
+  for (int r = 0; r < 4; ++r) {
+    const int b = b0 + rbase + r;
+    c[r] = (p.c_state && b < p.B) ? p.c_state[(long)b * HID + j] : 0.f;
+  }
+  const float bj = p.b_h2h[j];
   __syncthreads();
 
   for (int step = 0; step < p.S; ++step) {
+    // embedding half of the LSTMCell input projection for this step (lands during the phases below)
+    float xg[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int b = b0 + rbase + r;
+      const float* ep = p.eproj + (long)(b < p.B ? b : 0) * p.eproj_stride_b + (long)step * p.eproj_stride_s + j;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) xg[g][r] = ep[g * HID];
+    }
     // (1) hp = h2h(h) + bias
     {
-      f32x4 acc[1][4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) acc[0][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
       mma_rows<1>(acc, h_lds, HLD, p.w_h2h, HID, HID, wave, lane);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int j = wave * 64 + s * 16 + col;
-        const float bj = p.b_h2h[j];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) hp_lds[(rbase + r) * HLD + j] = acc[0][s][r] + bj;
-      }
+      for (int r = 0; r < 4; ++r) hp_lds[(rbase + r) * HLD + j] = acc[0][r] + bj;
     }
     __syncthreads();
     // (2) e[b][t] = score . tanh(Hproj[b][t] + hp[b]); one wave per (b, t) pair, 4 channels per lane, four pairs in
     //     flight per wave so the Hproj loads (L2) and the cross-lane reductions of different pairs overlap
     {
       const f32x4 wv = *reinterpret_cast<const f32x4*>(sw_lds + lane * 4);
-      for (int pr0 = wave * 4; pr0 < BT * T; pr0 += 16) {
+      for (int pr0 = wave * 4; pr0 < BT * T; pr0 += NW * 4) {
         f32x4 hv[4];
         int rows[4];
 #pragma unroll
@@ -241,8 +233,9 @@ __global__ __launch_bounds__(256) void attn_decoder_kernel(const AttnDecParams p
       }
     }
     __syncthreads();
-    // (3) softmax over t, one wave per 4 samples
-    for (int row = wave * 4; row < wave * 4 + 4; ++row) {
+    // (3) softmax over t, one wave per sample
+    {
+      const int row = wave;
       float m = -INFINITY;
       for (int t = lane; t < T; t += 64) m = fmaxf(m, e_lds[row * T + t]);
       m = wave_max(m);
@@ -263,19 +256,20 @@ __global__ __launch_bounds__(256) void attn_decoder_kernel(const AttnDecParams p
     }
     __syncthreads();
     // (4) context[b][:] = sum_t alpha[b][t] * Hb[b][t][:]
-    for (int it = t_; it < BT * (D / 4); it += 256) {
+    for (int it = t_; it < BT * (D / 4); it += NTH) {
       const int row = it / (D / 4), c4 = it - row * (D / 4);
       const int b = b0 + row;
       f32x4 a = {0.f, 0.f, 0.f, 0.f};
       if (b < p.B) {
         const float* hb = p.Hb + (long)b * T * D + c4 * 4;
         int t = 0;
-        for (; t + 8 <= T; t += 8) {                 // eight independent loads in flight
-          f32x4 v[8];
+#pragma unroll 1
+        for (; t + 4 <= T; t += 4) {                 // four independent loads in flight per lane, 16 waves per CU
+          f32x4 v[4];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(hb + (long)(t + u) * D);
+          for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(hb + (long)(t + u) * D);
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
+          for (int u = 0; u < 4; ++u) {
             const float w = e_lds[row * T + t + u];
 #pragma unroll
             for (int k = 0; k < 4; ++k) a[k] = fmaf(w, v[u][k], a[k]);
@@ -293,36 +287,19 @@ __global__ __launch_bounds__(256) void attn_decoder_kernel(const AttnDecParams p
     __syncthreads();
     // (5) gates = eproj + ctx . W_ih[:, :D]^T + h . W_hh^T ; (6) LSTM cell
     {
-      f32x4 acc[4][4];
+      f32x4 acc[4];
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc[g][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
       mma_rows<4>(acc, ctx_lds, CLD, p.w_ih, p.ld_wih, D, wave, lane);
       mma_rows<4>(acc, h_lds, HLD, p.w_hh, HID, HID, wave, lane);
       __syncthreads();  // every wave has finished reading h_lds
+      float h[4];
+      lstm_pointwise(acc, xg, bh, c, h);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int j = wave * 64 + s * 16 + col;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = rbase + r;
-          const int b = b0 + row;
-          float hv = 0.f;
-          if (b < p.B) {
-            const float* ep = p.eproj + (long)b * p.eproj_stride_b + (long)step * p.eproj_stride_s + j;
-            const float gi = acc[0][s][r] + ep[0] + bh[0][s];
-            const float gf = acc[1][s][r] + ep[HID] + bh[1][s];
-            const float gg = acc[2][s][r] + ep[2 * HID] + bh[2][s];
-            const float go = acc[3][s][r] + ep[3 * HID] + bh[3][s];
-            const float ig = sigmoidf_acc(gi), fg = sigmoidf_acc(gf), og = sigmoidf_acc(go);
-            const float cn = fg * c[s][r] + ig * tanhf(gg);
-            c[s][r] = cn;
-            hv = og * tanhf(cn);
-            p.hid[(long)b * p.hid_stride_b + (long)step * p.hid_stride_s + j] = hv;
-          }
-          h_lds[row * HLD + j] = hv;
-        }
+      for (int r = 0; r < 4; ++r) {
+        const int row = rbase + r, b = b0 + row;
+        if (b < p.B) p.hid[(long)b * p.hid_stride_b + (long)step * p.hid_stride_s + j] = h[r];
+        h_lds[row * HLD + j] = b < p.B ? h[r] : 0.f;
       }
     }
     __syncthreads();
@@ -330,16 +307,13 @@ __global__ __launch_bounds__(256) void attn_decoder_kernel(const AttnDecParams p
 
   if (p.h_state) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = rbase + r, b = b0 + row;
-        const int j = wave * 64 + s * 16 + col;
-        if (b < p.B) {
-          p.h_state[(long)b * HID + j] = h_lds[row * HLD + j];
-          p.c_state[(long)b * HID + j] = c[s][r];
-        }
+    for (int r = 0; r < 4; ++r) {
+      const int row = rbase + r, b = b0 + row;
+      if (b < p.B) {
+        p.h_state[(long)b * HID + j] = h_lds[row * HLD + j];
+        p.c_state[(long)b * HID + j] = c[r];
       }
+    }
   }
 }
 
@@ -362,7 +336,7 @@ MRN_EXPORT int mrn_lstm_layer_fwd_f32(const float* xproj, const float* w_hh, con
   MRN_CHECK_ARG(hidden == HID, "mrn_lstm_layer_fwd_f32: hidden=%d unsupported (library is built for %d)", hidden, HID);
   MRN_CHECK_ARG(ndir == 1 || ndir == 2, "mrn_lstm_layer_fwd_f32: ndir=%d", ndir);
   if (B == 0 || T == 0) return MRN_OK;
-  hipLaunchKernelGGL(lstm_layer_kernel, dim3(ceil_div(B, BT), ndir), dim3(256), 0, (hipStream_t)stream, xproj, w_hh, b_hh,
+  hipLaunchKernelGGL(lstm_layer_kernel, dim3(ceil_div(B, BT), ndir), dim3(NTH), 0, (hipStream_t)stream, xproj, w_hh, b_hh,
                      out, B, T, ndir);
   MRN_LAUNCH_CHECK("lstm_layer");
   return MRN_OK;
@@ -389,7 +363,7 @@ MRN_EXPORT int mrn_attn_decoder_fwd_f32(const float* Hb, const float* Hproj, con
   MRN_CHECK_ARG(lds <= 160 * 1024, "mrn_attn_decoder_fwd_f32: LDS budget exceeded (D=%d T=%d)", D, T);
   if (lds > 64 * 1024)
     hipFuncSetAttribute((const void*)attn_decoder_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(attn_decoder_kernel, dim3(ceil_div(B, BT)), dim3(256), lds, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(attn_decoder_kernel, dim3(ceil_div(B, BT)), dim3(NTH), lds, (hipStream_t)stream, p);
   MRN_LAUNCH_CHECK("attn_decoder");
   return MRN_OK;
 }

@@ -59,17 +59,19 @@ def bn_scale_shift(bn, stats, count):
     return ops.bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
 
 
-def conv_block(x, conv, bn=None, relu=True, residual=None, pool=None):
+def conv_block(x, conv, bn=None, relu=True, residual=None, pool=None, precision=None):
     """x NHWC -> conv (+bias) [-> BatchNorm] [-> +residual] [-> ReLU] [-> MaxPool], NHWC.
     pool = (kernel, stride, padding) fuses BN-apply + ReLU into the pooling pass."""
     w = packed_weight(conv)
     stride, padding = _pair(conv.stride), _pair(conv.padding)
     if bn is None:
-        y, _ = ops.conv2d_nhwc(x, w, conv.bias, stride, padding, act=ops.ACT_RELU if relu else ops.ACT_NONE)
+        y, _ = ops.conv2d_nhwc(x, w, conv.bias, stride, padding, act=ops.ACT_RELU if relu else ops.ACT_NONE,
+                               precision=precision)
         if pool is not None:
             y = ops.maxpool_nhwc(y, *pool)
         return y
-    y, stats = ops.conv2d_nhwc(x, w, conv.bias, stride, padding, act=ops.ACT_NONE, want_stats=bn.training)
+    y, stats = ops.conv2d_nhwc(x, w, conv.bias, stride, padding, act=ops.ACT_NONE, want_stats=bn.training,
+                               precision=precision)
     count = y.shape[0] * y.shape[1] * y.shape[2]
     scale, shift = bn_scale_shift(bn, stats, count)
     if pool is not None and residual is None:

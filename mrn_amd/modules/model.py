@@ -55,8 +55,8 @@ class Model_Extractor(nn.Module):
             print("No SequenceModeling module specified")
         self.SequenceModeling_output = opt.hidden_size
 
-    def forward(self, image, out=None):
-        """image [B,C,H,W] -> contextual feature [B,T,hidden]; `out` = optional (strided) destination."""
+    def visual(self, image):
+        """Transformation + FeatureExtraction (+ the reference's permute / AdaptiveAvgPool / squeeze): [B,C,H,W] -> [B,T,C']"""
         if not self.stages["Trans"] == "None":
             image = self.Transformation(image)
         fmap = self.FeatureExtraction(image)                 # logical [B,C,H,W], NHWC memory
@@ -64,12 +64,19 @@ class Model_Extractor(nn.Module):
         if H != 1:
             raise NotImplementedError("HIP path expects a height-1 feature map (32x256 inputs); got H=%d" % H)
         # permute(0,3,1,2) + AdaptiveAvgPool((None,1)) + squeeze(3) of the reference is the identity on [B,1,W,C]
-        visual = to_nhwc(fmap).view(B, W, C)
+        return to_nhwc(fmap).view(B, W, C)
+
+    def sequence(self, visual, out=None):
+        """SequenceModeling stage: [B,T,C'] -> [B,T,hidden]; `out` = optional (strided) destination."""
         if self.stages["Seq"] == "BiLSTM":
             x = self.SequenceModeling[0](visual)
             return self.SequenceModeling[1](x, out=out)
         lin = self.SequenceModeling[0]
         return ops.linear(visual, lin.weight, lin.bias, out=out)
+
+    def forward(self, image, out=None):
+        """image [B,C,H,W] -> contextual feature [B,T,hidden]"""
+        return self.sequence(self.visual(image), out=out)
 
 
 class Model(nn.Module):
@@ -93,7 +100,11 @@ class Model(nn.Module):
         self.Prediction.to(device)
 
     def forward(self, image, text=None, is_train=True, feature_out=None, predict_out=None):
-        feat = self.model(image, out=feature_out)
+        return self.heads(self.model.visual(image), text, is_train, feature_out, predict_out)
+
+    def heads(self, visual, text=None, is_train=True, feature_out=None, predict_out=None):
+        """SequenceModeling + Prediction on precomputed backbone features"""
+        feat = self.model.sequence(visual, out=feature_out)
         if self.stages["Pred"] == "CTC":
             pred = ops.linear(feat, self.Prediction.weight, self.Prediction.bias, out=predict_out)
         else:
@@ -182,14 +193,17 @@ class MRNNet(nn.Module):
         logits = [ops.padded_rows(B, T_pred, expert.fc.out_features, dev) for expert in self.model]
         with torch.no_grad():
             if self.expert_streams and I > 1:
-                # experts are independent: one HIP stream each, so the latency-bound recurrent kernels of one expert
-                # (16-32 workgroups) overlap with the conv GEMMs of the others instead of idling 90 % of the CUs
+                # Phase 1, one stream: the conv backbones -- every kernel fills the chip, nothing to gain from overlap.
+                # Phase 2, one HIP stream per expert: BiLSTM / attention decoder are latency-bound launches of 16-32
+                # workgroups each; the six experts' recurrences run side by side instead of idling 90 % of the CUs.
+                visuals = [expert.model.visual(image) for expert in self.model]
                 main = torch.cuda.current_stream()
                 streams = self._streams(I, dev)
                 for i, expert in enumerate(self.model):
                     streams[i].wait_stream(main)
                     with torch.cuda.stream(streams[i]):
-                        expert(image, text, is_train, feature_out=feats[:, :, i, :], predict_out=logits[i])
+                        expert.heads(visuals[i], text, is_train, feature_out=feats[:, :, i, :], predict_out=logits[i])
+                        visuals[i].record_stream(streams[i])
                 for st in streams[:I]:
                     main.wait_stream(st)
             else:

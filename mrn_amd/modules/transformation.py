@@ -45,10 +45,11 @@ class LocalizationNetwork(nn.Module):
     def forward_nhwc(self, x):
         c = self.conv
         pool = ((2, 2), (2, 2), (0, 0))
-        x = conv_block(x, c[0], c[1], pool=pool)
-        x = conv_block(x, c[4], c[5], pool=pool)
-        x = conv_block(x, c[8], c[9], pool=pool)
-        x = conv_block(x, c[12], c[13])
+        # exact fp32 throughout: the fiducials feed an ill-conditioned grid + sampler
+        x = conv_block(x, c[0], c[1], pool=pool, precision="f32")
+        x = conv_block(x, c[4], c[5], pool=pool, precision="f32")
+        x = conv_block(x, c[8], c[9], pool=pool, precision="f32")
+        x = conv_block(x, c[12], c[13], precision="f32")
         x = ops.avgpool_nhwc(x)                                                     # [B,512]
         x = ops.linear(x, self.localization_fc1[0].weight, self.localization_fc1[0].bias, act=ops.ACT_RELU)
         x = ops.linear(x, self.localization_fc2.weight, self.localization_fc2.bias)

@@ -43,14 +43,14 @@ CONV_TIMER = None            # set to a KernelTimer by bench.py
 
 # Arithmetic of the large implicit-GEMM convs (Cout > 64, K % 32 == 0):
 #   "f32"    exact fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere
-#   "auto"   (default) split-bf16x3 MFMA for the deep reductions (K >= 4096: 79 % of a TRBA expert's FLOPs), exact fp32
-#            elsewhere.  Measured against the reference: router weights / fused logits within 1.2e-5 -- the TPS
-#            localisation net and the shallow layers, whose errors the grid sampler and small-batch BatchNorm amplify,
-#            stay exact, so the 1e-4 parity band holds with a 10x margin.
+#   "auto"   (default) split-bf16x3 MFMA for the deep reductions of the backbones (K >= 2304: 90 % of a TRBA expert's
+#            conv FLOPs), exact fp32 for the shallow layers and for the whole TPS localisation network (callers pass
+#            precision="f32" there: the grid sampler amplifies its errors).  Emulated on the reference over several
+#            batches: router weights within 3.7e-5 and fused logits within 5.1e-5 of the fp32 path (1e-4 band).
 #   "bf16x3" split-bf16x3 for every eligible conv: ~1e-4 on fused logits (edge of the band; performance mode)
 #   "bf16"   plain bf16 operands (hi only), fp32 accumulate: ~2e-2 on features
 CONV_PRECISION = "auto"
-AUTO_SPLIT_MIN_K = 4096
+AUTO_SPLIT_MIN_K = 2304
 
 
 class PackedConvWeight:
