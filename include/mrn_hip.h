@@ -96,18 +96,21 @@ int mrn_tps_grid_sample_f32(const float* img_nhwc, const float* cprime, const fl
 /* ---- recurrent ------------------------------------------------------------------------------------------ */
 
 /* One (bi)directional LSTM layer given xproj = x W_ih^T + b_ih laid out [B][T][ndir*4*hidden]
- * (gate order i,f,g,o), w_hh [ndir][4*hidden][hidden], b_hh [ndir*4*hidden] or NULL; out [B][T][ndir*hidden].
+ * (gate order i,f,g,o), b_hh [ndir*4*hidden] or NULL; out [B][T][ndir*hidden].  w_hh is [ndir][4*hidden][hidden] in the
+ * FRAGMENT-MAJOR order the kernel streams (one contiguous 1 KiB line per wave load):
+ *   packed[dir][w][g][q][lane][r] = W[dir][g*hidden + 16w + (lane&15)][16q + 4(lane>>4) + r],  w<16, g<4, q<hidden/16.
  * modules/sequence_modeling.py:7-21 (nn.LSTM(bidirectional=True, batch_first=True)). */
 int mrn_lstm_layer_fwd_f32(const float* xproj, const float* w_hh, const float* b_hh, float* out, int B, int T,
                            int hidden, int ndir, void* stream);
 
 /* Attention decoder, S steps in one launch (modules/prediction.py:58-68 teacher forced; :78-86 greedy when
  * called with S = 1 and carried h_state/c_state).  Hb [B][T][D], Hproj = i2h(Hb) [B][T][hidden],
- * eproj = W_ih[:, D:] emb + b_ih (strided [B][S][4*hidden]), b_hh [4*hidden] or NULL, w_ih [4*hidden][ld_wih] (context part =
- * first D columns), hid out (strided [B][S][hidden]); alpha_out optional [B][S][T]. */
+ * eproj = W_ih[:, D:] emb + b_ih (strided [B][S][4*hidden]), b_hh [4*hidden] or NULL, hid out (strided [B][S][hidden]);
+ * alpha_out optional [B][S][T].  w_h2h [hidden][hidden], w_ih_ctx = W_ih[:, :D] and w_hh [4*hidden][hidden] are
+ * fragment-major (see mrn_lstm_layer_fwd_f32; one gate group for w_h2h, K = D for w_ih_ctx). */
 int mrn_attn_decoder_fwd_f32(const float* Hb, const float* Hproj, const float* eproj, int64_t eproj_stride_b,
                              int64_t eproj_stride_s, const float* w_h2h, const float* b_h2h,
-                             const float* w_score, const float* w_ih, int64_t ld_wih, const float* w_hh,
+                             const float* w_score, const float* w_ih_ctx, const float* w_hh,
                              const float* b_hh, float* hid, int64_t hid_stride_b, int64_t hid_stride_s, float* h_state,
                              float* c_state, float* alpha_out, int B, int T, int D, int S, int hidden,
                              void* stream);

@@ -23,25 +23,28 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// acc[g] += A(16 x K from LDS rows of stride lda) . W[(g*HID + 16*wave + n)][k]   for K a multiple of 16.
+// acc[g] += A(16 x K from LDS rows of stride lda) . W_g^T   for K a multiple of 16.
+// W is FRAGMENT-MAJOR: Wp[((wave*NG + g)*Q + q)*64 + lane] is the float4 the lane feeds to the four MFMAs of k-step q,
+//   = W[g*HID + 16*wave + (lane&15)][16q + 4*(lane>>4) .. +3]
+// so every wave-level load is one contiguous 1 KiB line instead of 16 rows x 64 B (pack_fragment_major on the host).
 // Weight fragments of step q+1 are fetched before the MFMAs of step q issue; consecutive MFMAs target different
 // accumulators (the 16x16x4 f32 MFMA has a 40-cycle dependent latency vs 32-cycle issue).
 template <int NG>
 __device__ __forceinline__ void mma_rows(f32x4 (&acc)[NG], const float* __restrict__ a_lds, int lda,
-                                         const float* __restrict__ W, long ldw, int K, int wave, int lane) {
+                                         const float* __restrict__ Wp, int K, int wave, int lane) {
   const int n = lane & 15, g4 = (lane >> 4) * 4;
   const float* ap = a_lds + n * lda + g4;
-  const float* wp = W + (long)(wave * 16 + n) * ldw + g4;
+  const int Q = K / 16;
+  const f32x4* wp = reinterpret_cast<const f32x4*>(Wp) + (long)wave * NG * Q * 64 + lane;
   f32x4 wv[NG];
 #pragma unroll
-  for (int g = 0; g < NG; ++g) wv[g] = *reinterpret_cast<const f32x4*>(wp + (long)(g * HID) * ldw);
-  const int Q = K / 16;
+  for (int g = 0; g < NG; ++g) wv[g] = wp[(long)g * Q * 64];
 #pragma unroll 1   // keep the one-step-ahead register pipeline; full unrolling hoists every load and spills
   for (int q = 0; q < Q; ++q) {
     f32x4 wn[NG];
     const int qn = (q + 1 < Q) ? q + 1 : q;
 #pragma unroll
-    for (int g = 0; g < NG; ++g) wn[g] = *reinterpret_cast<const f32x4*>(wp + (long)(g * HID) * ldw + qn * 16);
+    for (int g = 0; g < NG; ++g) wn[g] = wp[((long)g * Q + qn) * 64];
     const f32x4 av = *reinterpret_cast<const f32x4*>(ap + q * 16);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(NTH) void lstm_layer_kernel(const float* __restrict
     f32x4 acc[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-    mma_rows<4>(acc, h_lds[cur], HLD, W, HID, HID, wave, lane);
+    mma_rows<4>(acc, h_lds[cur], HLD, W, HID, wave, lane);
     float h[4];
     lstm_pointwise(acc, xg, bh, c, h);
 #pragma unroll
@@ -130,8 +133,8 @@ __global__ __launch_bounds__(NTH) void lstm_layer_kernel(const float* __restrict
 struct AttnDecParams {
   const float* Hb; const float* Hproj; const float* eproj;
   const float* w_h2h; const float* b_h2h; const float* w_score;
-  const float* w_ih; long ld_wih;   // LSTMCell weight_ih [4H][D+E], context part = first D columns
-  const float* w_hh;                // [4H][HID]
+  const float* w_ih;                // context part of LSTMCell weight_ih ([4H][D]), fragment-major
+  const float* w_hh;                // [4H][HID], fragment-major (w_h2h too)
   const float* b_hh;                // optional [4H] (eproj already carries b_ih)
   float* hid;
   float* h_state; float* c_state;   // optional [B][HID] carried state (nullptr: start from zero, do not store)
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecParams p
     // (1) hp = h2h(h) + bias
     {
       f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
-      mma_rows<1>(acc, h_lds, HLD, p.w_h2h, HID, HID, wave, lane);
+      mma_rows<1>(acc, h_lds, HLD, p.w_h2h, HID, wave, lane);
 #pragma unroll
       for (int r = 0; r < 4; ++r) hp_lds[(rbase + r) * HLD + j] = acc[0][r] + bj;
     }
@@ -290,8 +293,8 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecParams p
       f32x4 acc[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-      mma_rows<4>(acc, ctx_lds, CLD, p.w_ih, p.ld_wih, D, wave, lane);
-      mma_rows<4>(acc, h_lds, HLD, p.w_hh, HID, HID, wave, lane);
+      mma_rows<4>(acc, ctx_lds, CLD, p.w_ih, D, wave, lane);
+      mma_rows<4>(acc, h_lds, HLD, p.w_hh, HID, wave, lane);
       __syncthreads();  // every wave has finished reading h_lds
       float h[4];
       lstm_pointwise(acc, xg, bh, c, h);
@@ -344,18 +347,18 @@ MRN_EXPORT int mrn_lstm_layer_fwd_f32(const float* xproj, const float* w_hh, con
 
 MRN_EXPORT int mrn_attn_decoder_fwd_f32(const float* Hb, const float* Hproj, const float* eproj, int64_t eproj_stride_b,
                                         int64_t eproj_stride_s, const float* w_h2h, const float* b_h2h,
-                                        const float* w_score, const float* w_ih, int64_t ld_wih, const float* w_hh,
+                                        const float* w_score, const float* w_ih_ctx, const float* w_hh,
                                         const float* b_hh, float* hid, int64_t hid_stride_b, int64_t hid_stride_s, float* h_state,
                                         float* c_state, float* alpha_out, int B, int T, int D, int S, int hidden,
                                         void* stream) {
-  MRN_CHECK_ARG(Hb && Hproj && eproj && w_h2h && b_h2h && w_score && w_ih && w_hh && hid, "mrn_attn_decoder_fwd_f32: null operand");
+  MRN_CHECK_ARG(Hb && Hproj && eproj && w_h2h && b_h2h && w_score && w_ih_ctx && w_hh && hid, "mrn_attn_decoder_fwd_f32: null operand");
   MRN_CHECK_ARG(hidden == HID, "mrn_attn_decoder_fwd_f32: hidden=%d unsupported (library is built for %d)", hidden, HID);
-  MRN_CHECK_ARG(D % 16 == 0 && D > 0 && ld_wih % 4 == 0, "mrn_attn_decoder_fwd_f32: D=%d / ld=%ld must be multiples of 16 / 4", D, (long)ld_wih);
+  MRN_CHECK_ARG(D % 16 == 0 && D > 0, "mrn_attn_decoder_fwd_f32: D=%d must be a multiple of 16", D);
   MRN_CHECK_ARG((h_state == nullptr) == (c_state == nullptr), "mrn_attn_decoder_fwd_f32: h_state/c_state must come together");
   if (B == 0 || S == 0) return MRN_OK;
   AttnDecParams p;
   p.Hb = Hb; p.Hproj = Hproj; p.eproj = eproj; p.w_h2h = w_h2h; p.b_h2h = b_h2h; p.w_score = w_score;
-  p.w_ih = w_ih; p.ld_wih = ld_wih; p.w_hh = w_hh; p.b_hh = b_hh; p.hid = hid; p.h_state = h_state; p.c_state = c_state;
+  p.w_ih = w_ih_ctx; p.w_hh = w_hh; p.b_hh = b_hh; p.hid = hid; p.h_state = h_state; p.c_state = c_state;
   p.alpha_out = alpha_out; p.B = B; p.T = T; p.D = D; p.S = S;
   p.eproj_stride_b = eproj_stride_b; p.eproj_stride_s = eproj_stride_s;
   p.hid_stride_b = hid_stride_b; p.hid_stride_s = hid_stride_s;

@@ -36,12 +36,26 @@ class Attention(nn.Module):
     def cut_unknown(self, index):
         return torch.where(index >= self.num_class, 0, index)
 
+    def _packed(self):
+        """fragment-major copies of the three recurrent weight streams (rebuilt when a parameter changes)"""
+        cell = self.attention_cell
+        ps = (cell.h2h.weight, cell.rnn.weight_ih, cell.rnn.weight_hh)
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        cache = getattr(self, "_mrn_packed", None)
+        if cache is None or cache[0] != key:
+            with torch.no_grad():
+                D = cell.input_size
+                packed = (ops.pack_fragment_major(ps[0]), ops.pack_fragment_major(ps[1][:, :D]),
+                          ops.pack_fragment_major(ps[2]))
+            cache = (key, packed)
+            self._mrn_packed = cache
+        return cache[1]
+
     def _decode(self, batch_H, Hproj, eproj, hid=None, h=None, c=None):
         cell = self.attention_cell
-        D = cell.input_size
-        return ops.attn_decoder(batch_H, Hproj, eproj, cell.h2h.weight, cell.h2h.bias, cell.score.weight,
-                                cell.rnn.weight_ih, cell.rnn.weight_hh, cell.rnn.bias_hh, self.hidden_size,
-                                hid=hid, h_state=h, c_state=c)
+        w_h2h, w_ih_ctx, w_hh = self._packed()
+        return ops.attn_decoder(batch_H, Hproj, eproj, w_h2h, cell.h2h.bias, cell.score.weight,
+                                w_ih_ctx, w_hh, cell.rnn.bias_hh, self.hidden_size, hid=hid, h_state=h, c_state=c)
 
     def forward(self, batch_H, text, is_train=True, batch_max_length=25, out=None):
         """batch_H [B,T,D]; text [B,S] (teacher forcing) or [B] of [SOS] (greedy) -> logits [B,S,num_class].

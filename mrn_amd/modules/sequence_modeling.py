@@ -26,7 +26,7 @@ class BidirectionalLSTM(nn.Module):
         if cache is None or cache[0] != key:
             with torch.no_grad():
                 w_ih = torch.cat([ps[0], ps[1]], 0).contiguous()            # [2*4H, in]
-                w_hh = torch.stack([ps[2], ps[3]], 0).contiguous()          # [2, 4H, H]
+                w_hh = torch.stack([ops.pack_fragment_major(ps[2]), ops.pack_fragment_major(ps[3])], 0).contiguous()
                 b_ih = torch.cat([ps[4], ps[6]], 0).contiguous()
                 b_hh = torch.cat([ps[5], ps[7]], 0).contiguous()
             cache = (key, (w_ih, w_hh, b_ih, b_hh))

@@ -267,8 +267,18 @@ def tps_grid_sample(img_nhwc, cprime, inv_delta_c, p_hat, out_hw, want_grid=Fals
 # ---------------------------------------------------------------------------------------------------------
 # recurrent
 # ---------------------------------------------------------------------------------------------------------
+def pack_fragment_major(w, hidden=256):
+    """[G*hidden, K] weight (G gate groups, K % 16 == 0) -> the fragment-major stream order of the recurrent kernels:
+    packed[w][g][q][lane = gg*16 + n][r] = W[g*hidden + 16w + n][16q + 4gg + r]  (pure data movement)."""
+    G = w.shape[0] // hidden
+    K = w.shape[1]
+    assert w.shape[0] == G * hidden and hidden == 256 and K % 16 == 0
+    v = w.reshape(G, 16, 16, K // 16, 4, 4)              # g, w, n, q, gg, r
+    return v.permute(1, 0, 3, 4, 2, 5).contiguous()      # w, g, q, gg, n, r
+
+
 def lstm_layer(xproj, w_hh, b_hh, hidden, ndir):
-    """xproj [B,T,ndir*4H] (= x W_ih^T + b_ih), w_hh [ndir,4H,H], b_hh [ndir*4H] or None -> [B,T,ndir*H]"""
+    """xproj [B,T,ndir*4H] (= x W_ih^T + b_ih), w_hh: ndir stacked pack_fragment_major([4H,H]), b_hh [ndir*4H] or None"""
     _chk(xproj, w_hh, b_hh)
     B, T, _ = xproj.shape
     out = torch.empty(B, T, ndir * hidden, device=xproj.device, dtype=torch.float32)
@@ -288,15 +298,16 @@ def embed_gather(idx, table, num_class):
 
 def attn_decoder(Hb, Hproj, eproj, w_h2h, b_h2h, w_score, w_ih, w_hh, b_hh, hidden, hid=None, h_state=None,
                  c_state=None, want_alpha=False):
+    """w_h2h, w_ih (= W_ih[:, :D]) and w_hh must be pack_fragment_major()'d"""
     _chk(Hb, Hproj, eproj, w_h2h, b_h2h, w_score, w_ih, w_hh, b_hh)
     B, T, D = Hb.shape
     S = eproj.shape[1]
     if hid is None:
         hid = torch.empty(B, S, hidden, device=Hb.device, dtype=torch.float32)
     alpha = torch.empty(B, S, T, device=Hb.device, dtype=torch.float32) if want_alpha else None
-    assert eproj.stride(2) == 1 and hid.stride(2) == 1 and w_ih.stride(1) == 1
+    assert eproj.stride(2) == 1 and hid.stride(2) == 1 and w_ih.is_contiguous() and w_hh.is_contiguous()
     call("mrn_attn_decoder_fwd_f32", _p(Hb), _p(Hproj), _p(eproj), eproj.stride(0), eproj.stride(1), _p(w_h2h),
-         _p(b_h2h), _p(w_score), _p(w_ih), w_ih.stride(0), _p(w_hh), _p(b_hh), _p(hid), hid.stride(0), hid.stride(1),
+         _p(b_h2h), _p(w_score), _p(w_ih), _p(w_hh), _p(b_hh), _p(hid), hid.stride(0), hid.stride(1),
          _p(h_state), _p(c_state), _p(alpha), B, T, D, S, hidden, _stream())
     return (hid, alpha) if want_alpha else hid
 

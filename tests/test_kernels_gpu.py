@@ -160,7 +160,8 @@ def test_bilstm_layer(ops):
                      _lstm_dir(x, P["wi_r"], P["wh_r"], P["bi_r"], P["bh_r"], True)], 2)
     w_ih = cu(torch.cat([P["wi"], P["wi_r"]], 0))
     xproj = ops.linear(cu(x), w_ih, cu(torch.cat([P["bi"], P["bi_r"]])))
-    out = ops.lstm_layer(xproj, cu(torch.stack([P["wh"], P["wh_r"]])), cu(torch.cat([P["bh"], P["bh_r"]])), Hd, 2)
+    w_hh = torch.stack([ops.pack_fragment_major(cu(P["wh"])), ops.pack_fragment_major(cu(P["wh_r"]))])
+    out = ops.lstm_layer(xproj, w_hh, cu(torch.cat([P["bh"], P["bh_r"]])), Hd, 2)
     assert_close("bilstm", out, ref, atol=2e-5)
 
 
