@@ -56,6 +56,29 @@ int mrn_conv2d_nhwc_bf16split(const float* x, const void* w_hi, const void* w_lo
 /* fp32 [n] -> bf16 hi[n], lo[n] with hi = bf16(x), lo = bf16(x - hi) */
 int mrn_split_weight_bf16(const float* w, void* hi, void* lo, int64_t n, void* stream);
 
+/* Convolution backward (loss.backward() through Conv2d, il_modules/mrn.py:260-261):
+ *   data gradient  = mrn_conv2d_nhwc_* of dy (zero-dilated by the stride, mrn_dilate_nhwc_f32) with the flipped /
+ *                    transposed weight from mrn_pack_dgrad_weight_f32 and padding (k-1-p);
+ *   weight gradient = mrn_conv2d_wgrad_f32: split-K partial slabs [splits][Cout][kh*kw*Cin] (column-sum them),
+ *                    then mrn_unpack_conv_weight_f32 back to the parameter's [O][I][kh][kw] layout. */
+int mrn_conv2d_wgrad_f32(const float* dy, const float* x, float* dw_partial, int B, int H, int W, int Cin, int Cout,
+                         int kh, int kw, int sh, int sw, int ph, int pw, int splits, void* stream);
+int mrn_pack_dgrad_weight_f32(const float* w_ohwi, float* wt_ihwo, int O, int I, int kh, int kw, void* stream);
+int mrn_unpack_conv_weight_f32(const float* g_ohwi, float* g_oihw, int O, int I, int kh, int kw, int accumulate,
+                               void* stream);
+int mrn_dilate_nhwc_f32(const float* dy, float* out, int B, int Ho, int Wo, int C, int sh, int sw, void* stream);
+/* BatchNorm2d (training) backward with the ReLU mask fused: g = dz * (z > 0); partial per-channel sums of g and
+ * g*xhat (reduce), then dy = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)) and dres = g (apply). */
+int64_t mrn_bn_bwd_blocks(int64_t rows);
+int mrn_bn_bwd_reduce_f32(const float* dz, const float* z, const float* y, const float* mean, const float* invstd,
+                          float* partials, int64_t rows, int C, int relu, void* stream);
+int mrn_bn_bwd_apply_f32(const float* dz, const float* z, const float* y, const float* mean, const float* invstd,
+                         const float* gamma, const float* sums, float* dy, float* dres, int64_t rows, int C, int relu,
+                         void* stream);
+/* MaxPool2d backward: dx (zero-initialised) += dy at the first maximum of each window */
+int mrn_maxpool_bwd_nhwc_f32(const float* dy, const float* x, float* dx_zeroed, int B, int H, int W, int C, int kh, int kw,
+                             int sh, int sw, int ph, int pw, void* stream);
+
 /* conv weight repack [O][I][kh][kw] (state_dict layout) -> [O][kh][kw][I] */
 int mrn_pack_conv_weight_f32(const float* w_oihw, float* w_ohwi, int O, int I, int kh, int kw, void* stream);
 
@@ -100,8 +123,13 @@ int mrn_tps_grid_sample_f32(const float* img_nhwc, const float* cprime, const fl
  * FRAGMENT-MAJOR order the kernel streams (one contiguous 1 KiB line per wave load):
  *   packed[dir][w][g][q][lane][r] = W[dir][g*hidden + 16w + (lane&15)][16q + 4(lane>>4) + r],  w<16, g<4, q<hidden/16.
  * modules/sequence_modeling.py:7-21 (nn.LSTM(bidirectional=True, batch_first=True)). */
-int mrn_lstm_layer_fwd_f32(const float* xproj, const float* w_hh, const float* b_hh, float* out, int B, int T,
-                           int hidden, int ndir, void* stream);
+int mrn_lstm_layer_fwd_f32(const float* xproj, const float* w_hh, const float* b_hh, float* out, float* gates_out,
+                           float* c_out, int B, int T, int hidden, int ndir, void* stream);
+/* Backward through time of the same layer.  gates [B][T][ndir][4*hidden] (post-activation i,f,g,o) and cseq
+ * [B][T][ndir][hidden] are the forward's optional outputs; w_hhT = fragment-major W_hh^T per direction (rows = hidden
+ * units, K = 4*hidden); dgates receives the gradient of the gate pre-activations (dW_ih, dW_hh, db, dx follow as GEMMs). */
+int mrn_lstm_layer_bwd_f32(const float* dout, const float* gates, const float* cseq, const float* w_hhT, float* dgates,
+                           int B, int T, int hidden, int ndir, void* stream);
 
 /* Attention decoder, S steps in one launch (modules/prediction.py:58-68 teacher forced; :78-86 greedy when
  * called with S = 1 and carried h_state/c_state).  Hb [B][T][D], Hproj = i2h(Hb) [B][T][hidden],
@@ -136,7 +164,8 @@ int mrn_colnorm_fwd_f32(const float* x, const float* gamma, const float* beta, f
 /* partials [B*ceil(Wd/256)][2][P] */
 int mrn_colnorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                         float* dx, int accumulate, float* partials, int B, int P, int Wd, void* stream);
-/* elementwise on strided rows: op 0 y=gelu(a) (dm_router.py:42), 1 y=b*gelu'(a), 2 y=a*b (:17,:33), 3 y=a+b */
+/* elementwise on strided rows: op 0 y=gelu(a) (dm_router.py:42), 1 y=b*gelu'(a), 2 y=a*b (:17,:33), 3 y=a+b,
+ * 4 y=b*(a>0) (ReLU backward) */
 int mrn_ew_rows_f32(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy, int64_t rows,
                     int C, int op, void* stream);
 /* out[c] (+)= sum_r in[r][c] (bias / affine gradients, split-K combine); workspace: chunks*C floats */

@@ -1,0 +1,323 @@
+// Backward kernels of the expert stages (loop A, reference il_modules/mrn.py:260-261 `loss.backward()` through
+// modules/feature_extraction.py, modules/sequence_modeling.py): data-gradient weight packing, BatchNorm2d (training)
+// backward fused with the ReLU mask, max-pool backward, LSTM backward-through-time.
+// Convolution data / weight gradients themselves are implicit GEMMs on the forward kernels (gemm.hip):
+//   dgrad = conv(dy, flipped-transposed weight), wgrad = mrn_conv2d_wgrad_f32.
+#include "common.hpp"
+
+namespace {
+
+// w [O][kh][kw][I] -> wt [I][kh][kw][O] with both taps flipped (the weight of the data-gradient convolution)
+__global__ void pack_dgrad_weight_kernel(const float* __restrict__ w, float* __restrict__ wt, int O, int I, int kh, int kw) {
+  const long n = (long)O * I * kh * kw;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int co = (int)(i % O);
+    long r = i / O;
+    const int kx = (int)(r % kw);
+    r /= kw;
+    const int ky = (int)(r % kh);
+    const int ci = (int)(r / kh);
+    wt[i] = w[(((long)co * kh + (kh - 1 - ky)) * kw + (kw - 1 - kx)) * I + ci];
+  }
+}
+
+// [O][kh][kw][I] -> [O][I][kh][kw] (gradient back to the parameter's layout), optionally accumulating
+__global__ void unpack_ohwi_oihw_kernel(const float* __restrict__ g, float* __restrict__ out, int O, int I, int khw,
+                                        int accumulate) {
+  const long n = (long)O * I * khw;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % khw);
+    const long r = i / khw;
+    const int ci = (int)(r % I);
+    const int oc = (int)(r / I);
+    const float v = g[((long)oc * khw + tap) * I + ci];
+    out[i] = accumulate ? out[i] + v : v;
+  }
+}
+
+// zero-insertion: dy [B][Ho][Wo][C] -> out [B][(Ho-1)*sh+1][(Wo-1)*sw+1][C]  (data gradient of a strided conv)
+__global__ void dilate_nhwc_kernel(const float* __restrict__ dy, float* __restrict__ out, int B, int Ho, int Wo, int C4,
+                                   int sh, int sw) {
+  const int Hd = (Ho - 1) * sh + 1, Wd = (Wo - 1) * sw + 1;
+  const long n = (long)B * Hd * Wd * C4;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int c4 = (int)(i % C4);
+    long r = i / C4;
+    const int x = (int)(r % Wd);
+    r /= Wd;
+    const int y = (int)(r % Hd);
+    const int b = (int)(r / Hd);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (y % sh == 0 && x % sw == 0) v = reinterpret_cast<const f32x4*>(dy)[(((long)b * Ho + y / sh) * Wo + x / sw) * C4 + c4];
+    reinterpret_cast<f32x4*>(out)[i] = v;
+  }
+}
+
+// ---- BatchNorm2d (training) backward, ReLU mask fused -----------------------------------------------------
+// g = dz * (z > 0 when relu);  xhat = (y - mean) * invstd;  partial sums of g and g*xhat per channel.
+// thread -> (column quad, row lane); block covers rows_per_block rows; part[blk][2][C].
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dz, const float* __restrict__ z,
+                                                            const float* __restrict__ y, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, float* __restrict__ part,
+                                                            long rows, int C, int relu, int rows_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [lanes][2][C]
+  const int C4 = C >> 2;
+  const int cq = threadIdx.x % C4, rl = threadIdx.x / C4, lanes = 256 / C4;
+  const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[cq];
+  const f32x4 is = reinterpret_cast<const f32x4*>(invstd)[cq];
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  for (long r = r0 + rl; r < r1; r += lanes) {
+    f32x4 g = reinterpret_cast<const f32x4*>(dz)[r * C4 + cq];
+    const f32x4 yv = reinterpret_cast<const f32x4*>(y)[r * C4 + cq];
+    if (relu) {
+      const f32x4 zv = reinterpret_cast<const f32x4*>(z)[r * C4 + cq];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (!(zv[j] > 0.f)) g[j] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s1[j] += g[j];
+      s2[j] += g[j] * (yv[j] - mu[j]) * is[j];
+    }
+  }
+  reinterpret_cast<f32x4*>(red + (rl * 2 + 0) * C)[cq] = s1;
+  reinterpret_cast<f32x4*>(red + (rl * 2 + 1) * C)[cq] = s2;
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * C; c += 256) {
+    const int which = c / C, cc = c - which * C;
+    float s = 0.f;
+    for (int l = 0; l < lanes; ++l) s += red[(l * 2 + which) * C + cc];
+    part[((long)blockIdx.x * 2 + which) * C + cc] = s;
+  }
+}
+
+// dy = gamma*invstd*(g - sum_g/N - xhat*sum_gx/N);  dres = g (masked upstream gradient, for the residual branch)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ z,
+                                                           const float* __restrict__ y, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ sums,  // [2][C]: sum g, sum g*xhat
+                                                           float* __restrict__ dy, float* __restrict__ dres, long rows, int C,
+                                                           int relu, float inv_n) {
+  const int C4 = C >> 2;
+  const long n4 = rows * C4;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const int cq = (int)(i % C4);
+    f32x4 g = reinterpret_cast<const f32x4*>(dz)[i];
+    const f32x4 yv = reinterpret_cast<const f32x4*>(y)[i];
+    if (relu) {
+      const f32x4 zv = reinterpret_cast<const f32x4*>(z)[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (!(zv[j] > 0.f)) g[j] = 0.f;
+    }
+    const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[cq];
+    const f32x4 is = reinterpret_cast<const f32x4*>(invstd)[cq];
+    const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[cq];
+    const f32x4 a1 = reinterpret_cast<const f32x4*>(sums)[cq];
+    const f32x4 a2 = reinterpret_cast<const f32x4*>(sums + C)[cq];
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float xh = (yv[j] - mu[j]) * is[j];
+      o[j] = ga[j] * is[j] * (g[j] - a1[j] * inv_n - xh * a2[j] * inv_n);
+    }
+    reinterpret_cast<f32x4*>(dy)[i] = o;
+    if (dres) reinterpret_cast<f32x4*>(dres)[i] = g;
+  }
+}
+
+// dx[argmax window position] += dy ; first maximum in (ky, kx) scan order, as torch.  dx must be zero-initialised.
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                          float* __restrict__ dx, int B, int H, int W, int C, int Ho, int Wo,
+                                                          int kh, int kw, int sh, int sw, int ph, int pw) {
+  const long n = (long)B * Ho * Wo * C;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    long r = i / C;
+    const int ox = (int)(r % Wo);
+    r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int b = (int)(r / Ho);
+    float best = -INFINITY;
+    long bi = -1;
+    for (int ky = 0; ky < kh; ++ky) {
+      const int iy = oy * sh - ph + ky;
+      if (iy < 0 || iy >= H) continue;
+      for (int kx = 0; kx < kw; ++kx) {
+        const int ix = ox * sw - pw + kx;
+        if (ix < 0 || ix >= W) continue;
+        const long idx = (((long)b * H + iy) * W + ix) * C + c;
+        const float v = x[idx];
+        if (v > best || bi < 0) { best = v; bi = idx; }
+      }
+    }
+    if (bi >= 0) atomicAdd(dx + bi, dy[i]);
+  }
+}
+
+// ---- LSTM backward through time ------------------------------------------------------------------------
+constexpr int HID = 256, BT = 16, NW = 16, NTH = NW * 64;
+constexpr int GLD = 4 * HID + 4;
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// gates [B][T][ndir][4H] (post-activation i,f,g,o), cseq [B][T][ndir][H], dout [B][T][ndir*H]
+// w_hhT: fragment-major W_hh^T (rows = hidden unit j, K = 4H gate index), one gate group
+// dgates [B][T][ndir][4H]: gradient with respect to the gate pre-activations
+__global__ __launch_bounds__(NTH) void lstm_layer_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ gates,
+                                                             const float* __restrict__ cseq, const float* __restrict__ w_hhT,
+                                                             float* __restrict__ dgates, int B, int T, int ndir) {
+  extern __shared__ __attribute__((aligned(16))) float dg_lds[];   // [BT][GLD]
+  const int dir = blockIdx.y;
+  const int b0 = blockIdx.x * BT;
+  const int t_ = threadIdx.x, lane = t_ & 63, wave = t_ >> 6;
+  const int col = lane & 15, rbase = (lane >> 4) * 4;
+  const int j = wave * 16 + col;
+  const int Q = 4 * HID / 16;
+  const f32x4* wp = reinterpret_cast<const f32x4*>(w_hhT) + (long)dir * (HID * 4 * HID / 4) + (long)wave * Q * 64 + lane;
+  float dh_rec[4] = {0.f, 0.f, 0.f, 0.f}, dc_next[4] = {0.f, 0.f, 0.f, 0.f};
+
+  for (int step = T - 1; step >= 0; --step) {
+    const int t = dir == 0 ? step : T - 1 - step;           // time index processed at forward step `step`
+    const int tp = dir == 0 ? t - 1 : t + 1;                // previous time in the direction's order
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = rbase + r, b = b0 + row;
+      float di = 0.f, df = 0.f, dg = 0.f, dob = 0.f;
+      if (b < B) {
+        const long base = ((long)b * T + t) * ndir + dir;
+        const float* gp = gates + base * 4 * HID + j;
+        const float ig = gp[0], fg = gp[HID], gg = gp[2 * HID], og = gp[3 * HID];
+        const float ct = cseq[base * HID + j];
+        const float cp = step > 0 ? cseq[(((long)b * T + tp) * ndir + dir) * HID + j] : 0.f;
+        const float dh = dout[((long)b * T + t) * (ndir * HID) + dir * HID + j] + dh_rec[r];
+        const float tc = tanhf(ct);
+        dob = dh * tc * og * (1.f - og);
+        const float dc = dc_next[r] + dh * og * (1.f - tc * tc);
+        di = dc * gg * ig * (1.f - ig);
+        df = dc * cp * fg * (1.f - fg);
+        dg = dc * ig * (1.f - gg * gg);
+        dc_next[r] = dc * fg;
+        float* dp = dgates + base * 4 * HID + j;
+        dp[0] = di; dp[HID] = df; dp[2 * HID] = dg; dp[3 * HID] = dob;
+      }
+      float* l = dg_lds + row * GLD + j;
+      l[0] = di; l[HID] = df; l[2 * HID] = dg; l[3 * HID] = dob;
+    }
+    __syncthreads();
+    if (step > 0) {
+      // dh_rec[b][j] = sum_n dgate[b][n] * W_hh[n][j]
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const float* ap = dg_lds + col * GLD + (lane >> 4) * 4;
+      f32x4 wv = wp[0];
+#pragma unroll 1
+      for (int q = 0; q < Q; ++q) {
+        const f32x4 wn = wp[(long)((q + 1 < Q) ? q + 1 : q) * 64];
+        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + q * 16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = mfma4(av[r], wv[r], acc);
+        wv = wn;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dh_rec[r] = acc[r];
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+static inline int ew_grid(long n, int per_block) {
+  long g = (n + per_block - 1) / per_block;
+  if (g > 256 * 16) g = 256 * 16;
+  return g < 1 ? 1 : (int)g;
+}
+
+MRN_EXPORT int mrn_pack_dgrad_weight_f32(const float* w_ohwi, float* wt_ihwo, int O, int I, int kh, int kw, void* stream) {
+  MRN_CHECK_ARG(w_ohwi && wt_ihwo, "mrn_pack_dgrad_weight_f32: null operand");
+  hipLaunchKernelGGL(pack_dgrad_weight_kernel, dim3(ew_grid((long)O * I * kh * kw, 256)), dim3(256), 0, (hipStream_t)stream,
+                     w_ohwi, wt_ihwo, O, I, kh, kw);
+  MRN_LAUNCH_CHECK("pack_dgrad_weight");
+  return MRN_OK;
+}
+
+MRN_EXPORT int mrn_unpack_conv_weight_f32(const float* g_ohwi, float* g_oihw, int O, int I, int kh, int kw, int accumulate,
+                                          void* stream) {
+  MRN_CHECK_ARG(g_ohwi && g_oihw, "mrn_unpack_conv_weight_f32: null operand");
+  hipLaunchKernelGGL(unpack_ohwi_oihw_kernel, dim3(ew_grid((long)O * I * kh * kw, 256)), dim3(256), 0, (hipStream_t)stream,
+                     g_ohwi, g_oihw, O, I, kh * kw, accumulate);
+  MRN_LAUNCH_CHECK("unpack_conv_weight");
+  return MRN_OK;
+}
+
+MRN_EXPORT int mrn_dilate_nhwc_f32(const float* dy, float* out, int B, int Ho, int Wo, int C, int sh, int sw, void* stream) {
+  MRN_CHECK_ARG(dy && out && C % 4 == 0 && sh >= 1 && sw >= 1, "mrn_dilate_nhwc_f32: bad operands");
+  const long n = (long)B * ((Ho - 1) * sh + 1) * ((Wo - 1) * sw + 1) * (C / 4);
+  if (n <= 0) return MRN_OK;
+  hipLaunchKernelGGL(dilate_nhwc_kernel, dim3(ew_grid(n, 512)), dim3(256), 0, (hipStream_t)stream, dy, out, B, Ho, Wo, C / 4,
+                     sh, sw);
+  MRN_LAUNCH_CHECK("dilate_nhwc");
+  return MRN_OK;
+}
+
+MRN_EXPORT int64_t mrn_bn_bwd_blocks(int64_t rows) {
+  int64_t b = (rows + 255) / 256;
+  if (b > 2048) b = 2048;
+  return b < 1 ? 1 : b;
+}
+
+// partials: mrn_bn_bwd_blocks(rows) * 2 * C floats
+MRN_EXPORT int mrn_bn_bwd_reduce_f32(const float* dz, const float* z, const float* y, const float* mean, const float* invstd,
+                                     float* partials, int64_t rows, int C, int relu, void* stream) {
+  MRN_CHECK_ARG(dz && y && mean && invstd && partials && (!relu || z), "mrn_bn_bwd_reduce_f32: null operand");
+  MRN_CHECK_ARG(C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0, "mrn_bn_bwd_reduce_f32: unsupported C=%d", C);
+  if (rows == 0) return MRN_OK;
+  const long nblk = mrn_bn_bwd_blocks(rows);
+  const int rpb = (int)((rows + nblk - 1) / nblk);
+  const int lanes = 256 / (C / 4);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)nblk), dim3(256), sizeof(float) * lanes * 2 * C, (hipStream_t)stream,
+                     dz, z, y, mean, invstd, partials, (long)rows, C, relu, rpb);
+  MRN_LAUNCH_CHECK("bn_bwd_reduce");
+  return MRN_OK;
+}
+
+MRN_EXPORT int mrn_bn_bwd_apply_f32(const float* dz, const float* z, const float* y, const float* mean, const float* invstd,
+                                    const float* gamma, const float* sums, float* dy, float* dres, int64_t rows, int C,
+                                    int relu, void* stream) {
+  MRN_CHECK_ARG(dz && y && mean && invstd && gamma && sums && dy && (!relu || z) && C % 4 == 0, "mrn_bn_bwd_apply_f32: bad operands");
+  if (rows == 0) return MRN_OK;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(rows * (C / 4), 1024)), dim3(256), 0, (hipStream_t)stream, dz, z, y, mean,
+                     invstd, gamma, sums, dy, dres, (long)rows, C, relu, 1.f / (float)rows);
+  MRN_LAUNCH_CHECK("bn_bwd_apply");
+  return MRN_OK;
+}
+
+MRN_EXPORT int mrn_maxpool_bwd_nhwc_f32(const float* dy, const float* x, float* dx_zeroed, int B, int H, int W, int C, int kh,
+                                        int kw, int sh, int sw, int ph, int pw, void* stream) {
+  MRN_CHECK_ARG(dy && x && dx_zeroed, "mrn_maxpool_bwd_nhwc_f32: null operand");
+  const int Ho = (H + 2 * ph - kh) / sh + 1, Wo = (W + 2 * pw - kw) / sw + 1;
+  const long n = (long)B * Ho * Wo * C;
+  if (n <= 0) return MRN_OK;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(n, 512)), dim3(256), 0, (hipStream_t)stream, dy, x, dx_zeroed, B, H, W, C,
+                     Ho, Wo, kh, kw, sh, sw, ph, pw);
+  MRN_LAUNCH_CHECK("maxpool_bwd");
+  return MRN_OK;
+}
+
+MRN_EXPORT int mrn_lstm_layer_bwd_f32(const float* dout, const float* gates, const float* cseq, const float* w_hhT,
+                                      float* dgates, int B, int T, int hidden, int ndir, void* stream) {
+  MRN_CHECK_ARG(dout && gates && cseq && w_hhT && dgates, "mrn_lstm_layer_bwd_f32: null operand");
+  MRN_CHECK_ARG(hidden == HID && (ndir == 1 || ndir == 2), "mrn_lstm_layer_bwd_f32: hidden=%d ndir=%d unsupported", hidden, ndir);
+  if (B == 0 || T == 0) return MRN_OK;
+  const size_t lds = sizeof(float) * BT * GLD;
+  static bool attr = false;
+  if (!attr) { hipFuncSetAttribute((const void*)lstm_layer_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  hipLaunchKernelGGL(lstm_layer_bwd_kernel, dim3(ceil_div(B, BT), ndir), dim3(NTH), lds, (hipStream_t)stream, dout, gates, cseq,
+                     w_hhT, dgates, B, T, ndir);
+  MRN_LAUNCH_CHECK("lstm_layer_bwd");
+  return MRN_OK;
+}

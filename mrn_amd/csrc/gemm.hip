@@ -160,6 +160,38 @@ __device__ __forceinline__ void load_conv(float (&r)[stage_regs(ROWS, NT, BK)], 
   }
 }
 
+// ---- weight-gradient gather (W operand, wmode 4): element (n = (tap, ci), k = output pixel) is the input pixel the
+// tap sees, x[b][oy*sh-ph+ky][ox*sw-pw+kx][ci] (0 outside).  n is contiguous in ci, so the LDS image is written as
+// float4 along the row exactly like mode 3.  pix0 = first pixel of this block's split-K chunk.
+template <int ROWS, int NT, int BK>
+__device__ __forceinline__ void load_wgrad(float (&r)[stage_regs(ROWS, NT, BK)], const GemmParams& p, int n0, int k0,
+                                           long pix0, int kchunk) {
+  using S = Stage<ROWS, NT, BK>;
+  const int t = threadIdx.x;
+  const int rq = t % S::RQ, kk = t / S::RQ;
+  const int n = n0 + rq * 4;
+  const bool nok = n < p.N;
+  const int tap = nok ? n / p.Cin : 0;
+  const int ci = n - tap * p.Cin;
+  const int ky = tap / p.kw, kx = tap - ky * p.kw;
+#pragma unroll
+  for (int q = 0; q < S::NP3; ++q) {
+    const int k = k0 + kk + q * S::KPP3;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (kk < S::KPP3 && nok && k < kchunk) {
+      const long pix = pix0 + k;
+      const int hw = p.Ho * p.Wo;
+      const int b = (int)(pix / hw);
+      const int rem = (int)(pix - (long)b * hw);
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      const int iy = oy * p.sh - p.ph + ky, ix = ox * p.sw - p.pw + kx;
+      if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.Wd)
+        v = *reinterpret_cast<const f32x4*>(p.W + (((long)b * p.H + iy) * p.Wd + ix) * p.Cin + ci);
+    }
+    r[q * 4 + 0] = v[0]; r[q * 4 + 1] = v[1]; r[q * 4 + 2] = v[2]; r[q * 4 + 3] = v[3];
+  }
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == 1) return fmaxf(v, 0.f);
   if (act == 2) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
@@ -189,7 +221,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_kernel(const GemmParams 
   const int bz = blockIdx.z;
 
   const float* A = p.A + (CONV ? 0 : (long)bz * p.sAb);
-  const float* W = p.W + (long)bz * p.sWb;
+  const float* W = p.W + (p.wmode == 4 ? 0 : (long)bz * p.sWb);
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -228,9 +260,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_kernel(const GemmParams 
 
   if (CONV) load_conv<BM, NT, BK>(ra, p, crow, taps, 0);
   else load_strided<BM, NT, BK>(ra, A, p.sAm, p.sAk, m0, 0, p.M, p.K, p.amode);
-  load_strided<BN, NT, BK>(rb, W, p.sWn, p.sWk, n0, 0, p.N, p.K, p.wmode);
+  const bool wg = !CONV && p.wmode == 4;      // weight-gradient gather on the W operand
+  const long pix0 = (long)bz * p.K;
+  if (wg) load_wgrad<BN, NT, BK>(rb, p, n0, 0, pix0, p.K);
+  else load_strided<BN, NT, BK>(rb, W, p.sWn, p.sWk, n0, 0, p.N, p.K, p.wmode);
   store_lds<BM, NT, BK>(ra, As, CONV ? 2 : p.amode);
-  store_lds<BN, NT, BK>(rb, Bs, p.wmode);
+  store_lds<BN, NT, BK>(rb, Bs, wg ? 3 : p.wmode);
   __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
@@ -238,7 +273,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_kernel(const GemmParams 
     if (kt + 1 < nk) {
       if (CONV) load_conv<BM, NT, BK>(ra, p, crow, taps, (kt + 1) * BK);
       else load_strided<BM, NT, BK>(ra, A, p.sAm, p.sAk, m0, (kt + 1) * BK, p.M, p.K, p.amode);
-      load_strided<BN, NT, BK>(rb, W, p.sWn, p.sWk, n0, (kt + 1) * BK, p.N, p.K, p.wmode);
+      if (wg) load_wgrad<BN, NT, BK>(rb, p, n0, (kt + 1) * BK, pix0, p.K);
+      else load_strided<BN, NT, BK>(rb, W, p.sWn, p.sWk, n0, (kt + 1) * BK, p.N, p.K, p.wmode);
     }
     const float* as = As + cur * BK * LDA + wm * TM * 32 + (lane & 31) + (lane >> 5) * LDA;
     const float* bs = Bs + cur * BK * LDB + wn * TN * 32 + (lane & 31) + (lane >> 5) * LDB;
@@ -257,7 +293,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_kernel(const GemmParams 
     }
     if (kt + 1 < nk) {
       store_lds<BM, NT, BK>(ra, As + (cur ^ 1) * BK * LDA, CONV ? 2 : p.amode);
-      store_lds<BN, NT, BK>(rb, Bs + (cur ^ 1) * BK * LDB, p.wmode);
+      store_lds<BN, NT, BK>(rb, Bs + (cur ^ 1) * BK * LDB, wg ? 3 : p.wmode);
     }
     __syncthreads();
   }
@@ -412,4 +448,28 @@ MRN_EXPORT int mrn_conv2d_nhwc_f32(const float* x, const float* w_ohwi, const fl
   p.kh = kh; p.kw = kw; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw;
   p.act = act; p.alpha = 1.f;
   return mrn_gemm_launch(p, true, (hipStream_t)stream);
+}
+
+// dW[s][co][(ky,kx,ci)] = sum over the s-th chunk of output pixels of dy[pix][co] * x[pix shifted by the tap][ci]
+// (split-K partials; the caller column-sums the `splits` slabs).  dy: [B*Ho*Wo][Cout] (NHWC), x: NHWC input.
+MRN_EXPORT int mrn_conv2d_wgrad_f32(const float* dy, const float* x, float* dw_partial, int B, int H, int Wd, int Cin,
+                                    int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int splits, void* stream) {
+  MRN_CHECK_ARG(dy && x && dw_partial && splits >= 1, "mrn_conv2d_wgrad_f32: bad operands");
+  MRN_CHECK_ARG(Cin % 4 == 0 && Cout % 4 == 0, "mrn_conv2d_wgrad_f32: Cin=%d, Cout=%d must be multiples of 4", Cin, Cout);
+  const int Ho = (H + 2 * ph - kh) / sh + 1, Wo = (Wd + 2 * pw - kw) / sw + 1;
+  const long pixels = (long)B * Ho * Wo;
+  MRN_CHECK_ARG(pixels % splits == 0, "mrn_conv2d_wgrad_f32: %ld output pixels not divisible by splits=%d", pixels, splits);
+  if (pixels == 0) return MRN_OK;
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  const int Kc = (int)(pixels / splits);
+  p.A = dy; p.W = x; p.C = dw_partial;
+  p.M = Cout; p.N = kh * kw * Cin; p.K = Kc; p.batch = splits;
+  p.sAb = (long)Kc * Cout; p.sAm = 1; p.sAk = Cout; p.amode = 3;     // A[m = co][k = pixel] = dy[pixel][co]
+  p.wmode = 4;
+  p.sCb = (long)Cout * p.N; p.sCm = p.N; p.sCn = 1;
+  p.H = H; p.Wd = Wd; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo;
+  p.kh = kh; p.kw = kw; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw;
+  p.alpha = 1.f;
+  return mrn_gemm_launch(p, false, (hipStream_t)stream);
 }

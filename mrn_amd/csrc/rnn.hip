@@ -55,18 +55,20 @@ __device__ __forceinline__ void mma_rows(f32x4 (&acc)[NG], const float* __restri
   }
 }
 
+// act[g][r] receives the post-activation gates (i, f, g, o) for the backward pass
 __device__ __forceinline__ void lstm_pointwise(const f32x4 (&acc)[4], const float (&xg)[4][4], const float (&bh)[4],
-                                               float (&c)[4], float (&h)[4]) {
+                                               float (&c)[4], float (&h)[4], float (&act)[4][4]) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const float gi = acc[0][r] + xg[0][r] + bh[0];
     const float gf = acc[1][r] + xg[1][r] + bh[1];
     const float gg = acc[2][r] + xg[2][r] + bh[2];
     const float go = acc[3][r] + xg[3][r] + bh[3];
-    const float ig = sigmoidf_acc(gi), fg = sigmoidf_acc(gf), og = sigmoidf_acc(go);
-    const float cn = fg * c[r] + ig * tanhf(gg);
+    const float ig = sigmoidf_acc(gi), fg = sigmoidf_acc(gf), og = sigmoidf_acc(go), cg = tanhf(gg);
+    const float cn = fg * c[r] + ig * cg;
     c[r] = cn;
     h[r] = og * tanhf(cn);
+    act[0][r] = ig; act[1][r] = fg; act[2][r] = cg; act[3][r] = og;
   }
 }
 
@@ -76,6 +78,8 @@ __device__ __forceinline__ void lstm_pointwise(const f32x4 (&acc)[4], const floa
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NTH) void lstm_layer_kernel(const float* __restrict__ xproj, const float* __restrict__ w_hh,
                                                          const float* __restrict__ b_hh, float* __restrict__ out,
+                                                         float* __restrict__ gates_out,   // optional [B][T][ndir][4H]
+                                                         float* __restrict__ c_out,       // optional [B][T][ndir][H]
                                                          int B, int T, int ndir) {
   __shared__ __attribute__((aligned(16))) float h_lds[2][BT * HLD];
   const int dir = blockIdx.y;
@@ -107,12 +111,20 @@ __global__ __launch_bounds__(NTH) void lstm_layer_kernel(const float* __restrict
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
     mma_rows<4>(acc, h_lds[cur], HLD, W, HID, wave, lane);
-    float h[4];
-    lstm_pointwise(acc, xg, bh, c, h);
+    float h[4], act[4][4];
+    lstm_pointwise(acc, xg, bh, c, h, act);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = rbase + r, b = b0 + row;
-      if (b < B) out[((long)b * T + t) * (ndir * HID) + dir * HID + j] = h[r];
+      if (b < B) {
+        out[((long)b * T + t) * (ndir * HID) + dir * HID + j] = h[r];
+        if (gates_out) {
+          const long base = ((long)b * T + t) * ndir + dir;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) gates_out[base * 4 * HID + g * HID + j] = act[g][r];
+          c_out[base * HID + j] = c[r];
+        }
+      }
       h_lds[cur ^ 1][row * HLD + j] = b < B ? h[r] : 0.f;
     }
     __syncthreads();
@@ -296,8 +308,8 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecParams p
       mma_rows<4>(acc, ctx_lds, CLD, p.w_ih, D, wave, lane);
       mma_rows<4>(acc, h_lds, HLD, p.w_hh, HID, wave, lane);
       __syncthreads();  // every wave has finished reading h_lds
-      float h[4];
-      lstm_pointwise(acc, xg, bh, c, h);
+      float h[4], act[4][4];
+      lstm_pointwise(acc, xg, bh, c, h, act);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = rbase + r, b = b0 + row;
@@ -333,14 +345,15 @@ __global__ void embed_gather_kernel(const long* __restrict__ idx, const float* _
 
 }  // namespace
 
-MRN_EXPORT int mrn_lstm_layer_fwd_f32(const float* xproj, const float* w_hh, const float* b_hh, float* out, int B, int T,
-                                      int hidden, int ndir, void* stream) {
+MRN_EXPORT int mrn_lstm_layer_fwd_f32(const float* xproj, const float* w_hh, const float* b_hh, float* out,
+                                      float* gates_out, float* c_out, int B, int T, int hidden, int ndir, void* stream) {
   MRN_CHECK_ARG(xproj && w_hh && out, "mrn_lstm_layer_fwd_f32: null operand");
   MRN_CHECK_ARG(hidden == HID, "mrn_lstm_layer_fwd_f32: hidden=%d unsupported (library is built for %d)", hidden, HID);
   MRN_CHECK_ARG(ndir == 1 || ndir == 2, "mrn_lstm_layer_fwd_f32: ndir=%d", ndir);
+  MRN_CHECK_ARG((gates_out == nullptr) == (c_out == nullptr), "mrn_lstm_layer_fwd_f32: gates_out / c_out must come together");
   if (B == 0 || T == 0) return MRN_OK;
   hipLaunchKernelGGL(lstm_layer_kernel, dim3(ceil_div(B, BT), ndir), dim3(NTH), 0, (hipStream_t)stream, xproj, w_hh, b_hh,
-                     out, B, T, ndir);
+                     out, gates_out, c_out, B, T, ndir);
   MRN_LAUNCH_CHECK("lstm_layer");
   return MRN_OK;
 }

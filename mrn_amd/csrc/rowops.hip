@@ -216,7 +216,7 @@ __device__ __forceinline__ float gelu_grad_f(float v) {
   return cdf + v * pdf;
 }
 
-// op 0: y = gelu(a)   1: y = b * gelu'(a)   2: y = a * b   3: y = a + b
+// op 0: y = gelu(a)   1: y = b * gelu'(a)   2: y = a * b   3: y = a + b   4: y = b * (a > 0)
 __global__ __launch_bounds__(256) void ew_rows_kernel(const float* __restrict__ a, long lda, const float* __restrict__ b,
                                                       long ldb, float* __restrict__ y, long ldy, long rows, int C4, int op) {
   const long n = rows * C4;
@@ -232,7 +232,8 @@ __global__ __launch_bounds__(256) void ew_rows_kernel(const float* __restrict__ 
       if (op == 0) o[j] = gelu_f(av[j]);
       else if (op == 1) o[j] = bv[j] * gelu_grad_f(av[j]);
       else if (op == 2) o[j] = av[j] * bv[j];
-      else o[j] = av[j] + bv[j];
+      else if (op == 3) o[j] = av[j] + bv[j];
+      else o[j] = av[j] > 0.f ? bv[j] : 0.f;
     }
     reinterpret_cast<f32x4*>(y + r * ldy)[c4] = o;
   }
@@ -355,7 +356,7 @@ MRN_EXPORT int mrn_colnorm_bwd_f32(const float* dy, const float* x, const float*
 
 MRN_EXPORT int mrn_ew_rows_f32(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy,
                                int64_t rows, int C, int op, void* stream) {
-  MRN_CHECK_ARG(a && y && op >= 0 && op <= 3 && (op == 0 || b), "mrn_ew_rows_f32: bad operands for op %d", op);
+  MRN_CHECK_ARG(a && y && op >= 0 && op <= 4 && (op == 0 || b), "mrn_ew_rows_f32: bad operands for op %d", op);
   MRN_CHECK_ARG(C % 4 == 0 && lda % 4 == 0 && ldy % 4 == 0 && ldb % 4 == 0, "mrn_ew_rows_f32: C and row strides must be multiples of 4");
   if (rows == 0) return MRN_OK;
   hipLaunchKernelGGL(ew_rows_kernel, dim3(ew_grid(rows * (C / 4), 1024)), dim3(256), 0, (hipStream_t)stream, a, (long)lda, b,

@@ -250,3 +250,117 @@ def cross_entropy(logits, target, ignore_index=-100):
 
 def ctc_loss(logits, targets, target_len):
     return CTCLossFn.apply(logits, targets, target_len)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Differentiable expert stages (loop A: `loss.backward()` through the newest expert, il_modules/mrn.py:260-261)
+# ---------------------------------------------------------------------------------------------------------
+def needs_grad(module, *tensors):
+    """True when autograd must record this stage (a trainable parameter or an input that carries gradient)."""
+    if not torch.is_grad_enabled():
+        return False
+    return any(t is not None and t.requires_grad for t in tensors) or any(p.requires_grad for p in module.parameters())
+
+
+class ConvBlockFn(torch.autograd.Function):
+    """NHWC conv (+bias) [-> BatchNorm2d(train)] [-> +residual] [-> ReLU]; all math in HIP kernels.
+    forward(x, weight[O,I,kh,kw], bias, gamma, beta, residual, cfg)  with cfg = (conv_module, bn_module, relu, precision)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, residual, cfg):
+        from .modules._nn import packed_weight, _pair
+        conv, bn, relu, precision = cfg
+        w = packed_weight(conv)
+        stride, padding = _pair(conv.stride), _pair(conv.padding)
+        ctx.geom = (stride, padding, relu, precision, bn is not None, residual is not None)
+        ctx.wpacked = w
+        if bn is None:
+            y, _ = ops.conv2d_nhwc(x, w, bias, stride, padding, act=ops.ACT_RELU if relu else ops.ACT_NONE, precision=precision)
+            ctx.save_for_backward(x, y if relu else None, None, None, None, None)
+            return y
+        if not bn.training:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not implemented (experts train in train mode)")
+        y, stats = ops.conv2d_nhwc(x, w, bias, stride, padding, act=ops.ACT_NONE, want_stats=True, precision=precision)
+        count = y.shape[0] * y.shape[1] * y.shape[2]
+        mom = 0.1 if bn.momentum is None else bn.momentum
+        scale, shift, mean, invstd = ops.bn_finalize(stats, bn.num_features, count, gamma, beta, bn.running_mean,
+                                                     bn.running_var, mom, bn.eps, save=True)
+        if bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        z = torch.empty_like(y)
+        ops.scale_shift_act(y, scale, shift, relu=relu, residual=residual, out=z)
+        ctx.save_for_backward(x, z if relu else None, y, mean, invstd, gamma)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, z, y, mean, invstd, gamma = ctx.saved_tensors
+        stride, padding, relu, precision, has_bn, has_res = ctx.geom
+        w = ctx.wpacked
+        dz = dz.contiguous()
+        dgamma = dbeta = dres = dbias = None
+        if has_bn:
+            dy, dgamma, dbeta, dres = ops.bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres=has_res)
+        else:
+            dy = ops.ew_rows(ops.EW_RELU_BWD, z, dz) if relu else dz
+            if ctx.needs_input_grad[2]:
+                dbias = ops.colsum(dy.view(-1, dy.shape[-1]))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wt = ops.pack_dgrad_weight(w.ohwi)
+            dx = ops.conv2d_dgrad(dy, wt, (x.shape[1], x.shape[2]), stride, padding, precision=precision)
+        dw = None
+        if ctx.needs_input_grad[1]:
+            kh, kw = w.shape[1], w.shape[2]
+            dw = ops.unpack_conv_weight(ops.conv2d_wgrad(dy, x, (kh, kw), stride, padding))
+        return dx, dw, dbias, dgamma, dbeta, dres, None
+
+
+class MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kernel, stride, padding):
+        ctx.save_for_backward(x)
+        ctx.geom = (kernel, stride, padding)
+        return ops.maxpool_nhwc(x, kernel, stride, padding)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.maxpool_bwd(dy, x, *ctx.geom), None, None, None
+
+
+class BiLSTMFn(torch.autograd.Function):
+    """nn.LSTM(bidirectional=True, batch_first=True) forward + backward through time on the HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
+        H = w_hh_f.shape[1]
+        w_ih = torch.cat([w_ih_f, w_ih_r], 0)
+        b_ih = torch.cat([b_ih_f, b_ih_r], 0)
+        b_hh = torch.cat([b_hh_f, b_hh_r], 0)
+        w_hh = torch.stack([ops.pack_fragment_major(w_hh_f), ops.pack_fragment_major(w_hh_r)], 0)
+        x = x.contiguous()
+        xproj = ops.linear(x, w_ih, b_ih)
+        out, gates, cseq = ops.lstm_layer(xproj, w_hh, b_hh, H, 2, save=True)
+        ctx.save_for_backward(x, w_ih, w_hh_f, w_hh_r, out, gates, cseq)
+        ctx.H = H
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w_ih, w_hh_f, w_hh_r, out, gates, cseq = ctx.saved_tensors
+        H = ctx.H
+        B, T, _ = out.shape
+        w_hhT = torch.stack([ops.pack_fragment_major(w_hh_f.t().contiguous()), ops.pack_fragment_major(w_hh_r.t().contiguous())], 0)
+        dg = ops.lstm_layer_bwd(dout, gates, cseq, w_hhT, H, 2)              # [B,T,2,4H]
+        dg2 = dg.view(B * T, 8 * H)
+        dx = linear_dgrad(dg2, w_ih).view(x.shape) if ctx.needs_input_grad[0] else None
+        dw_ih = linear_wgrad(dg2, x.view(B * T, -1))                           # [8H, in]
+        db = ops.colsum(dg2)                                                   # d b_ih = d b_hh
+        # h_{t-1} in each direction's own time order (data movement only)
+        hprev = torch.zeros(B, T, 2, H, device=out.device, dtype=torch.float32)
+        hprev[:, 1:, 0, :] = out[:, :-1, :H]
+        hprev[:, :-1, 1, :] = out[:, 1:, H:]
+        dw_hh_f = linear_wgrad(dg[:, :, 0, :], hprev[:, :, 0, :])
+        dw_hh_r = linear_wgrad(dg[:, :, 1, :], hprev[:, :, 1, :])
+        return (dx, dw_ih[:4 * H], dw_hh_f, db[:4 * H], db[:4 * H], dw_ih[4 * H:], dw_hh_r, db[4 * H:], db[4 * H:])

@@ -11,7 +11,7 @@ from .. import ops
 
 
 def require_no_grad(module, what):
-    """The HIP expert stages are forward-only for now: fail loudly instead of silently dropping gradients."""
+    """Stages whose backward is not on the HIP path yet fail loudly instead of silently dropping gradients."""
     if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
         raise NotImplementedError(
             f"{what}: backward through this stage is not implemented in the HIP path yet; freeze the expert "
@@ -61,7 +61,17 @@ def bn_scale_shift(bn, stats, count):
 
 def conv_block(x, conv, bn=None, relu=True, residual=None, pool=None, precision=None):
     """x NHWC -> conv (+bias) [-> BatchNorm] [-> +residual] [-> ReLU] [-> MaxPool], NHWC.
-    pool = (kernel, stride, padding) fuses BN-apply + ReLU into the pooling pass."""
+    pool = (kernel, stride, padding) fuses BN-apply + ReLU into the pooling pass.
+    When a gradient is required the same kernels run inside autograd Functions (mrn_amd.functional)."""
+    from ..functional import ConvBlockFn, MaxPoolFn, needs_grad
+    trainable = needs_grad(conv, x, residual) or (bn is not None and needs_grad(bn))
+    if trainable:
+        y = ConvBlockFn.apply(x, conv.weight, conv.bias, bn.weight if bn is not None else None,
+                              bn.bias if bn is not None else None, residual,
+                              (conv, bn, relu, precision or ops.TRAIN_CONV_PRECISION))
+        if pool is not None:
+            y = MaxPoolFn.apply(y, *pool)
+        return y
     w = packed_weight(conv)
     stride, padding = _pair(conv.stride), _pair(conv.padding)
     if bn is None:

@@ -28,7 +28,6 @@ class VGG_FeatureExtractor(nn.Module):
         )
 
     def forward(self, input):
-        require_no_grad(self, "VGG_FeatureExtractor")
         c = self.ConvNet
         x = to_nhwc(input)
         p22, p21 = ((2, 2), (2, 2), (0, 0)), ((2, 1), (2, 1), (0, 0))
@@ -106,7 +105,6 @@ class ResNet(nn.Module):
         return nn.Sequential(*seq)
 
     def forward(self, x):
-        require_no_grad(self, "ResNet")
         x = to_nhwc(x)
         x = conv_block(x, self.conv0_1, self.bn0_1)
         x = conv_block(x, self.conv0_2, self.bn0_2, pool=((2, 2), (2, 2), (0, 0)))

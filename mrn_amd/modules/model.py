@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..functional import FaninFn, GateTailFn, LinearFn
+from ..functional import FaninFn, GateTailFn, LinearFn, needs_grad
 from ._nn import to_nhwc
 from .dm_router import DM_Router
 from .feature_extraction import ResNet_FeatureExtractor, VGG_FeatureExtractor
@@ -72,6 +72,8 @@ class Model_Extractor(nn.Module):
             x = self.SequenceModeling[0](visual)
             return self.SequenceModeling[1](x, out=out)
         lin = self.SequenceModeling[0]
+        if needs_grad(lin, visual):
+            return LinearFn.apply(visual, lin.weight, lin.bias)
         return ops.linear(visual, lin.weight, lin.bias, out=out)
 
     def forward(self, image, out=None):
@@ -106,7 +108,10 @@ class Model(nn.Module):
         """SequenceModeling + Prediction on precomputed backbone features"""
         feat = self.model.sequence(visual, out=feature_out)
         if self.stages["Pred"] == "CTC":
-            pred = ops.linear(feat, self.Prediction.weight, self.Prediction.bias, out=predict_out)
+            if needs_grad(self.Prediction, feat):
+                pred = LinearFn.apply(feat, self.Prediction.weight, self.Prediction.bias)
+            else:
+                pred = ops.linear(feat, self.Prediction.weight, self.Prediction.bias, out=predict_out)
         else:
             pred = self.Prediction(feat, text, is_train, batch_max_length=self.opt.batch_max_length, out=predict_out)
         return {"predict": pred, "feature": feat}

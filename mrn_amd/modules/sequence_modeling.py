@@ -35,7 +35,16 @@ class BidirectionalLSTM(nn.Module):
 
     def forward(self, input, out=None):
         """input [B,T,in] -> [B,T,out]; `out` may be a strided [B,T,out] view (zero-copy expert stacking)."""
-        require_no_grad(self, "BidirectionalLSTM")
+        from ..functional import BiLSTMFn, LinearFn, needs_grad
+        if needs_grad(self, input):
+            r = self.rnn
+            rec = BiLSTMFn.apply(input, r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0, r.weight_ih_l0_reverse,
+                                 r.weight_hh_l0_reverse, r.bias_ih_l0_reverse, r.bias_hh_l0_reverse)
+            y = LinearFn.apply(rec, self.linear.weight, self.linear.bias)
+            if out is not None:
+                out.copy_(y)
+                return out
+            return y
         w_ih, w_hh, b_ih, b_hh = self._packed()
         xproj = ops.linear(input, w_ih, b_ih)
         rec = ops.lstm_layer(xproj, w_hh, b_hh, self.hidden_size, 2)

@@ -51,6 +51,10 @@ CONV_TIMER = None            # set to a KernelTimer by bench.py
 #   "bf16"   plain bf16 operands (hi only), fp32 accumulate: ~2e-2 on features
 CONV_PRECISION = "auto"
 AUTO_SPLIT_MIN_K = 2304
+# Convs that are being TRAINED (loop A: forward, data and weight gradients) default to exact fp32: with split-bf16x3 the
+# 1e-5-level forward differences are amplified by small-batch BatchNorm backward to ~3e-3 relative in the early layers'
+# gradients, whereas the exact path matches torch autograd on the oracle to 2e-5 for every parameter.
+TRAIN_CONV_PRECISION = "f32"
 
 
 class PackedConvWeight:
@@ -277,13 +281,26 @@ def pack_fragment_major(w, hidden=256):
     return v.permute(1, 0, 3, 4, 2, 5).contiguous()      # w, g, q, gg, n, r
 
 
-def lstm_layer(xproj, w_hh, b_hh, hidden, ndir):
+def lstm_layer(xproj, w_hh, b_hh, hidden, ndir, save=False):
     """xproj [B,T,ndir*4H] (= x W_ih^T + b_ih), w_hh: ndir stacked pack_fragment_major([4H,H]), b_hh [ndir*4H] or None"""
     _chk(xproj, w_hh, b_hh)
     B, T, _ = xproj.shape
     out = torch.empty(B, T, ndir * hidden, device=xproj.device, dtype=torch.float32)
-    call("mrn_lstm_layer_fwd_f32", _p(xproj), _p(w_hh), _p(b_hh), _p(out), B, T, hidden, ndir, _stream())
-    return out
+    gates = cseq = None
+    if save:
+        gates = torch.empty(B, T, ndir, 4 * hidden, device=xproj.device, dtype=torch.float32)
+        cseq = torch.empty(B, T, ndir, hidden, device=xproj.device, dtype=torch.float32)
+    call("mrn_lstm_layer_fwd_f32", _p(xproj), _p(w_hh), _p(b_hh), _p(out), _p(gates), _p(cseq), B, T, hidden, ndir, _stream())
+    return (out, gates, cseq) if save else out
+
+
+def lstm_layer_bwd(dout, gates, cseq, w_hhT, hidden, ndir):
+    """-> dgates [B,T,ndir,4H] (gradient of the gate pre-activations); w_hhT: ndir stacked pack_fragment_major(W_hh.t())"""
+    B, T, _ = dout.shape
+    dout = dout.contiguous()
+    dgates = torch.empty(B, T, ndir, 4 * hidden, device=dout.device, dtype=torch.float32)
+    call("mrn_lstm_layer_bwd_f32", _p(dout), _p(gates), _p(cseq), _p(w_hhT), _p(dgates), B, T, hidden, ndir, _stream())
+    return dgates
 
 
 def embed_gather(idx, table, num_class):
@@ -557,3 +574,87 @@ def adam_step(p, g, m, v, norm_coef, lr, step, betas=(0.9, 0.999), eps=1e-8):
     bc2 = 1.0 - betas[1] ** step
     call("mrn_adam_step_f32", _p(p), _p(g), _p(m), _p(v), p.numel(), _p(norm_coef), float(lr / bc1), float(betas[0]),
          float(betas[1]), float(bc2 ** 0.5), float(eps), _stream())
+
+
+# ---------------------------------------------------------------------------------------------------------
+# convolution / BatchNorm / pooling backward
+# ---------------------------------------------------------------------------------------------------------
+EW_RELU_BWD = 4
+
+
+def pack_dgrad_weight(w_ohwi):
+    """[O,kh,kw,I] -> PackedConvWeight of the data-gradient conv: [I,kh,kw,O], taps flipped"""
+    O, kh, kw, I = w_ohwi.shape
+    out = torch.empty(I, kh, kw, O, device=w_ohwi.device, dtype=torch.float32)
+    call("mrn_pack_dgrad_weight_f32", _p(w_ohwi), _p(out), O, I, kh, kw, _stream())
+    return PackedConvWeight(out)
+
+
+def conv2d_dgrad(dy, wt_packed, x_hw, stride, padding, precision=None):
+    """dy [B,Ho,Wo,Cout] -> dx [B,H,W,Cin] with wt_packed = pack_dgrad_weight(w)"""
+    B, Ho, Wo, Cout = dy.shape
+    Cin, kh, kw, _ = wt_packed.shape
+    H, W = x_hw
+    if stride != (1, 1):
+        d = torch.empty(B, (Ho - 1) * stride[0] + 1, (Wo - 1) * stride[1] + 1, Cout, device=dy.device, dtype=torch.float32)
+        call("mrn_dilate_nhwc_f32", _p(dy), _p(d), B, Ho, Wo, Cout, stride[0], stride[1], _stream())
+        dy = d
+    # full correlation with the flipped kernel; any rows/cols the strided forward never touched get zero gradient
+    ph, pw = kh - 1 - padding[0], kw - 1 - padding[1]
+    need_h, need_w = H - (dy.shape[1] + 2 * ph - kh + 1), W - (dy.shape[2] + 2 * pw - kw + 1)
+    dx, _ = conv2d_nhwc(dy, wt_packed, None, (1, 1), (ph, pw), precision=precision)
+    if need_h or need_w:      # forward dropped trailing rows/cols (floor in the output-size formula)
+        full = torch.zeros(B, H, W, Cin, device=dy.device, dtype=torch.float32)
+        full[:, :dx.shape[1], :dx.shape[2]] = dx
+        dx = full
+    return dx
+
+
+def conv2d_wgrad(dy, x, ksize, stride, padding):
+    """-> dW [Cout,kh,kw,Cin] (packed layout)"""
+    B, Ho, Wo, Cout = dy.shape
+    _, H, W, Cin = x.shape
+    kh, kw = ksize
+    pixels = B * Ho * Wo
+    tiles = ((Cout + 127) // 128) * ((kh * kw * Cin + 127) // 128)
+    S = 1
+    want = max(1, min(1024 // max(tiles, 1), pixels // 256))
+    for s_ in range(want, 0, -1):
+        if pixels % s_ == 0:
+            S = s_
+            break
+    part = torch.empty(S, Cout, kh * kw * Cin, device=dy.device, dtype=torch.float32)
+    call("mrn_conv2d_wgrad_f32", _p(dy), _p(x), _p(part), B, H, W, Cin, Cout, kh, kw, stride[0], stride[1],
+         padding[0], padding[1], S, _stream())
+    dw = part[0] if S == 1 else colsum(part.view(S, -1))
+    return dw.view(Cout, kh, kw, Cin)
+
+
+def unpack_conv_weight(g_ohwi):
+    O, kh, kw, I = g_ohwi.shape
+    out = torch.empty(O, I, kh, kw, device=g_ohwi.device, dtype=torch.float32)
+    call("mrn_unpack_conv_weight_f32", _p(g_ohwi.contiguous()), _p(out), O, I, kh, kw, 0, _stream())
+    return out
+
+
+def bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres=False):
+    """BatchNorm2d(train) backward with fused ReLU mask -> (dy, dgamma, dbeta, dres or None)"""
+    C = y.shape[-1]
+    rows = y.numel() // C
+    nblk = call("mrn_bn_bwd_blocks", rows)
+    part = torch.empty(nblk, 2 * C, device=y.device, dtype=torch.float32)
+    call("mrn_bn_bwd_reduce_f32", _p(dz), _p(z), _p(y), _p(mean), _p(invstd), _p(part), rows, C, int(relu), _stream())
+    sums = colsum(part)                     # [2C]: sum g, sum g*xhat
+    dy = torch.empty_like(y)
+    dres = torch.empty_like(y) if want_dres else None
+    call("mrn_bn_bwd_apply_f32", _p(dz), _p(z), _p(y), _p(mean), _p(invstd), _p(gamma), _p(sums), _p(dy), _p(dres), rows, C,
+         int(relu), _stream())
+    return dy, sums[C:], sums[:C], dres
+
+
+def maxpool_bwd(dy, x, kernel, stride, padding):
+    B, H, W, C = x.shape
+    dx = torch.zeros_like(x)
+    call("mrn_maxpool_bwd_nhwc_f32", _p(dy.contiguous()), _p(x), _p(dx), B, H, W, C, kernel[0], kernel[1], stride[0], stride[1],
+         padding[0], padding[1], _stream())
+    return dx

@@ -179,3 +179,65 @@ def test_loop_b_two_steps_vs_golden(name):
         # two Adam steps move every element by <= ~5e-5 (2 x lr); where a gradient element is near zero the
         # normalised update m/sqrt(v) has an essentially random sign, so compare in L2 / quantile terms
         assert_sub_l2(g, f"stepB/delta2/{n}", p.detach() - b)
+
+
+def _grad_check(name, mine, ref, rel_l2=2e-3, rel_max=2e-3):
+    a = mine.detach().cpu().double().numpy()
+    b = ref.detach().double().numpy()
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    scale = max(np.abs(b).max(), 1e-12)
+    l2 = np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-12)
+    mx = np.abs(a - b).max() / scale
+    assert l2 <= rel_l2 and mx <= rel_max, f"{name}: rel L2 {l2:.2e}, rel max {mx:.2e} (|g|max {scale:.2e})"
+
+
+def test_loop_a_crnn_gradients_vs_oracle():
+    """loop A (il_modules/mrn.py:232-269) on a CRNN expert: every parameter gradient of loss.backward() against torch
+    autograd on the CPU oracle, then one clip + Adam step."""
+    from mrn_amd import functional as Fn
+    from mrn_amd.optim import FlatAdam
+    from oracle import mrn_oracle as O
+    kind, classes, B, seed = "crnn", (40,), 3, 4
+    g = load_golden("crnn_mrn3")
+    opt, net = build_net(kind, (40, 70, 97), g, 1)          # key layout from the fixture; only expert 0 is trained
+    image, words, chars, _ = det_inputs(kind, classes, B, seed)
+    conv, labels_index, labels_length = labels_for(kind, words, chars)
+    # oracle side
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    names = [n for n, p in net.named_parameters() if n.startswith("model.0.")]
+    params = [sd[n].requires_grad_(True) for n in names]
+    cfg = O.Cfg("None", "VGG", "BiLSTM", "CTC")
+    ref_out = O.model_forward(sd, "model.0.", cfg, image, None, True, training=True)["predict"]
+    ref_loss = O.ctc_loss(ref_out, labels_index.cpu(), labels_length.cpu())
+    ref_grads = torch.autograd.grad(ref_loss, params)
+    # HIP side
+    net.train()
+    for n, p in net.named_parameters():
+        p.requires_grad = n.startswith("model.0.")
+    expert = net.model[0]
+    preds = expert(image.cuda(), None, True)["predict"]
+    loss = Fn.ctc_loss(preds, labels_index.cuda(), labels_length.cuda())
+    assert_close("loop A logits", preds, ref_out, atol=1e-4)
+    assert abs(loss.item() - ref_loss.item()) < 1e-4 * max(1.0, abs(ref_loss.item()))
+    loss.backward()
+    mine = dict(net.named_parameters())
+    for n, rg in zip(names, ref_grads):
+        if rg.abs().max() < 1e-9:
+            continue
+        _grad_check(n, mine[n].grad, rg)
+    # BatchNorm running statistics advanced identically
+    for k in sd:
+        if k.startswith("model.0.") and k.endswith("running_var"):
+            assert_close(k, net.state_dict()[k], sd[k], atol=1e-5)
+    # one optimiser step on the flat buffers
+    tr = [p for p in net.parameters() if p.requires_grad]
+    grads = [p.grad.clone() for p in tr]
+    adam = FlatAdam(tr, lr=5e-4)
+    for p, gr in zip(tr, grads):
+        p.grad.copy_(gr)
+    before = [p.detach().clone() for p in tr]
+    nc = adam.step(lr=2.5e-5, max_norm=5.0)
+    total = torch.norm(torch.stack([torch.norm(gg) for gg in ref_grads]))
+    assert abs(nc[0].item() - total.item()) <= 2e-3 * total.item()
+    moved = sum(float((p.detach() - b).abs().sum()) for p, b in zip(tr, before))
+    assert moved > 0
