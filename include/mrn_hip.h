@@ -140,8 +140,29 @@ int mrn_attn_decoder_fwd_f32(const float* Hb, const float* Hproj, const float* e
                              int64_t eproj_stride_s, const float* w_h2h, const float* b_h2h,
                              const float* w_score, const float* w_ih_ctx, const float* w_hh,
                              const float* b_hh, float* hid, int64_t hid_stride_b, int64_t hid_stride_s, float* h_state,
-                             float* c_state, float* alpha_out, int B, int T, int D, int S, int hidden,
-                             void* stream);
+                             float* c_state, float* alpha_out, float* gates_out, float* c_out, float* ctx_out,
+                             float* hp_out, int B, int T, int D, int S, int hidden, void* stream);
+/* Backward of the teacher-forced decoder (26 steps of BPTT through attention + LSTMCell in one launch).
+ * Saved by the forward: alpha [B][S][T], gates [B][S][4H] (post-activation), cseq [B][S][H], ctx [B][S][D], hp [B][S][H].
+ * Weights transposed + fragment-major: w_h2hT (rows = input unit, K = H), w_ih_ctxT (rows = D index, K = 4H),
+ * w_hhT (rows = hidden unit, K = 4H).  Outputs: dgates [B][S][4H] (gate pre-activations), dhp [B][S][H],
+ * dHb [B][T][D] and dHproj [B][T][H] (must be zero-initialised; accumulated over the steps),
+ * dwscore_part [ceil(B/16)][H].  D must equal hidden (256). */
+int mrn_attn_decoder_bwd_f32(const float* Hb, const float* Hproj, const float* alpha, const float* gates,
+                             const float* cseq, const float* ctx, const float* hp, const float* dhid,
+                             const float* w_score, const float* w_h2hT, const float* w_ih_ctxT, const float* w_hhT,
+                             float* dgates, float* dhp, float* dHb, float* dHproj, float* dwscore_part,
+                             int B, int T, int D, int S, int hidden, void* stream);
+/* dtable[cut_unknown(idx[b][s])][:] += demb[b][s][:]  (nn.Embedding backward, modules/prediction.py:61) */
+int mrn_embed_scatter_add_f32(const int64_t* idx, int64_t idx_stride, const float* demb, float* dtable, int B, int S,
+                              int E, int num_class, void* stream);
+/* TPS backward: gradient of the rectified image with respect to the fiducials C' (through the bilinear sampler and
+ * the grid; modules/transformation.py:33-44,204-216).  dout NHWC [B][Hr][Wr][4] -> dcprime [B][F][2]. */
+int mrn_tps_grid_sample_bwd_f32(const float* img_nhwc, const float* cprime, const float* inv_delta_c,
+                                const float* p_hat, const float* dout_nhwc, float* dcprime, int B, int H, int W, int C,
+                                int Hr, int Wr, int F, void* stream);
+/* AdaptiveAvgPool2d(1) backward: dx[b][p][c] = dy[b][c] / HW */
+int mrn_avgpool_bwd_nhwc_f32(const float* dy, float* dx, int B, int HW, int C, void* stream);
 /* out[b][s][:] = table[cut_unknown(idx[b][s])][:]  (modules/prediction.py:35-36,61) */
 int mrn_embed_gather_f32(const int64_t* idx, int64_t idx_stride, const float* table, float* out, int B, int S,
                          int E, int num_class, void* stream);

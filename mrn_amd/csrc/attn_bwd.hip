@@ -1,0 +1,393 @@
+// Backward of the attention decoder (teacher-forced), TPS sampler and small companions.
+//
+// Reference: loss.backward() (il_modules/mrn.py:260-261) through modules/prediction.py:58-68,102-118 (26 steps of
+// additive attention + LSTMCell) and modules/transformation.py:33-44,204-216.  Same workgroup geometry as the
+// forward (rnn.hip): 16 samples per workgroup, 16 waves, wave w owns hidden units [16w, 16w+16); the transposed
+// recurrent weights stream fragment-major from L2.
+#include "common.hpp"
+
+namespace {
+
+constexpr int HID = 256, BT = 16, NW = 16, NTH = NW * 64;
+constexpr int HLD = HID + 4, GLD = 4 * HID + 4;
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// acc[g] += A(16 x K in LDS) . Wg^T with fragment-major weights; G weight sets share the A fragment reads
+template <int G>
+__device__ __forceinline__ void mma_shared_a(f32x4 (&acc)[G], const float* __restrict__ a_lds, int lda,
+                                             const f32x4* const (&wp)[G], int Q, int lane) {
+  const float* ap = a_lds + (lane & 15) * lda + (lane >> 4) * 4;
+  f32x4 wv[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) wv[g] = wp[g][0];
+#pragma unroll 1
+  for (int q = 0; q < Q; ++q) {
+    f32x4 wn[G];
+    const long qn = (q + 1 < Q) ? q + 1 : q;
+#pragma unroll
+    for (int g = 0; g < G; ++g) wn[g] = wp[g][qn * 64];
+    const f32x4 av = *reinterpret_cast<const f32x4*>(ap + q * 16);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int g = 0; g < G; ++g) acc[g] = mfma4(av[r], wv[g][r], acc[g]);
+#pragma unroll
+    for (int g = 0; g < G; ++g) wv[g] = wn[g];
+  }
+}
+
+struct AttnBwdParams {
+  const float *Hb, *Hproj, *alpha, *gates, *cseq, *ctx, *hp, *dhid, *w_score;
+  const float *w_h2hT, *w_ih_ctxT, *w_hhT;
+  float *dgates, *dhp, *dHb, *dHproj, *dws_part;
+  int B, T, D, S;
+};
+
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float e = __expf(2.f * x);
+  return 1.f - 2.f / (e + 1.f);
+}
+
+__global__ __launch_bounds__(NTH) void attn_decoder_bwd_kernel(const AttnBwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int T = p.T;
+  float* dg_lds = lds;                       // [BT][GLD]   gate gradients (A operand of the two transposed products)
+  float* dctx_lds = dg_lds + BT * GLD;       // [BT][HLD]
+  float* dhp_lds = dctx_lds + BT * HLD;      // [BT][HLD]
+  float* hp_lds = dhp_lds + BT * HLD;        // [BT][HLD]
+  float* de_lds = hp_lds + BT * HLD;         // [BT][T]
+  float* al_lds = de_lds + BT * T;           // [BT][T]
+  float* sw_lds = al_lds + BT * T;           // [HID]
+  float* red = sw_lds + HID;                 // [NW][HID] reduction of d w_score at the end
+
+  const int b0 = blockIdx.x * BT;
+  const int t_ = threadIdx.x, lane = t_ & 63, wave = t_ >> 6;
+  const int col = lane & 15, rbase = (lane >> 4) * 4;
+  const int j = wave * 16 + col;
+  const f32x4* w_ctx = reinterpret_cast<const f32x4*>(p.w_ih_ctxT) + (long)wave * (4 * HID / 16) * 64 + lane;
+  const f32x4* w_hh = reinterpret_cast<const f32x4*>(p.w_hhT) + (long)wave * (4 * HID / 16) * 64 + lane;
+  const f32x4* w_h2h = reinterpret_cast<const f32x4*>(p.w_h2hT) + (long)wave * (HID / 16) * 64 + lane;
+
+  for (int i = t_; i < HID; i += NTH) sw_lds[i] = p.w_score[i];
+  float dh_rec[4] = {0.f, 0.f, 0.f, 0.f}, dc_next[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x4 dws = {0.f, 0.f, 0.f, 0.f};          // d w_score for channels lane*4.. of this wave's sample
+  __syncthreads();
+
+  for (int s = p.S - 1; s >= 0; --s) {
+    // stage hp[s] and alpha[s] of the 16 samples
+    for (int i = t_; i < BT * HID; i += NTH) {
+      const int row = i / HID, c = i - row * HID, b = b0 + row;
+      hp_lds[row * HLD + c] = b < p.B ? p.hp[((long)b * p.S + s) * HID + c] : 0.f;
+    }
+    for (int i = t_; i < BT * T; i += NTH) {
+      const int row = i / T, t = i - row * T, b = b0 + row;
+      al_lds[i] = b < p.B ? p.alpha[((long)b * p.S + s) * T + t] : 0.f;
+    }
+    // (a) LSTMCell backward for (sample row, unit j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = rbase + r, b = b0 + row;
+      float di = 0.f, df = 0.f, dg = 0.f, dob = 0.f;
+      if (b < p.B) {
+        const long base = (long)b * p.S + s;
+        const float* gp = p.gates + base * 4 * HID + j;
+        const float ig = gp[0], fg = gp[HID], gg = gp[2 * HID], og = gp[3 * HID];
+        const float ct = p.cseq[base * HID + j];
+        const float cp = s > 0 ? p.cseq[(base - 1) * HID + j] : 0.f;
+        const float dh = p.dhid[base * HID + j] + dh_rec[r];
+        const float tc = tanhf(ct);
+        dob = dh * tc * og * (1.f - og);
+        const float dc = dc_next[r] + dh * og * (1.f - tc * tc);
+        di = dc * gg * ig * (1.f - ig);
+        df = dc * cp * fg * (1.f - fg);
+        dg = dc * ig * (1.f - gg * gg);
+        dc_next[r] = dc * fg;
+        float* dp = p.dgates + base * 4 * HID + j;
+        dp[0] = di; dp[HID] = df; dp[2 * HID] = dg; dp[3 * HID] = dob;
+      }
+      float* l = dg_lds + row * GLD + j;
+      l[0] = di; l[HID] = df; l[2 * HID] = dg; l[3 * HID] = dob;
+    }
+    __syncthreads();
+    // (b) dctx = dgates . W_ih[:, :D]   and   dh_prev = dgates . W_hh   (shared A fragments, K = 4H)
+    {
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      const f32x4* const wp[2] = {w_ctx, w_hh};
+      mma_shared_a<2>(acc, dg_lds, GLD, wp, 4 * HID / 16, lane);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        dctx_lds[(rbase + r) * HLD + j] = acc[0][r];
+        dh_rec[r] = acc[1][r];
+      }
+    }
+    __syncthreads();
+    // (c) dalpha[b][t] = dctx[b] . Hb[b][t] ;  dHb[b][t] += alpha[b][t] * dctx[b]     (wave per (b,t) pair)
+    for (int pr0 = wave * 4; pr0 < BT * T; pr0 += NW * 4) {
+      f32x4 hv[4];
+      int rows[4], ts[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pr = pr0 + u;
+        rows[u] = pr < BT * T ? pr / T : 0;
+        ts[u] = pr < BT * T ? pr - rows[u] * T : 0;
+        ok[u] = pr < BT * T && b0 + rows[u] < p.B;
+        hv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ok[u]) hv[u] = *reinterpret_cast<const f32x4*>(p.Hb + ((long)(b0 + rows[u]) * T + ts[u]) * HID + lane * 4);
+      }
+      float sacc[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const f32x4 dv = *reinterpret_cast<const f32x4*>(dctx_lds + rows[u] * HLD + lane * 4);
+        sacc[u] = hv[u][0] * dv[0] + hv[u][1] * dv[1] + hv[u][2] * dv[2] + hv[u][3] * dv[3];
+        if (ok[u]) {
+          const float a = al_lds[rows[u] * T + ts[u]];
+          f32x4* dst = reinterpret_cast<f32x4*>(p.dHb + ((long)(b0 + rows[u]) * T + ts[u]) * HID + lane * 4);
+          f32x4 o = *dst;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) o[k] = fmaf(a, dv[k], o[k]);
+          *dst = o;
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sacc[u] += __shfl_xor(sacc[u], o);
+      }
+      if (lane < 4 && pr0 + lane < BT * T) {
+        const float v = lane == 0 ? sacc[0] : lane == 1 ? sacc[1] : lane == 2 ? sacc[2] : sacc[3];
+        de_lds[pr0 + lane] = v;
+      }
+    }
+    __syncthreads();
+    // (d) softmax backward: de = alpha * (dalpha - sum_t alpha*dalpha)   (wave per sample)
+    {
+      const int row = wave;
+      float dot = 0.f;
+      for (int t = lane; t < T; t += 64) dot += al_lds[row * T + t] * de_lds[row * T + t];
+      dot = wave_sum(dot);
+      for (int t = lane; t < T; t += 64) de_lds[row * T + t] = al_lds[row * T + t] * (de_lds[row * T + t] - dot);
+    }
+    __syncthreads();
+    // (e) through e = score . tanh(Hproj + hp): wave = sample, lane = 4 channels; dhp accumulates in registers
+    {
+      const int row = wave, b = b0 + row;
+      f32x4 dhp = {0.f, 0.f, 0.f, 0.f};
+      if (b < p.B) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(sw_lds + lane * 4);
+        const f32x4 pv = *reinterpret_cast<const f32x4*>(hp_lds + row * HLD + lane * 4);
+        int t = 0;
+#pragma unroll 1
+        for (; t + 4 <= T; t += 4) {
+          f32x4 hv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) hv[u] = *reinterpret_cast<const f32x4*>(p.Hproj + ((long)b * T + t + u) * HID + lane * 4);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float de = de_lds[row * T + t + u];
+            f32x4* dst = reinterpret_cast<f32x4*>(p.dHproj + ((long)b * T + t + u) * HID + lane * 4);
+            f32x4 o = *dst;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float uu = fast_tanh(hv[u][k] + pv[k]);
+              const float dpre = de * wv[k] * (1.f - uu * uu);
+              dws[k] = fmaf(de, uu, dws[k]);
+              dhp[k] += dpre;
+              o[k] += dpre;
+            }
+            *dst = o;
+          }
+        }
+        for (; t < T; ++t) {
+          const f32x4 hv = *reinterpret_cast<const f32x4*>(p.Hproj + ((long)b * T + t) * HID + lane * 4);
+          const float de = de_lds[row * T + t];
+          f32x4* dst = reinterpret_cast<f32x4*>(p.dHproj + ((long)b * T + t) * HID + lane * 4);
+          f32x4 o = *dst;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float uu = fast_tanh(hv[k] + pv[k]);
+            const float dpre = de * wv[k] * (1.f - uu * uu);
+            dws[k] = fmaf(de, uu, dws[k]);
+            dhp[k] += dpre;
+            o[k] += dpre;
+          }
+          *dst = o;
+        }
+        *reinterpret_cast<f32x4*>(p.dhp + ((long)b * p.S + s) * HID + lane * 4) = dhp;
+      }
+      *reinterpret_cast<f32x4*>(dhp_lds + row * HLD + lane * 4) = dhp;
+    }
+    __syncthreads();
+    // (f) dh_prev += dhp . W_h2h
+    if (s > 0) {
+      f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+      const f32x4* const wp[1] = {w_h2h};
+      mma_shared_a<1>(acc, dhp_lds, HLD, wp, HID / 16, lane);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dh_rec[r] += acc[0][r];
+    }
+    __syncthreads();
+  }
+  // d w_score: sum the 16 waves (samples) of this workgroup
+  *reinterpret_cast<f32x4*>(red + wave * HID + lane * 4) = dws;
+  __syncthreads();
+  for (int c = t_; c < HID; c += NTH) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) v += red[w * HID + c];
+    p.dws_part[(long)blockIdx.x * HID + c] = v;
+  }
+}
+
+__global__ void embed_scatter_add_kernel(const long* __restrict__ idx, long idx_stride, const float* __restrict__ demb,
+                                         float* __restrict__ dtable, long n, int E, int num_class, int S) {
+  const long i = blockIdx.x;
+  if (i >= n) return;
+  const long b = i / S, s = i - b * S;
+  long k = idx[b * idx_stride + s];
+  if (k >= num_class || k < 0) k = 0;
+  for (int e = threadIdx.x; e < E; e += blockDim.x) atomicAdd(dtable + k * E + e, demb[i * E + e]);
+}
+
+__global__ void avgpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int HW, int C, float inv) {
+  const int b = blockIdx.y;
+  const long n = (long)HW * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dx[(long)b * n + i] = dy[(long)b * C + (i % C)] * inv;
+}
+
+// ---- TPS sampler backward: d C' -------------------------------------------------------------------------
+constexpr int MAXF = 64;
+
+__global__ __launch_bounds__(256) void tps_sample_bwd_kernel(const float* __restrict__ img, const float* __restrict__ cprime,
+                                                             const float* __restrict__ inv_delta, const float* __restrict__ p_hat,
+                                                             const float* __restrict__ dout, float* __restrict__ dcprime, int H,
+                                                             int W, int Hr, int Wr, int F) {
+  __shared__ float T[MAXF][2];
+  __shared__ float dT[MAXF][2];
+  __shared__ float scratch[4];
+  const int b = blockIdx.x;
+  const int F3 = F + 3;
+  for (int i = threadIdx.x; i < F3 * 2; i += 256) {
+    const int r = i >> 1, d = i & 1;
+    float s = 0.f;
+    for (int jj = 0; jj < F; ++jj) s = fmaf(inv_delta[r * F3 + jj], cprime[((long)b * F + jj) * 2 + d], s);
+    T[r][d] = s;
+  }
+  __syncthreads();
+  const int n = Hr * Wr;
+  const f32x4* im = reinterpret_cast<const f32x4*>(img) + (long)b * H * W;
+  float acc[MAXF / 2][2];     // F3 <= 32 supported in registers
+#pragma unroll
+  for (int q = 0; q < MAXF / 2; ++q) { acc[q][0] = 0.f; acc[q][1] = 0.f; }
+  for (int pix = threadIdx.x; pix < n; pix += 256) {
+    const float* ph = p_hat + (long)pix * F3;
+    float gx = 0.f, gy = 0.f;
+    for (int q = 0; q < F3; ++q) {
+      gx = fmaf(ph[q], T[q][0], gx);
+      gy = fmaf(ph[q], T[q][1], gy);
+    }
+    float ix = (gx + 1.f) * 0.5f * (float)(W - 1), iy = (gy + 1.f) * 0.5f * (float)(H - 1);
+    float mx = 1.f, my = 1.f;                    // border clamp kills the gradient (torch clip_coordinates_set_grad)
+    if (ix <= 0.f) { ix = 0.f; mx = 0.f; } else if (ix >= (float)(W - 1)) { ix = (float)(W - 1); mx = 0.f; }
+    if (iy <= 0.f) { iy = 0.f; my = 0.f; } else if (iy >= (float)(H - 1)) { iy = (float)(H - 1); my = 0.f; }
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const float tx = ix - fx, ty = iy - fy;
+    const bool xin1 = x1 < W, yin1 = y1 < H;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 nw = im[(long)y0 * W + x0];
+    const f32x4 ne = xin1 ? im[(long)y0 * W + x1] : zero;
+    const f32x4 sw = yin1 ? im[(long)y1 * W + x0] : zero;
+    const f32x4 se = (xin1 && yin1) ? im[(long)y1 * W + x1] : zero;
+    const f32x4 g = reinterpret_cast<const f32x4*>(dout)[(long)b * n + pix];
+    float dix = 0.f, diy = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      dix += g[c] * ((ne[c] - nw[c]) * (1.f - ty) + (se[c] - sw[c]) * ty);
+      diy += g[c] * ((sw[c] - nw[c]) * (1.f - tx) + (se[c] - ne[c]) * tx);
+    }
+    const float dgx = dix * mx * 0.5f * (float)(W - 1), dgy = diy * my * 0.5f * (float)(H - 1);
+#pragma unroll
+    for (int q = 0; q < MAXF / 2; ++q)
+      if (q < F3) {
+        acc[q][0] = fmaf(ph[q], dgx, acc[q][0]);
+        acc[q][1] = fmaf(ph[q], dgy, acc[q][1]);
+      }
+  }
+#pragma unroll
+  for (int q = 0; q < MAXF / 2; ++q) {
+    if (q < F3) {   // uniform condition
+      const float s0 = block_sum<256>(acc[q][0], scratch);
+      const float s1 = block_sum<256>(acc[q][1], scratch);
+      if (threadIdx.x == 0) { dT[q][0] = s0; dT[q][1] = s1; }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < F * 2; i += 256) {
+    const int f = i >> 1, d = i & 1;
+    float s = 0.f;
+    for (int r = 0; r < F3; ++r) s = fmaf(inv_delta[r * F3 + f], dT[r][d], s);
+    dcprime[((long)b * F + f) * 2 + d] = s;
+  }
+}
+
+}  // namespace
+
+MRN_EXPORT int mrn_attn_decoder_bwd_f32(const float* Hb, const float* Hproj, const float* alpha, const float* gates,
+                                        const float* cseq, const float* ctx, const float* hp, const float* dhid,
+                                        const float* w_score, const float* w_h2hT, const float* w_ih_ctxT, const float* w_hhT,
+                                        float* dgates, float* dhp, float* dHb, float* dHproj, float* dwscore_part, int B, int T,
+                                        int D, int S, int hidden, void* stream) {
+  MRN_CHECK_ARG(Hb && Hproj && alpha && gates && cseq && ctx && hp && dhid && w_score && w_h2hT && w_ih_ctxT && w_hhT && dgates &&
+                    dhp && dHb && dHproj && dwscore_part, "mrn_attn_decoder_bwd_f32: null operand");
+  MRN_CHECK_ARG(hidden == HID && D == HID, "mrn_attn_decoder_bwd_f32: needs D == hidden == %d (got D=%d hidden=%d)", HID, D, hidden);
+  if (B == 0 || S == 0) return MRN_OK;
+  AttnBwdParams p;
+  p.Hb = Hb; p.Hproj = Hproj; p.alpha = alpha; p.gates = gates; p.cseq = cseq; p.ctx = ctx; p.hp = hp; p.dhid = dhid;
+  p.w_score = w_score; p.w_h2hT = w_h2hT; p.w_ih_ctxT = w_ih_ctxT; p.w_hhT = w_hhT;
+  p.dgates = dgates; p.dhp = dhp; p.dHb = dHb; p.dHproj = dHproj; p.dws_part = dwscore_part;
+  p.B = B; p.T = T; p.D = D; p.S = S;
+  const size_t lds = sizeof(float) * (BT * GLD + 3 * BT * HLD + 2 * BT * T + HID + NW * HID);
+  MRN_CHECK_ARG(lds <= 160 * 1024, "mrn_attn_decoder_bwd_f32: LDS budget exceeded (T=%d)", T);
+  static bool attr = false;
+  if (!attr) { hipFuncSetAttribute((const void*)attn_decoder_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  hipLaunchKernelGGL(attn_decoder_bwd_kernel, dim3(ceil_div(B, BT)), dim3(NTH), lds, (hipStream_t)stream, p);
+  MRN_LAUNCH_CHECK("attn_decoder_bwd");
+  return MRN_OK;
+}
+
+MRN_EXPORT int mrn_embed_scatter_add_f32(const int64_t* idx, int64_t idx_stride, const float* demb, float* dtable, int B, int S,
+                                         int E, int num_class, void* stream) {
+  MRN_CHECK_ARG(idx && demb && dtable, "mrn_embed_scatter_add_f32: null operand");
+  const long n = (long)B * S;
+  if (n == 0) return MRN_OK;
+  hipLaunchKernelGGL(embed_scatter_add_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, (const long*)idx,
+                     (long)idx_stride, demb, dtable, n, E, num_class, S);
+  MRN_LAUNCH_CHECK("embed_scatter_add");
+  return MRN_OK;
+}
+
+MRN_EXPORT int mrn_avgpool_bwd_nhwc_f32(const float* dy, float* dx, int B, int HW, int C, void* stream) {
+  MRN_CHECK_ARG(dy && dx && HW > 0, "mrn_avgpool_bwd_nhwc_f32: bad operands");
+  if (B == 0) return MRN_OK;
+  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(ceil_div((long)HW * C, 256), B), dim3(256), 0, (hipStream_t)stream, dy, dx, HW, C,
+                     1.f / (float)HW);
+  MRN_LAUNCH_CHECK("avgpool_bwd");
+  return MRN_OK;
+}
+
+MRN_EXPORT int mrn_tps_grid_sample_bwd_f32(const float* img_nhwc, const float* cprime, const float* inv_delta_c,
+                                           const float* p_hat, const float* dout_nhwc, float* dcprime, int B, int H, int W, int C,
+                                           int Hr, int Wr, int F, void* stream) {
+  MRN_CHECK_ARG(img_nhwc && cprime && inv_delta_c && p_hat && dout_nhwc && dcprime, "mrn_tps_grid_sample_bwd_f32: null operand");
+  MRN_CHECK_ARG(C == 4 && F > 0 && F + 3 <= MAXF / 2, "mrn_tps_grid_sample_bwd_f32: C=%d F=%d unsupported", C, F);
+  if (B == 0) return MRN_OK;
+  hipLaunchKernelGGL(tps_sample_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, img_nhwc, cprime, inv_delta_c, p_hat,
+                     dout_nhwc, dcprime, H, W, Hr, Wr, F);
+  MRN_LAUNCH_CHECK("tps_grid_sample_bwd");
+  return MRN_OK;
+}

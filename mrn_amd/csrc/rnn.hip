@@ -151,6 +151,8 @@ struct AttnDecParams {
   float* hid;
   float* h_state; float* c_state;   // optional [B][HID] carried state (nullptr: start from zero, do not store)
   float* alpha_out;                 // optional [B][S][T]
+  float* gates_out; float* c_out;   // optional training saves: [B][S][4H] post-activation gates, [B][S][H] cell state
+  float* ctx_out; float* hp_out;    //                          [B][S][D] context vectors, [B][S][H] h2h(h)+b
   int B, T, D, S;
   long eproj_stride_b, eproj_stride_s, hid_stride_b, hid_stride_s;
 };
@@ -208,7 +210,12 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecParams p
       f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
       mma_rows<1>(acc, h_lds, HLD, p.w_h2h, HID, wave, lane);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) hp_lds[(rbase + r) * HLD + j] = acc[0][r] + bj;
+      for (int r = 0; r < 4; ++r) {
+        const float v = acc[0][r] + bj;
+        hp_lds[(rbase + r) * HLD + j] = v;
+        const int b = b0 + rbase + r;
+        if (p.hp_out && b < p.B) p.hp_out[((long)b * p.S + step) * HID + j] = v;
+      }
     }
     __syncthreads();
     // (2) e[b][t] = score . tanh(Hproj[b][t] + hp[b]); one wave per (b, t) pair, 4 channels per lane, four pairs in
@@ -298,6 +305,7 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecParams p
         }
       }
       *reinterpret_cast<f32x4*>(ctx_lds + row * CLD + c4 * 4) = a;
+      if (p.ctx_out && b < p.B) *reinterpret_cast<f32x4*>(p.ctx_out + ((long)b * p.S + step) * D + c4 * 4) = a;
     }
     __syncthreads();
     // (5) gates = eproj + ctx . W_ih[:, :D]^T + h . W_hh^T ; (6) LSTM cell
@@ -313,7 +321,15 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecParams p
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = rbase + r, b = b0 + row;
-        if (b < p.B) p.hid[(long)b * p.hid_stride_b + (long)step * p.hid_stride_s + j] = h[r];
+        if (b < p.B) {
+          p.hid[(long)b * p.hid_stride_b + (long)step * p.hid_stride_s + j] = h[r];
+          if (p.gates_out) {
+            const long base = (long)b * p.S + step;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) p.gates_out[base * 4 * HID + g * HID + j] = act[g][r];
+            p.c_out[base * HID + j] = c[r];
+          }
+        }
         h_lds[row * HLD + j] = b < p.B ? h[r] : 0.f;
       }
     }
@@ -362,8 +378,8 @@ MRN_EXPORT int mrn_attn_decoder_fwd_f32(const float* Hb, const float* Hproj, con
                                         int64_t eproj_stride_s, const float* w_h2h, const float* b_h2h,
                                         const float* w_score, const float* w_ih_ctx, const float* w_hh,
                                         const float* b_hh, float* hid, int64_t hid_stride_b, int64_t hid_stride_s, float* h_state,
-                                        float* c_state, float* alpha_out, int B, int T, int D, int S, int hidden,
-                                        void* stream) {
+                                        float* c_state, float* alpha_out, float* gates_out, float* c_out, float* ctx_out,
+                                        float* hp_out, int B, int T, int D, int S, int hidden, void* stream) {
   MRN_CHECK_ARG(Hb && Hproj && eproj && w_h2h && b_h2h && w_score && w_ih_ctx && w_hh && hid, "mrn_attn_decoder_fwd_f32: null operand");
   MRN_CHECK_ARG(hidden == HID, "mrn_attn_decoder_fwd_f32: hidden=%d unsupported (library is built for %d)", hidden, HID);
   MRN_CHECK_ARG(D % 16 == 0 && D > 0, "mrn_attn_decoder_fwd_f32: D=%d must be a multiple of 16", D);
@@ -372,7 +388,9 @@ MRN_EXPORT int mrn_attn_decoder_fwd_f32(const float* Hb, const float* Hproj, con
   AttnDecParams p;
   p.Hb = Hb; p.Hproj = Hproj; p.eproj = eproj; p.w_h2h = w_h2h; p.b_h2h = b_h2h; p.w_score = w_score;
   p.w_ih = w_ih_ctx; p.w_hh = w_hh; p.b_hh = b_hh; p.hid = hid; p.h_state = h_state; p.c_state = c_state;
-  p.alpha_out = alpha_out; p.B = B; p.T = T; p.D = D; p.S = S;
+  p.alpha_out = alpha_out; p.gates_out = gates_out; p.c_out = c_out; p.ctx_out = ctx_out; p.hp_out = hp_out;
+  MRN_CHECK_ARG(!gates_out || (c_out && ctx_out && hp_out && alpha_out), "mrn_attn_decoder_fwd_f32: training saves must all be given");
+  p.B = B; p.T = T; p.D = D; p.S = S;
   p.eproj_stride_b = eproj_stride_b; p.eproj_stride_s = eproj_stride_s;
   p.hid_stride_b = hid_stride_b; p.hid_stride_s = hid_stride_s;
   const size_t lds = sizeof(float) * (2 * BT * HLD + BT * (D + 4) + BT * T + HID);

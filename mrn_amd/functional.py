@@ -364,3 +364,100 @@ class BiLSTMFn(torch.autograd.Function):
         dw_hh_f = linear_wgrad(dg[:, :, 0, :], hprev[:, :, 0, :])
         dw_hh_r = linear_wgrad(dg[:, :, 1, :], hprev[:, :, 1, :])
         return (dx, dw_ih[:4 * H], dw_hh_f, db[:4 * H], db[:4 * H], dw_ih[4 * H:], dw_hh_r, db[4 * H:], db[4 * H:])
+
+
+class LinearReluFn(torch.autograd.Function):
+    """relu(x W^T + b)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        y = ops.linear(x, weight, bias, act=ops.ACT_RELU)
+        ctx.save_for_backward(x, weight, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        g = ops.ew_rows(ops.EW_RELU_BWD, y, dy.contiguous())
+        dx = linear_dgrad(g, weight).view(x.shape) if ctx.needs_input_grad[0] else None
+        return dx, linear_wgrad(g, x), ops.colsum(g)
+
+
+class AvgPoolFn(torch.autograd.Function):
+    """AdaptiveAvgPool2d(1) on NHWC: [B,H,W,C] -> [B,C]"""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = x.shape
+        return ops.avgpool_nhwc(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, H, W, C = ctx.shape
+        return ops.avgpool_bwd(dy, H * W).view(B, H, W, C)
+
+
+class TPSSampleFn(torch.autograd.Function):
+    """grid generation + bilinear sampling; gradient flows to the fiducials C' only (the image is an input)."""
+
+    @staticmethod
+    def forward(ctx, img_nhwc, cprime, inv_delta_c, p_hat, out_hw):
+        ctx.save_for_backward(img_nhwc, cprime, inv_delta_c, p_hat)
+        return ops.tps_grid_sample(img_nhwc, cprime, inv_delta_c, p_hat, out_hw)
+
+    @staticmethod
+    def backward(ctx, dout):
+        img, cprime, inv_delta_c, p_hat = ctx.saved_tensors
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("gradient of the TPS sampler with respect to the image is not implemented")
+        return None, ops.tps_grid_sample_bwd(img, cprime, inv_delta_c, p_hat, dout), None, None, None
+
+
+class AttnDecoderFn(torch.autograd.Function):
+    """Teacher-forced Attention.forward (modules/prediction.py:58-68) with its full backward."""
+
+    @staticmethod
+    def forward(ctx, batch_H, text, i2h_w, h2h_w, h2h_b, score_w, w_ih, w_hh, b_ih, b_hh, emb_w, gen_w, gen_b, S):
+        Hd = h2h_w.shape[0]
+        D = i2h_w.shape[1]
+        num_class = emb_w.shape[0]
+        batch_H = batch_H.contiguous()
+        Hproj = ops.linear(batch_H, i2h_w)
+        tok = text[:, :S]
+        emb = ops.embed_gather(tok, emb_w, num_class)
+        eproj = ops.linear(emb, w_ih[:, D:], b_ih)
+        hid, saves = ops.attn_decoder_train(batch_H, Hproj, eproj, ops.pack_fragment_major(h2h_w), h2h_b, score_w,
+                                            ops.pack_fragment_major(w_ih[:, :D]), ops.pack_fragment_major(w_hh), b_hh, Hd)
+        probs = ops.linear(hid, gen_w, gen_b)
+        ctx.save_for_backward(batch_H, Hproj, emb, hid, i2h_w, h2h_w, score_w, w_ih, w_hh, gen_w, tok, *saves)
+        ctx.dims = (Hd, D, num_class, S)
+        return probs
+
+    @staticmethod
+    def backward(ctx, dprobs):
+        (batch_H, Hproj, emb, hid, i2h_w, h2h_w, score_w, w_ih, w_hh, gen_w, tok, alpha, gates, cseq, cx, hp) = ctx.saved_tensors
+        Hd, D, num_class, S = ctx.dims
+        B, T, _ = batch_H.shape
+        dprobs = dprobs.contiguous()
+        dgen_w, dgen_b = linear_wgrad(dprobs, hid), ops.colsum(dprobs)
+        dhid = linear_dgrad(dprobs, gen_w).view(B, S, Hd)
+        dgates, dhp, dHb, dHproj, dws = ops.attn_decoder_bwd(
+            batch_H, Hproj, (alpha, gates, cseq, cx, hp), dhid, score_w,
+            ops.pack_fragment_major(h2h_w.t().contiguous()), ops.pack_fragment_major(w_ih[:, :D].t().contiguous()),
+            ops.pack_fragment_major(w_hh.t().contiguous()), Hd)
+        hprev = torch.zeros(B, S, Hd, device=hid.device, dtype=torch.float32)
+        hprev[:, 1:] = hid[:, :-1]                                      # h_{s-1} (data movement)
+        dg2 = dgates.view(B * S, 4 * Hd)
+        dw_ih = torch.empty_like(w_ih)
+        dw_ih[:, :D] = linear_wgrad(dg2, cx)
+        dw_ih[:, D:] = linear_wgrad(dg2, emb)
+        dw_hh = linear_wgrad(dg2, hprev)
+        db = ops.colsum(dg2)
+        dh2h_w, dh2h_b = linear_wgrad(dhp, hprev), ops.colsum(dhp.view(B * S, Hd))
+        demb = linear_dgrad(dg2, w_ih[:, D:])
+        demb_w = ops.embed_scatter_add(tok, demb.view(B, S, -1), num_class)
+        di2h_w = linear_wgrad(dHproj, batch_H)
+        dH = None
+        if ctx.needs_input_grad[0]:
+            dH = linear_dgrad(dHproj, i2h_w, out=dHb.view(B * T, D), accumulate=True).view(B, T, D)
+        return (dH, None, di2h_w, dh2h_w, dh2h_b, dws.view_as(score_w), dw_ih, dw_hh, db, db, demb_w, dgen_w, dgen_b, None)

@@ -60,10 +60,20 @@ class Attention(nn.Module):
     def forward(self, batch_H, text, is_train=True, batch_max_length=25, out=None):
         """batch_H [B,T,D]; text [B,S] (teacher forcing) or [B] of [SOS] (greedy) -> logits [B,S,num_class].
         `out` may be a preallocated (possibly strided) [B,S,num_class] buffer."""
-        require_no_grad(self, "Attention")
+        from ..functional import AttnDecoderFn, needs_grad
         cell = self.attention_cell
         B = batch_H.shape[0]
         S = batch_max_length + 1
+        if needs_grad(self, batch_H):
+            if not is_train:
+                raise NotImplementedError("greedy decoding is inference only; call it under torch.no_grad()")
+            probs = AttnDecoderFn.apply(batch_H, text, cell.i2h.weight, cell.h2h.weight, cell.h2h.bias, cell.score.weight,
+                                        cell.rnn.weight_ih, cell.rnn.weight_hh, cell.rnn.bias_ih, cell.rnn.bias_hh,
+                                        self.char_embeddings.weight, self.generator.weight, self.generator.bias, S)
+            if out is not None:
+                out.copy_(probs)
+                return out
+            return probs
         D = cell.input_size
         batch_H = batch_H.contiguous()
         Hproj = ops.linear(batch_H, cell.i2h.weight)

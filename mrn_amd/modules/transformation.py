@@ -9,7 +9,8 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ._nn import conv_block, from_nhwc, require_no_grad, to_nhwc
+from ..functional import AvgPoolFn, LinearFn, LinearReluFn, TPSSampleFn, needs_grad
+from ._nn import conv_block, from_nhwc, to_nhwc
 
 
 def fiducial_layout(num_fid, y_top, y_bottom):
@@ -50,13 +51,18 @@ class LocalizationNetwork(nn.Module):
         x = conv_block(x, c[4], c[5], pool=pool, precision="f32")
         x = conv_block(x, c[8], c[9], pool=pool, precision="f32")
         x = conv_block(x, c[12], c[13], precision="f32")
-        x = ops.avgpool_nhwc(x)                                                     # [B,512]
-        x = ops.linear(x, self.localization_fc1[0].weight, self.localization_fc1[0].bias, act=ops.ACT_RELU)
-        x = ops.linear(x, self.localization_fc2.weight, self.localization_fc2.bias)
+        fc1, fc2 = self.localization_fc1[0], self.localization_fc2
+        if needs_grad(self, x):
+            x = AvgPoolFn.apply(x)
+            x = LinearReluFn.apply(x, fc1.weight, fc1.bias)
+            x = LinearFn.apply(x, fc2.weight, fc2.bias)
+        else:
+            x = ops.avgpool_nhwc(x)                                                 # [B,512]
+            x = ops.linear(x, fc1.weight, fc1.bias, act=ops.ACT_RELU)
+            x = ops.linear(x, fc2.weight, fc2.bias)
         return x.view(x.shape[0], self.F, 2)
 
     def forward(self, batch_I):
-        require_no_grad(self, "LocalizationNetwork")
         return self.forward_nhwc(to_nhwc(batch_I))
 
 
@@ -112,10 +118,11 @@ class TPS_SpatialTransformerNetwork(nn.Module):
         self.GridGenerator = GridGenerator(F, I_r_size)
 
     def forward(self, batch_I, return_aux=False):
-        require_no_grad(self, "TPS_SpatialTransformerNetwork")
         x = to_nhwc(batch_I)
         cprime = self.LocalizationNetwork.forward_nhwc(x)
         g = self.GridGenerator
+        if needs_grad(self, batch_I) and not return_aux:
+            return from_nhwc(TPSSampleFn.apply(x, cprime, g.inv_delta_C, g.P_hat, self.I_r_size))
         if return_aux:
             out, grid = ops.tps_grid_sample(x, cprime, g.inv_delta_C, g.P_hat, self.I_r_size, want_grid=True)
             return from_nhwc(out), cprime, grid

@@ -325,7 +325,7 @@ def attn_decoder(Hb, Hproj, eproj, w_h2h, b_h2h, w_score, w_ih, w_hh, b_hh, hidd
     assert eproj.stride(2) == 1 and hid.stride(2) == 1 and w_ih.is_contiguous() and w_hh.is_contiguous()
     call("mrn_attn_decoder_fwd_f32", _p(Hb), _p(Hproj), _p(eproj), eproj.stride(0), eproj.stride(1), _p(w_h2h),
          _p(b_h2h), _p(w_score), _p(w_ih), _p(w_hh), _p(b_hh), _p(hid), hid.stride(0), hid.stride(1),
-         _p(h_state), _p(c_state), _p(alpha), B, T, D, S, hidden, _stream())
+         _p(h_state), _p(c_state), _p(alpha), None, None, None, None, B, T, D, S, hidden, _stream())
     return (hid, alpha) if want_alpha else hid
 
 
@@ -657,4 +657,67 @@ def maxpool_bwd(dy, x, kernel, stride, padding):
     dx = torch.zeros_like(x)
     call("mrn_maxpool_bwd_nhwc_f32", _p(dy.contiguous()), _p(x), _p(dx), B, H, W, C, kernel[0], kernel[1], stride[0], stride[1],
          padding[0], padding[1], _stream())
+    return dx
+
+
+# ---------------------------------------------------------------------------------------------------------
+# attention decoder / TPS backward
+# ---------------------------------------------------------------------------------------------------------
+def attn_decoder_train(Hb, Hproj, eproj, w_h2h, b_h2h, w_score, w_ih, w_hh, b_hh, hidden):
+    """teacher-forced forward that also returns what the backward needs: (hid, saves)"""
+    B, T, D = Hb.shape
+    S = eproj.shape[1]
+    dev = Hb.device
+    hid = torch.empty(B, S, hidden, device=dev, dtype=torch.float32)
+    alpha = torch.empty(B, S, T, device=dev, dtype=torch.float32)
+    gates = torch.empty(B, S, 4 * hidden, device=dev, dtype=torch.float32)
+    cseq = torch.empty(B, S, hidden, device=dev, dtype=torch.float32)
+    ctx = torch.empty(B, S, D, device=dev, dtype=torch.float32)
+    hp = torch.empty(B, S, hidden, device=dev, dtype=torch.float32)
+    call("mrn_attn_decoder_fwd_f32", _p(Hb), _p(Hproj), _p(eproj), eproj.stride(0), eproj.stride(1), _p(w_h2h),
+         _p(b_h2h), _p(w_score), _p(w_ih), _p(w_hh), _p(b_hh), _p(hid), hid.stride(0), hid.stride(1), None, None,
+         _p(alpha), _p(gates), _p(cseq), _p(ctx), _p(hp), B, T, D, S, hidden, _stream())
+    return hid, (alpha, gates, cseq, ctx, hp)
+
+
+def attn_decoder_bwd(Hb, Hproj, saves, dhid, w_score, w_h2hT, w_ih_ctxT, w_hhT, hidden):
+    """-> dgates [B,S,4H], dhp [B,S,H], dHb [B,T,D], dHproj [B,T,H], dw_score [H]"""
+    alpha, gates, cseq, ctx, hp = saves
+    B, T, D = Hb.shape
+    S = alpha.shape[1]
+    dev = Hb.device
+    dgates = torch.empty(B, S, 4 * hidden, device=dev, dtype=torch.float32)
+    dhp = torch.empty(B, S, hidden, device=dev, dtype=torch.float32)
+    dHb = torch.zeros(B, T, D, device=dev, dtype=torch.float32)
+    dHproj = torch.zeros(B, T, hidden, device=dev, dtype=torch.float32)
+    nwg = (B + 15) // 16
+    dws = torch.empty(nwg, hidden, device=dev, dtype=torch.float32)
+    call("mrn_attn_decoder_bwd_f32", _p(Hb), _p(Hproj), _p(alpha), _p(gates), _p(cseq), _p(ctx), _p(hp), _p(dhid.contiguous()),
+         _p(w_score), _p(w_h2hT), _p(w_ih_ctxT), _p(w_hhT), _p(dgates), _p(dhp), _p(dHb), _p(dHproj), _p(dws), B, T, D, S,
+         hidden, _stream())
+    return dgates, dhp, dHb, dHproj, (colsum(dws) if nwg > 1 else dws[0])
+
+
+def embed_scatter_add(idx, demb, num_class):
+    B, S = idx.shape
+    E = demb.shape[-1]
+    dtable = torch.zeros(num_class, E, device=demb.device, dtype=torch.float32)
+    call("mrn_embed_scatter_add_f32", _p(idx), idx.stride(0), _p(demb.contiguous()), _p(dtable), B, S, E, num_class, _stream())
+    return dtable
+
+
+def tps_grid_sample_bwd(img_nhwc, cprime, inv_delta_c, p_hat, dout_nhwc):
+    B, H, W, C = img_nhwc.shape
+    _, Hr, Wr, _ = dout_nhwc.shape
+    F = cprime.shape[1]
+    d = torch.empty(B, F, 2, device=cprime.device, dtype=torch.float32)
+    call("mrn_tps_grid_sample_bwd_f32", _p(img_nhwc), _p(cprime.contiguous()), _p(inv_delta_c), _p(p_hat), _p(dout_nhwc.contiguous()),
+         _p(d), B, H, W, C, Hr, Wr, F, _stream())
+    return d
+
+
+def avgpool_bwd(dy, HW):
+    B, C = dy.shape
+    dx = torch.empty(B, HW, C, device=dy.device, dtype=torch.float32)
+    call("mrn_avgpool_bwd_nhwc_f32", _p(dy.contiguous()), _p(dx), B, HW, C, _stream())
     return dx

@@ -325,3 +325,21 @@ def test_clip_and_adam(ops):
         assert_close("grad norm", nc[0:1], total.view(1), atol=1e-4, rtol=1e-5)
     assert_close("adam params", pd, pr[0], atol=1e-6, rtol=1e-5)
     assert_close("adam m", md, st[0]["m"], atol=1e-7, rtol=1e-4)
+
+
+def test_tps_backward_fiducial_gradient(ops):
+    from oracle.mrn_oracle import tps_constants
+    from mrn_amd.tools.weights import fiducial_bias, smooth_image, uniform
+    B, H, W = 3, 32, 256
+    img = torch.from_numpy(smooth_image("tps_test", (B, 4, H, W), 3))
+    cp = (torch.from_numpy(fiducial_bias(20)).view(1, 20, 2) + torch.from_numpy(uniform("cpn", (B, 20, 2), -0.15, 0.15, 1))).requires_grad_(True)
+    dout = torch.from_numpy(uniform("dout", (B, 4, H, W), -1, 1, 2))
+    inv, ph = tps_constants(20, (H, W))
+    cz = torch.cat([cp, torch.zeros(B, 3, 2)], 1)
+    grid = torch.bmm(ph.repeat(B, 1, 1), torch.bmm(inv.repeat(B, 1, 1), cz)).reshape(B, H, W, 2)
+    F.grid_sample(img, grid, padding_mode="border", align_corners=True).backward(dout)
+    d = ops.tps_grid_sample_bwd(ops.nchw_to_nhwc(cu(img)), cu(cp.detach()), cu(inv), cu(ph), ops.nchw_to_nhwc(cu(dout)))
+    # fp32 conditioning of the grid moves a few sampling points across pixel boundaries: ~1e-3 relative (f32 vs f64 on CPU: 6e-4)
+    a, b = d.cpu().double().numpy(), cp.grad.double().numpy()
+    rel = np.linalg.norm(a - b) / np.linalg.norm(b)
+    assert rel < 3e-3, f"d C' relative L2 error {rel:.3e}"
