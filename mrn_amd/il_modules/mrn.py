@@ -78,6 +78,11 @@ class MRN(BaseLearner):
             p.requires_grad = False
         self.model.module.model[-1].eval()
 
+    def test(self, AlignCollate_valid, valid_datas, best_scores, ned_scores, taski, val_choose="test"):
+        # task 0 evaluates the single expert, later tasks the routed ensemble (mrn.py:450-455)
+        return super().test(AlignCollate_valid, valid_datas, best_scores, ned_scores, taski,
+                            val_choose="FF" if taski == 0 else "TF")
+
     # -- loop B ------------------------------------------------------------------------------------------
     def prepare_routing(self, total_steps=None):
         """optimiser of step 1: Adam over the router parameters, OneCycle(total = 2 * num_iter) (mrn.py:308-312)"""

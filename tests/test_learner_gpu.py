@@ -1,0 +1,61 @@
+"""End-to-end plugin surface on the GPU: the MRN learner driven exactly like tiny_train.train() does
+(reference tiny_train.py:232-277): incremental_train -> test -> after_task over two synthetic tasks."""
+import contextlib
+import io
+import os
+import types
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def make_opt(tmp, model):
+    o = types.SimpleNamespace(
+        exp_name="t", il="mrn", memory="random", memory_num=2000, batch_max_length=25, imgH=32, imgW=256, manual_seed=111,
+        start_task=0, num_fiducial=20, input_channel=4, output_channel=512, hidden_size=256, schedule="super",
+        optimizer="adam", lr=0.0005, batch_size=4, num_iter=4, val_interval=2, grad_clip=5, lan_list=["A", "B"], NED=True,
+        workers=0)
+    if model == "crnn":
+        o.Transformation, o.FeatureExtraction, o.SequenceModeling, o.Prediction = "None", "VGG", "BiLSTM", "CTC"
+    else:
+        o.Transformation, o.FeatureExtraction, o.SequenceModeling, o.Prediction = "TPS", "ResNet", "BiLSTM", "Attn"
+    return o
+
+
+@pytest.mark.parametrize("model", ["crnn", "trba"])
+def test_mrn_learner_two_tasks(tmp_path, model):
+    from mrn_amd.data.synthetic import SyntheticTextLines, SyntheticValidation, synthetic_characters
+    from mrn_amd.il_modules.mrn import MRN
+    os.chdir(tmp_path)
+    opt = make_opt(tmp_path, model)
+    torch.manual_seed(0)
+    sink = io.StringIO()
+    with contextlib.redirect_stdout(sink):
+        learner = MRN(opt)
+        train, valid = SyntheticTextLines(opt), SyntheticValidation(opt)
+        best, ned = [], []
+        chars = ""
+        for taski, n_new in enumerate((30, 20)):
+            chars = synthetic_characters(len(chars) + n_new)
+            train.set_characters(chars)
+            valid.set_characters(chars)
+            if taski == 0:
+                train.init_start(taski)
+            learner.incremental_train(taski, chars, train, valid)
+            if taski == 0:
+                first = [p.detach().clone() for p in learner.model.module.model[0].parameters()]
+            best, ned = learner.test(None, [valid.create_dataset()], best, ned, taski)
+            learner.after_task()
+    net = learner.model
+    assert len(net.model) == 2 and len(best) == 2
+    # task 1: expert 0 stayed frozen through loop A of expert 1 and loop B of the router
+    for a, b in zip(first, net.model[0].parameters()):
+        assert torch.equal(a, b.detach())
+    assert all(torch.isfinite(p).all() for p in net.parameters())
+    assert os.path.exists(f"./saved_models/{opt.exp_name}/B_1_1_best_score.pth")
+    sd = torch.load(f"./saved_models/{opt.exp_name}/B_1_1_best_score.pth")
+    assert all(k.startswith("module.") for k in sd)          # reference checkpoint layout (DataParallel prefix)
+    log = sink.getvalue()
+    assert "Train_taski_loss" in log and "Current_score" in log
