@@ -96,8 +96,8 @@ int mrn_bn_finalize_f32(const float* partials, int nblk, int C, int64_t count, c
 /* eval-mode BatchNorm folded to (scale, shift) from running statistics */
 int mrn_bn_eval_affine_f32(const float* gamma, const float* beta, const float* running_mean,
                            const float* running_var, float eps, int C, float* scale, float* shift, void* stream);
-/* y = [relu](x * scale[c] + shift[c] + residual): BatchNorm apply + residual add + ReLU in one pass
- * (BasicBlock tail, modules/feature_extraction.py:184-199). In place allowed. */
+/* y = act(x * scale[c] + shift[c] + residual): BatchNorm apply + residual add + activation in one pass
+ * (BasicBlock tail, modules/feature_extraction.py:184-199; relu = 1 ReLU, 2 GELU for SVTR's PatchEmbed). In place allowed. */
 int mrn_scale_shift_act_f32(const float* x, const float* residual, float* y, const float* scale,
                             const float* shift, int64_t rows, int C, int relu, void* stream);
 /* NHWC max pooling (padding = -inf), optional fused (scale, shift, relu) on the input.
@@ -189,6 +189,12 @@ int mrn_colnorm_bwd_f32(const float* dy, const float* x, const float* gamma, con
  * 4 y=b*(a>0) (ReLU backward) */
 int mrn_ew_rows_f32(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy, int64_t rows,
                     int C, int op, void* stream);
+/* in-place softmax over the N columns of every row of s, with an optional additive mask [rows_per_mask][N] shared
+ * across the batch (row r uses mask row r % rows_per_mask): SVTR Local/Global mixing, modules/svtr.py:140-146 */
+int mrn_softmax_rows_f32(float* s, const float* mask, int64_t rows, int N, int rows_per_mask, void* stream);
+/* y = x + scale[row / rows_per_group] * branch : residual add with the per-sample DropPath scale (svtr.py:7-22,202-203) */
+int mrn_residual_scale_rows_f32(const float* x, const float* branch, const float* scale, float* y, int64_t rows, int C,
+                                int64_t rows_per_group, void* stream);
 /* out[c] (+)= sum_r in[r][c] (bias / affine gradients, split-K combine); workspace: chunks*C floats */
 int64_t mrn_colsum_chunks(int64_t rows, int C);
 int mrn_colsum_f32(const float* in, int64_t ld, float* out, float* workspace, int64_t rows, int C, int accumulate,

@@ -293,6 +293,57 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ x
   if (lane == 0) out[row] = bi;
 }
 
+// In-place row softmax of s[b][i][:] (N columns) with an optional additive mask[i][:] shared by all b:
+// softmax(q k^T + mask) of SVTR's Local mixing (modules/svtr.py:140-146).  One wave per row, N <= 1024.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s, const float* __restrict__ mask, long rows,
+                                                          int N, int rows_per_mask) {
+  const int lane = threadIdx.x & 63;
+  const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float* sr = s + row * N;
+  const float* mr = mask ? mask + (row % rows_per_mask) * (long)N : nullptr;
+  float v[16];
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = lane + i * 64;
+    v[i] = -INFINITY;
+    if (c < N) v[i] = sr[c] + (mr ? mr[c] : 0.f);
+    m = fmaxf(m, v[i]);
+  }
+  m = wave_max(m);
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = lane + i * 64;
+    v[i] = (c < N) ? expf(v[i] - m) : 0.f;
+    sum += v[i];
+  }
+  const float inv = 1.f / wave_sum(sum);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = lane + i * 64;
+    if (c < N) sr[c] = v[i] * inv;
+  }
+}
+
+// y = x + scale[row / rows_per_group] * branch   (DropPath: per-sample Bernoulli(keep)/keep scale, svtr.py:7-22,202-203)
+__global__ __launch_bounds__(256) void residual_scale_kernel(const float* __restrict__ x, const float* __restrict__ br,
+                                                            const float* __restrict__ scale, float* __restrict__ y, long rows,
+                                                            int C4, long rows_per_group) {
+  const long n = rows * C4;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long r = i / C4;
+    const float sc = scale[r / rows_per_group];
+    const f32x4 a = reinterpret_cast<const f32x4*>(x)[i];
+    const f32x4 b = reinterpret_cast<const f32x4*>(br)[i];
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = fmaf(sc, b[j], a[j]);
+    reinterpret_cast<f32x4*>(y)[i] = o;
+  }
+}
+
 }  // namespace
 
 static inline int ew_grid(long n, int per_block) {
@@ -411,5 +462,24 @@ MRN_EXPORT int mrn_argmax_f32(const float* x, int64_t ld, int64_t* out, int64_t 
   hipLaunchKernelGGL(argmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, (long)ld, out,
                      (long)rows, C);
   MRN_LAUNCH_CHECK("argmax");
+  return MRN_OK;
+}
+
+MRN_EXPORT int mrn_softmax_rows_f32(float* s, const float* mask, int64_t rows, int N, int rows_per_mask, void* stream) {
+  MRN_CHECK_ARG(s && N > 0 && N <= 1024 && rows_per_mask > 0, "mrn_softmax_rows_f32: bad operands (N=%d)", N);
+  if (rows == 0) return MRN_OK;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, s, mask, (long)rows,
+                     N, rows_per_mask);
+  MRN_LAUNCH_CHECK("softmax_rows");
+  return MRN_OK;
+}
+
+MRN_EXPORT int mrn_residual_scale_rows_f32(const float* x, const float* branch, const float* scale, float* y, int64_t rows,
+                                           int C, int64_t rows_per_group, void* stream) {
+  MRN_CHECK_ARG(x && branch && scale && y && C % 4 == 0 && rows_per_group > 0, "mrn_residual_scale_rows_f32: bad operands");
+  if (rows == 0) return MRN_OK;
+  hipLaunchKernelGGL(residual_scale_kernel, dim3(ew_grid(rows * (C / 4), 1024)), dim3(256), 0, (hipStream_t)stream, x, branch,
+                     scale, y, (long)rows, C / 4, (long)rows_per_group);
+  MRN_LAUNCH_CHECK("residual_scale_rows");
   return MRN_OK;
 }

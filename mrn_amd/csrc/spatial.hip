@@ -110,9 +110,12 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const float* __res
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] += r[j];
     }
-    if (relu) {
+    if (relu == 1) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.f);
+    } else if (relu == 2) {   // GELU (erf), SVTR PatchEmbed (modules/svtr.py:227-233)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = 0.5f * o[j] * (1.f + erff(o[j] * 0.70710678118654752440f));
     }
     reinterpret_cast<f32x4*>(y)[i] = o;
   }

@@ -59,12 +59,14 @@ def bn_scale_shift(bn, stats, count):
     return ops.bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
 
 
-def conv_block(x, conv, bn=None, relu=True, residual=None, pool=None, precision=None):
+def conv_block(x, conv, bn=None, relu=True, residual=None, pool=None, precision=None, act=None):
     """x NHWC -> conv (+bias) [-> BatchNorm] [-> +residual] [-> ReLU] [-> MaxPool], NHWC.
     pool = (kernel, stride, padding) fuses BN-apply + ReLU into the pooling pass.
     When a gradient is required the same kernels run inside autograd Functions (mrn_amd.functional)."""
     from ..functional import ConvBlockFn, MaxPoolFn, needs_grad
     trainable = needs_grad(conv, x, residual) or (bn is not None and needs_grad(bn))
+    if trainable and act == "gelu":
+        raise NotImplementedError("backward through conv + BatchNorm + GELU (SVTR PatchEmbed) is not implemented")
     if trainable:
         y = ConvBlockFn.apply(x, conv.weight, conv.bias, bn.weight if bn is not None else None,
                               bn.bias if bn is not None else None, residual,
@@ -86,7 +88,7 @@ def conv_block(x, conv, bn=None, relu=True, residual=None, pool=None, precision=
     scale, shift = bn_scale_shift(bn, stats, count)
     if pool is not None and residual is None:
         return ops.maxpool_nhwc(y, pool[0], pool[1], pool[2], scale=scale, shift=shift, relu=relu)
-    y = ops.scale_shift_act(y, scale, shift, relu=relu, residual=residual)
+    y = ops.scale_shift_act(y, scale, shift, relu=(2 if act == "gelu" else relu), residual=residual)
     if pool is not None:
         y = ops.maxpool_nhwc(y, *pool)
     return y

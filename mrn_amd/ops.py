@@ -721,3 +721,27 @@ def avgpool_bwd(dy, HW):
     dx = torch.empty(B, HW, C, device=dy.device, dtype=torch.float32)
     call("mrn_avgpool_bwd_nhwc_f32", _p(dy.contiguous()), _p(dx), B, HW, C, _stream())
     return dx
+
+
+# ---------------------------------------------------------------------------------------------------------
+# SVTR helpers
+# ---------------------------------------------------------------------------------------------------------
+def softmax_rows_(s, mask=None):
+    """in-place softmax over the last dim of s [..., Nq, N]; mask [Nq, N] additive, shared across leading dims"""
+    assert s.is_contiguous()
+    N = s.shape[-1]
+    rows = s.numel() // N
+    rpm = mask.shape[0] if mask is not None else 1
+    call("mrn_softmax_rows_f32", _p(s), _p(mask), rows, N, rpm, _stream())
+    return s
+
+
+def residual_scale_rows(x, branch, scale, rows_per_group, out=None):
+    """x + scale[group] * branch on [rows, C] (contiguous)"""
+    assert x.is_contiguous() and branch.is_contiguous()
+    C = x.shape[-1]
+    rows = x.numel() // C
+    if out is None:
+        out = torch.empty_like(x)
+    call("mrn_residual_scale_rows_f32", _p(x), _p(branch), _p(scale), _p(out), rows, C, rows_per_group, _stream())
+    return out

@@ -151,6 +151,76 @@ def resnet_forward(sd, pre, x, training):
 
 
 # ---------------------------------------------------------------------------------------------------------
+# SVTR backbone (modules/svtr.py)
+# ---------------------------------------------------------------------------------------------------------
+SVTR_DIMS, SVTR_DEPTH, SVTR_HEADS = (64, 128, 256), (3, 6, 3), (2, 4, 8)
+SVTR_MIXER = ["Local"] * 6 + ["Global"] * 6           # svtr.py:321-322
+SVTR_DROP_PATH = np.linspace(0, 0.1, 12)              # svtr.py:382 (drop_path_rate=0.1)
+
+
+def svtr_local_mask(H, W, hk=7, wk=11):
+    """additive attention mask of the Local mixer, svtr.py:117-128: 0 inside the hk x wk window, -inf outside"""
+    mask = torch.ones(H * W, H + hk - 1, W + wk - 1)
+    for h in range(H):
+        for w in range(W):
+            mask[h * W + w, h:h + hk, w:w + wk] = 0.0
+    m = mask[:, hk // 2:H + hk // 2, wk // 2:W + wk // 2].flatten(1)
+    return torch.where(m < 1, m, torch.full_like(m, float("-inf")))
+
+
+def _svtr_block(sd, p, x, heads, mask, training, drop_prob, masks):
+    """Block.forward svtr.py:200-204 (pre-norm attention + MLP, DropPath on both branches, LayerNorm eps 1e-6)"""
+    B, N, C = x.shape
+
+    def droppath(y):
+        if drop_prob == 0.0 or not training:
+            return y
+        keep = 1 - drop_prob
+        m = masks.pop(0).view(B, 1, 1).to(y.dtype)      # injected Bernoulli draw (svtr.py:17-22)
+        return y * (m / keep)
+
+    h = F.layer_norm(x, (C,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-6)
+    qkv = F.linear(h, sd[p + "mixer.qkv.weight"], sd[p + "mixer.qkv.bias"]).reshape(B, N, 3, heads, C // heads).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0] * (C // heads) ** -0.5, qkv[1], qkv[2]
+    attn = q.matmul(k.permute(0, 1, 3, 2))
+    if mask is not None:
+        attn = attn + mask
+    attn = F.softmax(attn, dim=-1)
+    h = attn.matmul(v).permute(0, 2, 1, 3).reshape(B, N, C)
+    x = x + droppath(F.linear(h, sd[p + "mixer.proj.weight"], sd[p + "mixer.proj.bias"]))
+    h = F.layer_norm(x, (C,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], 1e-6)
+    h = F.linear(F.gelu(F.linear(h, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"])), sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+    return x + droppath(h)
+
+
+def svtr_forward(sd, pre, x, training, masks=None):
+    """SVTR.forward_features, modules/svtr.py:500-528 (via SVTR_FeatureExtractor, feature_extraction.py:724-732).
+    masks: list of [B] 0/1 tensors consumed by the DropPath sites in order (needed in training mode)."""
+    p = pre + "ConvNet."
+    masks = list(masks) if masks is not None else []
+    B = x.shape[0]
+    for ci, bi in ((0, 1), (3, 4)):                     # PatchEmbed :227-233
+        x = F.conv2d(x, sd[f"{p}patch_embed.proj.{ci}.weight"], sd[f"{p}patch_embed.proj.{ci}.bias"], 2, 1)
+        x = F.gelu(_bn(sd, f"{p}patch_embed.proj.{bi}.", x, training))
+        _bn_tick(sd, f"{p}patch_embed.proj.{bi}.", training)
+    H, W = x.shape[2], x.shape[3]
+    x = x.flatten(2).transpose(1, 2) + sd[p + "pos_embed"]
+    blk = 0
+    for stage in range(3):
+        hw = (H >> stage, W)
+        for i in range(SVTR_DEPTH[stage]):
+            mask = svtr_local_mask(*hw) if SVTR_MIXER[blk] == "Local" else None
+            x = _svtr_block(sd, f"{p}blocks{stage + 1}.{i}.", x, SVTR_HEADS[stage], mask, training, float(SVTR_DROP_PATH[blk]), masks)
+            blk += 1
+        x = x.transpose(1, 2).reshape(B, SVTR_DIMS[stage], hw[0], hw[1])            # SubSample :298-305
+        x = F.conv2d(x, sd[f"{p}sub_sample{stage + 1}.conv.weight"], sd[f"{p}sub_sample{stage + 1}.conv.bias"], (2, 1), 1)
+        x = x.flatten(2).transpose(1, 2)
+        C = x.shape[-1]
+        x = F.layer_norm(x, (C,), sd[f"{p}sub_sample{stage + 1}.norm.weight"], sd[f"{p}sub_sample{stage + 1}.norm.bias"], 1e-5)
+    return x.permute(0, 2, 1).reshape(B, -1, H // 8, W)
+
+
+# ---------------------------------------------------------------------------------------------------------
 # sequence modelling and heads
 # ---------------------------------------------------------------------------------------------------------
 def _lstm_dir(x, w_ih, w_hh, b_ih, b_hh, reverse):
@@ -235,7 +305,7 @@ class Cfg:
         del self.__dict__["self"]
 
 
-def extractor_forward(sd, pre, cfg, image, training):
+def extractor_forward(sd, pre, cfg, image, training, masks=None):
     """Model_Extractor.forward, modules/model.py:82-101."""
     x = image
     if cfg.Transformation == "TPS":
@@ -244,6 +314,8 @@ def extractor_forward(sd, pre, cfg, image, training):
         x = vgg_forward(sd, pre + "FeatureExtraction.", x, training)
     elif cfg.FeatureExtraction == "ResNet":
         x = resnet_forward(sd, pre + "FeatureExtraction.", x, training)
+    elif cfg.FeatureExtraction == "SVTR":
+        x = svtr_forward(sd, pre + "FeatureExtraction.", x, training, masks)
     else:
         raise NotImplementedError(cfg.FeatureExtraction)
     x = x.permute(0, 3, 1, 2)                       # [b,c,h,w] -> [b,w,c,h]
@@ -256,9 +328,9 @@ def extractor_forward(sd, pre, cfg, image, training):
     return x
 
 
-def model_forward(sd, pre, cfg, image, text=None, is_train=True, training=True):
+def model_forward(sd, pre, cfg, image, text=None, is_train=True, training=True, masks=None):
     """Model.forward, modules/model.py:133-148 -> {"predict", "feature"}."""
-    feat = extractor_forward(sd, pre + "model.", cfg, image, training)
+    feat = extractor_forward(sd, pre + "model.", cfg, image, training, masks)
     if cfg.Prediction == "CTC":
         pred = F.linear(feat, sd[pre + "fc.weight"], sd[pre + "fc.bias"])
     else:
@@ -319,12 +391,14 @@ def select_expert(logits, index):
     return torch.stack([padded[ix][i] for i, ix in enumerate(index)], 0).contiguous()
 
 
-def mrn_forward(sd, cfg, n_experts, image, cross=True, text=None, is_train=True, training=True):
-    """MRNNet.forward, modules/model.py:343-359."""
+def mrn_forward(sd, cfg, n_experts, image, cross=True, text=None, is_train=True, training=True, masks=None):
+    """MRNNet.forward, modules/model.py:343-359.  masks: per-expert lists of DropPath draws (SVTR experts in train mode)."""
     if not cross:
-        out = model_forward(sd, f"model.{n_experts - 1}.", cfg, image, text, is_train, training)["predict"]
+        out = model_forward(sd, f"model.{n_experts - 1}.", cfg, image, text, is_train, training,
+                            masks[n_experts - 1] if masks else None)["predict"]
         return {"logits": out, "index": None, "aux_logits": None}
-    outs = [model_forward(sd, f"model.{i}.", cfg, image, text, is_train, training) for i in range(n_experts)]
+    outs = [model_forward(sd, f"model.{i}.", cfg, image, text, is_train, training, masks[i] if masks else None)
+            for i in range(n_experts)]
     feats = [o["feature"] for o in outs]
     logits = [o["predict"] for o in outs]
     if not is_train:

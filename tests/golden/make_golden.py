@@ -30,7 +30,28 @@ timm.models.layers = types.ModuleType("timm.models.layers")
 timm.models.layers.trunc_normal_ = torch.nn.init.trunc_normal_
 sys.modules.update({"timm": timm, "timm.models": timm.models, "timm.models.layers": timm.models.layers})
 
+torch.Tensor.cuda = lambda self, *a, **k: self   # SVTR's local-mask constructor calls .cuda() (svtr.py:119,125)
+import modules.svtr as ref_svtr  # noqa: E402  (reference)
 from modules.model import MRNNet  # noqa: E402  (reference)
+
+DROP_MASKS = []          # DropPath draws injected into the reference (svtr.py:17-22 uses the global torch RNG)
+
+
+def _injected_drop_path(x, drop_prob=0., training=False, scale_by_keep=True):
+    if drop_prob == 0. or not training:
+        return x
+    keep = 1 - drop_prob
+    m = DROP_MASKS.pop(0).view((x.shape[0],) + (1,) * (x.ndim - 1)).to(x.dtype)
+    return x * (m / keep if keep > 0.0 and scale_by_keep else m)
+
+
+ref_svtr.drop_path = _injected_drop_path
+
+
+def drop_masks(B, seed, tag, n_experts=1):
+    """22 draws per SVTR expert forward (11 blocks with drop_prob > 0, two sites each), Bernoulli(0.5) to exercise both arms"""
+    return [[torch.from_numpy(W.randint(f"droppath:{tag}:{e}:{k}", (B,), 0, 2, seed)).float() for k in range(22)]
+            for e in range(n_experts)]
 from tools.utils import AttnLabelConverter, CTCLabelConverter  # noqa: E402  (reference)
 
 from mrn_amd.tools import weights as W  # noqa: E402
@@ -61,6 +82,8 @@ def make_opt(kind):
                               batch_max_length=25)
     if kind == "crnn":
         o.Transformation, o.FeatureExtraction, o.SequenceModeling, o.Prediction = "None", "VGG", "BiLSTM", "CTC"
+    elif kind == "svtr":
+        o.Transformation, o.FeatureExtraction, o.SequenceModeling, o.Prediction = "None", "SVTR", "None", "CTC"
     else:
         o.Transformation, o.FeatureExtraction, o.SequenceModeling, o.Prediction = "TPS", "ResNet", "BiLSTM", "Attn"
     return o
@@ -95,13 +118,20 @@ def run(kind, classes, B, seed):
     d["sd_keys"] = np.array(sorted(sd0.keys()))                      # pins the reference's state_dict layout
     d["sd_shapes"] = np.array([",".join(map(str, sd0[k].shape)) for k in sorted(sd0.keys())])
     image = torch.from_numpy(W.smooth_image("input:image", (B, 4, 32, 256), seed))
-    nspecial = 4 if kind == "crnn" else 5
+    nspecial = 4 if kind in ("crnn", "svtr") else 5
     words, chars = words_for(B, classes[-1] - nspecial, seed)
-    conv = CTCLabelConverter(chars) if kind == "crnn" else AttnLabelConverter(chars)
+    ctc = kind in ("crnn", "svtr")
+    conv = CTCLabelConverter(chars) if ctc else AttnLabelConverter(chars)
     labels_index, labels_length = conv.encode(words, batch_max_length=25)
     d["labels_index"] = labels_index.numpy()
     d["labels_length"] = labels_length.numpy()
-    text = None if kind == "crnn" else labels_index[:, :-1]
+    text = None if ctc else labels_index[:, :-1]
+
+    def inject(tag, n=1):
+        DROP_MASKS.clear()
+        if kind == "svtr":
+            for e in drop_masks(B, seed, tag, n):
+                DROP_MASKS.extend(e)
     domain = torch.from_numpy(W.randint("domain", (B,), 0, 2, seed))
 
     # ---- per-stage outputs of expert 0, train-mode BN (batch statistics) --------------------------------
@@ -117,11 +147,13 @@ def run(kind, classes, B, seed):
             put(d, "tps/P_hat", tps.GridGenerator.P_hat)
             x = tps(image)          # second pass also moves the BN running stats a second time; restore below
             put(d, "e0/tps_out", x)
+        inject("featmap")
         fm = m0.model.FeatureExtraction(x)
         put(d, "e0/featmap", fm)
     # reset weights/buffers (running stats were touched) and run the real forward paths
     W.fill_state_dict(net.state_dict(), seed)
     with torch.no_grad():
+        inject("e0")
         o = m0(image, text, True)
         put(d, "e0/feature", o["feature"])
         put(d, "e0/predict", o["predict"])
@@ -132,7 +164,7 @@ def run(kind, classes, B, seed):
     # ---- eval-mode expert forward (running statistics; Attn decodes greedily) ---------------------------
     net.eval()
     with torch.no_grad():
-        sos = None if kind == "crnn" else torch.LongTensor(B).fill_(2)   # test.py:186-189
+        sos = None if ctc else torch.LongTensor(B).fill_(2)   # test.py:186-189
         o = m0(image, sos, False)
         put(d, "e0_eval/feature", o["feature"])
         put(d, "e0_eval/predict", o["predict"])
@@ -141,7 +173,7 @@ def run(kind, classes, B, seed):
         d["eval/index"] = oe["index"].numpy()
         put(d, "eval/logits", oe["logits"])
         d["eval/argmax"] = oe["logits"].max(2)[1].numpy()
-        if kind == "crnn":
+        if ctc:
             am = oe["logits"].max(2)[1]
             d["eval/ctc_strings"] = np.array(conv.decode(am.numpy(), [am.shape[1]] * B))
 
@@ -157,13 +189,14 @@ def run(kind, classes, B, seed):
     sched = torch.optim.lr_scheduler.OneCycleLR(opt_, max_lr=0.0005, cycle_momentum=False, div_factor=20,
                                                 final_div_factor=1000, total_steps=20 * 2)
     taski_crit = torch.nn.CrossEntropyLoss(reduction="mean")
-    if kind == "crnn":
+    if ctc:
         crit = torch.nn.CTCLoss(reduction="mean", zero_infinity=True)
     else:
         crit = torch.nn.CrossEntropyLoss(reduction="mean", ignore_index=conv.dict["[PAD]"])
     before = {n: p.detach().clone() for n, p in zip(names, params)}
     for it in range(2):
-        if kind == "crnn":
+        inject(f"stepB{it}", I)
+        if ctc:
             out = net(image, True)
             preds = out["logits"]
             taski = taski_crit(out["index"], domain)
@@ -199,7 +232,8 @@ def run(kind, classes, B, seed):
     W.fill_state_dict(net.state_dict(), seed)
     net.train()
     with torch.no_grad():
-        if kind == "crnn":
+        inject("stepA")
+        if ctc:
             preds = net(image, False)["logits"]
             lossA = crit(preds.log_softmax(2).permute(1, 0, 2), labels_index, torch.IntTensor([preds.size(1)] * B), labels_length)
         else:
@@ -243,6 +277,7 @@ if __name__ == "__main__":
     jobs = {
         "crnn_mrn3": lambda: run("crnn", (40, 70, 97), 2, 1),
         "trba_mrn3": lambda: run("trba", (41, 71, 98), 2, 2),
+        "svtr_mrn3": lambda: run("svtr", (40, 70, 97), 2, 3),
         "converters": converters,
     }
     for name, fn in jobs.items():

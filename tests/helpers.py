@@ -54,7 +54,7 @@ def assert_close(name, a, b, atol=1e-4, rtol=1e-4):
 def det_inputs(kind, classes, B, seed):
     """Same synthetic batch the golden generator used (tests/golden/make_golden.py: run())."""
     image = torch.from_numpy(W.smooth_image("input:image", (B, 4, 32, 256), seed))
-    nspecial = 4 if kind == "crnn" else 5
+    nspecial = 4 if kind in ("crnn", "svtr") else 5
     nchar = classes[-1] - nspecial
     chars = "".join(chr(0x4E00 + i) for i in range(nchar))
     lens = W.randint("label_len", (B,), 1, 26, seed)
@@ -78,3 +78,9 @@ def assert_sub_l2(g, name, t, rel=0.05, q=0.99, q_atol=6e-6):
     assert l2 <= rel, f"{name}: relative L2 error {l2:.3e} > {rel}"
     assert np.quantile(err, q) <= q_atol, f"{name}: {q}-quantile abs err {np.quantile(err, q):.3e} > {q_atol}"
     return l2
+
+
+def drop_masks(B, seed, tag, n_experts=1):
+    """the DropPath draws the golden generator injected into the reference (tests/golden/make_golden.py)"""
+    return [[torch.from_numpy(W.randint(f"droppath:{tag}:{e}:{k}", (B,), 0, 2, seed)).float() for k in range(22)]
+            for e in range(n_experts)]

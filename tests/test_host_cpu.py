@@ -67,7 +67,8 @@ def test_one_cycle_matches_torch_scheduler():
         mine.lr_at(200)
 
 
-@pytest.mark.parametrize("name,kind,classes", [("crnn_mrn3", "crnn", (40, 70, 97)), ("trba_mrn3", "trba", (41, 71, 98))])
+@pytest.mark.parametrize("name,kind,classes", [("crnn_mrn3", "crnn", (40, 70, 97)), ("trba_mrn3", "trba", (41, 71, 98)),
+                                               ("svtr_mrn3", "svtr", (40, 70, 97))])
 def test_state_dict_layout_matches_reference(name, kind, classes):
     from mrn_amd.modules.model import MRNNet
     from mrn_amd.parallel import ReplicaDataParallel
@@ -75,6 +76,8 @@ def test_state_dict_layout_matches_reference(name, kind, classes):
                               batch_max_length=25)
     if kind == "crnn":
         o.Transformation, o.FeatureExtraction, o.SequenceModeling, o.Prediction = "None", "VGG", "BiLSTM", "CTC"
+    elif kind == "svtr":
+        o.Transformation, o.FeatureExtraction, o.SequenceModeling, o.Prediction = "None", "SVTR", "None", "CTC"
     else:
         o.Transformation, o.FeatureExtraction, o.SequenceModeling, o.Prediction = "TPS", "ResNet", "BiLSTM", "Attn"
     with contextlib.redirect_stdout(io.StringIO()):
@@ -90,7 +93,7 @@ def test_state_dict_layout_matches_reference(name, kind, classes):
     assert all(k.startswith("module.") for k in ReplicaDataParallel(net).state_dict())
     # fc and Prediction[.generator] alias one tensor, as in the reference (model.py:181,185-187)
     m = net.model[0]
-    head = m.Prediction if kind == "crnn" else m.Prediction.generator
+    head = m.Prediction if kind != "trba" else m.Prediction.generator
     assert head.weight.data_ptr() == m.fc.weight.data_ptr()
 
 
@@ -114,16 +117,16 @@ gathered = [torch.zeros(64) for _ in range(2)]
 torch.distributed.all_gather(gathered, shard_grad)
 assert torch.equal(gathered[0], gathered[1])
 parallel.barrier()
-print("rank", rank, "ok")
+open(os.path.join(os.environ["MRN_OUT"], f"ok_{rank}"), "w").write("ok")     # stdout of the two ranks can interleave
 """
 
 
 def test_data_parallel_helpers_gloo_world2(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MRN_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    env = dict(os.environ, MRN_ROOT=ROOT, MRN_OUT=str(tmp_path), MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                         "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+    assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists(), r.stdout + r.stderr

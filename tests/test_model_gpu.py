@@ -10,11 +10,25 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import assert_close, assert_sub_close, assert_sub_l2, det_inputs, golden_state_dict, load_golden
+from tests.helpers import (assert_close, assert_sub_close, assert_sub_l2, det_inputs, drop_masks, golden_state_dict,
+                           load_golden)
 
 pytestmark = pytest.mark.gpu
 
-CASES = {"crnn_mrn3": ("crnn", (40, 70, 97), 2, 1), "trba_mrn3": ("trba", (41, 71, 98), 2, 2)}
+CASES = {"crnn_mrn3": ("crnn", (40, 70, 97), 2, 1), "trba_mrn3": ("trba", (41, 71, 98), 2, 2),
+         "svtr_mrn3": ("svtr", (40, 70, 97), 2, 3)}
+
+
+def set_drop_masks(net, kind, B, seed, tag, experts):
+    """pin the DropPath draws of the given SVTR experts to the ones the golden generator injected into the reference"""
+    if kind != "svtr":
+        return
+    from mrn_amd.modules.svtr import DropPath
+    for e, masks in zip(experts, drop_masks(B, seed, tag, len(experts))):
+        mods = [m for m in net.model[e].modules() if isinstance(m, DropPath)]      # forward order, 11 per expert
+        assert len(mods) == 11
+        for j, m in enumerate(mods):
+            m.forced_masks = [masks[2 * j], masks[2 * j + 1]]
 
 
 def make_opt(kind):
@@ -22,6 +36,8 @@ def make_opt(kind):
                               batch_max_length=25)
     if kind == "crnn":
         o.Transformation, o.FeatureExtraction, o.SequenceModeling, o.Prediction = "None", "VGG", "BiLSTM", "CTC"
+    elif kind == "svtr":
+        o.Transformation, o.FeatureExtraction, o.SequenceModeling, o.Prediction = "None", "SVTR", "None", "CTC"
     else:
         o.Transformation, o.FeatureExtraction, o.SequenceModeling, o.Prediction = "TPS", "ResNet", "BiLSTM", "Attn"
     return o
@@ -46,7 +62,7 @@ def reload(net, g, seed):
 def labels_for(kind, words, chars):
     from mrn_amd.tools.utils import AttnLabelConverter, CTCLabelConverter
     with contextlib.redirect_stdout(io.StringIO()):
-        conv = CTCLabelConverter(chars) if kind == "crnn" else AttnLabelConverter(chars)
+        conv = CTCLabelConverter(chars) if kind != "trba" else AttnLabelConverter(chars)
     idx, ln = conv.encode(words, batch_max_length=25)
     return conv, idx, ln
 
@@ -60,7 +76,8 @@ def test_expert_forward_vs_golden(name):
     conv, labels_index, labels_length = labels_for(kind, words, chars)
     assert np.array_equal(labels_index.cpu().numpy(), g["labels_index"])
     image = image.cuda()
-    text = None if kind == "crnn" else labels_index[:, :-1].cuda()
+    ctc = kind != "trba"
+    text = None if ctc else labels_index[:, :-1].cuda()
     m0 = net.model[0]
     with torch.no_grad():
         net.train()
@@ -69,6 +86,7 @@ def test_expert_forward_vs_golden(name):
             assert_close("cprime", cp, g["e0/tps_cprime"], atol=2e-5)
             assert_sub_close(g, "e0/tps_out", out, atol=5e-4)      # fp32 conditioning of the TPS grid, see weights.smooth_image
             reload(net, g, seed)
+        set_drop_masks(net, kind, B, seed, "e0", [0])
         o = m0(image, text, True)
         assert_sub_close(g, "e0/feature", o["feature"], atol=1e-4)
         assert_sub_close(g, "e0/predict", o["predict"], atol=1e-4)
@@ -79,7 +97,7 @@ def test_expert_forward_vs_golden(name):
         assert any(np.abs(r.cpu().numpy() - g["e0/bn_running_mean_after"]).max() < 1e-5 for r in rm)
         reload(net, g, seed)
         net.eval()
-        sos = None if kind == "crnn" else torch.LongTensor(B).fill_(2).cuda()
+        sos = None if ctc else torch.LongTensor(B).fill_(2).cuda()
         o = m0(image, sos, False)
         assert_sub_close(g, "e0_eval/feature", o["feature"], atol=1e-4)
         assert_sub_close(g, "e0_eval/predict", o["predict"], atol=1e-4)
@@ -89,13 +107,14 @@ def test_expert_forward_vs_golden(name):
         assert_sub_close(g, "eval/logits", oe["logits"], atol=1e-4)
         am = oe["logits"].max(2)[1].cpu().numpy()
         assert np.array_equal(am, g["eval/argmax"])
-        if kind == "crnn":
+        if ctc:
             assert conv.decode(am, [am.shape[1]] * B) == [str(s) for s in g["eval/ctc_strings"]]
         # loop A forward + loss
         reload(net, g, seed)
         net.train()
         from mrn_amd import functional as Fn
-        if kind == "crnn":
+        set_drop_masks(net, kind, B, seed, "stepA", [len(classes) - 1])
+        if ctc:
             preds = net(image, False)["logits"]
             loss = Fn.ctc_loss(preds.contiguous(), labels_index.cuda(), labels_length.cuda())
         else:
@@ -151,7 +170,8 @@ def test_loop_b_two_steps_vs_golden(name):
     adam = FlatAdam(params, lr=0.0005)
     sched = OneCycle(0.0005, 40)
     for it in range(2):
-        if kind == "crnn":
+        set_drop_masks(net, kind, B, seed, f"stepB{it}", list(range(len(classes))))
+        if kind != "trba":
             out = net(image, True)
             clf = Fn.ctc_loss(out["logits"], labels_index, labels_length)
         else:

@@ -5,15 +5,22 @@ import pytest
 import torch
 
 from oracle import mrn_oracle as O
-from tests.helpers import assert_close, assert_sub_close, det_inputs, golden_state_dict, load_golden
+from tests.helpers import assert_close, assert_sub_close, det_inputs, drop_masks, golden_state_dict, load_golden
 
-CASES = {"crnn_mrn3": ("crnn", (40, 70, 97), 2, 1), "trba_mrn3": ("trba", (41, 71, 98), 2, 2)}
+CASES = {"crnn_mrn3": ("crnn", (40, 70, 97), 2, 1), "trba_mrn3": ("trba", (41, 71, 98), 2, 2),
+         "svtr_mrn3": ("svtr", (40, 70, 97), 2, 3)}
 
 
 def cfg_for(kind):
     if kind == "crnn":
         return O.Cfg("None", "VGG", "BiLSTM", "CTC")
+    if kind == "svtr":
+        return O.Cfg("None", "SVTR", "None", "CTC")
     return O.Cfg("TPS", "ResNet", "BiLSTM", "Attn")
+
+
+def masks_for(kind, B, seed, tag, n=1):
+    return drop_masks(B, seed, tag, n) if kind == "svtr" else None
 
 
 def test_converters_match_reference():
@@ -43,11 +50,12 @@ def test_expert_forward_train_and_eval(name):
     g = load_golden(name)
     cfg = cfg_for(kind)
     image, words, chars, _ = det_inputs(kind, classes, B, seed)
-    conv = O.CTCConverter(chars) if kind == "crnn" else O.AttnConverter(chars)
+    ctc = kind != "trba"
+    conv = O.CTCConverter(chars) if ctc else O.AttnConverter(chars)
     labels_index, labels_length = conv.encode(words, 25)
     assert np.array_equal(labels_index.numpy(), g["labels_index"])
     assert np.array_equal(labels_length.numpy(), g["labels_length"])
-    text = None if kind == "crnn" else labels_index[:, :-1]
+    text = None if ctc else labels_index[:, :-1]
 
     torch.set_grad_enabled(False)
     try:
@@ -57,12 +65,15 @@ def test_expert_forward_train_and_eval(name):
             assert_close("cprime", cp, g["e0/tps_cprime"], atol=1e-5)
             assert_sub_close(g, "e0/tps_out", out, atol=1e-5)
             fm = O.resnet_forward(sd, "model.0.model.FeatureExtraction.", out, True)
+        elif kind == "svtr":
+            fm = O.svtr_forward(sd, "model.0.model.FeatureExtraction.", image, True, masks_for(kind, B, seed, "featmap")[0])
         else:
             fm = O.vgg_forward(sd, "model.0.model.FeatureExtraction.", image, True)
         assert_sub_close(g, "e0/featmap", fm, atol=2e-5)
 
         sd = golden_state_dict(g, seed)
-        o = O.model_forward(sd, "model.0.", cfg, image, text, True, training=True)
+        m = masks_for(kind, B, seed, "e0")
+        o = O.model_forward(sd, "model.0.", cfg, image, text, True, training=True, masks=m[0] if m else None)
         assert_sub_close(g, "e0/feature", o["feature"], atol=2e-5)
         assert_sub_close(g, "e0/predict", o["predict"], atol=2e-5)
         first_rm = sorted(k for k in sd if k.startswith("model.0.") and k.endswith("running_mean"))
@@ -71,7 +82,7 @@ def test_expert_forward_train_and_eval(name):
         assert any(np.abs(r.numpy() - g["e0/bn_running_mean_after"]).max() < 1e-5 for r in rm)
 
         sd = golden_state_dict(g, seed)
-        sos = None if kind == "crnn" else torch.LongTensor(B).fill_(2)
+        sos = None if ctc else torch.LongTensor(B).fill_(2)
         o = O.model_forward(sd, "model.0.", cfg, image, sos, False, training=False)
         assert_sub_close(g, "e0_eval/feature", o["feature"], atol=2e-5)
         assert_sub_close(g, "e0_eval/predict", o["predict"], atol=2e-5)
@@ -80,7 +91,7 @@ def test_expert_forward_train_and_eval(name):
         assert np.array_equal(oe["index"].numpy(), g["eval/index"])
         assert_sub_close(g, "eval/logits", oe["logits"], atol=2e-5)
         assert np.array_equal(oe["logits"].max(2)[1].numpy(), g["eval/argmax"])
-        if kind == "crnn":
+        if ctc:
             am = oe["logits"].max(2)[1].numpy()
             assert conv.decode(am, [am.shape[1]] * B) == [str(s) for s in g["eval/ctc_strings"]]
     finally:
@@ -94,16 +105,17 @@ def test_loop_b_two_steps(name):
     g = load_golden(name)
     cfg = cfg_for(kind)
     image, words, chars, domain = det_inputs(kind, classes, B, seed)
-    conv = O.CTCConverter(chars) if kind == "crnn" else O.AttnConverter(chars)
+    conv = O.CTCConverter(chars) if kind != "trba" else O.AttnConverter(chars)
     labels_index, labels_length = conv.encode(words, 25)
-    text = None if kind == "crnn" else labels_index[:, :-1]
+    text = None if kind != "trba" else labels_index[:, :-1]
     sd = golden_state_dict(g, seed)
     names = [str(n) for n in g["router_param_names"]]
     params = [sd[n].requires_grad_(True) for n in names]
     before = [p.detach().clone() for p in params]
     state = [{"m": torch.zeros_like(p), "v": torch.zeros_like(p)} for p in params]
     for it in range(2):
-        out = O.mrn_forward(sd, cfg, len(classes), image, True, text, True, training=True)
+        out = O.mrn_forward(sd, cfg, len(classes), image, True, text, True, training=True,
+                            masks=masks_for(kind, B, seed, f"stepB{it}", len(classes)))
         loss, clf, taski = O.mrn_step_loss(out, labels_index, labels_length, domain, cfg.Prediction)
         grads = torch.autograd.grad(loss, params)
         lr = O.one_cycle_lr(it, 40, 0.0005)
@@ -135,12 +147,14 @@ def test_loop_a_forward_loss(name):
     g = load_golden(name)
     cfg = cfg_for(kind)
     image, words, chars, _ = det_inputs(kind, classes, B, seed)
-    conv = O.CTCConverter(chars) if kind == "crnn" else O.AttnConverter(chars)
+    conv = O.CTCConverter(chars) if kind != "trba" else O.AttnConverter(chars)
     labels_index, labels_length = conv.encode(words, 25)
     with torch.no_grad():
         sd = golden_state_dict(g, seed)
-        text = None if kind == "crnn" else labels_index[:, :-1]
-        out = O.mrn_forward(sd, cfg, len(classes), image, False, text, True, training=True)
+        text = None if kind != "trba" else labels_index[:, :-1]
+        m = masks_for(kind, B, seed, "stepA")
+        masks = [None] * (len(classes) - 1) + [m[0]] if m else None       # cross=False runs the newest expert only
+        out = O.mrn_forward(sd, cfg, len(classes), image, False, text, True, training=True, masks=masks)
         assert_sub_close(g, "stepA/logits", out["logits"], atol=2e-5)
-        loss = O.ctc_loss(out["logits"], labels_index, labels_length) if kind == "crnn" else O.attn_ce_loss(out["logits"], labels_index)
+        loss = O.ctc_loss(out["logits"], labels_index, labels_length) if kind != "trba" else O.attn_ce_loss(out["logits"], labels_index)
         assert abs(loss.item() - float(g["stepA/loss"])) < 1e-5 * max(1, abs(float(g["stepA/loss"])))
