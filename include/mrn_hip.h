@@ -240,6 +240,23 @@ int mrn_ctc_loss_bwd_f32(const float* logits, int64_t ld, const float* lse, cons
                          int64_t tstride, const int* target_len, const float* nll, const float* upstream,
                          float* dlogits, int64_t ldd, int B, int T, int C, int blank, void* stream);
 
+/* Knowledge distillation of LwF / WA (il_modules/lwf.py:81-87,111-114): loss = -sum softmax(old/T) log_softmax(new/T) / rows
+ * over the class slice [c0, c1); bwd writes d loss / d new over all C columns (zeros outside the slice). */
+int mrn_kd_loss_fwd_f32(const float* xnew, int64_t ldn, const float* xold, int64_t ldo, int c0, int c1, float T,
+                        int64_t rows, float* loss_rows, float* loss, void* stream);
+int mrn_kd_loss_bwd_f32(const float* xnew, int64_t ldn, const float* xold, int64_t ldo, int c0, int c1, float T,
+                        int64_t rows, const float* upstream, float* dnew, int64_t ldd, int C, void* stream);
+
+/* ---- EWC and weight alignment (il_modules/ewc.py:120-167, modules/model.py:166-174) ------------------------------ */
+int mrn_fisher_accumulate_f32(float* fisher, const float* grad, int64_t n, void* stream);           /* F += g^2 */
+int mrn_fisher_finalize_f32(float* fisher, int64_t n, float inv_iterations, float fisher_max, void* stream);
+int mrn_ewc_penalty_fwd_f32(const float* fisher, const float* p, const float* mean, int64_t n, float* workspace,
+                            float* penalty, void* stream);                                       /* sum F (p-p*)^2 / 2 */
+int mrn_ewc_penalty_bwd_f32(const float* fisher, const float* p, const float* mean, float* grad, int64_t n, float coef,
+                            void* stream);                                                       /* g += coef F (p-p*) */
+int mrn_weight_align_f32(float* w, int64_t ld, int64_t rows, int64_t n_old, int C, float* workspace, float* gamma_out,
+                         void* stream);
+
 /* ---- optimiser (il_modules/base.py:85,255-262) ------------------------------------------------------------------ */
 
 int64_t mrn_grad_norm_workspace_floats(int64_t n);

@@ -185,7 +185,71 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
   }
 }
 
+// ---- knowledge distillation (LwF): -sum softmax(old/T) * log_softmax(new/T) / rows over the class slice [c0, c1) -------
+// reference il_modules/lwf.py:81-87,111-114.  One block per row.  loss_rows[row] = -sum_c p_old * logp_new.
+// When dnew != nullptr also writes d loss / d new = (softmax(new/T) - softmax(old/T)) / T * g (zeros outside the slice).
+__global__ __launch_bounds__(256) void kd_rows_kernel(const float* __restrict__ xnew, long ldn, const float* __restrict__ xold,
+                                                      long ldo, int c0, int c1, float invT, float* __restrict__ loss_rows,
+                                                      const float* __restrict__ upstream, float inv_rows,
+                                                      float* __restrict__ dnew, long ldd, int C) {
+  __shared__ float scratch[4];
+  const long row = blockIdx.x;
+  const float* a = xnew + row * ldn;
+  const float* b = xold + row * ldo;
+  float ma = -INFINITY, mb = -INFINITY;
+  for (int c = c0 + threadIdx.x; c < c1; c += 256) { ma = fmaxf(ma, a[c] * invT); mb = fmaxf(mb, b[c] * invT); }
+  ma = block_max<256>(ma, scratch);
+  mb = block_max<256>(mb, scratch);
+  float sa = 0.f, sb = 0.f;
+  for (int c = c0 + threadIdx.x; c < c1; c += 256) { sa += expf(a[c] * invT - ma); sb += expf(b[c] * invT - mb); }
+  sa = block_sum<256>(sa, scratch);
+  sb = block_sum<256>(sb, scratch);
+  const float lsa = ma + logf(sa), lsb = mb + logf(sb);
+  if (loss_rows) {
+    float l = 0.f;
+    for (int c = c0 + threadIdx.x; c < c1; c += 256) l -= expf(b[c] * invT - lsb) * (a[c] * invT - lsa);
+    l = block_sum<256>(l, scratch);
+    if (threadIdx.x == 0) loss_rows[row] = l;
+  }
+  if (dnew) {
+    const float g = upstream[0] * inv_rows * invT;
+    float* d = dnew + row * ldd;
+    for (int c = threadIdx.x; c < C; c += 256)
+      d[c] = (c >= c0 && c < c1) ? (expf(a[c] * invT - lsa) - expf(b[c] * invT - lsb)) * g : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void mean_finalize_kernel(const float* __restrict__ v, long n, float scale, float* __restrict__ out) {
+  __shared__ float scratch[4];
+  float s = 0.f;
+  for (long i = threadIdx.x; i < n; i += 256) s += v[i];
+  s = block_sum<256>(s, scratch);
+  if (threadIdx.x == 0) out[0] = s * scale;
+}
+
 }  // namespace
+
+MRN_EXPORT int mrn_kd_loss_fwd_f32(const float* xnew, int64_t ldn, const float* xold, int64_t ldo, int c0, int c1, float T,
+                                   int64_t rows, float* loss_rows, float* loss, void* stream) {
+  MRN_CHECK_ARG(xnew && xold && loss_rows && loss && c1 > c0 && T > 0.f, "mrn_kd_loss_fwd_f32: bad operands");
+  if (rows == 0) return MRN_OK;
+  hipLaunchKernelGGL(kd_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, xnew, (long)ldn, xold, (long)ldo, c0,
+                     c1, 1.f / T, loss_rows, (const float*)nullptr, 0.f, (float*)nullptr, 0L, 0);
+  hipLaunchKernelGGL(mean_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)loss_rows, (long)rows,
+                     1.f / (float)rows, loss);
+  MRN_LAUNCH_CHECK("kd_loss_fwd");
+  return MRN_OK;
+}
+
+MRN_EXPORT int mrn_kd_loss_bwd_f32(const float* xnew, int64_t ldn, const float* xold, int64_t ldo, int c0, int c1, float T,
+                                   int64_t rows, const float* upstream, float* dnew, int64_t ldd, int C, void* stream) {
+  MRN_CHECK_ARG(xnew && xold && upstream && dnew && c1 > c0 && T > 0.f, "mrn_kd_loss_bwd_f32: bad operands");
+  if (rows == 0) return MRN_OK;
+  hipLaunchKernelGGL(kd_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, xnew, (long)ldn, xold, (long)ldo, c0,
+                     c1, 1.f / T, (float*)nullptr, upstream, 1.f / (float)rows, dnew, (long)ldd, C);
+  MRN_LAUNCH_CHECK("kd_loss_bwd");
+  return MRN_OK;
+}
 
 MRN_EXPORT int mrn_ce_loss_fwd_f32(const float* logits, int64_t ld, const int64_t* target, int64_t ignore_index,
                                    int64_t rows, int C, float* lse, float* loss_rows, float* loss, float* inv_count,

@@ -54,7 +54,129 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
   }
 }
 
+// ---- EWC (il_modules/ewc.py:120-167) and weight alignment (modules/model.py:166-174) -------------------------------
+// mode 0: fisher += g*g        mode 1: fisher = min(fisher * a, b)      mode 2: g += a * fisher * (p - mean)
+__global__ __launch_bounds__(256) void ewc_elementwise_kernel(float* __restrict__ fisher, float* __restrict__ g,
+                                                              const float* __restrict__ p, const float* __restrict__ mean,
+                                                              long n, int mode, float a, float b) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    if (mode == 0) fisher[i] += g[i] * g[i];
+    else if (mode == 1) fisher[i] = fminf(fisher[i] * a, b);
+    else g[i] += a * fisher[i] * (p[i] - mean[i]);
+  }
+}
+
+// part[blk] = sum fisher * (p - mean)^2 / 2
+__global__ __launch_bounds__(256) void ewc_penalty_partial_kernel(const float* __restrict__ fisher, const float* __restrict__ p,
+                                                                  const float* __restrict__ mean, long n, float* __restrict__ part) {
+  __shared__ float scratch[4];
+  float s = 0.f;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float d = p[i] - mean[i];
+    s += fisher[i] * d * d;
+  }
+  s = block_sum<256>(s, scratch);
+  if (threadIdx.x == 0) part[blockIdx.x] = 0.5f * s;
+}
+
+__global__ __launch_bounds__(256) void sum_finalize_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
+  __shared__ float scratch[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+  s = block_sum<256>(s, scratch);
+  if (threadIdx.x == 0) out[0] = s;
+}
+
+// norms[r] = ||w[r][:]||_2   (one wave per row)
+__global__ __launch_bounds__(256) void row_l2norm_kernel(const float* __restrict__ w, long ld, float* __restrict__ norms, long rows,
+                                                        int C) {
+  const int lane = threadIdx.x & 63;
+  const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) { const float v = w[row * ld + c]; s += v * v; }
+  s = wave_sum(s);
+  if (lane == 0) norms[row] = sqrtf(s);
+}
+
+// gamma = mean(norms[:n_old]) / mean(norms[n_old:]);  w[n_old:] *= gamma   (single block computes gamma, then all scale)
+__global__ __launch_bounds__(256) void weight_align_kernel(float* __restrict__ w, long ld, const float* __restrict__ norms, long rows,
+                                                          long n_old, int C, float* __restrict__ gamma_out) {
+  __shared__ float scratch[4];
+  float so = 0.f, sn = 0.f;
+  for (long r = threadIdx.x; r < rows; r += 256) { if (r < n_old) so += norms[r]; else sn += norms[r]; }
+  so = block_sum<256>(so, scratch);
+  sn = block_sum<256>(sn, scratch);
+  const float gamma = (so / (float)n_old) / (sn / (float)(rows - n_old));
+  if (blockIdx.x == 0 && threadIdx.x == 0) gamma_out[0] = gamma;
+  const long n = (rows - n_old) * C;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long r = n_old + i / C;
+    const int c = (int)(i % C);
+    w[r * ld + c] *= gamma;
+  }
+}
+
 }  // namespace
+
+static inline int opt_grid(long n) {
+  long g = (n + 255) / 256;
+  if (g > 2048) g = 2048;
+  return g < 1 ? 1 : (int)g;
+}
+
+MRN_EXPORT int mrn_fisher_accumulate_f32(float* fisher, const float* grad, int64_t n, void* stream) {
+  MRN_CHECK_ARG(fisher && grad, "mrn_fisher_accumulate_f32: null operand");
+  if (n == 0) return MRN_OK;
+  hipLaunchKernelGGL(ewc_elementwise_kernel, dim3(opt_grid(n)), dim3(256), 0, (hipStream_t)stream, fisher, (float*)grad,
+                     (const float*)nullptr, (const float*)nullptr, (long)n, 0, 0.f, 0.f);
+  MRN_LAUNCH_CHECK("fisher_accumulate");
+  return MRN_OK;
+}
+
+// fisher = min(fisher / iterations, fisher_max)
+MRN_EXPORT int mrn_fisher_finalize_f32(float* fisher, int64_t n, float inv_iterations, float fisher_max, void* stream) {
+  MRN_CHECK_ARG(fisher, "mrn_fisher_finalize_f32: null operand");
+  if (n == 0) return MRN_OK;
+  hipLaunchKernelGGL(ewc_elementwise_kernel, dim3(opt_grid(n)), dim3(256), 0, (hipStream_t)stream, fisher, (float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, (long)n, 1, inv_iterations, fisher_max);
+  MRN_LAUNCH_CHECK("fisher_finalize");
+  return MRN_OK;
+}
+
+// penalty[0] = sum fisher * (p - mean)^2 / 2 ; workspace: 2048 floats
+MRN_EXPORT int mrn_ewc_penalty_fwd_f32(const float* fisher, const float* p, const float* mean, int64_t n, float* workspace,
+                                       float* penalty, void* stream) {
+  MRN_CHECK_ARG(fisher && p && mean && workspace && penalty, "mrn_ewc_penalty_fwd_f32: null operand");
+  const int nb = opt_grid(n);
+  hipLaunchKernelGGL(ewc_penalty_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, fisher, p, mean, (long)n, workspace);
+  hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, nb, penalty);
+  MRN_LAUNCH_CHECK("ewc_penalty_fwd");
+  return MRN_OK;
+}
+
+// grad += coef * fisher * (p - mean)
+MRN_EXPORT int mrn_ewc_penalty_bwd_f32(const float* fisher, const float* p, const float* mean, float* grad, int64_t n,
+                                       float coef, void* stream) {
+  MRN_CHECK_ARG(fisher && p && mean && grad, "mrn_ewc_penalty_bwd_f32: null operand");
+  if (n == 0) return MRN_OK;
+  hipLaunchKernelGGL(ewc_elementwise_kernel, dim3(opt_grid(n)), dim3(256), 0, (hipStream_t)stream, (float*)fisher, grad, p, mean,
+                     (long)n, 2, coef, 0.f);
+  MRN_LAUNCH_CHECK("ewc_penalty_bwd");
+  return MRN_OK;
+}
+
+// Model.weight_align: scale the newest `rows - n_old` rows of w by mean||old rows|| / mean||new rows||; workspace: rows floats
+MRN_EXPORT int mrn_weight_align_f32(float* w, int64_t ld, int64_t rows, int64_t n_old, int C, float* workspace, float* gamma_out,
+                                    void* stream) {
+  MRN_CHECK_ARG(w && workspace && gamma_out && n_old > 0 && n_old < rows, "mrn_weight_align_f32: bad operands");
+  hipLaunchKernelGGL(row_l2norm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)w,
+                     (long)ld, workspace, (long)rows, C);
+  hipLaunchKernelGGL(weight_align_kernel, dim3(opt_grid((rows - n_old) * C)), dim3(256), 0, (hipStream_t)stream, w, (long)ld,
+                     (const float*)workspace, (long)rows, (long)n_old, C, gamma_out);
+  MRN_LAUNCH_CHECK("weight_align");
+  return MRN_OK;
+}
 
 MRN_EXPORT int64_t mrn_grad_norm_workspace_floats(int64_t n) {
   int64_t b = (n / 4 + 255) / 256;

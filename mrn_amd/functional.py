@@ -461,3 +461,23 @@ class AttnDecoderFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dH = linear_dgrad(dHproj, i2h_w, out=dHb.view(B * T, D), accumulate=True).view(B, T, D)
         return (dH, None, di2h_w, dh2h_w, dh2h_b, dws.view_as(score_w), dw_ih, dw_hh, db, db, demb_w, dgen_w, dgen_b, None)
+
+
+class KDLossFn(torch.autograd.Function):
+    """_KD_loss of LwF/WA (reference il_modules/lwf.py:111-114) on the class slice [c0, c1); the teacher carries no grad."""
+
+    @staticmethod
+    def forward(ctx, pred, soft, c0, c1, T):
+        ctx.save_for_backward(pred, soft)
+        ctx.args = (c0, c1, T)
+        return ops.kd_loss_fwd(pred, soft, c0, c1, T).view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, soft = ctx.saved_tensors
+        c0, c1, T = ctx.args
+        return ops.kd_loss_bwd(pred, soft, c0, c1, T, g.contiguous().view(1)), None, None, None, None
+
+
+def kd_loss(pred, soft, c0, c1, T=2.0):
+    return KDLossFn.apply(pred, soft, c0, c1, T)

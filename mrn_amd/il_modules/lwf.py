@@ -1,0 +1,53 @@
+"""LwF learner (reference il_modules/lwf.py:26-114): tasks > 0 add a knowledge-distillation term against the frozen
+previous network: loss = 3 * KD(T=2 on the old classes) + loss_clf."""
+import time
+
+import torch
+
+from .. import functional as Fn
+from ..tools.utils import Averager
+from .base import BaseLearner
+
+T = 2
+lamda = 3
+
+
+class LwF(BaseLearner):
+    kd_weight = lamda
+
+    def after_task(self):
+        self.model = self.model.module
+        self._old_network = self.model.copy().freeze()
+        self._known_classes = self._total_classes
+
+    def _train(self, start_iter, taski, train_loader, valid_loader):
+        if taski == 0:
+            self._init_train(start_iter, taski, train_loader, valid_loader.create_dataset())
+        else:
+            self._update_representation(start_iter, taski, train_loader, valid_loader.create_dataset())
+
+    def kd_step(self, image, labels):
+        """one iteration of lwf.py:52-95"""
+        labels_index, labels_length = self.converter.encode(labels, batch_max_length=self.opt.batch_max_length)
+        ctc = "CTC" in self.opt.Prediction
+        text = None if ctc else labels_index[:, :-1]
+        preds = self.model(image, text, True)["predict"]
+        with torch.no_grad():
+            old = self._old_network(image, text, True)["predict"]
+        loss_clf = self.criterion(preds, labels_index, labels_length)
+        loss_kd = Fn.kd_loss(preds, old, 0 if ctc else 1, self._known_classes, T)
+        loss = self.kd_weight * loss_kd + loss_clf
+        self.optimizer_step(loss)
+        return loss, loss_kd
+
+    def _update_representation(self, start_iter, taski, train_loader, valid_loader):
+        train_loader.get_dataset(taski, memory=self.opt.memory)
+        avg = Averager()
+        start_time, best = time.time(), -1
+        for iteration in range(start_iter + 1, self.opt.num_iter + 1):
+            image, labels = train_loader.get_batch()
+            loss, _ = self.kd_step(image.to(self.device), labels)
+            avg.add(loss.detach())
+            if iteration % self.opt.val_interval == 0 or iteration == 1:
+                best = self.val(valid_loader, self.opt, best, start_time, iteration, avg, None, taski)
+                avg.reset()

@@ -129,12 +129,10 @@ class Model(nn.Module):
         self.fc = nn.Linear(hidden_size, nb_classes)
 
     def weight_align(self, increment):
-        weights = self.fc.weight.data
-        newnorm = torch.norm(weights[-increment:, :], p=2, dim=1)
-        oldnorm = torch.norm(weights[:-increment, :], p=2, dim=1)
-        gamma = torch.mean(oldnorm) / torch.mean(newnorm)
-        print("alignweights,gamma=", gamma)
-        self.fc.weight.data[-increment:, :] *= gamma
+        """rescale the newest `increment` rows of fc so their mean L2 norm matches the old rows' (reference :166-174)"""
+        gamma = ops.weight_align_(self.fc.weight.data, increment)
+        print("alignweights,gamma=", float(gamma))
+        return gamma
 
     def build_prediction(self, opt, num_class):
         if opt.Prediction == "CTC":
@@ -152,6 +150,97 @@ class Model(nn.Module):
             p.requires_grad = False
         self.eval()
         return self
+
+
+class DERNet(Model):
+    """Dynamically expanding network (reference modules/model.py:203-312): one Model_Extractor per task, features
+    concatenated on the channel axis, main head over all of them, auxiliary head over the newest 256."""
+
+    def __init__(self, opt):
+        super().__init__(opt)
+        self.model = nn.ModuleList()
+        self.out_dim = None
+        self.fc = None
+        self.aux_fc = None
+        self.task_sizes = []
+
+    @property
+    def feature_dim(self):
+        return 0 if self.out_dim is None else self.out_dim * len(self.model)
+
+    def _features(self, image):
+        """[B,T,out_dim*N]: frozen extractors write straight into their channel slice (no torch.cat pass)"""
+        image = to_nhwc(image).permute(0, 3, 1, 2)
+        trainable = [needs_grad(ext, image) for ext in self.model]
+        buf, outs = None, []
+        for i, ext in enumerate(self.model):
+            if trainable[i]:
+                outs.append(ext(image))
+                continue
+            with torch.no_grad():
+                vis = ext.visual(image)
+                if buf is None:
+                    buf = torch.empty(vis.shape[0], vis.shape[1], self.feature_dim, device=vis.device, dtype=torch.float32)
+                sl = buf[:, :, i * self.out_dim:(i + 1) * self.out_dim]
+                ext.sequence(vis, out=sl)
+                outs.append(sl)
+        return buf if not any(trainable) else torch.cat(outs, -1)
+
+    def _head(self, head, feat, text, is_train):
+        if self.stages["Pred"] == "CTC":
+            if needs_grad(head, feat):
+                return LinearFn.apply(feat, head.weight, head.bias)
+            return ops.linear(feat, head.weight, head.bias)
+        return head(feat if feat.is_contiguous() else feat.contiguous(), text, is_train, batch_max_length=self.opt.batch_max_length)
+
+    def forward(self, image, text=None, is_train=True):
+        feat = self._features(image)
+        logits = self._head(self.Prediction, feat, text, is_train)
+        aux = self._head(self.aux_Prediction, feat[:, :, -self.out_dim:], text, is_train)
+        return {"logits": logits, "aux_logits": aux, "features": feat}
+
+    def update_fc(self, hidden_size, nb_classes, device=None):
+        dev = next(self.parameters()).device if len(self.model) else None
+        self.model.append(Model_Extractor(self.opt))
+        if len(self.model) > 1:
+            self.model[-1].load_state_dict(self.model[-2].state_dict())
+        if self.out_dim is None:
+            self.out_dim = self.model[-1].SequenceModeling_output
+        fc = nn.Linear(self.feature_dim if self.opt.Prediction == "CTC" else self.out_dim, nb_classes)
+        if self.fc is not None:                       # keep the old classes' rows over the old extractors' columns
+            old_w, old_b = self.fc.weight.data.cpu(), self.fc.bias.data.cpu()
+            ncol = min(old_w.shape[1], self.feature_dim - self.out_dim, fc.weight.shape[1])
+            fc.weight.data[:old_w.shape[0], :ncol] = old_w[:, :ncol]
+            fc.bias.data[:old_b.shape[0]] = old_b
+        self.fc = fc
+        self.aux_fc = nn.Linear(self.out_dim, nb_classes)
+        if dev is not None:
+            self.to(dev)
+
+    def build_prediction(self, opt, num_class):
+        if opt.Prediction == "CTC":
+            self.Prediction = self.fc
+        elif opt.Prediction == "Attn":
+            self.Prediction = Attention(self.feature_dim, opt.hidden_size, num_class, self.fc)
+        else:
+            raise Exception("Prediction is neither CTC or Attn")
+        if len(self.model) > 1:
+            self.Prediction.to(next(self.model[0].parameters()).device)
+
+    def build_aux_prediction(self, opt, num_class):
+        if opt.Prediction == "CTC":
+            self.aux_Prediction = self.aux_fc
+        elif opt.Prediction == "Attn":
+            self.aux_Prediction = Attention(self.SequenceModeling_output, opt.hidden_size, num_class, self.aux_fc)
+        else:
+            raise Exception("Prediction is neither CTC or Attn")
+        if len(self.model) > 1:
+            self.aux_Prediction.to(next(self.model[0].parameters()).device)
+
+    def freeze_conv(self):
+        for p in self.model.parameters():
+            p.requires_grad = False
+        self.model.eval()
 
 
 class MRNNet(nn.Module):

@@ -745,3 +745,53 @@ def residual_scale_rows(x, branch, scale, rows_per_group, out=None):
         out = torch.empty_like(x)
     call("mrn_residual_scale_rows_f32", _p(x), _p(branch), _p(scale), _p(out), rows, C, rows_per_group, _stream())
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# LwF / EWC / weight alignment
+# ---------------------------------------------------------------------------------------------------------
+def kd_loss_fwd(xnew, xold, c0, c1, T):
+    n2, o2 = rows2d(xnew), rows2d(xold)
+    rows = n2.shape[0]
+    lrows = torch.empty(rows, device=xnew.device, dtype=torch.float32)
+    loss = torch.empty(1, device=xnew.device, dtype=torch.float32)
+    call("mrn_kd_loss_fwd_f32", _p(n2), n2.stride(0), _p(o2), o2.stride(0), c0, c1, float(T), rows, _p(lrows), _p(loss), _stream())
+    return loss
+
+
+def kd_loss_bwd(xnew, xold, c0, c1, T, upstream):
+    n2, o2 = rows2d(xnew), rows2d(xold)
+    rows, C = n2.shape
+    d = torch.empty_strided(xnew.shape, xnew.stride(), device=xnew.device, dtype=torch.float32)
+    d2 = rows2d(d)
+    call("mrn_kd_loss_bwd_f32", _p(n2), n2.stride(0), _p(o2), o2.stride(0), c0, c1, float(T), rows, _p(upstream), _p(d2),
+         d2.stride(0), C, _stream())
+    return d
+
+
+def fisher_accumulate(fisher, grad):
+    call("mrn_fisher_accumulate_f32", _p(fisher), _p(grad), fisher.numel(), _stream())
+
+
+def fisher_finalize(fisher, iterations, fisher_max):
+    call("mrn_fisher_finalize_f32", _p(fisher), fisher.numel(), 1.0 / iterations, float(fisher_max), _stream())
+
+
+def ewc_penalty(fisher, p, mean):
+    ws = torch.empty(2048, device=p.device, dtype=torch.float32)
+    out = torch.empty(1, device=p.device, dtype=torch.float32)
+    call("mrn_ewc_penalty_fwd_f32", _p(fisher), _p(p), _p(mean), p.numel(), _p(ws), _p(out), _stream())
+    return out
+
+
+def ewc_penalty_grad_(grad, fisher, p, mean, coef):
+    call("mrn_ewc_penalty_bwd_f32", _p(fisher), _p(p), _p(mean), _p(grad), p.numel(), float(coef), _stream())
+
+
+def weight_align_(weight, increment):
+    """scale the last `increment` rows of weight [rows, C] by mean||old||/mean||new|| (in place) -> gamma (device scalar)"""
+    rows, C = weight.shape
+    ws = torch.empty(rows, device=weight.device, dtype=torch.float32)
+    gamma = torch.empty(1, device=weight.device, dtype=torch.float32)
+    call("mrn_weight_align_f32", _p(weight), weight.stride(0), rows, rows - increment, C, _p(ws), _p(gamma), _stream())
+    return gamma

@@ -339,6 +339,37 @@ def model_forward(sd, pre, cfg, image, text=None, is_train=True, training=True, 
     return {"predict": pred, "feature": feat}
 
 
+def dernet_forward(sd, cfg, n_extractors, image, text=None, is_train=True, training=True, old_eval=True):
+    """DERNet.forward, modules/model.py:223-254: N extractors -> concat -> main head (+ aux head on the newest 256).
+    old_eval: old extractors run in eval mode during training (der.py:39-44 model_eval_and_train)."""
+    feats = []
+    for i in range(n_extractors):
+        tr = training and not (old_eval and i < n_extractors - 1)
+        feats.append(extractor_forward(sd, f"model.{i}.", cfg, image, tr))
+    feat = torch.cat(feats, -1)
+    hid = feats[-1].shape[-1]
+    if cfg.Prediction == "CTC":
+        logits = F.linear(feat, sd["fc.weight"], sd["fc.bias"])
+        aux = F.linear(feat[:, :, -hid:], sd["aux_fc.weight"], sd["aux_fc.bias"])
+    else:
+        logits = attention_forward(sd, "Prediction.", feat, text, is_train, cfg.batch_max_length, sd["fc.weight"], sd["fc.bias"])
+        aux = attention_forward(sd, "aux_Prediction.", feat[:, :, -hid:].contiguous(), text, is_train, cfg.batch_max_length,
+                                sd["aux_fc.weight"], sd["aux_fc.bias"])
+    return {"logits": logits, "aux_logits": aux, "features": feat}
+
+
+def kd_loss(pred, soft, T=2.0):
+    """_KD_loss, il_modules/lwf.py:111-114"""
+    return -1 * torch.mul(torch.softmax(soft / T, dim=1), torch.log_softmax(pred / T, dim=1)).sum() / pred.shape[0]
+
+
+def weight_align_gamma(fc_weight, increment):
+    """Model.weight_align, modules/model.py:166-174"""
+    new = torch.norm(fc_weight[-increment:, :], p=2, dim=1)
+    old = torch.norm(fc_weight[:-increment, :], p=2, dim=1)
+    return torch.mean(old) / torch.mean(new)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # DM-Router and MRN fan-in (modules/dm_router.py, modules/model.py:361-423)
 # ---------------------------------------------------------------------------------------------------------

@@ -251,6 +251,48 @@ def _first_bn(net, leaf):
     raise KeyError(leaf)
 
 
+def der(kind, classes, B, seed):
+    """DERNet with two extractors (reference modules/model.py:203-312): forward in the training configuration of
+    DER._update_representation (old extractor eval, new one train), weight_align gamma, LwF KD loss on the logits."""
+    from modules.model import DERNet
+
+    def _KD_loss(pred, soft, T):         # the three torch calls of il_modules/lwf.py:111-114 (importing il_modules needs lmdb/cv2/mmcv)
+        pred = torch.log_softmax(pred / T, dim=1)
+        soft = torch.softmax(soft / T, dim=1)
+        return -1 * torch.mul(soft, pred).sum() / pred.shape[0]
+    d = {}
+    opt = make_opt(kind)
+    net = DERNet(opt)
+    for c in classes:
+        net.update_fc(opt.hidden_size, c)
+        net.build_prediction(opt, c)
+        net.build_aux_prediction(opt, c)
+    sd0 = net.state_dict()
+    d["sd_keys"] = np.array(sorted(sd0.keys()))
+    d["sd_shapes"] = np.array([",".join(map(str, sd0[k].shape)) for k in sorted(sd0.keys())])
+    W.fill_state_dict(net.state_dict(), seed)
+    image = torch.from_numpy(W.smooth_image("input:image", (B, 4, 32, 256), seed))
+    words, chars = words_for(B, classes[-1] - 4, seed)
+    conv = CTCLabelConverter(chars)
+    labels_index, labels_length = conv.encode(words, batch_max_length=25)
+    net.train()
+    net.model[0].eval()
+    with torch.no_grad():
+        out = net(image)
+        put(d, "logits", out["logits"])
+        put(d, "aux_logits", out["aux_logits"])
+        put(d, "features", out["features"])
+        d["kd_loss"] = np.float64(_KD_loss(out["logits"].view(-1, classes[-1])[:, 0:classes[0]],
+                                           out["aux_logits"].view(-1, classes[-1])[:, 0:classes[0]], 2).item())
+        w = net.fc.weight.data.clone()
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            net.weight_align(classes[-1] - classes[0])
+        d["weight_align_gamma"] = np.float64((net.fc.weight.data[-1] / w[-1]).mean().item())
+        put(d, "fc_after_align", net.fc.weight.data)
+    return d
+
+
 def converters():
     d = {}
     chars = "abcdefghij klmno"   # includes a space duplicate, as real dictionaries may
@@ -278,6 +320,7 @@ if __name__ == "__main__":
         "crnn_mrn3": lambda: run("crnn", (40, 70, 97), 2, 1),
         "trba_mrn3": lambda: run("trba", (41, 71, 98), 2, 2),
         "svtr_mrn3": lambda: run("svtr", (40, 70, 97), 2, 3),
+        "crnn_der2": lambda: der("crnn", (40, 70), 2, 4),
         "converters": converters,
     }
     for name, fn in jobs.items():

@@ -324,3 +324,32 @@ def test_loop_a_trba_gradients_vs_oracle():
         e_ref = rel(a32.double().numpy(), ref64)
         e_hip = rel(mine[n].grad.detach().cpu().double().numpy(), ref64)
         assert e_hip <= max(3.0 * e_ref, 2e-3), f"{n}: HIP vs f64 {e_hip:.2e}, torch-f32 vs f64 {e_ref:.2e}"
+
+
+def test_dernet_vs_golden():
+    """DERNet (reference modules/model.py:203-312) forward in DER's training configuration + weight_align"""
+    from mrn_amd.modules.model import DERNet
+    g = load_golden("crnn_der2")
+    classes, B, seed = (40, 70), 2, 4
+    opt = make_opt("crnn")
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = DERNet(opt)
+        for c in classes:
+            net.update_fc(opt.hidden_size, c)
+            net.build_prediction(opt, c)
+            net.build_aux_prediction(opt, c)
+    ref = {str(k): str(s) for k, s in zip(g["sd_keys"], g["sd_shapes"])}
+    assert {k: ",".join(map(str, v.shape)) for k, v in net.state_dict().items()} == ref
+    net.load_state_dict(golden_state_dict(g, seed), strict=True)
+    net = net.cuda().train()
+    net.model[0].eval()
+    image, _, _, _ = det_inputs("crnn", classes, B, seed)
+    with torch.no_grad():
+        out = net(image.cuda())
+        assert_sub_close(g, "logits", out["logits"], atol=1e-4)
+        assert_sub_close(g, "aux_logits", out["aux_logits"], atol=1e-4)
+        assert_sub_close(g, "features", out["features"], atol=1e-4)
+        with contextlib.redirect_stdout(io.StringIO()):
+            gamma = net.weight_align(30)
+        assert abs(float(gamma) - float(g["weight_align_gamma"])) < 1e-5
+        assert_sub_close(g, "fc_after_align", net.fc.weight, atol=1e-6)

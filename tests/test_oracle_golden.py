@@ -158,3 +158,20 @@ def test_loop_a_forward_loss(name):
         assert_sub_close(g, "stepA/logits", out["logits"], atol=2e-5)
         loss = O.ctc_loss(out["logits"], labels_index, labels_length) if kind != "trba" else O.attn_ce_loss(out["logits"], labels_index)
         assert abs(loss.item() - float(g["stepA/loss"])) < 1e-5 * max(1, abs(float(g["stepA/loss"])))
+
+
+def test_dernet_forward_kd_and_weight_align():
+    g = load_golden("crnn_der2")
+    classes, B, seed = (40, 70), 2, 4
+    cfg = cfg_for("crnn")
+    image, _, _, _ = det_inputs("crnn", classes, B, seed)
+    with torch.no_grad():
+        sd = golden_state_dict(g, seed)
+        out = O.dernet_forward(sd, cfg, 2, image, training=True, old_eval=True)
+        assert_sub_close(g, "logits", out["logits"], atol=2e-5)
+        assert_sub_close(g, "aux_logits", out["aux_logits"], atol=2e-5)
+        assert_sub_close(g, "features", out["features"], atol=2e-5)
+        kd = O.kd_loss(out["logits"].view(-1, 70)[:, 0:40], out["aux_logits"].view(-1, 70)[:, 0:40], 2.0)
+        assert abs(kd.item() - float(g["kd_loss"])) < 1e-5
+        gamma = O.weight_align_gamma(sd["fc.weight"], 30)
+        assert abs(gamma.item() - float(g["weight_align_gamma"])) < 1e-5
