@@ -117,7 +117,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--verbose", action="store_true")
-    ap.add_argument("--precision", default="auto", choices=["auto", "f32", "bf16x3", "bf16"],
+    ap.add_argument("--precision", default="auto", choices=["auto", "f32", "fp16x3", "bf16x3", "fp16", "bf16"],
                     help="conv arithmetic (mrn_amd/ops.py: CONV_PRECISION); auto keeps the 1e-4 parity band")
     ap.add_argument("--no-streams", action="store_true", help="run the experts sequentially on one stream")
     args = ap.parse_args()
@@ -171,8 +171,9 @@ def main():
             "value": world * args.batch * args.steps / elapsed,
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"auto": "f32 (backbone conv reductions with K>=2304 as split-bf16x3 MFMA, fp32 accumulate)", "f32": "f32",
-                      "bf16x3": "bf16x3 (split-bf16 MFMA, fp32 accumulate)", "bf16": "bf16"}[ops.CONV_PRECISION],
+            "dtype": {"auto": "f32 (convs with Cout>64 as split-fp16 x3 MFMA products, 22-bit significand, fp32 accumulate)",
+                      "f32": "f32", "fp16x3": "fp16x3 (split-fp16 MFMA, fp32 accumulate)",
+                      "bf16x3": "bf16x3 (split-bf16 MFMA, fp32 accumulate)", "bf16": "bf16", "fp16": "fp16"}[ops.CONV_PRECISION],
             "data": "synthetic",
             "config": {"workload": f"MRN loop B (router phase): {args.model.upper()} x {args.experts} frozen experts "
                                    f"(train-mode BN) + DM-Router fwd/bwd + clip + Adam, 32x256x4 crops, random-init weights",
@@ -182,19 +183,27 @@ def main():
         }
         if timer is not None and timer.spans:
             kinds = timer.summary()
-            names = {"f32": "gemm_f32_kernel<2,2,2,2,16,true> (128x128x16 implicit-GEMM conv, v_mfma_f32_32x32x2_f32)",
-                     "bf16x3": "conv_bf16_kernel<3> (128x128x32 implicit-GEMM conv, split-bf16 x3 on v_mfma_f32_32x32x16_bf16)",
-                     "bf16": "conv_bf16_kernel<1> (128x128x32 implicit-GEMM conv, bf16 operands)"}
-            peaks = {"f32": FP32_MFMA_PEAK_TFLOPS, "bf16x3": BF16_MFMA_PEAK_TFLOPS, "bf16": BF16_MFMA_PEAK_TFLOPS}
-            mfma_per_flop = {"f32": 1, "bf16x3": 3, "bf16": 1}
+            def describe(kind):
+                if kind == "f32":
+                    return ("gemm_f32_kernel<2,2,2,2,16,true> (128x128x16 implicit-GEMM conv, v_mfma_f32_32x32x2_f32)",
+                            FP32_MFMA_PEAK_TFLOPS, 1)
+                arith, staging = kind.split("/")
+                nsplit = 3 if arith.endswith("x3") else 1
+                kern = "conv_bf16_dma_kernel" if staging == "dma" else "conv_bf16_kernel"
+                half = "true" if arith.startswith("fp16") else "false"
+                inst = "v_mfma_f32_32x32x16_f16" if arith.startswith("fp16") else "v_mfma_f32_32x32x16_bf16"
+                return (f"{kern}<{nsplit},{half}> (128x128x32 implicit-GEMM conv, {arith} on {inst}, "
+                        f"{'pre-split operands staged by global_load_lds' if staging == 'dma' else 'activation split in registers'})",
+                        BF16_MFMA_PEAK_TFLOPS, nsplit)
             rl = []
             for kind, s_ in kinds.items():
                 per_launch = s_["total_flops"] / s_["launches"]
                 avg_ms = s_["total_ms"] / s_["launches"]
                 ach = per_launch / (avg_ms * 1e-3) / 1e12
-                rl.append({"bound": "mfma", "achieved": ach, "peak": peaks[kind], "unit": "TFLOP/s", "frac": ach / peaks[kind],
-                           "traffic": None, "kernel": names[kind], "mfma_flops_per_algorithmic_flop": mfma_per_flop[kind],
-                           "mfma_issue_frac": ach * mfma_per_flop[kind] / peaks[kind],
+                kname, peak, per_flop = describe(kind)
+                rl.append({"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                           "traffic": None, "kernel": kname, "mfma_flops_per_algorithmic_flop": per_flop,
+                           "mfma_issue_frac": ach * per_flop / peak,
                            "launches_per_step": s_["launches"] / args.steps, "avg_launch_ms": avg_ms,
                            "algorithmic_gflop_per_launch": per_launch / 1e9,
                            "kernel_share_of_step": s_["total_ms"] / (elapsed * 1e3),

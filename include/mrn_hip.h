@@ -52,9 +52,21 @@ int64_t mrn_conv2d_stats_floats(int B, int Ho, int Wo, int Cout);
  * Requires Cin % 4 == 0 and (kh*kw*Cin) % 32 == 0. */
 int mrn_conv2d_nhwc_bf16split(const float* x, const void* w_hi, const void* w_lo, const float* bias, float* y,
                               float* stats, int B, int H, int W, int Cin, int Cout, int kh, int kw, int sh, int sw,
-                              int ph, int pw, int act, int nsplit, void* stream);
-/* fp32 [n] -> bf16 hi[n], lo[n] with hi = bf16(x), lo = bf16(x - hi) */
-int mrn_split_weight_bf16(const float* w, void* hi, void* lo, int64_t n, void* stream);
+                              int ph, int pw, int act, int nsplit, int half, const float* out_scale, void* stream);
+/* half = 1 selects fp16 halves (v_mfma_f32_32x32x16_f16): hi + lo then carries 22 significand bits and each product
+ * is good to ~2^-22 (fp32-rounding class).  The weight planes are then built with a power-of-two prescale
+ * (mrn_pow2_scale_f32 -> device float[2] = {scale, 1/scale}; pass it to mrn_split_weight_bf16) and the same array
+ * is passed as out_scale so the epilogue multiplies by 1/scale.  out_scale may be NULL (no scaling). */
+int mrn_pow2_scale_f32(const float* w, int64_t n, float target, float* scale, void* stream);
+/* Same product with the ACTIVATION pre-split too (x_hi / x_lo: bf16 NHWC planes from mrn_split_weight_bf16 on the fp32
+ * tensor) and both operands staged by direct-to-LDS DMA (no staging registers, no conversion in the GEMM loop).
+ * zero_page: >= 64 bytes of device zeros (source of padded taps).  Requires Cin % 8 == 0, (kh*kw*Cin) % 32 == 0. */
+int mrn_conv2d_nhwc_bf16split_dma(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo,
+                                  const void* zero_page, const float* bias, float* y, float* stats, int B, int H, int W,
+                                  int Cin, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int act, int nsplit,
+                                  int half, const float* out_scale, void* stream);
+/* fp32 [n] -> 16-bit hi[n], lo[n] with hi = r16(s x), lo = r16(s x - hi); half = 0 bf16, 1 fp16; s = scale[0] or 1 */
+int mrn_split_weight_bf16(const float* w, void* hi, void* lo, int64_t n, int half, const float* scale, void* stream);
 
 /* Convolution backward (loss.backward() through Conv2d, il_modules/mrn.py:260-261):
  *   data gradient  = mrn_conv2d_nhwc_* of dy (zero-dilated by the stride, mrn_dilate_nhwc_f32) with the flipped /

@@ -7,6 +7,12 @@
 // i.e. inside the 1e-4 parity band -- at 3/16 of the cost of the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).
 // nsplit = 1 keeps only hi*hi (plain bf16 operands, fp32 accumulate; 2e-2 features / 1e-3 logits on the same test).
 //
+// HALF variant ("fp16x3"): the same three-product scheme with fp16 halves on v_mfma_f32_32x32x16_f16.  fp16 carries 11
+// significand bits, so hi + lo represents 22 bits and each product is good to ~2^-22 -- fp32-rounding class -- at the
+// same MFMA cost.  fp16's narrow exponent is handled by a per-weight-tensor power-of-two prescale (exact; chosen on the
+// device from max|w| so the scaled weights peak near 2^14, which keeps the lo halves in the normal range) whose inverse
+// is folded into the epilogue; activations (|x| << 65504 after BatchNorm) are split unscaled.
+//
 // Activations stay fp32 NHWC in HBM (the split happens while staging a tile into LDS); weights are pre-split once
 // per weight version into two bf16 [Cout][K] arrays (mrn_split_weight_bf16).  Same epilogue contract as gemm.hip
 // (bias, activation, BatchNorm partial statistics).
@@ -23,6 +29,8 @@ typedef __bf16 bf16_t;
 typedef bf16_t bf16x2_t __attribute__((ext_vector_type(2)));
 typedef bf16_t bf16v8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16v8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -40,12 +48,37 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {   // two fp32 -> p
 __device__ __forceinline__ float lo_of(unsigned pk) { return __uint_as_float(pk << 16); }
 __device__ __forceinline__ float hi_of(unsigned pk) { return __uint_as_float(pk & 0xffff0000u); }
 
+__device__ __forceinline__ unsigned pack2h(float a, float b) {  // two fp32 -> packed fp16 pair (RNE)
+  f32x2 v = {a, b};
+  f16x2_t r = __builtin_convertvector(v, f16x2_t);
+  return *reinterpret_cast<unsigned*>(&r);
+}
+__device__ __forceinline__ f32x2 unpack2h(unsigned pk) {
+  f16x2_t r = *reinterpret_cast<f16x2_t*>(&pk);
+  return __builtin_convertvector(r, f32x2);
+}
+
 // split 4 floats -> (hi packed x2, lo packed x2)
+template <bool HALF>
 __device__ __forceinline__ void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
-  hi[0] = pack2(v[0], v[1]);
-  hi[1] = pack2(v[2], v[3]);
-  lo[0] = pack2(v[0] - lo_of(hi[0]), v[1] - hi_of(hi[0]));
-  lo[1] = pack2(v[2] - lo_of(hi[1]), v[3] - hi_of(hi[1]));
+  if (HALF) {
+    hi[0] = pack2h(v[0], v[1]);
+    hi[1] = pack2h(v[2], v[3]);
+    const f32x2 h0 = unpack2h(hi[0]), h1 = unpack2h(hi[1]);
+    lo[0] = pack2h(v[0] - h0[0], v[1] - h0[1]);
+    lo[1] = pack2h(v[2] - h1[0], v[3] - h1[1]);
+  } else {
+    hi[0] = pack2(v[0], v[1]);
+    hi[1] = pack2(v[2], v[3]);
+    lo[0] = pack2(v[0] - lo_of(hi[0]), v[1] - hi_of(hi[0]));
+    lo[1] = pack2(v[2] - lo_of(hi[1]), v[3] - hi_of(hi[1]));
+  }
+}
+
+template <bool HALF>
+__device__ __forceinline__ f32x16 mma16(const u32x4 a, const u32x4 b, const f32x16 c) {
+  if (HALF) return __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16v8*>(&a), *reinterpret_cast<const f16v8*>(&b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16v8*>(&a), *reinterpret_cast<const bf16v8*>(&b), c, 0, 0, 0);
 }
 
 // byte offset of 16-byte chunk c (0..3) of LDS row `row`
@@ -65,9 +98,10 @@ __device__ __forceinline__ int pack_tap(int k, int Cin, int kw) {
   return (ky << 26) | (kx << 20) | ci;
 }
 
-template <int NSPLIT>
+template <int NSPLIT, bool HALF>
 __global__ __launch_bounds__(NT) void conv_bf16_kernel(const GemmParams p, const unsigned short* __restrict__ w_hi,
-                                                       const unsigned short* __restrict__ w_lo) {
+                                                       const unsigned short* __restrict__ w_lo,
+                                                       const float* __restrict__ out_scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 stages + tap table
   int* const taps = reinterpret_cast<int*>(lds + 2 * STAGE);
 
@@ -132,7 +166,7 @@ __global__ __launch_bounds__(NT) void conv_bf16_kernel(const GemmParams p, const
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       u32x2 hi, lo;
-      split4(ra[q], hi, lo);
+      split4<HALF>(ra[q], hi, lo);
       const int off = swz((t >> 3) + 32 * q, akq >> 1) + (akq & 1) * 8;
       *reinterpret_cast<u32x2*>(st + off) = hi;
       if (NSPLIT > 1) *reinterpret_cast<u32x2*>(st + PLANE + off) = lo;
@@ -167,28 +201,28 @@ __global__ __launch_bounds__(NT) void conv_bf16_kernel(const GemmParams p, const
     if (kt + 1 < nk) load_tile((kt + 1) * BKB);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16v8 ah[2], al[2], bh[2], bl[2];
+      u32x4 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int o = swz(ra_ + i * 32, (lane >> 5) + 2 * ks);
-        ah[i] = *reinterpret_cast<const bf16v8*>(cur + o);
-        if (NSPLIT > 1) al[i] = *reinterpret_cast<const bf16v8*>(cur + PLANE + o);
+        ah[i] = *reinterpret_cast<const u32x4*>(cur + o);
+        if (NSPLIT > 1) al[i] = *reinterpret_cast<const u32x4*>(cur + PLANE + o);
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int o = swz(rb_ + j * 32, (lane >> 5) + 2 * ks);
-        bh[j] = *reinterpret_cast<const bf16v8*>(cur + 2 * PLANE + o);
-        if (NSPLIT > 1) bl[j] = *reinterpret_cast<const bf16v8*>(cur + 3 * PLANE + o);
+        bh[j] = *reinterpret_cast<const u32x4*>(cur + 2 * PLANE + o);
+        if (NSPLIT > 1) bl[j] = *reinterpret_cast<const u32x4*>(cur + 3 * PLANE + o);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           if (NSPLIT > 1) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = mma16<HALF>(al[i], bh[j], acc[i][j]);
+            acc[i][j] = mma16<HALF>(ah[i], bl[j], acc[i][j]);
           }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = mma16<HALF>(ah[i], bh[j], acc[i][j]);
         }
     }
     if (kt + 1 < nk) store_tile(lds + ((kt + 1) & 1) * STAGE);
@@ -204,13 +238,14 @@ __global__ __launch_bounds__(NT) void conv_bf16_kernel(const GemmParams p, const
     const int n = n0 + wn * 64 + j * 32 + (lane & 31);
     const bool nok = n < p.N;
     const float bn = (p.bias && nok) ? p.bias[n] : 0.f;
+    const float osc = out_scale ? out_scale[1] : 1.f;      // inverse of the weight prescale (exact power of two)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
         if (m < p.M && nok) {
-          float v = acc[i][j][e] + bn;
+          float v = acc[i][j][e] * osc + bn;
           csum[j] += v;
           csq[j] += v * v;
           if (p.act == 1) v = fmaxf(v, 0.f);
@@ -243,13 +278,190 @@ __global__ __launch_bounds__(NT) void conv_bf16_kernel(const GemmParams p, const
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Pre-split variant: the activation arrives as two bf16 NHWC planes (hi, lo; mrn_split_weight_bf16 on the fp32 tensor)
+// and BOTH operands are staged with direct-to-LDS DMA (global_load_lds_dwordx4): no staging registers, no VALU
+// conversion, no ds_write.  One DMA instruction moves 16 rows x 64 B = 1 KiB per wave; the LDS image is lane-linear,
+// so the XOR swizzle is applied to the SOURCE chunk a lane fetches (chunk_global = chunk_lds ^ key(row)) and the
+// fragment reads use the same involution (swz()).  Out-of-image taps / rows fetch from a 64-byte zero page.
+// ---------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+__device__ __forceinline__ void dma16(const void* g, unsigned char* l) {
+  __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, 0, 0);
+}
+
+template <int NSPLIT, bool HALF>
+__global__ __launch_bounds__(NT) void conv_bf16_dma_kernel(const GemmParams p, const unsigned short* __restrict__ x_hi,
+                                                           const unsigned short* __restrict__ x_lo,
+                                                           const unsigned short* __restrict__ w_hi,
+                                                           const unsigned short* __restrict__ w_lo,
+                                                           const unsigned short* __restrict__ zero_page,
+                                                           const float* __restrict__ out_scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  int* const taps = reinterpret_cast<int*>(lds + 2 * STAGE);
+
+  const int tilesN = (p.N + BN - 1) / BN;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = lid / tilesN, tile_n = lid - tile_m * tilesN;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // DMA geometry: wave w, instruction i (0,1) covers rows (i*4 + w)*16 .. +15 of a 128-row plane;
+  // lane -> row = +lane/4, LDS chunk = lane & 3, global chunk = LDS chunk ^ ((row >> 2) & 3)
+  const int lrow = lane >> 2, lch = lane & 3;
+  long abase[2];      // element offset of the image of A row (i), -1 if the row is beyond M
+  int aiy0[2], aix0[2], gch[2];
+  long brow[2];       // element offset of weight row, -1 if beyond N
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (i * 4 + wave) * 16 + lrow;
+    gch[i] = lch ^ ((row >> 2) & 3);
+    const int m = m0 + row;
+    const bool ok = m < p.M;
+    const int mm = ok ? m : 0;
+    const int hw = p.Ho * p.Wo;
+    const int b = mm / hw;
+    const int rem = mm - b * hw;
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    abase[i] = ok ? (long)b * p.H * p.Wd * p.Cin : -1;
+    aiy0[i] = oy * p.sh - p.ph;
+    aix0[i] = ox * p.sw - p.pw;
+    const int n = n0 + row;
+    brow[i] = n < p.N ? (long)n * p.K : -1;
+  }
+  for (int i = t; i < p.K / 4; i += NT) taps[i] = pack_tap(i * 4, p.Cin, p.kw);
+  __syncthreads();
+
+  auto issue_tile = [&](int k0, unsigned char* st) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      unsigned char* dst = st + (i * 4 + wave) * 16 * ROWB;            // wave-uniform; lane l lands at +16 l
+      const int k = k0 + gch[i] * 8;
+      const int info = taps[k >> 2];
+      const int ky = info >> 26, kx = (info >> 20) & 63, ci = info & 0xfffff;
+      const int iy = aiy0[i] + ky, ix = aix0[i] + kx;
+      const bool ok = abase[i] >= 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.Wd;
+      const long off = ok ? abase[i] + ((long)iy * p.Wd + ix) * p.Cin + ci : 0;
+      dma16(ok ? (const void*)(x_hi + off) : (const void*)zero_page, dst);
+      if (NSPLIT > 1) dma16(ok ? (const void*)(x_lo + off) : (const void*)zero_page, dst + PLANE);
+      const bool bok = brow[i] >= 0;
+      const long boff = bok ? brow[i] + k : 0;
+      dma16(bok ? (const void*)(w_hi + boff) : (const void*)zero_page, dst + 2 * PLANE);
+      if (NSPLIT > 1) dma16(bok ? (const void*)(w_lo + boff) : (const void*)zero_page, dst + 3 * PLANE);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = p.K / BKB;
+  issue_tile(0, lds);
+  __syncthreads();          // drains the DMA queue (vmcnt(0)) before the barrier releases
+
+  const int ra_ = wm * 64 + (lane & 31), rb_ = wn * 64 + (lane & 31);
+  for (int kt = 0; kt < nk; ++kt) {
+    unsigned char* cur = lds + (kt & 1) * STAGE;
+    if (kt + 1 < nk) issue_tile((kt + 1) * BKB, lds + ((kt + 1) & 1) * STAGE);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      u32x4 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int o = swz(ra_ + i * 32, (lane >> 5) + 2 * ks);
+        ah[i] = *reinterpret_cast<const u32x4*>(cur + o);
+        if (NSPLIT > 1) al[i] = *reinterpret_cast<const u32x4*>(cur + PLANE + o);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int o = swz(rb_ + j * 32, (lane >> 5) + 2 * ks);
+        bh[j] = *reinterpret_cast<const u32x4*>(cur + 2 * PLANE + o);
+        if (NSPLIT > 1) bl[j] = *reinterpret_cast<const u32x4*>(cur + 3 * PLANE + o);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (NSPLIT > 1) {
+            acc[i][j] = mma16<HALF>(al[i], bh[j], acc[i][j]);
+            acc[i][j] = mma16<HALF>(ah[i], bl[j], acc[i][j]);
+          }
+          acc[i][j] = mma16<HALF>(ah[i], bh[j], acc[i][j]);
+        }
+    }
+    __syncthreads();
+  }
+
+  float csum[2], csq[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+    const bool nok = n < p.N;
+    const float bn = (p.bias && nok) ? p.bias[n] : 0.f;
+    const float osc = out_scale ? out_scale[1] : 1.f;      // inverse of the weight prescale (exact power of two)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (m < p.M && nok) {
+          float v = acc[i][j][e] * osc + bn;
+          csum[j] += v;
+          csq[j] += v * v;
+          if (p.act == 1) v = fmaxf(v, 0.f);
+          p.C[(long)m * p.sCm + n] = v;
+        }
+      }
+    }
+  }
+  if (p.stats) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float s = csum[j] + __shfl_xor(csum[j], 32);
+      const float q = csq[j] + __shfl_xor(csq[j], 32);
+      if (lane < 32) {
+        const int c = wn * 64 + j * 32 + lane;
+        red[(wm * 2 + 0) * BN + c] = s;
+        red[(wm * 2 + 1) * BN + c] = q;
+      }
+    }
+    __syncthreads();
+    if (t < BN) {
+      const int n = n0 + t;
+      if (n < p.N) {
+        p.stats[((long)tile_m * 2 + 0) * p.N + n] = red[0 * BN + t] + red[2 * BN + t];
+        p.stats[((long)tile_m * 2 + 1) * p.N + n] = red[1 * BN + t] + red[3 * BN + t];
+      }
+    }
+  }
+}
+
 // fp32 [rows] -> bf16 hi / lo planes
 __global__ void split_bf16_kernel(const float* __restrict__ w, unsigned short* __restrict__ hi, unsigned short* __restrict__ lo,
-                                  long n) {
+                                  long n, int half, const float* __restrict__ scale) {
+  const float sc = scale ? scale[0] : 1.f;
   for (long i = (blockIdx.x * (long)blockDim.x + threadIdx.x) * 2; i < n; i += (long)gridDim.x * blockDim.x * 2) {
-    const float a = w[i], b = (i + 1 < n) ? w[i + 1] : 0.f;
-    const unsigned h = pack2(a, b);
-    const unsigned l = pack2(a - lo_of(h), b - hi_of(h));
+    const float a = w[i] * sc, b = (i + 1 < n) ? w[i + 1] * sc : 0.f;
+    unsigned h, l;
+    if (half) {
+      h = pack2h(a, b);
+      const f32x2 hf = unpack2h(h);
+      l = pack2h(a - hf[0], b - hf[1]);
+    } else {
+      h = pack2(a, b);
+      l = pack2(a - lo_of(h), b - hi_of(h));
+    }
     hi[i] = (unsigned short)(h & 0xffff);
     lo[i] = (unsigned short)(l & 0xffff);
     if (i + 1 < n) {
@@ -259,15 +471,38 @@ __global__ void split_bf16_kernel(const float* __restrict__ w, unsigned short* _
   }
 }
 
+// scale[0] = 2^floor(log2(target / max|w|)), scale[1] = 1 / scale[0]   (single block)
+__global__ __launch_bounds__(256) void pow2_scale_kernel(const float* __restrict__ w, long n, float target, float* __restrict__ scale) {
+  __shared__ float scratch[4];
+  float m = 0.f;
+  for (long i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(w[i]));
+  m = block_max<256>(m, scratch);
+  if (threadIdx.x == 0) {
+    float s = 1.f;
+    if (m > 0.f && isfinite(m)) s = exp2f(floorf(log2f(target / m)));
+    scale[0] = s;
+    scale[1] = 1.f / s;
+  }
+}
+
 }  // namespace
 
-MRN_EXPORT int mrn_split_weight_bf16(const float* w, void* hi, void* lo, int64_t n, void* stream) {
+// scale[0] = largest power of two with scale*max|w| <= target, scale[1] = its inverse (both on the device)
+MRN_EXPORT int mrn_pow2_scale_f32(const float* w, int64_t n, float target, float* scale, void* stream) {
+  MRN_CHECK_ARG(w && scale && target > 0.f, "mrn_pow2_scale_f32: bad operands");
+  hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, w, (long)n, target, scale);
+  MRN_LAUNCH_CHECK("pow2_scale");
+  return MRN_OK;
+}
+
+MRN_EXPORT int mrn_split_weight_bf16(const float* w, void* hi, void* lo, int64_t n, int half, const float* scale,
+                                     void* stream) {
   MRN_CHECK_ARG(w && hi && lo, "mrn_split_weight_bf16: null operand");
   if (n == 0) return MRN_OK;
   long grid = (n / 2 + 255) / 256;
   if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)hi,
-                     (unsigned short*)lo, (long)n);
+                     (unsigned short*)lo, (long)n, half, scale);
   MRN_LAUNCH_CHECK("split_weight_bf16");
   return MRN_OK;
 }
@@ -277,7 +512,8 @@ MRN_EXPORT int mrn_split_weight_bf16(const float* w, void* hi, void* lo, int64_t
 // Requires Cin % 4 == 0 and (kh*kw*Cin) % 32 == 0.
 MRN_EXPORT int mrn_conv2d_nhwc_bf16split(const float* x, const void* w_hi, const void* w_lo, const float* bias, float* y,
                                          float* stats, int B, int H, int Wd, int Cin, int Cout, int kh, int kw, int sh,
-                                         int sw, int ph, int pw, int act, int nsplit, void* stream) {
+                                         int sw, int ph, int pw, int act, int nsplit, int half, const float* out_scale,
+                                         void* stream) {
   MRN_CHECK_ARG(x && w_hi && y && (nsplit == 1 || (nsplit == 3 && w_lo)), "mrn_conv2d_nhwc_bf16split: bad operands");
   const int K = kh * kw * Cin;
   MRN_CHECK_ARG(Cin % 4 == 0 && K % 32 == 0 && K <= MAX_TAPS * 4, "mrn_conv2d_nhwc_bf16split: unsupported K=%d Cin=%d", K, Cin);
@@ -297,17 +533,65 @@ MRN_EXPORT int mrn_conv2d_nhwc_bf16split(const float* x, const void* w_hi, const
   const size_t ldsz = 2 * STAGE + (size_t)((K / 4 + 3) / 4 * 4) * sizeof(int);
   const int ldmax = 2 * STAGE + MAX_TAPS * (int)sizeof(int);
   const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
-  if (nsplit == 3) {
-    static bool attr3 = false;
-    if (!attr3) { hipFuncSetAttribute((const void*)conv_bf16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, ldmax); attr3 = true; }
-    hipLaunchKernelGGL(conv_bf16_kernel<3>, dim3(tiles), dim3(NT), ldsz, (hipStream_t)stream, p, (const unsigned short*)w_hi,
-                       (const unsigned short*)w_lo);
-  } else {
-    static bool attr1 = false;
-    if (!attr1) { hipFuncSetAttribute((const void*)conv_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ldmax); attr1 = true; }
-    hipLaunchKernelGGL(conv_bf16_kernel<1>, dim3(tiles), dim3(NT), ldsz, (hipStream_t)stream, p, (const unsigned short*)w_hi,
-                       (const unsigned short*)w_lo);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)conv_bf16_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ldmax);
+    hipFuncSetAttribute((const void*)conv_bf16_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ldmax);
+    hipFuncSetAttribute((const void*)conv_bf16_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ldmax);
+    hipFuncSetAttribute((const void*)conv_bf16_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ldmax);
+    attr_done = true;
   }
+  const unsigned short* wh = (const unsigned short*)w_hi;
+  const unsigned short* wl = (const unsigned short*)w_lo;
+  hipStream_t st = (hipStream_t)stream;
+  if (nsplit == 3 && !half) hipLaunchKernelGGL((conv_bf16_kernel<3, false>), dim3(tiles), dim3(NT), ldsz, st, p, wh, wl, out_scale);
+  else if (nsplit == 3) hipLaunchKernelGGL((conv_bf16_kernel<3, true>), dim3(tiles), dim3(NT), ldsz, st, p, wh, wl, out_scale);
+  else if (!half) hipLaunchKernelGGL((conv_bf16_kernel<1, false>), dim3(tiles), dim3(NT), ldsz, st, p, wh, wl, out_scale);
+  else hipLaunchKernelGGL((conv_bf16_kernel<1, true>), dim3(tiles), dim3(NT), ldsz, st, p, wh, wl, out_scale);
   MRN_LAUNCH_CHECK("conv_bf16split");
+  return MRN_OK;
+}
+
+// Pre-split activation variant: x_hi / x_lo are the bf16 planes of the NHWC activation (same element order as the fp32
+// tensor); zero_page: >= 64 bytes of device zeros.  Requires Cin % 8 == 0 (a 16-byte chunk never straddles a tap).
+MRN_EXPORT int mrn_conv2d_nhwc_bf16split_dma(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo,
+                                             const void* zero_page, const float* bias, float* y, float* stats, int B, int H,
+                                             int Wd, int Cin, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int act,
+                                             int nsplit, int half, const float* out_scale, void* stream) {
+  MRN_CHECK_ARG(x_hi && w_hi && y && zero_page && (nsplit == 1 || (nsplit == 3 && w_lo && x_lo)), "mrn_conv2d_nhwc_bf16split_dma: bad operands");
+  const int K = kh * kw * Cin;
+  MRN_CHECK_ARG(Cin % 8 == 0 && K % 32 == 0 && K <= MAX_TAPS * 4, "mrn_conv2d_nhwc_bf16split_dma: unsupported K=%d Cin=%d", K, Cin);
+  MRN_CHECK_ARG(((uintptr_t)x_hi % 16 == 0) && ((uintptr_t)x_lo % 16 == 0) && ((uintptr_t)w_hi % 16 == 0) &&
+                    ((uintptr_t)w_lo % 16 == 0) && ((uintptr_t)zero_page % 16 == 0), "mrn_conv2d_nhwc_bf16split_dma: operands must be 16-byte aligned");
+  const int Ho = (H + 2 * ph - kh) / sh + 1, Wo = (Wd + 2 * pw - kw) / sw + 1;
+  MRN_CHECK_ARG(Ho > 0 && Wo > 0 && B >= 0, "mrn_conv2d_nhwc_bf16split_dma: empty output");
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.bias = bias; p.C = y; p.stats = stats;
+  p.M = B * Ho * Wo; p.N = Cout; p.K = K; p.batch = 1;
+  p.sCm = Cout; p.sCn = 1;
+  p.H = H; p.Wd = Wd; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo;
+  p.kh = kh; p.kw = kw; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw;
+  p.act = act; p.alpha = 1.f;
+  if (p.M == 0) return MRN_OK;
+  const size_t ldsz = 2 * STAGE + (size_t)((K / 4 + 3) / 4 * 4) * sizeof(int);
+  const int ldmax = 2 * STAGE + MAX_TAPS * (int)sizeof(int);
+  const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)conv_bf16_dma_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ldmax);
+    hipFuncSetAttribute((const void*)conv_bf16_dma_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ldmax);
+    hipFuncSetAttribute((const void*)conv_bf16_dma_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ldmax);
+    hipFuncSetAttribute((const void*)conv_bf16_dma_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ldmax);
+    attr_done = true;
+  }
+  const unsigned short *xh = (const unsigned short*)x_hi, *xl = (const unsigned short*)x_lo;
+  const unsigned short *wh = (const unsigned short*)w_hi, *wl = (const unsigned short*)w_lo, *zp = (const unsigned short*)zero_page;
+  hipStream_t st = (hipStream_t)stream;
+  if (nsplit == 3 && !half) hipLaunchKernelGGL((conv_bf16_dma_kernel<3, false>), dim3(tiles), dim3(NT), ldsz, st, p, xh, xl, wh, wl, zp, out_scale);
+  else if (nsplit == 3) hipLaunchKernelGGL((conv_bf16_dma_kernel<3, true>), dim3(tiles), dim3(NT), ldsz, st, p, xh, xl, wh, wl, zp, out_scale);
+  else if (!half) hipLaunchKernelGGL((conv_bf16_dma_kernel<1, false>), dim3(tiles), dim3(NT), ldsz, st, p, xh, xl, wh, wl, zp, out_scale);
+  else hipLaunchKernelGGL((conv_bf16_dma_kernel<1, true>), dim3(tiles), dim3(NT), ldsz, st, p, xh, xl, wh, wl, zp, out_scale);
+  MRN_LAUNCH_CHECK("conv_bf16split_dma");
   return MRN_OK;
 }

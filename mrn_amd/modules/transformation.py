@@ -47,10 +47,10 @@ class LocalizationNetwork(nn.Module):
         c = self.conv
         pool = ((2, 2), (2, 2), (0, 0))
         # exact fp32 throughout: the fiducials feed an ill-conditioned grid + sampler
-        x = conv_block(x, c[0], c[1], pool=pool, precision="f32")
-        x = conv_block(x, c[4], c[5], pool=pool, precision="f32")
-        x = conv_block(x, c[8], c[9], pool=pool, precision="f32")
-        x = conv_block(x, c[12], c[13], precision="f32")
+        x = conv_block(x, c[0], c[1], pool=pool, precision=ops.LOCNET_CONV_PRECISION)
+        x = conv_block(x, c[4], c[5], pool=pool, precision=ops.LOCNET_CONV_PRECISION)
+        x = conv_block(x, c[8], c[9], pool=pool, precision=ops.LOCNET_CONV_PRECISION)
+        x = conv_block(x, c[12], c[13], precision=ops.LOCNET_CONV_PRECISION)
         fc1, fc2 = self.localization_fc1[0], self.localization_fc2
         if needs_grad(self, x):
             x = AvgPoolFn.apply(x)

@@ -90,6 +90,9 @@ def test_conv2d_and_batch_stats(ops, cfg):
     # split-bf16 (bf16x3) path: fp32-class accuracy; plain bf16: operand rounding only
     y3, st3 = ops.conv2d_nhwc(xn, wp, cu(b), s, p, act=0, want_stats=True, precision="bf16x3")
     assert_close("conv bf16x3", y3.permute(0, 3, 1, 2), ref, atol=6e-5, rtol=2e-5)
+    # split-fp16 (fp16x3) with the power-of-two weight prescale: 22-bit products, same band as the exact fp32 kernel
+    yh, sth = ops.conv2d_nhwc(xn, wp, cu(b), s, p, act=0, want_stats=True, precision="fp16x3")
+    assert_close("conv fp16x3", yh.permute(0, 3, 1, 2), ref, atol=2e-5, rtol=1e-5)
     y1, _ = ops.conv2d_nhwc(xn, wp, cu(b), s, p, act=1, precision="bf16")
     assert_close("conv bf16", y1.permute(0, 3, 1, 2), F.relu(ref), atol=3e-2, rtol=1e-2)
     if Cout > 64 and (Cin * k[0] * k[1]) % 32 == 0:

@@ -124,19 +124,20 @@ def test_expert_forward_vs_golden(name):
         assert abs(loss.item() - float(g["stepA/loss"])) < 1e-4 * max(1.0, abs(float(g["stepA/loss"])))
 
 
-@pytest.mark.parametrize("precision,tol", [("f32", 1e-4), ("bf16x3", 5e-4)])
-def test_loop_b_forward_other_conv_precisions(precision, tol):
-    """The default conv arithmetic is "auto" (covered by every other test at 1e-4).  This pins the two alternatives:
-    exact fp32 everywhere (1e-4) and split-bf16x3 everywhere (performance mode; written tolerance 5e-4 on router
-    weights / fused logits, routing argmax unchanged)."""
+@pytest.mark.parametrize("precision,locnet,tol", [("f32", None, 1e-4), ("fp16x3", None, 1e-4), ("bf16x3", "f32", 5e-4)])
+def test_loop_b_forward_other_conv_precisions(precision, locnet, tol):
+    """The default conv arithmetic is "auto" = split-fp16x3 on every eligible conv (covered by every other test at
+    1e-4).  This pins the alternatives: exact fp32 everywhere (1e-4), fp16x3 forced (1e-4) and split-bf16x3 with an
+    exact localisation network (16-bit products; written tolerance 5e-4 on router weights / fused logits, routing
+    argmax unchanged)."""
     from mrn_amd import ops
     kind, classes, B, seed = CASES["trba_mrn3"]
     g = load_golden("trba_mrn3")
     opt, net = build_net(kind, classes, g, seed)
     image, words, chars, _ = det_inputs(kind, classes, B, seed)
     conv, labels_index, _ = labels_for(kind, words, chars)
-    old = ops.CONV_PRECISION
-    ops.CONV_PRECISION = precision
+    old, old_loc = ops.CONV_PRECISION, ops.LOCNET_CONV_PRECISION
+    ops.CONV_PRECISION, ops.LOCNET_CONV_PRECISION = precision, locnet
     try:
         net.train()
         with torch.no_grad():
@@ -145,7 +146,7 @@ def test_loop_b_forward_other_conv_precisions(precision, tol):
         assert_sub_close(g, "stepB/logits", out["logits"], atol=tol, rtol=tol)
         assert np.array_equal(out["index"].argmax(1).cpu().numpy(), g["stepB/weights"].argmax(1))
     finally:
-        ops.CONV_PRECISION = old
+        ops.CONV_PRECISION, ops.LOCNET_CONV_PRECISION = old, old_loc
 
 
 @pytest.mark.parametrize("name", list(CASES))

@@ -21,6 +21,9 @@ def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
     if len(sys.argv) > 2:
         ops.CONV_PRECISION = sys.argv[2]
+    if len(sys.argv) > 3:
+        ops.USE_DMA_CONV = sys.argv[3] == "dma"
+        ops.DMA_MIN_CIN = 0
     print("precision", ops.CONV_PRECISION)
     for (B, H, W, Cin, Cout, k, s, p) in SHAPES:
         x = torch.rand(B, H, W, Cin, device="cuda") * 2 - 1
