@@ -188,6 +188,10 @@ def main():
                     return ("gemm_f32_kernel<2,2,2,2,16,true> (128x128x16 implicit-GEMM conv, v_mfma_f32_32x32x2_f32)",
                             FP32_MFMA_PEAK_TFLOPS, 1)
                 arith, staging = kind.split("/")
+                if staging.startswith("x3g"):
+                    tn = staging[3:]
+                    return (f"conv_x3_kernel<256x{tn}> (grouped 256x{tn}x32 implicit-GEMM conv over all experts, fp16x3 on "
+                            f"v_mfma_f32_32x32x16_f16, HL32 operands staged by buffer_load...lds)", BF16_MFMA_PEAK_TFLOPS, 3)
                 nsplit = 3 if arith.endswith("x3") else 1
                 kern = "conv_bf16_dma_kernel" if staging == "dma" else "conv_bf16_kernel"
                 half = "true" if arith.startswith("fp16") else "false"

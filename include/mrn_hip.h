@@ -68,6 +68,40 @@ int mrn_conv2d_nhwc_bf16split_dma(const void* x_hi, const void* x_lo, const void
 /* fp32 [n] -> 16-bit hi[n], lo[n] with hi = r16(s x), lo = r16(s x - hi); half = 0 bf16, 1 fp16; s = scale[0] or 1 */
 int mrn_split_weight_bf16(const float* w, void* hi, void* lo, int64_t n, int half, const float* scale, void* stream);
 
+/* Grouped split-fp16 x3 convolution on 256-wide tiles (the router phase runs the G frozen experts' backbones in
+ * lock-step: il_modules/mrn.py:323-337 calls every expert on the same batch; modules/model.py:399-401).
+ * Operands are in the "HL32" layout: one 128-byte line [hi fp16 x 32 | lo fp16 x 32] per (pixel, 32-channel block) for
+ * the activation (mrn_split_hl32_f32, or the fused BatchNorm-apply pass mrn_bn_apply_hl32_f32) and per
+ * (Cout row, 32-channel block, tap) for the weight (mrn_pack_weight_hl32; reduction order = channel block outer, tap
+ * inner).  x_hl: [G][B][H][W][Cin/32][128 B] with group stride x_group_stride_bytes (0 = all groups read the same
+ * input); w_hl: [G][Cout][Cin/32][kh*kw][128 B]; bias [G][Cout] or NULL; out_scale [G][2] = {s, 1/s} per group (the
+ * power-of-two weight prescale of mrn_pow2_scale_f32) or NULL; y [G][B][Ho][Wo][Cout] fp32; stats
+ * [G][ceil(B*Ho*Wo/256)][2][Cout] per-256-row-block sums / sums of squares (mrn_conv2d_x3_stats_floats) or NULL.
+ * tile_n = 256 (Cout >= 256) or 128.  Requires Cin % 32 == 0; zero_page: >= 128 bytes of device zeros. */
+int mrn_conv2d_x3_hl32(const void* x_hl, const void* w_hl, const void* zero_page, const float* bias, float* y,
+                       float* stats, const float* out_scale, int G, int64_t x_group_stride_bytes, int B, int H, int W,
+                       int Cin, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int act, int tile_n,
+                       void* stream);
+int64_t mrn_conv2d_x3_stats_floats(int G, int B, int Ho, int Wo, int Cout, int tile_m);
+int mrn_split_hl32_f32(const float* x, void* out, int64_t rows, int C, void* stream);
+int mrn_pack_weight_hl32(const float* w_ohwi, void* out, int Cout, int taps, int Cin, const float* scale, void* stream);
+
+/* Elementwise passes between grouped convolutions (G frozen experts in lock-step).
+ * mrn_bn_finalize_grouped_f32: train-mode BatchNorm2d statistics for G modules at once; partials [G][nblk][2][C] from
+ *   the conv epilogue; ptrs = device table [4][G] of device pointers {gamma, beta, running_mean, running_var} (NULL
+ *   entries allowed); scale / shift [G][C].  Same arithmetic as mrn_bn_finalize_f32.
+ * mrn_bn_apply_grouped_f32: out = relu?(y * scale[g] + shift[g] (+ residual)) over [G][rows_per_group][C]; writes the
+ *   fp32 tensor (out_f32, may alias y) and / or the HL32 operand of the next convolution (out_hl32, C % 32 == 0).
+ * mrn_maxpool_grouped_f32: the same with MaxPool2d (padding = -inf) applied after the affine + ReLU.
+ * modules/feature_extraction.py:171-199,222-294; modules/transformation.py:69-81. */
+int mrn_bn_finalize_grouped_f32(const float* partials, int G, int nblk, int C, int64_t count, const void* const* ptrs,
+                                float momentum, float eps, float* scale, float* shift, void* stream);
+int mrn_bn_apply_grouped_f32(const float* y, const float* residual, const float* scale, const float* shift,
+                             float* out_f32, void* out_hl32, int G, int64_t rows_per_group, int C, int relu, void* stream);
+int mrn_maxpool_grouped_f32(const float* x, const float* scale, const float* shift, int relu, float* out_f32,
+                            void* out_hl32, int G, int B, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw,
+                            void* stream);
+
 /* Convolution backward (loss.backward() through Conv2d, il_modules/mrn.py:260-261):
  *   data gradient  = mrn_conv2d_nhwc_* of dy (zero-dilated by the stride, mrn_dilate_nhwc_f32) with the flipped /
  *                    transposed weight from mrn_pack_dgrad_weight_f32 and padding (k-1-p);

@@ -1,0 +1,416 @@
+// Grouped split-fp16 x3 implicit-GEMM convolution, 256-wide tiles, both operands staged by direct-to-LDS DMA.
+//
+// Arithmetic: every fp32 operand is x = hi + lo (two fp16, 22 significand bits); product = lo*hi + hi*lo + hi*hi on
+// v_mfma_f32_32x32x16_f16 with fp32 accumulation (same numerics as conv_bf16_dma_kernel<3,true> in gemm_bf16.hip).
+//
+// Operand layout "HL32" (written by the producer pass, mrn_split_hl32_f32 / mrn_pack_weight_hl32):
+//   activation [pixel][Cin/32][ hi[32] | lo[32] ] fp16  -- one 128-byte line per (pixel, 32-channel block)
+//   weight     [Cout][Cin/32][tap][ hi[32] | lo[32] ] fp16
+// so that one K-step of the GEMM (32 channels of one tap) is exactly one 128-byte line per tile row for BOTH
+// operands: a DMA lane-group of 8 lanes fetches a full cache line, and the reduction runs channel-block-outer /
+// tap-inner: the kh*kw taps of one channel block re-read the same ~BM pixel lines back to back (L2 hits) instead
+// of sweeping the whole activation once per tap (the tap-outer order fetched 8x the activation from beyond L2:
+// profiles/r01c_pmc.json).
+//
+// Tile BM x BN x 32, 8 waves; LDS stage = (BM + BN) rows x 128 B, two stages; one barrier per K-step:
+//   wait own DMAs (tile kt) -> barrier -> issue DMAs (tile kt+1 -> other stage) -> 48 MFMAs on tile kt.
+// LDS rows are 128 B; the 16-byte chunk index is XOR-swizzled with (row >> 1) & 7 so that the 16-lane groups of
+// ds_read_b128 (16 rows, same logical chunk) touch 16 distinct 16-byte slots of the 256-byte bank row.  The DMA
+// writes LDS lane-linearly, so the swizzle is applied to the SOURCE chunk each lane fetches.
+//
+// Groups: G independent convolutions of identical geometry (the frozen experts of MRN's router phase run their
+// backbones in lock-step): weights / bias / scales / outputs / statistics are [G]-strided, the input is either
+// [G]-strided or shared (x_gstride = 0).  Tiles never straddle a group.
+#include "common.hpp"
+#include <stdlib.h>
+
+namespace {
+
+typedef _Float16 f16v8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+struct ConvX3Params {
+  const unsigned char* x;     // HL32 activation
+  const unsigned char* w;     // HL32 weight
+  const unsigned char* zero;  // >= 128 bytes of zeros
+  const float* bias;          // [G][N] or null
+  const float* out_scale;     // [G][2] = {s, 1/s} (epilogue multiplies by [1]) or null
+  float* y;                   // [G][M][N]
+  float* stats;               // [G][tilesM][2][N] or null
+  long x_gstride, w_gstride;  // bytes
+  int x_bytes;                // bytes of one group's activation
+  int G, M, N, Cb, taps, nk;
+  int H, W, Ho, Wo, kw, sh, sw, ph, pw, act;
+  int tilesM, tilesN;
+};
+
+// 16 bytes per lane, global (buffer descriptor + per-lane byte offset + wave-uniform offset) -> LDS (wave-uniform base + 16*lane)
+__device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t r, unsigned char* l, int voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)l, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const unsigned char* base, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
+}
+
+__device__ __forceinline__ f32x16 mma(const u32x4 a, const u32x4 b, const f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16v8*>(&a), *reinterpret_cast<const f16v8*>(&b), c, 0, 0, 0);
+}
+
+// WAVES_M x WAVES_N = 8 waves; wave tile = (WM*32) x (WN*32)
+template <int WAVES_M, int WAVES_N, int WM, int WN, int ABL = 0, bool SCHED = true>
+__global__ __launch_bounds__(512) void conv_x3_kernel(const ConvX3Params p) {
+  constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
+  constexpr int NA = BM / 64, NB = BN / 64;          // DMA instructions per wave per K-step (8 rows each, 8 waves)
+  constexpr int STAGE = (BM + BN) * 128;
+  extern __shared__ __attribute__((aligned(128))) unsigned char lds[];
+
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = lid % p.tilesN;
+  const int t2 = lid / p.tilesN;
+  const int tile_m = t2 % p.tilesM;
+  const int g = t2 / p.tilesM;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  // ---- DMA geometry: instruction j = i*8 + wave covers tile rows 8j .. 8j+7; lane -> row 8j + lane/8, LDS chunk lane&7.
+  // Both operands go through buffer descriptors: per-lane 32-bit byte offset (VGPR) + wave-uniform K-step offset; an
+  // offset beyond the descriptor's range returns zeros, which is how padded taps / rows beyond M are produced.
+  const int lrow = lane >> 3, lch = lane & 7;
+  int arow[NA];                     // byte offset of (pixel0 line + swizzled chunk) inside this group's activation (may be < 0)
+  unsigned amask[NA];               // bit tap = this row's tap is inside the image
+  int brow[NB];                     // byte offset of (weight row + swizzled chunk); rows beyond N re-read row N-1 (never stored)
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x + (long)g * p.x_gstride, p.x_bytes);
+  const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.w + (long)g * p.w_gstride, (int)p.w_gstride);
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int row = (i * 8 + wave) * 8 + lrow;
+    const int coff = (lch ^ ((row >> 1) & 7)) << 4;
+    const int m = m0 + row;
+    const bool ok = m < p.M;
+    const int mm = ok ? m : 0;
+    const int hw = p.Ho * p.Wo;
+    const int b = mm / hw;
+    const int rem = mm - b * hw;
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    const int iy0 = oy * p.sh - p.ph, ix0 = ox * p.sw - p.pw;
+    unsigned mask = 0;
+    if (ok) {
+      for (int tp = 0; tp < p.taps; ++tp) {
+        const int ky = tp / p.kw, kx = tp - ky * p.kw;
+        if ((unsigned)(iy0 + ky) < (unsigned)p.H && (unsigned)(ix0 + kx) < (unsigned)p.W) mask |= 1u << tp;
+      }
+    }
+    amask[i] = mask;
+    arow[i] = ((b * p.H + iy0) * p.W + ix0) * p.Cb * 128 + coff;
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int row = (i * 8 + wave) * 8 + lrow;
+    const int coff = (lch ^ ((row >> 1) & 7)) << 4;
+    const int n = min(n0 + row, p.N - 1);
+    brow[i] = n * p.nk * 128 + coff;
+  }
+
+  // K-step kt = cb * taps + tap (channel-block outer, tap inner); all wave-uniform
+  auto issue_tile = [&](int kt, unsigned char* st) {
+    const int cb = kt / p.taps, tap = kt - cb * p.taps;
+    const int ky = tap / p.kw, kx = tap - ky * p.kw;
+    const int aoff = ((ky * p.W + kx) * p.Cb + cb) * 128;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int voff = ((amask[i] >> tap) & 1u) ? arow[i] + aoff : (int)0x80000000;
+      dma16(xr, st + (i * 8 + wave) * 1024, voff, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      dma16(wr, st + BM * 128 + (i * 8 + wave) * 1024, brow[i], kt * 128);
+  };
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // fragment read offsets: row = lane & 31 (+32 per fragment), logical chunk = plane*4 + ks*2 + (lane >> 5);
+  // tile rows start at multiples of 32 so the swizzle key depends on the lane only
+  const int key = (lane >> 1) & 7;
+  const int rbase = (lane & 31) * 128;
+  int foff[2][2];   // [plane][ks]
+#pragma unroll
+  for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) foff[pl][ks] = rbase + (((pl * 4 + ks * 2 + (lane >> 5)) ^ key) << 4);
+  const int abase = wm * WM * 32 * 128, bbase = BM * 128 + wn * WN * 32 * 128;
+
+  constexpr int NMMA = WM * WN * 3;      // MFMAs per 16-deep k-slice
+  issue_tile(0, lds);
+  for (int kt = 0; kt < p.nk; ++kt) {
+    __syncthreads();      // own DMAs of tile kt retired (vmcnt(0)) + everyone finished reading the other stage
+    unsigned char* cur = lds + (kt & 1) * STAGE;
+    u32x4 ah[2][WM], al[2][WM], bh[2][WN], bl[2][WN];
+    auto read_frags = [&](int ks) {
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        al[ks][i] = *reinterpret_cast<const u32x4*>(cur + abase + i * 4096 + foff[1][ks]);
+        ah[ks][i] = *reinterpret_cast<const u32x4*>(cur + abase + i * 4096 + foff[0][ks]);
+      }
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        bh[ks][j] = *reinterpret_cast<const u32x4*>(cur + bbase + j * 4096 + foff[0][ks]);
+        bl[ks][j] = *reinterpret_cast<const u32x4*>(cur + bbase + j * 4096 + foff[1][ks]);
+      }
+    };
+    auto mmas = [&](int ks) {
+      // consecutive MFMAs target different accumulators
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = mma(al[ks][i], bh[ks][j], acc[i][j]);
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = mma(ah[ks][i], bl[ks][j], acc[i][j]);
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = mma(ah[ks][i], bh[ks][j], acc[i][j]);
+    };
+    read_frags(0);
+    // the last iteration re-fetches its own tile into the idle stage: keeps the loop body one basic block
+    if (ABL != 1) issue_tile(min(kt + 1, p.nk - 1), lds + ((kt + 1) & 1) * STAGE);
+    read_frags(1);
+    if (ABL == 2) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j) acc[i][j][0] += __uint_as_float(al[ks][i][0] ^ bh[ks][j][1] ^ ah[ks][i][2] ^ bl[ks][j][3]);
+    } else {
+      mmas(0);
+      mmas(1);
+      if (SCHED) {
+        // issue order: first k-slice's fragments, then the next tile's DMAs and the second slice's fragment reads
+        // threaded between the first slice's MFMAs, then the second slice's MFMAs back to back
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * (WM + WN), 0);
+        constexpr int NDMA = NA + NB, NRD = 2 * (WM + WN);
+        constexpr int PER = NMMA / (NDMA + NRD / 2);        // MFMAs between two memory issues
+#pragma unroll
+        for (int d = 0; d < NDMA; ++d) {
+          __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+#pragma unroll
+        for (int d = 0; d < NRD / 2; ++d) {
+          __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * NMMA - PER * (NDMA + NRD / 2), 0);
+      }
+    }
+  }
+
+  // ---- epilogue: scale, bias, BatchNorm partial statistics, activation, store ------------------------------
+  float* yg = p.y + (long)g * p.M * p.N;
+  const float osc = p.out_scale ? p.out_scale[g * 2 + 1] : 1.f;
+  float csum[WN], csq[WN];
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    csum[j] = 0.f;
+    csq[j] = 0.f;
+    const int n = n0 + (wn * WN + j) * 32 + (lane & 31);
+    const bool nok = n < p.N;
+    const float bn = (p.bias && nok) ? p.bias[(long)g * p.N + n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + (wm * WM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (m < p.M && nok) {
+          float v = acc[i][j][e] * osc + bn;
+          csum[j] += v;
+          csq[j] += v * v;
+          if (p.act == 1) v = fmaxf(v, 0.f);
+          yg[(long)m * p.N + n] = v;
+        }
+      }
+    }
+  }
+  if (p.stats) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);   // [WAVES_M][2][BN]
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const float s = csum[j] + __shfl_xor(csum[j], 32);
+      const float q = csq[j] + __shfl_xor(csq[j], 32);
+      if (lane < 32) {
+        const int c = (wn * WN + j) * 32 + lane;
+        red[(wm * 2 + 0) * BN + c] = s;
+        red[(wm * 2 + 1) * BN + c] = q;
+      }
+    }
+    __syncthreads();
+    if (t < BN) {
+      const int n = n0 + t;
+      if (n < p.N) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int r = 0; r < WAVES_M; ++r) {
+          s += red[(r * 2 + 0) * BN + t];
+          q += red[(r * 2 + 1) * BN + t];
+        }
+        float* sg = p.stats + ((long)g * p.tilesM + tile_m) * 2 * p.N;
+        sg[n] = s;
+        sg[p.N + n] = q;
+      }
+    }
+  }
+}
+
+#define X3_INSTANTIATE(A, B, C, D)                                              \
+  template __global__ void conv_x3_kernel<A, B, C, D, 0, true>(const ConvX3Params); \
+  template __global__ void conv_x3_kernel<A, B, C, D, 0, false>(const ConvX3Params); \
+  template __global__ void conv_x3_kernel<A, B, C, D, 2, true>(const ConvX3Params);
+X3_INSTANTIATE(2, 4, 4, 2)
+X3_INSTANTIATE(4, 2, 2, 2)
+#undef X3_INSTANTIATE
+
+// ---- producers of the HL32 layout -------------------------------------------------------------------------------
+__device__ __forceinline__ void split_h(float v, _Float16& h, _Float16& l) {
+  h = (_Float16)v;
+  l = (_Float16)(v - (float)h);
+}
+
+// fp32 [rows][C] -> HL32 [rows][C/32][hi 32 | lo 32]; one thread = 8 channels (32 B in, 2 x 16 B out)
+__global__ __launch_bounds__(256) void split_hl32_kernel(const float* __restrict__ x, unsigned char* __restrict__ out, long n8) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(x + i * 8), b = *reinterpret_cast<const f32x4*>(x + i * 8 + 4);
+    f16v8 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      _Float16 hh, ll;
+      split_h(a[e], hh, ll);
+      h[e] = hh; l[e] = ll;
+      split_h(b[e], hh, ll);
+      h[4 + e] = hh; l[4 + e] = ll;
+    }
+    const long blk = i >> 2;            // 32-channel block index (4 threads per block)
+    unsigned char* o = out + blk * 128 + (i & 3) * 16;
+    *reinterpret_cast<f16v8*>(o) = h;
+    *reinterpret_cast<f16v8*>(o + 64) = l;
+  }
+}
+
+// w [Cout][taps][Cin] fp32 (x scale[0]) -> [Cout][Cin/32][taps][hi 32 | lo 32]; one thread = 8 channels
+__global__ __launch_bounds__(256) void pack_weight_hl32_kernel(const float* __restrict__ w, unsigned char* __restrict__ out,
+                                                               int Cout, int taps, int Cin, const float* __restrict__ scale) {
+  const float sc = scale ? scale[0] : 1.f;
+  const int Cb = Cin >> 5;
+  const long n8 = (long)Cout * taps * (Cin >> 3);
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const int c8 = (int)(i % (Cin >> 3));
+    const long r = i / (Cin >> 3);
+    const int tap = (int)(r % taps);
+    const long o_ = r / taps;
+    const float* src = w + (o_ * taps + tap) * Cin + c8 * 8;
+    f16v8 h, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      _Float16 hh, ll;
+      split_h(src[e] * sc, hh, ll);
+      h[e] = hh; l[e] = ll;
+    }
+    const int cb = c8 >> 2;
+    unsigned char* o = out + ((o_ * Cb + cb) * taps + tap) * 128 + (c8 & 3) * 16;
+    *reinterpret_cast<f16v8*>(o) = h;
+    *reinterpret_cast<f16v8*>(o + 64) = l;
+  }
+}
+
+template <int WAVES_M, int WAVES_N, int WM, int WN>
+int launch_x3(const ConvX3Params& p0, hipStream_t st) {
+  constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
+  ConvX3Params p = p0;
+  p.tilesM = ceil_div(p.M, BM);
+  p.tilesN = ceil_div(p.N, BN);
+  const size_t ldsz = 2 * (size_t)(BM + BN) * 128;
+  const long tiles = (long)p.G * p.tilesM * p.tilesN;
+  static int abl = getenv("MRN_X3_ABL") ? atoi(getenv("MRN_X3_ABL")) : 0;     // ablation switches of tools/bench_conv_x3.py
+#define X3_LAUNCH(...)                                                                                                 \
+  do {                                                                                                                 \
+    (void)hipFuncSetAttribute((const void*)conv_x3_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz); \
+    hipLaunchKernelGGL((conv_x3_kernel<__VA_ARGS__>), dim3((unsigned)tiles), dim3(512), ldsz, st, p);                 \
+  } while (0)
+  if (abl == 2) X3_LAUNCH(WAVES_M, WAVES_N, WM, WN, 2, true);
+  else if (abl == 3) X3_LAUNCH(WAVES_M, WAVES_N, WM, WN, 0, false);
+  else X3_LAUNCH(WAVES_M, WAVES_N, WM, WN, 0, true);
+#undef X3_LAUNCH
+  MRN_LAUNCH_CHECK("conv2d_x3_hl32");
+  return MRN_OK;
+}
+
+}  // namespace
+
+MRN_EXPORT int64_t mrn_conv2d_x3_stats_floats(int G, int B, int Ho, int Wo, int Cout, int tile_m) {
+  return (int64_t)G * ceil_div((long)B * Ho * Wo, tile_m) * 2 * Cout;
+}
+
+// tile_m x tile_n: 256x256 (default for Cout >= 256) or 256x128
+MRN_EXPORT int mrn_conv2d_x3_hl32(const void* x_hl, const void* w_hl, const void* zero_page, const float* bias, float* y,
+                                  float* stats, const float* out_scale, int G, int64_t x_group_stride_bytes, int B, int H,
+                                  int W, int Cin, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int act,
+                                  int tile_n, void* stream) {
+  MRN_CHECK_ARG(x_hl && w_hl && zero_page && y && G >= 1, "mrn_conv2d_x3_hl32: bad operands");
+  MRN_CHECK_ARG(Cin % 32 == 0 && kh * kw <= 32, "mrn_conv2d_x3_hl32: unsupported Cin=%d kernel=%dx%d", Cin, kh, kw);
+  MRN_CHECK_ARG(((uintptr_t)x_hl % 128 == 0) && ((uintptr_t)w_hl % 128 == 0) && ((uintptr_t)zero_page % 16 == 0) &&
+                    (x_group_stride_bytes % 128 == 0), "mrn_conv2d_x3_hl32: HL32 operands must be 128-byte aligned");
+  MRN_CHECK_ARG(tile_n == 256 || tile_n == 128, "mrn_conv2d_x3_hl32: tile_n must be 128 or 256");
+  const int Ho = (H + 2 * ph - kh) / sh + 1, Wo = (W + 2 * pw - kw) / sw + 1;
+  MRN_CHECK_ARG(Ho > 0 && Wo > 0 && B >= 0, "mrn_conv2d_x3_hl32: empty output");
+  MRN_CHECK_ARG((long)B * H * W * Cin * 4 < (1L << 31) && (long)Cout * kh * kw * Cin * 4 < (1L << 31),
+                "mrn_conv2d_x3_hl32: one group's activation / weight must stay below 2 GiB (32-bit buffer offsets)");
+  ConvX3Params p;
+  memset(&p, 0, sizeof(p));
+  p.x = (const unsigned char*)x_hl; p.w = (const unsigned char*)w_hl; p.zero = (const unsigned char*)zero_page;
+  p.bias = bias; p.out_scale = out_scale; p.y = y; p.stats = stats;
+  p.Cb = Cin / 32; p.taps = kh * kw; p.nk = p.Cb * p.taps;
+  p.x_gstride = x_group_stride_bytes; p.w_gstride = (long)Cout * p.nk * 128;
+  p.x_bytes = (int)((long)B * H * W * Cin * 4);
+  p.G = G; p.M = B * Ho * Wo; p.N = Cout;
+  p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.kw = kw; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw; p.act = act;
+  if (p.M == 0) return MRN_OK;
+  if (tile_n == 256) return launch_x3<2, 4, 4, 2>(p, (hipStream_t)stream);
+  return launch_x3<4, 2, 2, 2>(p, (hipStream_t)stream);
+}
+
+// fp32 [rows][C] (C % 32 == 0) -> HL32
+MRN_EXPORT int mrn_split_hl32_f32(const float* x, void* out, int64_t rows, int C, void* stream) {
+  MRN_CHECK_ARG(x && out && C % 32 == 0, "mrn_split_hl32_f32: bad operands (C=%d)", C);
+  const long n8 = rows * (C / 8);
+  if (n8 == 0) return MRN_OK;
+  long grid = (n8 + 255) / 256;
+  if (grid > 16384) grid = 16384;
+  hipLaunchKernelGGL(split_hl32_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, (unsigned char*)out, n8);
+  MRN_LAUNCH_CHECK("split_hl32");
+  return MRN_OK;
+}
+
+// w [Cout][kh*kw][Cin] fp32 -> HL32 weight [Cout][Cin/32][kh*kw][128 B], multiplied by scale[0] (device) when given
+MRN_EXPORT int mrn_pack_weight_hl32(const float* w_ohwi, void* out, int Cout, int taps, int Cin, const float* scale,
+                                    void* stream) {
+  MRN_CHECK_ARG(w_ohwi && out && Cin % 32 == 0, "mrn_pack_weight_hl32: bad operands (Cin=%d)", Cin);
+  const long n8 = (long)Cout * taps * (Cin / 8);
+  if (n8 == 0) return MRN_OK;
+  long grid = (n8 + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(pack_weight_hl32_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, w_ohwi,
+                     (unsigned char*)out, Cout, taps, Cin, scale);
+  MRN_LAUNCH_CHECK("pack_weight_hl32");
+  return MRN_OK;
+}

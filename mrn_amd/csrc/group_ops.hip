@@ -1,0 +1,228 @@
+// Elementwise passes between the grouped convolutions (conv_x3.hip) when G frozen experts run their backbones in
+// lock-step: BatchNorm statistics finalisation for G BatchNorm modules at once, BatchNorm-apply (+ residual + ReLU)
+// and BatchNorm-apply + ReLU + MaxPool, each writing the fp32 tensor and / or the HL32 split-fp16 operand the next
+// convolution stages by DMA (one 128-byte line [hi x 32 | lo x 32] per (pixel, 32-channel block)).
+//
+// Reference op sites: BatchNorm2d / ReLU / residual add / MaxPool2d of modules/feature_extraction.py:171-199,222-294
+// and modules/transformation.py:69-81, evaluated for every expert of modules/model.py:399-401.
+// All kernels are HBM-bound: each activation byte is read once, 32 B per lane, channels innermost.
+#include "common.hpp"
+
+namespace {
+
+typedef _Float16 f16v8 __attribute__((ext_vector_type(8)));
+
+struct F8 {
+  f32x4 a, b;
+};
+
+__device__ __forceinline__ F8 load8(const float* p) {
+  F8 v;
+  v.a = *reinterpret_cast<const f32x4*>(p);
+  v.b = *reinterpret_cast<const f32x4*>(p + 4);
+  return v;
+}
+__device__ __forceinline__ void store8(float* p, const F8& v) {
+  *reinterpret_cast<f32x4*>(p) = v.a;
+  *reinterpret_cast<f32x4*>(p + 4) = v.b;
+}
+// 8 consecutive channels c8*8 .. +7 of row `row` -> their slots in the HL32 image
+__device__ __forceinline__ void store_hl(unsigned char* out, long row, int C, int c8, const F8& v) {
+  f16v8 h, l;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    h[e] = (_Float16)v.a[e];
+    l[e] = (_Float16)(v.a[e] - (float)h[e]);
+    h[4 + e] = (_Float16)v.b[e];
+    l[4 + e] = (_Float16)(v.b[e] - (float)h[4 + e]);
+  }
+  unsigned char* o = out + (row * (C >> 5) + (c8 >> 2)) * 128 + (c8 & 3) * 16;
+  *reinterpret_cast<f16v8*>(o) = h;
+  *reinterpret_cast<f16v8*>(o + 64) = l;
+}
+
+// one wave per (group, channel): same arithmetic as bn_finalize_kernel (spatial.hip), parameters through pointer tables
+__global__ __launch_bounds__(256) void bn_finalize_grouped_kernel(const float* __restrict__ part, int nblk, int C, long count,
+                                                                  const float* const* __restrict__ ptrs, int G, float momentum,
+                                                                  float eps, float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int g = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  if (c >= C) return;
+  const float* pg = part + (long)g * nblk * 2 * C;
+  double s = 0.0, q = 0.0;
+  for (int b = lane; b < nblk; b += 64) {
+    s += (double)pg[((long)b * 2 + 0) * C + c];
+    q += (double)pg[((long)b * 2 + 1) * C + c];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o);
+    q += __shfl_xor(q, o);
+  }
+  if (lane == 0) {
+    const float* gamma = ptrs[0 * G + g];
+    const float* beta = ptrs[1 * G + g];
+    float* run_mean = const_cast<float*>(ptrs[2 * G + g]);
+    float* run_var = const_cast<float*>(ptrs[3 * G + g]);
+    const double mean = s / (double)count;
+    double var = q / (double)count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float gm = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+    const float sc = gm * invstd;
+    scale[(long)g * C + c] = sc;
+    shift[(long)g * C + c] = bt - (float)mean * sc;
+    if (run_mean) {
+      const double unbiased = count > 1 ? var * (double)count / (double)(count - 1) : var;
+      run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)mean;
+      run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unbiased;
+    }
+  }
+}
+
+// out = act(y * scale[g][c] + shift[g][c] (+ res)); one lane = 8 channels
+__global__ __launch_bounds__(256) void bn_apply_grouped_kernel(const float* __restrict__ y, const float* __restrict__ res,
+                                                               const float* __restrict__ scale, const float* __restrict__ shift,
+                                                               float* __restrict__ out, unsigned char* __restrict__ out_hl,
+                                                               long rows_per_group, long n8, int C, int relu) {
+  const int C8 = C >> 3;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const int c8 = (int)(i % C8);
+    const long row = i / C8;
+    const int g = (int)(row / rows_per_group);
+    F8 v = load8(y + i * 8);
+    if (scale) {
+      const F8 sc = load8(scale + (long)g * C + c8 * 8), sh = load8(shift + (long)g * C + c8 * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v.a[e] = v.a[e] * sc.a[e] + sh.a[e];
+        v.b[e] = v.b[e] * sc.b[e] + sh.b[e];
+      }
+    }
+    if (res) {
+      const F8 r = load8(res + i * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v.a[e] += r.a[e];
+        v.b[e] += r.b[e];
+      }
+    }
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v.a[e] = fmaxf(v.a[e], 0.f);
+        v.b[e] = fmaxf(v.b[e], 0.f);
+      }
+    }
+    if (out) store8(out + i * 8, v);
+    if (out_hl) store_hl(out_hl, row, C, c8, v);
+  }
+}
+
+// NHWC max pooling over [G*B] images with the (scale, shift, relu) of group b / B fused on the input; padding = -inf
+__global__ __launch_bounds__(256) void maxpool_grouped_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, float* __restrict__ out,
+                                                              unsigned char* __restrict__ out_hl, int relu, int B, long n8,
+                                                              int H, int W, int C, int Ho, int Wo, int kh, int kw, int sh,
+                                                              int sw, int ph, int pw) {
+  const int C8 = C >> 3;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const int c8 = (int)(i % C8);
+    const long row = i / C8;
+    long r = row;
+    const int ox = (int)(r % Wo);
+    r /= Wo;
+    const int oy = (int)(r % Ho);
+    const long b = r / Ho;
+    const int g = (int)(b / B);
+    F8 sc, sf;
+    if (scale) {
+      sc = load8(scale + (long)g * C + c8 * 8);
+      sf = load8(shift + (long)g * C + c8 * 8);
+    }
+    F8 m;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m.a[e] = m.b[e] = -INFINITY;
+    for (int ky = 0; ky < kh; ++ky) {
+      const int iy = oy * sh - ph + ky;
+      if ((unsigned)iy >= (unsigned)H) continue;
+      for (int kx = 0; kx < kw; ++kx) {
+        const int ix = ox * sw - pw + kx;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        F8 v = load8(x + (((b * H + iy) * W + ix) * (long)C8 + c8) * 8);
+        if (scale) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v.a[e] = v.a[e] * sc.a[e] + sf.a[e];
+            v.b[e] = v.b[e] * sc.b[e] + sf.b[e];
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          m.a[e] = fmaxf(m.a[e], v.a[e]);
+          m.b[e] = fmaxf(m.b[e], v.b[e]);
+        }
+      }
+    }
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        m.a[e] = fmaxf(m.a[e], 0.f);
+        m.b[e] = fmaxf(m.b[e], 0.f);
+      }
+    }
+    if (out) store8(out + i * 8, m);
+    if (out_hl) store_hl(out_hl, row, C, c8, m);
+  }
+}
+
+}  // namespace
+
+// Train-mode BatchNorm2d statistics for G BatchNorm modules of C channels at once.  partials: [G][nblk][2][C] from the
+// grouped conv epilogue; ptrs: device table [4][G] of device pointers {gamma, beta, running_mean, running_var} (entries
+// may be NULL); scale / shift: [G][C].  Same arithmetic as mrn_bn_finalize_f32.
+MRN_EXPORT int mrn_bn_finalize_grouped_f32(const float* partials, int G, int nblk, int C, int64_t count,
+                                           const void* const* ptrs, float momentum, float eps, float* scale, float* shift,
+                                           void* stream) {
+  MRN_CHECK_ARG(partials && ptrs && scale && shift && G >= 1 && C >= 1 && count >= 1, "mrn_bn_finalize_grouped_f32: bad operands");
+  hipLaunchKernelGGL(bn_finalize_grouped_kernel, dim3((C + 3) / 4, G), dim3(256), 0, (hipStream_t)stream, partials, nblk, C,
+                     (long)count, (const float* const*)ptrs, G, momentum, eps, scale, shift);
+  MRN_LAUNCH_CHECK("bn_finalize_grouped");
+  return MRN_OK;
+}
+
+// out = act(y * scale[g] + shift[g] (+ residual)) over [G][rows_per_group][C]; scale/shift may be NULL (identity);
+// out_f32 and / or out_hl32 (C % 32 == 0) receive the result; out_f32 may alias y.  relu: 0 / 1.
+MRN_EXPORT int mrn_bn_apply_grouped_f32(const float* y, const float* residual, const float* scale, const float* shift,
+                                        float* out_f32, void* out_hl32, int G, int64_t rows_per_group, int C, int relu,
+                                        void* stream) {
+  MRN_CHECK_ARG(y && (out_f32 || out_hl32) && C % 8 == 0 && (!out_hl32 || C % 32 == 0) && (!scale == !shift),
+                "mrn_bn_apply_grouped_f32: bad operands (C=%d)", C);
+  const long n8 = (long)G * rows_per_group * (C / 8);
+  if (n8 == 0) return MRN_OK;
+  long grid = (n8 + 255) / 256;
+  if (grid > 32768) grid = 32768;
+  hipLaunchKernelGGL(bn_apply_grouped_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, y, residual, scale, shift,
+                     out_f32, (unsigned char*)out_hl32, (long)rows_per_group, n8, C, relu);
+  MRN_LAUNCH_CHECK("bn_apply_grouped");
+  return MRN_OK;
+}
+
+// MaxPool2d over x [G][B][H][W][C] with the BatchNorm-apply (+ ReLU) of group g fused on the input (scale/shift [G][C] or NULL)
+MRN_EXPORT int mrn_maxpool_grouped_f32(const float* x, const float* scale, const float* shift, int relu, float* out_f32,
+                                       void* out_hl32, int G, int B, int H, int W, int C, int kh, int kw, int sh, int sw, int ph,
+                                       int pw, void* stream) {
+  MRN_CHECK_ARG(x && (out_f32 || out_hl32) && C % 8 == 0 && (!out_hl32 || C % 32 == 0) && (!scale == !shift),
+                "mrn_maxpool_grouped_f32: bad operands (C=%d)", C);
+  const int Ho = (H + 2 * ph - kh) / sh + 1, Wo = (W + 2 * pw - kw) / sw + 1;
+  MRN_CHECK_ARG(Ho > 0 && Wo > 0, "mrn_maxpool_grouped_f32: empty output");
+  const long n8 = (long)G * B * Ho * Wo * (C / 8);
+  if (n8 == 0) return MRN_OK;
+  long grid = (n8 + 255) / 256;
+  if (grid > 32768) grid = 32768;
+  hipLaunchKernelGGL(maxpool_grouped_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, scale, shift, out_f32,
+                     (unsigned char*)out_hl32, relu, B, n8, H, W, C, Ho, Wo, kh, kw, sh, sw, ph, pw);
+  MRN_LAUNCH_CHECK("maxpool_grouped");
+  return MRN_OK;
+}

@@ -1,0 +1,232 @@
+"""Lock-step execution of the Transformation + FeatureExtraction stages of G frozen experts.
+
+In MRN's router phase every sample visits every expert (reference modules/model.py:399-401, il_modules/mrn.py:323-337)
+and the experts share one architecture, so their conv stacks are the same sequence of GEMM shapes with different
+weights.  Running them one after the other leaves the chip with a ragged tail of tiles at the end of each of the
+~200 conv launches (an expert's deepest layers are 520 tiles of 256x256 on 256 CUs); running them as ONE grouped
+launch per layer (G x tiles) fills the chip, cuts the launch count by G and lets the convolutions use the 256-wide
+tiles of csrc/conv_x3.hip.  Activations live as [G,B,H,W,C] stacks; between convolutions one elementwise pass applies
+BatchNorm (+ residual + ReLU [+ MaxPool]) and writes the fp32 tensor and / or the HL32 split-fp16 operand of the next
+convolution (csrc/group_ops.hip).
+
+Numerics are those of the per-expert path with CONV_PRECISION "fp16x3" (22-bit split products, fp32 accumulation, fp32
+BatchNorm statistics); layers the grouped kernel cannot take (Cin % 32 != 0) run per expert on the exact-fp32 kernel.
+The module parameters stay where they are (state_dict layout untouched): weights are re-packed into per-layer HL32
+stacks that are cached until a parameter changes.
+"""
+import torch
+
+from .. import ops
+from ._nn import _pair, packed_weight, to_nhwc
+
+
+class Act:
+    """A [G,B,H,W,C] activation stack: fp32 tensor and / or HL32 bytes.  shared=True: one [B,H,W,C] input for all groups."""
+
+    def __init__(self, shape, f32=None, hl=None, shared=False):
+        self.shape = tuple(shape)          # (G, B, H, W, C)
+        self.f32 = f32
+        self.hl = hl
+        self.shared = shared
+
+
+def _bn_modules(extractor):
+    got = getattr(extractor, "_mrn_bn_list", None)
+    if got is None:
+        got = [m for m in extractor.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+        extractor._mrn_bn_list = got
+    return got
+
+
+def supported(experts):
+    """Grouped execution covers TPS/None + ResNet/VGG experts of identical configuration, all frozen, same BN mode."""
+    if len(experts) < 2:
+        return False
+    e0 = experts[0]
+    for e in experts:
+        if e.stages != e0.stages or e.stages["Feat"] not in ("ResNet", "VGG") or e.stages["Trans"] not in ("TPS", "None"):
+            return False
+    for mods in zip(*[_bn_modules(e) for e in experts]):
+        if len({m.training for m in mods}) != 1:
+            return False
+    return ops.CONV_PRECISION in ("auto", "fp16x3") and ops.AUTO_SPLIT_KIND == "fp16x3" and ops.AUTO_SPLIT_MIN_K == 0
+
+
+class BackboneGroup:
+    def __init__(self, experts):
+        self.experts = list(experts)       # Model_Extractor modules
+        self.G = len(self.experts)
+        self._wcache = {}
+        self._bncache = {}
+        self._nbt = []
+
+    # ---- caches ------------------------------------------------------------------------------------------------
+    def _weights_hl(self, convs):
+        key = tuple((c.weight.data_ptr(), c.weight._version) for c in convs)
+        got = self._wcache.get(id(convs[0]))
+        if got is None or got[0] != key:
+            got = (key, ops.pack_weights_hl32([packed_weight(c).ohwi for c in convs]))
+            self._wcache[id(convs[0])] = got
+        return got[1]
+
+    def _bn_table(self, bns):
+        key = tuple(t.data_ptr() for b in bns for t in (b.weight, b.bias, b.running_mean, b.running_var))
+        got = self._bncache.get(id(bns[0]))
+        if got is None or got[0] != key:
+            rows = [[b.weight.data_ptr() for b in bns], [b.bias.data_ptr() for b in bns],
+                    [b.running_mean.data_ptr() for b in bns], [b.running_var.data_ptr() for b in bns]]
+            got = (key, torch.tensor(rows, dtype=torch.int64, device=bns[0].weight.device))
+            self._bncache[id(bns[0])] = got
+        return got[1]
+
+    def _bias_stack(self, convs):
+        if convs[0].bias is None:
+            return None
+        return torch.stack([c.bias.detach() for c in convs]).contiguous()
+
+    # ---- one conv (+BN) (+residual) (+ReLU) (+pool) layer for all groups ----------------------------------------------
+    def layer(self, x, convs, bns=None, relu=True, residual=None, pool=None, want_f32=False, want_hl=True):
+        G = self.G
+        _, B, H, W, Cin = x.shape
+        c0 = convs[0]
+        Cout = c0.out_channels
+        ksize, stride, padding = _pair(c0.kernel_size), _pair(c0.stride), _pair(c0.padding)
+        Ho, Wo = ops.conv_out_hw(H, W, ksize, stride, padding)
+        dev = c0.weight.device
+        training = bns is not None and bns[0].training
+        fuse_act = bns is None                       # no BatchNorm: bias + ReLU go into the conv epilogue
+        act = ops.ACT_RELU if (fuse_act and relu) else ops.ACT_NONE
+        y = torch.empty(G, B, Ho, Wo, Cout, device=dev, dtype=torch.float32)
+        stats = None
+        if Cin % 32 == 0 and Cout >= 64:
+            if x.hl is None:
+                assert x.f32 is not None
+                x.hl = ops.split_hl32(x.f32)
+            w_hl, w_scale = self._weights_hl(convs)
+            _, stats = ops.conv2d_x3(x.hl, G, x.shared, B, H, W, Cin, w_hl, w_scale, Cout, ksize, stride, padding,
+                                     bias=self._bias_stack(convs), act=act, want_stats=training, out=y)
+        else:   # small-Cin layers: exact-fp32 kernel per expert, written into the stack
+            assert x.f32 is not None
+            n = ops.call("mrn_conv2d_stats_floats", B, Ho, Wo, Cout) if training else 0
+            stats = torch.empty(G, n, device=dev, dtype=torch.float32) if training else None
+            for g, c in enumerate(convs):
+                xg = x.f32 if x.shared else x.f32[g]
+                ops.conv2d_nhwc(xg, packed_weight(c), c.bias, stride, padding, act=act, want_stats=training, precision="f32",
+                                out=y[g], stats_out=stats[g] if training else None)
+        scale = shift = None
+        if bns is not None:
+            if training:
+                mom = 0.1 if bns[0].momentum is None else bns[0].momentum
+                scale, shift = ops.bn_finalize_grouped(stats, G, Cout, B * Ho * Wo, self._bn_table(bns), mom, bns[0].eps)
+                self._nbt += [b.num_batches_tracked for b in bns if b.num_batches_tracked is not None]
+            else:
+                ss = [ops.bn_eval_affine(b.weight, b.bias, b.running_mean, b.running_var, b.eps) for b in bns]
+                scale = torch.stack([s for s, _ in ss]).contiguous()
+                shift = torch.stack([s for _, s in ss]).contiguous()
+        res = residual.f32 if residual is not None else None
+        post_relu = relu and not fuse_act
+        if pool is not None:
+            assert res is None
+            f32, hl, (Hp, Wp) = ops.maxpool_grouped(y, pool[0], pool[1], pool[2], scale, shift, relu=post_relu,
+                                                    want_f32=want_f32, want_hl=want_hl)
+            return Act((G, B, Hp, Wp, Cout), f32, hl)
+        if scale is None and res is None and not post_relu and not want_hl:
+            return Act((G, B, Ho, Wo, Cout), y, None)
+        f32, hl = ops.bn_apply_grouped(y, scale, shift, relu=post_relu, residual=res, want_f32=want_f32, want_hl=want_hl)
+        return Act((G, B, Ho, Wo, Cout), f32, hl)
+
+    # ---- network programs ---------------------------------------------------------------------------------------
+    def _basic_block(self, x, blocks, next_needs_f32):
+        out = self.layer(x, [b.conv1 for b in blocks], [b.bn1 for b in blocks])
+        if blocks[0].downsample is not None:
+            res = self.layer(x, [b.downsample[0] for b in blocks], [b.downsample[1] for b in blocks], relu=False,
+                             want_f32=True, want_hl=False)
+        else:
+            res = x
+            assert res.f32 is not None
+        return self.layer(out, [b.conv2 for b in blocks], [b.bn2 for b in blocks], relu=True, residual=res,
+                          want_f32=next_needs_f32, want_hl=True)
+
+    def _resnet(self, x):
+        nets = [e.FeatureExtraction.ConvNet for e in self.experts]
+        n0 = nets[0]
+        p22, p2_21 = ((2, 2), (2, 2), (0, 0)), ((2, 2), (2, 1), (0, 1))
+
+        def stage(x, name):
+            blocks = [list(getattr(n, name)) for n in nets]
+            nb = len(blocks[0])
+            for i in range(nb):
+                # the next consumer needs the fp32 tensor only when it is a block with an identity shortcut
+                nxt_identity = i + 1 < nb and blocks[0][i + 1].downsample is None
+                x = self._basic_block(x, [b[i] for b in blocks], nxt_identity)
+            return x
+
+        def first_block_identity(name):
+            return getattr(n0, name)[0].downsample is None
+
+        x = self.layer(x, [n.conv0_1 for n in nets], [n.bn0_1 for n in nets])
+        x = self.layer(x, [n.conv0_2 for n in nets], [n.bn0_2 for n in nets], pool=p22, want_f32=first_block_identity("layer1"))
+        x = stage(x, "layer1")
+        x = self.layer(x, [n.conv1 for n in nets], [n.bn1 for n in nets], pool=p22, want_f32=first_block_identity("layer2"))
+        x = stage(x, "layer2")
+        x = self.layer(x, [n.conv2 for n in nets], [n.bn2 for n in nets], pool=p2_21, want_f32=first_block_identity("layer3"))
+        x = stage(x, "layer3")
+        x = self.layer(x, [n.conv3 for n in nets], [n.bn3 for n in nets], want_f32=first_block_identity("layer4"))
+        x = stage(x, "layer4")
+        x = self.layer(x, [n.conv4_1 for n in nets], [n.bn4_1 for n in nets])
+        return self.layer(x, [n.conv4_2 for n in nets], [n.bn4_2 for n in nets], want_f32=True, want_hl=False)
+
+    def _vgg(self, x):
+        nets = [e.FeatureExtraction.ConvNet for e in self.experts]
+        p22, p21 = ((2, 2), (2, 2), (0, 0)), ((2, 1), (2, 1), (0, 0))
+
+        def L(x, i, bn=None, pool=None, last=False):
+            return self.layer(x, [n[i] for n in nets], None if bn is None else [n[bn] for n in nets], pool=pool,
+                              want_f32=last, want_hl=not last)
+        x = L(x, 0, pool=p22)
+        x = L(x, 3, pool=p22)
+        x = L(x, 6)
+        x = L(x, 8, pool=p21)
+        x = L(x, 11, bn=12)
+        x = L(x, 14, bn=15, pool=p21)
+        return L(x, 18, last=True)
+
+    def _tps(self, image):
+        """image [B,H,W,C] fp32 (shared) -> rectified images [G,B,H,W,C]"""
+        G = self.G
+        B, H, W, C = image.shape
+        tps = [e.Transformation for e in self.experts]
+        loc = [t.LocalizationNetwork for t in tps]
+        pool = ((2, 2), (2, 2), (0, 0))
+        x = Act((G, B, H, W, C), image, None, shared=True)
+        x = self.layer(x, [l.conv[0] for l in loc], [l.conv[1] for l in loc], pool=pool)
+        x = self.layer(x, [l.conv[4] for l in loc], [l.conv[5] for l in loc], pool=pool)
+        x = self.layer(x, [l.conv[8] for l in loc], [l.conv[9] for l in loc], pool=pool)
+        x = self.layer(x, [l.conv[12] for l in loc], [l.conv[13] for l in loc], want_f32=True, want_hl=False)
+        out = torch.empty(G, B, tps[0].I_r_size[0], tps[0].I_r_size[1], C, device=image.device, dtype=torch.float32)
+        for g, (t, l) in enumerate(zip(tps, loc)):
+            v = ops.avgpool_nhwc(x.f32[g])
+            fc1, fc2 = l.localization_fc1[0], l.localization_fc2
+            v = ops.linear(v, fc1.weight, fc1.bias, act=ops.ACT_RELU)
+            cprime = ops.linear(v, fc2.weight, fc2.bias).view(B, l.F, 2)
+            gg = t.GridGenerator
+            ops.tps_grid_sample(image, cprime, gg.inv_delta_C, gg.P_hat, t.I_r_size, out=out[g])
+        return Act(tuple(out.shape), out, None)
+
+    def visual_all(self, image):
+        """image: logical [B,C,H,W] -> backbone features [G,B,T,C'] (the reference's permute + AdaptiveAvgPool + squeeze
+        is the identity on the height-1 NHWC map)"""
+        img = to_nhwc(image)
+        B, H, W, C = img.shape
+        self._nbt = []
+        if self.experts[0].stages["Trans"] == "TPS":
+            x = self._tps(img)
+        else:
+            x = Act((self.G, B, H, W, C), img, None, shared=True)
+        x = self._resnet(x) if self.experts[0].stages["Feat"] == "ResNet" else self._vgg(x)
+        if self._nbt:
+            torch._foreach_add_(self._nbt, 1)
+        G, B, Ho, Wo, Cf = x.shape
+        if Ho != 1:
+            raise NotImplementedError("HIP path expects a height-1 feature map (32x256 inputs); got H=%d" % Ho)
+        return x.f32.view(G, B, Wo, Cf)

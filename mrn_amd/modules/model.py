@@ -256,12 +256,25 @@ class MRNNet(nn.Module):
         self.layer_num = 1
         self.beta = 1
         self.expert_streams = True          # run the frozen experts on separate HIP streams
+        self.expert_grouping = True         # run the frozen experts' conv backbones in lock-step (modules/expert_group.py)
         self._stream_pool = []
+        self._group = None
 
     def _streams(self, n, device):
         while len(self._stream_pool) < n:
             self._stream_pool.append(torch.cuda.Stream(device=device))
         return self._stream_pool
+
+    def _backbone_group(self):
+        """BackboneGroup over the current experts when they can run in lock-step, else None (per-expert path)"""
+        from . import expert_group
+        if not self.expert_grouping:
+            return None
+        extractors = [e.model for e in self.model]
+        key = tuple(id(e) for e in extractors)
+        if self._group is None or self._group[0] != key:
+            self._group = (key, expert_group.BackboneGroup(extractors))
+        return self._group[1] if expert_group.supported(extractors) else None
 
     @property
     def feature_dim(self):
@@ -290,7 +303,12 @@ class MRNNet(nn.Module):
                 # Phase 1, one stream: the conv backbones -- every kernel fills the chip, nothing to gain from overlap.
                 # Phase 2, one HIP stream per expert: BiLSTM / attention decoder are latency-bound launches of 16-32
                 # workgroups each; the six experts' recurrences run side by side instead of idling 90 % of the CUs.
-                visuals = [expert.model.visual(image) for expert in self.model]
+                group = self._backbone_group()
+                if group is not None:
+                    stack = group.visual_all(image)                      # [I,B,T,C'], one grouped launch per layer
+                    visuals = [stack[i] for i in range(I)]
+                else:
+                    visuals = [expert.model.visual(image) for expert in self.model]
                 main = torch.cuda.current_stream()
                 streams = self._streams(I, dev)
                 for i, expert in enumerate(self.model):
@@ -349,11 +367,13 @@ class MRNNet(nn.Module):
             raise Exception("Prediction is neither CTC or Attn")
 
     def copy(self):
-        pool, self._stream_pool = self._stream_pool, []      # streams are not copyable
+        pool, self._stream_pool = self._stream_pool, []      # streams / packed-weight caches are not copied
+        group, self._group = self._group, None
         try:
             return copy.deepcopy(self)
         finally:
             self._stream_pool = pool
+            self._group = group
 
     def freeze(self):
         for p in self.parameters():

@@ -199,7 +199,8 @@ def conv_out_hw(H, W, k, s, p):
     return (H + 2 * p[0] - k[0]) // s[0] + 1, (W + 2 * p[1] - k[1]) // s[1] + 1
 
 
-def conv2d_nhwc(x, w_ohwi, bias=None, stride=(1, 1), padding=(0, 0), act=ACT_NONE, want_stats=False, precision=None):
+def conv2d_nhwc(x, w_ohwi, bias=None, stride=(1, 1), padding=(0, 0), act=ACT_NONE, want_stats=False, precision=None,
+                out=None, stats_out=None):
     """x [B,H,W,Cin] -> y [B,Ho,Wo,Cout]; returns (y, stats or None) where stats are per-128-row-block partials.
     w_ohwi: [O,kh,kw,I] fp32 tensor or a PackedConvWeight."""
     packed = w_ohwi if isinstance(w_ohwi, PackedConvWeight) else None
@@ -210,11 +211,13 @@ def conv2d_nhwc(x, w_ohwi, bias=None, stride=(1, 1), padding=(0, 0), act=ACT_NON
     Cout, kh, kw, _ = w_ohwi.shape
     precision = precision or CONV_PRECISION
     Ho, Wo = conv_out_hw(H, W, (kh, kw), stride, padding)
-    y = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
+    y = out if out is not None else torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
+    assert y.is_contiguous() and y.numel() == B * Ho * Wo * Cout
     stats = None
     if want_stats:
         n = call("mrn_conv2d_stats_floats", B, Ho, Wo, Cout)
-        stats = torch.empty(n, device=x.device, dtype=torch.float32)
+        stats = stats_out if stats_out is not None else torch.empty(n, device=x.device, dtype=torch.float32)
+        assert stats.is_contiguous() and stats.numel() == n
     timed = CONV_TIMER is not None and Cout > 64          # the 128x128-tile kernels
     Kred = kh * kw * Cin
     kind = "f32"
@@ -248,6 +251,90 @@ def conv2d_nhwc(x, w_ohwi, bias=None, stride=(1, 1), padding=(0, 0), act=ACT_NON
     if timed:
         CONV_TIMER.end(t0, 2.0 * B * Ho * Wo * Cout * Kred, kind)
     return y, stats
+
+
+# ---------------------------------------------------------------------------------------------------------
+# grouped split-fp16 x3 convolution on HL32 operands (conv_x3.hip)
+# ---------------------------------------------------------------------------------------------------------
+X3_TILE_M = 256
+
+
+def split_hl32(x):
+    """fp32 [..., C] (C % 32 == 0, contiguous) -> HL32 bytes (same byte count), one 128-B line per (row, 32 channels)"""
+    _chk(x)
+    C = x.shape[-1]
+    rows = x.numel() // C
+    out = torch.empty(x.numel() * 4, device=x.device, dtype=torch.uint8)
+    call("mrn_split_hl32_f32", _p(x), _p(out), rows, C, _stream())
+    return out
+
+
+def pack_weights_hl32(ws):
+    """list of G [O,kh,kw,I] fp32 weights (same shape) -> (HL32 weight stack bytes [G][O][I/32][taps][128], scale [G,2])"""
+    O, kh, kw, I = ws[0].shape
+    G = len(ws)
+    dev = ws[0].device
+    per = O * kh * kw * I * 4
+    out = torch.empty(G * per, device=dev, dtype=torch.uint8)
+    scale = torch.empty(G, 2, device=dev, dtype=torch.float32)
+    for g, w in enumerate(ws):
+        _chk(w)
+        assert tuple(w.shape) == (O, kh, kw, I) and w.is_contiguous()
+        call("mrn_pow2_scale_f32", _p(w), w.numel(), FP16_WEIGHT_PEAK, scale[g].data_ptr(), _stream())
+        call("mrn_pack_weight_hl32", _p(w), out.data_ptr() + g * per, O, kh * kw, I, scale[g].data_ptr(), _stream())
+    return out, scale
+
+
+def conv2d_x3(x_hl, G, shared_input, B, H, W, Cin, w_hl, w_scale, Cout, ksize, stride=(1, 1), padding=(0, 0), bias=None,
+              act=ACT_NONE, want_stats=False, out=None):
+    """Grouped conv on HL32 operands -> (y [G,B,Ho,Wo,Cout] fp32, stats or None)."""
+    kh, kw = ksize
+    Ho, Wo = conv_out_hw(H, W, ksize, stride, padding)
+    dev = x_hl.device
+    y = out if out is not None else torch.empty(G, B, Ho, Wo, Cout, device=dev, dtype=torch.float32)
+    stats = None
+    if want_stats:
+        stats = torch.empty(call("mrn_conv2d_x3_stats_floats", G, B, Ho, Wo, Cout, X3_TILE_M), device=dev, dtype=torch.float32)
+    gstride = 0 if shared_input else B * H * W * Cin * 4
+    tile_n = 256 if Cout >= 256 else 128
+    timed = CONV_TIMER is not None
+    t0 = CONV_TIMER.begin() if timed else None
+    call("mrn_conv2d_x3_hl32", _p(x_hl), _p(w_hl), _p(_zero_page(dev)), _p(bias), _p(y), _p(stats), _p(w_scale), G, gstride,
+         B, H, W, Cin, Cout, kh, kw, stride[0], stride[1], padding[0], padding[1], act, tile_n, _stream())
+    if timed:
+        CONV_TIMER.end(t0, 2.0 * G * B * Ho * Wo * Cout * kh * kw * Cin, "fp16x3/x3g%d" % tile_n)
+    return y, stats
+
+
+def bn_finalize_grouped(stats, G, C, count, ptr_table, momentum, eps):
+    """stats [G][nblk][2][C]; ptr_table: int64 device tensor [4,G] of {gamma, beta, running_mean, running_var} addresses"""
+    scale = torch.empty(G, C, device=stats.device, dtype=torch.float32)
+    shift = torch.empty(G, C, device=stats.device, dtype=torch.float32)
+    nblk = stats.numel() // (2 * C * G)
+    call("mrn_bn_finalize_grouped_f32", _p(stats), G, nblk, C, count, _p(ptr_table), float(momentum), float(eps), _p(scale),
+         _p(shift), _stream())
+    return scale, shift
+
+
+def bn_apply_grouped(y, scale, shift, relu=True, residual=None, want_f32=True, want_hl=False):
+    """y [G,...,C] fp32 -> (fp32 result (in place) or None, HL32 bytes or None)"""
+    G, C = y.shape[0], y.shape[-1]
+    rows = y.numel() // (G * C)
+    out_hl = torch.empty(y.numel() * 4, device=y.device, dtype=torch.uint8) if want_hl else None
+    call("mrn_bn_apply_grouped_f32", _p(y), _p(residual), _p(scale), _p(shift), _p(y) if want_f32 else None, _p(out_hl), G, rows,
+         C, int(bool(relu)), _stream())
+    return (y if want_f32 else None), out_hl
+
+
+def maxpool_grouped(x, kernel, stride, padding, scale=None, shift=None, relu=False, want_f32=True, want_hl=False):
+    """x [G,B,H,W,C] -> (fp32 [G,B,Ho,Wo,C] or None, HL32 bytes or None)"""
+    G, B, H, W, C = x.shape
+    Ho, Wo = conv_out_hw(H, W, kernel, stride, padding)
+    out = torch.empty(G, B, Ho, Wo, C, device=x.device, dtype=torch.float32) if want_f32 else None
+    out_hl = torch.empty(G * B * Ho * Wo * C * 4, device=x.device, dtype=torch.uint8) if want_hl else None
+    call("mrn_maxpool_grouped_f32", _p(x), _p(scale), _p(shift), int(bool(relu)), _p(out), _p(out_hl), G, B, H, W, C, kernel[0],
+         kernel[1], stride[0], stride[1], padding[0], padding[1], _stream())
+    return out, out_hl, (Ho, Wo)
 
 
 def bn_finalize(stats, C, count, gamma, beta, running_mean, running_var, momentum, eps, save=False):
@@ -299,12 +386,14 @@ def avgpool_nhwc(x, scale=None, shift=None, relu=False):
 # ---------------------------------------------------------------------------------------------------------
 # TPS
 # ---------------------------------------------------------------------------------------------------------
-def tps_grid_sample(img_nhwc, cprime, inv_delta_c, p_hat, out_hw, want_grid=False):
+def tps_grid_sample(img_nhwc, cprime, inv_delta_c, p_hat, out_hw, want_grid=False, out=None):
     _chk(img_nhwc, cprime, inv_delta_c, p_hat)
     B, H, W, C = img_nhwc.shape
     Hr, Wr = out_hw
     F = cprime.shape[1]
-    out = torch.empty(B, Hr, Wr, C, device=img_nhwc.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty(B, Hr, Wr, C, device=img_nhwc.device, dtype=torch.float32)
+    assert out.is_contiguous() and out.numel() == B * Hr * Wr * C
     grid = torch.empty(B, Hr * Wr, 2, device=img_nhwc.device, dtype=torch.float32) if want_grid else None
     call("mrn_tps_grid_sample_f32", _p(img_nhwc), _p(cprime.contiguous()), _p(inv_delta_c), _p(p_hat), _p(out),
          _p(grid), B, H, W, C, Hr, Wr, F, _stream())
