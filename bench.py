@@ -124,6 +124,7 @@ def main():
 
     from mrn_amd import ops, parallel
     from mrn_amd.data.synthetic import SyntheticTextLines
+    from mrn_amd.tools.utils import to_device
     rank, world, local = parallel.init_distributed()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
@@ -142,7 +143,7 @@ def main():
 
     def step():
         image, labels, idx = data.get_batch2()
-        indexs = torch.LongTensor(idx).squeeze().to(dev)
+        indexs = to_device(torch.LongTensor(idx).squeeze())
         return learner.routing_step(image, labels, indexs)
 
     for _ in range(args.warmup):

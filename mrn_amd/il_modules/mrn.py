@@ -10,7 +10,7 @@ import torch
 from .. import functional as Fn
 from .. import parallel
 from ..modules.model import MRNNet
-from ..tools.utils import Averager
+from ..tools.utils import Averager, to_device
 from .base import BaseLearner
 
 
@@ -110,7 +110,7 @@ class MRN(BaseLearner):
         n_iter = int(self.opt.num_iter // 2)
         for iteration in range(start_iter + 1, n_iter + 1):
             image_tensors, labels, indexs = train_loader.get_batch2()
-            indexs = torch.LongTensor(indexs).squeeze().to(self.device)
+            indexs = to_device(torch.LongTensor(indexs).squeeze())
             loss_clf, taski_loss = self.routing_step(image_tensors.to(self.device), labels, indexs, pi)
             train_loss_avg.add(loss_clf.detach())
             train_taski_loss_avg.add(taski_loss.detach())

@@ -5,6 +5,14 @@ import torch
 device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
 
 
+def to_device(t):
+    """host tensor -> current device without stalling the host: a pageable H2D copy waits for everything queued on the
+    stream, which would serialise the label encoding of step n+1 behind the GPU work of step n"""
+    if device.type != "cuda":
+        return t
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 class CTCLabelConverter(object):
     """index 0 = CTC blank; then [PAD]=1, [UNK]=2, ' '=3, then the characters in order."""
 
@@ -23,7 +31,7 @@ class CTCLabelConverter(object):
         for row, word in enumerate(word_string):
             if word:
                 index[row, :len(word)] = torch.tensor([self.dict.get(ch, unk) for ch in word], dtype=torch.long)
-        return index.to(device), torch.IntTensor(lengths).to(device)
+        return to_device(index), to_device(torch.IntTensor(lengths))
 
     def decode(self, word_index, word_length):
         """greedy CTC collapse: drop blanks (0) and merge repeats"""
@@ -58,7 +66,7 @@ class AttnLabelConverter(object):
         for row, word in enumerate(word_string):
             ids = [self.dict.get(ch, unk) for ch in word] + [eos]
             index[row, 1:1 + len(ids)] = torch.tensor(ids, dtype=torch.long)
-        return index.to(device), torch.IntTensor(lengths).to(device)
+        return to_device(index), to_device(torch.IntTensor(lengths))
 
     def decode(self, word_index, word_length):
         return ["".join(self.character[int(k)] for k in row[:int(n)]) for row, n in zip(word_index, word_length)]

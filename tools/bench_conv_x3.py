@@ -60,6 +60,9 @@ def main():
                     serr = max(serr, ((tot - totr).abs().max() / totr.abs().max()).item())
             flops = 2.0 * G * y.shape[1] * y.shape[2] * y.shape[3] * Cout * k[0] * k[1] * Cin
             ms = timeit(lambda: ops.conv2d_x3(x_hl, G, False, B, H, W, Cin, w_hl, w_scale, Cout, k, s, p, want_stats=True), reps)
+            if "--only-x3" in sys.argv:
+                print(f"conv G{G} B{B} {H}x{W} {Cin}->{Cout} k{k[0]}x{k[1]}: x3g {ms:8.3f} ms {flops / ms / 1e9:7.1f} TF", flush=True)
+                continue
             ops.CONV_PRECISION = "fp16x3"
             ops.DMA_MIN_CIN = 0
             pw = [ops.PackedConvWeight(w) for w in ws]

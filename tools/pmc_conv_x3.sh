@@ -1,0 +1,31 @@
+#!/bin/bash
+# PMC counters of the grouped conv micro-benchmark (big TRBA shape, G=6); usage on the GPU box: bash tools/pmc_conv_x3.sh <tag>
+tag=$1
+R=$GRAFT_REPO_ROOT
+mkdir -p $R/gpurun_out/$tag
+cd /tmp && export TMPDIR=/tmp
+export NSHAPES=1
+i=0
+for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES" \
+           "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES SQ_INST_CYCLES_VMEM_RD GRBM_GUI_ACTIVE" \
+           "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" "FETCH_SIZE" "WRITE_SIZE" "TA_TA_BUSY_sum TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/$tag/p$i -o p -- python3 $R/tools/bench_conv_x3.py 2 6 --no-check --only-x3 > $R/gpurun_out/$tag/p$i.log 2>&1
+done
+cd $R
+python3 - <<PY
+import csv, glob, collections
+agg = collections.defaultdict(lambda: [0, 0.0])
+for f in glob.glob("gpurun_out/$tag/p*/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        if "conv_x3_kernel" not in row["Kernel_Name"]:
+            continue
+        a = agg[row["Counter_Name"]]
+        a[0] += 1
+        a[1] += float(row["Counter_Value"])
+with open("gpurun_out/$tag/pmc.txt", "w") as out:
+    for k in sorted(agg):
+        out.write(f"{k:40s} n={agg[k][0]:4d} avg={agg[k][1] / agg[k][0]:.6g}\n")
+print(open("gpurun_out/$tag/pmc.txt").read())
+PY
+rm -rf gpurun_out/$tag/p[0-9]
