@@ -77,11 +77,14 @@ int mrn_split_weight_bf16(const float* w, void* hi, void* lo, int64_t n, int hal
  * input); w_hl: [G][Cout][Cin/32][kh*kw][128 B]; bias [G][Cout] or NULL; out_scale [G][2] = {s, 1/s} per group (the
  * power-of-two weight prescale of mrn_pow2_scale_f32) or NULL; y [G][B][Ho][Wo][Cout] fp32; stats
  * [G][ceil(B*Ho*Wo/256)][2][Cout] per-256-row-block sums / sums of squares (mrn_conv2d_x3_stats_floats) or NULL.
- * tile_n = 256 (Cout >= 256) or 128.  Requires Cin % 32 == 0; zero_page: >= 128 bytes of device zeros. */
+ * tile_n = 256 (Cout >= 256) or 128.  Requires Cin % 32 == 0; zero_page: >= 128 bytes of device zeros.
+ * y_row_stride / y_group_stride (floats; 0 = dense [G][B*Ho*Wo][Cout]) let the result land in a wider buffer, e.g. one
+ * expert's slice of the router's [B][P][I][C] feature tensor.  With H = W = kh = kw = 1 this is a grouped Linear layer
+ * (nn.Linear sites of modules/sequence_modeling.py:10,19-22 and modules/prediction.py:58-68,104-107). */
 int mrn_conv2d_x3_hl32(const void* x_hl, const void* w_hl, const void* zero_page, const float* bias, float* y,
                        float* stats, const float* out_scale, int G, int64_t x_group_stride_bytes, int B, int H, int W,
                        int Cin, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int act, int tile_n,
-                       void* stream);
+                       int64_t y_row_stride, int64_t y_group_stride, void* stream);
 int64_t mrn_conv2d_x3_stats_floats(int G, int B, int Ho, int Wo, int Cout, int tile_m);
 int mrn_split_hl32_f32(const float* x, void* out, int64_t rows, int C, void* stream);
 int mrn_pack_weight_hl32(const float* w_ohwi, void* out, int Cout, int taps, int Cin, const float* scale, void* stream);
@@ -188,6 +191,18 @@ int mrn_attn_decoder_fwd_f32(const float* Hb, const float* Hproj, const float* e
                              const float* b_hh, float* hid, int64_t hid_stride_b, int64_t hid_stride_s, float* h_state,
                              float* c_state, float* alpha_out, float* gates_out, float* c_out, float* ctx_out,
                              float* hp_out, int B, int T, int D, int S, int hidden, void* stream);
+/* The same two recurrent kernels for `groups` experts of identical geometry in ONE launch (grid = groups x tiles): in
+ * the router phase every expert decodes the same batch (modules/model.py:399-401), and one expert alone occupies 16-32
+ * of the 256 CUs.  Every pointer argument is a HOST array of `groups` device pointers (b_hh may be NULL). */
+int mrn_lstm_layer_fwd_grouped_f32(const void* const* xproj, const void* const* w_hh, const void* const* b_hh,
+                                   const void* const* out, int groups, int B, int T, int hidden, int ndir, void* stream);
+int mrn_attn_decoder_fwd_grouped_f32(const void* const* Hb, const void* const* Hproj, const void* const* eproj,
+                                     int64_t eproj_stride_b, int64_t eproj_stride_s, const void* const* w_h2h,
+                                     const void* const* b_h2h, const void* const* w_score, const void* const* w_ih_ctx,
+                                     const void* const* w_hh, const void* const* b_hh, const void* const* hid,
+                                     int64_t hid_stride_b, int64_t hid_stride_s, int groups, int B, int T, int D, int S,
+                                     int hidden, void* stream);
+
 /* Backward of the teacher-forced decoder (26 steps of BPTT through attention + LSTMCell in one launch).
  * Saved by the forward: alpha [B][S][T], gates [B][S][4H] (post-activation), cseq [B][S][H], ctx [B][S][D], hp [B][S][H].
  * Weights transposed + fragment-major: w_h2hT (rows = input unit, K = H), w_ih_ctxT (rows = D index, K = 4H),

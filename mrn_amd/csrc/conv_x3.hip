@@ -40,6 +40,7 @@ struct ConvX3Params {
   float* y;                   // [G][M][N]
   float* stats;               // [G][tilesM][2][N] or null
   long x_gstride, w_gstride;  // bytes
+  long y_gstride, y_ld;       // output group stride / row pitch in floats
   int x_bytes;                // bytes of one group's activation
   int G, M, N, Cb, taps, nk;  // nk = Cb * taps = K-steps of the full reduction (weight row length in 128-byte lines)
   int H, W, Ho, Wo, kw, sh, sw, ph, pw, act;
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(512) void conv_x3_kernel(const ConvX3Params p) {
   }
 
   // ---- epilogue: scale, bias, BatchNorm partial statistics, activation, store ------------------------------
-  float* yg = p.y + (long)g * p.M * p.N;
+  float* yg = p.y + (long)g * p.y_gstride;
   const float osc = p.out_scale ? p.out_scale[g * 2 + 1] : 1.f;
   float csum[WN], csq[WN], bn[WN];
 #pragma unroll
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(512) void conv_x3_kernel(const ConvX3Params p) {
           csum[j] += v;
           csq[j] += v * v;
           if (p.act == 1) v = fmaxf(v, 0.f);
-          yg[pix * p.N + n] = v;
+          yg[pix * p.y_ld + n] = v;
         }
       }
     }
@@ -396,7 +397,7 @@ MRN_EXPORT int64_t mrn_conv2d_x3_stats_floats(int G, int B, int Ho, int Wo, int 
 MRN_EXPORT int mrn_conv2d_x3_hl32(const void* x_hl, const void* w_hl, const void* zero_page, const float* bias, float* y,
                                   float* stats, const float* out_scale, int G, int64_t x_group_stride_bytes, int B, int H,
                                   int W, int Cin, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int act,
-                                  int tile_n, void* stream) {
+                                  int tile_n, int64_t y_row_stride, int64_t y_group_stride, void* stream) {
   MRN_CHECK_ARG(x_hl && w_hl && zero_page && y && G >= 1, "mrn_conv2d_x3_hl32: bad operands");
   MRN_CHECK_ARG(Cin % 32 == 0 && kh * kw <= 32, "mrn_conv2d_x3_hl32: unsupported Cin=%d kernel=%dx%d", Cin, kh, kw);
   MRN_CHECK_ARG(((uintptr_t)x_hl % 128 == 0) && ((uintptr_t)w_hl % 128 == 0) && ((uintptr_t)zero_page % 16 == 0) &&
@@ -414,6 +415,8 @@ MRN_EXPORT int mrn_conv2d_x3_hl32(const void* x_hl, const void* w_hl, const void
   p.x_gstride = x_group_stride_bytes; p.w_gstride = (long)Cout * p.nk * 128;
   p.x_bytes = (int)((long)B * H * W * Cin * 4);
   p.G = G; p.M = B * Ho * Wo; p.N = Cout;
+  p.y_ld = y_row_stride > 0 ? y_row_stride : Cout;
+  p.y_gstride = y_group_stride > 0 ? y_group_stride : (long)p.M * p.y_ld;
   p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.kw = kw; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw; p.act = act;
   if (p.M == 0) return MRN_OK;
   // image-row-major tiles pay off when the kernel is padded vertically and the maps are only a few rows high (the TRBA

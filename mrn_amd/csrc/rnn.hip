@@ -76,14 +76,30 @@ __device__ __forceinline__ void lstm_pointwise(const f32x4 (&acc)[4], const floa
 // Bidirectional LSTM layer.  xproj[b][t][dir*4H + gate*H + j] holds W_ih x + b_ih.
 // grid = (ceil(B/16), ndir); out[b][t][dir*H + j].
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NTH) void lstm_layer_kernel(const float* __restrict__ xproj, const float* __restrict__ w_hh,
-                                                         const float* __restrict__ b_hh, float* __restrict__ out,
-                                                         float* __restrict__ gates_out,   // optional [B][T][ndir][4H]
-                                                         float* __restrict__ c_out,       // optional [B][T][ndir][H]
-                                                         int B, int T, int ndir) {
+// Up to MAX_GROUPS independent layers (the frozen experts of the router phase) share one launch: grid.x = groups * tiles.
+constexpr int MAX_GROUPS = 8;
+struct LstmParams {
+  const float* xproj; const float* w_hh; const float* b_hh; float* out;
+  float* gates_out;   // optional [B][T][ndir][4H]
+  float* c_out;       // optional [B][T][ndir][H]
+};
+struct LstmGroup {
+  LstmParams g[MAX_GROUPS];
+  int tiles, B, T, ndir;
+};
+
+__global__ __launch_bounds__(NTH) void lstm_layer_kernel(const LstmGroup grp) {
   __shared__ __attribute__((aligned(16))) float h_lds[2][BT * HLD];
+  const int gi = blockIdx.x / grp.tiles;
+  const float* __restrict__ xproj = grp.g[gi].xproj;
+  const float* __restrict__ w_hh = grp.g[gi].w_hh;
+  const float* __restrict__ b_hh = grp.g[gi].b_hh;
+  float* __restrict__ out = grp.g[gi].out;
+  float* __restrict__ gates_out = grp.g[gi].gates_out;
+  float* __restrict__ c_out = grp.g[gi].c_out;
+  const int B = grp.B, T = grp.T, ndir = grp.ndir;
   const int dir = blockIdx.y;
-  const int b0 = blockIdx.x * BT;
+  const int b0 = (blockIdx.x - gi * grp.tiles) * BT;
   const int t_ = threadIdx.x, lane = t_ & 63, wave = t_ >> 6;
   const float* W = w_hh + (long)dir * 4 * HID * HID;
   const int col = lane & 15, rbase = (lane >> 4) * 4;
@@ -163,8 +179,15 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return 1.f - 2.f / (e + 1.f);
 }
 
-__global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecParams p) {
+struct AttnDecGroup {
+  AttnDecParams g[MAX_GROUPS];
+  int tiles;
+};
+
+__global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecGroup grp) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int gi = blockIdx.x / grp.tiles;
+  const AttnDecParams p = grp.g[gi];
   const int D = p.D, T = p.T;
   const int CLD = D + 4;
   float* h_lds = lds;                      // [BT][HLD]
@@ -173,7 +196,7 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecParams p
   float* e_lds = ctx_lds + BT * CLD;       // [BT][T]
   float* sw_lds = e_lds + BT * T;          // [HID]
 
-  const int b0 = blockIdx.x * BT;
+  const int b0 = (blockIdx.x - gi * grp.tiles) * BT;
   const int t_ = threadIdx.x, lane = t_ & 63, wave = t_ >> 6;
   const int col = lane & 15, rbase = (lane >> 4) * 4;
   const int j = wave * 16 + col;
@@ -361,6 +384,12 @@ __global__ void embed_gather_kernel(const long* __restrict__ idx, const float* _
 
 }  // namespace
 
+static int lstm_launch(const LstmGroup& grp, int groups, hipStream_t st) {
+  hipLaunchKernelGGL(lstm_layer_kernel, dim3(groups * grp.tiles, grp.ndir), dim3(NTH), 0, st, grp);
+  MRN_LAUNCH_CHECK("lstm_layer");
+  return MRN_OK;
+}
+
 MRN_EXPORT int mrn_lstm_layer_fwd_f32(const float* xproj, const float* w_hh, const float* b_hh, float* out,
                                       float* gates_out, float* c_out, int B, int T, int hidden, int ndir, void* stream) {
   MRN_CHECK_ARG(xproj && w_hh && out, "mrn_lstm_layer_fwd_f32: null operand");
@@ -368,9 +397,58 @@ MRN_EXPORT int mrn_lstm_layer_fwd_f32(const float* xproj, const float* w_hh, con
   MRN_CHECK_ARG(ndir == 1 || ndir == 2, "mrn_lstm_layer_fwd_f32: ndir=%d", ndir);
   MRN_CHECK_ARG((gates_out == nullptr) == (c_out == nullptr), "mrn_lstm_layer_fwd_f32: gates_out / c_out must come together");
   if (B == 0 || T == 0) return MRN_OK;
-  hipLaunchKernelGGL(lstm_layer_kernel, dim3(ceil_div(B, BT), ndir), dim3(NTH), 0, (hipStream_t)stream, xproj, w_hh, b_hh,
-                     out, gates_out, c_out, B, T, ndir);
-  MRN_LAUNCH_CHECK("lstm_layer");
+  LstmGroup grp;
+  memset(&grp, 0, sizeof(grp));
+  grp.g[0] = LstmParams{xproj, w_hh, b_hh, out, gates_out, c_out};
+  grp.tiles = ceil_div(B, BT); grp.B = B; grp.T = T; grp.ndir = ndir;
+  return lstm_launch(grp, 1, (hipStream_t)stream);
+}
+
+// `groups` independent layers of identical geometry in one launch.  xproj / w_hh / b_hh / out are HOST arrays of
+// `groups` device pointers (b_hh may be NULL or hold NULL entries).
+MRN_EXPORT int mrn_lstm_layer_fwd_grouped_f32(const void* const* xproj, const void* const* w_hh, const void* const* b_hh,
+                                              const void* const* out, int groups, int B, int T, int hidden, int ndir,
+                                              void* stream) {
+  MRN_CHECK_ARG(xproj && w_hh && out && groups >= 1, "mrn_lstm_layer_fwd_grouped_f32: null operand");
+  MRN_CHECK_ARG(hidden == HID, "mrn_lstm_layer_fwd_grouped_f32: hidden=%d unsupported (library is built for %d)", hidden, HID);
+  MRN_CHECK_ARG(ndir == 1 || ndir == 2, "mrn_lstm_layer_fwd_grouped_f32: ndir=%d", ndir);
+  if (B == 0 || T == 0) return MRN_OK;
+  for (int g0 = 0; g0 < groups; g0 += MAX_GROUPS) {
+    const int n = groups - g0 < MAX_GROUPS ? groups - g0 : MAX_GROUPS;
+    LstmGroup grp;
+    memset(&grp, 0, sizeof(grp));
+    for (int i = 0; i < n; ++i) {
+      MRN_CHECK_ARG(xproj[g0 + i] && w_hh[g0 + i] && out[g0 + i], "mrn_lstm_layer_fwd_grouped_f32: null operand in group %d", g0 + i);
+      grp.g[i] = LstmParams{(const float*)xproj[g0 + i], (const float*)w_hh[g0 + i], b_hh ? (const float*)b_hh[g0 + i] : nullptr,
+                            (float*)out[g0 + i], nullptr, nullptr};
+    }
+    grp.tiles = ceil_div(B, BT); grp.B = B; grp.T = T; grp.ndir = ndir;
+    const int rc = lstm_launch(grp, n, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  return MRN_OK;
+}
+
+static int attn_fill(AttnDecParams& p, const float* Hb, const float* Hproj, const float* eproj, int64_t eproj_stride_b,
+                     int64_t eproj_stride_s, const float* w_h2h, const float* b_h2h, const float* w_score,
+                     const float* w_ih_ctx, const float* w_hh, const float* b_hh, float* hid, int64_t hid_stride_b,
+                     int64_t hid_stride_s, int B, int T, int D, int S) {
+  memset(&p, 0, sizeof(p));
+  p.Hb = Hb; p.Hproj = Hproj; p.eproj = eproj; p.w_h2h = w_h2h; p.b_h2h = b_h2h; p.w_score = w_score;
+  p.w_ih = w_ih_ctx; p.w_hh = w_hh; p.b_hh = b_hh; p.hid = hid;
+  p.B = B; p.T = T; p.D = D; p.S = S;
+  p.eproj_stride_b = eproj_stride_b; p.eproj_stride_s = eproj_stride_s;
+  p.hid_stride_b = hid_stride_b; p.hid_stride_s = hid_stride_s;
+  return MRN_OK;
+}
+
+static int attn_launch(const AttnDecGroup& grp, int groups, int D, int T, hipStream_t st) {
+  const size_t lds = sizeof(float) * (2 * BT * HLD + BT * (D + 4) + BT * T + HID);
+  MRN_CHECK_ARG(lds <= 160 * 1024, "mrn_attn_decoder_fwd: LDS budget exceeded (D=%d T=%d)", D, T);
+  if (lds > 64 * 1024)
+    hipFuncSetAttribute((const void*)attn_decoder_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(attn_decoder_kernel, dim3(groups * grp.tiles), dim3(NTH), lds, st, grp);
+  MRN_LAUNCH_CHECK("attn_decoder");
   return MRN_OK;
 }
 
@@ -385,20 +463,47 @@ MRN_EXPORT int mrn_attn_decoder_fwd_f32(const float* Hb, const float* Hproj, con
   MRN_CHECK_ARG(D % 16 == 0 && D > 0, "mrn_attn_decoder_fwd_f32: D=%d must be a multiple of 16", D);
   MRN_CHECK_ARG((h_state == nullptr) == (c_state == nullptr), "mrn_attn_decoder_fwd_f32: h_state/c_state must come together");
   if (B == 0 || S == 0) return MRN_OK;
-  AttnDecParams p;
-  p.Hb = Hb; p.Hproj = Hproj; p.eproj = eproj; p.w_h2h = w_h2h; p.b_h2h = b_h2h; p.w_score = w_score;
-  p.w_ih = w_ih_ctx; p.w_hh = w_hh; p.b_hh = b_hh; p.hid = hid; p.h_state = h_state; p.c_state = c_state;
-  p.alpha_out = alpha_out; p.gates_out = gates_out; p.c_out = c_out; p.ctx_out = ctx_out; p.hp_out = hp_out;
   MRN_CHECK_ARG(!gates_out || (c_out && ctx_out && hp_out && alpha_out), "mrn_attn_decoder_fwd_f32: training saves must all be given");
-  p.B = B; p.T = T; p.D = D; p.S = S;
-  p.eproj_stride_b = eproj_stride_b; p.eproj_stride_s = eproj_stride_s;
-  p.hid_stride_b = hid_stride_b; p.hid_stride_s = hid_stride_s;
-  const size_t lds = sizeof(float) * (2 * BT * HLD + BT * (D + 4) + BT * T + HID);
-  MRN_CHECK_ARG(lds <= 160 * 1024, "mrn_attn_decoder_fwd_f32: LDS budget exceeded (D=%d T=%d)", D, T);
-  if (lds > 64 * 1024)
-    hipFuncSetAttribute((const void*)attn_decoder_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(attn_decoder_kernel, dim3(ceil_div(B, BT)), dim3(NTH), lds, (hipStream_t)stream, p);
-  MRN_LAUNCH_CHECK("attn_decoder");
+  AttnDecGroup grp;
+  memset(&grp, 0, sizeof(grp));
+  AttnDecParams& p = grp.g[0];
+  attn_fill(p, Hb, Hproj, eproj, eproj_stride_b, eproj_stride_s, w_h2h, b_h2h, w_score, w_ih_ctx, w_hh, b_hh, hid, hid_stride_b,
+            hid_stride_s, B, T, D, S);
+  p.h_state = h_state; p.c_state = c_state;
+  p.alpha_out = alpha_out; p.gates_out = gates_out; p.c_out = c_out; p.ctx_out = ctx_out; p.hp_out = hp_out;
+  grp.tiles = ceil_div(B, BT);
+  return attn_launch(grp, 1, D, T, (hipStream_t)stream);
+}
+
+// Teacher-forced decoders of `groups` experts (identical geometry) in one launch.  Every pointer argument is a HOST
+// array of `groups` device pointers; strides are shared.  No carried state / training saves.
+MRN_EXPORT int mrn_attn_decoder_fwd_grouped_f32(const void* const* Hb, const void* const* Hproj, const void* const* eproj,
+                                                int64_t eproj_stride_b, int64_t eproj_stride_s, const void* const* w_h2h,
+                                                const void* const* b_h2h, const void* const* w_score,
+                                                const void* const* w_ih_ctx, const void* const* w_hh, const void* const* b_hh,
+                                                const void* const* hid, int64_t hid_stride_b, int64_t hid_stride_s, int groups,
+                                                int B, int T, int D, int S, int hidden, void* stream) {
+  MRN_CHECK_ARG(Hb && Hproj && eproj && w_h2h && b_h2h && w_score && w_ih_ctx && w_hh && hid && groups >= 1,
+                "mrn_attn_decoder_fwd_grouped_f32: null operand");
+  MRN_CHECK_ARG(hidden == HID, "mrn_attn_decoder_fwd_grouped_f32: hidden=%d unsupported (library is built for %d)", hidden, HID);
+  MRN_CHECK_ARG(D % 16 == 0 && D > 0, "mrn_attn_decoder_fwd_grouped_f32: D=%d must be a multiple of 16", D);
+  if (B == 0 || S == 0) return MRN_OK;
+  for (int g0 = 0; g0 < groups; g0 += MAX_GROUPS) {
+    const int n = groups - g0 < MAX_GROUPS ? groups - g0 : MAX_GROUPS;
+    AttnDecGroup grp;
+    memset(&grp, 0, sizeof(grp));
+    for (int i = 0; i < n; ++i) {
+      const int g = g0 + i;
+      MRN_CHECK_ARG(Hb[g] && Hproj[g] && eproj[g] && w_h2h[g] && b_h2h[g] && w_score[g] && w_ih_ctx[g] && w_hh[g] && hid[g],
+                    "mrn_attn_decoder_fwd_grouped_f32: null operand in group %d", g);
+      attn_fill(grp.g[i], (const float*)Hb[g], (const float*)Hproj[g], (const float*)eproj[g], eproj_stride_b, eproj_stride_s,
+                (const float*)w_h2h[g], (const float*)b_h2h[g], (const float*)w_score[g], (const float*)w_ih_ctx[g],
+                (const float*)w_hh[g], b_hh ? (const float*)b_hh[g] : nullptr, (float*)hid[g], hid_stride_b, hid_stride_s, B, T, D, S);
+    }
+    grp.tiles = ceil_div(B, BT);
+    const int rc = attn_launch(grp, n, D, T, (hipStream_t)stream);
+    if (rc) return rc;
+  }
   return MRN_OK;
 }
 

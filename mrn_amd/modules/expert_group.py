@@ -147,7 +147,7 @@ class BackboneGroup:
         return self.layer(out, [b.conv2 for b in blocks], [b.bn2 for b in blocks], relu=True, residual=res,
                           want_f32=next_needs_f32, want_hl=True)
 
-    def _resnet(self, x):
+    def _resnet(self, x, last_hl=False):
         nets = [e.FeatureExtraction.ConvNet for e in self.experts]
         n0 = nets[0]
         p22, p2_21 = ((2, 2), (2, 2), (0, 0)), ((2, 2), (2, 1), (0, 1))
@@ -174,15 +174,15 @@ class BackboneGroup:
         x = self.layer(x, [n.conv3 for n in nets], [n.bn3 for n in nets], want_f32=first_block_identity("layer4"))
         x = stage(x, "layer4")
         x = self.layer(x, [n.conv4_1 for n in nets], [n.bn4_1 for n in nets])
-        return self.layer(x, [n.conv4_2 for n in nets], [n.bn4_2 for n in nets], want_f32=True, want_hl=False)
+        return self.layer(x, [n.conv4_2 for n in nets], [n.bn4_2 for n in nets], want_f32=not last_hl, want_hl=last_hl)
 
-    def _vgg(self, x):
+    def _vgg(self, x, last_hl=False):
         nets = [e.FeatureExtraction.ConvNet for e in self.experts]
         p22, p21 = ((2, 2), (2, 2), (0, 0)), ((2, 1), (2, 1), (0, 0))
 
         def L(x, i, bn=None, pool=None, last=False):
             return self.layer(x, [n[i] for n in nets], None if bn is None else [n[bn] for n in nets], pool=pool,
-                              want_f32=last, want_hl=not last)
+                              want_f32=last and not last_hl, want_hl=not last or last_hl)
         x = L(x, 0, pool=p22)
         x = L(x, 3, pool=p22)
         x = L(x, 6)
@@ -213,9 +213,10 @@ class BackboneGroup:
             ops.tps_grid_sample(image, cprime, gg.inv_delta_C, gg.P_hat, t.I_r_size, out=out[g])
         return Act(tuple(out.shape), out, None)
 
-    def visual_all(self, image):
+    def visual_all(self, image, as_act=False):
         """image: logical [B,C,H,W] -> backbone features [G,B,T,C'] (the reference's permute + AdaptiveAvgPool + squeeze
-        is the identity on the height-1 NHWC map)"""
+        is the identity on the height-1 NHWC map).  as_act: return the [G,B,1,T,C'] Act holding only the HL32 operand
+        (what HeadsGroup's first grouped Linear consumes)."""
         img = to_nhwc(image)
         B, H, W, C = img.shape
         self._nbt = []
@@ -223,10 +224,111 @@ class BackboneGroup:
             x = self._tps(img)
         else:
             x = Act((self.G, B, H, W, C), img, None, shared=True)
-        x = self._resnet(x) if self.experts[0].stages["Feat"] == "ResNet" else self._vgg(x)
+        x = self._resnet(x, as_act) if self.experts[0].stages["Feat"] == "ResNet" else self._vgg(x, as_act)
         if self._nbt:
             torch._foreach_add_(self._nbt, 1)
         G, B, Ho, Wo, Cf = x.shape
         if Ho != 1:
             raise NotImplementedError("HIP path expects a height-1 feature map (32x256 inputs); got H=%d" % Ho)
-        return x.f32.view(G, B, Wo, Cf)
+        return x if as_act else x.f32.view(G, B, Wo, Cf)
+
+
+class HeadsGroup:
+    """SequenceModeling + Prediction of G frozen experts in lock-step (BiLSTM x 2 + CTC Linear / teacher-forced attention
+    decoder): every Linear is a grouped split-fp16 x3 GEMM (csrc/conv_x3.hip with a 1x1 kernel), every recurrence ONE
+    launch for all experts (mrn_lstm_layer_fwd_grouped_f32 / mrn_attn_decoder_fwd_grouped_f32).  Replaces six concurrent
+    streams of 16-32-workgroup launches whose overlap was left to the hardware queues."""
+
+    def __init__(self, experts):
+        self.experts = list(experts)        # Model modules
+        self.G = len(self.experts)
+        self._cache = {}
+
+    @staticmethod
+    def supported(experts, is_train):
+        e0 = experts[0]
+        if len(experts) < 2 or e0.model.stages["Seq"] != "BiLSTM":
+            return False
+        if any(e.model.stages != e0.model.stages or e.stages != e0.stages for e in experts):
+            return False
+        if e0.stages["Pred"] == "Attn" and not is_train:       # greedy decoding feeds argmax back step by step: per expert
+            return False
+        return ops.CONV_PRECISION in ("auto", "fp16x3") and ops.AUTO_SPLIT_KIND == "fp16x3"
+
+    def _cached(self, name, params, build):
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        got = self._cache.get(name)
+        if got is None or got[0] != key:
+            with torch.no_grad():
+                got = (key, build())
+            self._cache[name] = got
+        return got[1]
+
+    def _linear(self, name, x_hl, rows, K, weights, biases, out=None, out_row_stride=0, out_group_stride=0, groups=None,
+                act=ops.ACT_NONE):
+        """grouped y[g] = x[g] @ W[g]^T + b[g]; weights: list of [N,K] tensors (any stride), biases: list or None"""
+        G = len(weights)
+        N = weights[0].shape[0]
+        params = list(weights) + ([b for b in biases] if biases is not None else [])
+
+        def build():
+            w_hl, scale = ops.pack_weights_hl32([w.detach().contiguous().view(N, 1, 1, K) for w in weights])
+            bias = torch.stack([b.detach() for b in biases]).contiguous() if biases is not None else None
+            return w_hl, scale, bias
+        w_hl, scale, bias = self._cached(name, params, build)
+        y, _ = ops.conv2d_x3(x_hl, G, False, rows, 1, 1, K, w_hl, scale, N, (1, 1), bias=bias, act=act, out=out,
+                             out_row_stride=out_row_stride, out_group_stride=out_group_stride)
+        return y
+
+    def _bilstm(self, idx, x_hl, rows_shape, K):
+        """BidirectionalLSTM number idx of every expert: x [G, B*T, K] (HL32) -> [G,B,T,256] fp32"""
+        G = self.G
+        B, T = rows_shape
+        mods = [e.model.SequenceModeling[idx] for e in self.experts]
+        H = mods[0].hidden_size
+        packed = [m._packed() for m in mods]                     # (w_ih [2*4H,in], w_hh frag-major [2,...], b_ih, b_hh)
+        xproj = self._linear("ih%d" % idx, x_hl, B * T, K, [p[0] for p in packed], [p[2] for p in packed])
+        w_hh = self._cached("hh%d" % idx, [p[1] for p in packed], lambda: torch.stack([p[1] for p in packed]).contiguous())
+        b_hh = self._cached("bhh%d" % idx, [p[3] for p in packed], lambda: torch.stack([p[3] for p in packed]).contiguous())
+        rec = ops.lstm_layer_grouped(xproj.view(G, B, T, 2 * 4 * H), w_hh, b_hh, H, 2)
+        return self._linear("lin%d" % idx, ops.split_hl32(rec), B * T, 2 * H, [m.linear.weight for m in mods],
+                            [m.linear.bias for m in mods]).view(G, B, T, -1)
+
+    def run(self, visual, text, feats_out, logits_out):
+        """visual: Act with the backbone features [G,B,1,T,C'] (HL32 and / or fp32); feats_out [B,T,G,hidden] (router
+        layout, expert g -> slice [:, :, g, :]); logits_out: list of G [B,T_pred,C_g] views with padded rows."""
+        G = self.G
+        _, B, _, T, Cf = visual.shape
+        x_hl = visual.hl if visual.hl is not None else ops.split_hl32(visual.f32)
+        y1 = self._bilstm(0, x_hl, (B, T), Cf)
+        feat = self._bilstm(1, ops.split_hl32(y1), (B, T), y1.shape[-1])          # [G,B,T,hidden]
+        feats_out.copy_(feat.permute(1, 2, 0, 3))
+        hidden = feat.shape[-1]
+        feat_hl = ops.split_hl32(feat)
+        heads = [e.Prediction for e in self.experts]
+        if self.experts[0].stages["Pred"] == "CTC":
+            src_hl, rows, K = feat_hl, B * T, hidden
+            gens = heads
+        else:
+            S = self.experts[0].opt.batch_max_length + 1
+            cells = [h.attention_cell for h in heads]
+            D = cells[0].input_size
+            Hproj = self._linear("i2h", feat_hl, B * T, hidden, [c.i2h.weight for c in cells], None).view(G, B, T, -1)
+            E = heads[0].num_char_embeddings
+            emb = torch.empty(G, B, S, E, device=feat.device, dtype=torch.float32)
+            for g, h in enumerate(heads):
+                ops.embed_gather(text[:, :S], h.char_embeddings.weight, h.num_class, out=emb[g])
+            eproj = self._linear("emb", ops.split_hl32(emb), B * S, E, [c.rnn.weight_ih[:, D:] for c in cells],
+                                 [c.rnn.bias_ih for c in cells]).view(G, B, S, -1)
+            packed = [h._packed() for h in heads]                 # fragment-major (w_h2h, w_ih[:, :D], w_hh)
+            hid = ops.attn_decoder_grouped(feat, Hproj, eproj, [p[0] for p in packed], [c.h2h.bias for c in cells],
+                                           [c.score.weight for c in cells], [p[1] for p in packed], [p[2] for p in packed],
+                                           [c.rnn.bias_hh for c in cells], cells[0].hidden_size)
+            src_hl, rows, K = ops.split_hl32(hid), B * S, hid.shape[-1]
+            gens = [h.generator for h in heads]
+        per = rows * K * 4                                         # HL32 bytes of one expert's generator input
+        for g, gen in enumerate(gens):
+            out = logits_out[g]
+            assert out.stride(2) == 1 and out.stride(0) == out.shape[1] * out.stride(1)
+            self._linear("gen%d" % g, src_hl[g * per:(g + 1) * per], rows, K, [gen.weight], [gen.bias], out=out,
+                         out_row_stride=out.stride(1))

@@ -259,6 +259,7 @@ class MRNNet(nn.Module):
         self.expert_grouping = True         # run the frozen experts' conv backbones in lock-step (modules/expert_group.py)
         self._stream_pool = []
         self._group = None
+        self._heads = None
 
     def _streams(self, n, device):
         while len(self._stream_pool) < n:
@@ -275,6 +276,15 @@ class MRNNet(nn.Module):
         if self._group is None or self._group[0] != key:
             self._group = (key, expert_group.BackboneGroup(extractors))
         return self._group[1] if expert_group.supported(extractors) else None
+
+    def _heads_group(self, group, is_train):
+        """HeadsGroup (SequenceModeling + Prediction of all experts in lock-step) when `group` exists and the heads allow it"""
+        from .expert_group import HeadsGroup
+        if group is None or not HeadsGroup.supported(list(self.model), is_train):
+            return None
+        if self._heads is None or self._heads[0] is not group:
+            self._heads = (group, HeadsGroup(list(self.model)))
+        return self._heads[1]
 
     @property
     def feature_dim(self):
@@ -299,13 +309,17 @@ class MRNNet(nn.Module):
         feats = torch.empty(B, self.patch, I, self.out_dim, device=dev, dtype=torch.float32)
         logits = [ops.padded_rows(B, T_pred, expert.fc.out_features, dev) for expert in self.model]
         with torch.no_grad():
-            if self.expert_streams and I > 1:
-                # Phase 1, one stream: the conv backbones -- every kernel fills the chip, nothing to gain from overlap.
+            group = self._backbone_group() if I > 1 else None
+            heads = self._heads_group(group, is_train)
+            if heads is not None:
+                # backbones AND heads in lock-step: one grouped launch per conv layer / Linear / recurrence, one stream
+                heads.run(group.visual_all(image, as_act=True), text, feats, logits)
+            elif self.expert_streams and I > 1:
+                # Phase 1, one stream: the conv backbones (grouped when the experts allow it, else one after the other).
                 # Phase 2, one HIP stream per expert: BiLSTM / attention decoder are latency-bound launches of 16-32
-                # workgroups each; the six experts' recurrences run side by side instead of idling 90 % of the CUs.
-                group = self._backbone_group()
+                # workgroups each; the experts' recurrences run side by side instead of idling 90 % of the CUs.
                 if group is not None:
-                    stack = group.visual_all(image)                      # [I,B,T,C'], one grouped launch per layer
+                    stack = group.visual_all(image)                      # [I,B,T,C']
                     visuals = [stack[i] for i in range(I)]
                 else:
                     visuals = [expert.model.visual(image) for expert in self.model]
@@ -369,11 +383,13 @@ class MRNNet(nn.Module):
     def copy(self):
         pool, self._stream_pool = self._stream_pool, []      # streams / packed-weight caches are not copied
         group, self._group = self._group, None
+        heads, self._heads = self._heads, None
         try:
             return copy.deepcopy(self)
         finally:
             self._stream_pool = pool
             self._group = group
+            self._heads = heads
 
     def freeze(self):
         for p in self.parameters():

@@ -286,8 +286,9 @@ def pack_weights_hl32(ws):
 
 
 def conv2d_x3(x_hl, G, shared_input, B, H, W, Cin, w_hl, w_scale, Cout, ksize, stride=(1, 1), padding=(0, 0), bias=None,
-              act=ACT_NONE, want_stats=False, out=None):
-    """Grouped conv on HL32 operands -> (y [G,B,Ho,Wo,Cout] fp32, stats or None)."""
+              act=ACT_NONE, want_stats=False, out=None, out_row_stride=0, out_group_stride=0):
+    """Grouped conv on HL32 operands -> (y [G,B,Ho,Wo,Cout] fp32, stats or None).  With `out` and the two strides (floats)
+    the rows of group g land at out.data_ptr + g * out_group_stride + row * out_row_stride."""
     kh, kw = ksize
     Ho, Wo = conv_out_hw(H, W, ksize, stride, padding)
     dev = x_hl.device
@@ -297,10 +298,11 @@ def conv2d_x3(x_hl, G, shared_input, B, H, W, Cin, w_hl, w_scale, Cout, ksize, s
         stats = torch.empty(call("mrn_conv2d_x3_stats_floats", G, B, Ho, Wo, Cout, X3_TILE_M), device=dev, dtype=torch.float32)
     gstride = 0 if shared_input else B * H * W * Cin * 4
     tile_n = 256 if Cout >= 256 else 128
-    timed = CONV_TIMER is not None
+    timed = CONV_TIMER is not None and kh * kw > 1          # (the 1x1 calls are the heads' Linear layers)
     t0 = CONV_TIMER.begin() if timed else None
     call("mrn_conv2d_x3_hl32", _p(x_hl), _p(w_hl), _p(_zero_page(dev)), _p(bias), _p(y), _p(stats), _p(w_scale), G, gstride,
-         B, H, W, Cin, Cout, kh, kw, stride[0], stride[1], padding[0], padding[1], act, tile_n, _stream())
+         B, H, W, Cin, Cout, kh, kw, stride[0], stride[1], padding[0], padding[1], act, tile_n, out_row_stride, out_group_stride,
+         _stream())
     if timed:
         CONV_TIMER.end(t0, 2.0 * G * B * Ho * Wo * Cout * kh * kw * Cin, "fp16x3/x3g%d" % tile_n)
     return y, stats
@@ -426,6 +428,39 @@ def lstm_layer(xproj, w_hh, b_hh, hidden, ndir, save=False):
     return (out, gates, cseq) if save else out
 
 
+def _ptr_array(ptrs):
+    import ctypes
+    return (ctypes.c_void_p * len(ptrs))(*ptrs)
+
+
+def lstm_layer_grouped(xproj, w_hh, b_hh, hidden, ndir):
+    """xproj [G,B,T,ndir*4H], w_hh [G,ndir,...] (fragment-major stacks), b_hh [G,ndir*4H] -> [G,B,T,ndir*H], one launch"""
+    _chk(xproj, w_hh, b_hh)
+    G, B, T, _ = xproj.shape
+    assert xproj.is_contiguous() and w_hh.is_contiguous() and b_hh.is_contiguous()
+    out = torch.empty(G, B, T, ndir * hidden, device=xproj.device, dtype=torch.float32)
+    call("mrn_lstm_layer_fwd_grouped_f32", _ptr_array([xproj[g].data_ptr() for g in range(G)]),
+         _ptr_array([w_hh[g].data_ptr() for g in range(G)]), _ptr_array([b_hh[g].data_ptr() for g in range(G)]),
+         _ptr_array([out[g].data_ptr() for g in range(G)]), G, B, T, hidden, ndir, _stream())
+    return out
+
+
+def attn_decoder_grouped(Hb, Hproj, eproj, w_h2h, b_h2h, w_score, w_ih, w_hh, b_hh, hidden):
+    """Hb [G,B,T,D], Hproj [G,B,T,H], eproj [G,B,S,4H]; the weight arguments are lists of G tensors -> hid [G,B,S,H]"""
+    _chk(Hb, Hproj, eproj)
+    G, B, T, D = Hb.shape
+    S = eproj.shape[2]
+    assert Hb.is_contiguous() and Hproj.is_contiguous() and eproj.is_contiguous()
+    hid = torch.empty(G, B, S, hidden, device=Hb.device, dtype=torch.float32)
+
+    def arr(ts):
+        return _ptr_array([t.data_ptr() for t in ts])
+    call("mrn_attn_decoder_fwd_grouped_f32", arr(Hb), arr(Hproj), arr(eproj), eproj.stride(1), eproj.stride(2), arr(w_h2h),
+         arr(b_h2h), arr(w_score), arr(w_ih), arr(w_hh), arr(b_hh), arr(hid), hid.stride(1), hid.stride(2), G, B, T, D, S,
+         hidden, _stream())
+    return hid
+
+
 def lstm_layer_bwd(dout, gates, cseq, w_hhT, hidden, ndir):
     """-> dgates [B,T,ndir,4H] (gradient of the gate pre-activations); w_hhT: ndir stacked pack_fragment_major(W_hh.t())"""
     B, T, _ = dout.shape
@@ -435,12 +470,14 @@ def lstm_layer_bwd(dout, gates, cseq, w_hhT, hidden, ndir):
     return dgates
 
 
-def embed_gather(idx, table, num_class):
+def embed_gather(idx, table, num_class, out=None):
     """idx [B,S] int64 (any row stride), table [C,E] -> [B,S,E] with cut_unknown semantics"""
     assert idx.dtype == torch.int64 and idx.stride(1) == 1
     B, S = idx.shape
     E = table.shape[1]
-    out = torch.empty(B, S, E, device=table.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty(B, S, E, device=table.device, dtype=torch.float32)
+    assert out.is_contiguous() and out.numel() == B * S * E
     call("mrn_embed_gather_f32", _p(idx), idx.stride(0), _p(table), _p(out), B, S, E, num_class, _stream())
     return out
 

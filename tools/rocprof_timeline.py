@@ -40,6 +40,16 @@ def main():
           f"lstm {first_start(lambda n: 'lstm_layer' in n):.2f}..{last_end(lambda n: 'lstm_layer' in n):.2f} ms; "
           f"attn decoder ..{last_end(lambda n: 'attn_decoder' in n):.2f} ms; router from {first_start(lambda n: 'layernorm_fwd' in n):.2f} ms; "
           f"step end {span:.2f} ms")
+    t_heads = max([e for n, s_, e, st in rows if "attn_decoder" in n] or [t0])
+    tail = {}
+    for n, s_, e, st in rows:
+        if s_ >= t_heads:
+            d = tail.setdefault(n[:80], [0, 0])
+            d[0] += 1
+            d[1] += e - s_
+    print("after the last attention decoder (router fwd/bwd, losses, optimiser):")
+    for n, v in sorted(tail.items(), key=lambda kv: -kv[1][1])[:14]:
+        print(f"  {v[1] / 1e3:8.1f} us  x{v[0]:<3d} {n}")
     streams = {}
     for n, s, e, st in rows:
         d = streams.setdefault(st, [0, 0])
