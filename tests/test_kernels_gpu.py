@@ -346,3 +346,91 @@ def test_tps_backward_fiducial_gradient(ops):
     a, b = d.cpu().double().numpy(), cp.grad.double().numpy()
     rel = np.linalg.norm(a - b) / np.linalg.norm(b)
     assert rel < 3e-3, f"d C' relative L2 error {rel:.3e}"
+
+
+# ---------------------------------------------------------------------------------------------------------
+# grouped kernels of the lock-step expert path (conv_x3.hip, group_ops.hip, grouped recurrences)
+# ---------------------------------------------------------------------------------------------------------
+X3_CONVS = [
+    # G, B, H, W, Cin, Cout, k, s, p, shared input
+    (3, 5, 4, 65, 64, 128, (3, 3), (1, 1), (1, 1), False),      # image-row-major tiles + padded-tap skipping, ragged tiles
+    (2, 3, 8, 17, 32, 64, (3, 3), (1, 1), (1, 1), True),        # one input for all groups
+    (2, 7, 1, 1, 64, 96, (1, 1), (1, 1), (0, 0), False),        # a grouped Linear layer
+    (2, 2, 4, 66, 64, 256, (2, 2), (2, 1), (0, 1), False),      # ResNet conv4_1 geometry
+    (1, 3, 6, 10, 96, 320, (3, 3), (2, 2), (1, 1), False),      # strides, N not a tile multiple
+    (6, 2, 4, 65, 512, 512, (3, 3), (1, 1), (1, 1), False),     # the dominant TRBA shape
+]
+
+
+@pytest.mark.parametrize("cfg", X3_CONVS)
+def test_grouped_x3_conv_bn_pool(ops, cfg):
+    """mrn_conv2d_x3_hl32 + mrn_bn_finalize_grouped_f32 + mrn_bn_apply_grouped_f32 + mrn_maxpool_grouped_f32 against
+    torch fp32 conv2d / batch_norm / max_pool2d per group"""
+    G, B, H, W, Cin, Cout, k, s, p, shared = cfg
+    xs = [rnd(B, Cin, H, W, seed=100 + g) for g in range(1 if shared else G)]
+    ws = [rnd(Cout, Cin, *k, seed=110 + g, scale=(2.0 / (Cin * k[0] * k[1])) ** 0.5) for g in range(G)]
+    bias = rnd(G, Cout, seed=120)
+    refs = [F.conv2d(xs[0 if shared else g], ws[g], bias[g], s, p) for g in range(G)]
+    xn = torch.stack([x.permute(0, 2, 3, 1) for x in xs]).contiguous()
+    x_hl = ops.split_hl32(cu(xn))
+    w_hl, w_scale = ops.pack_weights_hl32([cu(w.permute(0, 2, 3, 1).contiguous()) for w in ws])
+    y, stats = ops.conv2d_x3(x_hl, G, shared, B, H, W, Cin, w_hl, w_scale, Cout, k, s, p, bias=cu(bias), want_stats=True)
+    Ho, Wo = refs[0].shape[2:]
+    for g in range(G):
+        assert_close(f"x3 conv g{g}", y[g].permute(0, 3, 1, 2), refs[g], atol=2e-5, rtol=1e-5)
+    # strided destination (one expert's slice of a wider buffer)
+    wide = torch.zeros(B * Ho * Wo, G, Cout + 4, device="cuda")
+    ops.conv2d_x3(x_hl, G, shared, B, H, W, Cin, w_hl, w_scale, Cout, k, s, p, bias=cu(bias), act=1, out=wide,
+                  out_row_stride=G * (Cout + 4), out_group_stride=Cout + 4)
+    for g in range(G):
+        assert_close(f"x3 conv strided g{g}", wide[:, g, :Cout], F.relu(refs[g]).permute(0, 2, 3, 1).reshape(-1, Cout), atol=2e-5, rtol=1e-5)
+    assert float(wide[:, :, Cout:].abs().max()) == 0.0
+    # BatchNorm (training) for all groups at once
+    gamma, beta = rnd(G, Cout, seed=121) + 1.5, rnd(G, Cout, seed=122)
+    rm, rv = rnd(G, Cout, seed=123) * 0.1, rnd(G, Cout, seed=124) * 0.2 + 1.0
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    res = rnd(G, *refs[0].shape, seed=125)
+    bn_ref = [F.relu(F.batch_norm(refs[g], rm_ref[g], rv_ref[g], gamma[g], beta[g], True, 0.1, 1e-5) + res[g]) for g in range(G)]
+    gd, bd, rmd, rvd = cu(gamma), cu(beta), cu(rm), cu(rv)
+    table = torch.tensor([[t[g].data_ptr() for g in range(G)] for t in (gd, bd, rmd, rvd)], dtype=torch.int64, device="cuda")
+    scale, shift = ops.bn_finalize_grouped(stats, G, Cout, B * Ho * Wo, table, 0.1, 1e-5)
+    assert_close("grouped running_mean", rmd, rm_ref, atol=1e-6, rtol=1e-5)
+    assert_close("grouped running_var", rvd, rv_ref, atol=1e-6, rtol=1e-5)
+    resn = cu(res.permute(0, 1, 3, 4, 2).contiguous())
+    want_hl = Cout % 32 == 0
+    f32, hl = ops.bn_apply_grouped(y.clone(), scale, shift, relu=True, residual=resn, want_f32=True, want_hl=want_hl)
+    for g in range(G):
+        assert_close(f"grouped bn apply g{g}", f32[g].permute(0, 3, 1, 2), bn_ref[g], atol=5e-5, rtol=1e-5)
+    if want_hl:
+        # the HL32 operand is hi + lo of the same values, laid out [row][C/32][hi x 32 | lo x 32]
+        v = hl.view(torch.float16).view(-1, Cout // 32, 2, 32).float()
+        assert_close("HL32 image", (v[:, :, 0] + v[:, :, 1]).reshape(f32.shape), f32, atol=1e-6, rtol=2e-7)
+    if Ho >= 2 and Wo >= 2:
+        pf, _, _ = ops.maxpool_grouped(y, (2, 2), (2, 1), (0, 1), scale, shift, relu=True, want_f32=True)
+        for g in range(G):
+            ref = F.max_pool2d(F.relu(F.batch_norm(refs[g], None, None, gamma[g], beta[g], True, 0.0, 1e-5)), (2, 2), (2, 1), (0, 1))
+            assert_close(f"grouped bn+relu+maxpool g{g}", pf[g].permute(0, 3, 1, 2), ref, atol=5e-5, rtol=1e-5)
+
+
+def test_grouped_recurrences_match_single_launches(ops):
+    """mrn_lstm_layer_fwd_grouped_f32 / mrn_attn_decoder_fwd_grouped_f32: bit-identical to one launch per expert"""
+    G, B, T, Hd, S = 3, 19, 13, 256, 7
+    xproj = cu(rnd(G, B, T, 8 * Hd, seed=130, scale=0.5))
+    w_hh = torch.stack([torch.stack([ops.pack_fragment_major(cu(rnd(4 * Hd, Hd, seed=131 + 2 * g + d, scale=1 / 16.0)))
+                                     for d in range(2)]) for g in range(G)]).contiguous()
+    b_hh = cu(rnd(G, 8 * Hd, seed=140, scale=1 / 16.0))
+    out = ops.lstm_layer_grouped(xproj, w_hh, b_hh, Hd, 2)
+    for g in range(G):
+        assert torch.equal(out[g], ops.lstm_layer(xproj[g], w_hh[g], b_hh[g], Hd, 2))
+    D = 256
+    Hb, Hproj = cu(rnd(G, B, T, D, seed=141)), cu(rnd(G, B, T, Hd, seed=142))
+    eproj = cu(rnd(G, B, S, 4 * Hd, seed=143, scale=0.5))
+    mk = lambda shape, seed: [cu(rnd(*shape, seed=seed + g, scale=1 / 16.0)) for g in range(G)]
+    w_h2h = [ops.pack_fragment_major(w) for w in mk((Hd, Hd), 150)]
+    w_ih = [ops.pack_fragment_major(w) for w in mk((4 * Hd, D), 160)]
+    w_hh2 = [ops.pack_fragment_major(w) for w in mk((4 * Hd, Hd), 170)]
+    b_h2h, w_score, b_hh2 = mk((Hd,), 180), mk((1, Hd), 190), mk((4 * Hd,), 200)
+    hid = ops.attn_decoder_grouped(Hb, Hproj, eproj, w_h2h, b_h2h, w_score, w_ih, w_hh2, b_hh2, Hd)
+    for g in range(G):
+        ref = ops.attn_decoder(Hb[g], Hproj[g], eproj[g], w_h2h[g], b_h2h[g], w_score[g], w_ih[g], w_hh2[g], b_hh2[g], Hd)
+        assert torch.equal(hid[g], ref)
