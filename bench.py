@@ -30,6 +30,20 @@ FP32_MFMA_PEAK_TFLOPS = 157.3                          # MI355X_MICROARCH.md: v_
 BF16_MFMA_PEAK_TFLOPS = 2500.0                         # MI355X_MICROARCH.md: dense bf16 MFMA peak
 
 
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes (profiles/r01_pmc.json, produced by
+    tools/pmc_pass.sh on this same command): FETCH_SIZE x 2 (the gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE,
+    both KiB counters.  None when the kernel has no entry (counters cannot be read from inside the timed run)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        pmc = json.load(f)
+    key = kernel_name.split(" (")[0]
+    ent = pmc.get("kernels", {}).get(key)
+    return None if ent is None else ent["hbm_bytes_per_launch"]
+
+
 def make_opt(model, batch):
     o = types.SimpleNamespace(
         exp_name="bench", il="mrn", memory="random", memory_num=2000, batch_max_length=25, imgH=32, imgW=256,
@@ -190,9 +204,10 @@ def main():
                             FP32_MFMA_PEAK_TFLOPS, 1)
                 arith, staging = kind.split("/")
                 if staging.startswith("x3g"):
-                    tn = staging[3:]
-                    return (f"conv_x3_kernel<256x{tn}> (grouped 256x{tn}x32 implicit-GEMM conv over all experts, fp16x3 on "
-                            f"v_mfma_f32_32x32x16_f16, HL32 operands staged by buffer_load...lds)", BF16_MFMA_PEAK_TFLOPS, 3)
+                    tile = staging[3:]
+                    targs = {"256x256": "2, 4, 4, 2", "256x128": "4, 2, 2, 2", "128x128": "4, 2, 1, 2"}[tile]
+                    return (f"conv_x3_kernel<{targs}> (grouped {tile}x32 implicit-GEMM conv / Linear over all experts, fp16x3 "
+                            f"on v_mfma_f32_32x32x16_f16, HL32 operands staged by buffer_load...lds)", BF16_MFMA_PEAK_TFLOPS, 3)
                 nsplit = 3 if arith.endswith("x3") else 1
                 kern = "conv_bf16_dma_kernel" if staging == "dma" else "conv_bf16_kernel"
                 half = "true" if arith.startswith("fp16") else "false"
@@ -207,7 +222,8 @@ def main():
                 ach = per_launch / (avg_ms * 1e-3) / 1e12
                 kname, peak, per_flop = describe(kind)
                 rl.append({"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                           "traffic": None, "kernel": kname, "mfma_flops_per_algorithmic_flop": per_flop,
+                           "traffic": pmc_traffic(kname), "algorithmic_bytes_per_launch": s_.get("total_bytes", 0.0) / s_["launches"],
+                           "kernel": kname, "mfma_flops_per_algorithmic_flop": per_flop,
                            "mfma_issue_frac": ach * per_flop / peak,
                            "launches_per_step": s_["launches"] / args.steps, "avg_launch_ms": avg_ms,
                            "algorithmic_gflop_per_launch": per_launch / 1e9,

@@ -306,6 +306,7 @@ __global__ __launch_bounds__(512) void conv_x3_kernel(const ConvX3Params p) {
 
 template __global__ void conv_x3_kernel<2, 4, 4, 2>(const ConvX3Params);
 template __global__ void conv_x3_kernel<4, 2, 2, 2>(const ConvX3Params);
+template __global__ void conv_x3_kernel<4, 2, 1, 2>(const ConvX3Params);
 
 // ---- producers of the HL32 layout -------------------------------------------------------------------------------
 __device__ __forceinline__ void split_h(float v, _Float16& h, _Float16& l) {
@@ -393,16 +394,17 @@ MRN_EXPORT int64_t mrn_conv2d_x3_stats_floats(int G, int B, int Ho, int Wo, int 
   return (int64_t)G * ceil_div((long)B * Ho * Wo, tile_m) * 2 * Cout;
 }
 
-// tile_m x tile_n: 256x256 (default for Cout >= 256) or 256x128
+// tile_m x tile_n: 256x256 (Cout >= 256), 256x128, or 128x128 (two workgroups per CU: short reductions)
 MRN_EXPORT int mrn_conv2d_x3_hl32(const void* x_hl, const void* w_hl, const void* zero_page, const float* bias, float* y,
                                   float* stats, const float* out_scale, int G, int64_t x_group_stride_bytes, int B, int H,
                                   int W, int Cin, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int act,
-                                  int tile_n, int64_t y_row_stride, int64_t y_group_stride, void* stream) {
+                                  int tile_m, int tile_n, int64_t y_row_stride, int64_t y_group_stride, void* stream) {
   MRN_CHECK_ARG(x_hl && w_hl && zero_page && y && G >= 1, "mrn_conv2d_x3_hl32: bad operands");
   MRN_CHECK_ARG(Cin % 32 == 0 && kh * kw <= 32, "mrn_conv2d_x3_hl32: unsupported Cin=%d kernel=%dx%d", Cin, kh, kw);
   MRN_CHECK_ARG(((uintptr_t)x_hl % 128 == 0) && ((uintptr_t)w_hl % 128 == 0) && ((uintptr_t)zero_page % 16 == 0) &&
                     (x_group_stride_bytes % 128 == 0), "mrn_conv2d_x3_hl32: HL32 operands must be 128-byte aligned");
-  MRN_CHECK_ARG(tile_n == 256 || tile_n == 128, "mrn_conv2d_x3_hl32: tile_n must be 128 or 256");
+  MRN_CHECK_ARG((tile_m == 256 && (tile_n == 256 || tile_n == 128)) || (tile_m == 128 && tile_n == 128),
+                "mrn_conv2d_x3_hl32: tile must be 256x256, 256x128 or 128x128");
   const int Ho = (H + 2 * ph - kh) / sh + 1, Wo = (W + 2 * pw - kw) / sw + 1;
   MRN_CHECK_ARG(Ho > 0 && Wo > 0 && B >= 0, "mrn_conv2d_x3_hl32: empty output");
   MRN_CHECK_ARG((long)B * H * W * Cin * 4 < (1L << 31) && (long)Cout * kh * kw * Cin * 4 < (1L << 31),
@@ -427,7 +429,8 @@ MRN_EXPORT int mrn_conv2d_x3_hl32(const void* x_hl, const void* w_hl, const void
   magic_div((unsigned)Wo, p.wo_magic, p.wo_shift);
   magic_div((unsigned)p.BWo, p.bw_magic, p.bw_shift);
   if (tile_n == 256) return launch_x3<2, 4, 4, 2>(p, (hipStream_t)stream);
-  return launch_x3<4, 2, 2, 2>(p, (hipStream_t)stream);
+  if (tile_m == 256) return launch_x3<4, 2, 2, 2>(p, (hipStream_t)stream);
+  return launch_x3<4, 2, 1, 2>(p, (hipStream_t)stream);
 }
 
 // fp32 [rows][C] (C % 32 == 0) -> HL32

@@ -85,12 +85,17 @@ struct LstmParams {
 };
 struct LstmGroup {
   LstmParams g[MAX_GROUPS];
-  int tiles, B, T, ndir;
+  int tiles, B, T, ndir, nsets, pinned;
 };
 
 __global__ __launch_bounds__(NTH) void lstm_layer_kernel(const LstmGroup grp) {
   __shared__ __attribute__((aligned(16))) float h_lds[2][BT * HLD];
-  const int gi = blockIdx.x / grp.tiles;
+  // set = (group, direction) owns one W_hh stream (1 MiB); all tiles of a set run on ONE XCD (block b lands on XCD b % 8)
+  // so the stream stays resident in that XCD's 4 MiB L2 instead of every XCD cycling through every set's weights
+  // (only while a set's tiles fit the 32 CUs of an XCD; larger batches keep the plain block order)
+  const int set = grp.pinned ? (int)(blockIdx.x % 8) + 8 * (int)((blockIdx.x / 8) / grp.tiles) : (int)blockIdx.x / grp.tiles;
+  if (set >= grp.nsets) return;
+  const int gi = set / grp.ndir;
   const float* __restrict__ xproj = grp.g[gi].xproj;
   const float* __restrict__ w_hh = grp.g[gi].w_hh;
   const float* __restrict__ b_hh = grp.g[gi].b_hh;
@@ -98,8 +103,8 @@ __global__ __launch_bounds__(NTH) void lstm_layer_kernel(const LstmGroup grp) {
   float* __restrict__ gates_out = grp.g[gi].gates_out;
   float* __restrict__ c_out = grp.g[gi].c_out;
   const int B = grp.B, T = grp.T, ndir = grp.ndir;
-  const int dir = blockIdx.y;
-  const int b0 = (blockIdx.x - gi * grp.tiles) * BT;
+  const int dir = set - gi * grp.ndir;
+  const int b0 = (grp.pinned ? (int)((blockIdx.x / 8) % grp.tiles) : (int)blockIdx.x % grp.tiles) * BT;
   const int t_ = threadIdx.x, lane = t_ & 63, wave = t_ >> 6;
   const float* W = w_hh + (long)dir * 4 * HID * HID;
   const int col = lane & 15, rbase = (lane >> 4) * 4;
@@ -181,12 +186,14 @@ __device__ __forceinline__ float fast_tanh(float x) {
 
 struct AttnDecGroup {
   AttnDecParams g[MAX_GROUPS];
-  int tiles;
+  int tiles, groups, pinned;
 };
 
 __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecGroup grp) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int gi = blockIdx.x / grp.tiles;
+  // one expert's recurrent weights (2.3 MiB) stay in one XCD's L2: all tiles of a group run on XCD (group % 8)
+  const int gi = grp.pinned ? (int)(blockIdx.x % 8) + 8 * (int)((blockIdx.x / 8) / grp.tiles) : (int)blockIdx.x / grp.tiles;
+  if (gi >= grp.groups) return;
   const AttnDecParams p = grp.g[gi];
   const int D = p.D, T = p.T;
   const int CLD = D + 4;
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecGroup gr
   float* e_lds = ctx_lds + BT * CLD;       // [BT][T]
   float* sw_lds = e_lds + BT * T;          // [HID]
 
-  const int b0 = (blockIdx.x - gi * grp.tiles) * BT;
+  const int b0 = (grp.pinned ? (int)((blockIdx.x / 8) % grp.tiles) : (int)blockIdx.x % grp.tiles) * BT;
   const int t_ = threadIdx.x, lane = t_ & 63, wave = t_ >> 6;
   const int col = lane & 15, rbase = (lane >> 4) * 4;
   const int j = wave * 16 + col;
@@ -384,8 +391,11 @@ __global__ void embed_gather_kernel(const long* __restrict__ idx, const float* _
 
 }  // namespace
 
-static int lstm_launch(const LstmGroup& grp, int groups, hipStream_t st) {
-  hipLaunchKernelGGL(lstm_layer_kernel, dim3(groups * grp.tiles, grp.ndir), dim3(NTH), 0, st, grp);
+static int lstm_launch(LstmGroup& grp, int groups, hipStream_t st) {
+  grp.nsets = groups * grp.ndir;
+  grp.pinned = grp.nsets > 2 && grp.tiles * ceil_div(grp.nsets, 8) <= 32;   // (a single layer already fits every L2)
+  const int blocks = grp.pinned ? 8 * ceil_div(grp.nsets, 8) * grp.tiles : grp.nsets * grp.tiles;
+  hipLaunchKernelGGL(lstm_layer_kernel, dim3(blocks), dim3(NTH), 0, st, grp);
   MRN_LAUNCH_CHECK("lstm_layer");
   return MRN_OK;
 }
@@ -442,12 +452,14 @@ static int attn_fill(AttnDecParams& p, const float* Hb, const float* Hproj, cons
   return MRN_OK;
 }
 
-static int attn_launch(const AttnDecGroup& grp, int groups, int D, int T, hipStream_t st) {
+static int attn_launch(AttnDecGroup& grp, int groups, int D, int T, hipStream_t st) {
+  grp.groups = groups;
+  grp.pinned = groups > 1 && grp.tiles * ceil_div(groups, 8) <= 32;
   const size_t lds = sizeof(float) * (2 * BT * HLD + BT * (D + 4) + BT * T + HID);
   MRN_CHECK_ARG(lds <= 160 * 1024, "mrn_attn_decoder_fwd: LDS budget exceeded (D=%d T=%d)", D, T);
   if (lds > 64 * 1024)
     hipFuncSetAttribute((const void*)attn_decoder_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(attn_decoder_kernel, dim3(groups * grp.tiles), dim3(NTH), lds, st, grp);
+  hipLaunchKernelGGL(attn_decoder_kernel, dim3(grp.pinned ? 8 * ceil_div(groups, 8) * grp.tiles : groups * grp.tiles), dim3(NTH), lds, st, grp);
   MRN_LAUNCH_CHECK("attn_decoder");
   return MRN_OK;
 }

@@ -22,20 +22,21 @@ class KernelTimer:
         e.record()
         return e
 
-    def end(self, start, flops, kind="f32"):
+    def end(self, start, flops, kind="f32", nbytes=0.0):
         e = torch.cuda.Event(enable_timing=True)
         e.record()
-        self.spans.append((start, e, flops, kind))
+        self.spans.append((start, e, flops, kind, nbytes))
 
     def summary(self):
         """per kernel kind: launches, total event time, total algorithmic flops"""
         torch.cuda.synchronize()
         out = {}
-        for s, e, f, kind in self.spans:
-            d = out.setdefault(kind, {"launches": 0, "total_ms": 0.0, "total_flops": 0.0})
+        for s, e, f, kind, nb in self.spans:
+            d = out.setdefault(kind, {"launches": 0, "total_ms": 0.0, "total_flops": 0.0, "total_bytes": 0.0})
             d["launches"] += 1
             d["total_ms"] += s.elapsed_time(e)
             d["total_flops"] += f
+            d["total_bytes"] += nb
         return out
 
 
@@ -256,7 +257,15 @@ def conv2d_nhwc(x, w_ohwi, bias=None, stride=(1, 1), padding=(0, 0), act=ACT_NON
 # ---------------------------------------------------------------------------------------------------------
 # grouped split-fp16 x3 convolution on HL32 operands (conv_x3.hip)
 # ---------------------------------------------------------------------------------------------------------
-X3_TILE_M = 256
+X3_SMALL_TILE_MAX_K = 1200     # measured on MI355X (tools/bench_conv_x3.py): +3.5 % at K = 1152, +7.6 % at K = 576
+
+
+def x3_tile(Cout, K):
+    """(tile_m, tile_n) of the grouped conv: 256x256 for wide outputs, 256x128 otherwise; 128x128 (two workgroups per CU)
+    for short reductions, where the prologue / epilogue of one tile overlaps the main loop of its neighbour"""
+    if Cout >= 256:
+        return 256, 256
+    return (128, 128) if K <= X3_SMALL_TILE_MAX_K else (256, 128)
 
 
 def split_hl32(x):
@@ -293,18 +302,20 @@ def conv2d_x3(x_hl, G, shared_input, B, H, W, Cin, w_hl, w_scale, Cout, ksize, s
     Ho, Wo = conv_out_hw(H, W, ksize, stride, padding)
     dev = x_hl.device
     y = out if out is not None else torch.empty(G, B, Ho, Wo, Cout, device=dev, dtype=torch.float32)
+    tile_m, tile_n = x3_tile(Cout, kh * kw * Cin)
     stats = None
     if want_stats:
-        stats = torch.empty(call("mrn_conv2d_x3_stats_floats", G, B, Ho, Wo, Cout, X3_TILE_M), device=dev, dtype=torch.float32)
+        stats = torch.empty(call("mrn_conv2d_x3_stats_floats", G, B, Ho, Wo, Cout, tile_m), device=dev, dtype=torch.float32)
     gstride = 0 if shared_input else B * H * W * Cin * 4
-    tile_n = 256 if Cout >= 256 else 128
-    timed = CONV_TIMER is not None and kh * kw > 1          # (the 1x1 calls are the heads' Linear layers)
+    timed = CONV_TIMER is not None
     t0 = CONV_TIMER.begin() if timed else None
     call("mrn_conv2d_x3_hl32", _p(x_hl), _p(w_hl), _p(_zero_page(dev)), _p(bias), _p(y), _p(stats), _p(w_scale), G, gstride,
-         B, H, W, Cin, Cout, kh, kw, stride[0], stride[1], padding[0], padding[1], act, tile_n, out_row_stride, out_group_stride,
+         B, H, W, Cin, Cout, kh, kw, stride[0], stride[1], padding[0], padding[1], act, tile_m, tile_n, out_row_stride, out_group_stride,
          _stream())
     if timed:
-        CONV_TIMER.end(t0, 2.0 * G * B * Ho * Wo * Cout * kh * kw * Cin, "fp16x3/x3g%d" % tile_n)
+        # algorithmic bytes: every operand element once (HL32 = 4 B / element, like fp32) + the fp32 result
+        nbytes = 4.0 * ((1 if shared_input else G) * B * H * W * Cin + G * Cout * kh * kw * Cin + G * B * Ho * Wo * Cout)
+        CONV_TIMER.end(t0, 2.0 * G * B * Ho * Wo * Cout * kh * kw * Cin, "fp16x3/x3g%dx%d" % (tile_m, tile_n), nbytes)
     return y, stats
 
 

@@ -1,28 +1,29 @@
-set -x
-mkdir -p gpurun_out/r1g
+#!/bin/bash
+# rocprofv3 PMC passes over bench.py (1 warm-up + 1 timed step), one counter group per run as the MI355X guide
+# prescribes (FETCH_SIZE and WRITE_SIZE cannot share a pass).  Usage on the GPU box: bash tools/pmc_pass.sh <tag>
+# Writes gpurun_out/<tag>/pmc_summary.json : {counter: {kernel: {"n": launches, "sum": total}}}.
+tag=${1:-pmc}
 R=$GRAFT_REPO_ROOT
+mkdir -p $R/gpurun_out/$tag
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/r1g/fetch -o f -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timer > $R/gpurun_out/r1g/fetch.log 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/r1g/write -o w -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timer > $R/gpurun_out/r1g/write.log 2>&1
-timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/gpurun_out/r1g/mfma -o m -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timer > $R/gpurun_out/r1g/mfma.log 2>&1
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
+  i=$((i+1))
+  timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/$tag/p$i -o p -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timer > $R/gpurun_out/$tag/p$i.log 2>&1
+done
 cd $R
-find gpurun_out/r1g -name "*.csv" | xargs ls -la
-python3 - <<'PY'
+python3 - <<PY
 import csv, glob, collections, json
-out = {}
-for tag in ("fetch", "write", "mfma"):
-    for f in glob.glob(f"gpurun_out/r1g/{tag}/**/*counter_collection.csv", recursive=True):
-        agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
-        with open(f) as fh:
-            rd = csv.DictReader(fh)
-            for row in rd:
-                k = row["Kernel_Name"][:100]
-                c = row["Counter_Name"]
-                a = agg[k][c]
-                a[0] += 1
-                a[1] += float(row["Counter_Value"])
-        out[tag] = {k: {c: {"n": v[0], "sum": v[1]} for c, v in d.items()} for k, d in agg.items()}
-json.dump(out, open("gpurun_out/r1g/pmc_summary.json", "w"), indent=1)
+agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+for f in glob.glob("gpurun_out/$tag/p*/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        a = agg[row["Counter_Name"]][row["Kernel_Name"].replace("(anonymous namespace)::", "")[:90]]
+        a[0] += 1
+        a[1] += float(row["Counter_Value"])
+out = {c: {k: {"n": v[0], "sum": v[1]} for k, v in sorted(d.items(), key=lambda kv: -kv[1][1])[:12]} for c, d in agg.items()}
+json.dump(out, open("gpurun_out/$tag/pmc_summary.json", "w"), indent=1)
+for c, d in out.items():
+    k, v = next(iter(d.items()))
+    print(c, k[:60], v)
 PY
-find gpurun_out/r1g -name "*.csv" -size +1M -delete
-ls -la gpurun_out/r1g
+rm -rf gpurun_out/$tag/p[0-9]
