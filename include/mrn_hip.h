@@ -77,7 +77,7 @@ int mrn_split_weight_bf16(const float* w, void* hi, void* lo, int64_t n, int hal
  * input); w_hl: [G][Cout][Cin/32][kh*kw][128 B]; bias [G][Cout] or NULL; out_scale [G][2] = {s, 1/s} per group (the
  * power-of-two weight prescale of mrn_pow2_scale_f32) or NULL; y [G][B][Ho][Wo][Cout] fp32; stats
  * [G][ceil(B*Ho*Wo/tile_m)][2][Cout] per-row-block sums / sums of squares (mrn_conv2d_x3_stats_floats) or NULL.
- * tile_m x tile_n = 256x256 (Cout >= 256), 256x128 or 128x128.  Requires Cin % 32 == 0; zero_page: >= 128 bytes of device zeros.
+ * tile_m x tile_n = 256x256 (Cout >= 256), 256x128, 256x64 (Cout <= 64) or 128x128.  Requires Cin % 32 == 0; zero_page: >= 128 bytes of device zeros.
  * y_row_stride / y_group_stride (floats; 0 = dense [G][B*Ho*Wo][Cout]) let the result land in a wider buffer, e.g. one
  * expert's slice of the router's [B][P][I][C] feature tensor.  With H = W = kh = kw = 1 this is a grouped Linear layer
  * (nn.Linear sites of modules/sequence_modeling.py:10,19-22 and modules/prediction.py:58-68,104-107). */

@@ -229,8 +229,10 @@ __global__ __launch_bounds__(512) void conv_x3_kernel(const ConvX3Params p) {
       for (int j = 0; j < WN; ++j) acc[i][j] = mma(ah[ks][i], bh[ks][j], acc[i][j]);
   };
 
-  // ---- main loop: every wave loads and computes every K-step; one barrier per K-step.  (A ping-pong variant -- half
-  // the waves compute while the other half fetch fragments, 4 barriers per K-step -- measured 371 vs 410 TFLOP/s.)
+  // ---- main loop: every wave loads and computes every K-step; one barrier per K-step.  (Measured alternatives: a
+  // ping-pong schedule -- half the waves compute while the other half fetch fragments, 4 barriers per K-step -- 371 vs
+  // 410 TFLOP/s; a 3-stage ring with counted vmcnt + raw s_barrier on the 256x128 tile +2.7 %, which does not fit the
+  // 160 KiB LDS at 256x256.)
   issue_next(lds);
   for (int kt = 0; kt < nk; ++kt) {
     __syncthreads();      // own DMAs of tile kt retired (vmcnt(0)) + everyone finished reading the other stage
@@ -307,6 +309,7 @@ __global__ __launch_bounds__(512) void conv_x3_kernel(const ConvX3Params p) {
 template __global__ void conv_x3_kernel<2, 4, 4, 2>(const ConvX3Params);
 template __global__ void conv_x3_kernel<4, 2, 2, 2>(const ConvX3Params);
 template __global__ void conv_x3_kernel<4, 2, 1, 2>(const ConvX3Params);
+template __global__ void conv_x3_kernel<8, 1, 1, 2>(const ConvX3Params);
 
 // ---- producers of the HL32 layout -------------------------------------------------------------------------------
 __device__ __forceinline__ void split_h(float v, _Float16& h, _Float16& l) {
@@ -403,8 +406,8 @@ MRN_EXPORT int mrn_conv2d_x3_hl32(const void* x_hl, const void* w_hl, const void
   MRN_CHECK_ARG(Cin % 32 == 0 && kh * kw <= 32, "mrn_conv2d_x3_hl32: unsupported Cin=%d kernel=%dx%d", Cin, kh, kw);
   MRN_CHECK_ARG(((uintptr_t)x_hl % 128 == 0) && ((uintptr_t)w_hl % 128 == 0) && ((uintptr_t)zero_page % 16 == 0) &&
                     (x_group_stride_bytes % 128 == 0), "mrn_conv2d_x3_hl32: HL32 operands must be 128-byte aligned");
-  MRN_CHECK_ARG((tile_m == 256 && (tile_n == 256 || tile_n == 128)) || (tile_m == 128 && tile_n == 128),
-                "mrn_conv2d_x3_hl32: tile must be 256x256, 256x128 or 128x128");
+  MRN_CHECK_ARG((tile_m == 256 && (tile_n == 256 || tile_n == 128 || tile_n == 64)) || (tile_m == 128 && tile_n == 128),
+                "mrn_conv2d_x3_hl32: tile must be 256x256, 256x128, 256x64 or 128x128");
   const int Ho = (H + 2 * ph - kh) / sh + 1, Wo = (W + 2 * pw - kw) / sw + 1;
   MRN_CHECK_ARG(Ho > 0 && Wo > 0 && B >= 0, "mrn_conv2d_x3_hl32: empty output");
   MRN_CHECK_ARG((long)B * H * W * Cin * 4 < (1L << 31) && (long)Cout * kh * kw * Cin * 4 < (1L << 31),
@@ -429,6 +432,7 @@ MRN_EXPORT int mrn_conv2d_x3_hl32(const void* x_hl, const void* w_hl, const void
   magic_div((unsigned)Wo, p.wo_magic, p.wo_shift);
   magic_div((unsigned)p.BWo, p.bw_magic, p.bw_shift);
   if (tile_n == 256) return launch_x3<2, 4, 4, 2>(p, (hipStream_t)stream);
+  if (tile_m == 256 && tile_n == 64) return launch_x3<8, 1, 1, 2>(p, (hipStream_t)stream);
   if (tile_m == 256) return launch_x3<4, 2, 2, 2>(p, (hipStream_t)stream);
   return launch_x3<4, 2, 1, 2>(p, (hipStream_t)stream);
 }

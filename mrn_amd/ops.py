@@ -41,6 +41,7 @@ class KernelTimer:
 
 
 CONV_TIMER = None            # set to a KernelTimer by bench.py
+TIMER_SHAPES = False         # tools/layer_times.py: one timer kind per layer shape
 
 # Arithmetic of the large implicit-GEMM convs (Cout > 64, K % 32 == 0):
 #   "f32"    exact fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere
@@ -263,8 +264,13 @@ X3_SMALL_TILE_MAX_K = 1200     # measured on MI355X (tools/bench_conv_x3.py): +3
 def x3_tile(Cout, K):
     """(tile_m, tile_n) of the grouped conv: 256x256 for wide outputs, 256x128 otherwise; 128x128 (two workgroups per CU)
     for short reductions, where the prologue / epilogue of one tile overlaps the main loop of its neighbour"""
+    force = __import__("os").environ.get("MRN_X3_TILE")
+    if force:
+        return tuple(int(v) for v in force.split("x"))
     if Cout >= 256:
         return 256, 256
+    if Cout <= 64:
+        return 256, 64
     return (128, 128) if K <= X3_SMALL_TILE_MAX_K else (256, 128)
 
 
@@ -315,7 +321,10 @@ def conv2d_x3(x_hl, G, shared_input, B, H, W, Cin, w_hl, w_scale, Cout, ksize, s
     if timed:
         # algorithmic bytes: every operand element once (HL32 = 4 B / element, like fp32) + the fp32 result
         nbytes = 4.0 * ((1 if shared_input else G) * B * H * W * Cin + G * Cout * kh * kw * Cin + G * B * Ho * Wo * Cout)
-        CONV_TIMER.end(t0, 2.0 * G * B * Ho * Wo * Cout * kh * kw * Cin, "fp16x3/x3g%dx%d" % (tile_m, tile_n), nbytes)
+        kind = "fp16x3/x3g%dx%d" % (tile_m, tile_n)
+        if TIMER_SHAPES:
+            kind += "|G%d B%d %dx%d %d->%d k%dx%d s%d%d" % (G, B, H, W, Cin, Cout, kh, kw, stride[0], stride[1])
+        CONV_TIMER.end(t0, 2.0 * G * B * Ho * Wo * Cout * kh * kw * Cin, kind, nbytes)
     return y, stats
 
 

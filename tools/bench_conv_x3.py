@@ -16,6 +16,7 @@ SHAPES_ALL = [  # B, H, W, Cin, Cout, k, s, p
     (256, 16, 128, 64, 128, (3, 3), (1, 1), (1, 1)),
     (256, 4, 65, 256, 512, (1, 1), (1, 1), (0, 0)),
     (256, 4, 65, 512, 512, (2, 2), (2, 1), (0, 1)),
+    (256, 32, 256, 32, 64, (3, 3), (1, 1), (1, 1)),
 ]
 
 
