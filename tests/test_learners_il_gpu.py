@@ -59,17 +59,18 @@ def test_kd_ewc_weight_align_kernels():
     assert_close("aligned", wd, wref, atol=1e-6, rtol=1e-5)
 
 
-@pytest.mark.parametrize("il", ["lwf", "ewc", "der"])
+@pytest.mark.parametrize("il", ["lwf", "ewc", "der", "wa"])
 def test_il_learners_two_tasks(tmp_path, il):
     from mrn_amd.data.synthetic import SyntheticTextLines, SyntheticValidation, synthetic_characters
     from mrn_amd.il_modules.der import DER
     from mrn_amd.il_modules.ewc import EWC
     from mrn_amd.il_modules.lwf import LwF
+    from mrn_amd.il_modules.wa import WA
     os.chdir(tmp_path)
     opt = make_opt(tmp_path, "crnn")
     opt.il, opt.memory = il, None
     torch.manual_seed(0)
-    cls = {"lwf": LwF, "ewc": EWC, "der": DER}[il]
+    cls = {"lwf": LwF, "ewc": EWC, "der": DER, "wa": WA}[il]
     sink = io.StringIO()
     with contextlib.redirect_stdout(sink):
         learner = cls(opt)
@@ -89,5 +90,30 @@ def test_il_learners_two_tasks(tmp_path, il):
     if il == "der":
         assert len(net.model) == 2 and net.fc.in_features == 512 and net.fc.out_features == 54
         assert "alignweights,gamma=" in sink.getvalue()
+    if il == "wa":
+        # aligned twice (end of the incremental task + after_task, wa.py:34-36,110): the second gamma must be ~1
+        gammas = [float(l.split("=")[1]) for l in sink.getvalue().splitlines() if l.startswith("alignweights,gamma=")]
+        assert len(gammas) == 2 and abs(gammas[1] - 1.0) < 1e-4
+        w = net.fc.weight.detach()
+        assert abs(float(w[:34].norm(dim=1).mean() / w[34:].norm(dim=1).mean()) - 1.0) < 1e-4
     if il == "ewc":
         assert learner.fisher is not None and all(float(v.max()) <= 1e-4 + 1e-12 for v in learner.fisher.values())
+
+
+def test_joint_learner_runs_test_pass(tmp_path):
+    """JointLearner (il_modules/joint.py): canonical loop + the per-dataset test pass at every validation interval"""
+    from mrn_amd.data.synthetic import SyntheticTextLines, SyntheticValidation, synthetic_characters
+    from mrn_amd.il_modules.joint import JointLearner
+    os.chdir(tmp_path)
+    opt = make_opt(tmp_path, "crnn")
+    opt.il, opt.memory = "joint", None
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        learner = JointLearner(opt)
+        chars = synthetic_characters(40)
+        train, valid = SyntheticTextLines(opt), SyntheticValidation(opt)
+        train.set_characters(chars)
+        valid.set_characters(chars)
+        scores, neds = learner.incremental_train(0, chars, train, valid, None, [valid.create_dataset(), valid.create_dataset()])
+    assert len(scores) == 1 and len(neds) == 1 and 0.0 <= scores[0] <= 100.0
+    assert all(torch.isfinite(p).all() for p in learner.model.parameters())
