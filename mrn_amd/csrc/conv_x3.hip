@@ -46,6 +46,7 @@ struct ConvX3Params {
   int H, W, Ho, Wo, kw, sh, sw, ph, pw, act;
   int tilesM, tilesN;
   int oy_major, BWo;           // image-row-major GEMM row order: m = (oy * B + b) * Wo + ox
+  int tiles_per_row;           // > 0: B * Wo is a multiple of the tile height and tiles are visited row-of-image fastest
   unsigned wo_magic, bw_magic; // fast_div constants for Wo and B * Wo
   int wo_shift, bw_shift;
 };
@@ -97,8 +98,12 @@ __global__ __launch_bounds__(512) void conv_x3_kernel(const ConvX3Params p) {
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
   const int tile_n = lid % p.tilesN;
   const int t2 = lid / p.tilesN;
-  const int tile_m = t2 % p.tilesM;
+  int tile_m = t2 % p.tilesM;
   const int g = t2 / p.tilesM;
+  // image-row-major order with whole tiles per image row: consecutive workgroups take the SAME image block at successive
+  // output rows (they share the input rows their kernel taps overlap in L2), and every XCD's contiguous share of tiles
+  // holds the same mix of short (border row, padded taps skipped) and long tiles
+  if (p.tiles_per_row > 0) tile_m = (tile_m % p.Ho) * p.tiles_per_row + tile_m / p.Ho;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -383,6 +388,7 @@ int launch_x3(const ConvX3Params& p0, hipStream_t st) {
   ConvX3Params p = p0;
   p.tilesM = ceil_div(p.M, BM);
   p.tilesN = ceil_div(p.N, BN);
+  p.tiles_per_row = (p.oy_major && p.BWo % BM == 0 && !getenv("MRN_X3_NO_INTERLEAVE")) ? p.BWo / BM : 0;
   const size_t ldsz = 2 * (size_t)(BM + BN) * 128;
   const long tiles = (long)p.G * p.tilesM * p.tilesN;
   (void)hipFuncSetAttribute((const void*)conv_x3_kernel<WAVES_M, WAVES_N, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);

@@ -129,9 +129,13 @@ def gemm_raw(A, W, C, M, N, K, batch=1, sA=(0, 0, 1), sW=(0, 0, 1), sC=(0, 0, 1)
              bias_batch_stride=0, residual=None, act=ACT_NONE, accumulate=False, alpha=1.0):
     """C[b,m,n] = act(alpha * sum_k A[b,m,k] W[b,n,k] + bias + residual); strides are (batch, row, k) in elements."""
     _chk(A, W, C, bias, residual)
+    timed = CONV_TIMER is not None and TIMER_SHAPES
+    t0 = CONV_TIMER.begin() if timed else None
     call("mrn_gemm_f32", _p(A), _p(W), _p(bias), _p(residual), _p(C), M, N, K, batch,
          sA[0], sA[1], sA[2], sW[0], sW[1], sW[2], sC[0], sC[1], sC[2], bias_batch_stride, bias_axis,
          act, int(accumulate), float(alpha), _stream())
+    if timed:
+        CONV_TIMER.end(t0, 2.0 * batch * M * N * K, "gemm_f32|b%d M%d N%d K%d sA%s sW%s sC%s" % (batch, M, N, K, sA[1:], sW[1:], sC[1:]))
     return C
 
 
