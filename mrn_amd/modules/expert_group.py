@@ -52,10 +52,40 @@ def supported(experts):
     return ops.CONV_PRECISION in ("auto", "fp16x3") and ops.AUTO_SPLIT_KIND == "fp16x3" and ops.AUTO_SPLIT_MIN_K == 0
 
 
-class BackboneGroup:
+class _GroupedLinear:
+    """cache of per-layer stacked operands + grouped Linear on the x3 GEMM (mrn_conv2d_x3_hl32 with a 1x1 kernel)"""
+
+    def _cached(self, name, params, build):
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        got = self._cache.get(name)
+        if got is None or got[0] != key:
+            with torch.no_grad():
+                got = (key, build())
+            self._cache[name] = got
+        return got[1]
+
+    def _linear(self, name, x_hl, rows, K, weights, biases, out=None, out_row_stride=0, out_group_stride=0, groups=None,
+                act=ops.ACT_NONE):
+        """grouped y[g] = x[g] @ W[g]^T + b[g]; weights: list of [N,K] tensors (any stride), biases: list or None"""
+        G = len(weights)
+        N = weights[0].shape[0]
+        params = list(weights) + ([b for b in biases] if biases is not None else [])
+
+        def build():
+            w_hl, scale = ops.pack_weights_hl32([w.detach().contiguous().view(N, 1, 1, K) for w in weights])
+            bias = torch.stack([b.detach() for b in biases]).contiguous() if biases is not None else None
+            return w_hl, scale, bias
+        w_hl, scale, bias = self._cached(name, params, build)
+        y, _ = ops.conv2d_x3(x_hl, G, False, rows, 1, 1, K, w_hl, scale, N, (1, 1), bias=bias, act=act, out=out,
+                             out_row_stride=out_row_stride, out_group_stride=out_group_stride)
+        return y
+
+
+class BackboneGroup(_GroupedLinear):
     def __init__(self, experts):
         self.experts = list(experts)       # Model_Extractor modules
         self.G = len(self.experts)
+        self._cache = {}
         self._wcache = {}
         self._bncache = {}
         self._nbt = []
@@ -147,6 +177,17 @@ class BackboneGroup:
         return self.layer(out, [b.conv2 for b in blocks], [b.bn2 for b in blocks], relu=True, residual=res,
                           want_f32=next_needs_f32, want_hl=True)
 
+    def _batched_linear_f32(self, name, x, layers, act=ops.ACT_NONE):
+        """x [G,R,K] fp32 -> [G,R,N]: y[g] = act(x[g] @ W_g^T + b_g) on the exact-fp32 GEMM, batch = expert"""
+        G, R, K = x.shape
+        N = layers[0].out_features
+        w, b = self._cached(name, [l.weight for l in layers] + [l.bias for l in layers],
+                            lambda: (torch.stack([l.weight.detach() for l in layers]).contiguous(),
+                                     torch.stack([l.bias.detach() for l in layers]).contiguous()))
+        y = torch.empty(G, R, N, device=x.device, dtype=torch.float32)
+        ops.gemm_raw(x, w, y, R, N, K, G, (R * K, K, 1), (N * K, K, 1), (R * N, N, 1), bias=b, bias_batch_stride=N, act=act)
+        return y
+
     def _resnet(self, x, last_hl=False):
         nets = [e.FeatureExtraction.ConvNet for e in self.experts]
         n0 = nets[0]
@@ -204,13 +245,16 @@ class BackboneGroup:
         x = self.layer(x, [l.conv[8] for l in loc], [l.conv[9] for l in loc], pool=pool)
         x = self.layer(x, [l.conv[12] for l in loc], [l.conv[13] for l in loc], want_f32=True, want_hl=False)
         out = torch.empty(G, B, tps[0].I_r_size[0], tps[0].I_r_size[1], C, device=image.device, dtype=torch.float32)
-        for g, (t, l) in enumerate(zip(tps, loc)):
-            v = ops.avgpool_nhwc(x.f32[g])
-            fc1, fc2 = l.localization_fc1[0], l.localization_fc2
-            v = ops.linear(v, fc1.weight, fc1.bias, act=ops.ACT_RELU)
-            cprime = ops.linear(v, fc2.weight, fc2.bias).view(B, l.F, 2)
+        _, _, Hl, Wl, Cl = x.shape
+        v = ops.avgpool_nhwc(x.f32.view(G * B, Hl, Wl, Cl))                          # [G*B, 512], one launch
+        fc1s, fc2s = [l.localization_fc1[0] for l in loc], [l.localization_fc2 for l in loc]
+        # the two fully connected layers stay on the exact-fp32 MFMA (the fiducials feed the ill-conditioned TPS grid,
+        # DESIGN.md section 2), as ONE batched launch over the experts instead of G tiny ones
+        v = self._batched_linear_f32("loc_fc1", v.view(G, B, Cl), fc1s, act=ops.ACT_RELU)
+        cp = self._batched_linear_f32("loc_fc2", v, fc2s).view(G, B, loc[0].F, 2)
+        for g, t in enumerate(tps):
             gg = t.GridGenerator
-            ops.tps_grid_sample(image, cprime, gg.inv_delta_C, gg.P_hat, t.I_r_size, out=out[g])
+            ops.tps_grid_sample(image, cp[g], gg.inv_delta_C, gg.P_hat, t.I_r_size, out=out[g])
         return Act(tuple(out.shape), out, None)
 
     def visual_all(self, image, as_act=False):
@@ -233,7 +277,7 @@ class BackboneGroup:
         return x if as_act else x.f32.view(G, B, Wo, Cf)
 
 
-class HeadsGroup:
+class HeadsGroup(_GroupedLinear):
     """SequenceModeling + Prediction of G frozen experts in lock-step (BiLSTM x 2 + CTC Linear / teacher-forced attention
     decoder): every Linear is a grouped split-fp16 x3 GEMM (csrc/conv_x3.hip with a 1x1 kernel), every recurrence ONE
     launch for all experts (mrn_lstm_layer_fwd_grouped_f32 / mrn_attn_decoder_fwd_grouped_f32).  Replaces six concurrent
@@ -254,31 +298,6 @@ class HeadsGroup:
         if e0.stages["Pred"] == "Attn" and not is_train:       # greedy decoding feeds argmax back step by step: per expert
             return False
         return ops.CONV_PRECISION in ("auto", "fp16x3") and ops.AUTO_SPLIT_KIND == "fp16x3"
-
-    def _cached(self, name, params, build):
-        key = tuple((p.data_ptr(), p._version) for p in params)
-        got = self._cache.get(name)
-        if got is None or got[0] != key:
-            with torch.no_grad():
-                got = (key, build())
-            self._cache[name] = got
-        return got[1]
-
-    def _linear(self, name, x_hl, rows, K, weights, biases, out=None, out_row_stride=0, out_group_stride=0, groups=None,
-                act=ops.ACT_NONE):
-        """grouped y[g] = x[g] @ W[g]^T + b[g]; weights: list of [N,K] tensors (any stride), biases: list or None"""
-        G = len(weights)
-        N = weights[0].shape[0]
-        params = list(weights) + ([b for b in biases] if biases is not None else [])
-
-        def build():
-            w_hl, scale = ops.pack_weights_hl32([w.detach().contiguous().view(N, 1, 1, K) for w in weights])
-            bias = torch.stack([b.detach() for b in biases]).contiguous() if biases is not None else None
-            return w_hl, scale, bias
-        w_hl, scale, bias = self._cached(name, params, build)
-        y, _ = ops.conv2d_x3(x_hl, G, False, rows, 1, 1, K, w_hl, scale, N, (1, 1), bias=bias, act=act, out=out,
-                             out_row_stride=out_row_stride, out_group_stride=out_group_stride)
-        return y
 
     def _bilstm(self, idx, x_hl, rows_shape, K):
         """BidirectionalLSTM number idx of every expert: x [G, B*T, K] (HL32) -> [G,B,T,256] fp32"""
