@@ -87,11 +87,12 @@ __device__ __forceinline__ int row_to_pixel(const ConvX3Params& p, int m, int& o
   return (b * p.Ho + oy) * p.Wo + ox;
 }
 
-// WAVES_M x WAVES_N = 8 waves; wave tile = (WM*32) x (WN*32)
+// WAVES_M x WAVES_N waves; wave tile = (WM*32) x (WN*32)
 template <int WAVES_M, int WAVES_N, int WM, int WN>
-__global__ __launch_bounds__(512) void conv_x3_kernel(const ConvX3Params p) {
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const ConvX3Params p) {
+  constexpr int NW = WAVES_M * WAVES_N;
   constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
-  constexpr int NA = BM / 64, NB = BN / 64;          // DMA instructions per wave per K-step (8 rows each, 8 waves)
+  constexpr int NA = BM / (8 * NW), NB = BN / (8 * NW);   // DMA instructions per wave per K-step (8 rows each)
   constexpr int STAGE = (BM + BN) * 128;
   extern __shared__ __attribute__((aligned(128))) unsigned char lds[];
 
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(512) void conv_x3_kernel(const ConvX3Params p) {
   const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.w + (long)g * p.w_gstride, (int)p.w_gstride);
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
-    const int row = (i * 8 + wave) * 8 + lrow;
+    const int row = (i * NW + wave) * 8 + lrow;
     const int coff = (lch ^ ((row >> 1) & 7)) << 4;
     const int m = m0 + row;
     const bool ok = m < p.M;
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(512) void conv_x3_kernel(const ConvX3Params p) {
   }
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
-    const int row = (i * 8 + wave) * 8 + lrow;
+    const int row = (i * NW + wave) * 8 + lrow;
     const int coff = (lch ^ ((row >> 1) & 7)) << 4;
     const int n = min(n0 + row, p.N - 1);
     brow[i] = n * p.nk * 128 + coff;
@@ -179,11 +180,11 @@ __global__ __launch_bounds__(512) void conv_x3_kernel(const ConvX3Params p) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int voff = ((amask[i] >> tap) & 1u) ? arow[i] + aoff : (int)0x80000000;
-      dma16(xr, st + (i * 8 + wave) * 1024, voff, 0);
+      dma16(xr, st + (i * NW + wave) * 1024, voff, 0);
     }
     const int boff = (cb * p.taps + tap) * 128;
 #pragma unroll
-    for (int i = 0; i < NB; ++i) dma16(wr, st + BM * 128 + (i * 8 + wave) * 1024, brow[i], boff);
+    for (int i = 0; i < NB; ++i) dma16(wr, st + BM * 128 + (i * NW + wave) * 1024, brow[i], boff);
   };
 
   f32x16 acc[WM][WN];
@@ -237,7 +238,8 @@ __global__ __launch_bounds__(512) void conv_x3_kernel(const ConvX3Params p) {
   // ---- main loop: every wave loads and computes every K-step; one barrier per K-step.  (Measured alternatives: a
   // ping-pong schedule -- half the waves compute while the other half fetch fragments, 4 barriers per K-step -- 371 vs
   // 410 TFLOP/s; a 3-stage ring with counted vmcnt + raw s_barrier on the 256x128 tile +2.7 %, which does not fit the
-  // 160 KiB LDS at 256x256.)
+  // 160 KiB LDS at 256x256; single-stage 256x128 tiles with 4 waves and two workgroups per CU (occupancy instead of
+  // software pipelining) 451 vs 478 TFLOP/s for the 256x256 double-buffered tile.)
   issue_next(lds);
   for (int kt = 0; kt < nk; ++kt) {
     __syncthreads();      // own DMAs of tile kt retired (vmcnt(0)) + everyone finished reading the other stage
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(512) void conv_x3_kernel(const ConvX3Params p) {
     }
   }
   if (p.stats) {
-    __syncthreads();
+    __syncthreads();      // (also drains any DMA still in flight: vmcnt(0))
     float* red = reinterpret_cast<float*>(lds);   // [WAVES_M][2][BN]
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
@@ -392,7 +394,7 @@ int launch_x3(const ConvX3Params& p0, hipStream_t st) {
   const size_t ldsz = 2 * (size_t)(BM + BN) * 128;
   const long tiles = (long)p.G * p.tilesM * p.tilesN;
   (void)hipFuncSetAttribute((const void*)conv_x3_kernel<WAVES_M, WAVES_N, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);
-  hipLaunchKernelGGL((conv_x3_kernel<WAVES_M, WAVES_N, WM, WN>), dim3((unsigned)tiles), dim3(512), ldsz, st, p);
+  hipLaunchKernelGGL((conv_x3_kernel<WAVES_M, WAVES_N, WM, WN>), dim3((unsigned)tiles), dim3(WAVES_M * WAVES_N * 64), ldsz, st, p);
   MRN_LAUNCH_CHECK("conv2d_x3_hl32");
   return MRN_OK;
 }
