@@ -163,22 +163,37 @@ class DERNet(Model):
         self.fc = None
         self.aux_fc = None
         self.task_sizes = []
+        self.expert_grouping = True         # frozen extractors run their conv backbones in lock-step
+        self._group = None
 
     @property
     def feature_dim(self):
         return 0 if self.out_dim is None else self.out_dim * len(self.model)
 
     def _features(self, image):
-        """[B,T,out_dim*N]: frozen extractors write straight into their channel slice (no torch.cat pass)"""
+        """[B,T,out_dim*N]: frozen extractors write straight into their channel slice (no torch.cat pass); two or more
+        frozen extractors of one architecture run their conv backbones in lock-step (modules/expert_group.py)"""
+        from . import expert_group
         image = to_nhwc(image).permute(0, 3, 1, 2)
         trainable = [needs_grad(ext, image) for ext in self.model]
+        frozen = [i for i, t in enumerate(trainable) if not t]
+        visuals = {}
+        if self.expert_grouping and len(frozen) >= 2:
+            exts = [self.model[i] for i in frozen]
+            key = tuple(id(e) for e in exts)
+            if self._group is None or self._group[0] != key:
+                self._group = (key, expert_group.BackboneGroup(exts))
+            if expert_group.supported(exts):
+                with torch.no_grad():
+                    stack = self._group[1].visual_all(image)
+                visuals = {i: stack[k] for k, i in enumerate(frozen)}
         buf, outs = None, []
         for i, ext in enumerate(self.model):
             if trainable[i]:
                 outs.append(ext(image))
                 continue
             with torch.no_grad():
-                vis = ext.visual(image)
+                vis = visuals[i] if i in visuals else ext.visual(image)
                 if buf is None:
                     buf = torch.empty(vis.shape[0], vis.shape[1], self.feature_dim, device=vis.device, dtype=torch.float32)
                 sl = buf[:, :, i * self.out_dim:(i + 1) * self.out_dim]
@@ -241,6 +256,13 @@ class DERNet(Model):
         for p in self.model.parameters():
             p.requires_grad = False
         self.model.eval()
+
+    def copy(self):
+        group, self._group = self._group, None               # packed-weight caches are not copied
+        try:
+            return copy.deepcopy(self)
+        finally:
+            self._group = group
 
 
 class MRNNet(nn.Module):

@@ -408,3 +408,35 @@ def test_grouped_backbones_match_per_expert_path(arch, train_mode):
             assert torch.equal(bna[k], bnb[k]), k
         else:
             assert_close(k, bna[k], bnb[k], atol=1e-6, rtol=2e-5)
+
+
+@pytest.mark.parametrize("train_mode", [True, False])
+def test_dernet_groups_frozen_extractors(train_mode):
+    """DERNet with three frozen extractors + one trainable: the frozen ones run in lock-step (expert_group.py) and give
+    the features / logits of the per-extractor path"""
+    from mrn_amd.modules.model import DERNet
+    from mrn_amd.tools import weights as W
+    opt = make_opt("crnn")
+    classes = (30, 45, 61, 80)
+    outs = []
+    for grouping in (True, False):
+        with contextlib.redirect_stdout(io.StringIO()):
+            net = DERNet(opt)
+            for c in classes:
+                net.update_fc(256, c)
+            net.build_prediction(opt, classes[-1])
+            net.build_aux_prediction(opt, classes[-1])
+        W.fill_state_dict(net.state_dict(), seed=13)
+        net = net.cuda()
+        for ext in list(net.model)[:-1]:
+            for p in ext.parameters():
+                p.requires_grad = False
+        net.train() if train_mode else net.eval()
+        net.expert_grouping = grouping
+        image = torch.from_numpy(W.smooth_image("der", (4, 4, 32, 256), 3)).cuda()
+        with contextlib.nullcontext() if train_mode else torch.no_grad():     # (eval-mode BatchNorm has no backward path)
+            o = net(image)
+        assert (net._group is not None) == grouping
+        outs.append((o["features"].detach().clone(), o["logits"].detach().clone()))
+    assert_close("der features", outs[0][0], outs[1][0], atol=2e-5, rtol=1e-4)
+    assert_close("der logits", outs[0][1], outs[1][1], atol=2e-5, rtol=1e-4)

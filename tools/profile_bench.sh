@@ -9,5 +9,6 @@ timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$tag/prof -o trace
 cd $R
 python3 tools/rocprof_summary.py gpurun_out/$tag/prof/trace_results.db 3 > gpurun_out/$tag/summary.md 2>&1
 python3 tools/rocprof_timeline.py gpurun_out/$tag/prof/trace_results.db > gpurun_out/$tag/timeline.txt 2>&1
+python3 tools/rocprof_copies.py gpurun_out/$tag/prof/trace_results.db > gpurun_out/$tag/copies.txt 2>&1
 rm -rf gpurun_out/$tag/prof
 tail -1 gpurun_out/$tag/prof.log | cut -c1-300
