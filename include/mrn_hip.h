@@ -75,18 +75,20 @@ int mrn_split_weight_bf16(const float* w, void* hi, void* lo, int64_t n, int hal
  * (Cout row, 32-channel block, tap) for the weight (mrn_pack_weight_hl32; reduction order = channel block outer, tap
  * inner).  x_hl: [G][B][H][W][Cin/32][128 B] with group stride x_group_stride_bytes (0 = all groups read the same
  * input); w_hl: [G][Cout][Cin/32][kh*kw][128 B]; bias [G][Cout] or NULL; out_scale [G][2] = {s, 1/s} per group (the
- * power-of-two weight prescale of mrn_pow2_scale_f32) or NULL; y [G][B][Ho][Wo][Cout] fp32; stats
+ * power-of-two weight prescale of mrn_pow2_scale_f32) or NULL; x_scale: {s, 1/s} of an activation that was split as
+ * s * x (mrn_split_hl32_f32 with a scale; keeps small-magnitude operands such as gradients inside fp16's normal range) or
+ * NULL; residual: optional fp32 tensor with y's layout, added before the activation; y [G][B][Ho][Wo][Cout] fp32; stats
  * [G][ceil(B*Ho*Wo/tile_m)][2][Cout] per-row-block sums / sums of squares (mrn_conv2d_x3_stats_floats) or NULL.
  * tile_m x tile_n = 256x256 (Cout >= 256), 256x128, 256x64 (Cout <= 64) or 128x128.  Requires Cin % 32 == 0; zero_page: >= 128 bytes of device zeros.
  * y_row_stride / y_group_stride (floats; 0 = dense [G][B*Ho*Wo][Cout]) let the result land in a wider buffer, e.g. one
  * expert's slice of the router's [B][P][I][C] feature tensor.  With H = W = kh = kw = 1 this is a grouped Linear layer
  * (nn.Linear sites of modules/sequence_modeling.py:10,19-22 and modules/prediction.py:58-68,104-107). */
-int mrn_conv2d_x3_hl32(const void* x_hl, const void* w_hl, const void* zero_page, const float* bias, float* y,
-                       float* stats, const float* out_scale, int G, int64_t x_group_stride_bytes, int B, int H, int W,
+int mrn_conv2d_x3_hl32(const void* x_hl, const void* w_hl, const void* zero_page, const float* bias,
+                       const float* residual, float* y, float* stats, const float* out_scale, const float* x_scale, int G, int64_t x_group_stride_bytes, int B, int H, int W,
                        int Cin, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int act, int tile_m, int tile_n,
                        int64_t y_row_stride, int64_t y_group_stride, void* stream);
 int64_t mrn_conv2d_x3_stats_floats(int G, int B, int Ho, int Wo, int Cout, int tile_m);
-int mrn_split_hl32_f32(const float* x, void* out, int64_t rows, int C, void* stream);
+int mrn_split_hl32_f32(const float* x, void* out, int64_t rows, int C, const float* scale, void* stream);
 int mrn_pack_weight_hl32(const float* w_ohwi, void* out, int Cout, int taps, int Cin, const float* scale, void* stream);
 
 /* Elementwise passes between grouped convolutions (G frozen experts in lock-step).

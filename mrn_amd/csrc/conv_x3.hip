@@ -37,6 +37,8 @@ struct ConvX3Params {
   const unsigned char* zero;  // >= 128 bytes of zeros
   const float* bias;          // [G][N] or null
   const float* out_scale;     // [G][2] = {s, 1/s} (epilogue multiplies by [1]) or null
+  const float* x_scale;       // [2] = {s, 1/s} of the activation operand (epilogue multiplies by [1]) or null
+  const float* res;           // optional residual, same layout as y, added before the activation
   float* y;                   // [G][M][N]
   float* stats;               // [G][tilesM][2][N] or null
   long x_gstride, w_gstride;  // bytes
@@ -253,7 +255,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
 
   // ---- epilogue: scale, bias, BatchNorm partial statistics, activation, store ------------------------------
   float* yg = p.y + (long)g * p.y_gstride;
-  const float osc = p.out_scale ? p.out_scale[g * 2 + 1] : 1.f;
+  const float osc = (p.out_scale ? p.out_scale[g * 2 + 1] : 1.f) * (p.x_scale ? p.x_scale[1] : 1.f);
+  const float* rg = p.res ? p.res + (long)g * p.y_gstride : nullptr;
   float csum[WN], csq[WN], bn[WN];
 #pragma unroll
   for (int j = 0; j < WN; ++j) {
@@ -274,6 +277,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
         const int n = n0 + (wn * WN + j) * 32 + (lane & 31);
         if (n < p.N) {
           float v = acc[i][j][e] * osc + bn[j];
+          if (rg) v += rg[pix * p.y_ld + n];
           csum[j] += v;
           csq[j] += v * v;
           if (p.act == 1) v = fmaxf(v, 0.f);
@@ -325,9 +329,11 @@ __device__ __forceinline__ void split_h(float v, _Float16& h, _Float16& l) {
 }
 
 // fp32 [rows][C] -> HL32 [rows][C/32][hi 32 | lo 32]; one thread = 8 channels (32 B in, 2 x 16 B out)
-__global__ __launch_bounds__(256) void split_hl32_kernel(const float* __restrict__ x, unsigned char* __restrict__ out, long n8) {
+__global__ __launch_bounds__(256) void split_hl32_kernel(const float* __restrict__ x, unsigned char* __restrict__ out, long n8,
+                                                         const float* __restrict__ scale) {
+  const float sc = scale ? scale[0] : 1.f;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(x + i * 8), b = *reinterpret_cast<const f32x4*>(x + i * 8 + 4);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(x + i * 8) * sc, b = *reinterpret_cast<const f32x4*>(x + i * 8 + 4) * sc;
     f16v8 h, l;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -406,8 +412,9 @@ MRN_EXPORT int64_t mrn_conv2d_x3_stats_floats(int G, int B, int Ho, int Wo, int 
 }
 
 // tile_m x tile_n: 256x256 (Cout >= 256), 256x128, or 128x128 (two workgroups per CU: short reductions)
-MRN_EXPORT int mrn_conv2d_x3_hl32(const void* x_hl, const void* w_hl, const void* zero_page, const float* bias, float* y,
-                                  float* stats, const float* out_scale, int G, int64_t x_group_stride_bytes, int B, int H,
+MRN_EXPORT int mrn_conv2d_x3_hl32(const void* x_hl, const void* w_hl, const void* zero_page, const float* bias,
+                                  const float* residual, float* y, float* stats, const float* out_scale,
+                                  const float* x_scale, int G, int64_t x_group_stride_bytes, int B, int H,
                                   int W, int Cin, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int act,
                                   int tile_m, int tile_n, int64_t y_row_stride, int64_t y_group_stride, void* stream) {
   MRN_CHECK_ARG(x_hl && w_hl && zero_page && y && G >= 1, "mrn_conv2d_x3_hl32: bad operands");
@@ -423,7 +430,7 @@ MRN_EXPORT int mrn_conv2d_x3_hl32(const void* x_hl, const void* w_hl, const void
   ConvX3Params p;
   memset(&p, 0, sizeof(p));
   p.x = (const unsigned char*)x_hl; p.w = (const unsigned char*)w_hl; p.zero = (const unsigned char*)zero_page;
-  p.bias = bias; p.out_scale = out_scale; p.y = y; p.stats = stats;
+  p.bias = bias; p.out_scale = out_scale; p.x_scale = x_scale; p.res = residual; p.y = y; p.stats = stats;
   p.Cb = Cin / 32; p.taps = kh * kw; p.nk = p.Cb * p.taps;
   p.x_gstride = x_group_stride_bytes; p.w_gstride = (long)Cout * p.nk * 128;
   p.x_bytes = (int)((long)B * H * W * Cin * 4);
@@ -445,14 +452,14 @@ MRN_EXPORT int mrn_conv2d_x3_hl32(const void* x_hl, const void* w_hl, const void
   return launch_x3<4, 2, 1, 2>(p, (hipStream_t)stream);
 }
 
-// fp32 [rows][C] (C % 32 == 0) -> HL32
-MRN_EXPORT int mrn_split_hl32_f32(const float* x, void* out, int64_t rows, int C, void* stream) {
+// fp32 [rows][C] (C % 32 == 0) -> HL32 of scale[0] * x (scale: device float[2] from mrn_pow2_scale_f32, or NULL)
+MRN_EXPORT int mrn_split_hl32_f32(const float* x, void* out, int64_t rows, int C, const float* scale, void* stream) {
   MRN_CHECK_ARG(x && out && C % 32 == 0, "mrn_split_hl32_f32: bad operands (C=%d)", C);
   const long n8 = rows * (C / 8);
   if (n8 == 0) return MRN_OK;
   long grid = (n8 + 255) / 256;
   if (grid > 16384) grid = 16384;
-  hipLaunchKernelGGL(split_hl32_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, (unsigned char*)out, n8);
+  hipLaunchKernelGGL(split_hl32_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, (unsigned char*)out, n8, scale);
   MRN_LAUNCH_CHECK("split_hl32");
   return MRN_OK;
 }

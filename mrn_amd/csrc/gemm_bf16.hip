@@ -471,18 +471,31 @@ __global__ void split_bf16_kernel(const float* __restrict__ w, unsigned short* _
   }
 }
 
-// scale[0] = 2^floor(log2(target / max|w|)), scale[1] = 1 / scale[0]   (single block)
-__global__ __launch_bounds__(256) void pow2_scale_kernel(const float* __restrict__ w, long n, float target, float* __restrict__ scale) {
+// scale[0] = 2^floor(log2(target / max|w|)), scale[1] = 1 / scale[0].  Three tiny launches, no workspace: scale[1] is
+// cleared, receives max|w| through atomicMax on its bit pattern (non-negative floats order like unsigned ints), and the
+// finalise kernel turns it into the pair.
+__global__ void pow2_clear_kernel(float* __restrict__ scale) { reinterpret_cast<unsigned*>(scale)[1] = 0u; }
+
+__global__ __launch_bounds__(256) void pow2_amax_kernel(const float* __restrict__ w, long n, float* __restrict__ scale) {
   __shared__ float scratch[4];
   float m = 0.f;
-  for (long i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(w[i]));
-  m = block_max<256>(m, scratch);
-  if (threadIdx.x == 0) {
-    float s = 1.f;
-    if (m > 0.f && isfinite(m)) s = exp2f(floorf(log2f(target / m)));
-    scale[0] = s;
-    scale[1] = 1.f / s;
+  const long n4 = n >> 2;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(w)[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
   }
+  if (blockIdx.x == 0)
+    for (long i = (n4 << 2) + threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(w[i]));
+  m = block_max<256>(m, scratch);
+  if (threadIdx.x == 0 && !(m <= 0.f)) atomicMax(reinterpret_cast<unsigned*>(scale) + 1, __float_as_uint(m));   // NaN / inf pass through
+}
+
+__global__ void pow2_finalize_kernel(float target, float* __restrict__ scale) {
+  const float m = scale[1];
+  float s = 1.f;
+  if (m > 0.f && isfinite(m)) s = exp2f(floorf(log2f(target / m)));
+  scale[0] = s;
+  scale[1] = 1.f / s;
 }
 
 }  // namespace
@@ -490,7 +503,12 @@ __global__ __launch_bounds__(256) void pow2_scale_kernel(const float* __restrict
 // scale[0] = largest power of two with scale*max|w| <= target, scale[1] = its inverse (both on the device)
 MRN_EXPORT int mrn_pow2_scale_f32(const float* w, int64_t n, float target, float* scale, void* stream) {
   MRN_CHECK_ARG(w && scale && target > 0.f, "mrn_pow2_scale_f32: bad operands");
-  hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, w, (long)n, target, scale);
+  MRN_CHECK_ARG((uintptr_t)w % 16 == 0, "mrn_pow2_scale_f32: operand must be 16-byte aligned");
+  long grid = (n / 4 + 255) / 256;
+  grid = grid < 1 ? 1 : (grid > 1024 ? 1024 : grid);
+  hipLaunchKernelGGL(pow2_clear_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, scale);
+  hipLaunchKernelGGL(pow2_amax_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, w, (long)n, scale);
+  hipLaunchKernelGGL(pow2_finalize_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, target, scale);
   MRN_LAUNCH_CHECK("pow2_scale");
   return MRN_OK;
 }

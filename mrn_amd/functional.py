@@ -14,11 +14,37 @@ from . import ops
 # ---------------------------------------------------------------------------------------------------------
 # GEMM helpers for backward passes
 # ---------------------------------------------------------------------------------------------------------
+def x3_eligible(x2, N, K):
+    return (ops.ROUTER_GEMM_PRECISION == "fp16x3" and K % 32 == 0 and N >= 64 and x2.is_contiguous()
+            and x2.shape[0] * max(N, K) * 4 < 2 ** 31)
+
+
+def x3_linear(x2, weight, bias=None, residual=None, act=ops.ACT_NONE):
+    """y = act(x2 @ weight^T + bias (+ residual)) on the split-fp16 x3 MFMA path, both operands prescaled on the device
+    (x2 [R,K] contiguous, weight [N,K]); 22-bit products, fp32 accumulation."""
+    R, K = x2.shape
+    N = weight.shape[0]
+    sx = ops.pow2_scale(x2)
+    w_hl, sw = ops.pack_weights_hl32([weight.detach().contiguous().view(N, 1, 1, K)])
+    y, _ = ops.conv2d_x3(ops.split_hl32(x2, sx), 1, False, R, 1, 1, K, w_hl, sw, N, (1, 1), bias=bias, act=act,
+                         residual=residual, x_scale=sx)
+    return y.view(R, N)
+
+
+def linear_fwd(x2, weight, bias=None, residual=None, act=ops.ACT_NONE):
+    """router Linear: split-fp16 x3 when eligible, exact fp32 otherwise"""
+    if x3_eligible(x2, weight.shape[0], weight.shape[1]) and (residual is None or residual.is_contiguous()):
+        return x3_linear(x2, weight, bias, residual, act)
+    return ops.linear(x2, weight, bias, act=act, residual=residual)
+
+
 def linear_dgrad(dy, weight, out=None, accumulate=False):
     """dx = dy @ weight ; dy rows [R, N], weight [N, K] -> [R, K]"""
     dy2 = ops.rows2d(dy)
     R, N = dy2.shape
     K = weight.shape[1]
+    if out is None and x3_eligible(dy2, K, N):
+        return x3_linear(dy2, weight.detach().t().contiguous())
     if out is None:
         out = torch.empty(R, K, device=dy.device, dtype=torch.float32)
         accumulate = False
@@ -94,7 +120,7 @@ class DMRouterFn(torch.autograd.Function):
         x = x.contiguous()
         X = x.view(R, C)
         xn, mu1, rs1 = ops.layernorm_fwd(X, n_w, n_b)
-        hpre = ops.linear(xn, w1, b1)
+        hpre = linear_fwd(xn, w1, b1)
         h = ops.ew_rows(ops.EW_GELU, hpre)
         u, v = h[:, :C], h[:, C:]
         vn, mu2, rs2 = ops.layernorm_fwd(v, sn_w, sn_b)
@@ -106,12 +132,12 @@ class DMRouterFn(torch.autograd.Function):
         # vp[b] = Wsp' . vn[b] + bsp'[:, None]
         ops.gemm_raw(wsp_p, vn, vp, N, C, N, B, (0, ldw, 1), (N * C, 1, C), (N * C, C, 1), bias=bsp_p, bias_axis=1)
         g = ops.ew_rows(ops.EW_MUL, u, vp)
-        y = ops.linear(g, w2, b2, residual=X)
+        y = linear_fwd(g, w2, b2, residual=X)
         y3 = y.view(B, P, I * C)
         zn, mu3, rs3 = ops.colnorm_fwd(y3, cn_w, cn_b)
-        zp = ops.linear(zn.view(B * P, I * C), wch, bch).view(R, C)
+        zp = linear_fwd(zn.view(B * P, I * C), wch, bch).view(R, C)
         z2 = ops.ew_rows(ops.EW_MUL, y, zp)
-        out = ops.linear(z2, w3, b3, residual=X)
+        out = linear_fwd(z2, w3, b3, residual=X)
         ctx.save_for_backward(X, n_w, w1, sn_w, w2, cn_w, wch, w3, mu1, rs1, xn, hpre, h, mu2, rs2, vn, wsp_p, vp, g, y,
                               mu3, rs3, zn, zp, z2, inv)
         ctx.dims = (B, P, I, C, ldw)

@@ -42,6 +42,11 @@ class KernelTimer:
 
 CONV_TIMER = None            # set to a KernelTimer by bench.py
 TIMER_SHAPES = False         # tools/layer_times.py: one timer kind per layer shape
+# Linear layers of the TRAINED router (DM-Router proj_1/2/3, channel gating; forward and data-gradient GEMMs):
+#   "fp16x3"  split-fp16 x3 on the grouped conv kernel with BOTH operands prescaled by a power of two computed on the
+#             device from max|.| (gradients of 1e-6 would otherwise fall into fp16's subnormal range)
+#   "f32"     exact fp32 MFMA
+ROUTER_GEMM_PRECISION = "fp16x3"
 
 # Arithmetic of the large implicit-GEMM convs (Cout > 64, K % 32 == 0):
 #   "f32"    exact fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere
@@ -278,14 +283,24 @@ def x3_tile(Cout, K):
     return (128, 128) if K <= X3_SMALL_TILE_MAX_K else (256, 128)
 
 
-def split_hl32(x):
-    """fp32 [..., C] (C % 32 == 0, contiguous) -> HL32 bytes (same byte count), one 128-B line per (row, 32 channels)"""
+def split_hl32(x, scale=None):
+    """fp32 [..., C] (C % 32 == 0, contiguous) -> HL32 bytes (same byte count), one 128-B line per (row, 32 channels);
+    scale: device float[2] {s, 1/s}: the halves hold s * x (pass the same tensor to conv2d_x3 as x_scale)"""
     _chk(x)
     C = x.shape[-1]
     rows = x.numel() // C
     out = torch.empty(x.numel() * 4, device=x.device, dtype=torch.uint8)
-    call("mrn_split_hl32_f32", _p(x), _p(out), rows, C, _stream())
+    call("mrn_split_hl32_f32", _p(x), _p(out), rows, C, _p(scale), _stream())
     return out
+
+
+def pow2_scale(x, target=FP16_WEIGHT_PEAK):
+    """device float[2] = {s, 1/s}, s = the largest power of two with s * max|x| <= target (no host sync)"""
+    _chk(x)
+    assert x.is_contiguous()
+    scale = torch.empty(2, device=x.device, dtype=torch.float32)
+    call("mrn_pow2_scale_f32", _p(x), x.numel(), float(target), _p(scale), _stream())
+    return scale
 
 
 def pack_weights_hl32(ws):
@@ -305,7 +320,7 @@ def pack_weights_hl32(ws):
 
 
 def conv2d_x3(x_hl, G, shared_input, B, H, W, Cin, w_hl, w_scale, Cout, ksize, stride=(1, 1), padding=(0, 0), bias=None,
-              act=ACT_NONE, want_stats=False, out=None, out_row_stride=0, out_group_stride=0):
+              act=ACT_NONE, want_stats=False, out=None, out_row_stride=0, out_group_stride=0, residual=None, x_scale=None):
     """Grouped conv on HL32 operands -> (y [G,B,Ho,Wo,Cout] fp32, stats or None).  With `out` and the two strides (floats)
     the rows of group g land at out.data_ptr + g * out_group_stride + row * out_row_stride."""
     kh, kw = ksize
@@ -319,7 +334,8 @@ def conv2d_x3(x_hl, G, shared_input, B, H, W, Cin, w_hl, w_scale, Cout, ksize, s
     gstride = 0 if shared_input else B * H * W * Cin * 4
     timed = CONV_TIMER is not None
     t0 = CONV_TIMER.begin() if timed else None
-    call("mrn_conv2d_x3_hl32", _p(x_hl), _p(w_hl), _p(_zero_page(dev)), _p(bias), _p(y), _p(stats), _p(w_scale), G, gstride,
+    call("mrn_conv2d_x3_hl32", _p(x_hl), _p(w_hl), _p(_zero_page(dev)), _p(bias), _p(residual), _p(y), _p(stats), _p(w_scale),
+         _p(x_scale), G, gstride,
          B, H, W, Cin, Cout, kh, kw, stride[0], stride[1], padding[0], padding[1], act, tile_m, tile_n, out_row_stride, out_group_stride,
          _stream())
     if timed:
