@@ -95,14 +95,16 @@ int mrn_pack_weight_hl32(const float* w_ohwi, void* out, int Cout, int taps, int
  * mrn_bn_finalize_grouped_f32: train-mode BatchNorm2d statistics for G modules at once; partials [G][nblk][2][C] from
  *   the conv epilogue; ptrs = device table [4][G] of device pointers {gamma, beta, running_mean, running_var} (NULL
  *   entries allowed); scale / shift [G][C].  Same arithmetic as mrn_bn_finalize_f32.
- * mrn_bn_apply_grouped_f32: out = relu?(y * scale[g] + shift[g] (+ residual)) over [G][rows_per_group][C]; writes the
+ * mrn_bn_apply_grouped_f32: out = relu?(y * scale[g] + shift[g] (+ residual)) over [G][rows_per_group][C] (residual as
+ *   fp32, or as the HL32 image the identity shortcut's source already exists in: hi + lo is added); writes the
  *   fp32 tensor (out_f32, may alias y) and / or the HL32 operand of the next convolution (out_hl32, C % 32 == 0).
  * mrn_maxpool_grouped_f32: the same with MaxPool2d (padding = -inf) applied after the affine + ReLU.
  * modules/feature_extraction.py:171-199,222-294; modules/transformation.py:69-81. */
 int mrn_bn_finalize_grouped_f32(const float* partials, int G, int nblk, int C, int64_t count, const void* const* ptrs,
                                 float momentum, float eps, float* scale, float* shift, void* stream);
-int mrn_bn_apply_grouped_f32(const float* y, const float* residual, const float* scale, const float* shift,
-                             float* out_f32, void* out_hl32, int G, int64_t rows_per_group, int C, int relu, void* stream);
+int mrn_bn_apply_grouped_f32(const float* y, const float* residual, const void* residual_hl32, const float* scale,
+                             const float* shift, float* out_f32, void* out_hl32, int G, int64_t rows_per_group, int C,
+                             int relu, void* stream);
 int mrn_maxpool_grouped_f32(const float* x, const float* scale, const float* shift, int relu, float* out_f32,
                             void* out_hl32, int G, int B, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw,
                             void* stream);

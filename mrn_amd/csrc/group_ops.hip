@@ -81,8 +81,22 @@ __global__ __launch_bounds__(256) void bn_finalize_grouped_kernel(const float* _
   }
 }
 
-// out = act(y * scale[g][c] + shift[g][c] (+ res)); one lane = 8 channels
+// 8 consecutive channels of row `row` from an HL32 image: value = hi + lo
+__device__ __forceinline__ F8 load_hl(const unsigned char* hl, long row, int C, int c8) {
+  const unsigned char* o = hl + (row * (C >> 5) + (c8 >> 2)) * 128 + (c8 & 3) * 16;
+  const f16v8 h = *reinterpret_cast<const f16v8*>(o), l = *reinterpret_cast<const f16v8*>(o + 64);
+  F8 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    v.a[e] = (float)h[e] + (float)l[e];
+    v.b[e] = (float)h[4 + e] + (float)l[4 + e];
+  }
+  return v;
+}
+
+// out = act(y * scale[g][c] + shift[g][c] (+ res)); one lane = 8 channels; the residual comes as fp32 or as an HL32 image
 __global__ __launch_bounds__(256) void bn_apply_grouped_kernel(const float* __restrict__ y, const float* __restrict__ res,
+                                                               const unsigned char* __restrict__ res_hl,
                                                                const float* __restrict__ scale, const float* __restrict__ shift,
                                                                float* __restrict__ out, unsigned char* __restrict__ out_hl,
                                                                long rows_per_group, long n8, int C, int relu) {
@@ -100,8 +114,8 @@ __global__ __launch_bounds__(256) void bn_apply_grouped_kernel(const float* __re
         v.b[e] = v.b[e] * sc.b[e] + sh.b[e];
       }
     }
-    if (res) {
-      const F8 r = load8(res + i * 8);
+    if (res || res_hl) {
+      const F8 r = res ? load8(res + i * 8) : load_hl(res_hl, row, C, c8);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         v.a[e] += r.a[e];
@@ -192,18 +206,21 @@ MRN_EXPORT int mrn_bn_finalize_grouped_f32(const float* partials, int G, int nbl
   return MRN_OK;
 }
 
-// out = act(y * scale[g] + shift[g] (+ residual)) over [G][rows_per_group][C]; scale/shift may be NULL (identity);
+// out = act(y * scale[g] + shift[g] (+ residual)) over [G][rows_per_group][C]; scale/shift may be NULL (identity); the
+// residual is given as fp32 (residual) or as an HL32 image (residual_hl32: hi + lo is added, 22 significand bits);
 // out_f32 and / or out_hl32 (C % 32 == 0) receive the result; out_f32 may alias y.  relu: 0 / 1.
-MRN_EXPORT int mrn_bn_apply_grouped_f32(const float* y, const float* residual, const float* scale, const float* shift,
-                                        float* out_f32, void* out_hl32, int G, int64_t rows_per_group, int C, int relu,
-                                        void* stream) {
-  MRN_CHECK_ARG(y && (out_f32 || out_hl32) && C % 8 == 0 && (!out_hl32 || C % 32 == 0) && (!scale == !shift),
+MRN_EXPORT int mrn_bn_apply_grouped_f32(const float* y, const float* residual, const void* residual_hl32, const float* scale,
+                                        const float* shift, float* out_f32, void* out_hl32, int G, int64_t rows_per_group,
+                                        int C, int relu, void* stream) {
+  MRN_CHECK_ARG(y && (out_f32 || out_hl32) && C % 8 == 0 && (!(out_hl32 || residual_hl32) || C % 32 == 0) &&
+                    (!scale == !shift) && !(residual && residual_hl32),
                 "mrn_bn_apply_grouped_f32: bad operands (C=%d)", C);
   const long n8 = (long)G * rows_per_group * (C / 8);
   if (n8 == 0) return MRN_OK;
   long grid = (n8 + 255) / 256;
   if (grid > 32768) grid = 32768;
-  hipLaunchKernelGGL(bn_apply_grouped_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, y, residual, scale, shift,
+  hipLaunchKernelGGL(bn_apply_grouped_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, y, residual,
+                     (const unsigned char*)residual_hl32, scale, shift,
                      out_f32, (unsigned char*)out_hl32, (long)rows_per_group, n8, C, relu);
   MRN_LAUNCH_CHECK("bn_apply_grouped");
   return MRN_OK;

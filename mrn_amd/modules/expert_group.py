@@ -20,6 +20,9 @@ from .. import ops
 from ._nn import _pair, packed_weight, to_nhwc
 
 
+RESIDUAL_FROM_F32 = bool(int(__import__("os").environ.get("MRN_RESIDUAL_F32", "0")))      # True: keep an fp32 copy of every identity-shortcut source (one extra 4 B/element write)
+
+
 class Act:
     """A [G,B,H,W,C] activation stack: fp32 tensor and / or HL32 bytes.  shared=True: one [B,H,W,C] input for all groups."""
 
@@ -153,16 +156,19 @@ class BackboneGroup(_GroupedLinear):
                 ss = [ops.bn_eval_affine(b.weight, b.bias, b.running_mean, b.running_var, b.eps) for b in bns]
                 scale = torch.stack([s for s, _ in ss]).contiguous()
                 shift = torch.stack([s for _, s in ss]).contiguous()
+        # identity shortcut: the fp32 tensor when it exists, else the HL32 image (hi + lo) the block input already has
         res = residual.f32 if residual is not None else None
+        res_hl = residual.hl if residual is not None and res is None else None
         post_relu = relu and not fuse_act
         if pool is not None:
-            assert res is None
+            assert res is None and res_hl is None
             f32, hl, (Hp, Wp) = ops.maxpool_grouped(y, pool[0], pool[1], pool[2], scale, shift, relu=post_relu,
                                                     want_f32=want_f32, want_hl=want_hl)
             return Act((G, B, Hp, Wp, Cout), f32, hl)
-        if scale is None and res is None and not post_relu and not want_hl:
+        if scale is None and res is None and res_hl is None and not post_relu and not want_hl:
             return Act((G, B, Ho, Wo, Cout), y, None)
-        f32, hl = ops.bn_apply_grouped(y, scale, shift, relu=post_relu, residual=res, want_f32=want_f32, want_hl=want_hl)
+        f32, hl = ops.bn_apply_grouped(y, scale, shift, relu=post_relu, residual=res, want_f32=want_f32, want_hl=want_hl,
+                                       residual_hl=res_hl)
         return Act((G, B, Ho, Wo, Cout), f32, hl)
 
     # ---- network programs ---------------------------------------------------------------------------------------
@@ -173,7 +179,7 @@ class BackboneGroup(_GroupedLinear):
                              want_f32=True, want_hl=False)
         else:
             res = x
-            assert res.f32 is not None
+            assert res.f32 is not None or res.hl is not None
         return self.layer(out, [b.conv2 for b in blocks], [b.bn2 for b in blocks], relu=True, residual=res,
                           want_f32=next_needs_f32, want_hl=True)
 
@@ -197,13 +203,12 @@ class BackboneGroup(_GroupedLinear):
             blocks = [list(getattr(n, name)) for n in nets]
             nb = len(blocks[0])
             for i in range(nb):
-                # the next consumer needs the fp32 tensor only when it is a block with an identity shortcut
-                nxt_identity = i + 1 < nb and blocks[0][i + 1].downsample is None
-                x = self._basic_block(x, [b[i] for b in blocks], nxt_identity)
+                # identity shortcuts read the block input back from its HL32 image: no fp32 copy is ever written
+                x = self._basic_block(x, [b[i] for b in blocks], RESIDUAL_FROM_F32 and i + 1 < nb and blocks[0][i + 1].downsample is None)
             return x
 
         def first_block_identity(name):
-            return getattr(n0, name)[0].downsample is None
+            return RESIDUAL_FROM_F32 and getattr(n0, name)[0].downsample is None
 
         x = self.layer(x, [n.conv0_1 for n in nets], [n.bn0_1 for n in nets])
         x = self.layer(x, [n.conv0_2 for n in nets], [n.bn0_2 for n in nets], pool=p22, want_f32=first_block_identity("layer1"))

@@ -358,12 +358,13 @@ def bn_finalize_grouped(stats, G, C, count, ptr_table, momentum, eps):
     return scale, shift
 
 
-def bn_apply_grouped(y, scale, shift, relu=True, residual=None, want_f32=True, want_hl=False):
+def bn_apply_grouped(y, scale, shift, relu=True, residual=None, want_f32=True, want_hl=False, residual_hl=None):
     """y [G,...,C] fp32 -> (fp32 result (in place) or None, HL32 bytes or None)"""
     G, C = y.shape[0], y.shape[-1]
     rows = y.numel() // (G * C)
     out_hl = torch.empty(y.numel() * 4, device=y.device, dtype=torch.uint8) if want_hl else None
-    call("mrn_bn_apply_grouped_f32", _p(y), _p(residual), _p(scale), _p(shift), _p(y) if want_f32 else None, _p(out_hl), G, rows,
+    call("mrn_bn_apply_grouped_f32", _p(y), _p(residual), _p(residual_hl), _p(scale), _p(shift), _p(y) if want_f32 else None,
+         _p(out_hl), G, rows,
          C, int(bool(relu)), _stream())
     return (y if want_f32 else None), out_hl
 

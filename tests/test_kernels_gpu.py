@@ -402,6 +402,9 @@ def test_grouped_x3_conv_bn_pool(ops, cfg):
     for g in range(G):
         assert_close(f"grouped bn apply g{g}", f32[g].permute(0, 3, 1, 2), bn_ref[g], atol=5e-5, rtol=1e-5)
     if want_hl:
+        # identity shortcut read back from an HL32 image (hi + lo, 22 bits) instead of the fp32 tensor
+        f2, _ = ops.bn_apply_grouped(y.clone(), scale, shift, relu=True, residual_hl=ops.split_hl32(resn), want_f32=True)
+        assert_close("grouped bn apply, HL32 residual", f2, f32, atol=1e-6, rtol=1e-6)
         # the HL32 operand is hi + lo of the same values, laid out [row][C/32][hi x 32 | lo x 32]
         v = hl.view(torch.float16).view(-1, Cout // 32, 2, 32).float()
         assert_close("HL32 image", (v[:, :, 0] + v[:, :, 1]).reshape(f32.shape), f32, atol=1e-6, rtol=2e-7)
