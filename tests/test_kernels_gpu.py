@@ -437,3 +437,22 @@ def test_grouped_recurrences_match_single_launches(ops):
     for g in range(G):
         ref = ops.attn_decoder(Hb[g], Hproj[g], eproj[g], w_h2h[g], b_h2h[g], w_score[g], w_ih[g], w_hh2[g], b_hh2[g], Hd)
         assert torch.equal(hid[g], ref)
+
+
+@pytest.mark.parametrize("magnitude", [1.0, 3e-6, 2e4])
+def test_range_safe_x3_linear(ops, magnitude):
+    """functional.x3_linear (router Linear layers): both operands prescaled by a device-computed power of two, so
+    gradient-sized (1e-6) and large (1e4) operands keep fp32-class accuracy on the fp16 MFMA path"""
+    from mrn_amd import functional as Fn
+    R, K, N = 1000, 256, 320
+    x, w, b, res = rnd(R, K, seed=210) * magnitude, rnd(N, K, seed=211) * 0.07, rnd(N, seed=212) * magnitude, rnd(R, N, seed=213) * magnitude
+    ref = (x.double() @ w.double().t() + b.double() + res.double())
+    y = Fn.x3_linear(cu(x), cu(w), cu(b), residual=cu(res))
+    assert_close("x3 linear", y.cpu().double(), ref, atol=3e-6 * magnitude, rtol=1e-6)
+    # data gradient form: dy @ W
+    dy = rnd(R, N, seed=214) * magnitude
+    dx = Fn.linear_dgrad(cu(dy), cu(w))
+    assert_close("x3 dgrad", dx.cpu().double(), dy.double() @ w.double(), atol=3e-6 * magnitude, rtol=1e-6)
+    s = ops.pow2_scale(cu(x))
+    m = float(x.abs().max())
+    assert 8192.0 < float(s[0]) * m <= 16384.0 and abs(float(s[0]) * float(s[1]) - 1.0) < 1e-7
