@@ -89,6 +89,9 @@ int mrn_conv2d_x3_hl32(const void* x_hl, const void* w_hl, const void* zero_page
                        int64_t y_row_stride, int64_t y_group_stride, void* stream);
 int64_t mrn_conv2d_x3_stats_floats(int G, int B, int Ho, int Wo, int Cout, int tile_m);
 int mrn_split_hl32_f32(const float* x, void* out, int64_t rows, int C, const float* scale, void* stream);
+/* transposed split for weight-gradient GEMMs (dW = dy^T x reduces over rows): x[rows][C] -> [splits][C][rows/splits/32][128 B],
+ * i.e. `splits` HL32 matrices whose reduction axis is a row chunk (split-K = the conv's group dimension) */
+int mrn_split_hl32_t_f32(const float* x, void* out, int64_t rows, int C, int splits, const float* scale, void* stream);
 int mrn_pack_weight_hl32(const float* w_ohwi, void* out, int Cout, int taps, int Cin, const float* scale, void* stream);
 
 /* Elementwise passes between grouped convolutions (G frozen experts in lock-step).

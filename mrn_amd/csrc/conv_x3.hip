@@ -350,6 +350,45 @@ __global__ __launch_bounds__(256) void split_hl32_kernel(const float* __restrict
   }
 }
 
+// Transposed split for weight-gradient GEMMs (dW = dy^T x reduces over ROWS): fp32 x[rows][C] -> `splits` HL32 matrices
+// out[s][c][rps/32][hi 32 | lo 32] with rps = rows / splits, element (c, r) = scale * x[s*rps + r][c].  One block moves a
+// 32-row x 32-column tile through LDS: coalesced 128-byte row reads, one 128-byte HL32 line per column written.
+__global__ __launch_bounds__(256) void split_hl32_t_kernel(const float* __restrict__ x, unsigned char* __restrict__ out, int C,
+                                                           long rps32, long tiles_c, long ntiles, const float* __restrict__ scale) {
+  __shared__ float tile[32][33];
+  const float sc = scale ? scale[0] : 1.f;
+  const int t = threadIdx.x;
+  for (long id = blockIdx.x; id < ntiles; id += gridDim.x) {
+    const long rb = id / tiles_c;                 // 32-row block (global)
+    const int c0 = (int)(id - rb * tiles_c) * 32;
+    {
+      const int r = t >> 3, c4 = (t & 7) * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (c0 + c4 < C) v = *reinterpret_cast<const f32x4*>(x + (rb * 32 + r) * C + c0 + c4);
+      tile[r][c4 + 0] = v[0] * sc; tile[r][c4 + 1] = v[1] * sc; tile[r][c4 + 2] = v[2] * sc; tile[r][c4 + 3] = v[3] * sc;
+    }
+    __syncthreads();
+    {
+      const int c = t >> 3, seg = t & 7;          // column c, rows seg*4 .. +3
+      if (c0 + c < C) {
+        const long s_ = rb / rps32, rl = rb - s_ * rps32;
+        unsigned char* o = out + ((s_ * C + c0 + c) * rps32 + rl) * 128 + seg * 8;
+        typedef _Float16 f16v4 __attribute__((ext_vector_type(4)));
+        f16v4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          _Float16 hh, ll;
+          split_h(tile[seg * 4 + e][c], hh, ll);
+          h[e] = hh; l[e] = ll;
+        }
+        *reinterpret_cast<f16v4*>(o) = h;
+        *reinterpret_cast<f16v4*>(o + 64) = l;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // w [Cout][taps][Cin] fp32 (x scale[0]) -> [Cout][Cin/32][taps][hi 32 | lo 32]; one thread = 8 channels
 __global__ __launch_bounds__(256) void pack_weight_hl32_kernel(const float* __restrict__ w, unsigned char* __restrict__ out,
                                                                int Cout, int taps, int Cin, const float* __restrict__ scale) {
@@ -475,5 +514,20 @@ MRN_EXPORT int mrn_pack_weight_hl32(const float* w_ohwi, void* out, int Cout, in
   hipLaunchKernelGGL(pack_weight_hl32_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, w_ohwi,
                      (unsigned char*)out, Cout, taps, Cin, scale);
   MRN_LAUNCH_CHECK("pack_weight_hl32");
+  return MRN_OK;
+}
+
+// fp32 x[rows][C] (C % 4 == 0) -> `splits` transposed HL32 matrices [splits][C][rows/splits/32][128 B] of scale[0] * x
+// (rows % (32 * splits) == 0): the operand layout of a weight-gradient GEMM that reduces over rows, split-K = groups.
+MRN_EXPORT int mrn_split_hl32_t_f32(const float* x, void* out, int64_t rows, int C, int splits, const float* scale,
+                                    void* stream) {
+  MRN_CHECK_ARG(x && out && splits >= 1 && C % 4 == 0 && rows % (32L * splits) == 0,
+                "mrn_split_hl32_t_f32: bad operands (rows=%ld C=%d splits=%d)", (long)rows, C, splits);
+  if (rows == 0 || C == 0) return MRN_OK;
+  const long tiles_c = (C + 31) / 32, ntiles = rows / 32 * tiles_c;
+  long grid = ntiles > 65536 ? 65536 : ntiles;
+  hipLaunchKernelGGL(split_hl32_t_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, (unsigned char*)out, C,
+                     (long)(rows / splits / 32), tiles_c, ntiles, scale);
+  MRN_LAUNCH_CHECK("split_hl32_t");
   return MRN_OK;
 }

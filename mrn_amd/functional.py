@@ -63,11 +63,32 @@ def _pick_split(R, tiles, target=1024, min_rows=128):
     return 1
 
 
+def x3_wgrad(dy2, x2):
+    """dW = dy2^T @ x2 on the split-fp16 x3 path: both operands transposed-split (reduction axis = rows) with device
+    prescales; split-K chunks are the grouped conv's groups, partial slabs reduced by a column-sum pass."""
+    R, N = dy2.shape
+    K = x2.shape[1]
+    blocks = R // 32
+    tiles = ((N + 255) // 256) * ((K + 255) // 256)
+    want = max(1, min(512 // tiles, blocks // 8))
+    S = next(s for s in range(want, 0, -1) if blocks % s == 0)
+    rps = R // S
+    sd, sx = ops.pow2_scale(dy2), ops.pow2_scale(x2)
+    a_hl = ops.split_hl32_t(dy2, S, sd)                      # [S][N][rps/32][128]: "activation" rows = n
+    w_hl = ops.split_hl32_t(x2, S, sx)                       # [S][K][rps/32][128]: "weight" rows = k
+    part, _ = ops.conv2d_x3(a_hl, S, False, N, 1, 1, rps, w_hl, sx.view(1, 2).expand(S, 2).contiguous(), K, (1, 1), x_scale=sd)
+    part = part.view(S, N * K)
+    return (ops.colsum(part) if S > 1 else part[0]).view(N, K)
+
+
 def linear_wgrad(dy, x):
     """dW[n][k] = sum_r dy[r][n] * x[r][k] with split-K over r (partials reduced by a column-sum pass)."""
     dy2, x2 = ops.rows2d(dy), ops.rows2d(x)
     R, N = dy2.shape
     K = x2.shape[1]
+    if (ops.ROUTER_GEMM_PRECISION == "fp16x3" and ops.ROUTER_WGRAD_X3 and R % 32 == 0 and R >= 4096 and K >= 64 and N >= 64 and N % 4 == 0 and K % 4 == 0
+            and dy2.is_contiguous() and x2.is_contiguous()):
+        return x3_wgrad(dy2, x2)
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     S = _pick_split(R, tiles)
     Rc = R // S

@@ -47,6 +47,7 @@ TIMER_SHAPES = False         # tools/layer_times.py: one timer kind per layer sh
 #             device from max|.| (gradients of 1e-6 would otherwise fall into fp16's subnormal range)
 #   "f32"     exact fp32 MFMA
 ROUTER_GEMM_PRECISION = "fp16x3"
+ROUTER_WGRAD_X3 = __import__("os").environ.get("MRN_WGRAD", "fp16x3") == "fp16x3"     # weight-gradient GEMMs too (A/B switch)
 
 # Arithmetic of the large implicit-GEMM convs (Cout > 64, K % 32 == 0):
 #   "f32"    exact fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere
@@ -291,6 +292,16 @@ def split_hl32(x, scale=None):
     rows = x.numel() // C
     out = torch.empty(x.numel() * 4, device=x.device, dtype=torch.uint8)
     call("mrn_split_hl32_f32", _p(x), _p(out), rows, C, _p(scale), _stream())
+    return out
+
+
+def split_hl32_t(x2, splits, scale=None):
+    """fp32 [rows, C] -> `splits` transposed HL32 matrices [splits][C][rows/splits/32][128 B] of scale[0] * x"""
+    _chk(x2)
+    rows, C = x2.shape
+    assert x2.is_contiguous() and rows % (32 * splits) == 0
+    out = torch.empty(rows * C * 4, device=x2.device, dtype=torch.uint8)
+    call("mrn_split_hl32_t_f32", _p(x2), _p(out), rows, C, splits, _p(scale), _stream())
     return out
 
 

@@ -456,3 +456,14 @@ def test_range_safe_x3_linear(ops, magnitude):
     s = ops.pow2_scale(cu(x))
     m = float(x.abs().max())
     assert 8192.0 < float(s[0]) * m <= 16384.0 and abs(float(s[0]) * float(s[1]) - 1.0) < 1e-7
+
+
+@pytest.mark.parametrize("magnitude", [1.0, 3e-6])
+def test_x3_weight_gradient(ops, magnitude):
+    """functional.x3_wgrad: dW = dy^T x through mrn_split_hl32_t_f32 (transposed split, split-K = groups)"""
+    from mrn_amd import functional as Fn
+    R, N, K = 8320, 320, 256
+    dy, x = rnd(R, N, seed=220) * magnitude, rnd(R, K, seed=221)
+    ref = dy.double().t() @ x.double()
+    dw = Fn.linear_wgrad(cu(dy), cu(x))
+    assert_close("x3 wgrad", dw.cpu().double(), ref, atol=2e-5 * magnitude, rtol=1e-6)
