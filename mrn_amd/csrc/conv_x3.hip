@@ -45,10 +45,11 @@ struct ConvX3Params {
   long y_gstride, y_ld;       // output group stride / row pitch in floats
   int x_bytes;                // bytes of one group's activation
   int G, M, N, Cb, taps, nk;  // nk = Cb * taps = K-steps of the full reduction (weight row length in 128-byte lines)
-  int H, W, Ho, Wo, kw, sh, sw, ph, pw, act;
+  int H, W, Ho, Wo, kh, kw, sh, sw, ph, pw, act;
   int tilesM, tilesN;
   int oy_major, BWo;           // image-row-major GEMM row order: m = (oy * B + b) * Wo + ox
   int tiles_per_row;           // > 0: B * Wo is a multiple of the tile height and tiles are visited row-of-image fastest
+  int class_order;             // interior-row tiles before border-row tiles inside every XCD's share
   unsigned wo_magic, bw_magic; // fast_div constants for Wo and B * Wo
   int wo_shift, bw_shift;
 };
@@ -98,15 +99,41 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
   constexpr int STAGE = (BM + BN) * 128;
   extern __shared__ __attribute__((aligned(128))) unsigned char lds[];
 
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_n = lid % p.tilesN;
-  const int t2 = lid / p.tilesN;
-  int tile_m = t2 % p.tilesM;
-  const int g = t2 / p.tilesM;
-  // image-row-major order with whole tiles per image row: consecutive workgroups take the SAME image block at successive
-  // output rows (they share the input rows their kernel taps overlap in L2), and every XCD's contiguous share of tiles
-  // holds the same mix of short (border row, padded taps skipped) and long tiles
-  if (p.tiles_per_row > 0) tile_m = (tile_m % p.Ho) * p.tiles_per_row + tile_m / p.Ho;
+  int lid = xcd_remap(blockIdx.x, gridDim.x);
+  int tile_n, tile_m, g;
+  if (p.tiles_per_row > 0 && p.class_order) {
+    // Image-row-major order with whole tiles per image row, two tile classes: INTERIOR rows run the full reduction,
+    // BORDER rows (oy = 0, Ho-1) skip the kernel rows that fall into the padding (2/3 of the K-steps for 3x3, pad 1).
+    // Every XCD's contiguous share [a, b) of the tile list gets its proportional part of both classes, interior tiles
+    // first: the XCDs finish together (equal work), and the workgroups of an XCD walk the weight matrix in lock-step
+    // (same class => same K-step sequence), which keeps the weight stream an L2 hit instead of three phases thrashing it.
+    const int nwg = gridDim.x, q8 = nwg / 8, r8 = nwg % 8, xcd = blockIdx.x % 8;
+    const int a = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int b = a + (xcd < r8 ? q8 + 1 : q8);
+    const int n_int = p.Ho - 2;                                   // interior rows per image (Ho >= 3 guaranteed by the host)
+    const long T = nwg, nl = (long)p.G * p.tiles_per_row * n_int * p.tilesN;
+    const int li0 = (int)((long)a * nl / T), li1 = (int)((long)b * nl / T);
+    const int u = lid - a;
+    const bool interior = u < li1 - li0;
+    const int idx = interior ? li0 + u : (a - li0) + (u - (li1 - li0));
+    const int rows_in_class = interior ? n_int : 2;
+    int row_sel;
+    tile_n = idx % p.tilesN;
+    int t2 = idx / p.tilesN;
+    row_sel = t2 % rows_in_class;
+    t2 /= rows_in_class;
+    const int j = t2 % p.tiles_per_row;
+    g = t2 / p.tiles_per_row;
+    const int oy = interior ? 1 + row_sel : (row_sel == 0 ? 0 : p.Ho - 1);
+    tile_m = oy * p.tiles_per_row + j;
+  } else {
+    tile_n = lid % p.tilesN;
+    const int t2 = lid / p.tilesN;
+    tile_m = t2 % p.tilesM;
+    g = t2 / p.tilesM;
+    // whole tiles per image row: consecutive workgroups take the SAME image block at successive output rows
+    if (p.tiles_per_row > 0) tile_m = (tile_m % p.Ho) * p.tiles_per_row + tile_m / p.Ho;
+  }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -436,6 +463,7 @@ int launch_x3(const ConvX3Params& p0, hipStream_t st) {
   p.tilesM = ceil_div(p.M, BM);
   p.tilesN = ceil_div(p.N, BN);
   p.tiles_per_row = (p.oy_major && p.BWo % BM == 0 && !getenv("MRN_X3_NO_INTERLEAVE")) ? p.BWo / BM : 0;
+  p.class_order = (p.tiles_per_row > 0 && p.Ho >= 3 && p.kh == 3 && p.ph == 1 && p.sh == 1 && !getenv("MRN_X3_NO_CLASS_ORDER")) ? 1 : 0;
   const size_t ldsz = 2 * (size_t)(BM + BN) * 128;
   const long tiles = (long)p.G * p.tilesM * p.tilesN;
   (void)hipFuncSetAttribute((const void*)conv_x3_kernel<WAVES_M, WAVES_N, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);
@@ -476,7 +504,7 @@ MRN_EXPORT int mrn_conv2d_x3_hl32(const void* x_hl, const void* w_hl, const void
   p.G = G; p.M = B * Ho * Wo; p.N = Cout;
   p.y_ld = y_row_stride > 0 ? y_row_stride : Cout;
   p.y_gstride = y_group_stride > 0 ? y_group_stride : (long)p.M * p.y_ld;
-  p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.kw = kw; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw; p.act = act;
+  p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.kh = kh; p.kw = kw; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw; p.act = act;
   if (p.M == 0) return MRN_OK;
   // image-row-major tiles pay off when the kernel is padded vertically and the maps are only a few rows high (the TRBA
   // backbone's 4 x 65 maps: the two border rows skip one of three kernel rows)
