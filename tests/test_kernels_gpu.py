@@ -360,7 +360,7 @@ X3_CONVS = [
     (1, 3, 6, 10, 96, 320, (3, 3), (2, 2), (1, 1), False),      # strides, N not a tile multiple
     (6, 2, 4, 65, 512, 512, (3, 3), (1, 1), (1, 1), False),     # the dominant TRBA shape
     (3, 8, 4, 64, 64, 256, (3, 3), (1, 1), (1, 1), False),      # whole tiles per image row: class-ordered tile schedule
-    (2, 4, 8, 64, 32, 300, (3, 3), (1, 1), (1, 1), False),      #   (interior rows first, border rows skip padded taps)
+    (2, 4, 8, 64, 32, 320, (3, 3), (1, 1), (1, 1), False),      #   (interior rows first, border rows skip padded taps)
     (5, 4, 3, 64, 64, 128, (3, 3), (1, 1), (1, 1), False),      #   one interior row, tile count not a multiple of 8
 ]
 
