@@ -282,6 +282,9 @@ class MRNNet(nn.Module):
         self._stream_pool = []
         self._group = None
         self._heads = None
+        self._halves = None
+        self.expert_halves = int(__import__("os").environ.get("MRN_EXPERT_HALVES", "2"))      # concurrent lock-step sub-groups
+        #   (measured on TRBA x 6, MI355X: 1 group 1.00, 2 halves on two streams 1.044, 3 thirds 1.015, staggered halves 1.035)
 
     def _streams(self, n, device):
         while len(self._stream_pool) < n:
@@ -298,6 +301,24 @@ class MRNNet(nn.Module):
         if self._group is None or self._group[0] != key:
             self._group = (key, expert_group.BackboneGroup(extractors))
         return self._group[1] if expert_group.supported(extractors) else None
+
+    def _half_groups(self, is_train):
+        """[(lo, hi, BackboneGroup, HeadsGroup)] per sub-group when the experts are split into `expert_halves` lock-step
+        groups that run on separate streams, else None"""
+        from . import expert_group
+        I = len(self.model)
+        k = self.expert_halves
+        if k < 2 or I < 2 * k:
+            return None
+        key = tuple(id(e) for e in self.model) + (k,)
+        if self._halves is None or self._halves[0] != key:
+            cuts = [I * i // k for i in range(k + 1)]
+            parts = []
+            for lo, hi in zip(cuts[:-1], cuts[1:]):
+                models = list(self.model)[lo:hi]
+                parts.append((lo, hi, expert_group.BackboneGroup([m.model for m in models]), expert_group.HeadsGroup(models)))
+            self._halves = (key, parts)
+        return self._halves[1]
 
     def _heads_group(self, group, is_train):
         """HeadsGroup (SequenceModeling + Prediction of all experts in lock-step) when `group` exists and the heads allow it"""
@@ -333,7 +354,20 @@ class MRNNet(nn.Module):
         with torch.no_grad():
             group = self._backbone_group() if I > 1 else None
             heads = self._heads_group(group, is_train)
-            if heads is not None:
+            halves = self._half_groups(is_train) if heads is not None else None
+            if halves is not None:
+                # two lock-step half-groups on two HIP streams: while one half's convolutions keep the matrix pipes busy,
+                # the other half's HBM-bound BatchNorm / pooling passes and latency-bound recurrences share the CUs
+                main = torch.cuda.current_stream()
+                streams = self._streams(len(halves), dev)
+                for (lo, hi, bg, hg), st in zip(halves, streams):
+                    st.wait_stream(main)
+                    with torch.cuda.stream(st):
+                        hg.run(bg.visual_all(image, as_act=True), text, feats[:, :, lo:hi, :], logits[lo:hi])
+                for st in streams[:len(halves)]:
+                    main.wait_stream(st)
+                    image.record_stream(st)
+            elif heads is not None:
                 # backbones AND heads in lock-step: one grouped launch per conv layer / Linear / recurrence, one stream
                 heads.run(group.visual_all(image, as_act=True), text, feats, logits)
             elif self.expert_streams and I > 1:
@@ -406,12 +440,14 @@ class MRNNet(nn.Module):
         pool, self._stream_pool = self._stream_pool, []      # streams / packed-weight caches are not copied
         group, self._group = self._group, None
         heads, self._heads = self._heads, None
+        halves, self._halves = self._halves, None
         try:
             return copy.deepcopy(self)
         finally:
             self._stream_pool = pool
             self._group = group
             self._heads = heads
+            self._halves = halves
 
     def freeze(self):
         for p in self.parameters():

@@ -440,3 +440,38 @@ def test_dernet_groups_frozen_extractors(train_mode):
         outs.append((o["features"].detach().clone(), o["logits"].detach().clone()))
     assert_close("der features", outs[0][0], outs[1][0], atol=2e-5, rtol=1e-4)
     assert_close("der logits", outs[0][1], outs[1][1], atol=2e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("arch", ["trba", "crnn"])
+def test_two_stream_half_groups_are_bit_identical(arch):
+    """MRNNet with >= 4 experts splits them into two lock-step half-groups on two HIP streams (so one half's HBM-bound
+    passes overlap the other half's convolutions); per-expert arithmetic is unchanged, so results are bit-identical to
+    the single group on one stream, including the BatchNorm running statistics"""
+    from mrn_amd.modules.model import MRNNet
+    from mrn_amd.tools import weights as W
+    opt = make_opt(arch)
+    classes = (30, 45, 61, 80, 97)
+    B = 3
+    image = torch.from_numpy(W.smooth_image("halves", (B, 4, 32, 256), 3)).cuda()
+    text = torch.from_numpy(W.randint("halves_text", (B, 26), 4, classes[-1], 3)).cuda()
+    text[:, 0] = 2
+    outs = []
+    for parts in (2, 0):
+        with contextlib.redirect_stdout(io.StringIO()):
+            net = MRNNet(opt)
+            for c in classes:
+                net.update_fc(256, c)
+                net.build_prediction(opt, c)
+        W.fill_state_dict(net.state_dict(), seed=17)
+        net = net.cuda().train()
+        for p in net.parameters():
+            p.requires_grad = False
+        net.expert_halves = parts
+        with torch.no_grad():
+            o = net(image, True, text if opt.Prediction == "Attn" else None, True)
+        torch.cuda.synchronize()
+        assert (net._halves is not None) == (parts == 2)
+        outs.append((o["logits"].clone(), o["index"].clone(), {k: v.clone() for k, v in net.state_dict().items() if "running_" in k}))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for k in outs[0][2]:
+        assert torch.equal(outs[0][2][k], outs[1][2][k]), k
