@@ -28,15 +28,32 @@ class KernelTimer:
         self.spans.append((start, e, flops, kind, nbytes))
 
     def summary(self):
-        """per kernel kind: launches, total event time, total algorithmic flops"""
+        """per kernel kind: launches, summed event time, UNION of the launch intervals (two lock-step half-groups run on
+        two streams, so launches of one kernel overlap; the union is the time the kernel actually occupied the GPU),
+        total algorithmic flops / bytes"""
         torch.cuda.synchronize()
-        out = {}
+        if not self.spans:
+            return {}
+        ref = self.spans[0][0]
+        out, ivals = {}, {}
         for s, e, f, kind, nb in self.spans:
             d = out.setdefault(kind, {"launches": 0, "total_ms": 0.0, "total_flops": 0.0, "total_bytes": 0.0})
             d["launches"] += 1
             d["total_ms"] += s.elapsed_time(e)
             d["total_flops"] += f
             d["total_bytes"] += nb
+            t0 = ref.elapsed_time(s)
+            ivals.setdefault(kind, []).append((t0, t0 + s.elapsed_time(e)))
+        for kind, iv in ivals.items():
+            iv.sort()
+            union, cur_s, cur_e = 0.0, iv[0][0], iv[0][1]
+            for a, b in iv[1:]:
+                if a > cur_e:
+                    union += cur_e - cur_s
+                    cur_s, cur_e = a, b
+                else:
+                    cur_e = max(cur_e, b)
+            out[kind]["union_ms"] = union + (cur_e - cur_s)
         return out
 
 
