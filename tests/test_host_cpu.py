@@ -130,3 +130,50 @@ def test_data_parallel_helpers_gloo_world2(tmp_path):
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists(), r.stdout + r.stderr
+
+
+def _opt(trans, feat, seq, pred):
+    return types.SimpleNamespace(Transformation=trans, FeatureExtraction=feat, SequenceModeling=seq, Prediction=pred,
+                                 num_fiducial=20, imgH=32, imgW=256, input_channel=4, output_channel=512, hidden_size=256,
+                                 batch_max_length=25)
+
+
+def test_lockstep_grouping_policy():
+    """host logic of modules/expert_group.py: which sets of experts may run in lock-step, and the tile choice of the
+    grouped conv (no kernel is launched)"""
+    from mrn_amd import ops
+    from mrn_amd.modules import expert_group
+    from mrn_amd.modules.model import Model, MRNNet
+    with contextlib.redirect_stdout(io.StringIO()):
+        trba = [Model(_opt("TPS", "ResNet", "BiLSTM", "Attn")) for _ in range(3)]
+        crnn = [Model(_opt("None", "VGG", "BiLSTM", "CTC")) for _ in range(2)]
+        net = MRNNet(_opt("None", "VGG", "BiLSTM", "CTC"))
+        for c in (20, 30, 40, 50, 60):
+            net.update_fc(256, c)
+            net.build_prediction(net.opt, c)
+    ext = [m.model for m in trba]
+    assert expert_group.supported(ext)
+    assert not expert_group.supported(ext[:1])                                     # a single expert: nothing to group
+    assert not expert_group.supported([trba[0].model, crnn[0].model])              # different architectures
+    trba[1].model.FeatureExtraction.ConvNet.bn1.eval()                             # one BatchNorm in another mode
+    assert not expert_group.supported(ext)
+    trba[1].model.train()
+    assert expert_group.supported(ext)
+    saved = ops.CONV_PRECISION
+    try:
+        ops.CONV_PRECISION = "f32"                                                 # exact mode keeps the per-expert kernels
+        assert not expert_group.supported(ext)
+    finally:
+        ops.CONV_PRECISION = saved
+    for m in crnn:
+        m.build_prediction(m.opt, 30) if m.fc is not None else None
+    assert expert_group.HeadsGroup.supported(trba, True) and not expert_group.HeadsGroup.supported(trba, False)   # greedy Attn decode: per expert
+    assert expert_group.HeadsGroup.supported(crnn, False)                          # CTC heads have no feedback loop
+    # tile selection of the grouped conv
+    assert ops.x3_tile(512, 4608) == (256, 256) and ops.x3_tile(64, 288) == (256, 64)
+    assert ops.x3_tile(128, 576) == (128, 128) and ops.x3_tile(128, 2304) == (256, 128)
+    # five experts -> two half-groups (2 + 3) on two streams, never for fewer than four
+    parts = net._half_groups(True)
+    assert [(lo, hi) for lo, hi, _, _ in parts] == [(0, 2), (2, 5)]
+    net.expert_halves = 0
+    assert net._half_groups(True) is None
