@@ -81,17 +81,24 @@ int mrn_split_weight_bf16(const float* w, void* hi, void* lo, int64_t n, int hal
  * [G][ceil(B*Ho*Wo/tile_m)][2][Cout] per-row-block sums / sums of squares (mrn_conv2d_x3_stats_floats) or NULL.
  * tile_m x tile_n = 256x256 (Cout >= 256), 256x128, 256x64 (Cout <= 64) or 128x128.  Requires Cin % 32 == 0; zero_page: >= 128 bytes of device zeros.
  * y_row_stride / y_group_stride (floats; 0 = dense [G][B*Ho*Wo][Cout]) let the result land in a wider buffer, e.g. one
- * expert's slice of the router's [B][P][I][C] feature tensor.  With H = W = kh = kw = 1 this is a grouped Linear layer
+ * expert's slice of the router's [B][P][I][C] feature tensor.  x_group_div > 1: group g reads activation group g / x_group_div.  With H = W = kh = kw = 1 this is a grouped Linear layer
  * (nn.Linear sites of modules/sequence_modeling.py:10,19-22 and modules/prediction.py:58-68,104-107). */
 int mrn_conv2d_x3_hl32(const void* x_hl, const void* w_hl, const void* zero_page, const float* bias,
                        const float* residual, float* y, float* stats, const float* out_scale, const float* x_scale, int G, int64_t x_group_stride_bytes, int B, int H, int W,
                        int Cin, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int act, int tile_m, int tile_n,
-                       int64_t y_row_stride, int64_t y_group_stride, void* stream);
+                       int64_t y_row_stride, int64_t y_group_stride, int x_group_div, void* stream);
 int64_t mrn_conv2d_x3_stats_floats(int G, int B, int Ho, int Wo, int Cout, int tile_m);
 int mrn_split_hl32_f32(const float* x, void* out, int64_t rows, int C, const float* scale, void* stream);
 /* transposed split for weight-gradient GEMMs (dW = dy^T x reduces over rows): x[rows][C] -> [splits][C][rows/splits/32][128 B],
  * i.e. `splits` HL32 matrices whose reduction axis is a row chunk (split-K = the conv's group dimension) */
-int mrn_split_hl32_t_f32(const float* x, void* out, int64_t rows, int C, int splits, const float* scale, void* stream);
+int mrn_split_hl32_t_f32(const float* x, void* out, int64_t rows, int64_t rows_padded, int C, int splits, const float* scale,
+                         void* stream);
+/* transposed im2col for the convolution weight gradient (loss.backward() through Conv2d, il_modules/mrn.py:260-261):
+ * out[s][tap][ci][rows_padded/splits/32][128 B], element (tap, ci, p) = scale * x[pixel(p) shifted by tap][ci] (0 in the
+ * padding).  With mrn_split_hl32_t_f32(dy) as the other operand, dW = mrn_conv2d_x3_hl32 with groups = splits * taps and
+ * x_group_div = taps (the activation group of the GEMM is the dy^T chunk g / taps). */
+int mrn_im2col_t_hl32_f32(const float* x, void* out, int B, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw,
+                          int64_t rows_padded, int splits, const float* scale, void* stream);
 int mrn_pack_weight_hl32(const float* w_ohwi, void* out, int Cout, int taps, int Cin, const float* scale, void* stream);
 
 /* Elementwise passes between grouped convolutions (G frozen experts in lock-step).

@@ -42,6 +42,7 @@ struct ConvX3Params {
   float* y;                   // [G][M][N]
   float* stats;               // [G][tilesM][2][N] or null
   long x_gstride, w_gstride;  // bytes
+  int x_group_div;            // activation group = g / x_group_div (weight-gradient GEMMs: one dy^T chunk serves all taps)
   long y_gstride, y_ld;       // output group stride / row pitch in floats
   int x_bytes;                // bytes of one group's activation
   int G, M, N, Cb, taps, nk;  // nk = Cb * taps = K-steps of the full reduction (weight row length in 128-byte lines)
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
   int arow[NA];                     // byte offset of (pixel0 line + swizzled chunk) inside this group's activation (may be < 0)
   unsigned amask[NA];               // bit tap = this row's tap is inside the image
   int brow[NB];                     // byte offset of (weight row + swizzled chunk); rows beyond N re-read row N-1 (never stored)
-  const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x + (long)g * p.x_gstride, p.x_bytes);
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x + (long)(g / p.x_group_div) * p.x_gstride, p.x_bytes);
   const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.w + (long)g * p.w_gstride, (int)p.w_gstride);
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
@@ -381,7 +382,8 @@ __global__ __launch_bounds__(256) void split_hl32_kernel(const float* __restrict
 // out[s][c][rps/32][hi 32 | lo 32] with rps = rows / splits, element (c, r) = scale * x[s*rps + r][c].  One block moves a
 // 32-row x 32-column tile through LDS: coalesced 128-byte row reads, one 128-byte HL32 line per column written.
 __global__ __launch_bounds__(256) void split_hl32_t_kernel(const float* __restrict__ x, unsigned char* __restrict__ out, int C,
-                                                           long rps32, long tiles_c, long ntiles, const float* __restrict__ scale) {
+                                                           long rows, long rps32, long tiles_c, long ntiles,
+                                                           const float* __restrict__ scale) {
   __shared__ float tile[32][33];
   const float sc = scale ? scale[0] : 1.f;
   const int t = threadIdx.x;
@@ -391,7 +393,7 @@ __global__ __launch_bounds__(256) void split_hl32_t_kernel(const float* __restri
     {
       const int r = t >> 3, c4 = (t & 7) * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (c0 + c4 < C) v = *reinterpret_cast<const f32x4*>(x + (rb * 32 + r) * C + c0 + c4);
+      if (c0 + c4 < C && rb * 32 + r < rows) v = *reinterpret_cast<const f32x4*>(x + (rb * 32 + r) * C + c0 + c4);
       tile[r][c4 + 0] = v[0] * sc; tile[r][c4 + 1] = v[1] * sc; tile[r][c4 + 2] = v[2] * sc; tile[r][c4 + 3] = v[3] * sc;
     }
     __syncthreads();
@@ -400,6 +402,61 @@ __global__ __launch_bounds__(256) void split_hl32_t_kernel(const float* __restri
       if (c0 + c < C) {
         const long s_ = rb / rps32, rl = rb - s_ * rps32;
         unsigned char* o = out + ((s_ * C + c0 + c) * rps32 + rl) * 128 + seg * 8;
+        typedef _Float16 f16v4 __attribute__((ext_vector_type(4)));
+        f16v4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          _Float16 hh, ll;
+          split_h(tile[seg * 4 + e][c], hh, ll);
+          h[e] = hh; l[e] = ll;
+        }
+        *reinterpret_cast<f16v4*>(o) = h;
+        *reinterpret_cast<f16v4*>(o + 64) = l;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+struct Im2colT {
+  const float* x; unsigned char* out; const float* scale;
+  int B, H, W, C, Ho, Wo, kw, taps, sh, sw, ph, pw;
+  long P, rps32, tiles_c, ntiles;
+};
+
+// one block = (32 output pixels) x (32 channels) of ONE tap; the tap index runs fastest over the grid so the nine taps of a
+// pixel block re-read the same input lines from L2
+__global__ __launch_bounds__(256) void im2col_t_hl32_kernel(const Im2colT p) {
+  __shared__ float tile[32][33];
+  const float sc = p.scale ? p.scale[0] : 1.f;
+  const int t = threadIdx.x;
+  for (long id = blockIdx.x; id < p.ntiles; id += gridDim.x) {
+    const int tap = (int)(id % p.taps);
+    const long id2 = id / p.taps;
+    const long rb = id2 / p.tiles_c;                 // 32-pixel block (global over the padded pixel axis)
+    const int c0 = (int)(id2 - rb * p.tiles_c) * 32;
+    const int ky = tap / p.kw, kx = tap - ky * p.kw;
+    {
+      const int r = t >> 3, c4 = (t & 7) * 4;
+      const long pix = rb * 32 + r;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (pix < p.P && c0 + c4 < p.C) {
+        const int hw = p.Ho * p.Wo;
+        const int b = (int)(pix / hw);
+        const int rem = (int)(pix - (long)b * hw);
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        const int iy = oy * p.sh - p.ph + ky, ix = ox * p.sw - p.pw + kx;
+        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+          v = *reinterpret_cast<const f32x4*>(p.x + (((long)b * p.H + iy) * p.W + ix) * p.C + c0 + c4);
+      }
+      tile[r][c4 + 0] = v[0] * sc; tile[r][c4 + 1] = v[1] * sc; tile[r][c4 + 2] = v[2] * sc; tile[r][c4 + 3] = v[3] * sc;
+    }
+    __syncthreads();
+    {
+      const int c = t >> 3, seg = t & 7;
+      if (c0 + c < p.C) {
+        const long s_ = rb / p.rps32, rl = rb - s_ * p.rps32;
+        unsigned char* o = p.out + ((((s_ * p.taps + tap) * p.C) + c0 + c) * p.rps32 + rl) * 128 + seg * 8;
         typedef _Float16 f16v4 __attribute__((ext_vector_type(4)));
         f16v4 h, l;
 #pragma unroll
@@ -483,7 +540,7 @@ MRN_EXPORT int mrn_conv2d_x3_hl32(const void* x_hl, const void* w_hl, const void
                                   const float* residual, float* y, float* stats, const float* out_scale,
                                   const float* x_scale, int G, int64_t x_group_stride_bytes, int B, int H,
                                   int W, int Cin, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int act,
-                                  int tile_m, int tile_n, int64_t y_row_stride, int64_t y_group_stride, void* stream) {
+                                  int tile_m, int tile_n, int64_t y_row_stride, int64_t y_group_stride, int x_group_div, void* stream) {
   MRN_CHECK_ARG(x_hl && w_hl && zero_page && y && G >= 1, "mrn_conv2d_x3_hl32: bad operands");
   MRN_CHECK_ARG(Cin % 32 == 0 && kh * kw <= 32, "mrn_conv2d_x3_hl32: unsupported Cin=%d kernel=%dx%d", Cin, kh, kw);
   MRN_CHECK_ARG(((uintptr_t)x_hl % 128 == 0) && ((uintptr_t)w_hl % 128 == 0) && ((uintptr_t)zero_page % 16 == 0) &&
@@ -500,6 +557,7 @@ MRN_EXPORT int mrn_conv2d_x3_hl32(const void* x_hl, const void* w_hl, const void
   p.bias = bias; p.out_scale = out_scale; p.x_scale = x_scale; p.res = residual; p.y = y; p.stats = stats;
   p.Cb = Cin / 32; p.taps = kh * kw; p.nk = p.Cb * p.taps;
   p.x_gstride = x_group_stride_bytes; p.w_gstride = (long)Cout * p.nk * 128;
+  p.x_group_div = x_group_div > 1 ? x_group_div : 1;
   p.x_bytes = (int)((long)B * H * W * Cin * 4);
   p.G = G; p.M = B * Ho * Wo; p.N = Cout;
   p.y_ld = y_row_stride > 0 ? y_row_stride : Cout;
@@ -545,17 +603,39 @@ MRN_EXPORT int mrn_pack_weight_hl32(const float* w_ohwi, void* out, int Cout, in
   return MRN_OK;
 }
 
-// fp32 x[rows][C] (C % 4 == 0) -> `splits` transposed HL32 matrices [splits][C][rows/splits/32][128 B] of scale[0] * x
-// (rows % (32 * splits) == 0): the operand layout of a weight-gradient GEMM that reduces over rows, split-K = groups.
-MRN_EXPORT int mrn_split_hl32_t_f32(const float* x, void* out, int64_t rows, int C, int splits, const float* scale,
-                                    void* stream) {
-  MRN_CHECK_ARG(x && out && splits >= 1 && C % 4 == 0 && rows % (32L * splits) == 0,
-                "mrn_split_hl32_t_f32: bad operands (rows=%ld C=%d splits=%d)", (long)rows, C, splits);
-  if (rows == 0 || C == 0) return MRN_OK;
-  const long tiles_c = (C + 31) / 32, ntiles = rows / 32 * tiles_c;
+// fp32 x[rows][C] (C % 4 == 0) -> `splits` transposed HL32 matrices [splits][C][rows_padded/splits/32][128 B] of scale[0] * x
+// (rows_padded % (32 * splits) == 0, rows beyond `rows` are zero): the operand layout of a weight-gradient GEMM that
+// reduces over rows, split-K = groups.
+MRN_EXPORT int mrn_split_hl32_t_f32(const float* x, void* out, int64_t rows, int64_t rows_padded, int C, int splits,
+                                    const float* scale, void* stream) {
+  MRN_CHECK_ARG(x && out && splits >= 1 && C % 4 == 0 && rows_padded >= rows && rows_padded % (32L * splits) == 0,
+                "mrn_split_hl32_t_f32: bad operands (rows=%ld padded=%ld C=%d splits=%d)", (long)rows, (long)rows_padded, C, splits);
+  if (rows_padded == 0 || C == 0) return MRN_OK;
+  const long tiles_c = (C + 31) / 32, ntiles = rows_padded / 32 * tiles_c;
   long grid = ntiles > 65536 ? 65536 : ntiles;
   hipLaunchKernelGGL(split_hl32_t_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, (unsigned char*)out, C,
-                     (long)(rows / splits / 32), tiles_c, ntiles, scale);
+                     (long)rows, (long)(rows_padded / splits / 32), tiles_c, ntiles, scale);
   MRN_LAUNCH_CHECK("split_hl32_t");
+  return MRN_OK;
+}
+
+// Transposed im2col for the convolution weight gradient dW[co][tap][ci] = sum_p dy[p][co] * x[pixel(p, tap)][ci]:
+//   out[s][tap][ci][rps/32][hi 32 | lo 32], element (tap, ci, p) = scale * x[b][oy*sh + ky - ph][ox*sw + kx - pw][ci]
+// (zero outside the image / beyond P = B*Ho*Wo), p = s*rps + r the output pixel.  x NHWC [B][H][W][C], C % 4 == 0.
+MRN_EXPORT int mrn_im2col_t_hl32_f32(const float* x, void* out, int B, int H, int W, int C, int kh, int kw, int sh, int sw,
+                                     int ph, int pw, int64_t rows_padded, int splits, const float* scale, void* stream) {
+  MRN_CHECK_ARG(x && out && splits >= 1 && C % 4 == 0 && rows_padded % (32L * splits) == 0, "mrn_im2col_t_hl32_f32: bad operands");
+  const int Ho = (H + 2 * ph - kh) / sh + 1, Wo = (W + 2 * pw - kw) / sw + 1;
+  MRN_CHECK_ARG(Ho > 0 && Wo > 0 && rows_padded >= (long)B * Ho * Wo, "mrn_im2col_t_hl32_f32: bad geometry");
+  if (rows_padded == 0 || C == 0) return MRN_OK;
+  Im2colT p;
+  p.x = x; p.out = (unsigned char*)out; p.scale = scale;
+  p.B = B; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.kw = kw; p.taps = kh * kw;
+  p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw;
+  p.P = (long)B * Ho * Wo; p.rps32 = rows_padded / splits / 32; p.tiles_c = (C + 31) / 32;
+  p.ntiles = rows_padded / 32 * p.tiles_c * p.taps;
+  long grid = p.ntiles > 262144 ? 262144 : p.ntiles;
+  hipLaunchKernelGGL(im2col_t_hl32_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p);
+  MRN_LAUNCH_CHECK("im2col_t_hl32");
   return MRN_OK;
 }

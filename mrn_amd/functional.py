@@ -359,7 +359,10 @@ class ConvBlockFn(torch.autograd.Function):
         dw = None
         if ctx.needs_input_grad[1]:
             kh, kw = w.shape[1], w.shape[2]
-            dw = ops.unpack_conv_weight(ops.conv2d_wgrad(dy, x, (kh, kw), stride, padding))
+            if precision == "fp16x3s" and x.shape[-1] % 4 == 0 and ops.TRAIN_WGRAD_X3:
+                dw = ops.unpack_conv_weight(ops.conv2d_wgrad_x3(dy, x, (kh, kw), stride, padding))
+            else:
+                dw = ops.unpack_conv_weight(ops.conv2d_wgrad(dy, x, (kh, kw), stride, padding))
         return dx, dw, dbias, dgamma, dbeta, dres, None
 
 

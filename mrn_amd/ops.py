@@ -85,6 +85,7 @@ AUTO_SPLIT_MIN_K = 0
 #   "f32"     exact fp32 MFMA.  (Unscaled "fp16x3" fails the TRBA gradient test: small gradients fall into fp16
 #             subnormals; "bf16x3" amplifies 1e-5 forward differences through small-batch BatchNorm backward to ~3e-3.)
 TRAIN_CONV_PRECISION = __import__("os").environ.get("MRN_TRAIN_PRECISION", "fp16x3s")
+TRAIN_WGRAD_X3 = __import__("os").environ.get("MRN_TRAIN_WGRAD", "fp16x3s") == "fp16x3s"   # weight gradients on the same path
 LOCNET_CONV_PRECISION = None   # TPS localisation network: None = follow CONV_PRECISION ("f32" to pin it exact)
 AUTO_SPLIT_KIND = "fp16x3"   # arithmetic "auto" picks for the deep reductions ("fp16x3" | "bf16x3")
 USE_DMA_CONV = True          # pre-split activation + direct-to-LDS staging for the split-16-bit convs
@@ -321,14 +322,44 @@ def split_hl32(x, scale=None):
     return out
 
 
-def split_hl32_t(x2, splits, scale=None):
-    """fp32 [rows, C] -> `splits` transposed HL32 matrices [splits][C][rows/splits/32][128 B] of scale[0] * x"""
+def split_hl32_t(x2, splits, scale=None, rows_padded=None):
+    """fp32 [rows, C] -> `splits` transposed HL32 matrices [splits][C][rows_padded/splits/32][128 B] of scale[0] * x
+    (rows beyond x2's are zero)"""
     _chk(x2)
     rows, C = x2.shape
-    assert x2.is_contiguous() and rows % (32 * splits) == 0
-    out = torch.empty(rows * C * 4, device=x2.device, dtype=torch.uint8)
-    call("mrn_split_hl32_t_f32", _p(x2), _p(out), rows, C, splits, _p(scale), _stream())
+    rows_padded = rows if rows_padded is None else rows_padded
+    assert x2.is_contiguous() and rows_padded % (32 * splits) == 0
+    out = torch.empty(rows_padded * C * 4, device=x2.device, dtype=torch.uint8)
+    call("mrn_split_hl32_t_f32", _p(x2), _p(out), rows, rows_padded, C, splits, _p(scale), _stream())
     return out
+
+
+def conv2d_wgrad_x3(dy, x, ksize, stride, padding):
+    """conv weight gradient on the split-fp16 x3 path: dW [Cout, kh, kw, Cin] = sum over output pixels of dy (x) im2col(x);
+    both operands are transposed-split with device prescales (reduction axis = pixels), the GEMM is ONE grouped launch
+    over (split-K chunk, tap); the partial slabs are reduced by a column-sum pass."""
+    B, Ho, Wo, Cout = dy.shape
+    _, H, W, Cin = x.shape
+    kh, kw = ksize
+    taps = kh * kw
+    P = B * Ho * Wo
+    blocks = (P + 31) // 32
+    tiles = ((Cout + 255) // 256) * ((Cin + 255) // 256) * taps
+    S = max(1, min(512 // tiles if tiles < 512 else 1, max(blocks // 8, 1)))
+    rps = ((blocks + S - 1) // S) * 32
+    Pp = rps * S
+    dy2 = dy.contiguous().view(P, Cout)
+    sd, sx = pow2_scale(dy2), pow2_scale(x)
+    a_hl = split_hl32_t(dy2, S, sd, rows_padded=Pp)                       # [S][Cout][rps/32][128]
+    w_hl = torch.empty(S * taps * Cin * rps * 4, device=x.device, dtype=torch.uint8)
+    call("mrn_im2col_t_hl32_f32", _p(x.contiguous()), _p(w_hl), B, H, W, Cin, kh, kw, stride[0], stride[1], padding[0], padding[1],
+         Pp, S, _p(sx), _stream())
+    G = S * taps
+    part = torch.empty(S, taps, Cout, Cin, device=x.device, dtype=torch.float32)
+    conv2d_x3(a_hl, G, False, Cout, 1, 1, rps, w_hl, sx.view(1, 2).expand(G, 2).contiguous(), Cin, (1, 1), x_scale=sd,
+              out=part, x_group_div=taps)
+    dw = colsum(part.view(S, taps * Cout * Cin)).view(taps, Cout, Cin) if S > 1 else part[0]
+    return dw.permute(1, 0, 2).contiguous().view(Cout, kh, kw, Cin)
 
 
 def pow2_scale(x, target=FP16_WEIGHT_PEAK):
@@ -357,7 +388,8 @@ def pack_weights_hl32(ws):
 
 
 def conv2d_x3(x_hl, G, shared_input, B, H, W, Cin, w_hl, w_scale, Cout, ksize, stride=(1, 1), padding=(0, 0), bias=None,
-              act=ACT_NONE, want_stats=False, out=None, out_row_stride=0, out_group_stride=0, residual=None, x_scale=None):
+              act=ACT_NONE, want_stats=False, out=None, out_row_stride=0, out_group_stride=0, residual=None, x_scale=None,
+              x_group_div=1):
     """Grouped conv on HL32 operands -> (y [G,B,Ho,Wo,Cout] fp32, stats or None).  With `out` and the two strides (floats)
     the rows of group g land at out.data_ptr + g * out_group_stride + row * out_row_stride."""
     kh, kw = ksize
@@ -374,7 +406,7 @@ def conv2d_x3(x_hl, G, shared_input, B, H, W, Cin, w_hl, w_scale, Cout, ksize, s
     call("mrn_conv2d_x3_hl32", _p(x_hl), _p(w_hl), _p(_zero_page(dev)), _p(bias), _p(residual), _p(y), _p(stats), _p(w_scale),
          _p(x_scale), G, gstride,
          B, H, W, Cin, Cout, kh, kw, stride[0], stride[1], padding[0], padding[1], act, tile_m, tile_n, out_row_stride, out_group_stride,
-         _stream())
+         x_group_div, _stream())
     if timed:
         # algorithmic bytes: every operand element once (HL32 = 4 B / element, like fp32) + the fp32 result
         nbytes = 4.0 * ((1 if shared_input else G) * B * H * W * Cin + G * Cout * kh * kw * Cin + G * B * Ho * Wo * Cout)

@@ -470,3 +470,20 @@ def test_x3_weight_gradient(ops, magnitude):
     ref = dy.double().t() @ x.double()
     dw = Fn.linear_wgrad(cu(dy), cu(x))
     assert_close("x3 wgrad", dw.cpu().double(), ref, atol=2e-5 * magnitude, rtol=1e-6)
+
+
+@pytest.mark.parametrize("cfg", [(3, 4, 65, 64, 128, (3, 3), (1, 1), (1, 1)), (2, 8, 17, 4, 32, (3, 3), (1, 1), (1, 1)),
+                                 (2, 4, 66, 32, 64, (2, 2), (2, 1), (0, 1)), (5, 6, 10, 96, 320, (3, 3), (2, 2), (1, 1)),
+                                 (2, 5, 9, 64, 48, (1, 1), (1, 1), (0, 0))])
+@pytest.mark.parametrize("magnitude", [1.0, 1e-6])
+def test_conv_weight_gradient_x3(ops, cfg, magnitude):
+    """ops.conv2d_wgrad_x3 (mrn_split_hl32_t_f32 + mrn_im2col_t_hl32_f32 + one grouped x3 GEMM over (split, tap)) against
+    torch autograd's conv2d weight gradient, also for gradient-sized dy"""
+    B, H, W, Cin, Cout, k, s, p = cfg
+    x = rnd(B, Cin, H, W, seed=230)
+    w = rnd(Cout, Cin, *k, seed=231, scale=0.1).requires_grad_(True)
+    y = F.conv2d(x, w, None, s, p)
+    dy = rnd(*y.shape, seed=232) * magnitude
+    y.backward(dy)
+    dw = ops.conv2d_wgrad_x3(cu(dy.permute(0, 2, 3, 1).contiguous()), cu(x.permute(0, 2, 3, 1).contiguous()), k, s, p)
+    assert_close("x3 conv wgrad", dw.permute(0, 3, 1, 2), w.grad, atol=2e-5 * magnitude, rtol=2e-6)
