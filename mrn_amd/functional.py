@@ -321,13 +321,17 @@ class ConvBlockFn(torch.autograd.Function):
         stride, padding = _pair(conv.stride), _pair(conv.padding)
         ctx.geom = (stride, padding, relu, precision, bn is not None, residual is not None)
         ctx.wpacked = w
+        # one max|x| pass serves the forward conv and the weight gradient (both split x with the same power-of-two scale)
+        x3s = precision == "fp16x3s" and x.shape[-1] % 32 == 0
+        ctx.x_scale = sx = ops.pow2_scale(x.contiguous()) if x3s else None
         if bn is None:
-            y, _ = ops.conv2d_nhwc(x, w, bias, stride, padding, act=ops.ACT_RELU if relu else ops.ACT_NONE, precision=precision)
+            y, _ = ops.conv2d_nhwc(x, w, bias, stride, padding, act=ops.ACT_RELU if relu else ops.ACT_NONE, precision=precision,
+                                   x_scale=sx)
             ctx.save_for_backward(x, y if relu else None, None, None, None, None)
             return y
         if not bn.training:
             raise NotImplementedError("backward through eval-mode BatchNorm is not implemented (experts train in train mode)")
-        y, stats = ops.conv2d_nhwc(x, w, bias, stride, padding, act=ops.ACT_NONE, want_stats=True, precision=precision)
+        y, stats = ops.conv2d_nhwc(x, w, bias, stride, padding, act=ops.ACT_NONE, want_stats=True, precision=precision, x_scale=sx)
         count = y.shape[0] * y.shape[1] * y.shape[2]
         mom = 0.1 if bn.momentum is None else bn.momentum
         scale, shift, mean, invstd = ops.bn_finalize(stats, bn.num_features, count, gamma, beta, bn.running_mean,
@@ -353,14 +357,16 @@ class ConvBlockFn(torch.autograd.Function):
             if ctx.needs_input_grad[2]:
                 dbias = ops.colsum(dy.view(-1, dy.shape[-1]))
         dx = None
+        dy = dy.contiguous()
+        sd = ops.pow2_scale(dy) if precision == "fp16x3s" else None          # shared by the data and weight gradients
         if ctx.needs_input_grad[0]:
             wt = ops.pack_dgrad_weight(w.ohwi)
-            dx = ops.conv2d_dgrad(dy, wt, (x.shape[1], x.shape[2]), stride, padding, precision=precision)
+            dx = ops.conv2d_dgrad(dy, wt, (x.shape[1], x.shape[2]), stride, padding, precision=precision, dy_scale=sd)
         dw = None
         if ctx.needs_input_grad[1]:
             kh, kw = w.shape[1], w.shape[2]
             if precision == "fp16x3s" and x.shape[-1] % 4 == 0 and ops.TRAIN_WGRAD_X3:
-                dw = ops.unpack_conv_weight(ops.conv2d_wgrad_x3(dy, x, (kh, kw), stride, padding))
+                dw = ops.unpack_conv_weight(ops.conv2d_wgrad_x3(dy, x, (kh, kw), stride, padding, dy_scale=sd, x_scale=ctx.x_scale))
             else:
                 dw = ops.unpack_conv_weight(ops.conv2d_wgrad(dy, x, (kh, kw), stride, padding))
         return dx, dw, dbias, dgamma, dbeta, dres, None

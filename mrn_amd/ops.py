@@ -233,7 +233,7 @@ def conv_out_hw(H, W, k, s, p):
 
 
 def conv2d_nhwc(x, w_ohwi, bias=None, stride=(1, 1), padding=(0, 0), act=ACT_NONE, want_stats=False, precision=None,
-                out=None, stats_out=None):
+                out=None, stats_out=None, x_scale=None):
     """x [B,H,W,Cin] -> y [B,Ho,Wo,Cout]; returns (y, stats or None) where stats are per-128-row-block partials.
     w_ohwi: [O,kh,kw,I] fp32 tensor or a PackedConvWeight."""
     packed = w_ohwi if isinstance(w_ohwi, PackedConvWeight) else None
@@ -247,7 +247,7 @@ def conv2d_nhwc(x, w_ohwi, bias=None, stride=(1, 1), padding=(0, 0), act=ACT_NON
         # range-safe split-fp16 x3 on the grouped kernel (G = 1): both operands prescaled by a device-computed power of
         # two -- the precision of TRAINED convolutions, whose gradient operands can be 1e-6-sized
         if Cin % 32 == 0 and out is None and stats_out is None:
-            return conv2d_x3_scaled(x, w_ohwi, bias, stride, padding, act, want_stats)
+            return conv2d_x3_scaled(x, w_ohwi, bias, stride, padding, act, want_stats, sx=x_scale)
         precision = "f32"
     Ho, Wo = conv_out_hw(H, W, (kh, kw), stride, padding)
     y = out if out is not None else torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
@@ -334,7 +334,7 @@ def split_hl32_t(x2, splits, scale=None, rows_padded=None):
     return out
 
 
-def conv2d_wgrad_x3(dy, x, ksize, stride, padding):
+def conv2d_wgrad_x3(dy, x, ksize, stride, padding, dy_scale=None, x_scale=None):
     """conv weight gradient on the split-fp16 x3 path: dW [Cout, kh, kw, Cin] = sum over output pixels of dy (x) im2col(x);
     both operands are transposed-split with device prescales (reduction axis = pixels), the GEMM is ONE grouped launch
     over (split-K chunk, tap); the partial slabs are reduced by a column-sum pass."""
@@ -349,7 +349,8 @@ def conv2d_wgrad_x3(dy, x, ksize, stride, padding):
     rps = ((blocks + S - 1) // S) * 32
     Pp = rps * S
     dy2 = dy.contiguous().view(P, Cout)
-    sd, sx = pow2_scale(dy2), pow2_scale(x)
+    sd = dy_scale if dy_scale is not None else pow2_scale(dy2)
+    sx = x_scale if x_scale is not None else pow2_scale(x)
     a_hl = split_hl32_t(dy2, S, sd, rows_padded=Pp)                       # [S][Cout][rps/32][128]
     w_hl = torch.empty(S * taps * Cin * rps * 4, device=x.device, dtype=torch.uint8)
     call("mrn_im2col_t_hl32_f32", _p(x.contiguous()), _p(w_hl), B, H, W, Cin, kh, kw, stride[0], stride[1], padding[0], padding[1],
@@ -417,13 +418,14 @@ def conv2d_x3(x_hl, G, shared_input, B, H, W, Cin, w_hl, w_scale, Cout, ksize, s
     return y, stats
 
 
-def conv2d_x3_scaled(x, w_ohwi, bias, stride, padding, act=ACT_NONE, want_stats=False):
+def conv2d_x3_scaled(x, w_ohwi, bias, stride, padding, act=ACT_NONE, want_stats=False, sx=None):
     """one convolution on the grouped x3 kernel with per-call operand scaling: x fp32 [B,H,W,Cin] (Cin % 32 == 0),
     w_ohwi fp32 [O,kh,kw,I] -> (y [B,Ho,Wo,O], stats or None)"""
     B, H, W, Cin = x.shape
     Cout, kh, kw, _ = w_ohwi.shape
     x = x.contiguous()
-    sx = pow2_scale(x)
+    if sx is None:
+        sx = pow2_scale(x)          # (callers that use x in several GEMMs compute it once: ConvBlockFn)
     w_hl, sw = pack_weights_hl32([w_ohwi.contiguous()])
     y, stats = conv2d_x3(split_hl32(x, sx), 1, False, B, H, W, Cin, w_hl, sw, Cout, (kh, kw), stride, padding, bias=bias, act=act,
                          want_stats=want_stats, x_scale=sx)
@@ -882,7 +884,7 @@ def pack_dgrad_weight(w_ohwi):
     return PackedConvWeight(out)
 
 
-def conv2d_dgrad(dy, wt_packed, x_hw, stride, padding, precision=None):
+def conv2d_dgrad(dy, wt_packed, x_hw, stride, padding, precision=None, dy_scale=None):
     """dy [B,Ho,Wo,Cout] -> dx [B,H,W,Cin] with wt_packed = pack_dgrad_weight(w)"""
     B, Ho, Wo, Cout = dy.shape
     Cin, kh, kw, _ = wt_packed.shape
@@ -894,7 +896,7 @@ def conv2d_dgrad(dy, wt_packed, x_hw, stride, padding, precision=None):
     # full correlation with the flipped kernel; any rows/cols the strided forward never touched get zero gradient
     ph, pw = kh - 1 - padding[0], kw - 1 - padding[1]
     need_h, need_w = H - (dy.shape[1] + 2 * ph - kh + 1), W - (dy.shape[2] + 2 * pw - kw + 1)
-    dx, _ = conv2d_nhwc(dy, wt_packed, None, (1, 1), (ph, pw), precision=precision)
+    dx, _ = conv2d_nhwc(dy, wt_packed, None, (1, 1), (ph, pw), precision=precision, x_scale=dy_scale)   # (dilation adds only zeros)
     if need_h or need_w:      # forward dropped trailing rows/cols (floor in the output-size formula)
         full = torch.zeros(B, H, W, Cin, device=dy.device, dtype=torch.float32)
         full[:, :dx.shape[1], :dx.shape[2]] = dx
