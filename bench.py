@@ -54,6 +54,8 @@ def make_opt(model, batch):
         o.Transformation, o.FeatureExtraction, o.SequenceModeling, o.Prediction = "TPS", "ResNet", "BiLSTM", "Attn"
     elif model == "crnn":
         o.Transformation, o.FeatureExtraction, o.SequenceModeling, o.Prediction = "None", "VGG", "BiLSTM", "CTC"
+    elif model == "svtr":
+        o.Transformation, o.FeatureExtraction, o.SequenceModeling, o.Prediction = "None", "SVTR", "None", "CTC"
     else:
         raise SystemExit(f"unknown model {model}")
     return o
@@ -125,7 +127,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--model", default="trba", choices=["trba", "crnn"])
+    ap.add_argument("--model", default="trba", choices=["trba", "crnn", "svtr"])
     ap.add_argument("--experts", type=int, default=6)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (reference default 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -193,7 +195,7 @@ def main():
             "config": {"workload": f"MRN loop B (router phase): {args.model.upper()} x {args.experts} frozen experts "
                                    f"(train-mode BN) + DM-Router fwd/bwd + clip + Adam, 32x256x4 crops, random-init weights",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "classes": [sum(CLASSES_MLT19[:i + 1]) + (4 if args.model == "crnn" else 5) for i in range(args.experts)],
+                       "classes": [sum(CLASSES_MLT19[:i + 1]) + (5 if args.model == "trba" else 4) for i in range(args.experts)],
                        "loss_clf": loss_clf.detach().item(), "loss_taski": loss_t.detach().item()},
         }
         if timer is not None and timer.spans:

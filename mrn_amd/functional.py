@@ -31,6 +31,29 @@ def x3_linear(x2, weight, bias=None, residual=None, act=ops.ACT_NONE):
     return y.view(R, N)
 
 
+_FROZEN_PACKS = {}
+
+
+def frozen_linear(x, weight, bias=None, act=ops.ACT_NONE, residual=None):
+    """Linear layer of a FROZEN module under no_grad (SVTR mixing blocks of the experts): split-fp16 x3 with the weight's
+    HL32 pack cached per (storage, version); x [..., K] contiguous.  Falls back to the exact-fp32 GEMM when not eligible."""
+    K, N = weight.shape[1], weight.shape[0]
+    ok = (not torch.is_grad_enabled() and not weight.requires_grad and ops.CONV_PRECISION in ("auto", "fp16x3") and K % 32 == 0
+          and N >= 64 and x.is_contiguous() and (residual is None or residual.is_contiguous()))
+    if not ok:
+        return ops.linear(x, weight, bias, act=act, residual=residual)
+    key = (weight.data_ptr(), weight._version, N, K)
+    got = _FROZEN_PACKS.get(id(weight))
+    if got is None or got[0] != key:
+        got = (key, ops.pack_weights_hl32([weight.detach().contiguous().view(N, 1, 1, K)]))
+        _FROZEN_PACKS[id(weight)] = got
+    w_hl, sw = got[1]
+    R = x.numel() // K
+    y, _ = ops.conv2d_x3(ops.split_hl32(x), 1, False, R, 1, 1, K, w_hl, sw, N, (1, 1), bias=bias, act=act,
+                         residual=residual.view(R, N) if residual is not None else None)
+    return y.view(*x.shape[:-1], N)
+
+
 def linear_fwd(x2, weight, bias=None, residual=None, act=ops.ACT_NONE):
     """router Linear: split-fp16 x3 when eligible, exact fp32 otherwise"""
     if x3_eligible(x2, weight.shape[0], weight.shape[1]) and (residual is None or residual.is_contiguous()):

@@ -379,16 +379,20 @@ class MRNNet(nn.Module):
                     stack = group.visual_all(image)                      # [I,B,T,C']
                     visuals = [stack[i] for i in range(I)]
                 else:
-                    visuals = [expert.model.visual(image) for expert in self.model]
-                main = torch.cuda.current_stream()
+                    visuals = None                                       # (SVTR: many small launches per expert -- whole
+                main = torch.cuda.current_stream()                       #  experts run side by side, one stream each)
                 streams = self._streams(I, dev)
                 for i, expert in enumerate(self.model):
                     streams[i].wait_stream(main)
                     with torch.cuda.stream(streams[i]):
-                        expert.heads(visuals[i], text, is_train, feature_out=feats[:, :, i, :], predict_out=logits[i])
-                        visuals[i].record_stream(streams[i])
+                        if visuals is None:
+                            expert(image, text, is_train, feature_out=feats[:, :, i, :], predict_out=logits[i])
+                        else:
+                            expert.heads(visuals[i], text, is_train, feature_out=feats[:, :, i, :], predict_out=logits[i])
+                            visuals[i].record_stream(streams[i])
                 for st in streams[:I]:
                     main.wait_stream(st)
+                    image.record_stream(st)
             else:
                 for i, expert in enumerate(self.model):
                     expert(image, text, is_train, feature_out=feats[:, :, i, :], predict_out=logits[i])

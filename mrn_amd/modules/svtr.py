@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from ..functional import frozen_linear
 from ._nn import conv_block, from_nhwc, require_no_grad, to_nhwc
 
 
@@ -86,7 +87,7 @@ class Attention(nn.Module):
         """x [B,N,C] -> proj(softmax(q k^T * scale + mask) v) (+ residual fused into the proj GEMM)"""
         B, N, C = x.shape
         h, d = self.num_heads, C // self.num_heads
-        qkv = ops.linear(x, self.qkv.weight, self.qkv.bias)                       # [B,N,3C] = (3, h, d) innermost
+        qkv = frozen_linear(x, self.qkv.weight, self.qkv.bias)                    # [B,N,3C] = (3, h, d) innermost
         mask = None
         if self.mask is not None:
             if self.mask.device != x.device:
@@ -107,7 +108,7 @@ class Attention(nn.Module):
             o = ctx[:, :, hd * d:(hd + 1) * d]
             # O[b][n][dd] = sum_m P[b][n][m] v[b][m][dd]  ->  "W operand"[dd][m] = v[m][dd]
             ops.gemm_raw(attn[:, hd], v, o, N, d, N, B, (h * N * N, N, 1), (N * 3 * C, 1, 3 * C), (N * C, C, 1))
-        return ops.linear(ctx, self.proj.weight, self.proj.bias, residual=residual)
+        return frozen_linear(ctx, self.proj.weight, self.proj.bias, residual=residual)
 
 
 class Block(nn.Module):
@@ -134,10 +135,10 @@ class Block(nn.Module):
             x = ops.residual_scale_rows(x, self.mixer.forward_tokens(y), sc, N)
         sc = self.drop_path.scale(B, x.device) if isinstance(self.drop_path, DropPath) else None
         y, _, _ = ops.layernorm_fwd(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        hdn = ops.linear(y, self.mlp.fc1.weight, self.mlp.fc1.bias, act=ops.ACT_GELU)
+        hdn = frozen_linear(y, self.mlp.fc1.weight, self.mlp.fc1.bias, act=ops.ACT_GELU)
         if sc is None:
-            return ops.linear(hdn, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=x)
-        return ops.residual_scale_rows(x, ops.linear(hdn, self.mlp.fc2.weight, self.mlp.fc2.bias), sc, N)
+            return frozen_linear(hdn, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=x)
+        return ops.residual_scale_rows(x, frozen_linear(hdn, self.mlp.fc2.weight, self.mlp.fc2.bias), sc, N)
 
 
 class PatchEmbed(nn.Module):
