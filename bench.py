@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 CLASSES_MLT19 = (2086, 220, 1728, 1160, 73, 102)      # README.md:103, per-task class counts
 FP32_MFMA_PEAK_TFLOPS = 157.3                          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0                         # MI355X_MICROARCH.md: dense bf16 MFMA peak
+HBM_PEAK_GBS = 8000.0                                  # MI355X_MICROARCH.md: HBM3E peak (6.3 TB/s achievable on a float4 copy)
 
 
 def pmc_traffic(kernel_name):
@@ -217,8 +218,19 @@ def main():
                 return (f"{kern}<{nsplit},{half}> (128x128x32 implicit-GEMM conv, {arith} on {inst}, "
                         f"{'pre-split operands staged by global_load_lds' if staging == 'dma' else 'activation split in registers'})",
                         BF16_MFMA_PEAK_TFLOPS, nsplit)
-            rl = []
+            rl, hbm = [], []
             for kind, s_ in kinds.items():
+                if kind.startswith("hbm/"):
+                    # HBM-bound pass: algorithmic bytes / union of its launch intervals against the 8 TB/s HBM3E peak
+                    gbs = s_["total_bytes"] / (s_["union_ms"] * 1e-3) / 1e9
+                    hbm.append({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                "traffic": pmc_traffic(kind[4:] + "_kernel"), "kernel": kind[4:] + "_kernel (BatchNorm-apply + "
+                                "residual + ReLU over all experts, fp32 in, HL32 split-fp16 operand out)",
+                                "algorithmic_bytes_per_launch": s_["total_bytes"] / s_["launches"],
+                                "launches_per_step": s_["launches"] / args.steps, "avg_launch_ms": s_["union_ms"] / s_["launches"],
+                                "avg_launch_ms_raw_event": s_["total_ms"] / s_["launches"],
+                                "kernel_share_of_step": s_["union_ms"] / (elapsed * 1e3)})
+                    continue
                 per_launch = s_["total_flops"] / s_["launches"]
                 raw_ms = s_["total_ms"] / s_["launches"]          # per-launch HIP-event time (what rocprofv3 reports)
                 # two lock-step half-groups run on two streams, so two launches of this kernel share the GPU most of the
@@ -237,8 +249,8 @@ def main():
                            })
             rl.sort(key=lambda r: -r["kernel_share_of_step"])
             res["roofline"] = rl[0]
-            if len(rl) > 1:
-                res["roofline_other_kernels"] = rl[1:]
+            if len(rl) > 1 or hbm:
+                res["roofline_other_kernels"] = rl[1:] + hbm
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(learner, opt, args.experts)
         print(json.dumps(res))

@@ -447,9 +447,13 @@ def bn_apply_grouped(y, scale, shift, relu=True, residual=None, want_f32=True, w
     G, C = y.shape[0], y.shape[-1]
     rows = y.numel() // (G * C)
     out_hl = torch.empty(y.numel() * 4, device=y.device, dtype=torch.uint8) if want_hl else None
+    t0 = CONV_TIMER.begin() if CONV_TIMER is not None else None
     call("mrn_bn_apply_grouped_f32", _p(y), _p(residual), _p(residual_hl), _p(scale), _p(shift), _p(y) if want_f32 else None,
          _p(out_hl), G, rows,
          C, int(bool(relu)), _stream())
+    if t0 is not None:       # algorithmic bytes: every input / output element once (fp32 and HL32 are both 4 B / element)
+        n_io = 1 + int(residual is not None or residual_hl is not None) + int(want_f32) + int(want_hl)
+        CONV_TIMER.end(t0, 0.0, "hbm/bn_apply_grouped", 4.0 * y.numel() * n_io)
     return (y if want_f32 else None), out_hl
 
 
