@@ -210,6 +210,12 @@ int mrn_attn_decoder_fwd_f32(const float* Hb, const float* Hproj, const float* e
  * of the 256 CUs.  Every pointer argument is a HOST array of `groups` device pointers (b_hh may be NULL). */
 int mrn_lstm_layer_fwd_grouped_f32(const void* const* xproj, const void* const* w_hh, const void* const* b_hh,
                                    const void* const* out, int groups, int B, int T, int hidden, int ndir, void* stream);
+/* Inference-only variant for the frozen experts: the recurrent product as split-fp16 x3 on v_mfma_f32_16x16x32_f16
+ * (h = hi + lo in LDS, W_hh pre-split with a power-of-two prescale into a fragment-major fp16 stream of the same size).
+ * w_hh[g]: [ndir][16][4][H/32][64 lanes][hi 8 | lo 8] fp16; w_inv[g]: device float[ndir] = 1 / prescale. */
+int mrn_lstm_layer_fwd_x3_grouped(const void* const* xproj, const void* const* w_hh, const void* const* w_inv,
+                                  const void* const* b_hh, const void* const* out, int groups, int B, int T, int hidden,
+                                  int ndir, void* stream);
 int mrn_attn_decoder_fwd_grouped_f32(const void* const* Hb, const void* const* Hproj, const void* const* eproj,
                                      int64_t eproj_stride_b, int64_t eproj_stride_s, const void* const* w_h2h,
                                      const void* const* b_h2h, const void* const* w_score, const void* const* w_ih_ctx,

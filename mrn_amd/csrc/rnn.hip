@@ -153,6 +153,126 @@ __global__ __launch_bounds__(NTH) void lstm_layer_kernel(const LstmGroup grp) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Inference variant of the LSTM layer for the FROZEN experts of the router phase: the recurrent product runs as
+// split-fp16 x3 on v_mfma_f32_16x16x32_f16 (h = hi + lo written to LDS as two fp16 planes by the pointwise stage, W_hh
+// pre-split with a power-of-two prescale into a fragment-major fp16 stream of the same byte size), 96 MFMAs of 16 cycles
+// per wave and step instead of 256 MFMAs of 32 cycles on the exact-fp32 matrix pipe.  Same launch geometry, grouping and
+// XCD pinning as lstm_layer_kernel; no training saves.
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 f16v8 __attribute__((ext_vector_type(8)));
+constexpr int LDH = HID + 8;   // fp16 LDS row (halves): 528 B, 16 rows hit 16 distinct 16-byte bank groups
+
+// acc[g] += A(16 x K, fp16 hi / lo planes in LDS) . W_g^T with W FRAGMENT-MAJOR fp16:
+//   Wp[(((wave*NG + g)*Q + q)*64 + lane)*2 + {0: hi, 1: lo}] = 8 halves W[g*HID + 16*wave + (lane&15)][32q + 8*(lane>>4) .. +7]
+template <int NG>
+__device__ __forceinline__ void mma_rows_h(f32x4 (&acc)[NG], const _Float16* __restrict__ a_hi, const _Float16* __restrict__ a_lo,
+                                           const unsigned char* __restrict__ Wp, int K, int wave, int lane) {
+  const int n = lane & 15, kg = lane >> 4;
+  const int Q = K / 32;
+  const f16v8* wp = reinterpret_cast<const f16v8*>(Wp) + ((long)wave * NG * Q * 64 + lane) * 2;
+  const _Float16* ah = a_hi + n * LDH + kg * 8;
+  const _Float16* al = a_lo + n * LDH + kg * 8;
+  f16v8 wh[NG], wl[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    wh[g] = wp[(long)g * Q * 128];
+    wl[g] = wp[(long)g * Q * 128 + 1];
+  }
+#pragma unroll 1
+  for (int q = 0; q < Q; ++q) {
+    f16v8 nh[NG], nl[NG];
+    const int qn = (q + 1 < Q) ? q + 1 : q;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      nh[g] = wp[((long)g * Q + qn) * 128];
+      nl[g] = wp[((long)g * Q + qn) * 128 + 1];
+    }
+    const f16v8 xh = *reinterpret_cast<const f16v8*>(ah + q * 32), xl = *reinterpret_cast<const f16v8*>(al + q * 32);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, wh[g], acc[g], 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wl[g], acc[g], 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wh[g], acc[g], 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      wh[g] = nh[g];
+      wl[g] = nl[g];
+    }
+  }
+}
+
+__device__ __forceinline__ void store_h_split(_Float16* hi, _Float16* lo, int idx, float v) {
+  const _Float16 h = (_Float16)v;
+  hi[idx] = h;
+  lo[idx] = (_Float16)(v - (float)h);
+}
+
+struct LstmX3Params {
+  const float* xproj; const unsigned char* w_hh; const float* w_inv; const float* b_hh; float* out;
+};
+struct LstmX3Group {
+  LstmX3Params g[MAX_GROUPS];
+  int tiles, B, T, ndir, nsets, pinned;
+};
+
+__global__ __launch_bounds__(NTH) void lstm_layer_x3_kernel(const LstmX3Group grp) {
+  __shared__ __attribute__((aligned(16))) _Float16 h_hi[2][BT * LDH];
+  __shared__ __attribute__((aligned(16))) _Float16 h_lo[2][BT * LDH];
+  const int set = grp.pinned ? (int)(blockIdx.x % 8) + 8 * (int)((blockIdx.x / 8) / grp.tiles) : (int)blockIdx.x / grp.tiles;
+  if (set >= grp.nsets) return;
+  const int gi = set / grp.ndir;
+  const float* __restrict__ xproj = grp.g[gi].xproj;
+  const float* __restrict__ b_hh = grp.g[gi].b_hh;
+  float* __restrict__ out = grp.g[gi].out;
+  const int B = grp.B, T = grp.T, ndir = grp.ndir;
+  const int dir = set - gi * grp.ndir;
+  const int b0 = (grp.pinned ? (int)((blockIdx.x / 8) % grp.tiles) : (int)blockIdx.x % grp.tiles) * BT;
+  const int t_ = threadIdx.x, lane = t_ & 63, wave = t_ >> 6;
+  const unsigned char* W = grp.g[gi].w_hh + (long)dir * 4 * HID * HID * 4;     // hi + lo fp16 = 4 bytes per weight
+  const float inv = grp.g[gi].w_inv[dir];
+  const int col = lane & 15, rbase = (lane >> 4) * 4;
+  const int j = wave * 16 + col;
+
+  for (int i = t_; i < BT * LDH; i += NTH) {
+    h_hi[0][i] = (_Float16)0.f;
+    h_lo[0][i] = (_Float16)0.f;
+  }
+  float c[4] = {0.f, 0.f, 0.f, 0.f}, bh[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) bh[g] = b_hh ? b_hh[dir * 4 * HID + g * HID + j] : 0.f;
+  __syncthreads();
+
+  for (int step = 0; step < T; ++step) {
+    const int t = dir == 0 ? step : T - 1 - step;
+    const int cur = step & 1;
+    float xg[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int b = b0 + rbase + r;
+      const float* xp = xproj + ((long)(b < B ? b : 0) * T + t) * (ndir * 4 * HID) + dir * 4 * HID + j;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) xg[g][r] = xp[g * HID];
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    mma_rows_h<4>(acc, h_hi[cur], h_lo[cur], W, HID, wave, lane);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] *= inv;            // undo the power-of-two weight prescale (exact)
+    float h[4], act[4][4];
+    lstm_pointwise(acc, xg, bh, c, h, act);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = rbase + r, b = b0 + row;
+      if (b < B) out[((long)b * T + t) * (ndir * HID) + dir * HID + j] = h[r];
+      store_h_split(h_hi[cur ^ 1], h_lo[cur ^ 1], row * LDH + j, b < B ? h[r] : 0.f);
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Attention decoder, all S steps in one launch (reference recomputes i2h(H) every step and issues ~10
 // small launches per step; here i2h(H) and the embedding half of the LSTMCell input projection are hoisted
 // into GEMMs by the caller).
@@ -435,6 +555,35 @@ MRN_EXPORT int mrn_lstm_layer_fwd_grouped_f32(const void* const* xproj, const vo
     grp.tiles = ceil_div(B, BT); grp.B = B; grp.T = T; grp.ndir = ndir;
     const int rc = lstm_launch(grp, n, (hipStream_t)stream);
     if (rc) return rc;
+  }
+  return MRN_OK;
+}
+
+// Inference-only LSTM layers of `groups` frozen experts with the recurrent product on the f16 MFMA (split-fp16 x3).
+// w_hh: HOST array of device pointers to the fragment-major fp16 streams ([ndir][16][4][H/32][64][hi 8 | lo 8 halves],
+// ops.pack_fragment_major_h), w_inv: HOST array of device float[ndir] = 1 / prescale of each direction's weights.
+MRN_EXPORT int mrn_lstm_layer_fwd_x3_grouped(const void* const* xproj, const void* const* w_hh, const void* const* w_inv,
+                                             const void* const* b_hh, const void* const* out, int groups, int B, int T,
+                                             int hidden, int ndir, void* stream) {
+  MRN_CHECK_ARG(xproj && w_hh && w_inv && out && groups >= 1, "mrn_lstm_layer_fwd_x3_grouped: null operand");
+  MRN_CHECK_ARG(hidden == HID, "mrn_lstm_layer_fwd_x3_grouped: hidden=%d unsupported (library is built for %d)", hidden, HID);
+  MRN_CHECK_ARG(ndir == 1 || ndir == 2, "mrn_lstm_layer_fwd_x3_grouped: ndir=%d", ndir);
+  if (B == 0 || T == 0) return MRN_OK;
+  for (int g0 = 0; g0 < groups; g0 += MAX_GROUPS) {
+    const int n = groups - g0 < MAX_GROUPS ? groups - g0 : MAX_GROUPS;
+    LstmX3Group grp;
+    memset(&grp, 0, sizeof(grp));
+    for (int i = 0; i < n; ++i) {
+      MRN_CHECK_ARG(xproj[g0 + i] && w_hh[g0 + i] && w_inv[g0 + i] && out[g0 + i], "mrn_lstm_layer_fwd_x3_grouped: null operand in group %d", g0 + i);
+      grp.g[i] = LstmX3Params{(const float*)xproj[g0 + i], (const unsigned char*)w_hh[g0 + i], (const float*)w_inv[g0 + i],
+                              b_hh ? (const float*)b_hh[g0 + i] : nullptr, (float*)out[g0 + i]};
+    }
+    grp.tiles = ceil_div(B, BT); grp.B = B; grp.T = T; grp.ndir = ndir;
+    grp.nsets = n * ndir;
+    grp.pinned = grp.nsets > 2 && grp.tiles * ceil_div(grp.nsets, 8) <= 32;
+    const int blocks = grp.pinned ? 8 * ceil_div(grp.nsets, 8) * grp.tiles : grp.nsets * grp.tiles;
+    hipLaunchKernelGGL(lstm_layer_x3_kernel, dim3(blocks), dim3(NTH), 0, (hipStream_t)stream, grp);
+    MRN_LAUNCH_CHECK("lstm_layer_x3");
   }
   return MRN_OK;
 }

@@ -314,7 +314,16 @@ class HeadsGroup(_GroupedLinear):
         xproj = self._linear("ih%d" % idx, x_hl, B * T, K, [p[0] for p in packed], [p[2] for p in packed])
         w_hh = self._cached("hh%d" % idx, [p[1] for p in packed], lambda: torch.stack([p[1] for p in packed]).contiguous())
         b_hh = self._cached("bhh%d" % idx, [p[3] for p in packed], lambda: torch.stack([p[3] for p in packed]).contiguous())
-        rec = ops.lstm_layer_grouped(xproj.view(G, B, T, 2 * 4 * H), w_hh, b_hh, H, 2)
+        if ops.RECURRENT_X3:
+            # recurrent product on the f16 MFMA: W_hh pre-split into a fragment-major fp16 stream (cached), h split in LDS
+            def build():
+                packs = [[ops.pack_fragment_major_h(w) for w in (m.rnn.weight_hh_l0, m.rnn.weight_hh_l0_reverse)] for m in mods]
+                return (torch.stack([torch.stack([d[0] for d in p]) for p in packs]).contiguous(),
+                        torch.stack([torch.cat([d[1] for d in p]) for p in packs]).contiguous())
+            w_h, w_inv = self._cached("hh16_%d" % idx, [w for m in mods for w in (m.rnn.weight_hh_l0, m.rnn.weight_hh_l0_reverse)], build)
+            rec = ops.lstm_layer_x3_grouped(xproj.view(G, B, T, 2 * 4 * H), w_h, w_inv, b_hh, H, 2)
+        else:
+            rec = ops.lstm_layer_grouped(xproj.view(G, B, T, 2 * 4 * H), w_hh, b_hh, H, 2)
         return self._linear("lin%d" % idx, ops.split_hl32(rec), B * T, 2 * H, [m.linear.weight for m in mods],
                             [m.linear.bias for m in mods]).view(G, B, T, -1)
 

@@ -64,6 +64,7 @@ TIMER_SHAPES = False         # tools/layer_times.py: one timer kind per layer sh
 #             device from max|.| (gradients of 1e-6 would otherwise fall into fp16's subnormal range)
 #   "f32"     exact fp32 MFMA
 ROUTER_GEMM_PRECISION = "fp16x3"
+RECURRENT_X3 = __import__("os").environ.get("MRN_RECURRENT", "fp16x3") == "fp16x3"   # frozen experts' LSTM recurrences on the f16 MFMA
 ROUTER_WGRAD_X3 = __import__("os").environ.get("MRN_WGRAD", "fp16x3") == "fp16x3"     # weight-gradient GEMMs too (A/B switch)
 
 # Arithmetic of the large implicit-GEMM convs (Cout > 64, K % 32 == 0):
@@ -560,6 +561,32 @@ def lstm_layer(xproj, w_hh, b_hh, hidden, ndir, save=False):
 def _ptr_array(ptrs):
     import ctypes
     return (ctypes.c_void_p * len(ptrs))(*ptrs)
+
+
+def pack_fragment_major_h(w, hidden=256):
+    """[G*hidden, K] fp32 weight (K % 32 == 0) -> (fp16 fragment-major split stream for the f16 MFMA recurrent kernels,
+    inverse prescale [1]): packed[w][g][q][lane = kg*16 + n][plane][e] = split(s * W[g*hidden + 16w + n][32q + 8kg + e])"""
+    G = w.shape[0] // hidden
+    K = w.shape[1]
+    assert w.shape[0] == G * hidden and hidden == 256 and K % 32 == 0
+    sc = pow2_scale(w.contiguous())
+    v = (w * sc[0]).reshape(G, 16, 16, K // 32, 4, 8).permute(1, 0, 3, 4, 2, 5)     # w, g, q, kg, n, e
+    hi = v.half()
+    lo = (v - hi.float()).half()
+    return torch.stack([hi, lo], dim=5).contiguous(), sc[1:2].clone()                  # [..., n, plane, e]
+
+
+def lstm_layer_x3_grouped(xproj, w_hh_h, w_inv, b_hh, hidden, ndir):
+    """xproj [G,B,T,ndir*4H]; w_hh_h [G,ndir,...] fp16 streams (pack_fragment_major_h), w_inv [G,ndir], b_hh [G,ndir*4H]"""
+    _chk(xproj, b_hh)
+    G, B, T, _ = xproj.shape
+    assert xproj.is_contiguous() and w_hh_h.is_contiguous() and w_inv.is_contiguous() and b_hh.is_contiguous()
+    out = torch.empty(G, B, T, ndir * hidden, device=xproj.device, dtype=torch.float32)
+    call("mrn_lstm_layer_fwd_x3_grouped", _ptr_array([xproj[g].data_ptr() for g in range(G)]),
+         _ptr_array([w_hh_h[g].data_ptr() for g in range(G)]), _ptr_array([w_inv[g].data_ptr() for g in range(G)]),
+         _ptr_array([b_hh[g].data_ptr() for g in range(G)]), _ptr_array([out[g].data_ptr() for g in range(G)]), G, B, T,
+         hidden, ndir, _stream())
+    return out
 
 
 def lstm_layer_grouped(xproj, w_hh, b_hh, hidden, ndir):

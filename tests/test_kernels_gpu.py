@@ -487,3 +487,19 @@ def test_conv_weight_gradient_x3(ops, cfg, magnitude):
     y.backward(dy)
     dw = ops.conv2d_wgrad_x3(cu(dy.permute(0, 2, 3, 1).contiguous()), cu(x.permute(0, 2, 3, 1).contiguous()), k, s, p)
     assert_close("x3 conv wgrad", dw.permute(0, 3, 1, 2), w.grad, atol=2e-5 * magnitude, rtol=2e-6)
+
+
+def test_lstm_recurrence_on_f16_mfma(ops):
+    """mrn_lstm_layer_fwd_x3_grouped (split-fp16 x3 recurrent product, fragment-major fp16 weight stream) against the
+    exact-fp32 recurrent kernel"""
+    G, B, T, Hd = 3, 19, 29, 256
+    xproj = cu(rnd(G, B, T, 8 * Hd, seed=240, scale=0.7))
+    ws = [[cu(rnd(4 * Hd, Hd, seed=241 + 2 * g + d, scale=(1 + g) / 16.0)) for d in range(2)] for g in range(G)]
+    b_hh = cu(rnd(G, 8 * Hd, seed=250, scale=1 / 16.0))
+    w_f32 = torch.stack([torch.stack([ops.pack_fragment_major(w) for w in p]) for p in ws]).contiguous()
+    ref = ops.lstm_layer_grouped(xproj, w_f32, b_hh, Hd, 2)
+    packs = [[ops.pack_fragment_major_h(w) for w in p] for p in ws]
+    w_h = torch.stack([torch.stack([d[0] for d in p]) for p in packs]).contiguous()
+    w_inv = torch.stack([torch.cat([d[1] for d in p]) for p in packs]).contiguous()
+    out = ops.lstm_layer_x3_grouped(xproj, w_h, w_inv, b_hh, Hd, 2)
+    assert_close("lstm on the f16 MFMA", out, ref, atol=2e-6, rtol=1e-5)
