@@ -306,7 +306,7 @@ __device__ __forceinline__ float fast_tanh(float x) {
 
 struct AttnDecGroup {
   AttnDecParams g[MAX_GROUPS];
-  int tiles, groups, pinned;
+  int tiles, groups, pinned, vb;
 };
 
 __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecGroup grp) {
@@ -323,7 +323,12 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecGroup gr
   float* e_lds = ctx_lds + BT * CLD;       // [BT][T]
   float* sw_lds = e_lds + BT * T;          // [HID]
 
-  const int b0 = (grp.pinned ? (int)((blockIdx.x / 8) % grp.tiles) : (int)blockIdx.x % grp.tiles) * BT;
+  // vb = samples per workgroup (16, or 8 when the batch would otherwise occupy less than half of the CUs: every step
+  // re-reads the workgroup's Hproj / Hb slices (66 KB per sample each), so more, smaller workgroups shorten the step);
+  // rows >= vb of the 16-row MFMA tile are treated like rows beyond the batch
+  const int vb = grp.vb;
+  const int b0 = (grp.pinned ? (int)((blockIdx.x / 8) % grp.tiles) : (int)blockIdx.x % grp.tiles) * vb;
+  const int Bend = min(p.B, b0 + vb);
   const int t_ = threadIdx.x, lane = t_ & 63, wave = t_ >> 6;
   const int col = lane & 15, rbase = (lane >> 4) * 4;
   const int j = wave * 16 + col;
@@ -331,8 +336,9 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecGroup gr
   for (int i = t_; i < BT * HLD; i += NTH) {
     const int row = i / HLD, jj = i - row * HLD;
     const int b = b0 + row;
-    h_lds[i] = (p.h_state && b < p.B && jj < HID) ? p.h_state[(long)b * HID + jj] : 0.f;
+    h_lds[i] = (p.h_state && b < Bend && jj < HID) ? p.h_state[(long)b * HID + jj] : 0.f;
   }
+  for (int i = t_; i < BT * (HLD + CLD + T); i += NTH) hp_lds[i] = 0.f;     // hp, ctx, e: rows >= vb stay zero
   for (int i = t_; i < HID; i += NTH) sw_lds[i] = p.w_score[i];
   float bh[4], c[4];
 #pragma unroll
@@ -340,7 +346,7 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecGroup gr
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int b = b0 + rbase + r;
-    c[r] = (p.c_state && b < p.B) ? p.c_state[(long)b * HID + j] : 0.f;
+    c[r] = (p.c_state && b < Bend) ? p.c_state[(long)b * HID + j] : 0.f;
   }
   const float bj = p.b_h2h[j];
   __syncthreads();
@@ -351,7 +357,7 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecGroup gr
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int b = b0 + rbase + r;
-      const float* ep = p.eproj + (long)(b < p.B ? b : 0) * p.eproj_stride_b + (long)step * p.eproj_stride_s + j;
+      const float* ep = p.eproj + (long)(b < Bend ? b : 0) * p.eproj_stride_b + (long)step * p.eproj_stride_s + j;
 #pragma unroll
       for (int g = 0; g < 4; ++g) xg[g][r] = ep[g * HID];
     }
@@ -364,7 +370,7 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecGroup gr
         const float v = acc[0][r] + bj;
         hp_lds[(rbase + r) * HLD + j] = v;
         const int b = b0 + rbase + r;
-        if (p.hp_out && b < p.B) p.hp_out[((long)b * p.S + step) * HID + j] = v;
+        if (p.hp_out && b < Bend) p.hp_out[((long)b * p.S + step) * HID + j] = v;
       }
     }
     __syncthreads();
@@ -372,17 +378,18 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecGroup gr
     //     flight per wave so the Hproj loads (L2) and the cross-lane reductions of different pairs overlap
     {
       const f32x4 wv = *reinterpret_cast<const f32x4*>(sw_lds + lane * 4);
-      for (int pr0 = wave * 4; pr0 < BT * T; pr0 += NW * 4) {
+      const int npair = vb * T;
+      for (int pr0 = wave * 4; pr0 < npair; pr0 += NW * 4) {
         f32x4 hv[4];
         int rows[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int pr = pr0 + u;
-          const int row = pr < BT * T ? pr / T : 0, t = pr < BT * T ? pr - row * T : 0;
+          const int row = pr < npair ? pr / T : 0, t = pr < npair ? pr - row * T : 0;
           rows[u] = row;
           const int b = b0 + row;
           hv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (pr < BT * T && b < p.B) hv[u] = *reinterpret_cast<const f32x4*>(p.Hproj + ((long)b * T + t) * HID + lane * 4);
+          if (pr < npair && b < Bend) hv[u] = *reinterpret_cast<const f32x4*>(p.Hproj + ((long)b * T + t) * HID + lane * 4);
         }
         float sacc[4];
 #pragma unroll
@@ -398,7 +405,7 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecGroup gr
 #pragma unroll
           for (int u = 0; u < 4; ++u) sacc[u] += __shfl_xor(sacc[u], o);
         }
-        if (lane < 4 && pr0 + lane < BT * T) {
+        if (lane < 4 && pr0 + lane < npair) {
           const float v = lane == 0 ? sacc[0] : lane == 1 ? sacc[1] : lane == 2 ? sacc[2] : sacc[3];
           e_lds[pr0 + lane] = (b0 + (pr0 + lane) / T < p.B) ? v : 0.f;
         }
@@ -406,7 +413,7 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecGroup gr
     }
     __syncthreads();
     // (3) softmax over t, one wave per sample
-    {
+    if (wave < vb) {
       const int row = wave;
       float m = -INFINITY;
       for (int t = lane; t < T; t += 64) m = fmaxf(m, e_lds[row * T + t]);
@@ -423,16 +430,16 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecGroup gr
         const float a = e_lds[row * T + t] * inv;
         e_lds[row * T + t] = a;
         const int b = b0 + row;
-        if (p.alpha_out && b < p.B) p.alpha_out[((long)b * p.S + step) * T + t] = a;
+        if (p.alpha_out && b < Bend) p.alpha_out[((long)b * p.S + step) * T + t] = a;
       }
     }
     __syncthreads();
     // (4) context[b][:] = sum_t alpha[b][t] * Hb[b][t][:]
-    for (int it = t_; it < BT * (D / 4); it += NTH) {
+    for (int it = t_; it < vb * (D / 4); it += NTH) {
       const int row = it / (D / 4), c4 = it - row * (D / 4);
       const int b = b0 + row;
       f32x4 a = {0.f, 0.f, 0.f, 0.f};
-      if (b < p.B) {
+      if (b < Bend) {
         const float* hb = p.Hb + (long)b * T * D + c4 * 4;
         int t = 0;
 #pragma unroll 1
@@ -455,7 +462,7 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecGroup gr
         }
       }
       *reinterpret_cast<f32x4*>(ctx_lds + row * CLD + c4 * 4) = a;
-      if (p.ctx_out && b < p.B) *reinterpret_cast<f32x4*>(p.ctx_out + ((long)b * p.S + step) * D + c4 * 4) = a;
+      if (p.ctx_out && b < Bend) *reinterpret_cast<f32x4*>(p.ctx_out + ((long)b * p.S + step) * D + c4 * 4) = a;
     }
     __syncthreads();
     // (5) gates = eproj + ctx . W_ih[:, :D]^T + h . W_hh^T ; (6) LSTM cell
@@ -471,7 +478,7 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecGroup gr
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = rbase + r, b = b0 + row;
-        if (b < p.B) {
+        if (b < Bend) {
           p.hid[(long)b * p.hid_stride_b + (long)step * p.hid_stride_s + j] = h[r];
           if (p.gates_out) {
             const long base = (long)b * p.S + step;
@@ -480,7 +487,7 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecGroup gr
             p.c_out[base * HID + j] = c[r];
           }
         }
-        h_lds[row * HLD + j] = b < p.B ? h[r] : 0.f;
+        h_lds[row * HLD + j] = b < Bend ? h[r] : 0.f;
       }
     }
     __syncthreads();
@@ -490,7 +497,7 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecGroup gr
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = rbase + r, b = b0 + row;
-      if (b < p.B) {
+      if (b < Bend) {
         p.h_state[(long)b * HID + j] = h_lds[row * HLD + j];
         p.c_state[(long)b * HID + j] = c[r];
       }
@@ -603,6 +610,9 @@ static int attn_fill(AttnDecParams& p, const float* Hb, const float* Hproj, cons
 
 static int attn_launch(AttnDecGroup& grp, int groups, int D, int T, hipStream_t st) {
   grp.groups = groups;
+  const int B = grp.g[0].B;
+  grp.vb = (groups * ceil_div(B, BT) <= 128 && B > 8) ? 8 : BT;
+  grp.tiles = ceil_div(B, grp.vb);
   grp.pinned = groups > 1 && grp.tiles * ceil_div(groups, 8) <= 32;
   const size_t lds = sizeof(float) * (2 * BT * HLD + BT * (D + 4) + BT * T + HID);
   MRN_CHECK_ARG(lds <= 160 * 1024, "mrn_attn_decoder_fwd: LDS budget exceeded (D=%d T=%d)", D, T);
