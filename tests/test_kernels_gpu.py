@@ -503,3 +503,29 @@ def test_lstm_recurrence_on_f16_mfma(ops):
     w_inv = torch.stack([torch.cat([d[1] for d in p]) for p in packs]).contiguous()
     out = ops.lstm_layer_x3_grouped(xproj, w_h, w_inv, b_hh, Hd, 2)
     assert_close("lstm on the f16 MFMA", out, ref, atol=2e-6, rtol=1e-5)
+
+
+def test_full_size_dominant_conv_properties(ops):
+    """BASELINE-size check of the dominant kernel (6 experts x 256 images, 4x65 maps, 512->512 3x3) through properties that
+    do not need a CPU reference: agreement with the exact-fp32 MFMA kernel, homogeneity under power-of-two scaling
+    (the tap-skipping tile schedule and the hi/lo splits are scale-invariant up to fp16 subnormals), agreement of the fused BatchNorm partial
+    statistics with reductions of the output, and independence of the groups."""
+    G, B, H, W, C = 6, 256, 4, 65, 512
+    torch.manual_seed(3)
+    x = torch.rand(G, B, H, W, C, device="cuda") * 2 - 1
+    ws = [(torch.rand(C, 3, 3, C, device="cuda") * 2 - 1) * 0.02 for _ in range(G)]
+    w_hl, w_scale = ops.pack_weights_hl32(ws)
+    y, stats = ops.conv2d_x3(ops.split_hl32(x), G, False, B, H, W, C, w_hl, w_scale, C, (3, 3), (1, 1), (1, 1), want_stats=True)
+    for g in (0, 5):
+        ref, _ = ops.conv2d_nhwc(x[g], ws[g], None, (1, 1), (1, 1), precision="f32")
+        assert_close(f"full-size x3 vs exact fp32, expert {g}", y[g], ref, atol=1e-5, rtol=1e-5)
+    y4, _ = ops.conv2d_x3(ops.split_hl32(x * 4.0), G, False, B, H, W, C, w_hl, w_scale, C, (3, 3), (1, 1), (1, 1))
+    # homogeneity under a power-of-two scale: exact up to the lo halves that cross fp16's subnormal threshold
+    assert_close("homogeneity", y4, y * 4.0, atol=2e-6, rtol=1e-6)
+    tot = stats.view(G, -1, 2, C).sum(1)
+    assert_close("fused column sums", tot[:, 0], y.sum((1, 2, 3)), atol=2e-2, rtol=2e-5)
+    assert_close("fused column sums of squares", tot[:, 1], (y * y).sum((1, 2, 3)), atol=2e-2, rtol=2e-5)
+    # groups are independent: expert 2 alone gives bit-identical rows
+    w2, s2 = ops.pack_weights_hl32([ws[2]])
+    y2, _ = ops.conv2d_x3(ops.split_hl32(x[2:3].contiguous()), 1, False, B, H, W, C, w2, s2, C, (3, 3), (1, 1), (1, 1))
+    assert torch.equal(y2[0], y[2])
