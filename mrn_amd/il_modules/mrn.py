@@ -89,13 +89,25 @@ class MRN(BaseLearner):
         self.criterion = self.build_criterion()
         self.build_optimizer(self.count_param(), scale=1.0, total_steps=total_steps or self.opt.num_iter * 2)
 
-    def routing_step(self, image, labels, indexs, pi=15):
-        """one iteration of mrn.py:329-371"""
+    def prefetch_experts(self, image, labels):
+        """Issue the frozen experts' forward of a FUTURE loop-B batch (label encoding + MRNNet.experts_prefetch); pass the
+        result to routing_step(..., prefetched=...).  The experts are frozen in loop B (mrn.py:285-286), so their forward
+        for batch n+1 does not depend on the router update of batch n; only the launch order changes, not the results."""
         labels_index, labels_length = self.converter.encode(labels, batch_max_length=self.opt.batch_max_length)
-        if "CTC" in self.opt.Prediction:
-            output = self.model(image, True)
+        text = None if "CTC" in self.opt.Prediction else labels_index[:, :-1]
+        return self.model.module.experts_prefetch(image, text, True), labels_index, labels_length
+
+    def routing_step(self, image, labels, indexs, pi=15, prefetched=None):
+        """one iteration of mrn.py:329-371"""
+        if prefetched is not None:
+            handle, labels_index, labels_length = prefetched
         else:
-            output = self.model(image, True, labels_index[:, :-1], True)
+            handle = None
+            labels_index, labels_length = self.converter.encode(labels, batch_max_length=self.opt.batch_max_length)
+        if "CTC" in self.opt.Prediction:
+            output = self.model(image, True, experts=handle)
+        else:
+            output = self.model(image, True, labels_index[:, :-1], True, experts=handle)
         taski_loss = Fn.cross_entropy(output["index"], indexs, -100)     # CE on the already-softmaxed weights
         loss_clf = self.criterion(output["logits"], labels_index, labels_length)
         loss = pi * loss_clf + taski_loss
@@ -108,10 +120,17 @@ class MRN(BaseLearner):
         start_time = time.time()
         best_score = -1
         n_iter = int(self.opt.num_iter // 2)
-        for iteration in range(start_iter + 1, n_iter + 1):
+        def fetch():
             image_tensors, labels, indexs = train_loader.get_batch2()
-            indexs = to_device(torch.LongTensor(indexs).squeeze())
-            loss_clf, taski_loss = self.routing_step(image_tensors.to(self.device), labels, indexs, pi)
+            image = image_tensors.to(self.device)
+            return image, labels, to_device(torch.LongTensor(indexs).squeeze()), self.prefetch_experts(image, labels)
+
+        nxt = fetch()             # software pipeline: batch n+1's frozen-expert forward is issued before batch n's router phase
+        for iteration in range(start_iter + 1, n_iter + 1):
+            image, labels, indexs, pre = nxt
+            if iteration < n_iter:
+                nxt = fetch()
+            loss_clf, taski_loss = self.routing_step(image, labels, indexs, pi, prefetched=pre if pre[0] is not None else None)
             train_loss_avg.add(loss_clf.detach())
             train_taski_loss_avg.add(taski_loss.detach())
             if iteration % max(self.opt.val_interval // 5, 1) == 0 or iteration == n_iter or iteration == 1:

@@ -334,20 +334,74 @@ class MRNNet(nn.Module):
     def feature_dim(self):
         return 0 if self.out_dim is None else self.out_dim * len(self.model)
 
-    def forward(self, image, cross=True, text=None, is_train=True):
+    def forward(self, image, cross=True, text=None, is_train=True, experts=None):
+        """`experts`: optional handle from experts_prefetch() -- the frozen experts' outputs for THIS batch, issued earlier"""
         if cross == False:  # noqa: E712  (learners pass cross positionally, exactly as in the reference)
             features, index = self.model[-1](image, text, is_train)["predict"], None
         elif is_train == False:  # noqa: E712
             features, index = self.cross_forward_expert(image, text, is_train)
         else:
-            features, index = self.cross_forward(image, text, is_train)
+            features, index = self.cross_forward(image, text, is_train, experts=experts)
         return {"logits": features, "index": index, "aux_logits": None}
 
     # -- shared by both routed paths -------------------------------------------------------------------
-    def _experts_and_gate(self, image, text, is_train):
+    def experts_prefetch(self, image, text=None, is_train=True):
+        """Issue the FROZEN experts' forward for a batch on the side streams and return a handle for
+        forward(..., experts=handle) -- or None when the experts cannot run as lock-step half-groups.
+
+        In the router phase the experts do not depend on the router being trained, so a learner can issue batch n+1's
+        expert forward before batch n's router forward / backward / Adam: the side streams then run it while the main
+        stream is busy with the router.  The side streams wait only for the inputs (an event recorded after the NHWC
+        conversion), every output lives in the issuing stream's allocator pool, and the consumer waits on per-half
+        events, so nothing orders the prefetch behind the router work of the previous step."""
+        I = len(self.model)
+        with torch.no_grad():
+            group = self._backbone_group() if I > 1 else None
+            halves = self._half_groups(is_train) if self._heads_group(group, is_train) is not None else None
+            if halves is None:
+                return None
+            B, dev = image.shape[0], image.device
+            img = to_nhwc(image).permute(0, 3, 1, 2)
+            T_pred = self.patch if self.opt.Prediction == "CTC" else self.opt.batch_max_length + 1
+            main = torch.cuda.current_stream()
+            ready = torch.cuda.Event()
+            ready.record(main)
+            streams = self._streams(len(halves), dev)
+            parts = []
+            for (lo, hi, bg, hg), st in zip(halves, streams):
+                st.wait_event(ready)
+                with torch.cuda.stream(st):
+                    f = torch.empty(B, self.patch, hi - lo, self.out_dim, device=dev, dtype=torch.float32)
+                    lg = [ops.padded_rows(B, T_pred, e.fc.out_features, dev) for e in list(self.model)[lo:hi]]
+                    hg.run(bg.visual_all(img, as_act=True), text, f, lg)
+                    done = torch.cuda.Event()
+                    done.record(st)
+                for t in (img, image, text):
+                    if t is not None:
+                        t.record_stream(st)
+                parts.append((f, lg, done))
+            return {"parts": parts, "batch": B}
+
+    def _experts_and_gate(self, image, text, is_train, experts=None):
         I = len(self.model)
         B = image.shape[0]
         dev = image.device
+        if experts is not None:
+            # outputs of experts_prefetch(): wait for the two half-groups, adopt their buffers on this stream
+            assert experts["batch"] == B
+            main = torch.cuda.current_stream()
+            fs, logits = [], []
+            for f, lg, done in experts["parts"]:
+                main.wait_event(done)
+                f.record_stream(main)
+                for l in lg:
+                    l.record_stream(main)
+                fs.append(f)
+                logits += lg
+            feats = torch.cat(fs, dim=2)
+            r = self.dm_router[0].forward_l2(feats)
+            r = LinearFn.apply(r.view(B * self.patch, I * self.out_dim), self.channel_route.weight, self.channel_route.bias)
+            return logits, r.view(B, self.patch, I)
         image = to_nhwc(image).permute(0, 3, 1, 2)          # one NHWC conversion shared by all experts
         T_pred = self.patch if self.opt.Prediction == "CTC" else self.opt.batch_max_length + 1
         feats = torch.empty(B, self.patch, I, self.out_dim, device=dev, dtype=torch.float32)
@@ -400,12 +454,12 @@ class MRNNet(nn.Module):
         r = LinearFn.apply(r.view(B * self.patch, I * self.out_dim), self.channel_route.weight, self.channel_route.bias)
         return logits, r.view(B, self.patch, I)
 
-    def cross_forward(self, image, text=None, is_train=True):
+    def cross_forward(self, image, text=None, is_train=True, experts=None):
         for expert in self.model:
             if torch.is_grad_enabled() and any(p.requires_grad for p in expert.parameters()):
                 raise NotImplementedError("cross_forward trains the router over FROZEN experts (il_modules/mrn.py:154-157,"
                                           "285-286); unfreeze is not supported on the HIP path")
-        logits, r = self._experts_and_gate(image, text, is_train)
+        logits, r = self._experts_and_gate(image, text, is_train, experts=experts)
         w = GateTailFn.apply(r, self.route.weight, self.route.bias, float(self.beta))
         return FaninFn.apply(w, *logits), w
 

@@ -59,3 +59,40 @@ def test_mrn_learner_two_tasks(tmp_path, model):
     assert all(k.startswith("module.") for k in sd)          # reference checkpoint layout (DataParallel prefix)
     log = sink.getvalue()
     assert "Train_taski_loss" in log and "Current_score" in log
+
+
+def test_prefetched_expert_forward_is_bit_identical(tmp_path):
+    """Loop B with the software pipeline (batch n+1's frozen-expert forward issued on the side streams before batch n's
+    router phase, MRN.prefetch_experts / MRNNet.experts_prefetch) against the strictly sequential loop: same losses and
+    bit-identical router parameters after several steps."""
+    import bench
+    from mrn_amd.data.synthetic import SyntheticTextLines
+    from mrn_amd.tools.utils import to_device
+    results = []
+    for pipeline in (True, False):
+        torch.manual_seed(111)
+        opt = bench.make_opt("crnn", 8)
+        learner = bench.build_learner(opt, 4)
+        data = SyntheticTextLines(opt, seed=5)
+        data.set_characters(learner.character)
+
+        def fetch():
+            image, labels, idx = data.get_batch2()
+            indexs = to_device(torch.LongTensor(idx).squeeze())
+            pre = learner.prefetch_experts(image, labels) if pipeline else None
+            assert not pipeline or pre[0] is not None
+            return image, labels, indexs, pre
+        nxt = fetch()
+        losses = []
+        for it in range(4):
+            image, labels, indexs, pre = nxt
+            if it < 3:                  # (as in MRN._update_representation: no look-ahead past the last batch)
+                nxt = fetch()
+            lc, lt = learner.routing_step(image, labels, indexs, prefetched=pre)
+            losses.append((float(lc), float(lt)))
+        torch.cuda.synchronize()
+        flat = learner.optimizer.flat.detach().clone()
+        bn = torch.cat([v.flatten().float() for k, v in learner.model.state_dict().items() if "running_var" in k])
+        results.append((losses, flat, bn))
+    assert results[0][0] == results[1][0]
+    assert torch.equal(results[0][1], results[1][1]) and torch.equal(results[0][2], results[1][2])
