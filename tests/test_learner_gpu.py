@@ -89,7 +89,7 @@ def test_prefetched_expert_forward_is_bit_identical(tmp_path):
             if it < 3:                  # (as in MRN._update_representation: no look-ahead past the last batch)
                 nxt = fetch()
             lc, lt = learner.routing_step(image, labels, indexs, prefetched=pre)
-            losses.append((float(lc), float(lt)))
+            losses.append((float(lc.detach()), float(lt.detach())))
         torch.cuda.synchronize()
         flat = learner.optimizer.flat.detach().clone()
         bn = torch.cat([v.flatten().float() for k, v in learner.model.state_dict().items() if "running_var" in k])
