@@ -138,6 +138,8 @@ def main():
                     help="conv arithmetic (mrn_amd/ops.py: CONV_PRECISION); auto keeps the 1e-4 parity band")
     ap.add_argument("--no-streams", action="store_true", help="run the experts sequentially on one stream")
     ap.add_argument("--no-pipeline", action="store_true", help="do not issue batch n+1's expert forward before batch n's router phase")
+    ap.add_argument("--serial", action="store_true", help="one lock-step group on one stream, no look-ahead (every kernel runs alone)")
+    ap.add_argument("--no-isolated-pass", action="store_true", help="skip the 2 extra serialized steps that measure the dominant kernel alone")
     args = ap.parse_args()
 
     from mrn_amd import ops, parallel
@@ -155,6 +157,9 @@ def main():
     opt = make_opt(args.model, args.batch)
     learner = build_learner(opt, args.experts, quiet=not args.verbose)
     learner.model.module.expert_streams = not args.no_streams
+    if args.serial:
+        learner.model.module.expert_halves = 0
+        args.no_pipeline = True
     data = SyntheticTextLines(opt, seed=111 + rank)
     data.set_characters(learner.character)
     dev = learner.device
@@ -190,6 +195,23 @@ def main():
     elapsed = time.perf_counter() - t0
     timer = ops.CONV_TIMER
     ops.CONV_TIMER = None
+    # Isolated pass (outside the timed region): the same workload with ONE lock-step group on ONE stream and no
+    # look-ahead, so every launch of the dominant kernel has the GPU to itself -- its own rate, next to the in-situ
+    # rate of the timed region where two half-groups and the router phase share the chip.
+    isolated = None
+    if timer is not None and rank == 0 and not args.no_isolated_pass:
+        net = learner.model.module
+        saved, net.expert_halves = net.expert_halves, 0
+        pending.clear()
+        image, labels, idx = data.get_batch2()
+        indexs = to_device(torch.LongTensor(idx).squeeze())
+        learner.routing_step(image, labels, indexs)            # (re-packs nothing: same weights; warms the G = 6 path)
+        ops.CONV_TIMER = ops.KernelTimer()
+        for _ in range(2):
+            learner.routing_step(image, labels, indexs)
+        isolated = ops.CONV_TIMER.summary()
+        ops.CONV_TIMER = None
+        net.expert_halves = saved
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -263,6 +285,20 @@ def main():
                            })
             rl.sort(key=lambda r: -r["kernel_share_of_step"])
             res["roofline"] = rl[0]
+            res["roofline"]["measured"] = ("timed region: HIP events per launch on the launch streams; two lock-step half-groups "
+                                           "and the router phase of the previous batch share the GPU, so the rate is taken over "
+                                           "the union of this kernel's launch intervals")
+            if isolated:
+                k = max((k for k in isolated if not k.startswith("hbm/")), key=lambda k: isolated[k]["total_ms"])
+                i_ = isolated[k]
+                ms = i_["total_ms"] / i_["launches"]
+                ach = i_["total_flops"] / i_["launches"] / (ms * 1e-3) / 1e12
+                kname, peak, per_flop = describe(k)
+                res["roofline"]["isolated"] = {
+                    "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "mfma_issue_frac": ach * per_flop / peak,
+                    "avg_launch_ms": ms, "launches_per_step": i_["launches"] / 2, "kernel": kname.split(" (")[0],
+                    "measured": "2 extra steps after the timed region, one lock-step group of all experts on one stream, "
+                                "no look-ahead: each launch has the GPU to itself (python bench.py --serial reproduces it)"}
             if len(rl) > 1 or hbm:
                 res["roofline_other_kernels"] = rl[1:] + hbm
         if world == 1 and not args.no_cpu_baseline:
