@@ -125,16 +125,25 @@ class MRN(BaseLearner):
             image = image_tensors.to(self.device)
             return image, labels, to_device(torch.LongTensor(indexs).squeeze()), self.prefetch_experts(image, labels)
 
-        nxt = fetch()             # software pipeline: batch n+1's frozen-expert forward is issued before batch n's router phase
+        def validates(it):
+            return it % max(self.opt.val_interval // 5, 1) == 0 or it == n_iter or it == 1
+
+        # Software pipeline: batch n+1's frozen-expert forward is issued before batch n's router phase -- except across a
+        # validation: the experts run train-mode BatchNorm here (mrn.py:107,401), so a look-ahead forward would advance their
+        # running statistics before the evaluation that the reference runs first.
+        nxt = fetch()
         for iteration in range(start_iter + 1, n_iter + 1):
             image, labels, indexs, pre = nxt
-            if iteration < n_iter:
+            nxt = None
+            if iteration < n_iter and not validates(iteration):
                 nxt = fetch()
             loss_clf, taski_loss = self.routing_step(image, labels, indexs, pi, prefetched=pre if pre[0] is not None else None)
             train_loss_avg.add(loss_clf.detach())
             train_taski_loss_avg.add(taski_loss.detach())
-            if iteration % max(self.opt.val_interval // 5, 1) == 0 or iteration == n_iter or iteration == 1:
+            if validates(iteration):
                 self.val(valid_loader, self.opt, best_score, start_time, iteration, train_loss_avg, train_taski_loss_avg,
                          taski, step=1, val_choose="TF")
                 train_loss_avg.reset()
                 train_taski_loss_avg.reset()
+            if nxt is None and iteration < n_iter:
+                nxt = fetch()
