@@ -244,7 +244,7 @@ def main():
                 arith, staging = kind.split("/")
                 if staging.startswith("x3g"):
                     tile = staging[3:]
-                    targs = {"256x256": "2, 4, 4, 2", "256x128": "4, 2, 2, 2", "128x128": "4, 2, 1, 2", "256x64": "8, 1, 1, 2"}[tile]
+                    targs = {"256x256": "4, 4, 2, 2", "256x128": "4, 2, 2, 2", "128x128": "4, 2, 1, 2", "256x64": "8, 1, 1, 2"}[tile]
                     return (f"conv_x3_kernel<{targs}> (grouped {tile}x32 implicit-GEMM conv / Linear over all experts, fp16x3 "
                             f"on v_mfma_f32_32x32x16_f16, HL32 operands staged by buffer_load...lds)", BF16_MFMA_PEAK_TFLOPS, 3)
                 nsplit = 3 if arith.endswith("x3") else 1

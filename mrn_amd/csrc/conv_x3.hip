@@ -12,7 +12,7 @@
 // of sweeping the whole activation once per tap (the tap-outer order fetched 8x the activation from beyond L2:
 // profiles/r01c_pmc.json).
 //
-// Tile BM x BN x 32, 8 waves; LDS stage = (BM + BN) rows x 128 B, two stages; one barrier per K-step:
+// Tile BM x BN x 32, 8 or 16 waves; LDS stage = (BM + BN) rows x 128 B, two stages; one barrier per K-step:
 //   wait own DMAs (tile kt) -> barrier -> issue DMAs (tile kt+1 -> other stage) -> 48 MFMAs on tile kt.
 // LDS rows are 128 B; the 16-byte chunk index is XOR-swizzled with (row >> 1) & 7 so that the 16-lane groups of
 // ds_read_b128 (16 rows, same logical chunk) touch 16 distinct 16-byte slots of the 256-byte bank row.  The DMA
@@ -350,6 +350,7 @@ template __global__ void conv_x3_kernel<2, 4, 4, 2>(const ConvX3Params);
 template __global__ void conv_x3_kernel<4, 2, 2, 2>(const ConvX3Params);
 template __global__ void conv_x3_kernel<4, 2, 1, 2>(const ConvX3Params);
 template __global__ void conv_x3_kernel<8, 1, 1, 2>(const ConvX3Params);
+template __global__ void conv_x3_kernel<4, 4, 2, 2>(const ConvX3Params);
 
 // ---- producers of the HL32 layout -------------------------------------------------------------------------------
 __device__ __forceinline__ void split_h(float v, _Float16& h, _Float16& l) {
@@ -572,7 +573,10 @@ MRN_EXPORT int mrn_conv2d_x3_hl32(const void* x_hl, const void* w_hl, const void
   p.BWo = B * Wo;
   magic_div((unsigned)Wo, p.wo_magic, p.wo_shift);
   magic_div((unsigned)p.BWo, p.bw_magic, p.bw_shift);
-  if (tile_n == 256) return launch_x3<2, 4, 4, 2>(p, (hipStream_t)stream);
+  // 256x256: 16 waves (64x64 wave tiles, four waves per SIMD) hide the per-K-step LDS / barrier stalls better than 8 waves
+  // with 128x64 tiles: 464 vs 438 TFLOP/s on the dominant shape (MRN_X3_W8=1 selects the 8-wave variant for A/B runs)
+  if (tile_n == 256 && getenv("MRN_X3_W8")) return launch_x3<2, 4, 4, 2>(p, (hipStream_t)stream);
+  if (tile_n == 256) return launch_x3<4, 4, 2, 2>(p, (hipStream_t)stream);
   if (tile_m == 256 && tile_n == 64) return launch_x3<8, 1, 1, 2>(p, (hipStream_t)stream);
   if (tile_m == 256) return launch_x3<4, 2, 2, 2>(p, (hipStream_t)stream);
   return launch_x3<4, 2, 1, 2>(p, (hipStream_t)stream);
