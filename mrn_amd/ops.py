@@ -299,17 +299,28 @@ def conv2d_nhwc(x, w_ohwi, bias=None, stride=(1, 1), padding=(0, 0), act=ACT_NON
 X3_SMALL_TILE_MAX_K = 1200     # measured on MI355X (tools/bench_conv_x3.py): +3.5 % at K = 1152, +7.6 % at K = 576
 
 
-def x3_tile(Cout, K):
+def x3_tile(Cout, K, M=None, G=1):
     """(tile_m, tile_n) of the grouped conv: 256x256 for wide outputs, 256x128 otherwise; 128x128 (two workgroups per CU)
-    for short reductions, where the prologue / epilogue of one tile overlaps the main loop of its neighbour"""
+    for short reductions, where the prologue / epilogue of one tile overlaps the main loop of its neighbour.  When the
+    tile count is known (M = rows per group), a 256x256 launch that would leave a ragged last round of workgroups on the
+    256 CUs (e.g. 520 tiles = 2.03 rounds for ONE expert's 4x65 layers in loop A) falls back to the tile with the best
+    (relative kernel speed x round efficiency)."""
     force = __import__("os").environ.get("MRN_X3_TILE")
     if force:
         return tuple(int(v) for v in force.split("x"))
-    if Cout >= 256:
-        return 256, 256
     if Cout <= 64:
         return 256, 64
-    return (128, 128) if K <= X3_SMALL_TILE_MAX_K else (256, 128)
+    if Cout < 256:
+        return (128, 128) if K <= X3_SMALL_TILE_MAX_K else (256, 128)
+    if M is None:
+        return 256, 256
+
+    def eff(tm, tn, slots):
+        tiles = G * ((M + tm - 1) // tm) * ((Cout + tn - 1) // tn)
+        rounds = (tiles + slots - 1) // slots
+        return tiles / (rounds * slots)
+    cands = [((256, 256), 1.00 * eff(256, 256, 256)), ((256, 128), 0.87 * eff(256, 128, 256)), ((128, 128), 0.88 * eff(128, 128, 512))]
+    return max(cands, key=lambda c: c[1])[0]
 
 
 def split_hl32(x, scale=None):
@@ -398,7 +409,7 @@ def conv2d_x3(x_hl, G, shared_input, B, H, W, Cin, w_hl, w_scale, Cout, ksize, s
     Ho, Wo = conv_out_hw(H, W, ksize, stride, padding)
     dev = x_hl.device
     y = out if out is not None else torch.empty(G, B, Ho, Wo, Cout, device=dev, dtype=torch.float32)
-    tile_m, tile_n = x3_tile(Cout, kh * kw * Cin)
+    tile_m, tile_n = x3_tile(Cout, kh * kw * Cin, M=B * Ho * Wo, G=G)
     stats = None
     if want_stats:
         stats = torch.empty(call("mrn_conv2d_x3_stats_floats", G, B, Ho, Wo, Cout, tile_m), device=dev, dtype=torch.float32)
