@@ -31,9 +31,6 @@ def x3_linear(x2, weight, bias=None, residual=None, act=ops.ACT_NONE):
     return y.view(R, N)
 
 
-_FROZEN_PACKS = {}
-
-
 def frozen_linear(x, weight, bias=None, act=ops.ACT_NONE, residual=None):
     """Linear layer of a FROZEN module under no_grad (SVTR mixing blocks of the experts): split-fp16 x3 with the weight's
     HL32 pack cached per (storage, version); x [..., K] contiguous.  Falls back to the exact-fp32 GEMM when not eligible."""
@@ -43,10 +40,10 @@ def frozen_linear(x, weight, bias=None, act=ops.ACT_NONE, residual=None):
     if not ok:
         return ops.linear(x, weight, bias, act=act, residual=residual)
     key = (weight.data_ptr(), weight._version, N, K)
-    got = _FROZEN_PACKS.get(id(weight))
+    got = getattr(weight, "_mrn_hl32", None)            # the pack lives (and dies) with the parameter it was built from
     if got is None or got[0] != key:
         got = (key, ops.pack_weights_hl32([weight.detach().contiguous().view(N, 1, 1, K)]))
-        _FROZEN_PACKS[id(weight)] = got
+        weight._mrn_hl32 = got
     w_hl, sw = got[1]
     R = x.numel() // K
     y, _ = ops.conv2d_x3(ops.split_hl32(x), 1, False, R, 1, 1, K, w_hl, sw, N, (1, 1), bias=bias, act=act,
