@@ -14,13 +14,15 @@ BatchNorm statistics); layers the grouped kernel cannot take (Cin % 32 != 0) run
 The module parameters stay where they are (state_dict layout untouched): weights are re-packed into per-layer HL32
 stacks that are cached until a parameter changes.
 """
+import os
+
 import torch
 
 from .. import ops
 from ._nn import _pair, packed_weight, to_nhwc
 
 
-RESIDUAL_FROM_F32 = bool(int(__import__("os").environ.get("MRN_RESIDUAL_F32", "0")))      # True: keep an fp32 copy of every identity-shortcut source (one extra 4 B/element write)
+RESIDUAL_FROM_F32 = bool(int(os.environ.get("MRN_RESIDUAL_F32", "0")))      # True: keep an fp32 copy of every identity-shortcut source (one extra 4 B/element write)
 
 
 class Act:

@@ -9,6 +9,7 @@ MI355X-first differences that do not change results:
   * the input image is converted to NHWC once and shared by all experts.
 """
 import copy
+import os
 
 import torch
 import torch.nn as nn
@@ -283,7 +284,7 @@ class MRNNet(nn.Module):
         self._group = None
         self._heads = None
         self._halves = None
-        self.expert_halves = int(__import__("os").environ.get("MRN_EXPERT_HALVES", "2"))      # concurrent lock-step sub-groups
+        self.expert_halves = int(os.environ.get("MRN_EXPERT_HALVES", "2"))      # concurrent lock-step sub-groups
         #   (measured on TRBA x 6, MI355X: 1 group 1.00, 2 halves on two streams 1.044, 3 thirds 1.015, staggered halves 1.035,
         #    halves with one high-priority stream 0.96)
 

@@ -3,6 +3,8 @@
 PyTorch is used here only for device memory (caching allocator), the current HIP stream and shapes; every
 arithmetic operation is a call into libmrn_hip.so.  All tensors must be fp32 CUDA tensors.
 """
+import os
+
 import torch
 
 from ._lib import call
@@ -64,8 +66,10 @@ TIMER_SHAPES = False         # tools/layer_times.py: one timer kind per layer sh
 #             device from max|.| (gradients of 1e-6 would otherwise fall into fp16's subnormal range)
 #   "f32"     exact fp32 MFMA
 ROUTER_GEMM_PRECISION = "fp16x3"
-RECURRENT_X3 = __import__("os").environ.get("MRN_RECURRENT", "fp16x3") == "fp16x3"   # frozen experts' LSTM recurrences on the f16 MFMA
-ROUTER_WGRAD_X3 = __import__("os").environ.get("MRN_WGRAD", "fp16x3") == "fp16x3"     # weight-gradient GEMMs too (A/B switch)
+# A/B switches (environment variables, read once at import): the defaults are the measured winners; tools/ and DESIGN.md
+# section 4 quote the runs.
+RECURRENT_X3 = os.environ.get("MRN_RECURRENT", "fp16x3") == "fp16x3"   # frozen experts' LSTM recurrences on the f16 MFMA
+ROUTER_WGRAD_X3 = os.environ.get("MRN_WGRAD", "fp16x3") == "fp16x3"     # weight-gradient GEMMs too (A/B switch)
 
 # Arithmetic of the large implicit-GEMM convs (Cout > 64, K % 32 == 0):
 #   "f32"    exact fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere
@@ -85,8 +89,8 @@ AUTO_SPLIT_MIN_K = 0
 #             torch autograd on the oracle inside the bands of tests/test_model_gpu.py::test_loop_a_*
 #   "f32"     exact fp32 MFMA.  (Unscaled "fp16x3" fails the TRBA gradient test: small gradients fall into fp16
 #             subnormals; "bf16x3" amplifies 1e-5 forward differences through small-batch BatchNorm backward to ~3e-3.)
-TRAIN_CONV_PRECISION = __import__("os").environ.get("MRN_TRAIN_PRECISION", "fp16x3s")
-TRAIN_WGRAD_X3 = __import__("os").environ.get("MRN_TRAIN_WGRAD", "fp16x3s") == "fp16x3s"   # weight gradients on the same path
+TRAIN_CONV_PRECISION = os.environ.get("MRN_TRAIN_PRECISION", "fp16x3s")
+TRAIN_WGRAD_X3 = os.environ.get("MRN_TRAIN_WGRAD", "fp16x3s") == "fp16x3s"   # weight gradients on the same path
 LOCNET_CONV_PRECISION = None   # TPS localisation network: None = follow CONV_PRECISION ("f32" to pin it exact)
 AUTO_SPLIT_KIND = "fp16x3"   # arithmetic "auto" picks for the deep reductions ("fp16x3" | "bf16x3")
 USE_DMA_CONV = True          # pre-split activation + direct-to-LDS staging for the split-16-bit convs
@@ -305,7 +309,7 @@ def x3_tile(Cout, K, M=None, G=1):
     tile count is known (M = rows per group), a 256x256 launch that would leave a ragged last round of workgroups on the
     256 CUs (e.g. 520 tiles = 2.03 rounds for ONE expert's 4x65 layers in loop A) falls back to the tile with the best
     (relative kernel speed x round efficiency)."""
-    force = __import__("os").environ.get("MRN_X3_TILE")
+    force = os.environ.get("MRN_X3_TILE")
     if force:
         return tuple(int(v) for v in force.split("x"))
     if Cout <= 64:
