@@ -9,11 +9,14 @@
 // so that one K-step of the GEMM (32 channels of one tap) is exactly one 128-byte line per tile row for BOTH
 // operands: a DMA lane-group of 8 lanes fetches a full cache line, and the reduction runs channel-block-outer /
 // tap-inner: the kh*kw taps of one channel block re-read the same ~BM pixel lines back to back (L2 hits) instead
-// of sweeping the whole activation once per tap (the tap-outer order fetched 8x the activation from beyond L2:
-// profiles/r01c_pmc.json).
+// of sweeping the whole activation once per tap (the earlier tap-outer kernel fetched 8x the activation from beyond L2;
+// this one 2x its algorithmic bytes, the excess being the weight matrix re-streamed per round of tiles: profiles/r01_pmc.json).
 //
-// Tile BM x BN x 32, 8 or 16 waves; LDS stage = (BM + BN) rows x 128 B, two stages; one barrier per K-step:
-//   wait own DMAs (tile kt) -> barrier -> issue DMAs (tile kt+1 -> other stage) -> 48 MFMAs on tile kt.
+// Tile BM x BN x 32; 256x256 runs 16 waves of 64x64 (four per SIMD, <= 128 VGPRs), the smaller tiles 8 waves and two
+// workgroups per CU.  LDS stage = (BM + BN) rows x 128 B, two stages; one barrier per K-step:
+//   wait own DMAs (tile kt) -> barrier -> issue DMAs (tile kt+1 -> other stage) -> 2 x (WM*WN*3) MFMAs on tile kt.
+// Tiles are visited image-row-major and class-ordered (see the kernel prologue): border image rows skip the kernel rows
+// that lie in the padding, and every XCD gets an equal share of both classes.
 // LDS rows are 128 B; the 16-byte chunk index is XOR-swizzled with (row >> 1) & 7 so that the 16-lane groups of
 // ds_read_b128 (16 rows, same logical chunk) touch 16 distinct 16-byte slots of the 256-byte bank row.  The DMA
 // writes LDS lane-linearly, so the swizzle is applied to the SOURCE chunk each lane fetches.
