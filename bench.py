@@ -107,7 +107,11 @@ def cpu_baseline(learner, opt, n_experts, batch=16, iters=1, max_threads=32):
         li, ll = conv.encode(labels, 25)
         t0 = time.time()
         text = None if opt.Prediction == "CTC" else li[:, :-1]
-        out = O.mrn_forward(sd, cfg, n_experts, image, True, text, True, training=True)
+        masks = None
+        if opt.FeatureExtraction == "SVTR":      # DropPath draws of the train-mode experts, two sites per block (svtr.py:17-22)
+            masks = [[torch.bernoulli(torch.full((batch,), 1.0 - float(dp))) for dp in O.SVTR_DROP_PATH if dp > 0 for _ in range(2)]
+                     for _ in range(n_experts)]
+        out = O.mrn_forward(sd, cfg, n_experts, image, True, text, True, training=True, masks=masks)
         loss, _, _ = O.mrn_step_loss(out, li, ll, domain, opt.Prediction)
         grads = torch.autograd.grad(loss, params)
         with torch.no_grad():

@@ -66,6 +66,7 @@ TIMER_SHAPES = False         # tools/layer_times.py: one timer kind per layer sh
 #             device from max|.| (gradients of 1e-6 would otherwise fall into fp16's subnormal range)
 #   "f32"     exact fp32 MFMA
 ROUTER_GEMM_PRECISION = "fp16x3"
+SVTR_FUSED_ATTENTION = os.environ.get("MRN_SVTR_ATTENTION", "fused") == "fused"   # frozen SVTR experts: mrn_svtr_attention_f32
 # A/B switches (environment variables, read once at import): the defaults are the measured winners; tools/ and DESIGN.md
 # section 4 quote the runs.
 RECURRENT_X3 = os.environ.get("MRN_RECURRENT", "fp16x3") == "fp16x3"   # frozen experts' LSTM recurrences on the f16 MFMA
@@ -1074,6 +1075,17 @@ def softmax_rows_(s, mask=None):
     rpm = mask.shape[0] if mask is not None else 1
     call("mrn_softmax_rows_f32", _p(s), _p(mask), rows, N, rpm, _stream())
     return s
+
+
+def svtr_attention(qkv, heads, scale, mask=None):
+    """qkv [B,N,3C] (q | k | v, head dim 32), mask [N,N] additive symmetric or None -> [B,N,C]: fused q k^T / softmax / attn v"""
+    _chk(qkv, mask)
+    B, N, C3 = qkv.shape
+    C = C3 // 3
+    assert qkv.is_contiguous() and C == heads * 32 and (mask is None or (mask.is_contiguous() and tuple(mask.shape) == (N, N)))
+    out = torch.empty(B, N, C, device=qkv.device, dtype=torch.float32)
+    call("mrn_svtr_attention_f32", _p(qkv), _p(mask), _p(out), B, N, C, heads, float(scale), _stream())
+    return out
 
 
 def residual_scale_rows(x, branch, scale, rows_per_group, out=None):

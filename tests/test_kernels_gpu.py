@@ -529,3 +529,19 @@ def test_full_size_dominant_conv_properties(ops):
     w2, s2 = ops.pack_weights_hl32([ws[2]])
     y2, _ = ops.conv2d_x3(ops.split_hl32(x[2:3].contiguous()), 1, False, B, H, W, C, w2, s2, C, (3, 3), (1, 1), (1, 1))
     assert torch.equal(y2[0], y[2])
+
+
+@pytest.mark.parametrize("B,N,heads,masked", [(3, 512, 2, True), (2, 256, 4, True), (5, 128, 8, False), (2, 100, 2, False)])
+def test_svtr_fused_attention(ops, B, N, heads, masked):
+    """mrn_svtr_attention_f32 (online softmax on the fp32 MFMA) against torch softmax attention with the SVTR local mask"""
+    from mrn_amd.modules.svtr import local_attention_mask
+    C = heads * 32
+    qkv = rnd(B, N, 3 * C, seed=260, scale=1.5)
+    mask = local_attention_mask(N // 64, 64, 7, 11) if masked else None
+    q, k, v = [t.reshape(B, N, heads, 32).permute(0, 2, 1, 3) for t in qkv.split(C, dim=2)]
+    s = (q @ k.transpose(-1, -2)) * 32 ** -0.5
+    if mask is not None:
+        s = s + mask
+    ref = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B, N, C)
+    out = ops.svtr_attention(cu(qkv), heads, 32 ** -0.5, cu(mask) if masked else None)
+    assert_close("fused attention", out, ref, atol=2e-6, rtol=1e-5)
