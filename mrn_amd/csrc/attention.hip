@@ -1,13 +1,17 @@
 // Fused multi-head attention of the SVTR mixing blocks (reference modules/svtr.py:90-152: qkv -> q k^T * scale (+ local
 // window mask) -> softmax -> attn v), head dimension 32, inference path of the frozen experts.
 //
-// One wave owns 32 query tokens of one (sample, head) and walks the keys in tiles of 32 with an online softmax, so the
-// [B, heads, N, N] score tensor (537 MB per block at B = 256, N = 512) never exists in HBM.  Products run on the exact
-// fp32 MFMA (v_mfma_f32_32x32x2_f32).  Scores are computed TRANSPOSED, S^T = K Q^T: in the 32x32 accumulator layout a
-// lane then holds one QUERY (column lane & 31) and its 16 registers hold 16 keys, so the softmax reductions over keys
-// are register reductions plus one cross-half shuffle, the running rescale of the output is a per-lane scalar, and the
-// probabilities P^T already sit in the B-operand layout of the second product O^T = V^T P^T (register e pairs key
-// k0(e) = (e&3) + 8(e>>2) in lanes 0-31 with key k0(e) + 4 in lanes 32-63; V is fetched in the same pairing).
+// One workgroup (4 waves) owns 128 query tokens of one (sample, head); each wave owns 32 of them and walks the keys in
+// tiles of 32 with an online softmax, so the [B, heads, N, N] score tensor (537 MB per block at B = 256, N = 512) never
+// exists in HBM.  The K and V tiles are fetched once per workgroup (one 16-byte load per thread and operand, prefetched
+// a tile ahead) into a two-stage LDS ring shared by the four waves.  Products run on the exact fp32 MFMA
+// (v_mfma_f32_32x32x2_f32).  Scores are computed TRANSPOSED, S^T = K Q^T: in the 32x32 accumulator layout a lane then
+// holds one QUERY (column lane & 31) and its 16 registers hold 16 keys, so the softmax reductions over keys are register
+// reductions plus one cross-half shuffle, the running rescale of the output is a per-lane scalar, and the probabilities
+// P^T already sit in the B-operand layout of the second product O^T = V^T P^T (register e pairs key
+// k0(e) = (e&3) + 8(e>>2) in lanes 0-31 with key k0(e) + 4 in lanes 32-63; V is read from LDS in the same pairing).
+// The contraction over d is order-free, so MFMA step t of the first product takes d = 16*(lane>>5) + t: every lane reads
+// 16 contiguous floats of its K (and Q) row.  Softmax runs in base 2 (log2 e folded into the q scale and the mask).
 // The additive mask must be symmetric (SVTR's local window mask is): mask[key][query] is read row-wise.
 #include "common.hpp"
 
@@ -15,6 +19,9 @@ namespace {
 
 constexpr int HD = 32;          // head dimension of every SVTR stage (embed_dim / num_heads = 64/2 = 128/4 = 256/8)
 constexpr int AW = 4;           // waves per workgroup: 128 query tokens
+constexpr int KS = 36;          // LDS row stride of the K tile in floats (16-byte aligned rows, conflict-free b128 reads)
+constexpr int VS = 40;          // LDS row stride of the V tile: rows key and key + 4 land on disjoint bank halves
+constexpr float LOG2E = 1.4426950408889634f;
 
 struct AttnParams {
   const float* qkv;    // [B][N][3*C]: q | k | v, each (head, d) innermost
@@ -29,76 +36,109 @@ __device__ __forceinline__ f32x16 mfma2(float a, float b, f32x16 c) {
 }
 
 __global__ __launch_bounds__(AW * 64) void svtr_attention_kernel(const AttnParams p) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ __attribute__((aligned(16))) float lds_k[2][32 * KS];
+  __shared__ __attribute__((aligned(16))) float lds_v[2][32 * VS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n31 = lane & 31, half = lane >> 5;
-  const int qblocks = (p.N + 31) / 32;
-  const int wid = blockIdx.x * AW + wave;                  // (sample, head, query block)
-  const int qb = wid % qblocks;
-  const int bh = wid / qblocks;
-  if (bh >= p.B * p.heads) return;
+  const int qchunks = (p.N + 32 * AW - 1) / (32 * AW);
+  const int qc = blockIdx.x % qchunks;                     // (sample, head, chunk of 128 queries)
+  const int bh = blockIdx.x / qchunks;
   const int h = bh % p.heads, b = bh / p.heads;
   const long rs = 3L * p.C;                                // row stride of qkv
   const float* qbase = p.qkv + (long)b * p.N * rs + h * HD;
   const float* kbase = qbase + p.C;
   const float* vbase = qbase + 2 * p.C;
 
-  // B operand of S^T = K Q^T: lane (query n31, d parity half) holds Q[query][2s + half], s = 0..15
-  const int q = qb * 32 + n31;
+  // B operand of S^T = K Q^T: lane (query n31, half) holds Q[query][16*half + t], t = 0..15, times scale * log2 e
+  const int q = (qc * AW + wave) * 32 + n31;
   const bool qok = q < p.N;
   float qreg[16];
   {
-    const float* qr = qbase + (long)(qok ? q : 0) * rs;
+    const float* qr = qbase + (long)(qok ? q : 0) * rs + 16 * half;
+    const float sc = p.scale * LOG2E;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < 4; ++j) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(qr + 4 * j);
-      qreg[2 * j] = (half ? v[1] : v[0]) * p.scale;
-      qreg[2 * j + 1] = (half ? v[3] : v[2]) * p.scale;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) qreg[4 * j + i] = v[i] * sc;
     }
   }
+
+  // tile loader: thread (row tid>>3, 16-byte chunk tid&7) of the 32 x 32 K and V tiles; rows past N read as zeros
+  const int lr = tid >> 3, lc = tid & 7;
+  f32x4 knext, vnext;
+  auto fetch = [&](int k0) {
+    const int key = k0 + lr;
+    if (key < p.N) {
+      knext = *reinterpret_cast<const f32x4*>(kbase + (long)key * rs + 4 * lc);
+      vnext = *reinterpret_cast<const f32x4*>(vbase + (long)key * rs + 4 * lc);
+    } else {
+      knext = f32x4{0.f, 0.f, 0.f, 0.f};
+      vnext = knext;
+    }
+  };
+  auto stash = [&](int stage) {
+    *reinterpret_cast<f32x4*>(&lds_k[stage][lr * KS + 4 * lc]) = knext;
+    *reinterpret_cast<f32x4*>(&lds_v[stage][lr * VS + 4 * lc]) = vnext;
+  };
+  fetch(0);
+  stash(0);
+  __syncthreads();
 
   f32x16 o;                                                // O^T: rows = d, column = this lane's query
 #pragma unroll
   for (int e = 0; e < 16; ++e) o[e] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
+  const float* mcol = p.mask ? p.mask + (qok ? q : 0) + 4L * half * p.N : nullptr;
 
-  for (int k0 = 0; k0 < p.N; k0 += 32) {
-    // ---- S^T tile: A operand lane (key n31, d parity half) = K[k0 + n31][2s + half]
+  const int ntiles = (p.N + 31) / 32;
+  for (int it = 0; it < ntiles; ++it) {
+    const int k0 = it * 32, cur = it & 1;
+    const bool more = it + 1 < ntiles;
+    if (more) fetch(k0 + 32);
+    // ---- mask column of this query: register e is key k0 + (e&3) + 8*(e>>2) + 4*half (symmetric: [key][query] coalesces)
+    float mreg[16];
+    if (mcol) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = k0 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        mreg[e] = key < p.N ? mcol[(long)(k0 + (e & 3) + 8 * (e >> 2)) * p.N] : 0.f;
+      }
+    }
+    // ---- S^T tile: A operand lane (key n31, half) = K[k0 + n31][16*half + t]
     f32x16 s;
 #pragma unroll
     for (int e = 0; e < 16; ++e) s[e] = 0.f;
     {
-      const int key = k0 + n31;
-      const float* kr = kbase + (long)(key < p.N ? key : 0) * rs;
-      float kreg[16];
+      const float* kr = &lds_k[cur][n31 * KS + 16 * half];
+      f32x4 kf[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(kr + 4 * j);
-        kreg[2 * j] = half ? v[1] : v[0];
-        kreg[2 * j + 1] = half ? v[3] : v[2];
-      }
+      for (int j = 0; j < 4; ++j) kf[j] = *reinterpret_cast<const f32x4*>(kr + 4 * j);
 #pragma unroll
-      for (int t = 0; t < 16; ++t) s = mfma2(kreg[t], qreg[t], s);
+      for (int t = 0; t < 16; ++t) s = mfma2(kf[t >> 2][t & 3], qreg[t], s);
     }
-    // ---- mask + online softmax: register e of this lane is key k0 + (e&3) + 8*(e>>2) + 4*half for query q
-    float mx = -INFINITY;
+    // ---- online softmax in base 2
+    if (mcol) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int key = k0 + (e & 3) + 8 * (e >> 2) + 4 * half;
-      float v = s[e];
-      if (key >= p.N) v = -INFINITY;
-      else if (p.mask && qok) v += p.mask[(long)key * p.N + q];           // symmetric: [key][query] is coalesced
-      s[e] = v;
-      mx = fmaxf(mx, v);
+      for (int e = 0; e < 16; ++e) s[e] = fmaf(mreg[e], LOG2E, s[e]);
     }
+    if (k0 + 32 > p.N) {                                   // ragged last tile: keys past N drop out
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        if (k0 + (e & 3) + 8 * (e >> 2) + 4 * half >= p.N) s[e] = -INFINITY;
+    }
+    float mx = s[0];
+#pragma unroll
+    for (int e = 1; e < 16; ++e) mx = fmaxf(mx, s[e]);
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float m_new = fmaxf(m_run, mx);
-    const float corr = (m_new == -INFINITY) ? 1.f : __expf(m_run - m_new);   // (m_run = -inf: exp(-inf) = 0)
+    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;   // every key so far masked out: all exponentials are 0
+    const float corr = __builtin_amdgcn_exp2f(m_run - m_safe);
     float psum = 0.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const float pe = (m_new == -INFINITY) ? 0.f : __expf(s[e] - m_new);
-      s[e] = pe;
-      psum += pe;
+      s[e] = __builtin_amdgcn_exp2f(s[e] - m_safe);
+      psum += s[e];
     }
     psum += __shfl_xor(psum, 32);
     l_run = l_run * corr + psum;
@@ -106,12 +146,13 @@ __global__ __launch_bounds__(AW * 64) void svtr_attention_kernel(const AttnParam
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[e] *= corr;
     // ---- O^T += V^T P^T: MFMA e pairs keys (k0(e), k0(e) + 4); A operand lane (d = n31, pair member half)
+    {
+      const float* vr = &lds_v[cur][4 * half * VS + n31];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int key = k0 + (e & 3) + 8 * (e >> 2) + 4 * half;
-      const float vv = key < p.N ? vbase[(long)key * rs + n31] : 0.f;
-      o = mfma2(vv, s[e], o);
+      for (int e = 0; e < 16; ++e) o = mfma2(vr[((e & 3) + 8 * (e >> 2)) * VS], s[e], o);
     }
+    if (more) stash(cur ^ 1);
+    __syncthreads();
   }
 
   // ---- normalise and store: register e of this lane is d = (e&3) + 8*(e>>2) + 4*half of query q
@@ -138,8 +179,8 @@ MRN_EXPORT int mrn_svtr_attention_f32(const float* qkv, const float* mask, float
   if (B == 0 || N == 0) return MRN_OK;
   AttnParams p;
   p.qkv = qkv; p.mask = mask; p.out = out; p.B = B; p.N = N; p.C = C; p.heads = heads; p.scale = scale;
-  const long waves = (long)B * heads * ((N + 31) / 32);
-  hipLaunchKernelGGL(svtr_attention_kernel, dim3((unsigned)((waves + AW - 1) / AW)), dim3(AW * 64), 0, (hipStream_t)stream, p);
+  const long groups = (long)B * heads * ((N + 32 * AW - 1) / (32 * AW));
+  hipLaunchKernelGGL(svtr_attention_kernel, dim3((unsigned)groups), dim3(AW * 64), 0, (hipStream_t)stream, p);
   MRN_LAUNCH_CHECK("svtr_attention");
   return MRN_OK;
 }
