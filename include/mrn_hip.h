@@ -273,12 +273,20 @@ int mrn_ew_rows_f32(const float* a, int64_t lda, const float* b, int64_t ldb, fl
 /* in-place softmax over the N columns of every row of s, with an optional additive mask [rows_per_mask][N] shared
  * across the batch (row r uses mask row r % rows_per_mask): SVTR Local/Global mixing, modules/svtr.py:140-146 */
 int mrn_softmax_rows_f32(float* s, const float* mask, int64_t rows, int N, int rows_per_mask, void* stream);
+/* One pass between two Linear layers of the SVTR mixing blocks of G lock-step experts (modules/svtr.py:200-204 Block.forward,
+ * :298-305 SubSample): t = x + drop[r / rows_per_drop] * branch (DropPath-scaled residual add; branch NULL: t = x, drop NULL: 1)
+ * -> sum_out (optional, may alias x); y = LayerNorm(t) * gamma[g] + beta[g] with g = r / rows_per_group (gamma NULL: y = t)
+ * -> y_f32 and / or y_hl32 (HL32 operand of the next grouped Linear, C % 32 == 0).  [rows][C] contiguous, gamma/beta [G][C]. */
+int mrn_add_layernorm_grouped_f32(const float* x, const float* branch, const float* drop, int64_t rows_per_drop,
+                                  const float* gamma, const float* beta, int64_t rows_per_group, float* sum_out, float* y_f32,
+                                  void* y_hl32, int64_t rows, int C, float eps, void* stream);
 /* Fused multi-head attention of the SVTR mixing blocks (head dimension 32), inference path of the frozen experts:
  * out[b][n][h*32 + :] = softmax_m(scale * q[b][n][h] . k[b][m][h] + mask[n][m]) @ v[b][m][h]; qkv [B][N][3*C] (q | k | v,
- * C = heads * 32), mask [N][N] additive and SYMMETRIC (SVTR's local window mask) or NULL, out [B][N][C].  Online softmax
+ * C = heads * 32), mask [N][N] additive and SYMMETRIC (SVTR's local window mask) or NULL, out [B][N][C] fp32 and / or
+ * out_hl32 (the same tensor as the HL32 operand of the proj Linear: a head IS one 32-channel block).  Online softmax
  * on the exact-fp32 MFMA: the [B][heads][N][N] score tensor of modules/svtr.py:140-149 never reaches HBM. */
-int mrn_svtr_attention_f32(const float* qkv, const float* mask, float* out, int B, int N, int C, int heads, float scale,
-                           void* stream);
+int mrn_svtr_attention_f32(const float* qkv, const float* mask, float* out, void* out_hl32, int B, int N, int C, int heads,
+                           float scale, void* stream);
 /* y = x + scale[row / rows_per_group] * branch : residual add with the per-sample DropPath scale (svtr.py:7-22,202-203) */
 int mrn_residual_scale_rows_f32(const float* x, const float* branch, const float* scale, float* y, int64_t rows, int C,
                                 int64_t rows_per_group, void* stream);

@@ -22,11 +22,13 @@ constexpr int AW = 4;           // waves per workgroup: 128 query tokens
 constexpr int KS = 36;          // LDS row stride of the K tile in floats (16-byte aligned rows, conflict-free b128 reads)
 constexpr int VS = 40;          // LDS row stride of the V tile: rows key and key + 4 land on disjoint bank halves
 constexpr float LOG2E = 1.4426950408889634f;
+typedef _Float16 f16v4 __attribute__((ext_vector_type(4)));
 
 struct AttnParams {
   const float* qkv;    // [B][N][3*C]: q | k | v, each (head, d) innermost
   const float* mask;   // [N][N] additive, symmetric, or null
-  float* out;          // [B][N][C]
+  float* out;          // [B][N][C] fp32, or null
+  unsigned char* out_hl;   // the same tensor as HL32 lines [B*N][heads][hi 32 | lo 32] (a head is one 32-channel block), or null
   int B, N, C, heads;
   float scale;
 };
@@ -158,11 +160,23 @@ __global__ __launch_bounds__(AW * 64) void svtr_attention_kernel(const AttnParam
   // ---- normalise and store: register e of this lane is d = (e&3) + 8*(e>>2) + 4*half of query q
   if (qok) {
     const float inv = 1.f / l_run;
-    float* orow = p.out + ((long)b * p.N + q) * p.C + h * HD;
+    const long row = (long)b * p.N + q;
 #pragma unroll
     for (int e = 0; e < 16; e += 4) {
-      f32x4 v = {o[e] * inv, o[e + 1] * inv, o[e + 2] * inv, o[e + 3] * inv};
-      *reinterpret_cast<f32x4*>(orow + 8 * (e >> 2) + 4 * half) = v;
+      const f32x4 v = {o[e] * inv, o[e + 1] * inv, o[e + 2] * inv, o[e + 3] * inv};
+      const int d0 = 8 * (e >> 2) + 4 * half;
+      if (p.out) *reinterpret_cast<f32x4*>(p.out + row * p.C + h * HD + d0) = v;
+      if (p.out_hl) {
+        f16v4 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          hi[j] = (_Float16)v[j];
+          lo[j] = (_Float16)(v[j] - (float)hi[j]);
+        }
+        unsigned char* line = p.out_hl + (row * p.heads + h) * 128 + d0 * 2;
+        *reinterpret_cast<f16v4*>(line) = hi;
+        *reinterpret_cast<f16v4*>(line + 64) = lo;
+      }
     }
   }
 }
@@ -170,15 +184,16 @@ __global__ __launch_bounds__(AW * 64) void svtr_attention_kernel(const AttnParam
 }  // namespace
 
 // out[b][n][h*32 + :] = softmax_m(scale * q[b][n][h] . k[b][m][h] + mask[n][m]) @ v[b][m][h]  for every head h;
-// qkv [B][N][3*C] (q | k | v, C = heads * 32), mask [N][N] additive and SYMMETRIC or NULL, out [B][N][C].
+// qkv [B][N][3*C] (q | k | v, C = heads * 32), mask [N][N] additive and SYMMETRIC or NULL, out [B][N][C] fp32 and / or
+// out_hl32 (HL32 operand of the proj Linear).
 // Replaces the q k^T / softmax / attn v chain of modules/svtr.py:140-149 without materialising [B][heads][N][N].
-MRN_EXPORT int mrn_svtr_attention_f32(const float* qkv, const float* mask, float* out, int B, int N, int C, int heads,
-                                      float scale, void* stream) {
-  MRN_CHECK_ARG(qkv && out && heads >= 1 && C == heads * HD, "mrn_svtr_attention_f32: head dimension must be %d (C=%d heads=%d)", HD, C, heads);
+MRN_EXPORT int mrn_svtr_attention_f32(const float* qkv, const float* mask, float* out, void* out_hl32, int B, int N, int C,
+                                      int heads, float scale, void* stream) {
+  MRN_CHECK_ARG(qkv && (out || out_hl32) && heads >= 1 && C == heads * HD, "mrn_svtr_attention_f32: head dimension must be %d (C=%d heads=%d)", HD, C, heads);
   MRN_CHECK_ARG(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)out % 16 == 0), "mrn_svtr_attention_f32: operands must be 16-byte aligned");
   if (B == 0 || N == 0) return MRN_OK;
   AttnParams p;
-  p.qkv = qkv; p.mask = mask; p.out = out; p.B = B; p.N = N; p.C = C; p.heads = heads; p.scale = scale;
+  p.qkv = qkv; p.mask = mask; p.out = out; p.out_hl = (unsigned char*)out_hl32; p.B = B; p.N = N; p.C = C; p.heads = heads; p.scale = scale;
   const long groups = (long)B * heads * ((N + 32 * AW - 1) / (32 * AW));
   hipLaunchKernelGGL(svtr_attention_kernel, dim3((unsigned)groups), dim3(AW * 64), 0, (hipStream_t)stream, p);
   MRN_LAUNCH_CHECK("svtr_attention");

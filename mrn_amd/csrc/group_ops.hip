@@ -11,6 +11,7 @@
 namespace {
 
 typedef _Float16 f16v8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16v4 __attribute__((ext_vector_type(4)));
 
 struct F8 {
   f32x4 a, b;
@@ -191,6 +192,90 @@ __global__ __launch_bounds__(256) void maxpool_grouped_kernel(const float* __res
   }
 }
 
+// SVTR mixing blocks of G lock-step experts (modules/svtr.py:200-204, :298-305): t = x + drop[r / rows_per_drop] * branch
+// (the DropPath-scaled residual add of the PREVIOUS half block; branch NULL: t = x), optionally written back as the new
+// fp32 residual stream, then y = LayerNorm(t; gamma[g], beta[g]) with g = r / rows_per_group (gamma NULL: y = t), written
+// as fp32 and / or straight as the HL32 operand of the next grouped Linear.  LPR lanes share one row (a 16-byte chunk
+// each per pass), so C = 64 / 128 rows still fill the wave.  Same arithmetic as layernorm_fwd_kernel (rowops.hip).
+template <int LPR>
+__global__ __launch_bounds__(256) void add_layernorm_grouped_kernel(const float* __restrict__ x, const float* __restrict__ branch,
+                                                                   const float* __restrict__ drop, long rows_per_drop,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   long rows_per_group, float* __restrict__ sum_out,
+                                                                   float* __restrict__ y_f32, unsigned char* __restrict__ y_hl,
+                                                                   long rows, int C, float eps) {
+  constexpr int RPW = 64 / LPR;                            // rows per wave
+  constexpr int NV = 4;                                    // 16-byte chunks per lane: C <= LPR * 16
+  const int lane = threadIdx.x & 63, sub = lane % LPR;
+  const long row = (blockIdx.x * 4L + (threadIdx.x >> 6)) * RPW + lane / LPR;
+  if (row >= rows) return;                                 // (whole sub-rows drop out together: shuffles stay inside LPR lanes)
+  const int C4 = C >> 2;
+  const float* xr = x + row * C;
+  f32x4 v[NV];
+  float s = 0.f;
+  const float ds = (branch && drop) ? drop[row / rows_per_drop] : 1.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c4 = sub + i * LPR;
+    v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c4 < C4) {
+      v[i] = reinterpret_cast<const f32x4*>(xr)[c4];
+      if (branch) {
+        const f32x4 b = reinterpret_cast<const f32x4*>(branch + row * C)[c4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[i][j] = fmaf(ds, b[j], v[i][j]);
+      }
+      if (sum_out) reinterpret_cast<f32x4*>(sum_out + row * C)[c4] = v[i];
+    }
+    s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+  }
+  if (gamma) {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if (sub + i * LPR < C4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q += d * d; }
+      }
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.f / sqrtf(q / (float)C + eps);
+    const long g = row / rows_per_group;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c4 = sub + i * LPR;
+      if (c4 < C4) {
+        const f32x4 gm = reinterpret_cast<const f32x4*>(gamma + g * C)[c4];
+        const f32x4 bt = reinterpret_cast<const f32x4*>(beta + g * C)[c4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[i][j] = (v[i][j] - mean) * rstd * gm[j] + bt[j];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c4 = sub + i * LPR;
+    if (c4 < C4) {
+      if (y_f32) reinterpret_cast<f32x4*>(y_f32 + row * C)[c4] = v[i];
+      if (y_hl) {
+        f16v4 h, l;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          h[j] = (_Float16)v[i][j];
+          l[j] = (_Float16)(v[i][j] - (float)h[j]);
+        }
+        unsigned char* o = y_hl + (row * (C >> 5) + (c4 >> 3)) * 128 + (c4 & 7) * 8;
+        *reinterpret_cast<f16v4*>(o) = h;
+        *reinterpret_cast<f16v4*>(o + 64) = l;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // Train-mode BatchNorm2d statistics for G BatchNorm modules of C channels at once.  partials: [G][nblk][2][C] from the
@@ -241,5 +326,30 @@ MRN_EXPORT int mrn_maxpool_grouped_f32(const float* x, const float* scale, const
   hipLaunchKernelGGL(maxpool_grouped_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, scale, shift, out_f32,
                      (unsigned char*)out_hl32, relu, B, n8, H, W, C, Ho, Wo, kh, kw, sh, sw, ph, pw);
   MRN_LAUNCH_CHECK("maxpool_grouped");
+  return MRN_OK;
+}
+
+// t = x + drop[r / rows_per_drop] * branch (branch NULL: t = x; drop NULL: 1) -> sum_out (optional, may alias x);
+// y = LayerNorm(t) * gamma[g] + beta[g], g = r / rows_per_group (gamma NULL: y = t) -> y_f32 and / or y_hl32 (C % 32 == 0).
+// x, branch, sum_out, y_f32: [rows][C] contiguous; gamma, beta: [G][C].  Replaces the residual add + DropPath scale + LayerNorm
+// + operand split chain between two Linear layers of an SVTR block (modules/svtr.py:200-204) by one pass.
+MRN_EXPORT int mrn_add_layernorm_grouped_f32(const float* x, const float* branch, const float* drop, int64_t rows_per_drop,
+                                             const float* gamma, const float* beta, int64_t rows_per_group, float* sum_out,
+                                             float* y_f32, void* y_hl32, int64_t rows, int C, float eps, void* stream) {
+  MRN_CHECK_ARG(x && (y_f32 || y_hl32 || sum_out) && C % 4 == 0 && C <= 1024 && (!y_hl32 || C % 32 == 0) && (!gamma == !beta) &&
+                    rows_per_group >= 1 && (!drop || rows_per_drop >= 1),
+                "mrn_add_layernorm_grouped_f32: bad operands (C=%d)", C);
+  if (rows == 0) return MRN_OK;
+  const hipStream_t st = (hipStream_t)stream;
+  unsigned char* hl = (unsigned char*)y_hl32;
+#define MRN_ALN_LAUNCH(LPR)                                                                                                   \
+  hipLaunchKernelGGL(add_layernorm_grouped_kernel<LPR>, dim3((unsigned)((rows + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)))),     \
+                     dim3(256), 0, st, x, branch, drop, (long)rows_per_drop, gamma, beta, (long)rows_per_group, sum_out, y_f32,  \
+                     hl, (long)rows, C, eps)
+  if (C <= 64) MRN_ALN_LAUNCH(16);
+  else if (C <= 128) MRN_ALN_LAUNCH(32);
+  else MRN_ALN_LAUNCH(64);
+#undef MRN_ALN_LAUNCH
+  MRN_LAUNCH_CHECK("add_layernorm_grouped");
   return MRN_OK;
 }

@@ -19,7 +19,7 @@ import os
 import torch
 
 from .. import ops
-from ._nn import _pair, packed_weight, to_nhwc
+from ._nn import _pair, packed_weight, require_no_grad, to_nhwc
 
 
 RESIDUAL_FROM_F32 = bool(int(os.environ.get("MRN_RESIDUAL_F32", "0")))      # True: keep an fp32 copy of every identity-shortcut source (one extra 4 B/element write)
@@ -44,12 +44,16 @@ def _bn_modules(extractor):
 
 
 def supported(experts):
-    """Grouped execution covers TPS/None + ResNet/VGG experts of identical configuration, all frozen, same BN mode."""
+    """Grouped execution covers TPS/None + ResNet/VGG and None + SVTR experts of identical configuration, all frozen, same
+    BN / DropPath mode."""
     if len(experts) < 2:
         return False
     e0 = experts[0]
     for e in experts:
-        if e.stages != e0.stages or e.stages["Feat"] not in ("ResNet", "VGG") or e.stages["Trans"] not in ("TPS", "None"):
+        if e.stages != e0.stages or e.stages["Feat"] not in ("ResNet", "VGG", "SVTR") or e.stages["Trans"] not in ("TPS", "None"):
+            return False
+    if e0.stages["Feat"] == "SVTR":
+        if e0.stages["Trans"] != "None" or not ops.SVTR_FUSED_ATTENTION or len({e.training for e in experts}) != 1:
             return False
     for mods in zip(*[_bn_modules(e) for e in experts]):
         if len({m.training for m in mods}) != 1:
@@ -239,6 +243,83 @@ class BackboneGroup(_GroupedLinear):
         x = L(x, 14, bn=15, pool=p21)
         return L(x, 18, last=True)
 
+    # ---- SVTR: tokens [G*B, N, C] fp32 residual stream, every Linear one grouped x3 GEMM ------------------------------------
+    def _drop_scales(self, blks, B, dev):
+        """[G*B] DropPath multipliers of one residual branch (modules/svtr.py:17-22), or None when every path is kept"""
+        dp = blks[0].drop_path
+        if not hasattr(dp, "drop_prob") or dp.drop_prob == 0. or not dp.training:
+            return None
+        if any(b.drop_path.forced_masks for b in blks):       # parity tests pin the draws per expert
+            return torch.cat([b.drop_path.scale(B, dev) for b in blks])
+        keep = 1 - dp.drop_prob
+        m = torch.empty(self.G * B, device=dev).bernoulli_(keep)
+        return m / keep if (keep > 0.0 and dp.scale_by_keep) else m
+
+    def _ln_params(self, name, norms):
+        return self._cached(name, [n.weight for n in norms] + [n.bias for n in norms],
+                            lambda: (torch.stack([n.weight.detach() for n in norms]).contiguous(),
+                                     torch.stack([n.bias.detach() for n in norms]).contiguous()))
+
+    def _svtr_block(self, name, x, pending, blks, B, N):
+        """one Block (svtr.py:154-204) of every expert.  x [G*B,N,C] residual stream; pending = (branch, drop) of the previous
+        block's MLP, folded into this block's first LayerNorm pass.  Returns (x, pending)."""
+        G = self.G
+        C = x.shape[-1]
+        rows = B * N
+        b0 = blks[0]
+        mixer = b0.mixer
+        if mixer.mask is not None and mixer.mask.device != x.device:
+            mixer.mask = mixer.mask.to(x.device)
+        drop1 = self._drop_scales(blks, B, x.device)          # same draw order as Block.forward: mixer branch, then MLP branch
+        g1, b1 = self._ln_params(name + ".ln1", [b.norm1 for b in blks])
+        br, dr = pending if pending is not None else (None, None)
+        t, _, y_hl = ops.add_layernorm_grouped(x, br, dr, N, g1, b1, rows, b0.norm1.eps, want_sum=br is not None)
+        x = t if t is not None else x
+        qkv = self._linear(name + ".qkv", y_hl, rows, C, [b.mixer.qkv.weight for b in blks],
+                           [b.mixer.qkv.bias for b in blks] if mixer.qkv.bias is not None else None)
+        ctx_hl = ops.svtr_attention(qkv.view(G * B, N, 3 * C), mixer.num_heads, mixer.scale, mixer.mask, want_f32=False, want_hl=True)
+        br = self._linear(name + ".proj", ctx_hl, rows, C, [b.mixer.proj.weight for b in blks], [b.mixer.proj.bias for b in blks])
+        drop2 = self._drop_scales(blks, B, x.device)
+        g2, b2 = self._ln_params(name + ".ln2", [b.norm2 for b in blks])
+        x, _, y_hl = ops.add_layernorm_grouped(x, br.view(G * B, N, C), drop1, N, g2, b2, rows, b0.norm2.eps, want_sum=True)
+        hdn = self._linear(name + ".fc1", y_hl, rows, C, [b.mlp.fc1.weight for b in blks], [b.mlp.fc1.bias for b in blks],
+                           act=ops.ACT_GELU)
+        Ch = blks[0].mlp.fc1.out_features
+        br = self._linear(name + ".fc2", ops.split_hl32(hdn), rows, Ch, [b.mlp.fc2.weight for b in blks],
+                          [b.mlp.fc2.bias for b in blks])
+        return x, (br.view(G * B, N, C), drop2)
+
+    def _svtr(self, image, last_hl=False):
+        """image [B,H,W,C] fp32 (shared) -> features Act [G,B,1,W,out] (SVTR.forward_features, modules/svtr.py:500-528)"""
+        G = self.G
+        nets = [e.FeatureExtraction.ConvNet for e in self.experts]
+        n0 = nets[0]
+        B = image.shape[0]
+        logical = image.permute(0, 3, 1, 2)                   # [B,C,H,W] view of the NHWC image: what PatchEmbed takes
+        H, W = n0.HW
+        N, C = H * W, n0.embed_dim[0]
+        x = torch.empty(G * B, N, C, device=image.device, dtype=torch.float32)
+        for g, n in enumerate(nets):
+            # PatchEmbed (Cin = 4 and 32: exact-fp32 convs + BatchNorm + GELU, as on the per-expert path) + position embedding
+            tok = n.patch_embed(logical)
+            ops.ew_rows(ops.EW_ADD, tok.view(B, N * C), n.pos_embed.view(1, N * C).expand(B, N * C), out=x[g * B:(g + 1) * B].view(B, N * C))
+        for si in range(3):
+            blocks = [list(getattr(n, "blocks%d" % (si + 1))) for n in nets]
+            pending = None
+            for i in range(len(blocks[0])):
+                x, pending = self._svtr_block("svtr%d.%d" % (si, i), x, pending, [b[i] for b in blocks], B, N)
+            # SubSample (:298-305): fold the last residual add, 3x3 stride-(2,1) conv, LayerNorm
+            _, _, hl = ops.add_layernorm_grouped(x, pending[0], pending[1], N, want_sum=False, want_f32=False, want_hl=True)
+            subs = [getattr(n, "sub_sample%d" % (si + 1)) for n in nets]
+            y = self.layer(Act((G, B, H, W, C), None, hl), [s.conv for s in subs], None, relu=False, want_f32=True, want_hl=False)
+            _, _, H, W, C = y.shape
+            N = H * W
+            gm, bt = self._ln_params("svtr_sub%d" % si, [s.norm for s in subs])
+            last = si == 2
+            _, x, hl = ops.add_layernorm_grouped(y.f32.view(G * B, N, C), None, None, N, gm, bt, B * N, subs[0].norm.eps,
+                                                 want_f32=not (last and last_hl), want_hl=last and last_hl)
+        return Act((G, B, H, W, C), x.view(G, B, H, W, C) if x is not None else None, hl if last_hl else None)
+
     def _tps(self, image):
         """image [B,H,W,C] fp32 (shared) -> rectified images [G,B,H,W,C]"""
         G = self.G
@@ -275,7 +356,13 @@ class BackboneGroup(_GroupedLinear):
             x = self._tps(img)
         else:
             x = Act((self.G, B, H, W, C), img, None, shared=True)
-        x = self._resnet(x, as_act) if self.experts[0].stages["Feat"] == "ResNet" else self._vgg(x, as_act)
+        feat = self.experts[0].stages["Feat"]
+        if feat == "SVTR":
+            for e in self.experts:
+                require_no_grad(e.FeatureExtraction.ConvNet, "SVTR")
+            x = self._svtr(img, as_act)
+        else:
+            x = self._resnet(x, as_act) if feat == "ResNet" else self._vgg(x, as_act)
         if self._nbt:
             torch._foreach_add_(self._nbt, 1)
         G, B, Ho, Wo, Cf = x.shape
@@ -298,7 +385,7 @@ class HeadsGroup(_GroupedLinear):
     @staticmethod
     def supported(experts, is_train):
         e0 = experts[0]
-        if len(experts) < 2 or e0.model.stages["Seq"] != "BiLSTM":
+        if len(experts) < 2 or e0.model.stages["Seq"] not in ("BiLSTM", "None"):
             return False
         if any(e.model.stages != e0.model.stages or e.stages != e0.stages for e in experts):
             return False
@@ -335,8 +422,12 @@ class HeadsGroup(_GroupedLinear):
         G = self.G
         _, B, _, T, Cf = visual.shape
         x_hl = visual.hl if visual.hl is not None else ops.split_hl32(visual.f32)
-        y1 = self._bilstm(0, x_hl, (B, T), Cf)
-        feat = self._bilstm(1, ops.split_hl32(y1), (B, T), y1.shape[-1])          # [G,B,T,hidden]
+        if self.experts[0].model.stages["Seq"] == "BiLSTM":
+            y1 = self._bilstm(0, x_hl, (B, T), Cf)
+            feat = self._bilstm(1, ops.split_hl32(y1), (B, T), y1.shape[-1])      # [G,B,T,hidden]
+        else:                                                                     # Seq "None": one Linear (model.py sequence())
+            lins = [e.model.SequenceModeling[0] for e in self.experts]
+            feat = self._linear("seq", x_hl, B * T, Cf, [l.weight for l in lins], [l.bias for l in lins]).view(G, B, T, -1)
         feats_out.copy_(feat.permute(1, 2, 0, 3))
         hidden = feat.shape[-1]
         feat_hl = ops.split_hl32(feat)

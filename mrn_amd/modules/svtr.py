@@ -249,8 +249,8 @@ class SVTR(nn.Module):
         require_no_grad(self, "SVTR")
         B = x.shape[0]
         t = self.patch_embed(x)                                               # [B, 8*64, 64]
-        pos = self.pos_embed.expand(B, -1, -1).contiguous()
-        t = ops.ew_rows(ops.EW_ADD, t, pos)
+        NC = t.shape[1] * t.shape[2]
+        t = ops.ew_rows(ops.EW_ADD, t.view(B, NC), self.pos_embed.view(1, NC).expand(B, NC)).view(t.shape)   # row stride 0: no copy
         H, W = self.HW
         for blk in self.blocks1:
             t = blk(t)

@@ -1077,15 +1077,33 @@ def softmax_rows_(s, mask=None):
     return s
 
 
-def svtr_attention(qkv, heads, scale, mask=None):
-    """qkv [B,N,3C] (q | k | v, head dim 32), mask [N,N] additive symmetric or None -> [B,N,C]: fused q k^T / softmax / attn v"""
+def svtr_attention(qkv, heads, scale, mask=None, want_f32=True, want_hl=False):
+    """qkv [B,N,3C] (q | k | v, head dim 32), mask [N,N] additive symmetric or None -> [B,N,C]: fused q k^T / softmax / attn v.
+    want_hl: also (or only) the HL32 operand of the proj Linear; returns the fp32 tensor, the HL32 bytes, or (fp32, hl)"""
     _chk(qkv, mask)
     B, N, C3 = qkv.shape
     C = C3 // 3
     assert qkv.is_contiguous() and C == heads * 32 and (mask is None or (mask.is_contiguous() and tuple(mask.shape) == (N, N)))
-    out = torch.empty(B, N, C, device=qkv.device, dtype=torch.float32)
-    call("mrn_svtr_attention_f32", _p(qkv), _p(mask), _p(out), B, N, C, heads, float(scale), _stream())
-    return out
+    out = torch.empty(B, N, C, device=qkv.device, dtype=torch.float32) if want_f32 else None
+    hl = torch.empty(B * N * C * 4, device=qkv.device, dtype=torch.uint8) if want_hl else None
+    call("mrn_svtr_attention_f32", _p(qkv), _p(mask), _p(out), _p(hl), B, N, C, heads, float(scale), _stream())
+    return (out, hl) if (want_f32 and want_hl) else (hl if want_hl else out)
+
+
+def add_layernorm_grouped(x, branch=None, drop=None, rows_per_drop=1, gamma=None, beta=None, rows_per_group=None, eps=1e-6,
+                          want_sum=False, want_f32=False, want_hl=True):
+    """x, branch [..., C] contiguous: t = x + drop[row // rows_per_drop] * branch; y = LayerNorm(t) * gamma[g] + beta[g]
+    (gamma, beta [G,C]; None: y = t) -> (t or None, y fp32 or None, y HL32 bytes or None)"""
+    _chk(x, branch, drop, gamma, beta)
+    C = x.shape[-1]
+    rows = x.numel() // C
+    assert x.is_contiguous() and (branch is None or (branch.is_contiguous() and branch.numel() == x.numel()))
+    t = torch.empty_like(x) if want_sum else None
+    y = torch.empty_like(x) if want_f32 else None
+    hl = torch.empty(x.numel() * 4, device=x.device, dtype=torch.uint8) if want_hl else None
+    call("mrn_add_layernorm_grouped_f32", _p(x), _p(branch), _p(drop), int(rows_per_drop), _p(gamma), _p(beta),
+         int(rows_per_group if rows_per_group is not None else rows), _p(t), _p(y), _p(hl), rows, C, float(eps), _stream())
+    return t, y, hl
 
 
 def residual_scale_rows(x, branch, scale, rows_per_group, out=None):

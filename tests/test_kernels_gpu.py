@@ -545,3 +545,39 @@ def test_svtr_fused_attention(ops, B, N, heads, masked):
     ref = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B, N, C)
     out = ops.svtr_attention(cu(qkv), heads, 32 ** -0.5, cu(mask) if masked else None)
     assert_close("fused attention", out, ref, atol=2e-6, rtol=1e-5)
+
+
+def _hl32_to_f32(hl, rows, C):
+    """HL32 bytes -> fp32 [rows, C] (hi + lo)"""
+    v = hl.view(torch.float16).view(rows, C // 32, 2, 32).float()
+    return (v[:, :, 0] + v[:, :, 1]).reshape(rows, C)
+
+
+def test_svtr_fused_attention_hl32_output(ops):
+    """the HL32 image the attention kernel writes for the proj Linear is the split of its fp32 output"""
+    B, N, heads = 3, 256, 4
+    C = heads * 32
+    qkv = cu(rnd(B, N, 3 * C, seed=261))
+    out, hl = ops.svtr_attention(qkv, heads, 32 ** -0.5, None, want_f32=True, want_hl=True)
+    assert torch.equal(hl, ops.split_hl32(out))
+
+
+@pytest.mark.parametrize("C,G,rows_pg", [(64, 3, 700), (128, 2, 515), (256, 3, 130), (512, 2, 67)])
+def test_add_layernorm_grouped(ops, C, G, rows_pg):
+    """mrn_add_layernorm_grouped_f32: DropPath-scaled residual add + per-expert LayerNorm + HL32 split in one pass"""
+    N = rows_pg // 5 if rows_pg % 5 == 0 else 1                       # rows per DropPath sample
+    rows = G * rows_pg
+    x, br = rnd(rows, C, seed=270), rnd(rows, C, seed=271)
+    drop = (torch.rand(rows // N, generator=torch.Generator().manual_seed(3)) > 0.3).float() / 0.7
+    gamma, beta = rnd(G, C, seed=272) + 1.0, rnd(G, C, seed=273)
+    t_ref = x + drop.repeat_interleave(N)[:, None] * br
+    y_ref = torch.cat([torch.nn.functional.layer_norm(t_ref[g * rows_pg:(g + 1) * rows_pg], (C,), gamma[g], beta[g], 1e-6) for g in range(G)])
+    t, y, hl = ops.add_layernorm_grouped(cu(x), cu(br), cu(drop), N, cu(gamma), cu(beta), rows_pg, 1e-6, want_sum=True,
+                                         want_f32=True, want_hl=True)
+    assert_close("residual sum", t, t_ref, atol=1e-6, rtol=1e-6)
+    assert_close("layernorm", y, y_ref, atol=2e-5, rtol=1e-5)
+    assert torch.equal(hl, ops.split_hl32(y))
+    # no LayerNorm, no branch: plain operand split
+    _, _, hl2 = ops.add_layernorm_grouped(cu(x), want_hl=True)
+    assert torch.equal(hl2, ops.split_hl32(cu(x)))
+    assert_close("hl32 round trip", _hl32_to_f32(hl2, rows, C), x, atol=1e-6, rtol=1e-6)
