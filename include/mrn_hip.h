@@ -129,7 +129,10 @@ int mrn_conv2d_wgrad_f32(const float* dy, const float* x, float* dw_partial, int
 int mrn_pack_dgrad_weight_f32(const float* w_ohwi, float* wt_ihwo, int O, int I, int kh, int kw, void* stream);
 int mrn_unpack_conv_weight_f32(const float* g_ohwi, float* g_oihw, int O, int I, int kh, int kw, int accumulate,
                                void* stream);
-int mrn_dilate_nhwc_f32(const float* dy, float* out, int B, int Ho, int Wo, int C, int sh, int sw, void* stream);
+/* zero-insertion of a strided conv's output gradient: out [B][(Ho-1)*sh+1+extra_h][(Wo-1)*sw+1+extra_w][C]; the extra trailing
+ * zero rows / columns cover the input rows the floor in the output-size formula left over (they still sit under kernel taps) */
+int mrn_dilate_nhwc_f32(const float* dy, float* out, int B, int Ho, int Wo, int C, int sh, int sw, int extra_h, int extra_w,
+                        void* stream);
 /* BatchNorm2d (training) backward with the ReLU mask fused: g = dz * (z > 0); partial per-channel sums of g and
  * g*xhat (reduce), then dy = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)) and dres = g (apply). */
 int64_t mrn_bn_bwd_blocks(int64_t rows);
@@ -273,6 +276,8 @@ int mrn_ew_rows_f32(const float* a, int64_t lda, const float* b, int64_t ldb, fl
 /* in-place softmax over the N columns of every row of s, with an optional additive mask [rows_per_mask][N] shared
  * across the batch (row r uses mask row r % rows_per_mask): SVTR Local/Global mixing, modules/svtr.py:140-146 */
 int mrn_softmax_rows_f32(float* s, const float* mask, int64_t rows, int N, int rows_per_mask, void* stream);
+/* backward of mrn_softmax_rows_f32, in place on dp: ds = p * (dp - rowsum(p * dp)) (autograd of svtr.py:146 in expert training) */
+int mrn_softmax_rows_bwd_f32(const float* p, float* dp, int64_t rows, int N, void* stream);
 /* One pass between two Linear layers of the SVTR mixing blocks of G lock-step experts (modules/svtr.py:200-204 Block.forward,
  * :298-305 SubSample): t = x + drop[r / rows_per_drop] * branch (DropPath-scaled residual add; branch NULL: t = x, drop NULL: 1)
  * -> sum_out (optional, may alias x); y = LayerNorm(t) * gamma[g] + beta[g] with g = r / rows_per_group (gamma NULL: y = t)

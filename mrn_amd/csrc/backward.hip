@@ -37,8 +37,8 @@ __global__ void unpack_ohwi_oihw_kernel(const float* __restrict__ g, float* __re
 
 // zero-insertion: dy [B][Ho][Wo][C] -> out [B][(Ho-1)*sh+1][(Wo-1)*sw+1][C]  (data gradient of a strided conv)
 __global__ void dilate_nhwc_kernel(const float* __restrict__ dy, float* __restrict__ out, int B, int Ho, int Wo, int C4,
-                                   int sh, int sw) {
-  const int Hd = (Ho - 1) * sh + 1, Wd = (Wo - 1) * sw + 1;
+                                   int sh, int sw, int extra_h, int extra_w) {
+  const int Hd = (Ho - 1) * sh + 1 + extra_h, Wd = (Wo - 1) * sw + 1 + extra_w;
   const long n = (long)B * Hd * Wd * C4;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const int c4 = (int)(i % C4);
@@ -48,7 +48,7 @@ __global__ void dilate_nhwc_kernel(const float* __restrict__ dy, float* __restri
     const int y = (int)(r % Hd);
     const int b = (int)(r / Hd);
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (y % sh == 0 && x % sw == 0) v = reinterpret_cast<const f32x4*>(dy)[(((long)b * Ho + y / sh) * Wo + x / sw) * C4 + c4];
+    if (y % sh == 0 && x % sw == 0 && y / sh < Ho && x / sw < Wo) v = reinterpret_cast<const f32x4*>(dy)[(((long)b * Ho + y / sh) * Wo + x / sw) * C4 + c4];
     reinterpret_cast<f32x4*>(out)[i] = v;
   }
 }
@@ -254,12 +254,13 @@ MRN_EXPORT int mrn_unpack_conv_weight_f32(const float* g_ohwi, float* g_oihw, in
   return MRN_OK;
 }
 
-MRN_EXPORT int mrn_dilate_nhwc_f32(const float* dy, float* out, int B, int Ho, int Wo, int C, int sh, int sw, void* stream) {
-  MRN_CHECK_ARG(dy && out && C % 4 == 0 && sh >= 1 && sw >= 1, "mrn_dilate_nhwc_f32: bad operands");
-  const long n = (long)B * ((Ho - 1) * sh + 1) * ((Wo - 1) * sw + 1) * (C / 4);
+MRN_EXPORT int mrn_dilate_nhwc_f32(const float* dy, float* out, int B, int Ho, int Wo, int C, int sh, int sw, int extra_h,
+                                   int extra_w, void* stream) {
+  MRN_CHECK_ARG(dy && out && C % 4 == 0 && sh >= 1 && sw >= 1 && extra_h >= 0 && extra_w >= 0, "mrn_dilate_nhwc_f32: bad operands");
+  const long n = (long)B * ((Ho - 1) * sh + 1 + extra_h) * ((Wo - 1) * sw + 1 + extra_w) * (C / 4);
   if (n <= 0) return MRN_OK;
   hipLaunchKernelGGL(dilate_nhwc_kernel, dim3(ew_grid(n, 512)), dim3(256), 0, (hipStream_t)stream, dy, out, B, Ho, Wo, C / 4,
-                     sh, sw);
+                     sh, sw, extra_h, extra_w);
   MRN_LAUNCH_CHECK("dilate_nhwc");
   return MRN_OK;
 }

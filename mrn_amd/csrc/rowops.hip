@@ -327,6 +327,30 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s
   }
 }
 
+// Backward of the row softmax, in place on dp: ds = p * (dp - sum_j p_j dp_j).  One wave per row, N <= 1024.
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __restrict__ p, float* __restrict__ dp, long rows, int N) {
+  const int lane = threadIdx.x & 63;
+  const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* pr = p + row * N;
+  float* dr = dp + row * N;
+  float pv[16], dv[16];
+  float dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = lane + i * 64;
+    pv[i] = dv[i] = 0.f;
+    if (c < N) { pv[i] = pr[c]; dv[i] = dr[c]; }
+    dot = fmaf(pv[i], dv[i], dot);
+  }
+  dot = wave_sum(dot);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = lane + i * 64;
+    if (c < N) dr[c] = pv[i] * (dv[i] - dot);
+  }
+}
+
 // y = x + scale[row / rows_per_group] * branch   (DropPath: per-sample Bernoulli(keep)/keep scale, svtr.py:7-22,202-203)
 __global__ __launch_bounds__(256) void residual_scale_kernel(const float* __restrict__ x, const float* __restrict__ br,
                                                             const float* __restrict__ scale, float* __restrict__ y, long rows,
@@ -462,6 +486,16 @@ MRN_EXPORT int mrn_argmax_f32(const float* x, int64_t ld, int64_t* out, int64_t 
   hipLaunchKernelGGL(argmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, (long)ld, out,
                      (long)rows, C);
   MRN_LAUNCH_CHECK("argmax");
+  return MRN_OK;
+}
+
+// ds = p * (dp - rowsum(p * dp)), in place on dp: backward of mrn_softmax_rows_f32 (SVTR attention, expert training)
+MRN_EXPORT int mrn_softmax_rows_bwd_f32(const float* p, float* dp, int64_t rows, int N, void* stream) {
+  MRN_CHECK_ARG(p && dp && N > 0 && N <= 1024, "mrn_softmax_rows_bwd_f32: bad operands (N=%d)", N);
+  if (rows == 0) return MRN_OK;
+  hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, dp,
+                     (long)rows, N);
+  MRN_LAUNCH_CHECK("softmax_rows_bwd");
   return MRN_OK;
 }
 

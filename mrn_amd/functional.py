@@ -372,6 +372,8 @@ class ConvBlockFn(torch.autograd.Function):
         dgamma = dbeta = dres = dbias = None
         if has_bn:
             dy, dgamma, dbeta, dres = ops.bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres=has_res)
+            if ctx.needs_input_grad[2]:       # a conv bias in front of train-mode BatchNorm (SVTR PatchEmbed) cancels in the
+                dbias = torch.zeros(dy.shape[-1], device=dy.device, dtype=torch.float32)     # mean: its gradient is exactly 0
         else:
             dy = ops.ew_rows(ops.EW_RELU_BWD, z, dz) if relu else dz
             if ctx.needs_input_grad[2]:
@@ -557,3 +559,140 @@ class KDLossFn(torch.autograd.Function):
 
 def kd_loss(pred, soft, c0, c1, T=2.0):
     return KDLossFn.apply(pred, soft, c0, c1, T)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# SVTR mixing blocks in expert training (loop A): autograd of modules/svtr.py Block / Attention / Mlp / SubSample
+class TrainLinearFn(torch.autograd.Function):
+    """y = x W^T + b over contiguous rows, Linear layers of an expert being trained: forward, data gradient and weight
+    gradient on the range-safe split-fp16 x3 GEMM when the shape is eligible (exact fp32 otherwise)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = x.contiguous()
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        K = x.shape[-1]
+        return linear_fwd(x.view(-1, K), weight, bias).view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy2 = dy.contiguous().view(-1, dy.shape[-1])
+        dx = linear_dgrad(dy2, weight).view(x.shape) if ctx.needs_input_grad[0] else None
+        dw = linear_wgrad(dy2, x.view(-1, x.shape[-1])) if ctx.needs_input_grad[1] else None
+        db = ops.colsum(dy2) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = x.contiguous()
+        y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, eps)
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        dx, dgamma, dbeta = ops.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd)
+        return dx, dgamma, dbeta, None
+
+
+class GeluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return ops.ew_rows(ops.EW_GELU, x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.ew_rows(ops.EW_GELU_BWD, x, dy.contiguous())
+
+
+class AddPosFn(torch.autograd.Function):
+    """tokens [B,N,C] + pos_embed [1,N,C] (svtr.py:503): the broadcast operand is read with row stride 0"""
+
+    @staticmethod
+    def forward(ctx, t, pos):
+        B = t.shape[0]
+        NC = t.shape[1] * t.shape[2]
+        t = t.contiguous()
+        return ops.ew_rows(ops.EW_ADD, t.view(B, NC), pos.view(1, NC).expand(B, NC)).view(t.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        dpos = ops.colsum(dy.view(dy.shape[0], -1)).view(1, dy.shape[1], dy.shape[2]) if ctx.needs_input_grad[1] else None
+        return dy, dpos
+
+
+class ResidualScaleFn(torch.autograd.Function):
+    """x + drop[b] * branch (residual add with the per-sample DropPath multiplier, svtr.py:17-22,202-203); drop None: x + branch"""
+
+    @staticmethod
+    def forward(ctx, x, branch, drop, rows_per_sample):
+        x, branch = x.contiguous(), branch.contiguous()
+        ctx.drop, ctx.rps = drop, rows_per_sample
+        if drop is None:
+            return ops.ew_rows(ops.EW_ADD, x, branch)
+        return ops.residual_scale_rows(x, branch, drop, rows_per_sample)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        if ctx.drop is None:
+            return dy, dy, None, None
+        return dy, ops.residual_scale_rows(dy, dy, ctx.drop - 1.0, ctx.rps), None, None       # dy + (drop - 1) dy = drop * dy
+
+
+class SvtrAttentionFn(torch.autograd.Function):
+    """softmax(scale q k^T + mask) v for every head (svtr.py:140-149) with the probabilities kept for the backward pass:
+    per-head batched exact-fp32 GEMMs on strided views of qkv [B,N,3C] (no head split / merge copies)."""
+
+    @staticmethod
+    def forward(ctx, qkv, mask, heads, scale):
+        qkv = qkv.contiguous()
+        B, N, C3 = qkv.shape
+        C, h = C3 // 3, heads
+        d = C // h
+        attn = torch.empty(B, h, N, N, device=qkv.device, dtype=torch.float32)
+        out = torch.empty(B, N, C, device=qkv.device, dtype=torch.float32)
+        sq, sp = (N * C3, C3, 1), (h * N * N, N, 1)
+        for hd in range(h):
+            q, k = qkv[:, :, hd * d:(hd + 1) * d], qkv[:, :, C + hd * d:C + (hd + 1) * d]
+            ops.gemm_raw(q, k, attn[:, hd], N, N, d, B, sq, sq, sp, alpha=scale)
+        ops.softmax_rows_(attn, mask)
+        for hd in range(h):
+            v = qkv[:, :, 2 * C + hd * d:2 * C + (hd + 1) * d]
+            ops.gemm_raw(attn[:, hd], v, out[:, :, hd * d:(hd + 1) * d], N, d, N, B, sp, (N * C3, 1, C3), (N * C, C, 1))
+        ctx.save_for_backward(qkv, attn)
+        ctx.cfg = (h, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, attn = ctx.saved_tensors
+        h, scale = ctx.cfg
+        dout = dout.contiguous()
+        B, N, C3 = qkv.shape
+        C = C3 // 3
+        d = C // h
+        dqkv = torch.empty_like(qkv)
+        dp = torch.empty_like(attn)
+        sq, sp, so = (N * C3, C3, 1), (h * N * N, N, 1), (N * C, C, 1)
+        spt, sqt, sot = (h * N * N, 1, N), (N * C3, 1, C3), (N * C, 1, C)
+        for hd in range(h):
+            do = dout[:, :, hd * d:(hd + 1) * d]
+            v = qkv[:, :, 2 * C + hd * d:2 * C + (hd + 1) * d]
+            ops.gemm_raw(do, v, dp[:, hd], N, N, d, B, so, sq, sp)                                   # dP = dO V^T
+            ops.gemm_raw(attn[:, hd], do, dqkv[:, :, 2 * C + hd * d:2 * C + (hd + 1) * d], N, d, N, B, spt, sot, sq)   # dV = P^T dO
+        ops.softmax_rows_bwd_(attn, dp)                                                              # dS (the mask is constant)
+        for hd in range(h):
+            q, k = qkv[:, :, hd * d:(hd + 1) * d], qkv[:, :, C + hd * d:C + (hd + 1) * d]
+            ops.gemm_raw(dp[:, hd], k, dqkv[:, :, hd * d:(hd + 1) * d], N, d, N, B, sp, sqt, sq, alpha=scale)           # dQ = scale dS K
+            ops.gemm_raw(dp[:, hd], q, dqkv[:, :, C + hd * d:C + (hd + 1) * d], N, d, N, B, spt, sqt, sq, alpha=scale)  # dK = scale dS^T Q
+        return dqkv, None, None, None

@@ -3,8 +3,9 @@ Block :154-204, SubSample :265-312, SVTR :315-531; wrapper modules/feature_extra
 
 Same constructor defaults, attribute names and state_dict keys (including the reference's unused `linear`,
 `last_conv`, `norm` parameters).  Tokens are the NHWC pixels of the feature map, so `flatten(2).transpose(1, 2)` and
-the reshapes before every SubSample are views.  Forward only: experts with this backbone are frozen in MRN's router
-phase; training it (loop A) raises NotImplementedError.
+the reshapes before every SubSample are views.  Frozen experts (MRN's router phase) take the fused inference kernels
+(or run in lock-step groups, modules/expert_group.py); an expert being trained (loop A) runs the same stages as autograd
+Functions of mrn_amd.functional (LayerNormFn, TrainLinearFn, SvtrAttentionFn, ResidualScaleFn, GeluFn, ConvBlockFn).
 """
 from functools import partial
 
@@ -13,8 +14,9 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..functional import frozen_linear
-from ._nn import conv_block, from_nhwc, require_no_grad, to_nhwc
+from ..functional import (AddPosFn, GeluFn, LayerNormFn, ResidualScaleFn, SvtrAttentionFn, TrainLinearFn, frozen_linear,
+                          needs_grad)
+from ._nn import conv_block, from_nhwc, to_nhwc
 
 
 class Identity(nn.Module):
@@ -83,6 +85,17 @@ class Attention(nn.Module):
             if mixer == 'Local':
                 self.mask = local_attention_mask(HW[0], HW[1], local_k[0], local_k[1])
 
+    def _mask_on(self, device):
+        if self.mask is not None and self.mask.device != device:
+            self.mask = self.mask.to(device)
+        return self.mask
+
+    def forward_train(self, x):
+        """autograd path of an expert being trained: x [B,N,C] -> proj(softmax(q k^T * scale + mask) v)"""
+        qkv = TrainLinearFn.apply(x, self.qkv.weight, self.qkv.bias)
+        ctx = SvtrAttentionFn.apply(qkv, self._mask_on(x.device), self.num_heads, self.scale)
+        return TrainLinearFn.apply(ctx, self.proj.weight, self.proj.bias)
+
     def forward_tokens(self, x, residual=None):
         """x [B,N,C] -> proj(softmax(q k^T * scale + mask) v) (+ residual fused into the proj GEMM)"""
         B, N, C = x.shape
@@ -129,7 +142,20 @@ class Block(nn.Module):
         self.mlp_ratio = mlp_ratio
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
 
+    def forward_train(self, x):
+        """Block.forward (svtr.py:200-204) under autograd, same DropPath draw order as the inference path"""
+        B, N, C = x.shape
+        sc = self.drop_path.scale(B, x.device) if isinstance(self.drop_path, DropPath) else None
+        y = LayerNormFn.apply(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        x = ResidualScaleFn.apply(x, self.mixer.forward_train(y), sc, N)
+        sc = self.drop_path.scale(B, x.device) if isinstance(self.drop_path, DropPath) else None
+        y = LayerNormFn.apply(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        hdn = GeluFn.apply(TrainLinearFn.apply(y, self.mlp.fc1.weight, self.mlp.fc1.bias))
+        return ResidualScaleFn.apply(x, TrainLinearFn.apply(hdn, self.mlp.fc2.weight, self.mlp.fc2.bias), sc, N)
+
     def forward(self, x):
+        if needs_grad(self, x):
+            return self.forward_train(x)
         B, N, C = x.shape
         sc = self.drop_path.scale(B, x.device) if isinstance(self.drop_path, DropPath) else None
         y, _, _ = ops.layernorm_fwd(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
@@ -162,9 +188,13 @@ class PatchEmbed(nn.Module):
         B, C, H, W = x.shape
         assert H == self.img_size[0] and W == self.img_size[1], \
             f"Input image size ({H}*{W}) doesn't match model ({self.img_size[0]}*{self.img_size[1]})."
-        y = conv_block(to_nhwc(x), self.proj[0], self.proj[1], relu=False, act="gelu", precision="f32")
-        y = conv_block(y, self.proj[3], self.proj[4], relu=False, act="gelu", precision="f32")
-        return y.view(B, -1, y.shape[-1])                      # NHWC pixels are the tokens
+        if needs_grad(self, x):                               # expert training: conv + BatchNorm under autograd, then GELU
+            y = GeluFn.apply(conv_block(to_nhwc(x), self.proj[0], self.proj[1], relu=False, precision="f32"))
+            y = GeluFn.apply(conv_block(y, self.proj[3], self.proj[4], relu=False, precision="f32"))
+        else:
+            y = conv_block(to_nhwc(x), self.proj[0], self.proj[1], relu=False, act="gelu", precision="f32")
+            y = conv_block(y, self.proj[3], self.proj[4], relu=False, act="gelu", precision="f32")
+        return y.reshape(B, -1, y.shape[-1])                   # NHWC pixels are the tokens
 
 
 class SubSample(nn.Module):
@@ -182,8 +212,10 @@ class SubSample(nn.Module):
     def forward_tokens(self, x, HW):
         """tokens [B, H*W, C] -> conv stride (2,1) -> LayerNorm -> tokens [B, (H/2)*W, C']"""
         B, N, C = x.shape
-        y = conv_block(x.view(B, HW[0], HW[1], C), self.conv, None, relu=False)
-        y = y.view(B, -1, y.shape[-1])
+        y = conv_block(x.reshape(B, HW[0], HW[1], C), self.conv, None, relu=False)
+        y = y.reshape(B, -1, y.shape[-1])
+        if needs_grad(self, y):
+            return LayerNormFn.apply(y, self.norm.weight, self.norm.bias, self.norm.eps)
         out, _, _ = ops.layernorm_fwd(y, self.norm.weight, self.norm.bias, self.norm.eps)
         return out
 
@@ -246,11 +278,13 @@ class SVTR(nn.Module):
             nn.init.kaiming_normal_(m.weight, mode='fan_in')
 
     def forward_features(self, x):
-        require_no_grad(self, "SVTR")
         B = x.shape[0]
         t = self.patch_embed(x)                                               # [B, 8*64, 64]
-        NC = t.shape[1] * t.shape[2]
-        t = ops.ew_rows(ops.EW_ADD, t.view(B, NC), self.pos_embed.view(1, NC).expand(B, NC)).view(t.shape)   # row stride 0: no copy
+        if needs_grad(self, t):
+            t = AddPosFn.apply(t, self.pos_embed)
+        else:
+            NC = t.shape[1] * t.shape[2]
+            t = ops.ew_rows(ops.EW_ADD, t.view(B, NC), self.pos_embed.view(1, NC).expand(B, NC)).view(t.shape)   # row stride 0: no copy
         H, W = self.HW
         for blk in self.blocks1:
             t = blk(t)
@@ -261,7 +295,7 @@ class SVTR(nn.Module):
         for blk in self.blocks3:
             t = blk(t)
         t = self.sub_sample3.forward_tokens(t, (H // 4, W))                   # [B, (H/8)*W, out]
-        return from_nhwc(t.view(B, H // 8, W, self.out_channels))            # logical [B, out, H/8, W]
+        return from_nhwc(t.reshape(B, H // 8, W, self.out_channels))         # logical [B, out, H/8, W]
 
     def forward(self, x):
         return self.forward_features(x)

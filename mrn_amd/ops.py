@@ -936,18 +936,18 @@ def conv2d_dgrad(dy, wt_packed, x_hw, stride, padding, precision=None, dy_scale=
     B, Ho, Wo, Cout = dy.shape
     Cin, kh, kw, _ = wt_packed.shape
     H, W = x_hw
-    if stride != (1, 1):
-        d = torch.empty(B, (Ho - 1) * stride[0] + 1, (Wo - 1) * stride[1] + 1, Cout, device=dy.device, dtype=torch.float32)
-        call("mrn_dilate_nhwc_f32", _p(dy), _p(d), B, Ho, Wo, Cout, stride[0], stride[1], _stream())
-        dy = d
-    # full correlation with the flipped kernel; any rows/cols the strided forward never touched get zero gradient
+    # full correlation with the flipped kernel.  Input rows / columns the floor of the output-size formula left over still sit
+    # under kernel taps of the last output row (they overlap what would be trailing padding), so the dilated gradient gets that
+    # many extra trailing zero rows: the correlation then produces exactly [H, W]
     ph, pw = kh - 1 - padding[0], kw - 1 - padding[1]
-    need_h, need_w = H - (dy.shape[1] + 2 * ph - kh + 1), W - (dy.shape[2] + 2 * pw - kw + 1)
+    Hd, Wd = (Ho - 1) * stride[0] + 1, (Wo - 1) * stride[1] + 1
+    eh, ew = H - (Hd + 2 * ph - kh + 1), W - (Wd + 2 * pw - kw + 1)
+    assert eh >= 0 and ew >= 0
+    if stride != (1, 1) or eh or ew:
+        d = torch.empty(B, Hd + eh, Wd + ew, Cout, device=dy.device, dtype=torch.float32)
+        call("mrn_dilate_nhwc_f32", _p(dy), _p(d), B, Ho, Wo, Cout, stride[0], stride[1], eh, ew, _stream())
+        dy = d
     dx, _ = conv2d_nhwc(dy, wt_packed, None, (1, 1), (ph, pw), precision=precision, x_scale=dy_scale)   # (dilation adds only zeros)
-    if need_h or need_w:      # forward dropped trailing rows/cols (floor in the output-size formula)
-        full = torch.zeros(B, H, W, Cin, device=dy.device, dtype=torch.float32)
-        full[:, :dx.shape[1], :dx.shape[2]] = dx
-        dx = full
     return dx
 
 
@@ -1075,6 +1075,14 @@ def softmax_rows_(s, mask=None):
     rpm = mask.shape[0] if mask is not None else 1
     call("mrn_softmax_rows_f32", _p(s), _p(mask), rows, N, rpm, _stream())
     return s
+
+
+def softmax_rows_bwd_(p, dp):
+    """in place on dp: ds = p * (dp - rowsum(p * dp))"""
+    assert p.is_contiguous() and dp.is_contiguous() and p.shape == dp.shape
+    N = p.shape[-1]
+    call("mrn_softmax_rows_bwd_f32", _p(p), _p(dp), p.numel() // N, N, _stream())
+    return dp
 
 
 def svtr_attention(qkv, heads, scale, mask=None, want_f32=True, want_hl=False):

@@ -581,3 +581,28 @@ def test_add_layernorm_grouped(ops, C, G, rows_pg):
     _, _, hl2 = ops.add_layernorm_grouped(cu(x), want_hl=True)
     assert torch.equal(hl2, ops.split_hl32(cu(x)))
     assert_close("hl32 round trip", _hl32_to_f32(hl2, rows, C), x, atol=1e-6, rtol=1e-6)
+
+
+@pytest.mark.parametrize("H,W,Cin,Cout,stride", [(32, 64, 4, 32, (2, 2)), (16, 32, 32, 64, (2, 2)), (8, 64, 64, 128, (2, 1)),
+                                                 (2, 64, 256, 512, (2, 1)), (7, 9, 32, 64, (2, 2))])
+def test_strided_conv_block_gradients(ops, H, W, Cin, Cout, stride):
+    """ConvBlockFn (conv 3x3 pad 1, no BatchNorm) with stride > 1 -- SVTR's PatchEmbed / SubSample convs in expert training:
+    data, weight and bias gradients against torch autograd, including the even-size case where the floor in the output-size
+    formula leaves an input row that still receives gradient"""
+    from mrn_amd.modules._nn import conv_block
+    B = 3
+    conv = torch.nn.Conv2d(Cin, Cout, 3, stride, 1)
+    x = rnd(B, Cin, H, W, seed=280)
+    xr = x.clone().requires_grad_(True)
+    y = conv(xr)
+    g = rnd(*y.shape, seed=281)
+    y.backward(g)
+    convc = torch.nn.Conv2d(Cin, Cout, 3, stride, 1).cuda()
+    convc.load_state_dict(conv.state_dict())
+    xc = cu(x).permute(0, 2, 3, 1).contiguous().requires_grad_(True)          # NHWC
+    yc = conv_block(xc, convc, None, relu=False)
+    assert_close("strided conv", yc.permute(0, 3, 1, 2), y, atol=2e-5, rtol=1e-5)
+    yc.backward(cu(g).permute(0, 2, 3, 1).contiguous())
+    assert_close("strided conv dx", xc.grad.permute(0, 3, 1, 2), xr.grad, atol=2e-5, rtol=1e-4)
+    assert_close("strided conv dw", convc.weight.grad, conv.weight.grad, atol=1e-4, rtol=1e-4)
+    assert_close("strided conv db", convc.bias.grad, conv.bias.grad, atol=1e-4, rtol=1e-4)

@@ -264,6 +264,55 @@ def test_loop_a_crnn_gradients_vs_oracle():
     assert moved > 0
 
 
+def test_loop_a_svtr_gradients_vs_oracle():
+    """loop A on an SVTR expert (BASELINE config 4's first task): every parameter gradient of loss.backward() -- LayerNorm,
+    qkv / proj / MLP Linear layers, attention with the local mask, DropPath-scaled residuals, PatchEmbed conv + BN + GELU,
+    SubSample convs, pos_embed -- against torch autograd on the CPU oracle with the same DropPath draws."""
+    from mrn_amd import functional as Fn
+    from oracle import mrn_oracle as O
+    kind, classes, B, seed = "svtr", (40,), 3, 4
+    g = load_golden("svtr_mrn3")
+    opt, net = build_net(kind, (40, 70, 97), g, 3)
+    image, words, chars, _ = det_inputs(kind, classes, B, seed)
+    conv, labels_index, labels_length = labels_for(kind, words, chars)
+    masks = drop_masks(B, seed, "loopA", 1)
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    names = [n for n, p in net.named_parameters() if n.startswith("model.0.")]
+    params = [sd[n].requires_grad_(True) for n in names]
+    cfg = O.Cfg("None", "SVTR", "None", "CTC")
+    ref_out = O.model_forward(sd, "model.0.", cfg, image, None, True, training=True, masks=masks[0])["predict"]
+    ref_loss = O.ctc_loss(ref_out, labels_index.cpu(), labels_length.cpu())
+    ref_grads = torch.autograd.grad(ref_loss, params, allow_unused=True)
+    net.train()
+    for n, p in net.named_parameters():
+        p.requires_grad = n.startswith("model.0.")
+    set_drop_masks(net, kind, B, seed, "loopA", [0])
+    expert = net.model[0]
+    preds = expert(image.cuda(), None, True)["predict"]
+    loss = Fn.ctc_loss(preds, labels_index.cuda(), labels_length.cuda())
+    assert_close("loop A logits", preds, ref_out, atol=1e-4)
+    assert abs(loss.item() - ref_loss.item()) < 1e-4 * max(1.0, abs(ref_loss.item()))
+    loss.backward()
+    mine = dict(net.named_parameters())
+    checked = 0
+    for n, rg in zip(names, ref_grads):
+        if rg is None:                        # the reference's unused parameters (svtr.py:465-479) never receive gradients
+            assert mine[n].grad is None or float(mine[n].grad.abs().max()) == 0.0, n
+            continue
+        if rg.abs().max() < 1e-9:
+            continue
+        if ".patch_embed.proj." in n and n.endswith(".bias") and n.split(".")[-2] in ("0", "3"):
+            # conv bias in front of train-mode BatchNorm: exactly 0 here, fp32 round-off noise in torch autograd
+            assert float(mine[n].grad.abs().max()) == 0.0 and float(rg.abs().max()) < 1e-5, n
+            continue
+        _grad_check(n, mine[n].grad, rg)
+        checked += 1
+    assert checked > 130          # (blocks whose DropPath draw is 0 for every sample have exactly-zero gradients)
+    for k in sd:
+        if k.startswith("model.0.") and k.endswith("running_var"):
+            assert_close(k, net.state_dict()[k], sd[k], atol=1e-5)
+
+
 def _oracle_trba_grads(g, image, labels_index, dtype):
     """loss and parameter gradients of a TRBA expert's loop A on the CPU oracle in the given precision"""
     from oracle import mrn_oracle as O
