@@ -19,12 +19,14 @@ def make_opt(tmp, model):
         workers=0)
     if model == "crnn":
         o.Transformation, o.FeatureExtraction, o.SequenceModeling, o.Prediction = "None", "VGG", "BiLSTM", "CTC"
+    elif model == "svtr":
+        o.Transformation, o.FeatureExtraction, o.SequenceModeling, o.Prediction = "None", "SVTR", "None", "CTC"
     else:
         o.Transformation, o.FeatureExtraction, o.SequenceModeling, o.Prediction = "TPS", "ResNet", "BiLSTM", "Attn"
     return o
 
 
-@pytest.mark.parametrize("model", ["crnn", "trba"])
+@pytest.mark.parametrize("model", ["crnn", "trba", "svtr"])
 def test_mrn_learner_two_tasks(tmp_path, model):
     from mrn_amd.data.synthetic import SyntheticTextLines, SyntheticValidation, synthetic_characters
     from mrn_amd.il_modules.mrn import MRN
