@@ -82,11 +82,13 @@ int mrn_split_weight_bf16(const float* w, void* hi, void* lo, int64_t n, int hal
  * tile_m x tile_n = 256x256 (Cout >= 256), 256x128, 256x64 (Cout <= 64) or 128x128.  Requires Cin % 32 == 0; zero_page: >= 128 bytes of device zeros.
  * y_row_stride / y_group_stride (floats; 0 = dense [G][B*Ho*Wo][Cout]) let the result land in a wider buffer, e.g. one
  * expert's slice of the router's [B][P][I][C] feature tensor.  x_group_div > 1: group g reads activation group g / x_group_div.  With H = W = kh = kw = 1 this is a grouped Linear layer
- * (nn.Linear sites of modules/sequence_modeling.py:10,19-22 and modules/prediction.py:58-68,104-107). */
+ * (nn.Linear sites of modules/sequence_modeling.py:10,19-22 and modules/prediction.py:58-68,104-107).
+ * y_hl32 (optional, Cout % 32 == 0, dense rows): the result also (y != NULL) or only (y == NULL) as the HL32 operand of the
+ * next GEMM -- fc1 + GELU -> fc2 of the SVTR Mlp (modules/svtr.py:46-67) without an operand-split pass in between. */
 int mrn_conv2d_x3_hl32(const void* x_hl, const void* w_hl, const void* zero_page, const float* bias,
                        const float* residual, float* y, float* stats, const float* out_scale, const float* x_scale, int G, int64_t x_group_stride_bytes, int B, int H, int W,
                        int Cin, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int act, int tile_m, int tile_n,
-                       int64_t y_row_stride, int64_t y_group_stride, int x_group_div, void* stream);
+                       int64_t y_row_stride, int64_t y_group_stride, int x_group_div, void* y_hl32, void* stream);
 int64_t mrn_conv2d_x3_stats_floats(int G, int B, int Ho, int Wo, int Cout, int tile_m);
 int mrn_split_hl32_f32(const float* x, void* out, int64_t rows, int C, const float* scale, void* stream);
 /* transposed split for weight-gradient GEMMs (dW = dy^T x reduces over rows): x[rows][C] -> [splits][C][rows/splits/32][128 B],

@@ -12,7 +12,7 @@ import torch  # noqa: F401  -- must come first: torch's bundled libamdhip64 has 
 #                              without a device gets bound ("no ROCm-capable device is detected")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmrn_hip.so")
+LIB_PATH = os.environ.get("MRN_LIB_PATH") or os.path.join(_HERE, "csrc", "libmrn_hip.so")   # (override: A/B builds)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mrn_hip.h")
 
 _CTYPES = {

@@ -42,7 +42,8 @@ struct ConvX3Params {
   const float* out_scale;     // [G][2] = {s, 1/s} (epilogue multiplies by [1]) or null
   const float* x_scale;       // [2] = {s, 1/s} of the activation operand (epilogue multiplies by [1]) or null
   const float* res;           // optional residual, same layout as y, added before the activation
-  float* y;                   // [G][M][N]
+  float* y;                   // [G][M][N], or null when only y_hl is wanted
+  unsigned char* y_hl;        // the same result as HL32 lines [G][M][N/32][128 B] (dense rows, N % 32 == 0), or null
   float* stats;               // [G][tilesM][2][N] or null
   long x_gstride, w_gstride;  // bytes
   int x_group_div;            // activation group = g / x_group_div (weight-gradient GEMMs: one dy^T chunk serves all taps)
@@ -94,8 +95,8 @@ __device__ __forceinline__ int row_to_pixel(const ConvX3Params& p, int m, int& o
   return (b * p.Ho + oy) * p.Wo + ox;
 }
 
-// WAVES_M x WAVES_N waves; wave tile = (WM*32) x (WN*32)
-template <int WAVES_M, int WAVES_N, int WM, int WN>
+// WAVES_M x WAVES_N waves; wave tile = (WM*32) x (WN*32); HL_OUT: the epilogue can also write the HL32 result (p.y_hl)
+template <int WAVES_M, int WAVES_N, int WM, int WN, bool HL_OUT = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const ConvX3Params p) {
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
@@ -313,7 +314,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
           csq[j] += v * v;
           if (p.act == 1) v = fmaxf(v, 0.f);
           else if (p.act == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));     // GELU (erf), SVTR Mlp
-          yg[pix * p.y_ld + n] = v;
+          if (!HL_OUT || p.y) yg[pix * p.y_ld + n] = v;
+          if (HL_OUT && p.y_hl) {       // operand of the next GEMM: 32 lanes fill the hi half and the lo half of one 128-byte line
+            const _Float16 h = (_Float16)v, l = (_Float16)(v - (float)h);
+            unsigned char* line = p.y_hl + ((long)g * p.y_gstride + pix * p.y_ld + (n & ~31)) * 4 + (n & 31) * 2;
+            *reinterpret_cast<_Float16*>(line) = h;
+            *reinterpret_cast<_Float16*>(line + 64) = l;
+          }
         }
       }
     }
@@ -354,6 +361,10 @@ template __global__ void conv_x3_kernel<4, 2, 2, 2>(const ConvX3Params);
 template __global__ void conv_x3_kernel<4, 2, 1, 2>(const ConvX3Params);
 template __global__ void conv_x3_kernel<8, 1, 1, 2>(const ConvX3Params);
 template __global__ void conv_x3_kernel<4, 4, 2, 2>(const ConvX3Params);
+template __global__ void conv_x3_kernel<4, 2, 2, 2, true>(const ConvX3Params);
+template __global__ void conv_x3_kernel<4, 2, 1, 2, true>(const ConvX3Params);
+template __global__ void conv_x3_kernel<8, 1, 1, 2, true>(const ConvX3Params);
+template __global__ void conv_x3_kernel<4, 4, 2, 2, true>(const ConvX3Params);
 
 // ---- producers of the HL32 layout -------------------------------------------------------------------------------
 __device__ __forceinline__ void split_h(float v, _Float16& h, _Float16& l) {
@@ -518,7 +529,7 @@ void magic_div(unsigned d, unsigned& magic, int& shift) {
   shift = s - 1;
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN>
+template <int WAVES_M, int WAVES_N, int WM, int WN, bool HL_OUT = false>
 int launch_x3(const ConvX3Params& p0, hipStream_t st) {
   constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
   ConvX3Params p = p0;
@@ -528,8 +539,8 @@ int launch_x3(const ConvX3Params& p0, hipStream_t st) {
   p.class_order = (p.tiles_per_row > 0 && p.Ho >= 3 && p.kh == 3 && p.ph == 1 && p.sh == 1 && !getenv("MRN_X3_NO_CLASS_ORDER")) ? 1 : 0;
   const size_t ldsz = 2 * (size_t)(BM + BN) * 128;
   const long tiles = (long)p.G * p.tilesM * p.tilesN;
-  (void)hipFuncSetAttribute((const void*)conv_x3_kernel<WAVES_M, WAVES_N, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);
-  hipLaunchKernelGGL((conv_x3_kernel<WAVES_M, WAVES_N, WM, WN>), dim3((unsigned)tiles), dim3(WAVES_M * WAVES_N * 64), ldsz, st, p);
+  (void)hipFuncSetAttribute((const void*)conv_x3_kernel<WAVES_M, WAVES_N, WM, WN, HL_OUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);
+  hipLaunchKernelGGL((conv_x3_kernel<WAVES_M, WAVES_N, WM, WN, HL_OUT>), dim3((unsigned)tiles), dim3(WAVES_M * WAVES_N * 64), ldsz, st, p);
   MRN_LAUNCH_CHECK("conv2d_x3_hl32");
   return MRN_OK;
 }
@@ -545,8 +556,11 @@ MRN_EXPORT int mrn_conv2d_x3_hl32(const void* x_hl, const void* w_hl, const void
                                   const float* residual, float* y, float* stats, const float* out_scale,
                                   const float* x_scale, int G, int64_t x_group_stride_bytes, int B, int H,
                                   int W, int Cin, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int act,
-                                  int tile_m, int tile_n, int64_t y_row_stride, int64_t y_group_stride, int x_group_div, void* stream) {
-  MRN_CHECK_ARG(x_hl && w_hl && zero_page && y && G >= 1, "mrn_conv2d_x3_hl32: bad operands");
+                                  int tile_m, int tile_n, int64_t y_row_stride, int64_t y_group_stride, int x_group_div,
+                                  void* y_hl32, void* stream) {
+  MRN_CHECK_ARG(x_hl && w_hl && zero_page && (y || y_hl32) && G >= 1, "mrn_conv2d_x3_hl32: bad operands");
+  MRN_CHECK_ARG(!y_hl32 || (Cout % 32 == 0 && y_row_stride <= 0 && y_group_stride <= 0 && (uintptr_t)y_hl32 % 128 == 0),
+                "mrn_conv2d_x3_hl32: the HL32 result needs Cout %% 32 == 0 and dense rows");
   MRN_CHECK_ARG(Cin % 32 == 0 && kh * kw <= 32, "mrn_conv2d_x3_hl32: unsupported Cin=%d kernel=%dx%d", Cin, kh, kw);
   MRN_CHECK_ARG(((uintptr_t)x_hl % 128 == 0) && ((uintptr_t)w_hl % 128 == 0) && ((uintptr_t)zero_page % 16 == 0) &&
                     (x_group_stride_bytes % 128 == 0), "mrn_conv2d_x3_hl32: HL32 operands must be 128-byte aligned");
@@ -559,7 +573,7 @@ MRN_EXPORT int mrn_conv2d_x3_hl32(const void* x_hl, const void* w_hl, const void
   ConvX3Params p;
   memset(&p, 0, sizeof(p));
   p.x = (const unsigned char*)x_hl; p.w = (const unsigned char*)w_hl; p.zero = (const unsigned char*)zero_page;
-  p.bias = bias; p.out_scale = out_scale; p.x_scale = x_scale; p.res = residual; p.y = y; p.stats = stats;
+  p.bias = bias; p.out_scale = out_scale; p.x_scale = x_scale; p.res = residual; p.y = y; p.y_hl = (unsigned char*)y_hl32; p.stats = stats;
   p.Cb = Cin / 32; p.taps = kh * kw; p.nk = p.Cb * p.taps;
   p.x_gstride = x_group_stride_bytes; p.w_gstride = (long)Cout * p.nk * 128;
   p.x_group_div = x_group_div > 1 ? x_group_div : 1;
@@ -578,6 +592,12 @@ MRN_EXPORT int mrn_conv2d_x3_hl32(const void* x_hl, const void* w_hl, const void
   magic_div((unsigned)p.BWo, p.bw_magic, p.bw_shift);
   // 256x256: 16 waves (64x64 wave tiles, four waves per SIMD) hide the per-K-step LDS / barrier stalls better than 8 waves
   // with 128x64 tiles: 464 vs 438 TFLOP/s on the dominant shape (MRN_X3_W8=1 selects the 8-wave variant for A/B runs)
+  if (y_hl32) {     // separate instantiations: the store path of the plain kernels stays as it was
+    if (tile_n == 256) return launch_x3<4, 4, 2, 2, true>(p, (hipStream_t)stream);
+    if (tile_m == 256 && tile_n == 64) return launch_x3<8, 1, 1, 2, true>(p, (hipStream_t)stream);
+    if (tile_m == 256) return launch_x3<4, 2, 2, 2, true>(p, (hipStream_t)stream);
+    return launch_x3<4, 2, 1, 2, true>(p, (hipStream_t)stream);
+  }
   if (tile_n == 256 && getenv("MRN_X3_W8")) return launch_x3<2, 4, 4, 2>(p, (hipStream_t)stream);
   if (tile_n == 256) return launch_x3<4, 4, 2, 2>(p, (hipStream_t)stream);
   if (tile_m == 256 && tile_n == 64) return launch_x3<8, 1, 1, 2>(p, (hipStream_t)stream);

@@ -74,8 +74,9 @@ class _GroupedLinear:
         return got[1]
 
     def _linear(self, name, x_hl, rows, K, weights, biases, out=None, out_row_stride=0, out_group_stride=0, groups=None,
-                act=ops.ACT_NONE):
-        """grouped y[g] = x[g] @ W[g]^T + b[g]; weights: list of [N,K] tensors (any stride), biases: list or None"""
+                act=ops.ACT_NONE, hl_only=False):
+        """grouped y[g] = x[g] @ W[g]^T + b[g]; weights: list of [N,K] tensors (any stride), biases: list or None.
+        hl_only: return the result as the HL32 operand of the next grouped Linear instead of fp32"""
         G = len(weights)
         N = weights[0].shape[0]
         params = list(weights) + ([b for b in biases] if biases is not None else [])
@@ -86,7 +87,7 @@ class _GroupedLinear:
             return w_hl, scale, bias
         w_hl, scale, bias = self._cached(name, params, build)
         y, _ = ops.conv2d_x3(x_hl, G, False, rows, 1, 1, K, w_hl, scale, N, (1, 1), bias=bias, act=act, out=out,
-                             out_row_stride=out_row_stride, out_group_stride=out_group_stride)
+                             out_row_stride=out_row_stride, out_group_stride=out_group_stride, hl_only=hl_only)
         return y
 
 
@@ -282,11 +283,11 @@ class BackboneGroup(_GroupedLinear):
         drop2 = self._drop_scales(blks, B, x.device)
         g2, b2 = self._ln_params(name + ".ln2", [b.norm2 for b in blks])
         x, _, y_hl = ops.add_layernorm_grouped(x, br.view(G * B, N, C), drop1, N, g2, b2, rows, b0.norm2.eps, want_sum=True)
-        hdn = self._linear(name + ".fc1", y_hl, rows, C, [b.mlp.fc1.weight for b in blks], [b.mlp.fc1.bias for b in blks],
-                           act=ops.ACT_GELU)
+        # fc1 + GELU lands straight in the HL32 layout fc2 reads: the 4C-wide hidden tensor crosses HBM once each way
+        hdn_hl = self._linear(name + ".fc1", y_hl, rows, C, [b.mlp.fc1.weight for b in blks], [b.mlp.fc1.bias for b in blks],
+                              act=ops.ACT_GELU, hl_only=True)
         Ch = blks[0].mlp.fc1.out_features
-        br = self._linear(name + ".fc2", ops.split_hl32(hdn), rows, Ch, [b.mlp.fc2.weight for b in blks],
-                          [b.mlp.fc2.bias for b in blks])
+        br = self._linear(name + ".fc2", hdn_hl, rows, Ch, [b.mlp.fc2.weight for b in blks], [b.mlp.fc2.bias for b in blks])
         return x, (br.view(G * B, N, C), drop2)
 
     def _svtr(self, image, last_hl=False):

@@ -606,3 +606,17 @@ def test_strided_conv_block_gradients(ops, H, W, Cin, Cout, stride):
     assert_close("strided conv dx", xc.grad.permute(0, 3, 1, 2), xr.grad, atol=2e-5, rtol=1e-4)
     assert_close("strided conv dw", convc.weight.grad, conv.weight.grad, atol=1e-4, rtol=1e-4)
     assert_close("strided conv db", convc.bias.grad, conv.bias.grad, atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("G,rows,K,N,act", [(3, 700, 64, 256, 2), (2, 300, 256, 1024, 2), (1, 515, 128, 64, 0), (2, 260, 512, 512, 1)])
+def test_x3_linear_hl32_result(ops, G, rows, K, N, act):
+    """mrn_conv2d_x3_hl32 with y_hl32: the epilogue writes the result as the next GEMM's HL32 operand -- identical to
+    splitting the fp32 result"""
+    x = rnd(G, rows, K, seed=290)
+    w = [rnd(N, K, seed=291 + g, scale=K ** -0.5) for g in range(G)]
+    b = cu(rnd(G, N, seed=295))
+    w_hl, sw = ops.pack_weights_hl32([cu(t).view(N, 1, 1, K) for t in w])
+    x_hl = ops.split_hl32(cu(x))
+    y, _ = ops.conv2d_x3(x_hl, G, False, rows, 1, 1, K, w_hl, sw, N, (1, 1), bias=b, act=act)
+    hl, _ = ops.conv2d_x3(x_hl, G, False, rows, 1, 1, K, w_hl, sw, N, (1, 1), bias=b, act=act, hl_only=True)
+    assert torch.equal(hl, ops.split_hl32(y))
