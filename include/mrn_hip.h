@@ -292,8 +292,14 @@ int mrn_add_layernorm_grouped_f32(const float* x, const float* branch, const flo
  * C = heads * 32), mask [N][N] additive and SYMMETRIC (SVTR's local window mask) or NULL, out [B][N][C] fp32 and / or
  * out_hl32 (the same tensor as the HL32 operand of the proj Linear: a head IS one 32-channel block).  Online softmax
  * on the exact-fp32 MFMA: the [B][heads][N][N] score tensor of modules/svtr.py:140-149 never reaches HBM. */
-int mrn_svtr_attention_f32(const float* qkv, const float* mask, float* out, void* out_hl32, int B, int N, int C, int heads,
-                           float scale, void* stream);
+int mrn_svtr_attention_f32(const float* qkv, const float* mask, float* out, void* out_hl32, float* lse, int B, int N, int C,
+                           int heads, float scale, void* stream);
+/* Backward of the above for an expert being trained (autograd of svtr.py:140-149 under loss.backward(), il_modules/mrn.py:260):
+ * the forward call also stores lse [B][heads][N] (base-2 log-sum-exp of the scaled, masked scores; pass NULL when frozen);
+ * dqkv [B][N][3*C] is recomputed tile by tile from qkv, out, dout and lse -- no [N][N] tensor is kept.  dsum: [B][heads][N]
+ * floats of workspace (rowsum(dout o out)). */
+int mrn_svtr_attention_bwd_f32(const float* qkv, const float* mask, const float* out, const float* dout, const float* lse,
+                               float* dsum, float* dqkv, int B, int N, int C, int heads, float scale, void* stream);
 /* y = x + scale[row / rows_per_group] * branch : residual add with the per-sample DropPath scale (svtr.py:7-22,202-203) */
 int mrn_residual_scale_rows_f32(const float* x, const float* branch, const float* scale, float* y, int64_t rows, int C,
                                 int64_t rows_per_group, void* stream);

@@ -29,6 +29,7 @@ struct AttnParams {
   const float* mask;   // [N][N] additive, symmetric, or null
   float* out;          // [B][N][C] fp32, or null
   unsigned char* out_hl;   // the same tensor as HL32 lines [B*N][heads][hi 32 | lo 32] (a head is one 32-channel block), or null
+  float* lse;          // [B][heads][N] base-2 log-sum-exp of the scaled, masked scores (kept for the backward pass), or null
   int B, N, C, heads;
   float scale;
 };
@@ -161,6 +162,7 @@ __global__ __launch_bounds__(AW * 64) void svtr_attention_kernel(const AttnParam
   if (qok) {
     const float inv = 1.f / l_run;
     const long row = (long)b * p.N + q;
+    if (p.lse && half == 0) p.lse[(long)bh * p.N + q] = m_run + __builtin_amdgcn_logf(l_run);     // (v_log_f32 is log2)
 #pragma unroll
     for (int e = 0; e < 16; e += 4) {
       const f32x4 v = {o[e] * inv, o[e + 1] * inv, o[e + 2] * inv, o[e + 3] * inv};
@@ -181,21 +183,313 @@ __global__ __launch_bounds__(AW * 64) void svtr_attention_kernel(const AttnParam
   }
 }
 
+// ---- backward (expert training, loop A) ------------------------------------------------------------------------------------
+// Flash-style: nothing of size N x N is kept from the forward pass, only the per-query log-sum-exp.  Two kernels recompute
+// the probabilities tile by tile:
+//   dq kernel    (workgroup = 128 queries, wave = 32 queries, walks the keys; same orientation as the forward kernel):
+//                P^T = exp2(S^T - lse), dP^T = V dO^T, dS^T = P^T o (dP^T - D), dQ^T += K^T dS^T; also writes D = rowsum(dO o O)
+//   dk/dv kernel (workgroup = 128 keys, wave = 32 keys, walks the queries; a lane owns one KEY):
+//                P = exp2(S - lse), dV^T += dO^T P, dP = dO V^T, dS = P o (dP - D), dK^T += Q^T dS
+// Every product is on v_mfma_f32_32x32x2_f32; the probabilities / score gradients always come out of one product in exactly
+// the B-operand layout of the next.
+struct AttnBwdParams {
+  const float* qkv;    // [B][N][3*C]
+  const float* mask;   // [N][N] additive, symmetric, or null
+  const float* out;    // [B][N][C] forward result
+  const float* dout;   // [B][N][C]
+  const float* lse;    // [B][heads][N] from the forward pass (base 2)
+  float* dsum;         // [B][heads][N] workspace: D = rowsum(dO o O), written by the dq kernel, read by the dk/dv kernel
+  float* dqkv;         // [B][N][3*C]
+  int B, N, C, heads;
+  float scale;
+};
+
+constexpr int RS = 40;          // LDS row stride of tiles that are read both by rows (b128) and by columns
+constexpr int kKeyOf(int e) { return (e & 3) + 8 * (e >> 2); }
+
+__global__ __launch_bounds__(AW * 64) void svtr_attention_dq_kernel(const AttnBwdParams p) {
+  __shared__ __attribute__((aligned(16))) float lds_k[2][32 * RS];
+  __shared__ __attribute__((aligned(16))) float lds_v[2][32 * KS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n31 = lane & 31, half = lane >> 5;
+  const int qchunks = (p.N + 32 * AW - 1) / (32 * AW);
+  const int qc = blockIdx.x % qchunks;
+  const int bh = blockIdx.x / qchunks;
+  const int h = bh % p.heads, b = bh / p.heads;
+  const long rs = 3L * p.C;
+  const float* qbase = p.qkv + (long)b * p.N * rs + h * HD;
+  const float* kbase = qbase + p.C;
+  const float* vbase = qbase + 2 * p.C;
+  const int q = (qc * AW + wave) * 32 + n31;
+  const bool qok = q < p.N;
+  const int qs = qok ? q : 0;
+
+  float qreg[16], doreg[16];
+  float dsum_q;
+  {
+    const float* qr = qbase + (long)qs * rs + 16 * half;
+    const float* dr = p.dout + ((long)b * p.N + qs) * p.C + h * HD + 16 * half;
+    const float* orow = p.out + ((long)b * p.N + qs) * p.C + h * HD + 16 * half;
+    const float sc = p.scale * LOG2E;
+    float part = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(qr + 4 * j);
+      const f32x4 g = *reinterpret_cast<const f32x4*>(dr + 4 * j);
+      const f32x4 o = *reinterpret_cast<const f32x4*>(orow + 4 * j);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        qreg[4 * j + i] = v[i] * sc;
+        doreg[4 * j + i] = g[i];
+        part = fmaf(g[i], o[i], part);
+      }
+    }
+    dsum_q = part + __shfl_xor(part, 32);
+    if (qok && half == 0) p.dsum[(long)bh * p.N + q] = dsum_q;
+  }
+  const float lse_q = p.lse[(long)bh * p.N + qs];
+
+  const int lr = tid >> 3, lc = tid & 7;
+  f32x4 knext, vnext;
+  auto fetch = [&](int k0) {
+    const int key = k0 + lr;
+    if (key < p.N) {
+      knext = *reinterpret_cast<const f32x4*>(kbase + (long)key * rs + 4 * lc);
+      vnext = *reinterpret_cast<const f32x4*>(vbase + (long)key * rs + 4 * lc);
+    } else {
+      knext = f32x4{0.f, 0.f, 0.f, 0.f};
+      vnext = knext;
+    }
+  };
+  auto stash = [&](int stage) {
+    *reinterpret_cast<f32x4*>(&lds_k[stage][lr * RS + 4 * lc]) = knext;
+    *reinterpret_cast<f32x4*>(&lds_v[stage][lr * KS + 4 * lc]) = vnext;
+  };
+  fetch(0);
+  stash(0);
+  __syncthreads();
+
+  f32x16 dq;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) dq[e] = 0.f;
+  const float* mcol = p.mask ? p.mask + qs + 4L * half * p.N : nullptr;
+
+  const int ntiles = (p.N + 31) / 32;
+  for (int it = 0; it < ntiles; ++it) {
+    const int k0 = it * 32, cur = it & 1;
+    const bool more = it + 1 < ntiles;
+    if (more) fetch(k0 + 32);
+    float mreg[16];
+    if (mcol) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mreg[e] = (k0 + kKeyOf(e) + 4 * half) < p.N ? mcol[(long)(k0 + kKeyOf(e)) * p.N] : 0.f;
+    }
+    f32x16 s, dp;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = dp[e] = 0.f;
+    {
+      const float* kr = &lds_k[cur][n31 * RS + 16 * half];
+      const float* vr = &lds_v[cur][n31 * KS + 16 * half];
+      f32x4 kf[4], vf[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        kf[j] = *reinterpret_cast<const f32x4*>(kr + 4 * j);
+        vf[j] = *reinterpret_cast<const f32x4*>(vr + 4 * j);
+      }
+#pragma unroll
+      for (int t = 0; t < 16; ++t) s = mfma2(kf[t >> 2][t & 3], qreg[t], s);        // S^T = K Q^T
+#pragma unroll
+      for (int t = 0; t < 16; ++t) dp = mfma2(vf[t >> 2][t & 3], doreg[t], dp);     // dP^T = V dO^T
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      float v = s[e];
+      if (mcol) v = fmaf(mreg[e], LOG2E, v);
+      if (k0 + kKeyOf(e) + 4 * half >= p.N) v = -INFINITY;
+      const float pe = __builtin_amdgcn_exp2f(v - lse_q);
+      s[e] = pe * (dp[e] - dsum_q);                                                  // dS^T
+    }
+    {
+      const float* kc = &lds_k[cur][4 * half * RS + n31];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) dq = mfma2(kc[kKeyOf(e) * RS], s[e], dq);         // dQ^T += K^T dS^T
+    }
+    if (more) stash(cur ^ 1);
+    __syncthreads();
+  }
+  if (qok) {
+    float* drow = p.dqkv + ((long)b * p.N + q) * rs + h * HD;
+#pragma unroll
+    for (int e = 0; e < 16; e += 4) {
+      const f32x4 v = {dq[e] * p.scale, dq[e + 1] * p.scale, dq[e + 2] * p.scale, dq[e + 3] * p.scale};
+      *reinterpret_cast<f32x4*>(drow + 8 * (e >> 2) + 4 * half) = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(AW * 64) void svtr_attention_dkv_kernel(const AttnBwdParams p) {
+  __shared__ __attribute__((aligned(16))) float lds_q[2][32 * RS];
+  __shared__ __attribute__((aligned(16))) float lds_g[2][32 * RS];      // dO tile
+  __shared__ float lds_l[2][32], lds_d[2][32];                          // lse, D of the tile's queries
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n31 = lane & 31, half = lane >> 5;
+  const int kchunks = (p.N + 32 * AW - 1) / (32 * AW);
+  const int kc = blockIdx.x % kchunks;
+  const int bh = blockIdx.x / kchunks;
+  const int h = bh % p.heads, b = bh / p.heads;
+  const long rs = 3L * p.C;
+  const float* qbase = p.qkv + (long)b * p.N * rs + h * HD;
+  const float* gbase = p.dout + (long)b * p.N * p.C + h * HD;
+  const int key = (kc * AW + wave) * 32 + n31;
+  const bool kok = key < p.N;
+  const int ks = kok ? key : 0;
+
+  float kreg[16], vreg[16];
+  {
+    const float* kr = qbase + p.C + (long)ks * rs + 16 * half;
+    const float* vr = qbase + 2 * p.C + (long)ks * rs + 16 * half;
+    const float sc = p.scale * LOG2E;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(kr + 4 * j);
+      const f32x4 c = *reinterpret_cast<const f32x4*>(vr + 4 * j);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        kreg[4 * j + i] = a[i] * sc;
+        vreg[4 * j + i] = c[i];
+      }
+    }
+  }
+
+  const int lr = tid >> 3, lc = tid & 7;
+  f32x4 qnext, gnext;
+  float lnext = 0.f, dnext = 0.f;
+  auto fetch = [&](int q0) {
+    const int qq = q0 + lr;
+    if (qq < p.N) {
+      qnext = *reinterpret_cast<const f32x4*>(qbase + (long)qq * rs + 4 * lc);
+      gnext = *reinterpret_cast<const f32x4*>(gbase + (long)qq * p.C + 4 * lc);
+    } else {
+      qnext = f32x4{0.f, 0.f, 0.f, 0.f};
+      gnext = qnext;
+    }
+    if (tid < 32) {
+      const bool ok = q0 + tid < p.N;
+      lnext = ok ? p.lse[(long)bh * p.N + q0 + tid] : INFINITY;      // queries past N: probability 0
+      dnext = ok ? p.dsum[(long)bh * p.N + q0 + tid] : 0.f;
+    }
+  };
+  auto stash = [&](int stage) {
+    *reinterpret_cast<f32x4*>(&lds_q[stage][lr * RS + 4 * lc]) = qnext;
+    *reinterpret_cast<f32x4*>(&lds_g[stage][lr * RS + 4 * lc]) = gnext;
+    if (tid < 32) { lds_l[stage][tid] = lnext; lds_d[stage][tid] = dnext; }
+  };
+  fetch(0);
+  stash(0);
+  __syncthreads();
+
+  f32x16 dk, dv;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) dk[e] = dv[e] = 0.f;
+  const float* mrow = p.mask ? p.mask + ks : nullptr;
+
+  const int ntiles = (p.N + 31) / 32;
+  for (int it = 0; it < ntiles; ++it) {
+    const int q0 = it * 32, cur = it & 1;
+    const bool more = it + 1 < ntiles;
+    if (more) fetch(q0 + 32);
+    float mreg[16];
+    if (mrow) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int qq = q0 + kKeyOf(e) + 4 * half;
+        mreg[e] = qq < p.N ? mrow[(long)qq * p.N] : 0.f;
+      }
+    }
+    f32x16 s, dp;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = dp[e] = 0.f;
+    {
+      const float* qr = &lds_q[cur][n31 * RS + 16 * half];
+      const float* gr = &lds_g[cur][n31 * RS + 16 * half];
+      f32x4 qf[4], gf[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        qf[j] = *reinterpret_cast<const f32x4*>(qr + 4 * j);
+        gf[j] = *reinterpret_cast<const f32x4*>(gr + 4 * j);
+      }
+#pragma unroll
+      for (int t = 0; t < 16; ++t) s = mfma2(qf[t >> 2][t & 3], kreg[t], s);         // S = Q K^T   (rows = queries, lane = key)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) dp = mfma2(gf[t >> 2][t & 3], vreg[t], dp);       // dP = dO V^T
+    }
+    {
+      const float* lq = &lds_l[cur][4 * half];
+      const float* dq_ = &lds_d[cur][4 * half];
+      const float* gc = &lds_g[cur][4 * half * RS + n31];
+      const float* qc = &lds_q[cur][4 * half * RS + n31];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float v = s[e];
+        if (mrow) v = fmaf(mreg[e], LOG2E, v);
+        const float pe = __builtin_amdgcn_exp2f(v - lq[kKeyOf(e)]);
+        dv = mfma2(gc[kKeyOf(e) * RS], pe, dv);                                      // dV^T += dO^T P
+        s[e] = pe * (dp[e] - dq_[kKeyOf(e)]);                                        // dS
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) dk = mfma2(qc[kKeyOf(e) * RS], s[e], dk);         // dK^T += Q^T dS
+    }
+    if (more) stash(cur ^ 1);
+    __syncthreads();
+  }
+  if (kok) {
+    float* krow = p.dqkv + ((long)b * p.N + key) * rs + p.C + h * HD;
+    float* vrow = krow + p.C;
+#pragma unroll
+    for (int e = 0; e < 16; e += 4) {
+      const f32x4 a = {dk[e] * p.scale, dk[e + 1] * p.scale, dk[e + 2] * p.scale, dk[e + 3] * p.scale};
+      const f32x4 c = {dv[e], dv[e + 1], dv[e + 2], dv[e + 3]};
+      *reinterpret_cast<f32x4*>(krow + 8 * (e >> 2) + 4 * half) = a;
+      *reinterpret_cast<f32x4*>(vrow + 8 * (e >> 2) + 4 * half) = c;
+    }
+  }
+}
+
 }  // namespace
 
 // out[b][n][h*32 + :] = softmax_m(scale * q[b][n][h] . k[b][m][h] + mask[n][m]) @ v[b][m][h]  for every head h;
 // qkv [B][N][3*C] (q | k | v, C = heads * 32), mask [N][N] additive and SYMMETRIC or NULL, out [B][N][C] fp32 and / or
 // out_hl32 (HL32 operand of the proj Linear).
 // Replaces the q k^T / softmax / attn v chain of modules/svtr.py:140-149 without materialising [B][heads][N][N].
-MRN_EXPORT int mrn_svtr_attention_f32(const float* qkv, const float* mask, float* out, void* out_hl32, int B, int N, int C,
-                                      int heads, float scale, void* stream) {
+MRN_EXPORT int mrn_svtr_attention_f32(const float* qkv, const float* mask, float* out, void* out_hl32, float* lse, int B, int N,
+                                      int C, int heads, float scale, void* stream) {
   MRN_CHECK_ARG(qkv && (out || out_hl32) && heads >= 1 && C == heads * HD, "mrn_svtr_attention_f32: head dimension must be %d (C=%d heads=%d)", HD, C, heads);
   MRN_CHECK_ARG(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)out % 16 == 0), "mrn_svtr_attention_f32: operands must be 16-byte aligned");
   if (B == 0 || N == 0) return MRN_OK;
   AttnParams p;
-  p.qkv = qkv; p.mask = mask; p.out = out; p.out_hl = (unsigned char*)out_hl32; p.B = B; p.N = N; p.C = C; p.heads = heads; p.scale = scale;
+  p.qkv = qkv; p.mask = mask; p.out = out; p.out_hl = (unsigned char*)out_hl32; p.lse = lse; p.B = B; p.N = N; p.C = C; p.heads = heads; p.scale = scale;
   const long groups = (long)B * heads * ((N + 32 * AW - 1) / (32 * AW));
   hipLaunchKernelGGL(svtr_attention_kernel, dim3((unsigned)groups), dim3(AW * 64), 0, (hipStream_t)stream, p);
   MRN_LAUNCH_CHECK("svtr_attention");
+  return MRN_OK;
+}
+
+// Backward of mrn_svtr_attention_f32 for an expert being trained: dqkv [B][N][3*C] from dout, the forward result `out` and the
+// forward pass's log-sum-exp `lse` [B][heads][N]; dsum: [B][heads][N] floats of workspace.  No N x N tensor is stored or read.
+MRN_EXPORT int mrn_svtr_attention_bwd_f32(const float* qkv, const float* mask, const float* out, const float* dout,
+                                          const float* lse, float* dsum, float* dqkv, int B, int N, int C, int heads,
+                                          float scale, void* stream) {
+  MRN_CHECK_ARG(qkv && out && dout && lse && dsum && dqkv && heads >= 1 && C == heads * HD,
+                "mrn_svtr_attention_bwd_f32: bad operands (C=%d heads=%d)", C, heads);
+  MRN_CHECK_ARG(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)dout % 16 == 0) && ((uintptr_t)dqkv % 16 == 0),
+                "mrn_svtr_attention_bwd_f32: operands must be 16-byte aligned");
+  if (B == 0 || N == 0) return MRN_OK;
+  AttnBwdParams p;
+  p.qkv = qkv; p.mask = mask; p.out = out; p.dout = dout; p.lse = lse; p.dsum = dsum; p.dqkv = dqkv;
+  p.B = B; p.N = N; p.C = C; p.heads = heads; p.scale = scale;
+  const long groups = (long)B * heads * ((N + 32 * AW - 1) / (32 * AW));
+  hipLaunchKernelGGL(svtr_attention_dq_kernel, dim3((unsigned)groups), dim3(AW * 64), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(svtr_attention_dkv_kernel, dim3((unsigned)groups), dim3(AW * 64), 0, (hipStream_t)stream, p);
+  MRN_LAUNCH_CHECK("svtr_attention_bwd");
   return MRN_OK;
 }

@@ -650,8 +650,9 @@ class ResidualScaleFn(torch.autograd.Function):
 
 
 class SvtrAttentionFn(torch.autograd.Function):
-    """softmax(scale q k^T + mask) v for every head (svtr.py:140-149) with the probabilities kept for the backward pass:
-    per-head batched exact-fp32 GEMMs on strided views of qkv [B,N,3C] (no head split / merge copies)."""
+    """softmax(scale q k^T + mask) v for every head (svtr.py:140-149).  Head dimension 32: the fused attention kernel forward
+    (keeping the log-sum-exp) and the two recomputing backward kernels of csrc/attention.hip.  Otherwise (or with
+    MRN_SVTR_ATTENTION=gemm) per-head batched exact-fp32 GEMMs on strided views of qkv [B,N,3C] with the probabilities kept."""
 
     @staticmethod
     def forward(ctx, qkv, mask, heads, scale):
@@ -659,6 +660,12 @@ class SvtrAttentionFn(torch.autograd.Function):
         B, N, C3 = qkv.shape
         C, h = C3 // 3, heads
         d = C // h
+        ctx.fused = d == 32 and ops.SVTR_FUSED_ATTENTION
+        if ctx.fused:      # flash-style: the fused forward kernel keeps only the log-sum-exp, backward recomputes the tiles
+            out, lse = ops.svtr_attention(qkv, h, scale, mask, want_lse=True)
+            ctx.save_for_backward(qkv, out, lse, mask)
+            ctx.cfg = (h, scale)
+            return out
         attn = torch.empty(B, h, N, N, device=qkv.device, dtype=torch.float32)
         out = torch.empty(B, N, C, device=qkv.device, dtype=torch.float32)
         sq, sp = (N * C3, C3, 1), (h * N * N, N, 1)
@@ -675,9 +682,12 @@ class SvtrAttentionFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        qkv, attn = ctx.saved_tensors
         h, scale = ctx.cfg
         dout = dout.contiguous()
+        if ctx.fused:
+            qkv, out, lse, mask = ctx.saved_tensors
+            return ops.svtr_attention_bwd(qkv, mask, out, dout, lse, h, scale), None, None, None
+        qkv, attn = ctx.saved_tensors
         B, N, C3 = qkv.shape
         C = C3 // 3
         d = C // h

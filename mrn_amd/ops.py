@@ -1092,17 +1092,33 @@ def softmax_rows_bwd_(p, dp):
     return dp
 
 
-def svtr_attention(qkv, heads, scale, mask=None, want_f32=True, want_hl=False):
+def svtr_attention(qkv, heads, scale, mask=None, want_f32=True, want_hl=False, want_lse=False):
     """qkv [B,N,3C] (q | k | v, head dim 32), mask [N,N] additive symmetric or None -> [B,N,C]: fused q k^T / softmax / attn v.
-    want_hl: also (or only) the HL32 operand of the proj Linear; returns the fp32 tensor, the HL32 bytes, or (fp32, hl)"""
+    want_hl: also (or only) the HL32 operand of the proj Linear; returns the fp32 tensor, the HL32 bytes, or (fp32, hl).
+    want_lse: returns (fp32, lse [B,heads,N]) -- what svtr_attention_bwd needs"""
     _chk(qkv, mask)
     B, N, C3 = qkv.shape
     C = C3 // 3
     assert qkv.is_contiguous() and C == heads * 32 and (mask is None or (mask.is_contiguous() and tuple(mask.shape) == (N, N)))
     out = torch.empty(B, N, C, device=qkv.device, dtype=torch.float32) if want_f32 else None
     hl = torch.empty(B * N * C * 4, device=qkv.device, dtype=torch.uint8) if want_hl else None
-    call("mrn_svtr_attention_f32", _p(qkv), _p(mask), _p(out), _p(hl), B, N, C, heads, float(scale), _stream())
+    lse = torch.empty(B, heads, N, device=qkv.device, dtype=torch.float32) if want_lse else None
+    call("mrn_svtr_attention_f32", _p(qkv), _p(mask), _p(out), _p(hl), _p(lse), B, N, C, heads, float(scale), _stream())
+    if want_lse:
+        return out, lse
     return (out, hl) if (want_f32 and want_hl) else (hl if want_hl else out)
+
+
+def svtr_attention_bwd(qkv, mask, out, dout, lse, heads, scale):
+    """-> dqkv [B,N,3C]; recomputes the probabilities from lse (nothing of size N x N is stored)"""
+    _chk(qkv, mask, out, dout, lse)
+    B, N, C3 = qkv.shape
+    assert qkv.is_contiguous() and out.is_contiguous() and dout.is_contiguous() and lse.is_contiguous()
+    dqkv = torch.empty_like(qkv)
+    dsum = torch.empty_like(lse)
+    call("mrn_svtr_attention_bwd_f32", _p(qkv), _p(mask), _p(out), _p(dout), _p(lse), _p(dsum), _p(dqkv), B, N, C3 // 3, heads,
+         float(scale), _stream())
+    return dqkv
 
 
 def add_layernorm_grouped(x, branch=None, drop=None, rows_per_drop=1, gamma=None, beta=None, rows_per_group=None, eps=1e-6,

@@ -620,3 +620,27 @@ def test_x3_linear_hl32_result(ops, G, rows, K, N, act):
     y, _ = ops.conv2d_x3(x_hl, G, False, rows, 1, 1, K, w_hl, sw, N, (1, 1), bias=b, act=act)
     hl, _ = ops.conv2d_x3(x_hl, G, False, rows, 1, 1, K, w_hl, sw, N, (1, 1), bias=b, act=act, hl_only=True)
     assert torch.equal(hl, ops.split_hl32(y))
+
+
+@pytest.mark.parametrize("B,N,heads,H", [(3, 512, 2, 8), (2, 256, 4, 4), (3, 128, 8, 2), (2, 100, 2, 0), (2, 64, 8, 0)])
+def test_svtr_attention_backward(ops, B, N, heads, H):
+    """SvtrAttentionFn (fused forward keeping the log-sum-exp + the two recomputing backward kernels) against torch autograd
+    of softmax(scale q k^T + mask) v, with the SVTR local mask (H > 0) and without, ragged N included"""
+    from mrn_amd import functional as Fn
+    from mrn_amd.modules.svtr import local_attention_mask
+    C = heads * 32
+    qkv = rnd(B, N, 3 * C, seed=300, scale=1.2).requires_grad_(True)
+    mask = local_attention_mask(H, 64, 7, 11) if H else None
+    g = rnd(B, N, C, seed=301)
+    q, k, v = [t.reshape(B, N, heads, 32).permute(0, 2, 1, 3) for t in qkv.split(C, dim=2)]
+    s = (q @ k.transpose(-1, -2)) * 32 ** -0.5
+    if mask is not None:
+        s = s + mask
+    ref = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B, N, C)
+    ref.backward(g)
+    qc = cu(qkv.detach()).requires_grad_(True)
+    out = Fn.SvtrAttentionFn.apply(qc, cu(mask) if mask is not None else None, heads, 32 ** -0.5)
+    out.backward(cu(g))
+    assert_close("attention", out, ref, atol=2e-6, rtol=1e-5)
+    for i, nm in enumerate(("dq", "dk", "dv")):
+        assert_close(nm, qc.grad[:, :, i * C:(i + 1) * C], qkv.grad[:, :, i * C:(i + 1) * C], atol=5e-6, rtol=1e-4)
