@@ -19,16 +19,17 @@ def x3_eligible(x2, N, K):
             and x2.shape[0] * max(N, K) * 4 < 2 ** 31)
 
 
-def x3_linear(x2, weight, bias=None, residual=None, act=ops.ACT_NONE):
+def x3_linear(x2, weight, bias=None, residual=None, act=ops.ACT_NONE, sx=None, sw=None, want_sw=False):
     """y = act(x2 @ weight^T + bias (+ residual)) on the split-fp16 x3 MFMA path, both operands prescaled on the device
     (x2 [R,K] contiguous, weight [N,K]); 22-bit products, fp32 accumulation."""
     R, K = x2.shape
     N = weight.shape[0]
-    sx = ops.pow2_scale(x2)
-    w_hl, sw = ops.pack_weights_hl32([weight.detach().contiguous().view(N, 1, 1, K)])
+    if sx is None:
+        sx = ops.pow2_scale(x2)
+    w_hl, sw = ops.pack_weights_hl32([weight.detach().contiguous().view(N, 1, 1, K)], scale=sw)
     y, _ = ops.conv2d_x3(ops.split_hl32(x2, sx), 1, False, R, 1, 1, K, w_hl, sw, N, (1, 1), bias=bias, act=act,
                          residual=residual, x_scale=sx)
-    return y.view(R, N)
+    return (y.view(R, N), sw) if want_sw else y.view(R, N)
 
 
 def frozen_linear(x, weight, bias=None, act=ops.ACT_NONE, residual=None):
@@ -58,13 +59,13 @@ def linear_fwd(x2, weight, bias=None, residual=None, act=ops.ACT_NONE):
     return ops.linear(x2, weight, bias, act=act, residual=residual)
 
 
-def linear_dgrad(dy, weight, out=None, accumulate=False):
-    """dx = dy @ weight ; dy rows [R, N], weight [N, K] -> [R, K]"""
+def linear_dgrad(dy, weight, out=None, accumulate=False, sd=None, sw=None):
+    """dx = dy @ weight ; dy rows [R, N], weight [N, K] -> [R, K]; sd / sw: pow2 scales of dy / weight when already known"""
     dy2 = ops.rows2d(dy)
     R, N = dy2.shape
     K = weight.shape[1]
     if out is None and x3_eligible(dy2, K, N):
-        return x3_linear(dy2, weight.detach().t().contiguous())
+        return x3_linear(dy2, weight.detach().t().contiguous(), sx=sd, sw=sw)
     if out is None:
         out = torch.empty(R, K, device=dy.device, dtype=torch.float32)
         accumulate = False
@@ -83,7 +84,7 @@ def _pick_split(R, tiles, target=1024, min_rows=128):
     return 1
 
 
-def x3_wgrad(dy2, x2):
+def x3_wgrad(dy2, x2, sd=None, sx=None):
     """dW = dy2^T @ x2 on the split-fp16 x3 path: both operands transposed-split (reduction axis = rows) with device
     prescales; split-K chunks are the grouped conv's groups, partial slabs reduced by a column-sum pass."""
     R, N = dy2.shape
@@ -93,7 +94,8 @@ def x3_wgrad(dy2, x2):
     want = max(1, min(512 // tiles, blocks // 8))
     S = next(s for s in range(want, 0, -1) if blocks % s == 0)
     rps = R // S
-    sd, sx = ops.pow2_scale(dy2), ops.pow2_scale(x2)
+    sd = ops.pow2_scale(dy2) if sd is None else sd
+    sx = ops.pow2_scale(x2) if sx is None else sx
     a_hl = ops.split_hl32_t(dy2, S, sd)                      # [S][N][rps/32][128]: "activation" rows = n
     w_hl = ops.split_hl32_t(x2, S, sx)                       # [S][K][rps/32][128]: "weight" rows = k
     part, _ = ops.conv2d_x3(a_hl, S, False, N, 1, 1, rps, w_hl, sx.view(1, 2).expand(S, 2).contiguous(), K, (1, 1), x_scale=sd)
@@ -101,14 +103,14 @@ def x3_wgrad(dy2, x2):
     return (ops.colsum(part) if S > 1 else part[0]).view(N, K)
 
 
-def linear_wgrad(dy, x):
+def linear_wgrad(dy, x, sd=None, sx=None):
     """dW[n][k] = sum_r dy[r][n] * x[r][k] with split-K over r (partials reduced by a column-sum pass)."""
     dy2, x2 = ops.rows2d(dy), ops.rows2d(x)
     R, N = dy2.shape
     K = x2.shape[1]
     if (ops.ROUTER_GEMM_PRECISION == "fp16x3" and ops.ROUTER_WGRAD_X3 and R % 32 == 0 and R >= 4096 and K >= 64 and N >= 64 and N % 4 == 0 and K % 4 == 0
             and dy2.is_contiguous() and x2.is_contiguous()):
-        return x3_wgrad(dy2, x2)
+        return x3_wgrad(dy2, x2, sd, sx)
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     S = _pick_split(R, tiles)
     Rc = R // S
@@ -570,17 +572,23 @@ class TrainLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         x = x.contiguous()
-        ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        K = x.shape[-1]
-        return linear_fwd(x.view(-1, K), weight, bias).view(*x.shape[:-1], weight.shape[0])
+        K, N = x.shape[-1], weight.shape[0]
+        x2 = x.view(-1, K)
+        # one max|x| pass serves the forward product and the weight gradient; one max|dy| pass both gradients
+        ctx.x3 = x3_eligible(x2, N, K)
+        sx = ops.pow2_scale(x2) if ctx.x3 else None
+        y, sw = x3_linear(x2, weight, bias, sx=sx, want_sw=True) if ctx.x3 else (ops.linear(x2, weight, bias), None)
+        ctx.save_for_backward(x, weight, sx, sw)          # (sw: max|W| is the same for W^T in the data gradient)
+        return y.view(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
+        x, weight, sx, sw = ctx.saved_tensors
         dy2 = dy.contiguous().view(-1, dy.shape[-1])
-        dx = linear_dgrad(dy2, weight).view(x.shape) if ctx.needs_input_grad[0] else None
-        dw = linear_wgrad(dy2, x.view(-1, x.shape[-1])) if ctx.needs_input_grad[1] else None
+        sd = ops.pow2_scale(dy2) if (ctx.x3 or x3_eligible(dy2, x.shape[-1], dy2.shape[1])) else None
+        dx = linear_dgrad(dy2, weight, sd=sd, sw=sw).view(x.shape) if ctx.needs_input_grad[0] else None
+        dw = linear_wgrad(dy2, x.view(-1, x.shape[-1]), sd, sx) if ctx.needs_input_grad[1] else None
         db = ops.colsum(dy2) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db
 

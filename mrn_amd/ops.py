@@ -389,18 +389,22 @@ def pow2_scale(x, target=FP16_WEIGHT_PEAK):
     return scale
 
 
-def pack_weights_hl32(ws):
-    """list of G [O,kh,kw,I] fp32 weights (same shape) -> (HL32 weight stack bytes [G][O][I/32][taps][128], scale [G,2])"""
+def pack_weights_hl32(ws, scale=None):
+    """list of G [O,kh,kw,I] fp32 weights (same shape) -> (HL32 weight stack bytes [G][O][I/32][taps][128], scale [G,2]).
+    scale: [G,2] power-of-two prescales already known for these tensors (e.g. of the same weights in another layout)"""
     O, kh, kw, I = ws[0].shape
     G = len(ws)
     dev = ws[0].device
     per = O * kh * kw * I * 4
     out = torch.empty(G * per, device=dev, dtype=torch.uint8)
-    scale = torch.empty(G, 2, device=dev, dtype=torch.float32)
+    known = scale is not None
+    if not known:
+        scale = torch.empty(G, 2, device=dev, dtype=torch.float32)
     for g, w in enumerate(ws):
         _chk(w)
         assert tuple(w.shape) == (O, kh, kw, I) and w.is_contiguous()
-        call("mrn_pow2_scale_f32", _p(w), w.numel(), FP16_WEIGHT_PEAK, scale[g].data_ptr(), _stream())
+        if not known:
+            call("mrn_pow2_scale_f32", _p(w), w.numel(), FP16_WEIGHT_PEAK, scale[g].data_ptr(), _stream())
         call("mrn_pack_weight_hl32", _p(w), out.data_ptr() + g * per, O, kh * kw, I, scale[g].data_ptr(), _stream())
     return out, scale
 
