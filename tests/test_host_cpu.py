@@ -169,6 +169,21 @@ def test_lockstep_grouping_policy():
         m.build_prediction(m.opt, 30) if m.fc is not None else None
     assert expert_group.HeadsGroup.supported(trba, True) and not expert_group.HeadsGroup.supported(trba, False)   # greedy Attn decode: per expert
     assert expert_group.HeadsGroup.supported(crnn, False)                          # CTC heads have no feedback loop
+    # SVTR experts (Trans None, Seq None, CTC): lock-step with the fused attention kernel, all in the same train / eval mode
+    with contextlib.redirect_stdout(io.StringIO()):
+        svtr = [Model(_opt("None", "SVTR", "None", "CTC")) for _ in range(2)]
+    sext = [m.model for m in svtr]
+    assert expert_group.supported(sext) and expert_group.HeadsGroup.supported(svtr, True) and expert_group.HeadsGroup.supported(svtr, False)
+    svtr[1].model.eval()                                                           # DropPath / BatchNorm mode differs
+    assert not expert_group.supported(sext)
+    svtr[1].model.train()
+    saved_attn = ops.SVTR_FUSED_ATTENTION
+    try:
+        ops.SVTR_FUSED_ATTENTION = False                                           # per-head GEMM attention: per-expert path
+        assert not expert_group.supported(sext)
+    finally:
+        ops.SVTR_FUSED_ATTENTION = saved_attn
+    assert not expert_group.supported([svtr[0].model, crnn[0].model])
     # tile selection of the grouped conv
     assert ops.x3_tile(512, 4608) == (256, 256) and ops.x3_tile(64, 288) == (256, 64)
     assert ops.x3_tile(128, 576) == (128, 128) and ops.x3_tile(128, 2304) == (256, 128)
