@@ -172,8 +172,210 @@ __global__ __launch_bounds__(AW * 64) void svtr_attention_kernel(const AttnParam
         f16v4 hi, lo;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          hi[j] = (_Float16)v[j];
-          lo[j] = (_Float16)(v[j] - (float)hi[j]);
+          _Float16 hh, ll;
+          split_f16(v[j], hh, ll);
+          hi[j] = hh;
+          lo[j] = ll;
+        }
+        unsigned char* line = p.out_hl + (row * p.heads + h) * 128 + d0 * 2;
+        *reinterpret_cast<f16v4*>(line) = hi;
+        *reinterpret_cast<f16v4*>(line + 64) = lo;
+      }
+    }
+  }
+}
+
+// ---- split-fp16 x3 variant for the frozen experts ----------------------------------------------------------------------------
+// Same schedule as svtr_attention_kernel, both products as hi/lo fp16 pairs on v_mfma_f32_32x32x16_f16 (lo*hi + hi*lo + hi*hi,
+// fp32 accumulate: 22-bit products like every other GEMM of the frozen experts) -- 12 MFMAs of 8 passes per key tile instead
+// of 32 of 16 passes, which leaves the softmax VALU work as the bound.  K tiles are staged as HL32 lines [hi 32 | lo 32] per
+// key, V tiles TRANSPOSED as one line per d with the keys in the order the score accumulator holds them (lane half h, register
+// e -> slot 16h + e), so P^T goes from the first product's accumulator into the second product's B operand by a register
+// pack.  The probabilities carry a 2^12 bias (exp2(s - m + 12), cancelled by the final 1 / l) to keep small ones out of
+// fp16's subnormal range.
+typedef _Float16 f16v8 __attribute__((ext_vector_type(8)));
+constexpr int XS = 144;         // LDS line stride in bytes (128-byte line + 16: conflict-free 16-byte fragment reads)
+constexpr float PBIAS = 12.f;
+constexpr float OPSCALE = 64.f;  // q, k, v are split as 64 * x: the lo halves of O(1) operands stay out of fp16's subnormal range
+
+__device__ __forceinline__ f32x16 mfma16h(f16v8 a, f16v8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ void split2(float v, _Float16& h, _Float16& l) {
+  split_f16(v, h, l);
+}
+
+__global__ __launch_bounds__(AW * 64) void svtr_attention_x3_kernel(const AttnParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds_k[2][32 * XS];     // [key][hi d 0..31 | lo d 0..31]
+  __shared__ __attribute__((aligned(16))) unsigned char lds_v[2][32 * XS];     // [d][hi slot 0..31 | lo slot 0..31]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n31 = lane & 31, half = lane >> 5;
+  const int qchunks = (p.N + 32 * AW - 1) / (32 * AW);
+  const int qc = blockIdx.x % qchunks;
+  const int bh = blockIdx.x / qchunks;
+  const int h = bh % p.heads, b = bh / p.heads;
+  const long rs = 3L * p.C;
+  const float* qbase = p.qkv + (long)b * p.N * rs + h * HD;
+  const float* kbase = qbase + p.C;
+  const float* vbase = qbase + 2 * p.C;
+  const int q = (qc * AW + wave) * 32 + n31;
+  const bool qok = q < p.N;
+
+  // B operand of S^T = K Q^T: MFMA m, lane (query n31, half), slot s holds d = 16m + 8*half + s of scale * log2e * q
+  f16v8 qh[2], ql[2];
+  {
+    const float* qr = qbase + (long)(qok ? q : 0) * rs;
+    const float sc = p.scale * LOG2E * OPSCALE;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(qr + 16 * m + 8 * half);
+      const f32x4 c = *reinterpret_cast<const f32x4*>(qr + 16 * m + 8 * half + 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        _Float16 hh, ll;
+        split2(a[i] * sc, hh, ll); qh[m][i] = hh; ql[m][i] = ll;
+        split2(c[i] * sc, hh, ll); qh[m][4 + i] = hh; ql[m][4 + i] = ll;
+      }
+    }
+  }
+
+  // tile loader: thread (key row tid>>3, d chunk 4*(tid&7) .. +3); V goes in transposed, key -> slot 16*((key>>2)&1) + (key&3) + 4*(key>>3)
+  const int lr = tid >> 3, lc = tid & 7;
+  const int vslot = 16 * ((lr >> 2) & 1) + (lr & 3) + 4 * (lr >> 3);
+  f32x4 knext, vnext;
+  auto fetch = [&](int k0) {
+    const int key = k0 + lr;
+    if (key < p.N) {
+      knext = *reinterpret_cast<const f32x4*>(kbase + (long)key * rs + 4 * lc);
+      vnext = *reinterpret_cast<const f32x4*>(vbase + (long)key * rs + 4 * lc);
+    } else {
+      knext = f32x4{0.f, 0.f, 0.f, 0.f};
+      vnext = knext;
+    }
+  };
+  auto stash = [&](int stage) {
+    f16v4 kh, kl;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      _Float16 hh, ll;
+      split2(knext[i] * OPSCALE, hh, ll); kh[i] = hh; kl[i] = ll;
+      split2(vnext[i] * OPSCALE, hh, ll);
+      unsigned char* vline = &lds_v[stage][(4 * lc + i) * XS + vslot * 2];
+      *reinterpret_cast<_Float16*>(vline) = hh;
+      *reinterpret_cast<_Float16*>(vline + 64) = ll;
+    }
+    *reinterpret_cast<f16v4*>(&lds_k[stage][lr * XS + lc * 8]) = kh;
+    *reinterpret_cast<f16v4*>(&lds_k[stage][lr * XS + 64 + lc * 8]) = kl;
+  };
+  fetch(0);
+  stash(0);
+  __syncthreads();
+
+  f32x16 o;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) o[e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float* mcol = p.mask ? p.mask + (qok ? q : 0) + 4L * half * p.N : nullptr;
+
+  const int ntiles = (p.N + 31) / 32;
+  for (int it = 0; it < ntiles; ++it) {
+    const int k0 = it * 32, cur = it & 1;
+    const bool more = it + 1 < ntiles;
+    if (more) fetch(k0 + 32);
+    float mreg[16];
+    if (mcol) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mreg[e] = (k0 + (e & 3) + 8 * (e >> 2) + 4 * half) < p.N ? mcol[(long)(k0 + (e & 3) + 8 * (e >> 2)) * p.N] : 0.f;
+    }
+    f32x16 s;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = 0.f;
+    {
+      const unsigned char* kl_ = &lds_k[cur][n31 * XS + 16 * half];
+      f16v8 kh[2], kl[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        kh[m] = *reinterpret_cast<const f16v8*>(kl_ + 32 * m);
+        kl[m] = *reinterpret_cast<const f16v8*>(kl_ + 64 + 32 * m);
+      }
+#pragma unroll
+      for (int m = 0; m < 2; ++m) s = mfma16h(kl[m], qh[m], s);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) s = mfma16h(kh[m], ql[m], s);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) s = mfma16h(kh[m], qh[m], s);
+    }
+    if (mcol) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[e] = fmaf(s[e], 1.f / (OPSCALE * OPSCALE), mreg[e] * LOG2E);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[e] *= 1.f / (OPSCALE * OPSCALE);
+    }
+    if (k0 + 32 > p.N) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        if (k0 + (e & 3) + 8 * (e >> 2) + 4 * half >= p.N) s[e] = -INFINITY;
+    }
+    float mx = s[0];
+#pragma unroll
+    for (int e = 1; e < 16; ++e) mx = fmaxf(mx, s[e]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+    const float corr = __builtin_amdgcn_exp2f(m_run - m_safe);
+    const float mb = m_safe - PBIAS;
+    float psum = 0.f;
+    f16v8 ph[2], pl[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float pe = __builtin_amdgcn_exp2f(s[e] - mb);
+      psum += pe;
+      _Float16 hh, ll;
+      split2(pe, hh, ll);
+      ph[e >> 3][e & 7] = hh;
+      pl[e >> 3][e & 7] = ll;
+    }
+    psum += __shfl_xor(psum, 32);
+    l_run = l_run * corr + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[e] *= corr;
+    {
+      const unsigned char* vl_ = &lds_v[cur][n31 * XS + 32 * half];
+      f16v8 vh[2], vl[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        vh[m] = *reinterpret_cast<const f16v8*>(vl_ + 16 * m);
+        vl[m] = *reinterpret_cast<const f16v8*>(vl_ + 64 + 16 * m);
+      }
+#pragma unroll
+      for (int m = 0; m < 2; ++m) o = mfma16h(vl[m], ph[m], o);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) o = mfma16h(vh[m], pl[m], o);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) o = mfma16h(vh[m], ph[m], o);
+    }
+    if (more) stash(cur ^ 1);
+    __syncthreads();
+  }
+
+  if (qok) {
+    const float inv = 1.f / (l_run * OPSCALE);
+    const long row = (long)b * p.N + q;
+#pragma unroll
+    for (int e = 0; e < 16; e += 4) {
+      const f32x4 v = {o[e] * inv, o[e + 1] * inv, o[e + 2] * inv, o[e + 3] * inv};
+      const int d0 = 8 * (e >> 2) + 4 * half;
+      if (p.out) *reinterpret_cast<f32x4*>(p.out + row * p.C + h * HD + d0) = v;
+      if (p.out_hl) {
+        f16v4 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          _Float16 hh, ll;
+          split_f16(v[j], hh, ll);
+          hi[j] = hh;
+          lo[j] = ll;
         }
         unsigned char* line = p.out_hl + (row * p.heads + h) * 128 + d0 * 2;
         *reinterpret_cast<f16v4*>(line) = hi;
@@ -461,15 +663,18 @@ __global__ __launch_bounds__(AW * 64) void svtr_attention_dkv_kernel(const AttnB
 // qkv [B][N][3*C] (q | k | v, C = heads * 32), mask [N][N] additive and SYMMETRIC or NULL, out [B][N][C] fp32 and / or
 // out_hl32 (HL32 operand of the proj Linear).
 // Replaces the q k^T / softmax / attn v chain of modules/svtr.py:140-149 without materialising [B][heads][N][N].
+// x3 != 0: both products as split-fp16 x3 (frozen experts; lse must be NULL), else exact fp32 products.
 MRN_EXPORT int mrn_svtr_attention_f32(const float* qkv, const float* mask, float* out, void* out_hl32, float* lse, int B, int N,
-                                      int C, int heads, float scale, void* stream) {
+                                      int C, int heads, float scale, int x3, void* stream) {
+  MRN_CHECK_ARG(!(x3 && lse), "mrn_svtr_attention_f32: the x3 variant keeps no log-sum-exp (training uses the fp32 kernel)");
   MRN_CHECK_ARG(qkv && (out || out_hl32) && heads >= 1 && C == heads * HD, "mrn_svtr_attention_f32: head dimension must be %d (C=%d heads=%d)", HD, C, heads);
   MRN_CHECK_ARG(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)out % 16 == 0), "mrn_svtr_attention_f32: operands must be 16-byte aligned");
   if (B == 0 || N == 0) return MRN_OK;
   AttnParams p;
   p.qkv = qkv; p.mask = mask; p.out = out; p.out_hl = (unsigned char*)out_hl32; p.lse = lse; p.B = B; p.N = N; p.C = C; p.heads = heads; p.scale = scale;
   const long groups = (long)B * heads * ((N + 32 * AW - 1) / (32 * AW));
-  hipLaunchKernelGGL(svtr_attention_kernel, dim3((unsigned)groups), dim3(AW * 64), 0, (hipStream_t)stream, p);
+  if (x3) hipLaunchKernelGGL(svtr_attention_x3_kernel, dim3((unsigned)groups), dim3(AW * 64), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(svtr_attention_kernel, dim3((unsigned)groups), dim3(AW * 64), 0, (hipStream_t)stream, p);
   MRN_LAUNCH_CHECK("svtr_attention");
   return MRN_OK;
 }

@@ -52,6 +52,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + idx;
 }
 
+// x = hi + lo as two fp16 (22 significand bits).  The operand is pinned in a register first: under -ffp-contract=fast the
+// compiler may otherwise fold the multiply / fma that PRODUCED x into the conversion (v_fma_mixlo_f16: one rounding from the
+// exact product) for one use of hi and convert the fp32-rounded value (two roundings) for another -- the two differ by one
+// fp16 ulp when the fp32 value sits on an fp16 tie, and the pair then misses x by 2^-11 (seen on 2 of 65536 elements).
+__device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
+  asm volatile("" : "+v"(x));
+  hi = (_Float16)x;
+  lo = (_Float16)(x - (float)hi);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -316,7 +316,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
           else if (p.act == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));     // GELU (erf), SVTR Mlp
           if (!HL_OUT || p.y) yg[pix * p.y_ld + n] = v;
           if (HL_OUT && p.y_hl) {       // operand of the next GEMM: 32 lanes fill the hi half and the lo half of one 128-byte line
-            const _Float16 h = (_Float16)v, l = (_Float16)(v - (float)h);
+            _Float16 h, l;
+            split_f16(v, h, l);
             unsigned char* line = p.y_hl + ((long)g * p.y_gstride + pix * p.y_ld + (n & ~31)) * 4 + (n & 31) * 2;
             *reinterpret_cast<_Float16*>(line) = h;
             *reinterpret_cast<_Float16*>(line + 64) = l;
@@ -368,8 +369,7 @@ template __global__ void conv_x3_kernel<4, 4, 2, 2, true>(const ConvX3Params);
 
 // ---- producers of the HL32 layout -------------------------------------------------------------------------------
 __device__ __forceinline__ void split_h(float v, _Float16& h, _Float16& l) {
-  h = (_Float16)v;
-  l = (_Float16)(v - (float)h);
+  split_f16(v, h, l);
 }
 
 // fp32 [rows][C] -> HL32 [rows][C/32][hi 32 | lo 32]; one thread = 8 channels (32 B in, 2 x 16 B out)

@@ -32,10 +32,11 @@ __device__ __forceinline__ void store_hl(unsigned char* out, long row, int C, in
   f16v8 h, l;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    h[e] = (_Float16)v.a[e];
-    l[e] = (_Float16)(v.a[e] - (float)h[e]);
-    h[4 + e] = (_Float16)v.b[e];
-    l[4 + e] = (_Float16)(v.b[e] - (float)h[4 + e]);
+    _Float16 hh, ll;
+    split_f16(v.a[e], hh, ll);
+    h[e] = hh; l[e] = ll;
+    split_f16(v.b[e], hh, ll);
+    h[4 + e] = hh; l[4 + e] = ll;
   }
   unsigned char* o = out + (row * (C >> 5) + (c8 >> 2)) * 128 + (c8 & 3) * 16;
   *reinterpret_cast<f16v8*>(o) = h;
@@ -265,8 +266,9 @@ __global__ __launch_bounds__(256) void add_layernorm_grouped_kernel(const float*
         f16v4 h, l;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          h[j] = (_Float16)v[i][j];
-          l[j] = (_Float16)(v[i][j] - (float)h[j]);
+          _Float16 hh, ll;
+          split_f16(v[i][j], hh, ll);
+          h[j] = hh; l[j] = ll;
         }
         unsigned char* o = y_hl + (row * (C >> 5) + (c4 >> 3)) * 128 + (c4 & 7) * 8;
         *reinterpret_cast<f16v4*>(o) = h;

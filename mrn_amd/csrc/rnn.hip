@@ -203,9 +203,10 @@ __device__ __forceinline__ void mma_rows_h(f32x4 (&acc)[NG], const _Float16* __r
 }
 
 __device__ __forceinline__ void store_h_split(_Float16* hi, _Float16* lo, int idx, float v) {
-  const _Float16 h = (_Float16)v;
+  _Float16 h, l;
+  split_f16(v, h, l);
   hi[idx] = h;
-  lo[idx] = (_Float16)(v - (float)h);
+  lo[idx] = l;
 }
 
 struct LstmX3Params {

@@ -278,7 +278,8 @@ class BackboneGroup(_GroupedLinear):
         x = t if t is not None else x
         qkv = self._linear(name + ".qkv", y_hl, rows, C, [b.mixer.qkv.weight for b in blks],
                            [b.mixer.qkv.bias for b in blks] if mixer.qkv.bias is not None else None)
-        ctx_hl = ops.svtr_attention(qkv.view(G * B, N, 3 * C), mixer.num_heads, mixer.scale, mixer.mask, want_f32=False, want_hl=True)
+        ctx_hl = ops.svtr_attention(qkv.view(G * B, N, 3 * C), mixer.num_heads, mixer.scale, mixer.mask, want_f32=False, want_hl=True,
+                                    x3=ops.SVTR_ATTENTION_X3)
         br = self._linear(name + ".proj", ctx_hl, rows, C, [b.mixer.proj.weight for b in blks], [b.mixer.proj.bias for b in blks])
         drop2 = self._drop_scales(blks, B, x.device)
         g2, b2 = self._ln_params(name + ".ln2", [b.norm2 for b in blks])

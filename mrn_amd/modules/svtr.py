@@ -108,7 +108,7 @@ class Attention(nn.Module):
             mask = self.mask
         if d == 32 and not torch.is_grad_enabled() and ops.SVTR_FUSED_ATTENTION:
             # frozen experts: one fused launch (online softmax, scores never reach HBM) instead of 2h batched GEMMs + softmax
-            ctx = ops.svtr_attention(qkv, h, self.scale, mask)
+            ctx = ops.svtr_attention(qkv, h, self.scale, mask, x3=ops.SVTR_ATTENTION_X3)
             return frozen_linear(ctx, self.proj.weight, self.proj.bias, residual=residual)
         attn = torch.empty(B, h, N, N, device=x.device, dtype=torch.float32)
         ctx = torch.empty(B, N, C, device=x.device, dtype=torch.float32)

@@ -67,6 +67,7 @@ TIMER_SHAPES = False         # tools/layer_times.py: one timer kind per layer sh
 #   "f32"     exact fp32 MFMA
 ROUTER_GEMM_PRECISION = "fp16x3"
 SVTR_FUSED_ATTENTION = os.environ.get("MRN_SVTR_ATTENTION", "fused") == "fused"   # frozen SVTR experts: mrn_svtr_attention_f32
+SVTR_ATTENTION_X3 = os.environ.get("MRN_SVTR_ATTENTION_PRECISION", "fp16x3") == "fp16x3"   # frozen experts: x3 products ("f32": exact)
 # A/B switches (environment variables, read once at import): the defaults are the measured winners; tools/ and DESIGN.md
 # section 4 quote the runs.
 RECURRENT_X3 = os.environ.get("MRN_RECURRENT", "fp16x3") == "fp16x3"   # frozen experts' LSTM recurrences on the f16 MFMA
@@ -1096,10 +1097,10 @@ def softmax_rows_bwd_(p, dp):
     return dp
 
 
-def svtr_attention(qkv, heads, scale, mask=None, want_f32=True, want_hl=False, want_lse=False):
+def svtr_attention(qkv, heads, scale, mask=None, want_f32=True, want_hl=False, want_lse=False, x3=False):
     """qkv [B,N,3C] (q | k | v, head dim 32), mask [N,N] additive symmetric or None -> [B,N,C]: fused q k^T / softmax / attn v.
     want_hl: also (or only) the HL32 operand of the proj Linear; returns the fp32 tensor, the HL32 bytes, or (fp32, hl).
-    want_lse: returns (fp32, lse [B,heads,N]) -- what svtr_attention_bwd needs"""
+    want_lse: returns (fp32, lse [B,heads,N]) -- what svtr_attention_bwd needs.  x3: split-fp16 x3 products (frozen experts)"""
     _chk(qkv, mask)
     B, N, C3 = qkv.shape
     C = C3 // 3
@@ -1107,7 +1108,8 @@ def svtr_attention(qkv, heads, scale, mask=None, want_f32=True, want_hl=False, w
     out = torch.empty(B, N, C, device=qkv.device, dtype=torch.float32) if want_f32 else None
     hl = torch.empty(B * N * C * 4, device=qkv.device, dtype=torch.uint8) if want_hl else None
     lse = torch.empty(B, heads, N, device=qkv.device, dtype=torch.float32) if want_lse else None
-    call("mrn_svtr_attention_f32", _p(qkv), _p(mask), _p(out), _p(hl), _p(lse), B, N, C, heads, float(scale), _stream())
+    call("mrn_svtr_attention_f32", _p(qkv), _p(mask), _p(out), _p(hl), _p(lse), B, N, C, heads, float(scale),
+         int(bool(x3) and not want_lse), _stream())
     if want_lse:
         return out, lse
     return (out, hl) if (want_f32 and want_hl) else (hl if want_hl else out)

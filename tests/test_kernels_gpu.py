@@ -531,9 +531,11 @@ def test_full_size_dominant_conv_properties(ops):
     assert torch.equal(y2[0], y[2])
 
 
+@pytest.mark.parametrize("x3", [False, True])
 @pytest.mark.parametrize("B,N,heads,masked", [(3, 512, 2, True), (2, 256, 4, True), (5, 128, 8, False), (2, 100, 2, False)])
-def test_svtr_fused_attention(ops, B, N, heads, masked):
-    """mrn_svtr_attention_f32 (online softmax on the fp32 MFMA) against torch softmax attention with the SVTR local mask"""
+def test_svtr_fused_attention(ops, B, N, heads, masked, x3):
+    """mrn_svtr_attention_f32 (online softmax; exact-fp32 MFMA products, or split-fp16 x3 products for the frozen experts)
+    against torch softmax attention with the SVTR local mask"""
     from mrn_amd.modules.svtr import local_attention_mask
     C = heads * 32
     qkv = rnd(B, N, 3 * C, seed=260, scale=1.5)
@@ -543,8 +545,8 @@ def test_svtr_fused_attention(ops, B, N, heads, masked):
     if mask is not None:
         s = s + mask
     ref = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B, N, C)
-    out = ops.svtr_attention(cu(qkv), heads, 32 ** -0.5, cu(mask) if masked else None)
-    assert_close("fused attention", out, ref, atol=2e-6, rtol=1e-5)
+    out = ops.svtr_attention(cu(qkv), heads, 32 ** -0.5, cu(mask) if masked else None, x3=x3)
+    assert_close("fused attention", out, ref, atol=4e-6 if x3 else 2e-6, rtol=1e-5)
 
 
 def _hl32_to_f32(hl, rows, C):
@@ -558,8 +560,9 @@ def test_svtr_fused_attention_hl32_output(ops):
     B, N, heads = 3, 256, 4
     C = heads * 32
     qkv = cu(rnd(B, N, 3 * C, seed=261))
-    out, hl = ops.svtr_attention(qkv, heads, 32 ** -0.5, None, want_f32=True, want_hl=True)
-    assert torch.equal(hl, ops.split_hl32(out))
+    for x3 in (False, True):
+        out, hl = ops.svtr_attention(qkv, heads, 32 ** -0.5, None, want_f32=True, want_hl=True, x3=x3)
+        assert torch.equal(hl, ops.split_hl32(out))
 
 
 @pytest.mark.parametrize("C,G,rows_pg", [(64, 3, 700), (128, 2, 515), (256, 3, 130), (512, 2, 67)])
