@@ -203,7 +203,7 @@ def main():
     # look-ahead, so every launch of the dominant kernel has the GPU to itself -- its own rate, next to the in-situ
     # rate of the timed region where two half-groups and the router phase share the chip.
     isolated = None
-    if timer is not None and rank == 0 and not args.no_isolated_pass:
+    if timer is not None and not args.no_isolated_pass:     # (every rank: routing_step holds the gradient all-reduce)
         net = learner.model.module
         saved, net.expert_halves = net.expert_halves, 0
         pending.clear()

@@ -33,7 +33,9 @@ def init_distributed(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("MRN_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if os.environ.get("MRN_SHARE_DEVICE"):      # test hook: every rank on cuda:0 (gloo only) -- exercises the N > 1
+            local = 0                               # control flow of bench.py / the learners on a one-GPU box
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

@@ -1,0 +1,54 @@
+"""bench.py end to end on the GPU box: the single-process line (all contract fields, roofline + isolated pass + cpu_baseline
+object) and the N = 2 control flow (two ranks sharing cuda:0 over gloo -- the box has one GPU -- so every collective of the
+timed region, the isolated pass and the max-over-ranks reduction is matched on both ranks)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIELDS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+          "dtype", "data", "config", "roofline")
+
+
+def _fresh_process_only():
+    """bench.py is started as a child process; this file sorts first in the suite, so the pytest process has not touched the
+    GPU yet -- if it has (another order), skip rather than spawn a program from a process that already initialised the GPU"""
+    torch = sys.modules.get("torch")
+    if torch is not None and torch.cuda.is_initialized():
+        pytest.skip("run tests/test_bench_gpu.py in a fresh process")
+
+
+def _last_json(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert lines, out[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_single_process_line():
+    _fresh_process_only()
+    r = subprocess.run([sys.executable, "bench.py", "--model", "crnn", "--experts", "3", "--batch", "32", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    for k in FIELDS:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["scaling"] == "weak" and d["data"] == "synthetic"
+    rl = d["roofline"]
+    assert rl["bound"] in ("mfma", "hbm") and 0 < rl["frac"] < 1 and rl["peak"] > 0 and "isolated" in rl
+
+
+def test_bench_two_ranks_control_flow():
+    _fresh_process_only()
+    env = dict(os.environ, MRN_DIST_BACKEND="gloo", MRN_SHARE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", "bench.py", "--gpus", "2", "--model", "crnn", "--experts", "3", "--batch", "16", "--steps", "2",
+           "--warmup", "1"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 32 and d["config"]["parallelism"] == "dp2"
+    assert "cpu_baseline" not in d          # reported at N = 1 only
