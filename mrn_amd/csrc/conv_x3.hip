@@ -313,7 +313,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
           csum[j] += v;
           csq[j] += v * v;
           if (p.act == 1) v = fmaxf(v, 0.f);
-          else if (p.act == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));     // GELU (erf), SVTR Mlp
+          else if (p.act == 2) v = gelu_fast(v);                                             // GELU (erf), SVTR Mlp
           if (!HL_OUT || p.y) yg[pix * p.y_ld + n] = v;
           if (HL_OUT && p.y_hl) {       // operand of the next GEMM: 32 lanes fill the hi half and the lo half of one 128-byte line
             _Float16 h, l;
