@@ -306,12 +306,15 @@ class MRNNet(nn.Module):
 
     def _half_groups(self, is_train):
         """[(lo, hi, BackboneGroup, HeadsGroup)] per sub-group when the experts are split into `expert_halves` lock-step
-        groups that run on separate streams, else None"""
+        groups that run on separate streams, else None.  Fewer than two experts per sub-group: ONE group on one side stream,
+        so that the loop-B software pipeline (experts_prefetch) still overlaps the router phase with the next batch's experts."""
         from . import expert_group
         I = len(self.model)
         k = self.expert_halves
-        if k < 2 or I < 2 * k:
+        if k < 2 or I < 2:
             return None
+        if I < 2 * k:
+            k = 1
         key = tuple(id(e) for e in self.model) + (k,)
         if self._halves is None or self._halves[0] != key:
             cuts = [I * i // k for i in range(k + 1)]

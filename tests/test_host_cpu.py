@@ -194,3 +194,9 @@ def test_lockstep_grouping_policy():
     assert [(lo, hi) for lo, hi, _, _ in parts] == [(0, 2), (2, 5)]
     net.expert_halves = 0
     assert net._half_groups(True) is None
+    # two or three experts: ONE lock-step group on a side stream, so the loop-B pipeline still overlaps the router phase
+    net.expert_halves = 2
+    saved_models = net.model
+    net.model = torch.nn.ModuleList(list(saved_models)[:3])
+    assert [(lo, hi) for lo, hi, _, _ in net._half_groups(True)] == [(0, 3)]
+    net.model = saved_models
