@@ -156,7 +156,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
       if (hi >= 0 && lo < p.H) active |= 1u << tp;
     }
   }
-  const int nact = __builtin_popcount(active);
+  active = (unsigned)__builtin_amdgcn_readfirstlane((int)active);   // wave-uniform by construction: keeps the K-step iterator
+  const int nact = __builtin_popcount(active);                      // (tap, channel block) and the DMA's scalar offset in SGPRs
   const int nk = p.Cb * nact;
 
   // ---- DMA geometry: instruction j = i*8 + wave covers tile rows 8j .. 8j+7; lane -> row 8j + lane/8, LDS chunk lane&7.
@@ -274,14 +275,64 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
   // 410 TFLOP/s; a 3-stage ring with counted vmcnt + raw s_barrier on the 256x128 tile +2.7 %, which does not fit the
   // 160 KiB LDS at 256x256; single-stage 256x128 tiles with 4 waves and two workgroups per CU (occupancy instead of
   // software pipelining) 451 vs 478 TFLOP/s for the 256x256 double-buffered tile.)
-  issue_next(lds);
-  for (int kt = 0; kt < nk; ++kt) {
-    __syncthreads();      // own DMAs of tile kt retired (vmcnt(0)) + everyone finished reading the other stage
-    const unsigned char* cur = lds + (kt & 1) * STAGE;
-    read_frags(cur, 0);
-    issue_next(lds + ((kt + 1) & 1) * STAGE);
-    read_frags(cur, 1);
+  if constexpr (NW == 16) {
+    // 16 waves x 64x64 (four waves per SIMD: 128 VGPRs each): only the hi x hi third of a K-step's second half is carried
+    // across the barrier (16 fragment registers) -- the full skew of the 8-wave variants would need both fragment sets live
+    // (36 spills inside the loop: 185 TFLOP/s).
+    auto mmas_cross = [&](int ks) {
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = mma(al[ks][i], bh[ks][j], acc[i][j]);
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = mma(ah[ks][i], bl[ks][j], acc[i][j]);
+    };
+    auto mmas_hh = [&](int ks) {
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = mma(ah[ks][i], bh[ks][j], acc[i][j]);
+    };
+    issue_next(lds);
+    __syncthreads();
+    read_frags(lds, 0);
+    issue_next(lds + STAGE);
+    read_frags(lds, 1);
     mmas(0);
+    mmas_cross(1);
+    for (int kt = 1; kt < nk; ++kt) {
+      __syncthreads();      // own DMAs of tile kt retired (vmcnt(0)) + everyone has read both halves of tile kt-1's stage
+      const unsigned char* cur = lds + (kt & 1) * STAGE;
+      read_frags(cur, 0);
+      issue_next(lds + ((kt + 1) & 1) * STAGE);
+      mmas_hh(1);           // tile kt-1: the last four MFMAs cover the fragment reads issued above
+      read_frags(cur, 1);
+      mmas(0);
+      mmas_cross(1);
+    }
+    mmas_hh(1);
+  } else {
+    // 8-wave variants: the MFMAs are skewed by half a K-step against the barrier -- when a wave leaves the barrier of tile
+    // kt it still owes the second half (ks = 1) of tile kt-1, whose fragments are already in registers, so the burst of
+    // fragment reads that all waves issue right after the barrier is covered by MFMAs instead of starving the matrix pipes
+    // (128x128 tile 311 -> 335 TFLOP/s, 256x64 186 -> 194, 8-wave 256x256 438 -> 454).
+    issue_next(lds);
+    __syncthreads();
+    read_frags(lds, 0);
+    issue_next(lds + STAGE);
+    read_frags(lds, 1);
+    mmas(0);
+    for (int kt = 1; kt < nk; ++kt) {
+      __syncthreads();      // own DMAs of tile kt retired (vmcnt(0)) + everyone has read both halves of tile kt-1's stage
+      const unsigned char* cur = lds + (kt & 1) * STAGE;
+      read_frags(cur, 0);
+      issue_next(lds + ((kt + 1) & 1) * STAGE);
+      mmas(1);              // tile kt-1, second half
+      read_frags(cur, 1);
+      mmas(0);
+    }
     mmas(1);
   }
 
