@@ -57,6 +57,8 @@ struct ConvX3Params {
   int class_order;             // interior-row tiles before border-row tiles inside every XCD's share
   unsigned wo_magic, bw_magic; // fast_div constants for Wo and B * Wo
   int wo_shift, bw_shift;
+  unsigned kw_magic;          // ... and for kw (tap -> (ky, kx) once per K-step, on the scalar unit)
+  int kw_shift;
 };
 
 // 16 bytes per lane, global (buffer descriptor + per-lane byte offset + wave-uniform offset) -> LDS (wave-uniform base + 16*lane)
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
       it_rem &= it_rem - 1;
     }
     const int tap = it_tap, cb = it_cb;
-    const int ky = tap / p.kw, kx = tap - ky * p.kw;
+    const int ky = fast_div(tap, p.kw_magic, p.kw_shift), kx = tap - ky * p.kw;
     const int aoff = ((ky * p.W + kx) * p.Cb + cb) * 128;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -641,6 +643,7 @@ MRN_EXPORT int mrn_conv2d_x3_hl32(const void* x_hl, const void* w_hl, const void
   p.BWo = B * Wo;
   magic_div((unsigned)Wo, p.wo_magic, p.wo_shift);
   magic_div((unsigned)p.BWo, p.bw_magic, p.bw_shift);
+  magic_div((unsigned)kw, p.kw_magic, p.kw_shift);
   // 256x256: 16 waves (64x64 wave tiles, four waves per SIMD) hide the per-K-step LDS / barrier stalls better than 8 waves
   // with 128x64 tiles: 464 vs 438 TFLOP/s on the dominant shape (MRN_X3_W8=1 selects the 8-wave variant for A/B runs)
   if (y_hl32) {     // separate instantiations: the store path of the plain kernels stays as it was
