@@ -286,7 +286,8 @@ class MRNNet(nn.Module):
         self._halves = None
         self.expert_halves = int(os.environ.get("MRN_EXPERT_HALVES", "2"))      # concurrent lock-step sub-groups
         #   (measured on TRBA x 6, MI355X: 1 group 1.00, 2 halves on two streams 1.044, 3 thirds 1.015, staggered halves 1.035,
-        #    halves with one high-priority stream 0.96)
+        #    halves with one high-priority stream 0.96; with the final conv kernel and the loop-B pipeline: one group on a
+        #    side stream 0.992 of two halves)
 
     def _streams(self, n, device):
         while len(self._stream_pool) < n:
