@@ -292,9 +292,11 @@ int mrn_add_layernorm_grouped_f32(const float* x, const float* branch, const flo
  * C = heads * 32), mask [N][N] additive and SYMMETRIC (SVTR's local window mask) or NULL, out [B][N][C] fp32 and / or
  * out_hl32 (the same tensor as the HL32 operand of the proj Linear: a head IS one 32-channel block).  Online softmax
  * on the exact-fp32 MFMA (x3 = 0) or, for frozen experts, with both products as split-fp16 x3 on the f16 MFMA (x3 = 1, 22-bit
- * products like the experts' other GEMMs): the [B][heads][N][N] score tensor of modules/svtr.py:140-149 never reaches HBM. */
-int mrn_svtr_attention_f32(const float* qkv, const float* mask, float* out, void* out_hl32, float* lse, int B, int N, int C,
-                           int heads, float scale, int x3, void* stream);
+ * products like the experts' other GEMMs): the [B][heads][N][N] score tensor of modules/svtr.py:140-149 never reaches HBM.
+ * mask_bits: instead of `mask`, the visibility bits [N][ceil(N/32)] of a mask whose entries are 0 or -inf (SVTR's local window
+ * mask, svtr.py:117-128): bit k of word t of row q set = key 32t + k is visible to query q. */
+int mrn_svtr_attention_f32(const float* qkv, const float* mask, const void* mask_bits, float* out, void* out_hl32, float* lse,
+                           int B, int N, int C, int heads, float scale, int x3, void* stream);
 /* Backward of the above for an expert being trained (autograd of svtr.py:140-149 under loss.backward(), il_modules/mrn.py:260):
  * the forward call also stores lse [B][heads][N] (base-2 log-sum-exp of the scaled, masked scores; pass NULL when frozen);
  * dqkv [B][N][3*C] is recomputed tile by tile from qkv, out, dout and lse -- no [N][N] tensor is kept.  dsum: [B][heads][N]

@@ -27,6 +27,7 @@ typedef _Float16 f16v4 __attribute__((ext_vector_type(4)));
 struct AttnParams {
   const float* qkv;    // [B][N][3*C]: q | k | v, each (head, d) innermost
   const float* mask;   // [N][N] additive, symmetric, or null
+  const unsigned* mask_bits;   // [N][ceil(N/32)] bit k of word t of row q: key 32t + k is visible to query q (a 0 / -inf mask), or null
   float* out;          // [B][N][C] fp32, or null
   unsigned char* out_hl;   // the same tensor as HL32 lines [B*N][heads][hi 32 | lo 32] (a head is one 32-channel block), or null
   float* lse;          // [B][heads][N] base-2 log-sum-exp of the scaled, masked scores (kept for the backward pass), or null
@@ -93,20 +94,20 @@ __global__ __launch_bounds__(AW * 64) void svtr_attention_kernel(const AttnParam
   for (int e = 0; e < 16; ++e) o[e] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
   const float* mcol = p.mask ? p.mask + (qok ? q : 0) + 4L * half * p.N : nullptr;
+  const unsigned* brow = p.mask_bits ? p.mask_bits + (long)(qok ? q : 0) * ((p.N + 31) / 32) : nullptr;
 
   const int ntiles = (p.N + 31) / 32;
   for (int it = 0; it < ntiles; ++it) {
     const int k0 = it * 32, cur = it & 1;
     const bool more = it + 1 < ntiles;
     if (more) fetch(k0 + 32);
+    const unsigned bw = brow ? brow[it] >> (4 * half) : 0u;
     // ---- mask column of this query: register e is key k0 + (e&3) + 8*(e>>2) + 4*half (symmetric: [key][query] coalesces)
     float mreg[16];
-    if (mcol) {
+    if (mcol) {      // rows past N are clamped, not branched around (their scores are dropped below): 16 plain loads
+      const int last = p.N - 1 - 4 * half;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int key = k0 + (e & 3) + 8 * (e >> 2) + 4 * half;
-        mreg[e] = key < p.N ? mcol[(long)(k0 + (e & 3) + 8 * (e >> 2)) * p.N] : 0.f;
-      }
+      for (int e = 0; e < 16; ++e) mreg[e] = mcol[(long)min(k0 + (e & 3) + 8 * (e >> 2), last) * p.N];
     }
     // ---- S^T tile: A operand lane (key n31, half) = K[k0 + n31][16*half + t]
     f32x16 s;
@@ -124,6 +125,11 @@ __global__ __launch_bounds__(AW * 64) void svtr_attention_kernel(const AttnParam
     if (mcol) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) s[e] = fmaf(mreg[e], LOG2E, s[e]);
+    }
+    if (brow) {                                            // one mask word per (query, key tile) instead of 16 floats
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        if (!((bw >> ((e & 3) + 8 * (e >> 2))) & 1u)) s[e] = -INFINITY;
     }
     if (k0 + 32 > p.N) {                                   // ragged last tile: keys past N drop out
 #pragma unroll
@@ -276,16 +282,19 @@ __global__ __launch_bounds__(AW * 64) void svtr_attention_x3_kernel(const AttnPa
   for (int e = 0; e < 16; ++e) o[e] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
   const float* mcol = p.mask ? p.mask + (qok ? q : 0) + 4L * half * p.N : nullptr;
+  const unsigned* brow = p.mask_bits ? p.mask_bits + (long)(qok ? q : 0) * ((p.N + 31) / 32) : nullptr;
 
   const int ntiles = (p.N + 31) / 32;
   for (int it = 0; it < ntiles; ++it) {
     const int k0 = it * 32, cur = it & 1;
     const bool more = it + 1 < ntiles;
     if (more) fetch(k0 + 32);
+    const unsigned bw = brow ? brow[it] >> (4 * half) : 0u;
     float mreg[16];
     if (mcol) {
+      const int last = p.N - 1 - 4 * half;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) mreg[e] = (k0 + (e & 3) + 8 * (e >> 2) + 4 * half) < p.N ? mcol[(long)(k0 + (e & 3) + 8 * (e >> 2)) * p.N] : 0.f;
+      for (int e = 0; e < 16; ++e) mreg[e] = mcol[(long)min(k0 + (e & 3) + 8 * (e >> 2), last) * p.N];
     }
     f32x16 s;
 #pragma unroll
@@ -311,6 +320,11 @@ __global__ __launch_bounds__(AW * 64) void svtr_attention_x3_kernel(const AttnPa
     } else {
 #pragma unroll
       for (int e = 0; e < 16; ++e) s[e] *= 1.f / (OPSCALE * OPSCALE);
+    }
+    if (brow) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        if (!((bw >> ((e & 3) + 8 * (e >> 2))) & 1u)) s[e] = -INFINITY;
     }
     if (k0 + 32 > p.N) {
 #pragma unroll
@@ -483,8 +497,9 @@ __global__ __launch_bounds__(AW * 64) void svtr_attention_dq_kernel(const AttnBw
     if (more) fetch(k0 + 32);
     float mreg[16];
     if (mcol) {
+      const int last = p.N - 1 - 4 * half;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) mreg[e] = (k0 + kKeyOf(e) + 4 * half) < p.N ? mcol[(long)(k0 + kKeyOf(e)) * p.N] : 0.f;
+      for (int e = 0; e < 16; ++e) mreg[e] = mcol[(long)min(k0 + kKeyOf(e), last) * p.N];
     }
     f32x16 s, dp;
 #pragma unroll
@@ -601,12 +616,9 @@ __global__ __launch_bounds__(AW * 64) void svtr_attention_dkv_kernel(const AttnB
     const bool more = it + 1 < ntiles;
     if (more) fetch(q0 + 32);
     float mreg[16];
-    if (mrow) {
+    if (mrow) {      // queries past N are clamped (their probability is 0 through lse = +inf)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int qq = q0 + kKeyOf(e) + 4 * half;
-        mreg[e] = qq < p.N ? mrow[(long)qq * p.N] : 0.f;
-      }
+      for (int e = 0; e < 16; ++e) mreg[e] = mrow[(long)min(q0 + kKeyOf(e) + 4 * half, p.N - 1) * p.N];
     }
     f32x16 s, dp;
 #pragma unroll
@@ -664,14 +676,17 @@ __global__ __launch_bounds__(AW * 64) void svtr_attention_dkv_kernel(const AttnB
 // out_hl32 (HL32 operand of the proj Linear).
 // Replaces the q k^T / softmax / attn v chain of modules/svtr.py:140-149 without materialising [B][heads][N][N].
 // x3 != 0: both products as split-fp16 x3 (frozen experts; lse must be NULL), else exact fp32 products.
-MRN_EXPORT int mrn_svtr_attention_f32(const float* qkv, const float* mask, float* out, void* out_hl32, float* lse, int B, int N,
-                                      int C, int heads, float scale, int x3, void* stream) {
+// mask_bits (optional, instead of mask): [N][ceil(N/32)] visibility bits of a 0 / -inf mask (bit k of word t of row q = key
+// 32t + k is visible to query q): one word per (query, key tile) instead of 16 floats per lane.
+MRN_EXPORT int mrn_svtr_attention_f32(const float* qkv, const float* mask, const void* mask_bits, float* out, void* out_hl32,
+                                      float* lse, int B, int N, int C, int heads, float scale, int x3, void* stream) {
+  MRN_CHECK_ARG(!(mask && mask_bits), "mrn_svtr_attention_f32: pass the additive mask or its bit form, not both");
   MRN_CHECK_ARG(!(x3 && lse), "mrn_svtr_attention_f32: the x3 variant keeps no log-sum-exp (training uses the fp32 kernel)");
   MRN_CHECK_ARG(qkv && (out || out_hl32) && heads >= 1 && C == heads * HD, "mrn_svtr_attention_f32: head dimension must be %d (C=%d heads=%d)", HD, C, heads);
   MRN_CHECK_ARG(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)out % 16 == 0), "mrn_svtr_attention_f32: operands must be 16-byte aligned");
   if (B == 0 || N == 0) return MRN_OK;
   AttnParams p;
-  p.qkv = qkv; p.mask = mask; p.out = out; p.out_hl = (unsigned char*)out_hl32; p.lse = lse; p.B = B; p.N = N; p.C = C; p.heads = heads; p.scale = scale;
+  p.qkv = qkv; p.mask = mask; p.mask_bits = (const unsigned*)mask_bits; p.out = out; p.out_hl = (unsigned char*)out_hl32; p.lse = lse; p.B = B; p.N = N; p.C = C; p.heads = heads; p.scale = scale;
   const long groups = (long)B * heads * ((N + 32 * AW - 1) / (32 * AW));
   if (x3) hipLaunchKernelGGL(svtr_attention_x3_kernel, dim3((unsigned)groups), dim3(AW * 64), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(svtr_attention_kernel, dim3((unsigned)groups), dim3(AW * 64), 0, (hipStream_t)stream, p);

@@ -1097,6 +1097,25 @@ def softmax_rows_bwd_(p, dp):
     return dp
 
 
+def _mask_bits(mask):
+    """visibility bits [N, ceil(N/32)] (int32) of an additive mask whose entries are all 0 or -inf, cached on the tensor; None
+    for any other mask (one device->host check per mask tensor, when the cache is built)"""
+    got = getattr(mask, "_mrn_bits", None)
+    if got is None or got[0] != mask._version:
+        vis = mask == 0
+        binary = bool(torch.all(vis | torch.isneginf(mask)))
+        bits = None
+        if binary:
+            N, M = mask.shape
+            pad = (-M) % 32
+            v = torch.nn.functional.pad(vis, (0, pad)).view(N, (M + pad) // 32, 32).to(torch.int64)
+            w = (v << torch.arange(32, device=mask.device, dtype=torch.int64)).sum(-1)
+            bits = torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32).contiguous()
+        got = (mask._version, bits)
+        mask._mrn_bits = got
+    return got[1]
+
+
 def svtr_attention(qkv, heads, scale, mask=None, want_f32=True, want_hl=False, want_lse=False, x3=False):
     """qkv [B,N,3C] (q | k | v, head dim 32), mask [N,N] additive symmetric or None -> [B,N,C]: fused q k^T / softmax / attn v.
     want_hl: also (or only) the HL32 operand of the proj Linear; returns the fp32 tensor, the HL32 bytes, or (fp32, hl).
@@ -1108,8 +1127,9 @@ def svtr_attention(qkv, heads, scale, mask=None, want_f32=True, want_hl=False, w
     out = torch.empty(B, N, C, device=qkv.device, dtype=torch.float32) if want_f32 else None
     hl = torch.empty(B * N * C * 4, device=qkv.device, dtype=torch.uint8) if want_hl else None
     lse = torch.empty(B, heads, N, device=qkv.device, dtype=torch.float32) if want_lse else None
-    call("mrn_svtr_attention_f32", _p(qkv), _p(mask), _p(out), _p(hl), _p(lse), B, N, C, heads, float(scale),
-         int(bool(x3) and not want_lse), _stream())
+    bits = _mask_bits(mask) if (mask is not None and not want_lse) else None     # (the backward kernels read the additive mask)
+    call("mrn_svtr_attention_f32", _p(qkv), None if bits is not None else _p(mask), _p(bits), _p(out), _p(hl), _p(lse), B, N, C,
+         heads, float(scale), int(bool(x3) and not want_lse), _stream())
     if want_lse:
         return out, lse
     return (out, hl) if (want_f32 and want_hl) else (hl if want_hl else out)
