@@ -101,7 +101,13 @@ __global__ __launch_bounds__(AW * 64) void svtr_attention_kernel(const AttnParam
     const int k0 = it * 32, cur = it & 1;
     const bool more = it + 1 < ntiles;
     if (more) fetch(k0 + 32);
-    const unsigned bw = brow ? brow[it] >> (4 * half) : 0u;
+    const unsigned bword = brow ? brow[it] : 0xffffffffu;
+    if (__ballot(bword != 0u) == 0) {                      // no query of this wave sees a key of this tile (local window): skip
+      if (more) stash(cur ^ 1);
+      __syncthreads();
+      continue;
+    }
+    const unsigned bw = bword >> (4 * half);
     // ---- mask column of this query: register e is key k0 + (e&3) + 8*(e>>2) + 4*half (symmetric: [key][query] coalesces)
     float mreg[16];
     if (mcol) {      // rows past N are clamped, not branched around (their scores are dropped below): 16 plain loads
@@ -289,7 +295,13 @@ __global__ __launch_bounds__(AW * 64) void svtr_attention_x3_kernel(const AttnPa
     const int k0 = it * 32, cur = it & 1;
     const bool more = it + 1 < ntiles;
     if (more) fetch(k0 + 32);
-    const unsigned bw = brow ? brow[it] >> (4 * half) : 0u;
+    const unsigned bword = brow ? brow[it] : 0xffffffffu;
+    if (__ballot(bword != 0u) == 0) {                      // no query of this wave sees a key of this tile (local window): skip
+      if (more) stash(cur ^ 1);
+      __syncthreads();
+      continue;
+    }
+    const unsigned bw = bword >> (4 * half);
     float mreg[16];
     if (mcol) {
       const int last = p.N - 1 - 4 * half;
