@@ -103,6 +103,15 @@ int mrn_im2col_t_hl32_f32(const float* x, void* out, int B, int H, int W, int C,
                           int64_t rows_padded, int splits, const float* scale, void* stream);
 int mrn_pack_weight_hl32(const float* w_ohwi, void* out, int Cout, int taps, int Cin, const float* scale, void* stream);
 
+/* First convolution of the frozen experts' stacks (3x3, stride 1, padding 1, Cin = 4, Cout = 32 or 64: VGG conv 0
+ * feature_extraction.py:19, ResNet conv0_1 :214, TPS localisation conv 1 transformation.py:60), G experts in one launch on the
+ * exact-fp32 MFMA; x [Gx][B][H][W][4] with x_group_stride floats between groups (0: all experts read the same crops), w
+ * [G][Cout][3][3][4], bias [G][Cout] or NULL, y [G][B][H][W][Cout], stats [G][mrn_conv3x3_c4_stats_blocks][2][Cout] (BatchNorm
+ * partial sums / sums of squares of the pre-activation result) or NULL; act 0 / 1 (ReLU). */
+int64_t mrn_conv3x3_c4_stats_blocks(int B, int H, int W);
+int mrn_conv3x3_c4_grouped_f32(const float* x, const float* w_ohwi, const float* bias, float* y, float* stats, int G,
+                               int64_t x_group_stride, int B, int H, int W, int Cout, int act, void* stream);
+
 /* Elementwise passes between grouped convolutions (G frozen experts in lock-step).
  * mrn_bn_finalize_grouped_f32: train-mode BatchNorm2d statistics for G modules at once; partials [G][nblk][2][C] from
  *   the conv epilogue; ptrs = device table [4][G] of device pointers {gamma, beta, running_mean, running_var} (NULL

@@ -145,7 +145,12 @@ class BackboneGroup(_GroupedLinear):
             w_hl, w_scale = self._weights_hl(convs)
             _, stats = ops.conv2d_x3(x.hl, G, x.shared, B, H, W, Cin, w_hl, w_scale, Cout, ksize, stride, padding,
                                      bias=self._bias_stack(convs), act=act, want_stats=training, out=y)
-        else:   # small-Cin layers: exact-fp32 kernel per expert, written into the stack
+        elif Cin == 4 and ksize == (3, 3) and stride == (1, 1) and padding == (1, 1) and Cout in (32, 64) and x.f32 is not None:
+            # first conv of the stacks: one launch for all experts on the dedicated Cin = 4 kernel (csrc/conv_first.hip)
+            w = self._cached("c4w%d" % id(c0), [c.weight for c in convs],
+                             lambda: torch.stack([packed_weight(c).ohwi for c in convs]).contiguous())
+            _, stats = ops.conv3x3_c4_grouped(x.f32, w, self._bias_stack(convs), act=act, want_stats=training, out=y)
+        else:   # other small-Cin layers: exact-fp32 kernel per expert, written into the stack
             assert x.f32 is not None
             n = ops.call("mrn_conv2d_stats_floats", B, Ho, Wo, Cout) if training else 0
             stats = torch.empty(G, n, device=dev, dtype=torch.float32) if training else None

@@ -461,6 +461,24 @@ def conv2d_x3_scaled(x, w_ohwi, bias, stride, padding, act=ACT_NONE, want_stats=
     return y[0], stats
 
 
+def conv3x3_c4_grouped(x, weights, bias=None, act=ACT_NONE, want_stats=False, out=None):
+    """First conv of G frozen experts (3x3, stride 1, padding 1, Cin = 4, Cout 32 / 64) in one launch.  x: [B,H,W,4] (shared by
+    all experts) or [G,B,H,W,4]; weights: [G,Cout,3,3,4] stack; bias [G,Cout] or None -> (y [G,B,H,W,Cout], stats or None)"""
+    _chk(x, weights, bias)
+    G, Cout = weights.shape[0], weights.shape[1]
+    shared = x.dim() == 4
+    B, H, W, C = x.shape[-4:]
+    assert C == 4 and x.is_contiguous() and weights.is_contiguous() and tuple(weights.shape[2:]) == (3, 3, 4)
+    y = out if out is not None else torch.empty(G, B, H, W, Cout, device=x.device, dtype=torch.float32)
+    stats = None
+    if want_stats:
+        nblk = call("mrn_conv3x3_c4_stats_blocks", B, H, W)
+        stats = torch.empty(G, nblk, 2, Cout, device=x.device, dtype=torch.float32)
+    call("mrn_conv3x3_c4_grouped_f32", _p(x), _p(weights), _p(bias), _p(y), _p(stats), G, 0 if shared else B * H * W * 4, B, H, W,
+         Cout, act, _stream())
+    return y, stats
+
+
 def bn_finalize_grouped(stats, G, C, count, ptr_table, momentum, eps):
     """stats [G][nblk][2][C]; ptr_table: int64 device tensor [4,G] of {gamma, beta, running_mean, running_var} addresses"""
     scale = torch.empty(G, C, device=stats.device, dtype=torch.float32)

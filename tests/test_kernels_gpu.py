@@ -647,3 +647,22 @@ def test_svtr_attention_backward(ops, B, N, heads, H):
     assert_close("attention", out, ref, atol=2e-6, rtol=1e-5)
     for i, nm in enumerate(("dq", "dk", "dv")):
         assert_close(nm, qc.grad[:, :, i * C:(i + 1) * C], qkv.grad[:, :, i * C:(i + 1) * C], atol=5e-6, rtol=1e-4)
+
+
+@pytest.mark.parametrize("G,B,H,W,Cout,shared,act", [(3, 5, 32, 256, 32, False, 0), (2, 3, 32, 256, 64, True, 1), (1, 2, 7, 100, 64, True, 0),
+                                                     (2, 2, 5, 130, 32, False, 1)])
+def test_first_conv_c4_grouped(ops, G, B, H, W, Cout, shared, act):
+    """mrn_conv3x3_c4_grouped_f32 (first conv of the experts' stacks, Cin = 4) against torch conv2d: outputs, and the
+    BatchNorm partial statistics summed over blocks against the pre-activation result; ragged widths included"""
+    x = rnd(*( (B, H, W, 4) if shared else (G, B, H, W, 4) ), seed=320)
+    w = rnd(G, Cout, 3, 3, 4, seed=321, scale=0.3)
+    bias = rnd(G, Cout, seed=322)
+    y, stats = ops.conv3x3_c4_grouped(cu(x), cu(w), cu(bias), act=act, want_stats=True)
+    for g in range(G):
+        xg = (x if shared else x[g]).permute(0, 3, 1, 2)
+        pre = torch.nn.functional.conv2d(xg, w[g].permute(0, 3, 1, 2), bias[g], 1, 1)
+        ref = torch.relu(pre) if act else pre
+        assert_close(f"first conv, expert {g}", y[g].permute(0, 3, 1, 2), ref, atol=2e-5, rtol=1e-5)
+        tot = stats[g].double().sum(0).cpu()
+        assert_close("sum", tot[0].float(), pre.double().sum((0, 2, 3)).float(), atol=2e-2, rtol=1e-4)
+        assert_close("sum of squares", tot[1].float(), (pre.double() ** 2).sum((0, 2, 3)).float(), atol=2e-2, rtol=1e-4)
