@@ -68,7 +68,6 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const ConvFirstParams p
 #pragma unroll
   for (int s = 0; s < KTOT / 2; ++s) {
     const int k = 2 * s + kg;                     // tap = s / 2 and channel pair 2 * (s & 1) are compile-time, + kg per lane
-    constexpr int dummy = 0; (void)dummy;
     const int tap = s >> 1, ky = tap / 3, kx = tap - ky * 3;
     const float a = patch[(ky * PW + px + kx) * CIN + 2 * (s & 1) + kg];
 #pragma unroll
