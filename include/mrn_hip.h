@@ -385,6 +385,13 @@ int mrn_grad_norm_clip_f32(const float* g, int64_t n, float max_norm, float* wor
 /* g *= coef (in place), then torch.optim.Adam's update; step_size = lr/(1-beta1^t), bc2_sqrt = sqrt(1-beta2^t) */
 int mrn_adam_step_f32(float* p, float* g, float* m, float* v, int64_t n, const float* norm_coef, float step_size,
                       float beta1, float beta2, float bc2_sqrt, float eps, void* stream);
+/* torch.optim.SGD (il_modules/base.py:74-79: momentum, weight decay; dampening 0, no Nesterov): g *= coef, buf = mu*buf + g + wd*p,
+   p -= lr*buf.  buf zero-initialised by the caller (may be NULL when momentum == 0). */
+int mrn_sgd_step_f32(float* p, float* g, float* buf, int64_t n, const float* norm_coef, float lr, float momentum,
+                     float weight_decay, void* stream);
+/* torch.optim.Adadelta (il_modules/base.py:80-83: rho, eps): running averages square_avg / acc_delta zero-initialised by the caller */
+int mrn_adadelta_step_f32(float* p, float* g, float* square_avg, float* acc_delta, int64_t n, const float* norm_coef, float lr,
+                          float rho, float eps, void* stream);
 
 #ifdef __cplusplus
 }

@@ -67,7 +67,8 @@ __global__ __launch_bounds__(NTH) void attn_decoder_bwd_kernel(const AttnBwdPara
   const int t_ = threadIdx.x, lane = t_ & 63, wave = t_ >> 6;
   const int col = lane & 15, rbase = (lane >> 4) * 4;
   const int j = wave * 16 + col;
-  const f32x4* w_ctx = reinterpret_cast<const f32x4*>(p.w_ih_ctxT) + (long)wave * (4 * HID / 16) * 64 + lane;
+  // pack_fragment_major([D, 4H]) = [wave][D / 256 blocks][4H / 16 steps][64 lanes] float4s
+  const f32x4* w_ctx = reinterpret_cast<const f32x4*>(p.w_ih_ctxT) + (long)wave * (p.D / HID) * (4 * HID / 16) * 64 + lane;
   const f32x4* w_hh = reinterpret_cast<const f32x4*>(p.w_hhT) + (long)wave * (4 * HID / 16) * 64 + lane;
   const f32x4* w_h2h = reinterpret_cast<const f32x4*>(p.w_h2hT) + (long)wave * (HID / 16) * 64 + lane;
 
@@ -112,57 +113,68 @@ __global__ __launch_bounds__(NTH) void attn_decoder_bwd_kernel(const AttnBwdPara
       l[0] = di; l[HID] = df; l[2 * HID] = dg; l[3 * HID] = dob;
     }
     __syncthreads();
-    // (b) dctx = dgates . W_ih[:, :D]   and   dh_prev = dgates . W_hh   (shared A fragments, K = 4H)
-    {
-      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-      const f32x4* const wp[2] = {w_ctx, w_hh};
-      mma_shared_a<2>(acc, dg_lds, GLD, wp, 4 * HID / 16, lane);
+    // (b) + (c), one 256-column block of the context at a time (D = 256 * G: DERNet's main head attends over the G
+    // extractors' concatenated features, modules/model.py:289-291):
+    //   dctx[:, blk] = dgates . W_ih[:, blk]   (block 0 shares its A fragments with dh_prev = dgates . W_hh, K = 4H)
+    //   dalpha[b][t] += dctx[b, blk] . Hb[b][t][blk] ;  dHb[b][t][blk] += alpha[b][t] * dctx[b, blk]   (wave per (b,t) pair)
+    const int G = p.D / HID;
+    for (int blk = 0; blk < G; ++blk) {
+      if (blk == 0) {
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        const f32x4* const wp[2] = {w_ctx, w_hh};
+        mma_shared_a<2>(acc, dg_lds, GLD, wp, 4 * HID / 16, lane);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        dctx_lds[(rbase + r) * HLD + j] = acc[0][r];
-        dh_rec[r] = acc[1][r];
+        for (int r = 0; r < 4; ++r) {
+          dctx_lds[(rbase + r) * HLD + j] = acc[0][r];
+          dh_rec[r] = acc[1][r];
+        }
+      } else {
+        f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+        const f32x4* const wp[1] = {w_ctx + (long)blk * (4 * HID / 16) * 64};
+        mma_shared_a<1>(acc, dg_lds, GLD, wp, 4 * HID / 16, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dctx_lds[(rbase + r) * HLD + j] = acc[0][r];
       }
-    }
-    __syncthreads();
-    // (c) dalpha[b][t] = dctx[b] . Hb[b][t] ;  dHb[b][t] += alpha[b][t] * dctx[b]     (wave per (b,t) pair)
-    for (int pr0 = wave * 4; pr0 < BT * T; pr0 += NW * 4) {
-      f32x4 hv[4];
-      int rows[4], ts[4];
-      bool ok[4];
+      __syncthreads();
+      for (int pr0 = wave * 4; pr0 < BT * T; pr0 += NW * 4) {
+        f32x4 hv[4];
+        int rows[4], ts[4];
+        bool ok[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int pr = pr0 + u;
-        rows[u] = pr < BT * T ? pr / T : 0;
-        ts[u] = pr < BT * T ? pr - rows[u] * T : 0;
-        ok[u] = pr < BT * T && b0 + rows[u] < p.B;
-        hv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (ok[u]) hv[u] = *reinterpret_cast<const f32x4*>(p.Hb + ((long)(b0 + rows[u]) * T + ts[u]) * HID + lane * 4);
-      }
-      float sacc[4];
+        for (int u = 0; u < 4; ++u) {
+          const int pr = pr0 + u;
+          rows[u] = pr < BT * T ? pr / T : 0;
+          ts[u] = pr < BT * T ? pr - rows[u] * T : 0;
+          ok[u] = pr < BT * T && b0 + rows[u] < p.B;
+          hv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (ok[u]) hv[u] = *reinterpret_cast<const f32x4*>(p.Hb + ((long)(b0 + rows[u]) * T + ts[u]) * p.D + blk * HID + lane * 4);
+        }
+        float sacc[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const f32x4 dv = *reinterpret_cast<const f32x4*>(dctx_lds + rows[u] * HLD + lane * 4);
-        sacc[u] = hv[u][0] * dv[0] + hv[u][1] * dv[1] + hv[u][2] * dv[2] + hv[u][3] * dv[3];
-        if (ok[u]) {
-          const float a = al_lds[rows[u] * T + ts[u]];
-          f32x4* dst = reinterpret_cast<f32x4*>(p.dHb + ((long)(b0 + rows[u]) * T + ts[u]) * HID + lane * 4);
-          f32x4 o = *dst;
+        for (int u = 0; u < 4; ++u) {
+          const f32x4 dv = *reinterpret_cast<const f32x4*>(dctx_lds + rows[u] * HLD + lane * 4);
+          sacc[u] = hv[u][0] * dv[0] + hv[u][1] * dv[1] + hv[u][2] * dv[2] + hv[u][3] * dv[3];
+          if (ok[u]) {
+            const float a = al_lds[rows[u] * T + ts[u]];
+            f32x4* dst = reinterpret_cast<f32x4*>(p.dHb + ((long)(b0 + rows[u]) * T + ts[u]) * p.D + blk * HID + lane * 4);
+            f32x4 o = *dst;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) o[k] = fmaf(a, dv[k], o[k]);
-          *dst = o;
+            for (int k = 0; k < 4; ++k) o[k] = fmaf(a, dv[k], o[k]);
+            *dst = o;
+          }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) sacc[u] += __shfl_xor(sacc[u], o);
+        }
+        if (lane < 4 && pr0 + lane < BT * T) {
+          const float v = lane == 0 ? sacc[0] : lane == 1 ? sacc[1] : lane == 2 ? sacc[2] : sacc[3];
+          de_lds[pr0 + lane] = blk == 0 ? v : de_lds[pr0 + lane] + v;      // (the same wave owns this pair in every block)
         }
       }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) sacc[u] += __shfl_xor(sacc[u], o);
-      }
-      if (lane < 4 && pr0 + lane < BT * T) {
-        const float v = lane == 0 ? sacc[0] : lane == 1 ? sacc[1] : lane == 2 ? sacc[2] : sacc[3];
-        de_lds[pr0 + lane] = v;
-      }
+      __syncthreads();
     }
-    __syncthreads();
     // (d) softmax backward: de = alpha * (dalpha - sum_t alpha*dalpha)   (wave per sample)
     {
       const int row = wave;
@@ -344,7 +356,8 @@ MRN_EXPORT int mrn_attn_decoder_bwd_f32(const float* Hb, const float* Hproj, con
                                         int D, int S, int hidden, void* stream) {
   MRN_CHECK_ARG(Hb && Hproj && alpha && gates && cseq && ctx && hp && dhid && w_score && w_h2hT && w_ih_ctxT && w_hhT && dgates &&
                     dhp && dHb && dHproj && dwscore_part, "mrn_attn_decoder_bwd_f32: null operand");
-  MRN_CHECK_ARG(hidden == HID && D == HID, "mrn_attn_decoder_bwd_f32: needs D == hidden == %d (got D=%d hidden=%d)", HID, D, hidden);
+  MRN_CHECK_ARG(hidden == HID && D >= HID && D % HID == 0,
+                "mrn_attn_decoder_bwd_f32: needs hidden == %d and D a multiple of it (got D=%d hidden=%d)", HID, D, hidden);
   if (B == 0 || S == 0) return MRN_OK;
   AttnBwdParams p;
   p.Hb = Hb; p.Hproj = Hproj; p.alpha = alpha; p.gates = gates; p.cseq = cseq; p.ctx = ctx; p.hp = hp; p.dhid = dhid;

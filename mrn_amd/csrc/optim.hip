@@ -54,6 +54,39 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
   }
 }
 
+// torch.optim.SGD (momentum, weight decay; dampening 0, no Nesterov -- il_modules/base.py:74-79): buf = mu * buf + (g + wd * p),
+// p -= lr * buf.  With buf zero-initialised the first step equals torch's "buf = clone(g)".
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ buf, long n,
+                                                  const float* __restrict__ norm_coef, float lr, float momentum, float weight_decay) {
+  const float coef = norm_coef ? norm_coef[1] : 1.f;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float gc = g[i] * coef;
+    g[i] = gc;
+    float d = gc + weight_decay * p[i];
+    if (momentum != 0.f) {
+      d = momentum * buf[i] + d;
+      buf[i] = d;
+    }
+    p[i] = p[i] - lr * d;
+  }
+}
+
+// torch.optim.Adadelta (rho, eps, no weight decay -- il_modules/base.py:80-83)
+__global__ __launch_bounds__(256) void adadelta_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ sq,
+                                                       float* __restrict__ acc, long n, const float* __restrict__ norm_coef,
+                                                       float lr, float rho, float eps) {
+  const float coef = norm_coef ? norm_coef[1] : 1.f;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float gc = g[i] * coef;
+    g[i] = gc;
+    const float s = sq[i] * rho + (1.f - rho) * gc * gc;
+    sq[i] = s;
+    const float delta = sqrtf(acc[i] + eps) / sqrtf(s + eps) * gc;
+    acc[i] = acc[i] * rho + (1.f - rho) * delta * delta;
+    p[i] = p[i] - lr * delta;
+  }
+}
+
 // ---- EWC (il_modules/ewc.py:120-167) and weight alignment (modules/model.py:166-174) -------------------------------
 // mode 0: fisher += g*g        mode 1: fisher = min(fisher * a, b)      mode 2: g += a * fisher * (p - mean)
 __global__ __launch_bounds__(256) void ewc_elementwise_kernel(float* __restrict__ fisher, float* __restrict__ g,
@@ -206,5 +239,27 @@ MRN_EXPORT int mrn_adam_step_f32(float* p, float* g, float* m, float* v, int64_t
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, norm_coef,
                      step_size, beta1, beta2, bc2_sqrt, eps);
   MRN_LAUNCH_CHECK("adam_step");
+  return MRN_OK;
+}
+
+// g *= coef (in place), then torch.optim.SGD's update (momentum buffer `buf`, may be NULL when momentum == 0)
+MRN_EXPORT int mrn_sgd_step_f32(float* p, float* g, float* buf, int64_t n, const float* norm_coef, float lr, float momentum,
+                                float weight_decay, void* stream) {
+  MRN_CHECK_ARG(p && g && (buf || momentum == 0.f), "mrn_sgd_step_f32: null operand");
+  if (n == 0) return MRN_OK;
+  hipLaunchKernelGGL(sgd_kernel, dim3(opt_grid(n) * 2), dim3(256), 0, (hipStream_t)stream, p, g, buf, (long)n, norm_coef, lr,
+                     momentum, weight_decay);
+  MRN_LAUNCH_CHECK("sgd_step");
+  return MRN_OK;
+}
+
+// g *= coef (in place), then torch.optim.Adadelta's update (running averages square_avg / acc_delta)
+MRN_EXPORT int mrn_adadelta_step_f32(float* p, float* g, float* square_avg, float* acc_delta, int64_t n, const float* norm_coef,
+                                     float lr, float rho, float eps, void* stream) {
+  MRN_CHECK_ARG(p && g && square_avg && acc_delta, "mrn_adadelta_step_f32: null operand");
+  if (n == 0) return MRN_OK;
+  hipLaunchKernelGGL(adadelta_kernel, dim3(opt_grid(n) * 2), dim3(256), 0, (hipStream_t)stream, p, g, square_avg, acc_delta, (long)n,
+                     norm_coef, lr, rho, eps);
+  MRN_LAUNCH_CHECK("adadelta_step");
   return MRN_OK;
 }

@@ -23,10 +23,19 @@ class SyntheticTextLines:
         self.taski = taski
 
     def get_dataset(self, taski, memory=None, index_list=None):
+        """same contract as Dataset_Manager.get_dataset (data/data_manage.py:16-61): with a rehearsal memory the learner must
+        hand over one index array per previous task (rehearsal_memory() indexes index_array[i] for i < taski)"""
         self.taski = taski
+        if memory is not None and getattr(self.opt, "il", None) == "mrn":
+            assert index_list is not None and len(index_list) >= taski, "rehearsal memory needs one index array per previous task"
+            for idx in index_list[:taski]:
+                assert len(idx) > 0 and int(max(idx)) < self.dataset_len
+        return index_list
+
+    dataset_len = 50000          # nominal samples per task (the reference repeats small datasets up to 50k, data_manage.py:137-141)
 
     def rehearsal_prev_model(self, taski):
-        return self, self.opt.batch_size
+        return self, self.dataset_len
 
     def set_characters(self, characters):
         self.characters = characters

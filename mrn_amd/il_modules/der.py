@@ -32,14 +32,12 @@ class DER(BaseLearner):
         return net
 
     def change_model(self):
-        self.model = parallel.ReplicaDataParallel(self._expand()).to(self.device)
-        self.model.train()
+        self._wrap(self._expand())
 
     def build_model(self):
         self.model = self._expand()
         self._reference_init()
-        self.model = parallel.ReplicaDataParallel(self.model).to(self.device)
-        self.model.train()
+        self._wrap(self.model)
 
     def incremental_train(self, taski, character, train_loader, valid_loader):
         self.character = character
@@ -50,20 +48,26 @@ class DER(BaseLearner):
         else:
             self.criterion = self.build_criterion()
             self.build_model()
-        for i in range(taski):
+        for i in range(taski):                               # der.py:101-104
             for p in self.model.module.model[i].parameters():
                 p.requires_grad = False
         self.build_optimizer(self.count_param())
-        self._train(0, taski, train_loader, valid)
+        if self.opt.start_task > taski:                      # resume (der.py:112-129)
+            if taski > 0:
+                self.load_task_data(train_loader, taski)
+            self.load_checkpoint(self.checkpoint_path(taski))
+        else:
+            print("Task {} start training for model ------{}------".format(taski, self.opt.exp_name))
+            self._train(0, taski, train_loader, valid)
 
     def _train(self, start_iter, taski, train_loader, valid_loader):
         if taski == 0:
             self._update(start_iter, taski, train_loader, valid_loader)
         else:
-            train_loader.get_dataset(taski, memory=self.opt.memory)
+            self.load_task_data(train_loader, taski)
             self.model_eval_and_train(taski)
             self._update(start_iter, taski, train_loader, valid_loader)
-            self.model.module.weight_align(self._total_classes - self._known_classes)
+            self.model.module.weight_align(self._total_classes - self._known_classes)       # der.py:148
 
     def der_step(self, image, labels):
         """one iteration of der.py:226-271"""
@@ -73,19 +77,22 @@ class DER(BaseLearner):
         else:
             output = self.model(image, labels_index[:, :-1])
         loss_clf = self.criterion(output["logits"], labels_index, labels_length)
-        loss_aux = self.criterion(output["aux_logits"].detach(), labels_index, labels_length)   # logged only
-        self.optimizer_step(loss_clf)
+        loss_aux = self.criterion(output["aux_logits"].detach(), labels_index, labels_length)   # logged only (:264-265)
+        self.backward_and_step(loss_clf)
         return loss_clf, loss_aux
 
     def _update(self, start_iter, taski, train_loader, valid_loader):
-        avg, aux_avg = Averager(), Averager()
-        start_time, best = time.time(), -1
+        avg, clf_avg, aux_avg = Averager(), Averager(), Averager()
+        start_time = time.time()
         for iteration in range(start_iter + 1, self.opt.num_iter + 1):
             image, labels = train_loader.get_batch()
             loss, aux = self.der_step(image.to(self.device), labels)
             avg.add(loss.detach())
+            clf_avg.add(loss.detach())
             aux_avg.add(aux.detach())
+            self.end_iteration(iteration)
             if iteration % self.opt.val_interval == 0 or iteration == 1:
-                best = self.val(valid_loader, self.opt, best, start_time, iteration, avg, None, taski, None, "val")
-                avg.reset()
-                aux_avg.reset()
+                self.val(valid_loader, self.opt, -1, start_time, iteration, avg, None, taski)
+                print(f"CLF_loss: {float(clf_avg.val()):0.5f} , Aux_loss: {float(aux_avg.val()):0.5f}")
+                for a in (avg, clf_avg, aux_avg):
+                    a.reset()

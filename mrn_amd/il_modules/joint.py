@@ -2,7 +2,7 @@
 tasks' data, with the per-dataset test pass run at every validation interval."""
 import time
 
-from ..tools.utils import Averager, adjust_learning_rate
+from ..tools.utils import Averager
 from .base import BaseLearner
 
 
@@ -22,19 +22,17 @@ class JointLearner(BaseLearner):
         self.build_optimizer(self.count_param())
         return self._init_train(0, taski, train_loader, valid, AlignCollate_valid, valid_datas)
 
-    def _init_train(self, start_iter, taski, train_loader, valid_loader, AlignCollate_valid=None, valid_datas=None,
-                    cross=False):
+    def _init_train(self, start_iter, taski, train_loader, valid_loader, AlignCollate_valid=None, valid_datas=None):
         train_loss_avg = Averager()
         best_scores, ned_scores = [], []
-        start_time, best_score = time.time(), -1
+        start_time = time.time()
         for iteration in range(start_iter + 1, self.opt.num_iter + 1):
             image_tensors, labels = train_loader.get_batch()
             loss = self.train_step(image_tensors.to(self.device), labels)
             train_loss_avg.add(loss.detach())
-            if self.scheduler is None:
-                adjust_learning_rate(self.optimizer, iteration, self.opt)
+            self.end_iteration(iteration)
             if iteration % self.opt.val_interval == 0 or iteration == 1:
-                best_score = self.val(valid_loader, self.opt, best_score, start_time, iteration, train_loss_avg, None, taski)
+                self.val(valid_loader, self.opt, -1, start_time, iteration, train_loss_avg, None, taski)
                 if iteration != 1 and valid_datas is not None:
                     # the reference indexes its score lists by task; joint training reports one running entry
                     scores, neds = self.test(AlignCollate_valid, valid_datas, [0.0] * taski, [0.0] * taski, taski)

@@ -20,34 +20,29 @@ class LwF(BaseLearner):
         self._old_network = self.model.copy().freeze()
         self._known_classes = self._total_classes
 
-    def _train(self, start_iter, taski, train_loader, valid_loader):
-        if taski == 0:
-            self._init_train(start_iter, taski, train_loader, valid_loader.create_dataset())
-        else:
-            self._update_representation(start_iter, taski, train_loader, valid_loader.create_dataset())
-
     def kd_step(self, image, labels):
         """one iteration of lwf.py:52-95"""
         labels_index, labels_length = self.converter.encode(labels, batch_max_length=self.opt.batch_max_length)
         ctc = "CTC" in self.opt.Prediction
         text = None if ctc else labels_index[:, :-1]
         preds = self.model(image, text, True)["predict"]
-        with torch.no_grad():
+        with torch.no_grad():                                 # frozen + eval-mode copy (Model.freeze(), model.py:191-197)
             old = self._old_network(image, text, True)["predict"]
         loss_clf = self.criterion(preds, labels_index, labels_length)
-        loss_kd = Fn.kd_loss(preds, old, 0 if ctc else 1, self._known_classes, T)
+        loss_kd = Fn.kd_loss(preds, old, 0 if ctc else 1, self._known_classes, T)          # [:, start_index:known] (:81-85)
         loss = self.kd_weight * loss_kd + loss_clf
-        self.optimizer_step(loss)
+        self.backward_and_step(loss)
         return loss, loss_kd
 
     def _update_representation(self, start_iter, taski, train_loader, valid_loader):
-        train_loader.get_dataset(taski, memory=self.opt.memory)
+        train_loader.get_dataset(taski, memory=self.opt.memory)             # lwf.py:37 (on top of what _train already loaded)
         avg = Averager()
-        start_time, best = time.time(), -1
+        start_time = time.time()
         for iteration in range(start_iter + 1, self.opt.num_iter + 1):
             image, labels = train_loader.get_batch()
             loss, _ = self.kd_step(image.to(self.device), labels)
             avg.add(loss.detach())
+            self.end_iteration(iteration)
             if iteration % self.opt.val_interval == 0 or iteration == 1:
-                best = self.val(valid_loader, self.opt, best, start_time, iteration, avg, None, taski)
+                self.val(valid_loader, self.opt, -1, start_time, iteration, avg, None, taski)
                 avg.reset()

@@ -15,6 +15,8 @@ from .base import BaseLearner
 
 
 class MRN(BaseLearner):
+    checkpoint_has_step = True         # {lan}_{taski}_{step}_best_score.pth (mrn.py:414)
+
     def __init__(self, opt):
         super().__init__(opt)
         self.model = MRNNet(opt)
@@ -24,20 +26,11 @@ class MRN(BaseLearner):
         self._known_classes = self._total_classes
         self._old_network = self.model.copy().freeze()
 
-    def change_model(self):
-        if isinstance(self.model, parallel.ReplicaDataParallel):
-            self.model = self.model.module
-        self.model.update_fc(self.opt.hidden_size, self._total_classes)
-        self.model.build_prediction(self.opt, self._total_classes)
-        self.model = parallel.ReplicaDataParallel(self.model).to(self.device)
-        self.model.train()
-
     def build_model(self):
         self.model.build_fc(self.opt.hidden_size, self._total_classes)
         self.model.build_prediction(self.opt, self._total_classes)
         self._reference_init()
-        self.model = parallel.ReplicaDataParallel(self.model).to(self.device)
-        self.model.train()
+        self._wrap(self.model)
 
     def freeze_experts(self, upto):
         for i in range(upto):
@@ -58,7 +51,30 @@ class MRN(BaseLearner):
         if taski > 0:
             self._train(0, taski, train_loader, valid_loader, step=1)
 
+    def memory_per_task(self, taski):
+        """mrn.py:170-175: memories of 5000+ samples are per task, smaller ones are split over the previous tasks"""
+        return self.opt.memory_num if self.opt.memory_num >= 5000 else int(self.opt.memory_num / taski)
+
+    def build_rehearsal_memory(self, train_loader, taski):
+        num_i = self.memory_per_task(taski)
+        self.build_random_current_memory(num_i, taski, train_loader)
+        if self.opt.memory_num < 5000:
+            if len(self.memory_index) != 0 and len(self.memory_index) * len(self.memory_index[0]) > self.opt.memory_num:
+                self.reduce_samplers(taski, taski_num=num_i)
+        train_loader.get_dataset(taski, memory=self.opt.memory, index_list=self.memory_index)
+        print("Is using rehearsal memory, has {} prev datasets, each has {}\n".format(len(self.memory_index), self.memory_index[0].size))
+
     def _train(self, start_iter, taski, train_loader, valid_loader, step=0):
+        if self.opt.start_task > taski + step * 0.5:           # resume: load this (task, step)'s checkpoint (mrn.py:187-203)
+            self.load_checkpoint(self.checkpoint_path(taski, step))
+            if taski > 0 and step == 0:
+                train_loader.get_dataset(taski, memory=None)
+                for p in self.model.module.model[-1].parameters():     # what update_step1 leaves behind: newest expert frozen
+                    p.requires_grad = False
+                self.model.module.model[-1].eval()
+            elif taski > 0 and step == 1:
+                self.load_task_data(train_loader, taski)
+            return
         print("Task {} start training for model ------{}------".format(taski, self.opt.exp_name))
         if taski == 0:
             self._init_train(start_iter, taski, train_loader, valid_loader.create_dataset(), cross=False)
@@ -66,11 +82,25 @@ class MRN(BaseLearner):
             train_loader.get_dataset(taski, memory=None)
             self.update_step1(start_iter, taski, train_loader, valid_loader.create_dataset())
         else:
-            train_loader.get_dataset(taski, memory=self.opt.memory, index_list=self.memory_index)
+            self.load_task_data(train_loader, taski)
             self._update_representation(start_iter, taski, train_loader, valid_loader.create_list_dataset())
 
     def _forward_train(self, image, text):
         return self.model(image, False, text)["logits"]          # cross=False: newest expert only (mrn.py:248,254)
+
+    def _init_train(self, start_iter, taski, train_loader, valid_loader, cross=False):
+        """mrn.py:225-279: loop A on the newest expert; validates at every val_interval and at the last iteration, "FF"""
+        train_loss_avg = Averager()
+        start_time = time.time()
+        best_score = -1
+        for iteration in range(start_iter + 1, self.opt.num_iter + 1):
+            image_tensors, labels = train_loader.get_batch()
+            loss = self.train_step(image_tensors.to(self.device), labels)
+            train_loss_avg.add(loss.detach())
+            self.end_iteration(iteration)
+            if iteration % self.opt.val_interval == 0 or iteration == self.opt.num_iter:
+                self.val(valid_loader, self.opt, best_score, start_time, iteration, train_loss_avg, None, taski, 0, "FF")
+                train_loss_avg.reset()
 
     def update_step1(self, start_iter, taski, train_loader, valid_loader):
         self._init_train(start_iter, taski, train_loader, valid_loader, cross=False)
@@ -79,15 +109,16 @@ class MRN(BaseLearner):
         self.model.module.model[-1].eval()
 
     def test(self, AlignCollate_valid, valid_datas, best_scores, ned_scores, taski, val_choose="test"):
-        # task 0 evaluates the single expert, later tasks the routed ensemble (mrn.py:450-455)
+        # task 0 evaluates the single expert (checkpoint of step 0), later tasks the routed ensemble (step 1): mrn.py:450-466
         return super().test(AlignCollate_valid, valid_datas, best_scores, ned_scores, taski,
-                            val_choose="FF" if taski == 0 else "TF")
+                            val_choose="FF" if taski == 0 else "TF", step=0 if taski == 0 else 1)
 
     # -- loop B ------------------------------------------------------------------------------------------
     def prepare_routing(self, total_steps=None):
         """optimiser of step 1: Adam over the router parameters, OneCycle(total = 2 * num_iter) (mrn.py:308-312)"""
         self.criterion = self.build_criterion()
-        self.build_optimizer(self.count_param(), scale=1.0, total_steps=total_steps or self.opt.num_iter * 2)
+        self.build_optimizer(self.count_param(), scale=1.0, total_steps=total_steps or self.opt.num_iter * 2, optimizer="adam",
+                             schedule="super")            # build_custom_optimizer(optimizer="adam", schedule="super", the=2)
 
     def prefetch_experts(self, image, labels):
         """Issue the frozen experts' forward of a FUTURE loop-B batch (label encoding + MRNNet.experts_prefetch); pass the

@@ -132,6 +132,7 @@ class Model(nn.Module):
     def weight_align(self, increment):
         """rescale the newest `increment` rows of fc so their mean L2 norm matches the old rows' (reference :166-174)"""
         gamma = ops.weight_align_(self.fc.weight.data, increment)
+        torch.autograd.graph.increment_version(self.fc.weight)      # written through a raw pointer: invalidate repacked copies
         print("alignweights,gamma=", float(gamma))
         return gamma
 

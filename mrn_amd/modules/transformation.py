@@ -66,9 +66,18 @@ class LocalizationNetwork(nn.Module):
         return self.forward_nhwc(to_nhwc(batch_I))
 
 
+def _reference_persists_tps_buffers():
+    """The reference registers inv_delta_C / P_hat as (persistent) buffers only on hosts with more than one GPU and keeps
+    them as plain tensors otherwise (:127-146), so its checkpoints carry two extra keys per TPS stage when written on a
+    multi-GPU host.  Same rule here, so checkpoints saved on a host have the key set the reference would write there."""
+    return torch.cuda.device_count() > 1
+
+
 class GridGenerator(nn.Module):
-    """Constant TPS matrices (reference :115-216).  They are non-persistent buffers: they follow .to(device) but stay
-    out of the state_dict, matching the reference's single-GPU key set (:137-146)."""
+    """Constant TPS matrices (reference :115-216): buffers that follow .to(device); in the state_dict exactly when the
+    reference would put them there (see _reference_persists_tps_buffers).  Loading accepts both checkpoint flavours: the two
+    keys are constants of (F, I_r_size), so a checkpoint without them keeps the computed values and one with them is
+    accepted under strict=True even when this host would not save them."""
 
     def __init__(self, F, I_r_size):
         super().__init__()
@@ -77,8 +86,19 @@ class GridGenerator(nn.Module):
         self.F = F
         C = fiducial_layout(F, -1.0, 1.0)
         inv_delta_C, P_hat = self._build(F, C, self.I_r_width, self.I_r_height)
-        self.register_buffer("inv_delta_C", torch.tensor(inv_delta_C).float(), persistent=False)
-        self.register_buffer("P_hat", torch.tensor(P_hat).float(), persistent=False)
+        persistent = _reference_persists_tps_buffers()
+        self.register_buffer("inv_delta_C", torch.tensor(inv_delta_C).float(), persistent=persistent)
+        self.register_buffer("P_hat", torch.tensor(P_hat).float(), persistent=persistent)
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        for name in ("inv_delta_C", "P_hat"):
+            key = prefix + name
+            persistent = name not in self._non_persistent_buffers_set
+            if key in state_dict and not persistent:
+                state_dict.pop(key)                       # multi-GPU-host checkpoint on a single-GPU host
+            elif key not in state_dict and persistent:
+                state_dict[key] = getattr(self, name)     # single-GPU-host checkpoint on a multi-GPU host
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
 
     def _build(self, F, C, W, H):
         # pairwise TPS kernel U(r) = r^2 log r between fiducials (diagonal: r := 1 -> 0)

@@ -947,6 +947,16 @@ def adam_step(p, g, m, v, norm_coef, lr, step, betas=(0.9, 0.999), eps=1e-8):
          float(betas[1]), float(bc2 ** 0.5), float(eps), _stream())
 
 
+def sgd_step(p, g, buf, norm_coef, lr, momentum=0.0, weight_decay=0.0):
+    call("mrn_sgd_step_f32", _p(p), _p(g), _p(buf), p.numel(), _p(norm_coef), float(lr), float(momentum), float(weight_decay),
+         _stream())
+
+
+def adadelta_step(p, g, square_avg, acc_delta, norm_coef, lr, rho=0.9, eps=1e-6):
+    call("mrn_adadelta_step_f32", _p(p), _p(g), _p(square_avg), _p(acc_delta), p.numel(), _p(norm_coef), float(lr), float(rho),
+         float(eps), _stream())
+
+
 # ---------------------------------------------------------------------------------------------------------
 # convolution / BatchNorm / pooling backward
 # ---------------------------------------------------------------------------------------------------------

@@ -1,9 +1,11 @@
-"""Data parallelism the MI355X way: one process per GPU, replicas hold identical weights, one RCCL all-reduce of the
-flat trainable-gradient buffer per step over xGMI (torch.distributed backend "nccl" is RCCL on ROCm; "gloo" on CPU).
+"""Data parallelism the MI355X way: one process per GPU, replicas hold identical weights, the flat trainable-gradient
+buffer is averaged over xGMI by RCCL all-reduces (torch.distributed backend "nccl" is RCCL on ROCm; "gloo" on CPU) that
+are launched bucket by bucket while backward is still running.
 
 Replaces torch.nn.DataParallel at il_modules/base.py:68, il_modules/mrn.py:106,133 (single process: per-iteration
 broadcast of ALL parameters -- 1.26 GB for TRBA+MRN-6 -- scatter, gather, reduce on GPU 0).  Frozen experts need no
-traffic at all; BatchNorm statistics stay per replica exactly as under DataParallel.
+per-step traffic at all; BatchNorm statistics stay per replica exactly as under DataParallel; parameters AND buffers are
+broadcast from rank 0 once, when a learner builds or grows its model.
 """
 import os
 
@@ -27,7 +29,7 @@ def init_distributed(backend=None):
     """Initialise torch.distributed from the torchrun environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).
     Returns (rank, world, local_rank).  Single-process runs need no initialisation."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
+    rank_ = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -38,32 +40,143 @@ def init_distributed(backend=None):
             local = 0                               # control flow of bench.py / the learners on a one-GPU box
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    return rank, world, local
+        dist.init_process_group(backend=backend, rank=rank_, world_size=world)
+    return rank_, world, local
 
 
 def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def _avg_inplace(t, async_op=False):
+    """all-reduce average of t over the ranks; returns the work handle when async_op"""
+    if dist.get_backend() == "nccl":
+        return dist.all_reduce(t, op=dist.ReduceOp.AVG, async_op=async_op)
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op)      # gloo has no AVG: the caller divides
+
+
 def average_gradients(flat_grad):
-    """One collective over the flat gradient buffer (sum, then divide by world inside the collective)."""
+    """One blocking collective over the flat gradient buffer."""
     if world_size() == 1:
         return flat_grad
-    if dist.get_backend() == "nccl":
-        dist.all_reduce(flat_grad, op=dist.ReduceOp.AVG)
-    else:                                   # gloo has no AVG
-        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+    _avg_inplace(flat_grad)
+    if dist.get_backend() != "nccl":
         flat_grad.div_(world_size())
     return flat_grad
 
 
-def broadcast_parameters(flat_param, src=0):
+def broadcast_parameters(flat_param, src=0, params=None):
+    """the optimiser's flat parameter buffer from rank `src`; `params`: the parameters viewing it (their version counters are
+    bumped so that repacked-weight caches notice)"""
     if world_size() > 1:
         dist.broadcast(flat_param, src=src)
+        if params:
+            torch.autograd.graph.increment_version(list(params))
     return flat_param
+
+
+def broadcast_module(module, src=0):
+    """Every parameter and buffer of `module` from rank `src` (frozen experts, BatchNorm running statistics and counters
+    included), coalesced into one collective per dtype.  DataParallel does this every iteration (replicate); here it runs when
+    a learner builds or grows its model, after which only gradients travel."""
+    if world_size() == 1:
+        return
+    seen, groups = set(), {}
+    for t in list(module.parameters()) + list(module.buffers()):
+        if t.data_ptr() in seen or t.numel() == 0:       # aliased tensors (fc / Prediction.generator) travel once
+            continue
+        seen.add(t.data_ptr())
+        groups.setdefault(t.dtype, []).append(t.data)
+    for dtype, tensors in groups.items():
+        flat = torch.cat([t.reshape(-1) for t in tensors])
+        dist.broadcast(flat, src=src)
+        off = 0
+        for t in tensors:
+            t.copy_(flat[off:off + t.numel()].view(t.shape))
+            off += t.numel()
+    torch.autograd.graph.increment_version(list(module.parameters()))      # (.data copies do not bump the parameters' versions)
 
 
 def barrier():
     if world_size() > 1:
         dist.barrier()
+
+
+class BucketedAllReduce:
+    """Gradient all-reduce overlapped with backward: the optimiser's flat gradient buffer is cut into contiguous buckets,
+    filled from the END of the buffer (parameters are laid out in forward order, backward produces their gradients roughly in
+    reverse); a post-accumulate hook on every parameter counts its bucket down and the bucket's all-reduce is launched
+    asynchronously as soon as it is complete -- in bucket order on every rank, so the collectives match up.  finish()
+    launches whatever is left (parameters that got no gradient this step keep their zeros) and waits.
+
+    Sizes this replaces: loop A 25 MB (SVTR) / 35 MB (CRNN) / 201 MB (TRBA) / 231 MB (DER-6) of fp32
+    gradients per step; loop B (router only) 2-11 MB = one bucket.  Ring all-reduce over xGMI is per-link bound (~153 GB/s),
+    so 25 MB buckets take ~0.3 ms each and hide behind the remaining backward kernels."""
+
+    def __init__(self, optimizer, bucket_bytes=None):
+        self.opt = optimizer
+        bucket_bytes = bucket_bytes or int(os.environ.get("MRN_BUCKET_MB", "25")) * (1 << 20)
+        cap = max(bucket_bytes // 4, 1)
+        n = optimizer.grad.numel()
+        ends = [off + (p.numel() + 3) // 4 * 4 for p, off in zip(optimizer.params, optimizer.offsets)]
+        # walk the parameters backwards, closing a bucket when it reaches the capacity
+        self.buckets = []          # (start, end) element ranges, bucket 0 = the tail of the buffer
+        self.bucket_of = [0] * len(optimizer.params)
+        hi, count = n, 0
+        members = []
+        for i in range(len(optimizer.params) - 1, -1, -1):
+            members.append(i)
+            lo = optimizer.offsets[i]
+            if hi - lo >= cap or i == 0:
+                for m in members:
+                    self.bucket_of[m] = len(self.buckets)
+                self.buckets.append((lo, hi))
+                hi, members = lo, []
+        assert self.buckets[-1][0] == 0 and ends[-1] <= n
+        self.sizes = [0] * len(self.buckets)
+        for b in self.bucket_of:
+            self.sizes[b] += 1
+        self.active = False
+        for i, p in enumerate(optimizer.params):
+            p.register_post_accumulate_grad_hook(self._make_hook(i))
+        self.launched_log = []     # bucket indices in launch order of the last step (tests)
+
+    def _make_hook(self, i):
+        def hook(_param):
+            if self.active:
+                b = self.bucket_of[i]
+                self.pending[b] -= 1
+                self._launch_ready()
+        return hook
+
+    def begin(self):
+        self.pending = list(self.sizes)
+        self.next = 0
+        self.handles = []
+        self.launched_log = []
+        self.active = True
+
+    def _launch(self, b):
+        lo, hi = self.buckets[b]
+        self.handles.append(_avg_inplace(self.opt.grad[lo:hi], async_op=True))
+        self.launched_log.append(b)
+
+    def _launch_ready(self):
+        while self.next < len(self.buckets) and self.pending[self.next] <= 0:
+            self._launch(self.next)
+            self.next += 1
+
+    def finish(self):
+        self.active = False
+        while self.next < len(self.buckets):
+            self._launch(self.next)
+            self.next += 1
+        for h in self.handles:
+            h.wait()
+        if dist.get_backend() != "nccl":
+            self.opt.grad.div_(world_size())
+        self.handles = []

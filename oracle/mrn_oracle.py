@@ -545,3 +545,42 @@ class AttnConverter:
 
     def decode(self, word_index, word_length):
         return ["".join(self.character[int(k)] for k in row[:int(n)]) for row, n in zip(word_index, word_length)]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# BASELINE config 5 extras: EWC Fisher / penalty (il_modules/ewc.py:120-167), LwF step loss (il_modules/lwf.py:63-87)
+# ---------------------------------------------------------------------------------------------------------
+def fisher_diagonal(grad_lists, fishermax=1e-4):
+    """getFisherDiagonal, il_modules/ewc.py:128-167: mean over iterations of the squared gradients, clipped at fishermax.
+    grad_lists: one list of per-parameter gradients per iteration."""
+    n = len(grad_lists)
+    out = []
+    for per_param in zip(*grad_lists):
+        f = sum(g.pow(2) for g in per_param) / n
+        out.append(torch.min(f, torch.tensor(fishermax)))
+    return out
+
+
+def fisher_blend(old, new, alpha=0.5):
+    """the positional blend of il_modules/ewc.py:48-55: new[i][:len(old[i])] = alpha * old[i] + (1 - alpha) * new[i][:len(old[i])]"""
+    out = [n.clone() for n in new]
+    for i, o in enumerate(old):
+        k = len(o)
+        out[i][:k] = alpha * o + (1 - alpha) * out[i][:k]
+    return out
+
+
+def ewc_penalty(fisher, params, mean):
+    """compute_ewc as written (il_modules/ewc.py:120-126) for matching keys: sum F * (p[:len(mean)] - mean)^2 / 2"""
+    loss = torch.zeros(())
+    for f, p, m in zip(fisher, params, mean):
+        loss = loss + torch.sum(f * (p[:len(m)] - m).pow(2)) / 2
+    return loss
+
+
+def lwf_step_loss(new_logits, old_logits, labels_index, labels_length, prediction, known, T=2.0, lamda=3.0):
+    """loss = lamda * KD(new[:, s:known], old[:, s:known]) + loss_clf with s = 0 (CTC) / 1 (Attn), il_modules/lwf.py:63-87"""
+    s = 0 if prediction == "CTC" else 1
+    kd = kd_loss(new_logits.reshape(-1, new_logits.shape[-1])[:, s:known], old_logits.reshape(-1, old_logits.shape[-1])[:, s:known], T)
+    clf = ctc_loss(new_logits, labels_index, labels_length) if prediction == "CTC" else attn_ce_loss(new_logits, labels_index)
+    return lamda * kd + clf, kd, clf

@@ -110,14 +110,18 @@ def build(kind, classes, seed):
     return opt, net
 
 
-def run(kind, classes, B, seed):
+def run(kind, classes, B, seed, noise=False):
+    """noise: U(-1,1) white-noise crops -- the distribution bench.py runs (mrn_amd/data/synthetic.py) -- instead of smooth ones"""
     d = {}
     opt, net = build(kind, classes, seed)
     I = len(classes)
     sd0 = net.state_dict()
     d["sd_keys"] = np.array(sorted(sd0.keys()))                      # pins the reference's state_dict layout
     d["sd_shapes"] = np.array([",".join(map(str, sd0[k].shape)) for k in sorted(sd0.keys())])
-    image = torch.from_numpy(W.smooth_image("input:image", (B, 4, 32, 256), seed))
+    if noise:
+        image = torch.from_numpy(W.uniform("input:image", (B, 4, 32, 256), -1.0, 1.0, seed))
+    else:
+        image = torch.from_numpy(W.smooth_image("input:image", (B, 4, 32, 256), seed))
     nspecial = 4 if kind in ("crnn", "svtr") else 5
     words, chars = words_for(B, classes[-1] - nspecial, seed)
     ctc = kind in ("crnn", "svtr")
@@ -321,6 +325,9 @@ if __name__ == "__main__":
         "trba_mrn3": lambda: run("trba", (41, 71, 98), 2, 2),
         "svtr_mrn3": lambda: run("svtr", (40, 70, 97), 2, 3),
         "crnn_der2": lambda: der("crnn", (40, 70), 2, 4),
+        "crnn_mrn3_noise": lambda: run("crnn", (40, 70, 97), 2, 1, noise=True),
+        "trba_mrn3_noise": lambda: run("trba", (41, 71, 98), 2, 2, noise=True),
+        "svtr_mrn3_noise": lambda: run("svtr", (40, 70, 97), 2, 3, noise=True),
         "converters": converters,
     }
     for name, fn in jobs.items():

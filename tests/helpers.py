@@ -51,9 +51,12 @@ def assert_close(name, a, b, atol=1e-4, rtol=1e-4):
     return err
 
 
-def det_inputs(kind, classes, B, seed):
+def det_inputs(kind, classes, B, seed, noise=False):
     """Same synthetic batch the golden generator used (tests/golden/make_golden.py: run())."""
-    image = torch.from_numpy(W.smooth_image("input:image", (B, 4, 32, 256), seed))
+    if noise:
+        image = torch.from_numpy(W.uniform("input:image", (B, 4, 32, 256), -1.0, 1.0, seed))
+    else:
+        image = torch.from_numpy(W.smooth_image("input:image", (B, 4, 32, 256), seed))
     nspecial = 4 if kind in ("crnn", "svtr") else 5
     nchar = classes[-1] - nspecial
     chars = "".join(chr(0x4E00 + i) for i in range(nchar))
@@ -84,3 +87,85 @@ def drop_masks(B, seed, tag, n_experts=1):
     """the DropPath draws the golden generator injected into the reference (tests/golden/make_golden.py)"""
     return [[torch.from_numpy(W.randint(f"droppath:{tag}:{e}:{k}", (B,), 0, 2, seed)).float() for k in range(22)]
             for e in range(n_experts)]
+
+
+class DetLoader:
+    """Deterministic stand-in for the reference's Dataset_Manager / Val_Dataset (data/data_manage.py:8-283): every batch is
+    a pure function of (tag, seed, call number), so the golden generator (driving the REFERENCE learners) and the tests
+    (driving the HIP learners) see byte-identical batches.  Labels are drawn over the characters set by set_characters();
+    `oov` appends a character outside every dictionary to the first label of each batch (the [UNK] path)."""
+
+    def __init__(self, B, tag, seed, noise=False, oov=False, n_valid=1):
+        self.B, self.tag, self.seed, self.noise, self.oov, self.n_valid = B, tag, seed, noise, oov, n_valid
+        self.chars = ""
+        self.count = 0
+        self.calls = []            # (method, args) log: lets tests assert how a learner drove the loader
+
+    def set_characters(self, chars):
+        self.chars = chars
+
+    def _batch(self, n):
+        name = f"{self.tag}:{n}"
+        if self.noise:
+            image = W.uniform(name + ":img", (self.B, 4, 32, 256), -1.0, 1.0, self.seed)
+        else:
+            image = W.smooth_image(name + ":img", (self.B, 4, 32, 256), self.seed)
+        lens = W.randint(name + ":len", (self.B,), 1, 26, self.seed)
+        labels = []
+        for b in range(self.B):
+            ids = W.randint(f"{name}:lab{b}", (int(lens[b]),), 0, len(self.chars), self.seed)
+            labels.append("".join(self.chars[i] for i in ids))
+        if self.oov:
+            labels[0] = (labels[0][:24] + "é")
+        return torch.from_numpy(image), labels
+
+    # -- Dataset_Manager interface -------------------------------------------------------------------------
+    def init_start(self, *a, **k):
+        self.calls.append(("init_start", a))
+
+    def get_dataset(self, taski, memory=None, index_list=None):
+        self.calls.append(("get_dataset", (taski, memory, None if index_list is None else [np.asarray(i).copy() for i in index_list])))
+        return index_list
+
+    def rehearsal_prev_model(self, taski):
+        self.calls.append(("rehearsal_prev_model", (taski,)))
+        return self, 500
+
+    def get_batch(self):
+        self.count += 1
+        return self._batch(self.count - 1)
+
+    def get_batch2(self):
+        image, labels = self.get_batch()
+        index = tuple(int(v) for v in W.randint(f"{self.tag}:{self.count - 1}:dom", (self.B,), 0, 2, self.seed))
+        return image, labels, [index]
+
+    # -- Val_Dataset interface -----------------------------------------------------------------------------
+    def create_dataset(self, val_data=None):
+        return [self._batch(10_000 + i) for i in range(self.n_valid)]
+
+    def create_list_dataset(self, valid_datas=None):
+        return self.create_dataset()
+
+
+class oracle_dtype:
+    """run the CPU oracle in another floating-point precision (float64: the exact-arithmetic yardstick for conditioning
+    bands): sets torch's default dtype and casts the oracle's TPS constants"""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        from oracle import mrn_oracle as O
+        self.O, self.old = O, O.tps_constants
+        dt = self.dtype
+        O.tps_constants = lambda *a: tuple(t.to(dt) for t in self.old(*a))
+        torch.set_default_dtype(dt)
+        return self
+
+    def __exit__(self, *exc):
+        torch.set_default_dtype(torch.float32)
+        self.O.tps_constants = self.old
+
+    def cast(self, sd):
+        return {k: (v.to(self.dtype) if v.is_floating_point() else v.clone()) for k, v in sd.items()}

@@ -1,0 +1,318 @@
+"""BASELINE config 5 on the GPU against fixtures produced by the REFERENCE learners (tests/golden/make_golden_il.py):
+LwF / EWC / DER flows over two tasks for the CRNN and the TRBA family, DERNet over two TRBA extractors, and a full-size
+property test of DERNet TRBA x 6 at B = 256.  Reference: il_modules/{base,lwf,ewc,der}.py, modules/model.py:203-312."""
+import contextlib
+import io
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from mrn_amd.tools import weights as W
+from tests.helpers import DetLoader, assert_close, assert_sub_close, assert_sub_l2, golden_state_dict, load_golden
+
+pytestmark = pytest.mark.gpu
+
+NCHARS = (36, 30)
+SEEDS = {"lwf": (21, 22), "ewc": (23, 24), "der": (25, 26)}
+
+
+def chars_upto(t):
+    return "".join(chr(0x4E00 + i) for i in range(sum(NCHARS[:t + 1])))
+
+
+def learner_opt(kind, num_iter=2):
+    o = types.SimpleNamespace(num_fiducial=20, imgH=32, imgW=256, input_channel=4, output_channel=512, hidden_size=256,
+                              batch_max_length=25, exp_name="g", il="x", memory=None, memory_num=2000, start_task=0,
+                              schedule="super", optimizer="adam", lr=0.00003, batch_size=2, num_iter=num_iter, val_interval=1000,
+                              grad_clip=5, lan_list=["A", "B"], NED=True, workers=0, manual_seed=111)
+    if kind == "crnn":
+        o.Transformation, o.FeatureExtraction, o.SequenceModeling, o.Prediction = "None", "VGG", "BiLSTM", "CTC"
+    else:
+        o.Transformation, o.FeatureExtraction, o.SequenceModeling, o.Prediction = "TPS", "ResNet", "BiLSTM", "Attn"
+    return o
+
+
+def hooked(cls, seeds):
+    """the same hooks the golden generator put on the reference learners: deterministic weights after (re)building"""
+    class Hooked(cls):
+        def build_model(self):
+            super().build_model()
+            W.fill_state_dict(self.model.state_dict(), seeds[0])
+
+        def change_model(self):
+            super().change_model()
+            W.fill_state_dict(self.model.state_dict(), seeds[1])
+    return Hooked
+
+
+def record(learner, name, out):
+    """wrap a step method so that its returned loss tensors are logged (what the reference feeds its Averagers)"""
+    fn = getattr(learner, name)
+
+    def wrapped(*a, **k):
+        r = fn(*a, **k)
+        out.append(tuple(float(v.detach()) for v in (r if isinstance(r, tuple) else (r,))))
+        return r
+    setattr(learner, name, wrapped)
+
+
+def rel_close(a, b, rtol):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert np.all(np.abs(a - b) <= rtol * np.maximum(1.0, np.abs(b))), (a, b)
+
+
+@pytest.mark.parametrize("kind", ["crnn", "trba"])
+@pytest.mark.parametrize("which", ["lwf", "ewc", "der"])
+def test_il_flow_vs_reference(tmp_path, kind, which):
+    """Two tasks of LwF / EWC / DER driven through incremental_train() / after_task() exactly like the reference learners
+    were when the fixture was generated: per-iteration losses, KD terms, Fisher diagonals (incl. the positional blend of
+    task 1), the reference's identically-zero EWC penalty, weight_align gamma, parameter movement, checkpoints written."""
+    from mrn_amd.il_modules.der import DER
+    from mrn_amd.il_modules.ewc import EWC
+    from mrn_amd.il_modules.lwf import LwF
+    g = load_golden(f"il_{kind}")
+    pre = which + "/"
+    os.chdir(tmp_path)
+    opt = learner_opt(kind)
+    cls = {"lwf": LwF, "ewc": EWC, "der": DER}[which]
+    seeds = SEEDS[which]
+    train = DetLoader(2, f"il:{kind}:{which}", 31)
+    valid = DetLoader(2, f"il:{kind}:{which}:val", 32)
+    sink = io.StringIO()
+    steps, kd_vals, ewc_vals = [], [], []
+    with contextlib.redirect_stdout(sink):
+        learner = hooked(cls, seeds)(opt)
+        if which == "ewc":
+            learner.fisher_iterations = 2
+        record(learner, "train_step", steps)
+        if which == "lwf":
+            record(learner, "kd_step", steps)
+        if which == "ewc":
+            record(learner, "ewc_step", steps)
+            orig = learner.compute_ewc
+
+            def compute():
+                v = orig()
+                ewc_vals.append(float(v))
+                return v
+            learner.compute_ewc = compute
+        if which == "der":
+            record(learner, "der_step", steps)
+        for taski in range(2):
+            chars = chars_upto(taski)
+            train.set_characters(chars)
+            valid.set_characters(chars)
+            n0 = len(steps)
+            learner.incremental_train(taski, chars, train, valid)
+            got = steps[n0:]
+            ref = g[f"{pre}t{taski}/losses"]
+            # --- per-iteration losses (iteration 2 has seen one clipped Adam step) ---
+            if which == "der" and taski == 1:
+                mine = np.array([[clf, clf, aux] for clf, aux in got]).reshape(-1)      # Averagers: loss, loss_clf, loss_aux
+            elif which == "lwf" and taski == 1:
+                mine = np.array([s[0] for s in got])
+                rel_close([s[1] for s in got], g[pre + "t1/kd"], 2e-4)
+            else:
+                mine = np.array([s[0] for s in got])
+            rel_close(mine, ref, 2e-4)
+            # --- parameter movement of the task's optimiser steps ---
+            sd = {k.replace("module.", ""): v for k, v in learner.model.state_dict().items()}
+            for k in [str(s) for s in g[f"{pre}t{taski}/param_keys"]]:
+                init = torch.from_numpy(W.det_param(W.canonical_key(k), tuple(sd[k].shape), seeds[taski])).to(sd[k].device)
+                name = f"{pre}t{taski}/delta/{k}"
+                if float(np.abs(g[name + "/sub"]).max()) == 0.0:
+                    assert float((sd[k] - init).abs().max()) == 0.0, k      # frozen (DER's old extractor)
+                    continue
+                moved = (sd[k] - init).detach().cpu().double().numpy().reshape(-1)
+                step_ = max(1, moved.size // 1024)
+                s = moved[::step_][:1024]
+                r = g[name + "/sub"].astype(np.float64)
+                # Adam normalises every element's update to ~lr, so elements whose gradient is ~0 move with an essentially
+                # random sign (fp32 conditioning, see tests/helpers.py::assert_sub_l2): compare in L2 terms
+                l2 = np.linalg.norm(s - r) / max(np.linalg.norm(r), 1e-30)
+                assert l2 <= (0.5 if kind == "trba" else 0.1), (k, l2)
+            if which == "ewc":
+                fk = [str(s) for s in g[f"{pre}t{taski}/fisher_keys"]]
+                assert list(learner.fisher.keys()) == fk
+                total = sum(float(v.double().sum()) for v in learner.fisher.values())
+                rel_close(total, g[f"{pre}t{taski}/fisher_total"], 5e-2 if kind == "trba" else 5e-3)
+                for k in [str(s) for s in g[f"{pre}t{taski}/param_keys"]]:
+                    f = learner.fisher["module." + k]
+                    assert float(f.max()) <= 1e-4 + 1e-12 and float(f.min()) >= 0.0
+                    ref_f = g[f"{pre}t{taski}/fisher/{k}/sub"].astype(np.float64)
+                    a = f.detach().cpu().double().numpy().reshape(-1)
+                    step_ = max(1, a.size // 4096)
+                    a = a[::step_][:4096]
+                    l2 = np.linalg.norm(a - ref_f) / max(np.linalg.norm(ref_f), 1e-30)
+                    assert l2 <= (0.35 if kind == "trba" else 0.02), (k, l2)      # (TRBA: grad^2 of fp32-ill-conditioned backbone gradients after two optimiser steps, cf. test_loop_a_trba_gradients_vs_oracle; the step-free Fisher is pinned at 0.1 below)
+            learner.after_task()
+            assert learner._known_classes == int(g[f"{pre}t{taski}/known_classes"])
+            if which == "lwf" and taski == 0:
+                W.fill_state_dict(learner._old_network.state_dict(), 27)
+                assert learner._old_network.training == bool(g[pre + "old_network_training"])
+    if which == "ewc":
+        # reference quirk: Fisher keys carry "module.", compute_ewc looks names up without it -> the penalty is exactly 0
+        assert ewc_vals == [float(v) for v in g[pre + "t1/compute_ewc"]] == [0.0, 0.0]
+    if which == "der":
+        gam = [float(l.split("=")[1]) for l in sink.getvalue().splitlines() if l.startswith("alignweights,gamma=")]
+        rel_close(gam, g[pre + "t1/weight_align_gamma"], 1e-4)
+        ref_keys = {str(k): str(s) for k, s in zip(g[pre + "sd_keys"], g[pre + "sd_shapes"])}
+        assert {k: ",".join(map(str, v.shape)) for k, v in learner.model.state_dict().items()} == ref_keys
+    assert sink.getvalue().count("Current_score") == int(g[pre + "n_valid_calls"])
+    assert sorted(os.listdir(f"./saved_models/{opt.exp_name}")) == [str(s) for s in g[pre + "checkpoints"]]
+
+
+@pytest.mark.parametrize("kind", ["crnn", "trba"])
+def test_fisher_diagonal_vs_reference(tmp_path, kind):
+    """EWC.getFisherDiagonal (ewc.py:128-167) on a freshly filled model: mean of squared gradients over 2 batches, clipped at 1e-4
+    -- a pure function of the seeds (no optimiser step before it)"""
+    from mrn_amd.il_modules.ewc import EWC
+    g = load_golden(f"il_{kind}")
+    os.chdir(tmp_path)
+    opt = learner_opt(kind)
+    with contextlib.redirect_stdout(io.StringIO()):
+        learner = hooked(EWC, (41, 42))(opt)
+        learner.fisher_iterations = 2
+        learner.character = chars_upto(0)
+        learner.converter = learner.build_converter()
+        learner.criterion = learner.build_criterion()
+        learner.build_model()
+        learner.build_optimizer(learner.count_param())
+        loader = DetLoader(2, f"il:{kind}:fisher", 33)
+        loader.set_characters(chars_upto(0))
+        fisher = learner.getFisherDiagonal(loader)
+    assert [k.replace("module.", "") for k in fisher] == [str(s) for s in g["fisher0/all_keys"]]
+    total = sum(float(v.double().sum()) for v in fisher.values())
+    rel_close(total, g["fisher0/total"], 3e-2 if kind == "trba" else 2e-3)
+    for k in [str(s) for s in g["fisher0/keys"]]:
+        ref = g[f"fisher0/{k}/sub"].astype(np.float64)
+        a = fisher["module." + k].detach().cpu().double().numpy().reshape(-1)
+        step_ = max(1, a.size // 4096)
+        a = a[::step_][:4096]
+        l2 = np.linalg.norm(a - ref) / max(np.linalg.norm(ref), 1e-30)
+        assert l2 <= (0.1 if kind == "trba" else 0.01), (k, l2)
+
+
+def build_dernet(opt, classes, seed=None, sd=None):
+    from mrn_amd.modules.model import DERNet
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = DERNet(opt)
+        for c in classes:
+            net.update_fc(opt.hidden_size, c)
+            net.build_prediction(opt, c)
+            net.build_aux_prediction(opt, c)
+    if sd is not None:
+        net.load_state_dict(sd, strict=True)
+    else:
+        W.fill_state_dict(net.state_dict(), seed)
+    return net.cuda()
+
+
+def test_trba_dernet_vs_reference():
+    """DERNet over two TRBA extractors (BASELINE config 5's model at N = 2): state_dict layout, teacher-forced logits /
+    auxiliary logits / concatenated features in DER's training configuration (old extractor eval, new one train), the two
+    losses of a DER step, the clipped gradient norm and head gradients, greedy eval logits + argmax (bit-exact)"""
+    from mrn_amd import functional as Fn
+    from mrn_amd import ops
+    from mrn_amd.tools.utils import AttnLabelConverter
+    g = load_golden("trba_der2")
+    opt = learner_opt("trba")
+    classes, seed, B = (41, 71), 8, 2
+    net = build_dernet(opt, classes, sd=golden_state_dict(g, seed))
+    ref = {str(k): str(s) for k, s in zip(g["sd_keys"], g["sd_shapes"])}
+    assert {k: ",".join(map(str, v.shape)) for k, v in net.state_dict().items()} == ref
+    loader = DetLoader(B, "trba_der2", seed)
+    loader.set_characters(chars_upto(1))
+    image, words = loader.get_batch()
+    with contextlib.redirect_stdout(io.StringIO()):
+        conv = AttnLabelConverter(chars_upto(1))
+    labels_index, _ = conv.encode(words, batch_max_length=25)
+    assert np.array_equal(labels_index.cpu().numpy(), g["labels_index"])
+    for ext in list(net.model)[:-1]:
+        for p in ext.parameters():
+            p.requires_grad = False
+    net.train()
+    net.model[0].eval()
+    out = net(image.cuda(), labels_index[:, :-1])
+    assert_sub_close(g, "features", out["features"], atol=1e-4)
+    assert_sub_close(g, "logits", out["logits"], atol=1e-4)
+    assert_sub_close(g, "aux_logits", out["aux_logits"], atol=1e-4)
+    loss_clf = Fn.cross_entropy(out["logits"], labels_index[:, 1:], 1)
+    loss_aux = Fn.cross_entropy(out["aux_logits"].detach(), labels_index[:, 1:], 1)
+    assert abs(loss_clf.item() - float(g["loss_clf"])) < 1e-4 * max(1.0, float(g["loss_clf"]))
+    assert abs(loss_aux.item() - float(g["loss_aux"])) < 1e-4 * max(1.0, float(g["loss_aux"]))
+    loss_clf.backward()
+    grads = [p.grad for p in net.parameters() if p.grad is not None]
+    norm = torch.sqrt(sum((gr.double() ** 2).sum() for gr in grads)).item()
+    assert abs(norm - float(g["grad_norm"])) <= 2e-2 * float(g["grad_norm"])       # (TRBA backbone gradients: fp32 conditioning)
+    for k in ("fc.weight", "Prediction.attention_cell.i2h.weight", "Prediction.attention_cell.rnn.weight_ih",
+              "model.1.SequenceModeling.1.linear.weight"):
+        assert_sub_close(g, f"grad/{k}", net.get_parameter(k).grad, atol=1e-7, rtol=5e-3)
+    assert all(p.grad is None or float(p.grad.abs().max()) == 0.0 for p in net.aux_Prediction.attention_cell.parameters())
+    net.load_state_dict(golden_state_dict(g, seed), strict=True)
+    net.eval()
+    with torch.no_grad():
+        sos = torch.LongTensor(B).fill_(conv.dict["[SOS]"]).cuda()
+        oe = net(image.cuda(), sos, False)
+    assert_sub_close(g, "eval/logits", oe["logits"], atol=1e-4)
+    assert np.array_equal(ops.argmax_lastdim(oe["logits"]).cpu().numpy(), g["eval/argmax"])
+
+
+def test_full_size_dernet_trba6_properties():
+    """BASELINE config 5 at full size: DERNet over SIX TRBA extractors, 256 images -- five frozen extractors in lock-step
+    (grouped x3 convolutions, eval-mode BatchNorm) + the newest one, main attention head over the 1536-wide concatenation.
+    Size-independent properties: (1) lock-step frozen extractors == per-extractor path; (2) each extractor's slice of
+    `features` equals that extractor run alone; (3) the auxiliary head sees exactly the newest 256 channels; (4) a DER step
+    moves only the newest extractor and the heads, and the frozen extractors' BatchNorm statistics do not move."""
+    from mrn_amd import functional as Fn
+    opt = learner_opt("trba")
+    classes = (2091, 2311, 4039, 5199, 5272, 5374)
+    B = 256
+    image = torch.from_numpy(W.uniform("full_der", (B, 4, 32, 256), -1.0, 1.0, 3)).cuda()
+    text = torch.from_numpy(W.randint("full_der_text", (B, 27), 4, classes[-1], 3)).cuda()
+    text[:, 0] = 2
+    feats = []
+    for grouping in (True, False):
+        net = build_dernet(opt, classes, seed=29)
+        for ext in list(net.model)[:-1]:
+            for p in ext.parameters():
+                p.requires_grad = False
+        net.train()
+        for ext in list(net.model)[:-1]:
+            ext.eval()
+        net.expert_grouping = grouping
+        with torch.no_grad():
+            o = net(image, text[:, :-1])
+        torch.cuda.synchronize()
+        assert tuple(o["features"].shape) == (B, 65, 1536) and tuple(o["logits"].shape) == (B, 26, classes[-1])
+        feats.append((o["features"].clone(), o["logits"].clone(), o["aux_logits"].clone()))
+        if grouping:
+            keep = net
+        else:
+            del net
+    assert_close("full-size DER features (lock-step vs per extractor)", feats[0][0], feats[1][0], atol=2e-4, rtol=1e-4)
+    assert_close("full-size DER logits", feats[0][1], feats[1][1], atol=2e-4, rtol=1e-4)
+    net = keep
+    with torch.no_grad():
+        alone = net.model[2](image)                                   # one frozen extractor on its own
+        assert_close("extractor 2 slice", feats[0][0][:, :, 512:768], alone, atol=2e-4, rtol=1e-4)
+        aux = net.aux_Prediction(feats[0][0][:, :, -256:].contiguous(), text[:, :-1], True, batch_max_length=25)
+        assert_close("aux head = newest 256 channels", aux, feats[0][2], atol=1e-5, rtol=1e-5)
+    # one DER step at full size
+    from mrn_amd.optim import FlatAdam
+    frozen_before = {k: v.clone() for k, v in net.state_dict().items() if k.startswith(("model.0.", "model.3."))}
+    adam = FlatAdam([p for p in net.parameters() if p.requires_grad], lr=5e-4)
+    adam.zero_grad()
+    out = net(image, text[:, :-1])
+    loss = Fn.cross_entropy(out["logits"], text[:, 1:], 1)
+    loss.backward()
+    nc = adam.step(lr=2.5e-5, max_norm=5.0)
+    assert torch.isfinite(loss).item() and torch.isfinite(nc).all().item() and float(nc[0]) > 0
+    after = net.state_dict()
+    for k, v in frozen_before.items():
+        assert torch.equal(v, after[k]), k
+    assert float((net.aux_fc.weight.grad if net.aux_fc.weight.grad is not None else torch.zeros(1)).abs().max()) == 0.0

@@ -16,7 +16,10 @@ from tests.helpers import (assert_close, assert_sub_close, assert_sub_l2, det_in
 pytestmark = pytest.mark.gpu
 
 CASES = {"crnn_mrn3": ("crnn", (40, 70, 97), 2, 1), "trba_mrn3": ("trba", (41, 71, 98), 2, 2),
-         "svtr_mrn3": ("svtr", (40, 70, 97), 2, 3)}
+         "svtr_mrn3": ("svtr", (40, 70, 97), 2, 3),
+         # the same cases on U(-1,1) white-noise crops, the distribution bench.py runs (no TPS stage: the 1e-4 band holds;
+         # TRBA on noise: test_trba_noise_inside_reference_band)
+         "crnn_mrn3_noise": ("crnn", (40, 70, 97), 2, 1), "svtr_mrn3_noise": ("svtr", (40, 70, 97), 2, 3)}
 
 
 def set_drop_masks(net, kind, B, seed, tag, experts):
@@ -72,7 +75,7 @@ def test_expert_forward_vs_golden(name):
     kind, classes, B, seed = CASES[name]
     g = load_golden(name)
     opt, net = build_net(kind, classes, g, seed)
-    image, words, chars, _ = det_inputs(kind, classes, B, seed)
+    image, words, chars, _ = det_inputs(kind, classes, B, seed, noise=name.endswith("_noise"))
     conv, labels_index, labels_length = labels_for(kind, words, chars)
     assert np.array_equal(labels_index.cpu().numpy(), g["labels_index"])
     image = image.cuda()
@@ -157,7 +160,7 @@ def test_loop_b_two_steps_vs_golden(name):
     kind, classes, B, seed = CASES[name]
     g = load_golden(name)
     opt, net = build_net(kind, classes, g, seed)
-    image, words, chars, domain = det_inputs(kind, classes, B, seed)
+    image, words, chars, domain = det_inputs(kind, classes, B, seed, noise=name.endswith("_noise"))
     conv, labels_index, labels_length = labels_for(kind, words, chars)
     image, domain, labels_index, labels_length = image.cuda(), domain.cuda(), labels_index.cuda(), labels_length.cuda()
     net.train()
@@ -200,6 +203,140 @@ def test_loop_b_two_steps_vs_golden(name):
         # two Adam steps move every element by <= ~5e-5 (2 x lr); where a gradient element is near zero the
         # normalised update m/sqrt(v) has an essentially random sign, so compare in L2 / quantile terms
         assert_sub_l2(g, f"stepB/delta2/{n}", p.detach() - b)
+
+
+def test_trba_noise_inside_reference_band():
+    """TRBA x 3 loop-B forward on U(-1,1) white noise (bench.py's input distribution) against the reference's own output AND
+    against exact arithmetic.  The TPS grid is an ill-conditioned fp32 sum (the CPU side of this claim is
+    tests/test_oracle_golden.py::test_trba_tps_conditioning_smooth_vs_noise): on noise the REFERENCE's fp32 result is `band`
+    (several 1e-3) away from the float64 result, so no fp32 implementation can be asked for 1e-4 against it.  Required here:
+    the HIP path is as close to exact arithmetic as the reference is (within 2x its band), therefore within 3x band of the
+    reference; the routing argmax is bit-exact (the float64 top-2 margin is far above the band)."""
+    from oracle import mrn_oracle as O
+    from tests.helpers import oracle_dtype, sub
+    kind, classes, B, seed = "trba", (41, 71, 98), 2, 2
+    g = load_golden("trba_mrn3_noise")
+    opt, net = build_net(kind, classes, g, seed)
+    image, words, chars, _ = det_inputs(kind, classes, B, seed, noise=True)
+    conv, labels_index, _ = labels_for(kind, words, chars)
+    with oracle_dtype(torch.float64) as od, torch.no_grad():
+        out64 = O.mrn_forward(od.cast(golden_state_dict(g, seed)), O.Cfg("TPS", "ResNet", "BiLSTM", "Attn"), 3, image.double(), True,
+                              labels_index.cpu()[:, :-1], True, training=True)
+    w64, l64 = out64["index"].numpy(), sub(out64["logits"])[0].astype(np.float64)
+    band_w = np.abs(g["stepB/weights"] - w64).max()
+    band_l = np.abs(g["stepB/logits/sub"] - l64).max()
+    assert band_w > 1e-3 and band_l > 1e-3           # the premise: the reference itself is > 1e-3 from exact arithmetic here
+    net.train()
+    with torch.no_grad():
+        out = net(image.cuda(), True, labels_index[:, :-1].cuda(), True)
+    w = out["index"].cpu().double().numpy()
+    lg = sub(out["logits"])[0].astype(np.float64)
+    assert np.abs(w - w64).max() <= 2 * band_w, (np.abs(w - w64).max(), band_w)
+    assert np.abs(lg - l64).max() <= 2 * band_l, (np.abs(lg - l64).max(), band_l)
+    assert np.abs(w - g["stepB/weights"]).max() <= 3 * band_w and np.abs(lg - g["stepB/logits/sub"]).max() <= 3 * band_l
+    top2 = np.sort(w64, axis=1)[:, ::-1]
+    assert (top2[:, 0] - top2[:, 1]).min() > 10 * band_w
+    assert np.array_equal(w.argmax(1), g["stepB/weights"].argmax(1)) and np.array_equal(w.argmax(1), w64.argmax(1))
+    # eval routing (hard argmax + per-sample expert selection + greedy decode): indices bit-exact against the reference
+    net.load_state_dict(golden_state_dict(g, seed), strict=True)
+    net.eval()
+    with torch.no_grad():
+        oe = net(image.cuda(), True, torch.LongTensor(B).fill_(2).cuda(), False)
+    assert np.array_equal(oe["index"].cpu().numpy(), g["eval/index"])
+    assert np.array_equal(oe["logits"].max(2)[1].cpu().numpy(), g["eval/argmax"])
+
+
+def test_full_size_trba6_loop_b_properties():
+    """The headline workload itself (bench.py: TRBA x 6 experts, 256 crops, class counts 2091...5374) as a test: the production
+    schedule -- six experts in two lock-step half-groups on two HIP streams, split-fp16 x3 convolutions, the frozen-expert
+    forward issued ahead through MRNNet.experts_prefetch -- against the plainest one: expert after expert, exact-fp32 MFMA
+    everywhere.  Smooth crops: tight agreement; U(-1,1) noise (the bench's distribution): agreement inside the TPS conditioning
+    band.  Size-independent properties: routing weights row-stochastic, prefetched == direct bit for bit, BatchNorm running
+    statistics advanced identically, one loop-B optimiser step moves router parameters only."""
+    from mrn_amd import functional as Fn
+    from mrn_amd import ops
+    from mrn_amd.modules.model import MRNNet
+    from mrn_amd.optim import FlatAdam
+    from mrn_amd.tools import weights as W
+    opt = make_opt("trba")
+    classes = (2091, 2311, 4039, 5199, 5272, 5374)
+    B = 256
+
+    def build():
+        with contextlib.redirect_stdout(io.StringIO()):
+            net = MRNNet(opt)
+            for c in classes:
+                net.update_fc(256, c)
+                net.build_prediction(opt, c)
+        W.fill_state_dict(net.state_dict(), seed=31)
+        net = net.cuda().train()
+        for e in net.model:
+            for p in e.parameters():
+                p.requires_grad = False
+        return net
+
+    text = torch.from_numpy(W.randint("full_text", (B, 27), 4, classes[-1], 3)).cuda()
+    text[:, 0] = 2
+    for kind, tol_w, tol_l in (("smooth", 5e-4, 2e-3), ("noise", 3e-2, 1e-1)):
+        if kind == "smooth":
+            image = torch.from_numpy(W.smooth_image("full_trba", (B, 4, 32, 256), 3)).cuda()
+        else:
+            image = torch.from_numpy(W.uniform("full_trba", (B, 4, 32, 256), -1.0, 1.0, 3)).cuda()
+        net = build()
+        with torch.no_grad():
+            handle = net.experts_prefetch(image, text[:, :-1], True)
+            assert handle is not None and len(handle["parts"]) == 2
+            fast = net(image, True, text[:, :-1], True, experts=handle)
+        torch.cuda.synchronize()
+        bn_fast = {k: v.clone() for k, v in net.state_dict().items() if "running_" in k}
+        w_fast, l_fast = fast["index"].clone(), fast["logits"].clone()
+        assert_close("routing weights sum to 1", w_fast.sum(1), torch.ones(B), atol=1e-5)
+        assert torch.isfinite(l_fast).all()
+        # the same schedule without the look-ahead: bit-identical
+        net2 = build()
+        with torch.no_grad():
+            direct = net2(image, True, text[:, :-1], True)
+        assert torch.equal(direct["index"], w_fast) and torch.equal(direct["logits"], l_fast)
+        del net2
+        # plain schedule, exact fp32
+        net3 = build()
+        net3.expert_grouping = False
+        net3.expert_streams = False
+        old = ops.CONV_PRECISION
+        try:
+            ops.CONV_PRECISION = "f32"
+            with torch.no_grad():
+                plain = net3(image, True, text[:, :-1], True)
+        finally:
+            ops.CONV_PRECISION = old
+        torch.cuda.synchronize()
+        dw = (plain["index"] - w_fast).abs()
+        dl = (plain["logits"] - l_fast).abs()
+        assert float(dw.max()) <= tol_w and float(dl.max()) <= tol_l, (kind, float(dw.max()), float(dl.max()))
+        assert float(dw.mean()) <= tol_w / 10 and float(dl.mean()) <= tol_l / 20, (kind, float(dw.mean()), float(dl.mean()))
+        agree = float((plain["index"].argmax(1) == w_fast.argmax(1)).float().mean())
+        assert agree >= (1.0 if kind == "smooth" else 0.97), (kind, agree)
+        for k, v in net3.state_dict().items():
+            if "running_" in k:
+                assert_close(k, bn_fast[k], v, atol=1e-5 if kind == "smooth" else 1e-3, rtol=1e-3)
+        del net3
+        if kind == "noise":
+            # one full loop-B step (il_modules/mrn.py:329-371) at full size
+            for n, p in net.named_parameters():
+                p.requires_grad = not n.startswith("model.")
+            before = {n: p.detach().clone() for n, p in net.named_parameters()}
+            adam = FlatAdam([p for p in net.parameters() if p.requires_grad], lr=5e-4)
+            adam.zero_grad()
+            out = net(image, True, text[:, :-1], True)
+            domain = torch.from_numpy(W.randint("full_dom", (B,), 0, 2, 3)).cuda()
+            loss = 15 * Fn.cross_entropy(out["logits"], text[:, 1:], 1) + Fn.cross_entropy(out["index"], domain, -100)
+            loss.backward()
+            nc = adam.step(lr=2.5e-5, max_norm=5.0)
+            assert torch.isfinite(loss).item() and float(nc[0]) > 0
+            for n, p in net.named_parameters():
+                moved = not torch.equal(before[n], p.detach())
+                assert moved == (not n.startswith("model.") and n != "route.bias" or (n == "route.bias" and moved)), n
+        del net
 
 
 def _grad_check(name, mine, ref, rel_l2=2e-3, rel_max=2e-3):

@@ -8,7 +8,10 @@ from oracle import mrn_oracle as O
 from tests.helpers import assert_close, assert_sub_close, det_inputs, drop_masks, golden_state_dict, load_golden
 
 CASES = {"crnn_mrn3": ("crnn", (40, 70, 97), 2, 1), "trba_mrn3": ("trba", (41, 71, 98), 2, 2),
-         "svtr_mrn3": ("svtr", (40, 70, 97), 2, 3)}
+         "svtr_mrn3": ("svtr", (40, 70, 97), 2, 3),
+         # the same cases on U(-1,1) white-noise crops: the distribution bench.py runs
+         "crnn_mrn3_noise": ("crnn", (40, 70, 97), 2, 1), "trba_mrn3_noise": ("trba", (41, 71, 98), 2, 2),
+         "svtr_mrn3_noise": ("svtr", (40, 70, 97), 2, 3)}
 
 
 def cfg_for(kind):
@@ -49,7 +52,7 @@ def test_expert_forward_train_and_eval(name):
     kind, classes, B, seed = CASES[name]
     g = load_golden(name)
     cfg = cfg_for(kind)
-    image, words, chars, _ = det_inputs(kind, classes, B, seed)
+    image, words, chars, _ = det_inputs(kind, classes, B, seed, noise=name.endswith("_noise"))
     ctc = kind != "trba"
     conv = O.CTCConverter(chars) if ctc else O.AttnConverter(chars)
     labels_index, labels_length = conv.encode(words, 25)
@@ -104,7 +107,7 @@ def test_loop_b_two_steps(name):
     kind, classes, B, seed = CASES[name]
     g = load_golden(name)
     cfg = cfg_for(kind)
-    image, words, chars, domain = det_inputs(kind, classes, B, seed)
+    image, words, chars, domain = det_inputs(kind, classes, B, seed, noise=name.endswith("_noise"))
     conv = O.CTCConverter(chars) if kind != "trba" else O.AttnConverter(chars)
     labels_index, labels_length = conv.encode(words, 25)
     text = None if kind != "trba" else labels_index[:, :-1]
@@ -146,7 +149,7 @@ def test_loop_a_forward_loss(name):
     kind, classes, B, seed = CASES[name]
     g = load_golden(name)
     cfg = cfg_for(kind)
-    image, words, chars, _ = det_inputs(kind, classes, B, seed)
+    image, words, chars, _ = det_inputs(kind, classes, B, seed, noise=name.endswith("_noise"))
     conv = O.CTCConverter(chars) if kind != "trba" else O.AttnConverter(chars)
     labels_index, labels_length = conv.encode(words, 25)
     with torch.no_grad():
@@ -175,3 +178,34 @@ def test_dernet_forward_kd_and_weight_align():
         assert abs(kd.item() - float(g["kd_loss"])) < 1e-5
         gamma = O.weight_align_gamma(sd["fc.weight"], 30)
         assert abs(gamma.item() - float(g["weight_align_gamma"])) < 1e-5
+
+
+def test_trba_tps_conditioning_smooth_vs_noise():
+    """DESIGN.md section 2, as a test: the TPS grid P_hat (inv_delta_C C') is an ill-conditioned fp32 sum, so the REFERENCE's own
+    fp32 outputs sit a distance `band` away from exact (float64) arithmetic, and that band depends on the image content:
+    ~1e-4 on smooth crops, tens of times more on U(-1,1) white noise (the sampler multiplies the ~1e-5 grid error by the image
+    gradient).  Consequences pinned here: (1) the fp32 oracle reproduces the reference to round-off on BOTH distributions;
+    (2) on noise no fp32 implementation -- the reference included -- is within 1e-4 of exact arithmetic, so TRBA parity on
+    noise is judged against this band (tests/test_model_gpu.py::test_trba_noise_inside_reference_band); (3) the routing argmax
+    is decided by margins far above the band."""
+    from tests.helpers import oracle_dtype, sub
+    cfg = cfg_for("trba")
+    bands = {}
+    for name in ("trba_mrn3", "trba_mrn3_noise"):
+        kind, classes, B, seed = CASES[name]
+        g = load_golden(name)
+        image, words, chars, _ = det_inputs(kind, classes, B, seed, noise=name.endswith("_noise"))
+        li, _ = O.AttnConverter(chars).encode(words, 25)
+        with oracle_dtype(torch.float64) as od, torch.no_grad():
+            out = O.mrn_forward(od.cast(golden_state_dict(g, seed)), cfg, 3, image.double(), True, li[:, :-1], True, training=True)
+        w64, l64 = out["index"], out["logits"]
+        band_w = float(np.abs(g["stepB/weights"] - w64.numpy()).max())
+        band_l = float(np.abs(g["stepB/logits/sub"] - sub(l64)[0]).max())
+        top2 = torch.sort(w64, dim=1, descending=True)[0]
+        margin = float((top2[:, 0] - top2[:, 1]).min())
+        bands[name] = (band_w, band_l, margin)
+        assert np.array_equal(w64.argmax(1).numpy(), g["stepB/weights"].argmax(1))
+        assert margin > 20 * band_w
+    (sw, sl, _), (nw, nl, _) = bands["trba_mrn3"], bands["trba_mrn3_noise"]
+    assert sw < 3e-4 and sl < 3e-4                       # smooth crops: the reference is ~1e-4 from exact arithmetic
+    assert nw > 1e-3 and nl > 1e-3 and nw > 10 * sw      # white noise: the reference itself is > 1e-3 away
