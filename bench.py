@@ -84,9 +84,21 @@ def build_learner(opt, n_experts, quiet=True):
     return learner
 
 
-def cpu_baseline(learner, opt, n_experts, batch=16, iters=1, max_threads=32):
+def cpu_model_string():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(learner, opt, n_experts, batch=32, iters=3, max_threads=32, budget_s=40.0):
     """The CPU oracle (oracle/mrn_oracle.py, validated against the reference by tests/test_oracle_golden.py) on a bounded
-    sample of the same workload: loop B at a smaller batch, all host threads."""
+    sample of the same workload, as SURVEY.md section 8d planned it: loop B at batch 32, 1 warm-up + 3 timed iterations, all
+    host threads (capped: more threads only add synchronisation overhead at this size)."""
     from oracle import mrn_oracle as O
     from mrn_amd.data.synthetic import SyntheticTextLines
     torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), max_threads)))   # more threads only add sync overhead at this size
@@ -100,7 +112,7 @@ def cpu_baseline(learner, opt, n_experts, batch=16, iters=1, max_threads=32):
     data = SyntheticTextLines(o2, device=torch.device("cpu"))
     data.set_characters(learner.character)
     conv = O.CTCConverter(learner.character) if opt.Prediction == "CTC" else O.AttnConverter(learner.character)
-    times = []
+    times, spent = [], 0.0
     for it in range(iters + 1):
         image, labels, idx = data.get_batch2()
         domain = torch.LongTensor(idx).squeeze()
@@ -117,13 +129,17 @@ def cpu_baseline(learner, opt, n_experts, batch=16, iters=1, max_threads=32):
         with torch.no_grad():
             O.clip_and_adam(params, grads, state, 2.5e-5, it + 1)
         dt = time.time() - t0
+        spent += dt
         if it > 0:
             times.append(dt)
-        elif dt > 45.0:          # keep the default run within minutes: a slow host reports its (cold) first iteration
+        elif dt > budget_s:      # keep the default run within minutes: a slow host reports its (cold) first iteration
             times.append(dt)
+            break
+        if spent + dt > budget_s and times:
             break
     sec = sum(times) / len(times)
     return {"value": batch / sec, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "cpu": cpu_model_string(),
             "sample": f"{len(times)} timed iteration(s) (+1 warm-up) of the same loop B at batch {batch}, fp32, torch-CPU oracle"}
 
 

@@ -324,6 +324,9 @@ int mrn_gather2d_f32(const float* in, int64_t ld_in, const int* row_idx, const i
                      int64_t ld_out, int R, int C, void* stream);
 /* first index of the row maximum (preds.max(2), test.py:211; greedy decode prediction.py:84) */
 int mrn_argmax_f32(const float* x, int64_t ld, int64_t* out, int64_t rows, int C, void* stream);
+/* greedy decode + confidence in one pass (test.py:211,218-219: preds.max(2); F.softmax(preds, 2).max(2)): idx = first argmax,
+   prob = softmax(row)[argmax] */
+int mrn_argmax_prob_f32(const float* x, int64_t ld, int64_t* idx, float* prob, int64_t rows, int C, void* stream);
 
 /* ---- MRN fan-in and gate tail (modules/model.py:361-423) --------------------------------------------------- */
 

@@ -293,6 +293,35 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ x
   if (lane == 0) out[row] = bi;
 }
 
+// greedy decoding + confidence in one pass (reference test.py:211,218-219: preds.max(2) and F.softmax(preds, 2).max(2)):
+// idx[row] = first argmax, prob[row] = softmax(x[row])[argmax] = 1 / sum_c exp(x[c] - max).  One wave per row.
+__global__ __launch_bounds__(256) void argmax_prob_kernel(const float* __restrict__ x, long ld, int64_t* __restrict__ idx,
+                                                          float* __restrict__ prob, long rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int c = lane; c < C; c += 64) {
+    const float v = x[row * ld + c];
+    if (v > best || (v != v && best == best)) { best = v; bi = c; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o);
+    const int oi = __shfl_xor(bi, o);
+    const bool take = (ov > best) || (ov == best && oi < bi) || (ov != ov && best == best);
+    if (take) { best = ov; bi = oi; }
+  }
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += expf(x[row * ld + c] - best);
+  s = wave_sum(s);
+  if (lane == 0) {
+    idx[row] = bi;
+    prob[row] = 1.f / s;
+  }
+}
+
 // In-place row softmax of s[b][i][:] (N columns) with an optional additive mask[i][:] shared by all b:
 // softmax(q k^T + mask) of SVTR's Local mixing (modules/svtr.py:140-146).  One wave per row, N <= 1024.
 __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s, const float* __restrict__ mask, long rows,
@@ -486,6 +515,15 @@ MRN_EXPORT int mrn_argmax_f32(const float* x, int64_t ld, int64_t* out, int64_t 
   hipLaunchKernelGGL(argmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, (long)ld, out,
                      (long)rows, C);
   MRN_LAUNCH_CHECK("argmax");
+  return MRN_OK;
+}
+
+MRN_EXPORT int mrn_argmax_prob_f32(const float* x, int64_t ld, int64_t* idx, float* prob, int64_t rows, int C, void* stream) {
+  MRN_CHECK_ARG(x && idx && prob && C > 0, "mrn_argmax_prob_f32: bad operands");
+  if (rows == 0) return MRN_OK;
+  hipLaunchKernelGGL(argmax_prob_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, (long)ld, idx,
+                     prob, (long)rows, C);
+  MRN_LAUNCH_CHECK("argmax_prob");
   return MRN_OK;
 }
 

@@ -270,6 +270,7 @@ class BaseLearner(object):
         if current_score > best_score:
             best_score = current_score
             self.save_checkpoint(taski, step)
+        ned_score = 0.0 if ned_score is None else ned_score
         lr = self.optimizer.param_groups[0]["lr"]
         log = (f"\n[{iteration}/{opt.num_iter}] Train_loss: {float(train_loss_avg.val()):0.5f}, Valid_loss: {float(valid_loss):0.5f}\n"
                f'{"":9s}Current_score: {current_score:0.2f}, Ned_score: {ned_score:0.2f}\n'

@@ -710,6 +710,15 @@ def argmax_lastdim(x):
     return out.view(x.shape[:-1])
 
 
+def argmax_prob_lastdim(x):
+    """(first argmax, softmax probability of it) along the last dim -- greedy decoding + confidence in one pass"""
+    x2 = rows2d(x)
+    idx = torch.empty(x2.shape[0], device=x.device, dtype=torch.int64)
+    prob = torch.empty(x2.shape[0], device=x.device, dtype=torch.float32)
+    call("mrn_argmax_prob_f32", _p(x2), x2.stride(0), _p(idx), _p(prob), x2.shape[0], x2.shape[1], _stream())
+    return idx.view(x.shape[:-1]), prob.view(x.shape[:-1])
+
+
 def layernorm_fwd(x, gamma, beta, eps=1e-5, out=None):
     """LayerNorm over the last dim of (strided) rows -> (y, mean, rstd)"""
     x2 = rows2d(x)

@@ -353,51 +353,88 @@ def trba_der2():
 
 
 def validation_fixture():
-    """reference test.py:139-279 on a CTC model and an Attn model: accuracy / NED / confidence / decoded strings, with an
-    out-of-dictionary label character, predictions with and without [EOS] (Attn) and an empty prediction"""
+    """reference test.py:139-279 (validation) on hand-made logits (tests/helpers.py::crafted_validation_case: every scoring
+    branch) and on real models (a CRNN and a TRBA recogniser with deterministic weights): loss / accuracy / normalised edit
+    distance / decoded strings / confidences."""
     from modules.model import Model
+    from tools.utils import AttnLabelConverter, CTCLabelConverter
+    from tests.helpers import crafted_validation_case
     d = {}
-    for kind, classes, seed in (("crnn", 40, 51), ("trba", 41, 52)):
+    for kind in ("crnn", "trba"):
         opt = make_opt(kind)
         opt.NED = True
+        chars, batches, logits = crafted_validation_case(kind)
+        with contextlib.redirect_stdout(io.StringIO()):
+            conv = CTCLabelConverter(chars) if kind == "crnn" else AttnLabelConverter(chars)
+        crit = torch.nn.CTCLoss(zero_infinity=True) if kind == "crnn" else torch.nn.CrossEntropyLoss(ignore_index=conv.dict["[PAD]"])
+        calls = iter(logits)
+        stub = lambda image, *a, **k: {"predict": next(calls), "feature": None}        # noqa: E731
+        preds_all, conf_all = [], []
+        with torch.no_grad(), contextlib.redirect_stderr(io.StringIO()):
+            loss, acc, ned, preds, conf, labels, _, n = ref_test.validation(stub, crit, batches, conv, opt)
+            # per-batch results too (the reference returns the strings / confidences of the LAST batch only)
+            for i in range(len(batches)):
+                one = iter([logits[i]])
+                r = ref_test.validation(lambda image, *a, **k: {"predict": next(one), "feature": None}, crit, [batches[i]], conv, opt)
+                d[f"crafted/{kind}/batch{i}/accuracy"], d[f"crafted/{kind}/batch{i}/ned"] = np.float64(r[1]), np.float64(r[2])
+                d[f"crafted/{kind}/batch{i}/loss"] = np.float64(float(r[0]))
+                d[f"crafted/{kind}/batch{i}/preds"] = np.array(list(r[3]))
+                d[f"crafted/{kind}/batch{i}/confidence"] = np.array([float(c) for c in r[4]], dtype=np.float64)
+        pre = f"crafted/{kind}/"
+        d[pre + "valid_loss"], d[pre + "accuracy"], d[pre + "ned"] = np.float64(float(loss)), np.float64(acc), np.float64(ned)
+        d[pre + "preds_last_batch"] = np.array(list(preds))
+        d[pre + "confidence_last_batch"] = np.array([float(c) for c in conf], dtype=np.float64)
+        d[pre + "labels_last_batch"] = np.array(list(labels))
+        d[pre + "length"] = np.int64(n)
+        print(kind, "crafted: acc", acc, "ned", ned, [str(p)[:30] for p in preds], [float(c) for c in conf])
+        # ---- a real model: forward path + decoding + scoring together ----
+        classes = 40 if kind == "crnn" else 41
+        seed = 51 if kind == "crnn" else 52
         with contextlib.redirect_stdout(io.StringIO()):
             net = Model(opt)
             net.update_fc(opt.hidden_size, classes)
             net.build_prediction(opt, classes)
         W.fill_state_dict(net.state_dict(), seed)
+        with torch.no_grad():
+            net.fc.weight *= 60.0             # make the argmax depend on the input instead of on the head's bias
         net.eval()
-        chars = chars_upto(0)
-        from tools.utils import AttnLabelConverter, CTCLabelConverter
-        with contextlib.redirect_stdout(io.StringIO()):
-            conv = CTCLabelConverter(chars) if kind == "crnn" else AttnLabelConverter(chars)
-        if kind == "trba":
-            # make [EOS] win at some decoding steps of some samples: predictions with an [EOS] (pruned there), without one
-            # (the reference then drops the LAST character: prd[:find] with find = -1) and empty ones
-            with torch.no_grad():
-                net.fc.bias[conv.dict["[EOS]"]] += EOS_BIAS
-            crit = torch.nn.CrossEntropyLoss(ignore_index=conv.dict["[PAD]"])
-        else:
-            crit = torch.nn.CTCLoss(zero_infinity=True)
         loader = DetLoader(3, f"validation:{kind}", seed, oov=True, n_valid=2)
         loader.set_characters(chars)
-        batches = loader.create_dataset()
-        # batch 2: labels = the model's own predictions on it, so that some words count as correct
-        with torch.no_grad():
-            r = ref_test.validation(net, crit, batches[1:], conv, opt)
-        batches[1] = (batches[1][0], [s for s in r[3]])
-        if kind == "trba":
-            batches[1] = (batches[1][0], [s[:s.find("[EOS]")] if "[EOS]" in s else s[:-1] for s in r[3]])
-        with torch.no_grad():
-            loss, acc, ned, preds, conf, labels, _, n = ref_test.validation(net, crit, batches, conv, opt)
-        d[f"{kind}/labels_batch1"] = np.array(list(batches[1][1]))
-        d[f"{kind}/valid_loss"] = np.float64(float(loss))
-        d[f"{kind}/accuracy"], d[f"{kind}/ned"] = np.float64(acc), np.float64(ned)
-        d[f"{kind}/preds_last_batch"] = np.array(list(preds))
-        d[f"{kind}/confidence_last_batch"] = np.array([float(c) for c in conf], dtype=np.float64)
-        d[f"{kind}/labels_last_batch"] = np.array(list(labels))
-        d[f"{kind}/length"] = np.int64(n)
-        print(kind, "acc", acc, "ned", ned, "preds", [p[:12] for p in preds], "conf", [float(c) for c in conf])
-    d["eos_bias"] = np.float64(EOS_BIAS)
+        real = loader.create_dataset()
+        with torch.no_grad(), contextlib.redirect_stderr(io.StringIO()):
+            loss, acc, ned, preds, conf, labels, _, n = ref_test.validation(net, crit, real, conv, opt)
+        pre = f"model/{kind}/"
+        d[pre + "valid_loss"], d[pre + "accuracy"], d[pre + "ned"] = np.float64(float(loss)), np.float64(acc), np.float64(ned)
+        d[pre + "preds_last_batch"] = np.array(list(preds))
+        d[pre + "confidence_last_batch"] = np.array([float(c) for c in conf], dtype=np.float64)
+        d[pre + "length"] = np.int64(n)
+        print(kind, "model: acc", acc, "ned", ned, "loss", float(loss), [float(c) for c in conf])
+    return d
+
+
+def rehearsal_fixture():
+    """index bookkeeping of the rehearsal memory (il_modules/base.py:278-302, il_modules/mrn.py:168-181): the memory_index lists the
+    REFERENCE learners build over four tasks from a seeded numpy RNG, and what they hand to train_loader.get_dataset()"""
+    import il_modules.mrn as ref_mrn
+    d = {}
+    for name, cls, memory_num in (("base", ref_base.BaseLearner, 2000), ("mrn", ref_mrn.MRN, 2000), ("mrn_large", ref_mrn.MRN, 6000)):
+        opt = learner_opt("crnn")
+        opt.memory, opt.memory_num, opt.il = "random", memory_num, "mrn"
+        with contextlib.redirect_stdout(io.StringIO()):
+            learner = cls(opt)
+            loader = DetLoader(2, "rehearsal", 1)
+            loader.dataset_len = 9000
+            loader.rehearsal_prev_model = lambda taski: (loader, 9000 - 1000 * taski)
+            np.random.seed(1234)
+            for taski in range(1, 4):
+                learner.build_rehearsal_memory(loader, taski)
+                d[f"{name}/t{taski}/lengths"] = np.array([len(i) for i in learner.memory_index], dtype=np.int64)
+                d[f"{name}/t{taski}/checksums"] = np.array([int(np.asarray(i, dtype=np.int64).sum()) for i in learner.memory_index], dtype=np.int64)
+            for i, idx in enumerate(learner.memory_index):
+                d[f"{name}/final/memory_index/{i}"] = np.asarray(idx).astype(np.int32)
+        calls = [c for c in loader.calls if c[0] == "get_dataset"]
+        d[f"{name}/get_dataset_memory_args"] = np.array([str(c[1][1]) for c in calls])
+        d[f"{name}/get_dataset_index_checksums"] = np.array([sum(int(i.sum()) for i in c[1][2]) for c in calls], dtype=np.int64)
     return d
 
 
@@ -416,6 +453,7 @@ if __name__ == "__main__":
         "il_crnn": lambda: il_fixture("crnn"),
         "il_trba": lambda: il_fixture("trba"),
         "validation": validation_fixture,
+        "rehearsal": rehearsal_fixture,
     }
     for name, fn in jobs.items():
         if args.only and args.only != name:

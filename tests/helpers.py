@@ -169,3 +169,56 @@ class oracle_dtype:
 
     def cast(self, sd):
         return {k: (v.to(self.dtype) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+
+
+def crafted_validation_case(kind):
+    """Two evaluation batches with hand-made logits for validation() (reference test.py:139-279): every scoring branch is hit --
+    exact match, a wrong character (fractional normalised edit distance), an out-of-dictionary label character ([UNK] never
+    counts as correct), an empty prediction, an empty ground truth and, for the attention head, predictions with an [EOS]
+    (pruned there) and without one (the reference then drops the LAST character: prd[:prd.find('[EOS]')] with find = -1).
+    Returns (chars, batches [(image, labels)], logits [tensor [B,T,C]]): the stub model returns logits[i] for batch i."""
+    chars = "".join(chr(0x4E00 + i) for i in range(36))
+    ctc = kind == "crnn"
+    T, C = (63, 40) if ctc else (26, 41)
+    first = 4 if ctc else 5                                  # index of chars[0] in the converters' tables
+
+    def ids(word):
+        return [first + chars.index(c) for c in word]
+
+    def attn_row(tokens):                                    # tokens then [EOS]=3 ... ; None = no [EOS] anywhere
+        return (tokens + [3] + [first] * T)[:T]
+
+    def ctc_row(tokens):                                     # every character twice, blanks between characters, then blanks
+        seq = []
+        for t in tokens:
+            seq += [t, t, 0]
+        return (seq + [0] * T)[:T]
+
+    w = [chars[:5], chars[3:12], chars[7:9], chars[10:14] + "é", chars[20:23], ""]
+    batches, logits = [], []
+    for bi in range(2):
+        labels = [w[(i + 3 * bi) % len(w)] for i in range(3)] if bi == 0 else [w[3], w[4], w[5]]
+        rows = []
+        for si, word in enumerate(labels):
+            tok = [first + chars.index(c) if c in chars else (2 if ctc else 0) for c in word]          # [UNK] = 2 (CTC) / 0 (Attn)
+            case = (bi, si)
+            if case == (0, 1):                               # one wrong character
+                tok = tok[:2] + [first + 30] + tok[3:]
+            if ctc:
+                if case == (0, 2):
+                    tok = []                                 # all blanks: empty prediction
+                rows.append(ctc_row(tok))
+            else:
+                if case == (0, 2):
+                    rows.append(attn_row([]))                # [EOS] first: empty prediction
+                elif case == (1, 1):
+                    rows.append(([first + 1, first + 2] * T)[:T])      # no [EOS] at all
+                else:
+                    rows.append(attn_row(tok))
+        tgt = torch.tensor(rows, dtype=torch.long)           # [B,T]
+        lg = torch.from_numpy(W.uniform(f"crafted:{kind}:{bi}", (len(labels), T, C), -1.0, 1.0, 77))
+        lg.scatter_add_(2, tgt.unsqueeze(2), torch.full((len(labels), T, 1), 4.0))
+        image = torch.zeros(len(labels), 4, 32, 256)
+        batches.append((image, labels))
+        logits.append(lg)
+    return chars, batches, logits

@@ -132,6 +132,68 @@ def test_data_parallel_helpers_gloo_world2(tmp_path):
     assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists(), r.stdout + r.stderr
 
 
+WORKER_BUCKETS = r"""
+import os, sys, torch
+sys.path.insert(0, os.environ["MRN_ROOT"])
+from mrn_amd import parallel
+from mrn_amd.optim import FlatAdam
+rank, world, local = parallel.init_distributed(backend="gloo")
+torch.manual_seed(100 + rank)                       # replicas start DIFFERENT: broadcast_module must equalise them
+net = torch.nn.Sequential(torch.nn.Linear(40, 64), torch.nn.BatchNorm1d(64), torch.nn.ReLU(), torch.nn.Linear(64, 64),
+                          torch.nn.ReLU(), torch.nn.Linear(64, 7))
+net[1].running_mean.add_(rank + 1.0)
+net[1].num_batches_tracked.add_(3 * rank + 1)
+unused = torch.nn.Parameter(torch.randn(33))         # a trainable parameter that never gets a gradient (router at task 0)
+net.register_parameter("unused", unused)
+parallel.broadcast_module(net)
+state = torch.cat([t.reshape(-1).double() for t in list(net.parameters()) + list(net.buffers())])
+both = [torch.zeros_like(state) for _ in range(2)]
+torch.distributed.all_gather(both, state)
+assert torch.equal(both[0], both[1]), "parameters / buffers differ after broadcast_module"
+assert int(net[1].num_batches_tracked) == 1
+opt = FlatAdam(list(net.parameters()), lr=1e-3)
+red = parallel.BucketedAllReduce(opt, bucket_bytes=4 * 2000)     # several buckets
+assert len(red.buckets) >= 3 and red.buckets[0][1] == opt.grad.numel() and red.buckets[-1][0] == 0
+for step in range(2):
+    torch.manual_seed(7 + 10 * step + rank)         # per-rank shards
+    x, y = torch.randn(16, 40), torch.randn(16, 7)
+    opt.zero_grad()
+    red.begin()
+    loss = ((net(x) - y) ** 2).mean()
+    loss.backward()
+    local_grad = None
+    red.finish()
+    assert red.launched_log == list(range(len(red.buckets))), red.launched_log      # in order, every bucket exactly once
+    g = opt.grad.clone()
+    both = [torch.zeros_like(g) for _ in range(2)]
+    torch.distributed.all_gather(both, g)
+    assert torch.equal(both[0], both[1]), "averaged gradients differ between ranks"
+    # the average really is the mean of the two ranks' local gradients
+    opt.zero_grad()
+    ((net(x) - y) ** 2).mean().backward()
+    mine = opt.grad.clone()
+    both = [torch.zeros_like(mine) for _ in range(2)]
+    torch.distributed.all_gather(both, mine)
+    assert torch.allclose(g, (both[0] + both[1]) / 2, atol=1e-7)
+    assert float(opt.view_of(g, [i for i, q in enumerate(opt.params) if q is unused][0]).abs().max()) == 0.0   # unused parameter: zeros travel
+parallel.barrier()
+open(os.path.join(os.environ["MRN_OUT"], f"bok_{rank}"), "w").write("ok")
+"""
+
+
+def test_bucketed_all_reduce_and_module_broadcast_gloo_world2(tmp_path):
+    """parallel.BucketedAllReduce (gradient buckets launched from post-accumulate hooks, in bucket order on every rank) and
+    parallel.broadcast_module (parameters AND buffers from rank 0) on two CPU ranks"""
+    script = tmp_path / "worker_buckets.py"
+    script.write_text(WORKER_BUCKETS)
+    env = dict(os.environ, MRN_ROOT=ROOT, MRN_OUT=str(tmp_path), MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29541", str(script)],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert (tmp_path / "bok_0").exists() and (tmp_path / "bok_1").exists(), r.stdout + r.stderr
+
+
 def _opt(trans, feat, seq, pred):
     return types.SimpleNamespace(Transformation=trans, FeatureExtraction=feat, SequenceModeling=seq, Prediction=pred,
                                  num_fiducial=20, imgH=32, imgW=256, input_channel=4, output_channel=512, hidden_size=256,

@@ -666,3 +666,36 @@ def test_first_conv_c4_grouped(ops, G, B, H, W, Cout, shared, act):
         tot = stats[g].double().sum(0).cpu()
         assert_close("sum", tot[0].float(), pre.double().sum((0, 2, 3)).float(), atol=2e-2, rtol=1e-4)
         assert_close("sum of squares", tot[1].float(), (pre.double() ** 2).sum((0, 2, 3)).float(), atol=2e-2, rtol=1e-4)
+
+
+def test_sgd_and_adadelta_steps_vs_torch():
+    """FlatSGD / FlatAdadelta (mrn_sgd_step_f32 / mrn_adadelta_step_f32) against torch.optim.SGD(momentum, weight_decay) and
+    torch.optim.Adadelta(rho, eps) with clip_grad_norm_ in front -- the other two optimisers of il_modules/base.py:72-85"""
+    from mrn_amd.optim import FlatAdadelta, FlatSGD
+    g = torch.Generator().manual_seed(5)
+    shapes = [(37, 5), (130,), (4, 3, 3, 3)]
+    init = [torch.randn(*s, generator=g) for s in shapes]
+    grads = [[torch.randn(*s, generator=g) * 3 for s in shapes] for _ in range(3)]
+    for kind in ("sgd", "adadelta"):
+        ref_p = [torch.nn.Parameter(t.clone()) for t in init]
+        mine_p = [torch.nn.Parameter(t.clone().cuda()) for t in init]
+        if kind == "sgd":
+            ref = torch.optim.SGD(ref_p, lr=0.05, momentum=0.9, weight_decay=1e-3)
+            mine = FlatSGD(mine_p, 0.05, momentum=0.9, weight_decay=1e-3)
+        else:
+            ref = torch.optim.Adadelta(ref_p, lr=1.0, rho=0.95, eps=1e-8)
+            mine = FlatAdadelta(mine_p, 1.0, rho=0.95, eps=1e-8)
+        for it in range(3):
+            for p, q, gr in zip(ref_p, mine_p, grads[it]):
+                p.grad = gr.clone()
+                q.grad.copy_(gr)
+            total = torch.nn.utils.clip_grad_norm_(ref_p, 5.0)
+            ref.step()
+            v0 = mine_p[0]._version
+            nc = mine.step(lr=0.05 if kind == "sgd" else 1.0, max_norm=5.0, momentum=0.8 if (kind == "sgd" and it == 2) else None)
+            assert mine_p[0]._version > v0                       # raw-pointer update is announced to torch (repack caches)
+            assert abs(float(nc[0]) - float(total)) <= 1e-5 * float(total)
+            if kind == "sgd" and it == 2:                        # OneCycle-cycled momentum: torch reads param_groups each step
+                break
+            for p, q in zip(ref_p, mine_p):
+                assert_close(f"{kind} step {it}", q.detach(), p.detach(), atol=1e-6, rtol=1e-5)

@@ -98,3 +98,38 @@ def test_prefetched_expert_forward_is_bit_identical(tmp_path):
         results.append((losses, flat, bn))
     assert results[0][0] == results[1][0]
     assert torch.equal(results[0][1], results[1][1]) and torch.equal(results[0][2], results[1][2])
+
+
+def test_mrn_resume_from_checkpoints(tmp_path):
+    """opt.start_task (reference base.py:178-195, mrn.py:187-203): tasks below it skip training and load the checkpoints the
+    earlier run wrote ({lan}_{taski}_{step}_best_score.pth); the resumed learner ends with the trained learner's parameters"""
+    from mrn_amd.data.synthetic import SyntheticTextLines, SyntheticValidation, synthetic_characters
+    from mrn_amd.il_modules.mrn import MRN
+    os.chdir(tmp_path)
+    states = []
+    for start_task in (0, 2):
+        opt = make_opt(tmp_path, "crnn")
+        opt.start_task = start_task
+        torch.manual_seed(0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            learner = MRN(opt)
+            train, valid = SyntheticTextLines(opt), SyntheticValidation(opt)
+            chars = ""
+            for taski, n_new in enumerate((30, 20)):
+                chars = synthetic_characters(len(chars) + n_new)
+                train.set_characters(chars)
+                valid.set_characters(chars)
+                learner.incremental_train(taski, chars, train, valid)
+                if start_task == 2:
+                    assert learner.opt_step == 0                  # nothing was trained
+                learner.after_task()
+        states.append({k: v.detach().clone() for k, v in learner.model.state_dict().items()})
+        if start_task == 0:
+            assert sorted(f for f in os.listdir("./saved_models/t") if f.endswith(".pth")) == \
+                ["A_0_0_best_score.pth", "B_1_0_best_score.pth", "B_1_1_best_score.pth"]
+        else:
+            assert not any(p.requires_grad for p in learner.model.model[-1].parameters())     # what update_step1 leaves behind
+    trained, resumed = states
+    assert trained.keys() == resumed.keys()
+    for k in trained:
+        assert torch.equal(trained[k], resumed[k]), k
