@@ -154,8 +154,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--verbose", action="store_true")
-    ap.add_argument("--precision", default="auto", choices=["auto", "f32", "fp16x3", "bf16x3", "fp16", "bf16"],
-                    help="conv arithmetic (mrn_amd/ops.py: CONV_PRECISION); auto keeps the 1e-4 parity band")
+    ap.add_argument("--precision", default="auto", choices=["auto", "f32", "fp16x3", "bf16x3", "fp16"],
+                    help="arithmetic of the frozen experts' convolutions / Linear layers: auto = split-fp16 x3 (22-bit products, keeps "
+                         "the 1e-4 parity band: the headline); fp16 = ONE fp16 product per term on the same grouped kernels (the "
+                         "reduced-precision mode of BASELINE configs 2 and 5: a separate line, never the headline); f32 / bf16x3: "
+                         "the per-expert kernels (mrn_amd/ops.py: CONV_PRECISION)")
     ap.add_argument("--no-streams", action="store_true", help="run the experts sequentially on one stream")
     ap.add_argument("--no-pipeline", action="store_true", help="do not issue batch n+1's expert forward before batch n's router phase")
     ap.add_argument("--serial", action="store_true", help="one lock-step group on one stream, no look-ahead (every kernel runs alone)")
@@ -173,7 +176,10 @@ def main():
     torch.cuda.set_device(local)
     torch.manual_seed(111)
 
-    ops.CONV_PRECISION = args.precision
+    if args.precision == "fp16":
+        ops.X3_PRODUCTS = 1
+    else:
+        ops.CONV_PRECISION = args.precision
     opt = make_opt(args.model, args.batch)
     learner = build_learner(opt, args.experts, quiet=not args.verbose)
     learner.model.module.expert_streams = not args.no_streams
@@ -245,9 +251,11 @@ def main():
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "host_issue_ms_per_step": host_elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"auto": "f32 (convs with Cout>64 as split-fp16 x3 MFMA products, 22-bit significand, fp32 accumulate)",
-                      "f32": "f32", "fp16x3": "fp16x3 (split-fp16 MFMA, fp32 accumulate)",
-                      "bf16x3": "bf16x3 (split-bf16 MFMA, fp32 accumulate)", "bf16": "bf16", "fp16": "fp16"}[ops.CONV_PRECISION],
+            "dtype": "fp16 (one fp16 MFMA product per term, fp32 accumulate and fp32 storage: reduced-precision mode, NOT the headline)"
+            if ops.X3_PRODUCTS == 1 else
+            {"auto": "f32 (convs with Cout>64 as split-fp16 x3 MFMA products, 22-bit significand, fp32 accumulate)",
+             "f32": "f32", "fp16x3": "fp16x3 (split-fp16 MFMA, fp32 accumulate)",
+             "bf16x3": "bf16x3 (split-bf16 MFMA, fp32 accumulate)"}[ops.CONV_PRECISION],
             "data": "synthetic",
             "config": {"workload": f"MRN loop B (router phase): {args.model.upper()} x {args.experts} frozen experts "
                                    f"(train-mode BN) + DM-Router fwd/bwd + clip + Adam, 32x256x4 crops, random-init weights",
@@ -265,8 +273,10 @@ def main():
                 if staging.startswith("x3g"):
                     tile = staging[3:]
                     targs = {"256x256": "4, 4, 2, 2", "256x128": "4, 2, 2, 2", "128x128": "4, 2, 1, 2", "256x64": "8, 1, 1, 2"}[tile]
-                    return (f"conv_x3_kernel<{targs}> (grouped {tile}x32 implicit-GEMM conv / Linear over all experts, fp16x3 "
-                            f"on v_mfma_f32_32x32x16_f16, HL32 operands staged by buffer_load...lds)", BF16_MFMA_PEAK_TFLOPS, 3)
+                    nprod = 3 if arith == "fp16x3" else 1
+                    return (f"conv_x3_kernel<{targs}{', false, 1' if nprod == 1 else ''}> (grouped {tile}x32 implicit-GEMM conv / Linear over "
+                            f"all experts, {arith} on v_mfma_f32_32x32x16_f16, HL32 operands staged by buffer_load...lds)",
+                            BF16_MFMA_PEAK_TFLOPS, nprod)
                 nsplit = 3 if arith.endswith("x3") else 1
                 kern = "conv_bf16_dma_kernel" if staging == "dma" else "conv_bf16_kernel"
                 half = "true" if arith.startswith("fp16") else "false"

@@ -84,11 +84,13 @@ int mrn_split_weight_bf16(const float* w, void* hi, void* lo, int64_t n, int hal
  * expert's slice of the router's [B][P][I][C] feature tensor.  x_group_div > 1: group g reads activation group g / x_group_div.  With H = W = kh = kw = 1 this is a grouped Linear layer
  * (nn.Linear sites of modules/sequence_modeling.py:10,19-22 and modules/prediction.py:58-68,104-107).
  * y_hl32 (optional, Cout % 32 == 0, dense rows): the result also (y != NULL) or only (y == NULL) as the HL32 operand of the
- * next GEMM -- fc1 + GELU -> fc2 of the SVTR Mlp (modules/svtr.py:46-67) without an operand-split pass in between. */
+ * next GEMM -- fc1 + GELU -> fc2 of the SVTR Mlp (modules/svtr.py:46-67) without an operand-split pass in between.
+ * products: 3 = split-fp16 x3 (22-bit products, the 1e-4 parity mode); 1 = hi x hi only: plain fp16 products with fp32
+ * accumulation, the reduced-precision mode BASELINE configs 2 ("bf16") and 5 ("fp16 MFMA") ask for. */
 int mrn_conv2d_x3_hl32(const void* x_hl, const void* w_hl, const void* zero_page, const float* bias,
                        const float* residual, float* y, float* stats, const float* out_scale, const float* x_scale, int G, int64_t x_group_stride_bytes, int B, int H, int W,
                        int Cin, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int act, int tile_m, int tile_n,
-                       int64_t y_row_stride, int64_t y_group_stride, int x_group_div, void* y_hl32, void* stream);
+                       int64_t y_row_stride, int64_t y_group_stride, int x_group_div, void* y_hl32, int products, void* stream);
 int64_t mrn_conv2d_x3_stats_floats(int G, int B, int Ho, int Wo, int Cout, int tile_m);
 int mrn_split_hl32_f32(const float* x, void* out, int64_t rows, int C, const float* scale, void* stream);
 /* transposed split for weight-gradient GEMMs (dW = dy^T x reduces over rows): x[rows][C] -> [splits][C][rows/splits/32][128 B],
@@ -316,6 +318,10 @@ int mrn_svtr_attention_bwd_f32(const float* qkv, const float* mask, const float*
 int mrn_residual_scale_rows_f32(const float* x, const float* branch, const float* scale, float* y, int64_t rows, int C,
                                 int64_t rows_per_group, void* stream);
 /* out[c] (+)= sum_r in[r][c] (bias / affine gradients, split-K combine); workspace: chunks*C floats */
+/* BatchNorm batch statistics of a tensor that is not a conv output (RCNN extractor: BN over gated products,
+ * modules/feature_extraction.py:146-161): part [mrn_bn_stats_blocks(rows)][2][C] partial sums / sums of squares of x [rows][C] */
+int64_t mrn_bn_stats_blocks(int64_t rows);
+int mrn_bn_stats_f32(const float* x, int64_t rows, int C, float* part, void* stream);
 int64_t mrn_colsum_chunks(int64_t rows, int C);
 int mrn_colsum_f32(const float* in, int64_t ld, float* out, float* workspace, int64_t rows, int C, int accumulate,
                    void* stream);

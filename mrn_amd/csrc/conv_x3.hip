@@ -70,6 +70,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const unsigned char*
 }
 
 __device__ __forceinline__ f32x16 mma(const u32x4 a, const u32x4 b, const f32x16 c) {
+#ifdef MRN_PROBE_NO_MFMA
+  f32x16 r = c;                 // (what-if probe, never in the product build: the staging floor without matrix work)
+  r[0] += __builtin_bit_cast(float, a[0] ^ b[0]);
+  return r;
+#endif
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16v8*>(&a), *reinterpret_cast<const f16v8*>(&b), c, 0, 0, 0);
 }
 
@@ -98,7 +103,9 @@ __device__ __forceinline__ int row_to_pixel(const ConvX3Params& p, int m, int& o
 }
 
 // WAVES_M x WAVES_N waves; wave tile = (WM*32) x (WN*32); HL_OUT: the epilogue can also write the HL32 result (p.y_hl)
-template <int WAVES_M, int WAVES_N, int WM, int WN, bool HL_OUT = false>
+// NPROD: 3 = split-fp16 x3 (lo*hi + hi*lo + hi*hi, 22-bit products: the parity mode); 1 = hi*hi only (plain fp16 products with fp32
+// accumulation -- the reduced-precision mode of BASELINE configs 2 and 5; the lo halves of the staged lines are not read)
+template <int WAVES_M, int WAVES_N, int WM, int WN, bool HL_OUT = false, int NPROD = 3>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const ConvX3Params p) {
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
@@ -214,12 +221,18 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
     const int tap = it_tap, cb = it_cb;
     const int ky = fast_div(tap, p.kw_magic, p.kw_shift), kx = tap - ky * p.kw;
     const int aoff = ((ky * p.W + kx) * p.Cb + cb) * 128;
+#ifdef MRN_PROBE_NO_DMA_A
+    if (it_cb == 0 && tap == __builtin_ctz(active))      // (what-if probe, never in the product build: activations staged once)
+#endif
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int voff = ((amask[i] >> tap) & 1u) ? arow[i] + aoff : (int)0x80000000;
       dma16(xr, st + (i * NW + wave) * 1024, voff, 0);
     }
     const int boff = (cb * p.taps + tap) * 128;
+#ifdef MRN_PROBE_NO_DMA_B
+    if (it_cb == 0 && tap == __builtin_ctz(active))      // (what-if probe, never in the product build: weights staged once)
+#endif
 #pragma unroll
     for (int i = 0; i < NB; ++i) dma16(wr, st + BM * 128 + (i * NW + wave) * 1024, brow[i], boff);
   };
@@ -245,27 +258,32 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
 
   u32x4 ah[2][WM], al[2][WM], bh[2][WN], bl[2][WN];
   auto read_frags = [&](const unsigned char* cur, int ks) {
+#ifdef MRN_PROBE_NO_DSREAD
+    if (it_cb > 0 || it_rem != active) return;          // (what-if probe, never in the product build: fragments read once)
+#endif
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
-      al[ks][i] = *reinterpret_cast<const u32x4*>(cur + abase + i * 4096 + foff[1][ks]);
+      if constexpr (NPROD == 3) al[ks][i] = *reinterpret_cast<const u32x4*>(cur + abase + i * 4096 + foff[1][ks]);
       ah[ks][i] = *reinterpret_cast<const u32x4*>(cur + abase + i * 4096 + foff[0][ks]);
     }
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
       bh[ks][j] = *reinterpret_cast<const u32x4*>(cur + bbase + j * 4096 + foff[0][ks]);
-      bl[ks][j] = *reinterpret_cast<const u32x4*>(cur + bbase + j * 4096 + foff[1][ks]);
+      if constexpr (NPROD == 3) bl[ks][j] = *reinterpret_cast<const u32x4*>(cur + bbase + j * 4096 + foff[1][ks]);
     }
   };
   auto mmas = [&](int ks) {
     // consecutive MFMAs target different accumulators
+    if constexpr (NPROD == 3) {
 #pragma unroll
-    for (int i = 0; i < WM; ++i)
+      for (int i = 0; i < WM; ++i)
 #pragma unroll
-      for (int j = 0; j < WN; ++j) acc[i][j] = mma(al[ks][i], bh[ks][j], acc[i][j]);
+        for (int j = 0; j < WN; ++j) acc[i][j] = mma(al[ks][i], bh[ks][j], acc[i][j]);
 #pragma unroll
-    for (int i = 0; i < WM; ++i)
+      for (int i = 0; i < WM; ++i)
 #pragma unroll
-      for (int j = 0; j < WN; ++j) acc[i][j] = mma(ah[ks][i], bl[ks][j], acc[i][j]);
+        for (int j = 0; j < WN; ++j) acc[i][j] = mma(ah[ks][i], bl[ks][j], acc[i][j]);
+    }
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -277,7 +295,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
   // 410 TFLOP/s; a 3-stage ring with counted vmcnt + raw s_barrier on the 256x128 tile +2.7 %, which does not fit the
   // 160 KiB LDS at 256x256; single-stage 256x128 tiles with 4 waves and two workgroups per CU (occupancy instead of
   // software pipelining) 451 vs 478 TFLOP/s for the 256x256 double-buffered tile.)
-  if constexpr (NW == 16) {
+  if constexpr (NW == 16 && NPROD == 3) {
     // 16 waves x 64x64 (four waves per SIMD: 128 VGPRs each): only the hi x hi third of a K-step's second half is carried
     // across the barrier (16 fragment registers) -- the full skew of the 8-wave variants would need both fragment sets live
     // (36 spills inside the loop: 185 TFLOP/s).
@@ -419,6 +437,14 @@ template __global__ void conv_x3_kernel<4, 2, 2, 2, true>(const ConvX3Params);
 template __global__ void conv_x3_kernel<4, 2, 1, 2, true>(const ConvX3Params);
 template __global__ void conv_x3_kernel<8, 1, 1, 2, true>(const ConvX3Params);
 template __global__ void conv_x3_kernel<4, 4, 2, 2, true>(const ConvX3Params);
+template __global__ void conv_x3_kernel<4, 2, 2, 2, false, 1>(const ConvX3Params);
+template __global__ void conv_x3_kernel<4, 2, 1, 2, false, 1>(const ConvX3Params);
+template __global__ void conv_x3_kernel<8, 1, 1, 2, false, 1>(const ConvX3Params);
+template __global__ void conv_x3_kernel<4, 4, 2, 2, false, 1>(const ConvX3Params);
+template __global__ void conv_x3_kernel<4, 2, 2, 2, true, 1>(const ConvX3Params);
+template __global__ void conv_x3_kernel<4, 2, 1, 2, true, 1>(const ConvX3Params);
+template __global__ void conv_x3_kernel<8, 1, 1, 2, true, 1>(const ConvX3Params);
+template __global__ void conv_x3_kernel<4, 4, 2, 2, true, 1>(const ConvX3Params);
 
 // ---- producers of the HL32 layout -------------------------------------------------------------------------------
 __device__ __forceinline__ void split_h(float v, _Float16& h, _Float16& l) {
@@ -582,18 +608,30 @@ void magic_div(unsigned d, unsigned& magic, int& shift) {
   shift = s - 1;
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, bool HL_OUT = false>
+// A/B switches of the tile order, read from the environment ONCE (not per launch)
+struct EnvFlags { bool no_interleave, no_class_order, row_major, w8; };
+const EnvFlags& env_flags() {
+  static const EnvFlags f = {getenv("MRN_X3_NO_INTERLEAVE") != nullptr, getenv("MRN_X3_NO_CLASS_ORDER") != nullptr,
+                             getenv("MRN_X3_ROW_MAJOR") != nullptr, getenv("MRN_X3_W8") != nullptr};
+  return f;
+}
+
+template <int WAVES_M, int WAVES_N, int WM, int WN, bool HL_OUT = false, int NPROD = 3>
 int launch_x3(const ConvX3Params& p0, hipStream_t st) {
   constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
   ConvX3Params p = p0;
   p.tilesM = ceil_div(p.M, BM);
   p.tilesN = ceil_div(p.N, BN);
-  p.tiles_per_row = (p.oy_major && p.BWo % BM == 0 && !getenv("MRN_X3_NO_INTERLEAVE")) ? p.BWo / BM : 0;
-  p.class_order = (p.tiles_per_row > 0 && p.Ho >= 3 && p.kh == 3 && p.ph == 1 && p.sh == 1 && !getenv("MRN_X3_NO_CLASS_ORDER")) ? 1 : 0;
+  p.tiles_per_row = (p.oy_major && p.BWo % BM == 0 && !env_flags().no_interleave) ? p.BWo / BM : 0;
+  p.class_order = (p.tiles_per_row > 0 && p.Ho >= 3 && p.kh == 3 && p.ph == 1 && p.sh == 1 && !env_flags().no_class_order) ? 1 : 0;
   const size_t ldsz = 2 * (size_t)(BM + BN) * 128;
   const long tiles = (long)p.G * p.tilesM * p.tilesN;
-  (void)hipFuncSetAttribute((const void*)conv_x3_kernel<WAVES_M, WAVES_N, WM, WN, HL_OUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);
-  hipLaunchKernelGGL((conv_x3_kernel<WAVES_M, WAVES_N, WM, WN, HL_OUT>), dim3((unsigned)tiles), dim3(WAVES_M * WAVES_N * 64), ldsz, st, p);
+  static bool attr_set = false;      // (per instantiation: the attribute is sticky, one driver call instead of one per launch)
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv_x3_kernel<WAVES_M, WAVES_N, WM, WN, HL_OUT, NPROD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_x3_kernel<WAVES_M, WAVES_N, WM, WN, HL_OUT, NPROD>), dim3((unsigned)tiles), dim3(WAVES_M * WAVES_N * 64), ldsz, st, p);
   MRN_LAUNCH_CHECK("conv2d_x3_hl32");
   return MRN_OK;
 }
@@ -610,11 +648,12 @@ MRN_EXPORT int mrn_conv2d_x3_hl32(const void* x_hl, const void* w_hl, const void
                                   const float* x_scale, int G, int64_t x_group_stride_bytes, int B, int H,
                                   int W, int Cin, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int act,
                                   int tile_m, int tile_n, int64_t y_row_stride, int64_t y_group_stride, int x_group_div,
-                                  void* y_hl32, void* stream) {
+                                  void* y_hl32, int products, void* stream) {
   MRN_CHECK_ARG(x_hl && w_hl && zero_page && (y || y_hl32) && G >= 1, "mrn_conv2d_x3_hl32: bad operands");
   MRN_CHECK_ARG(!y_hl32 || (Cout % 32 == 0 && y_row_stride <= 0 && y_group_stride <= 0 && (uintptr_t)y_hl32 % 128 == 0),
                 "mrn_conv2d_x3_hl32: the HL32 result needs Cout %% 32 == 0 and dense rows");
   MRN_CHECK_ARG(Cin % 32 == 0 && kh * kw <= 32, "mrn_conv2d_x3_hl32: unsupported Cin=%d kernel=%dx%d", Cin, kh, kw);
+  MRN_CHECK_ARG(products == 3 || products == 1, "mrn_conv2d_x3_hl32: products must be 3 (split-fp16 x3) or 1 (hi x hi), got %d", products);
   MRN_CHECK_ARG(((uintptr_t)x_hl % 128 == 0) && ((uintptr_t)w_hl % 128 == 0) && ((uintptr_t)zero_page % 16 == 0) &&
                     (x_group_stride_bytes % 128 == 0), "mrn_conv2d_x3_hl32: HL32 operands must be 128-byte aligned");
   MRN_CHECK_ARG((tile_m == 256 && (tile_n == 256 || tile_n == 128 || tile_n == 64)) || (tile_m == 128 && tile_n == 128),
@@ -639,20 +678,33 @@ MRN_EXPORT int mrn_conv2d_x3_hl32(const void* x_hl, const void* w_hl, const void
   // image-row-major tiles pay off when the kernel is padded vertically and the maps are only a few rows high (the TRBA
   // backbone's 4 x 65 maps: the two border rows skip one of three kernel rows)
   p.oy_major = (ph > 0 && kh > 1 && Ho <= 8) ? 1 : 0;   // (taller maps lose more L2 reuse across kernel rows than they skip)
-  if (getenv("MRN_X3_ROW_MAJOR")) p.oy_major = 0;
+  if (env_flags().row_major) p.oy_major = 0;
   p.BWo = B * Wo;
   magic_div((unsigned)Wo, p.wo_magic, p.wo_shift);
   magic_div((unsigned)p.BWo, p.bw_magic, p.bw_shift);
   magic_div((unsigned)kw, p.kw_magic, p.kw_shift);
   // 256x256: 16 waves (64x64 wave tiles, four waves per SIMD) hide the per-K-step LDS / barrier stalls better than 8 waves
   // with 128x64 tiles: 464 vs 438 TFLOP/s on the dominant shape (MRN_X3_W8=1 selects the 8-wave variant for A/B runs)
+  if (products == 1) {   // reduced-precision mode: one fp16 product per term, the lo halves stay unread
+    hipStream_t st1 = (hipStream_t)stream;
+    if (y_hl32) {
+      if (tile_n == 256) return launch_x3<4, 4, 2, 2, true, 1>(p, st1);
+      if (tile_m == 256 && tile_n == 64) return launch_x3<8, 1, 1, 2, true, 1>(p, st1);
+      if (tile_m == 256) return launch_x3<4, 2, 2, 2, true, 1>(p, st1);
+      return launch_x3<4, 2, 1, 2, true, 1>(p, st1);
+    }
+    if (tile_n == 256) return launch_x3<4, 4, 2, 2, false, 1>(p, st1);
+    if (tile_m == 256 && tile_n == 64) return launch_x3<8, 1, 1, 2, false, 1>(p, st1);
+    if (tile_m == 256) return launch_x3<4, 2, 2, 2, false, 1>(p, st1);
+    return launch_x3<4, 2, 1, 2, false, 1>(p, st1);
+  }
   if (y_hl32) {     // separate instantiations: the store path of the plain kernels stays as it was
     if (tile_n == 256) return launch_x3<4, 4, 2, 2, true>(p, (hipStream_t)stream);
     if (tile_m == 256 && tile_n == 64) return launch_x3<8, 1, 1, 2, true>(p, (hipStream_t)stream);
     if (tile_m == 256) return launch_x3<4, 2, 2, 2, true>(p, (hipStream_t)stream);
     return launch_x3<4, 2, 1, 2, true>(p, (hipStream_t)stream);
   }
-  if (tile_n == 256 && getenv("MRN_X3_W8")) return launch_x3<2, 4, 4, 2>(p, (hipStream_t)stream);
+  if (tile_n == 256 && env_flags().w8) return launch_x3<2, 4, 4, 2>(p, (hipStream_t)stream);
   if (tile_n == 256) return launch_x3<4, 4, 2, 2>(p, (hipStream_t)stream);
   if (tile_m == 256 && tile_n == 64) return launch_x3<8, 1, 1, 2>(p, (hipStream_t)stream);
   if (tile_m == 256) return launch_x3<4, 2, 2, 2>(p, (hipStream_t)stream);

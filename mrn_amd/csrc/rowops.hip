@@ -217,6 +217,8 @@ __device__ __forceinline__ float gelu_grad_f(float v) {
 }
 
 // op 0: y = gelu(a)   1: y = b * gelu'(a)   2: y = a * b   3: y = a + b   4: y = b * (a > 0)
+//    5: y = sigmoid(a)   6: y = b * a * (1 - a)  (a = sigmoid output)   7: y = relu(a + b)      (5-7: the gated recurrent conv
+//    layer of the RCNN extractor, modules/feature_extraction.py:146-161)
 __global__ __launch_bounds__(256) void ew_rows_kernel(const float* __restrict__ a, long lda, const float* __restrict__ b,
                                                       long ldb, float* __restrict__ y, long ldy, long rows, int C4, int op) {
   const long n = rows * C4;
@@ -233,9 +235,32 @@ __global__ __launch_bounds__(256) void ew_rows_kernel(const float* __restrict__ 
       else if (op == 1) o[j] = bv[j] * gelu_grad_f(av[j]);
       else if (op == 2) o[j] = av[j] * bv[j];
       else if (op == 3) o[j] = av[j] + bv[j];
-      else o[j] = av[j] > 0.f ? bv[j] : 0.f;
+      else if (op == 4) o[j] = av[j] > 0.f ? bv[j] : 0.f;
+      else if (op == 5) o[j] = 1.f / (1.f + expf(-av[j]));
+      else if (op == 6) o[j] = bv[j] * av[j] * (1.f - av[j]);
+      else o[j] = fmaxf(av[j] + bv[j], 0.f);
     }
     reinterpret_cast<f32x4*>(y + r * ldy)[c4] = o;
+  }
+}
+
+// BatchNorm batch statistics of a tensor that is NOT a conv output (the RCNN extractor normalises sums and gated products):
+// part[blk][0][c] = sum over the block's rows of x[r][c], part[blk][1][c] = sum of squares -- the partial-sum layout that
+// mrn_bn_finalize_f32 consumes (same as the conv epilogues').  One block = BN_STATS_ROWS rows, thread = column.
+constexpr int BN_STATS_ROWS = 256;
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, long rows, int C, float* __restrict__ part) {
+  const long r0 = (long)blockIdx.x * BN_STATS_ROWS, r1 = min(rows, r0 + BN_STATS_ROWS);
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+    long r = r0;
+    for (; r + 1 < r1; r += 2) {
+      const float a = x[r * C + c], b = x[(r + 1) * C + c];
+      s0 += a; q0 += a * a;
+      s1 += b; q1 += b * b;
+    }
+    if (r < r1) { const float a = x[r * C + c]; s0 += a; q0 += a * a; }
+    part[((long)blockIdx.x * 2 + 0) * C + c] = s0 + s1;
+    part[((long)blockIdx.x * 2 + 1) * C + c] = q0 + q1;
   }
 }
 
@@ -460,12 +485,24 @@ MRN_EXPORT int mrn_colnorm_bwd_f32(const float* dy, const float* x, const float*
 
 MRN_EXPORT int mrn_ew_rows_f32(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy,
                                int64_t rows, int C, int op, void* stream) {
-  MRN_CHECK_ARG(a && y && op >= 0 && op <= 4 && (op == 0 || b), "mrn_ew_rows_f32: bad operands for op %d", op);
+  MRN_CHECK_ARG(a && y && op >= 0 && op <= 7 && (op == 0 || op == 5 || b), "mrn_ew_rows_f32: bad operands for op %d", op);
   MRN_CHECK_ARG(C % 4 == 0 && lda % 4 == 0 && ldy % 4 == 0 && ldb % 4 == 0, "mrn_ew_rows_f32: C and row strides must be multiples of 4");
   if (rows == 0) return MRN_OK;
   hipLaunchKernelGGL(ew_rows_kernel, dim3(ew_grid(rows * (C / 4), 1024)), dim3(256), 0, (hipStream_t)stream, a, (long)lda, b,
                      (long)ldb, y, (long)ldy, (long)rows, C / 4, op);
   MRN_LAUNCH_CHECK("ew_rows");
+  return MRN_OK;
+}
+
+MRN_EXPORT int64_t mrn_bn_stats_blocks(int64_t rows) { return (rows + BN_STATS_ROWS - 1) / BN_STATS_ROWS; }
+
+// part [mrn_bn_stats_blocks(rows)][2][C]: per-block column sums / sums of squares of x [rows][C] (input of mrn_bn_finalize_f32)
+MRN_EXPORT int mrn_bn_stats_f32(const float* x, int64_t rows, int C, float* part, void* stream) {
+  MRN_CHECK_ARG(x && part && C > 0, "mrn_bn_stats_f32: bad operands");
+  if (rows == 0) return MRN_OK;
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3((unsigned)mrn_bn_stats_blocks(rows)), dim3(256), 0, (hipStream_t)stream, x,
+                     (long)rows, C, part);
+  MRN_LAUNCH_CHECK("bn_stats");
   return MRN_OK;
 }
 

@@ -19,8 +19,9 @@ class SyntheticTextLines:
         self.taski = 0
 
     # -- reference interface ---------------------------------------------------------------------------
-    def init_start(self, taski=0):
-        self.taski = taski
+    def init_start(self, *args, **kwargs):
+        """Dataset_Manager.init_start(opt, select_data, log, taski) (data/data_manage.py:80-95); init_start(taski) also accepted"""
+        self.taski = kwargs.get("taski", args[-1] if args else 0)
 
     def get_dataset(self, taski, memory=None, index_list=None):
         """same contract as Dataset_Manager.get_dataset (data/data_manage.py:16-61): with a rehearsal memory the learner must

@@ -48,7 +48,7 @@ def frozen_linear(x, weight, bias=None, act=ops.ACT_NONE, residual=None):
     w_hl, sw = got[1]
     R = x.numel() // K
     y, _ = ops.conv2d_x3(ops.split_hl32(x), 1, False, R, 1, 1, K, w_hl, sw, N, (1, 1), bias=bias, act=act,
-                         residual=residual.view(R, N) if residual is not None else None)
+                         residual=residual.view(R, N) if residual is not None else None, products=ops.X3_PRODUCTS)
     return y.view(*x.shape[:-1], N)
 
 
@@ -394,6 +394,103 @@ class ConvBlockFn(torch.autograd.Function):
             else:
                 dw = ops.unpack_conv_weight(ops.conv2d_wgrad(dy, x, (kh, kw), stride, padding))
         return dx, dw, dbias, dgamma, dbeta, dres, None
+
+
+class BatchNorm2dFn(torch.autograd.Function):
+    """nn.BatchNorm2d on an NHWC tensor that is not a conv output (the gated recurrent conv layer of the RCNN extractor normalises
+    the same conv result under several BatchNorms, and a gated product: modules/feature_extraction.py:146-161).  Train mode:
+    batch statistics + running-statistics update; backward through the statistics."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, bn, relu=False):
+        x = x.contiguous()
+        C = x.shape[-1]
+        count = x.numel() // C
+        mom = 0.1 if bn.momentum is None else bn.momentum
+        scale, shift, mean, invstd = ops.bn_finalize(ops.bn_stats(x), C, count, gamma, beta, bn.running_mean, bn.running_var,
+                                                     mom, bn.eps, save=True)
+        if bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        y = torch.empty_like(x)
+        ops.scale_shift_act(x, scale, shift, relu=relu, out=y)
+        ctx.save_for_backward(x, y, mean, invstd, gamma)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mean, invstd, gamma = ctx.saved_tensors
+        dx, dgamma, dbeta, _ = ops.bn_bwd(dy.contiguous(), y, x, mean, invstd, gamma, ctx.relu)
+        return dx, dgamma, dbeta, None, None
+
+
+def batch_norm_nhwc(x, bn, relu=False):
+    """BatchNorm2d module `bn` applied to an NHWC tensor: autograd Function in train mode with gradients, plain kernels otherwise"""
+    if bn.training:
+        if needs_grad(bn, x):
+            return BatchNorm2dFn.apply(x, bn.weight, bn.bias, bn, relu)
+        C = x.shape[-1]
+        mom = 0.1 if bn.momentum is None else bn.momentum
+        scale, shift, _, _ = ops.bn_finalize(ops.bn_stats(x.contiguous()), C, x.numel() // C, bn.weight, bn.bias, bn.running_mean,
+                                             bn.running_var, mom, bn.eps)
+        if bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+    else:
+        if needs_grad(bn, x):
+            raise NotImplementedError("backward through eval-mode BatchNorm is not implemented (experts train in train mode)")
+        scale, shift = ops.bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+    return ops.scale_shift_act(x.contiguous(), scale, shift, relu=relu, out=torch.empty_like(x))
+
+
+class SigmoidFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = ops.ew_rows(ops.EW_SIGMOID, x.contiguous())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return ops.ew_rows(ops.EW_SIGMOID_BWD, y, dy.contiguous())
+
+
+class MulFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        ctx.save_for_backward(a, b)
+        return ops.ew_rows(ops.EW_MUL, a, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, b = ctx.saved_tensors
+        dy = dy.contiguous()
+        return ops.ew_rows(ops.EW_MUL, dy, b), ops.ew_rows(ops.EW_MUL, dy, a)
+
+
+class AddReluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        y = ops.ew_rows(ops.EW_ADD_RELU, a.contiguous(), b.contiguous())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        d = ops.ew_rows(ops.EW_RELU_BWD, y, dy.contiguous())
+        return d, d
+
+
+class AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return ops.ew_rows(ops.EW_ADD, a.contiguous(), b.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
 
 
 class MaxPoolFn(torch.autograd.Function):

@@ -87,7 +87,8 @@ class _GroupedLinear:
             return w_hl, scale, bias
         w_hl, scale, bias = self._cached(name, params, build)
         y, _ = ops.conv2d_x3(x_hl, G, False, rows, 1, 1, K, w_hl, scale, N, (1, 1), bias=bias, act=act, out=out,
-                             out_row_stride=out_row_stride, out_group_stride=out_group_stride, hl_only=hl_only)
+                             out_row_stride=out_row_stride, out_group_stride=out_group_stride, hl_only=hl_only,
+                             products=ops.X3_PRODUCTS)
         return y
 
 
@@ -144,7 +145,7 @@ class BackboneGroup(_GroupedLinear):
                 x.hl = ops.split_hl32(x.f32)
             w_hl, w_scale = self._weights_hl(convs)
             _, stats = ops.conv2d_x3(x.hl, G, x.shared, B, H, W, Cin, w_hl, w_scale, Cout, ksize, stride, padding,
-                                     bias=self._bias_stack(convs), act=act, want_stats=training, out=y)
+                                     bias=self._bias_stack(convs), act=act, want_stats=training, out=y, products=ops.X3_PRODUCTS)
         elif Cin == 4 and ksize == (3, 3) and stride == (1, 1) and padding == (1, 1) and Cout in (32, 64) and x.f32 is not None:
             # first conv of the stacks: one launch for all experts on the dedicated Cin = 4 kernel (csrc/conv_first.hip)
             w = self._cached("c4w%d" % id(c0), [c.weight for c in convs],

@@ -4,11 +4,88 @@ Same class names, constructor signatures and state_dict keys as the reference's 
 (VGG_FeatureExtractor :8-47, ResNet_FeatureExtractor :100-108, BasicBlock :165-199, ResNet :202-352); the layers
 are parameter containers, the forward is a chain of implicit-GEMM conv launches with BatchNorm statistics fused
 into the conv epilogue and BN-apply / residual / ReLU / max-pool fused into one elementwise pass.
-RCNN_FeatureExtractor is out of scope (no shipped config selects it).
+RCNN_FeatureExtractor / GRCL / GRCL_unit (:50-162; selectable through opt.FeatureExtraction = "RCNN", used by no shipped
+config) run on the same conv kernels plus the standalone BatchNorm / sigmoid / gating passes of mrn_amd.functional.
 """
 import torch.nn as nn
 
 from ._nn import conv_block, from_nhwc, require_no_grad, to_nhwc
+
+
+class GRCL_unit(nn.Module):
+    """one iteration of the gated recurrent conv layer (reference :146-161): five BatchNorms, a sigmoid gate, a gated sum"""
+
+    def __init__(self, output_channel):
+        super().__init__()
+        self.BN_gfu = nn.BatchNorm2d(output_channel)
+        self.BN_grx = nn.BatchNorm2d(output_channel)
+        self.BN_fu = nn.BatchNorm2d(output_channel)
+        self.BN_rx = nn.BatchNorm2d(output_channel)
+        self.BN_Gx = nn.BatchNorm2d(output_channel)
+
+    def forward(self, wgf_u, wgr_x, wf_u, wr_x):
+        """all four NHWC: G = sigmoid(BN(wgf_u) + BN(wgr_x)); x = relu(BN(wf_u) + BN(BN(wr_x) * G))"""
+        from ..functional import AddFn, AddReluFn, MulFn, SigmoidFn, batch_norm_nhwc
+        G = SigmoidFn.apply(AddFn.apply(batch_norm_nhwc(wgf_u, self.BN_gfu), batch_norm_nhwc(wgr_x, self.BN_grx)))
+        x_second = batch_norm_nhwc(MulFn.apply(batch_norm_nhwc(wr_x, self.BN_rx), G), self.BN_Gx)
+        return AddReluFn.apply(batch_norm_nhwc(wf_u, self.BN_fu), x_second)
+
+
+class GRCL(nn.Module):
+    """Gated recurrent convolution layer (reference :112-143): the feed-forward terms wgf_u / wf_u of the input are computed once,
+    the recurrent 1x1 / 3x3 convolutions run num_iteration times"""
+
+    def __init__(self, input_channel, output_channel, num_iteration, kernel_size, pad):
+        super().__init__()
+        self.wgf_u = nn.Conv2d(input_channel, output_channel, 1, 1, 0, bias=False)
+        self.wgr_x = nn.Conv2d(output_channel, output_channel, 1, 1, 0, bias=False)
+        self.wf_u = nn.Conv2d(input_channel, output_channel, kernel_size, 1, pad, bias=False)
+        self.wr_x = nn.Conv2d(output_channel, output_channel, kernel_size, 1, pad, bias=False)
+        self.BN_x_init = nn.BatchNorm2d(output_channel)
+        self.num_iteration = num_iteration
+        self.GRCL = nn.Sequential(*[GRCL_unit(output_channel) for _ in range(num_iteration)])
+
+    def forward_nhwc(self, u):
+        from ..functional import batch_norm_nhwc
+        wgf_u = conv_block(u, self.wgf_u, relu=False)
+        wf_u = conv_block(u, self.wf_u, relu=False)
+        x = batch_norm_nhwc(wf_u, self.BN_x_init, relu=True)
+        for i in range(self.num_iteration):
+            x = self.GRCL[i](wgf_u, conv_block(x, self.wgr_x, relu=False), wf_u, conv_block(x, self.wr_x, relu=False))
+        return x
+
+    def forward(self, input):
+        return from_nhwc(self.forward_nhwc(to_nhwc(input)))
+
+
+class RCNN_FeatureExtractor(nn.Module):
+    """FeatureExtractor of GRCNN (reference :50-97): conv + 3 gated recurrent conv layers + 2x2 conv, [B,512,1,65] for 32x256 crops"""
+
+    def __init__(self, input_channel, output_channel=512):
+        super().__init__()
+        oc = [output_channel // 8, output_channel // 4, output_channel // 2, output_channel]
+        self.output_channel = oc
+        self.ConvNet = nn.Sequential(
+            nn.Conv2d(input_channel, oc[0], 3, 1, 1), nn.ReLU(True), nn.MaxPool2d(2, 2),
+            GRCL(oc[0], oc[0], num_iteration=5, kernel_size=3, pad=1), nn.MaxPool2d(2, 2),
+            GRCL(oc[0], oc[1], num_iteration=5, kernel_size=3, pad=1), nn.MaxPool2d(2, (2, 1), (0, 1)),
+            GRCL(oc[1], oc[2], num_iteration=5, kernel_size=3, pad=1), nn.MaxPool2d(2, (2, 1), (0, 1)),
+            nn.Conv2d(oc[2], oc[3], 2, 1, 0, bias=False), nn.BatchNorm2d(oc[3]), nn.ReLU(True))
+
+    def forward(self, input):
+        from ..functional import MaxPoolFn, needs_grad
+        from .. import ops
+        c = self.ConvNet
+        p22, p2_21 = ((2, 2), (2, 2), (0, 0)), ((2, 2), (2, 1), (0, 1))
+
+        def pool(x, p):
+            return MaxPoolFn.apply(x, *p) if (needs_grad(self, x)) else ops.maxpool_nhwc(x, *p)
+        x = conv_block(to_nhwc(input), c[0], pool=p22)
+        x = pool(c[3].forward_nhwc(x), p22)
+        x = pool(c[5].forward_nhwc(x), p2_21)
+        x = pool(c[7].forward_nhwc(x), p2_21)
+        x = conv_block(x, c[9], c[10])
+        return from_nhwc(x)
 
 
 class VGG_FeatureExtractor(nn.Module):

@@ -40,6 +40,9 @@ class Model_Extractor(nn.Module):
             self.FeatureExtraction = VGG_FeatureExtractor(opt.input_channel, opt.output_channel)
         elif opt.FeatureExtraction == "ResNet":
             self.FeatureExtraction = ResNet_FeatureExtractor(opt.input_channel, opt.output_channel)
+        elif opt.FeatureExtraction == "RCNN":
+            from .feature_extraction import RCNN_FeatureExtractor
+            self.FeatureExtraction = RCNN_FeatureExtractor(opt.input_channel, opt.output_channel)
         elif opt.FeatureExtraction == "SVTR":
             from .svtr import SVTR_FeatureExtractor
             self.FeatureExtraction = SVTR_FeatureExtractor(opt.input_channel, opt.output_channel)

@@ -302,6 +302,11 @@ def conv2d_nhwc(x, w_ohwi, bias=None, stride=(1, 1), padding=(0, 0), act=ACT_NON
 # ---------------------------------------------------------------------------------------------------------
 # grouped split-fp16 x3 convolution on HL32 operands (conv_x3.hip)
 # ---------------------------------------------------------------------------------------------------------
+# Products per term of the grouped conv / Linear of the FROZEN experts (conv_x3.hip): 3 = split-fp16 x3 (default: the 1e-4 parity
+# mode); 1 = hi x hi only, i.e. plain fp16 products with fp32 accumulation -- the reduced-precision mode of BASELINE configs 2
+# and 5 (bench.py --precision fp16; measured tolerance and routing agreement: tests/test_model_gpu.py::test_reduced_precision_*).
+# Callers on the TRAINED path (router Linear layers, loop-A convolutions, weight gradients) always pass products=3.
+X3_PRODUCTS = 1 if os.environ.get("MRN_X3_PRODUCTS") == "1" else 3
 X3_SMALL_TILE_MAX_K = 1200     # measured on MI355X (tools/bench_conv_x3.py): +3.5 % at K = 1152, +7.6 % at K = 576
 
 
@@ -412,7 +417,7 @@ def pack_weights_hl32(ws, scale=None):
 
 def conv2d_x3(x_hl, G, shared_input, B, H, W, Cin, w_hl, w_scale, Cout, ksize, stride=(1, 1), padding=(0, 0), bias=None,
               act=ACT_NONE, want_stats=False, out=None, out_row_stride=0, out_group_stride=0, residual=None, x_scale=None,
-              x_group_div=1, hl_only=False):
+              x_group_div=1, hl_only=False, products=3):
     """Grouped conv on HL32 operands -> (y [G,B,Ho,Wo,Cout] fp32, stats or None).  With `out` and the two strides (floats)
     the rows of group g land at out.data_ptr + g * out_group_stride + row * out_row_stride.
     hl_only: the result is written ONLY as the HL32 operand of the next GEMM (returned in place of y)."""
@@ -436,11 +441,11 @@ def conv2d_x3(x_hl, G, shared_input, B, H, W, Cin, w_hl, w_scale, Cout, ksize, s
     call("mrn_conv2d_x3_hl32", _p(x_hl), _p(w_hl), _p(_zero_page(dev)), _p(bias), _p(residual), _p(y), _p(stats), _p(w_scale),
          _p(x_scale), G, gstride,
          B, H, W, Cin, Cout, kh, kw, stride[0], stride[1], padding[0], padding[1], act, tile_m, tile_n, out_row_stride, out_group_stride,
-         x_group_div, _p(y_hl), _stream())
+         x_group_div, _p(y_hl), int(products), _stream())
     if timed:
         # algorithmic bytes: every operand element once (HL32 = 4 B / element, like fp32) + the fp32 result
         nbytes = 4.0 * ((1 if shared_input else G) * B * H * W * Cin + G * Cout * kh * kw * Cin + G * B * Ho * Wo * Cout)
-        kind = "fp16x3/x3g%dx%d" % (tile_m, tile_n)
+        kind = ("fp16x3" if products == 3 else "fp16") + "/x3g%dx%d" % (tile_m, tile_n)
         if TIMER_SHAPES:
             kind += "|G%d B%d %dx%d %d->%d k%dx%d s%d%d" % (G, B, H, W, Cin, Cout, kh, kw, stride[0], stride[1])
         CONV_TIMER.end(t0, 2.0 * G * B * Ho * Wo * Cout * kh * kw * Cin, kind, nbytes)
@@ -775,6 +780,19 @@ def colnorm_bwd(dy, x, gamma, mean, rstd, dx=None, accumulate=False):
 
 
 EW_GELU, EW_GELU_BWD, EW_MUL, EW_ADD = 0, 1, 2, 3
+EW_SIGMOID, EW_SIGMOID_BWD, EW_ADD_RELU = 5, 6, 7        # (4 = EW_RELU_BWD, defined with the backward ops)
+
+
+def bn_stats(x):
+    """per-block partial sums / sums of squares of x [..., C] over its rows: the `stats` input of bn_finalize() for tensors
+    that are not conv outputs"""
+    _chk(x)
+    assert x.is_contiguous()
+    C = x.shape[-1]
+    rows = x.numel() // C
+    part = torch.empty(call("mrn_bn_stats_blocks", rows), 2, C, device=x.device, dtype=torch.float32)
+    call("mrn_bn_stats_f32", _p(x), rows, C, _p(part), _stream())
+    return part
 
 
 def ew_rows(op, a, b=None, out=None):

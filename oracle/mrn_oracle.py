@@ -106,6 +106,35 @@ def vgg_forward(sd, pre, x, training):
     return F.relu(F.conv2d(x, sd[p + "18.weight"], sd[p + "18.bias"], 1, 0))
 
 
+def _grcl(sd, p, u, training, num_iteration=5):
+    """GRCL.forward + GRCL_unit.forward, modules/feature_extraction.py:112-161"""
+    def bn(name, x):
+        y = _bn(sd, p + name + ".", x, training)
+        _bn_tick(sd, p + name + ".", training)
+        return y
+    pad = sd[p + "wf_u.weight"].shape[-1] // 2
+    wgf_u = F.conv2d(u, sd[p + "wgf_u.weight"])
+    wf_u = F.conv2d(u, sd[p + "wf_u.weight"], None, 1, pad)
+    x = F.relu(bn("BN_x_init", wf_u))
+    for i in range(num_iteration):
+        q = f"GRCL.{i}."
+        G = torch.sigmoid(bn(q + "BN_gfu", wgf_u) + bn(q + "BN_grx", F.conv2d(x, sd[p + "wgr_x.weight"])))
+        x = F.relu(bn(q + "BN_fu", wf_u) + bn(q + "BN_Gx", bn(q + "BN_rx", F.conv2d(x, sd[p + "wr_x.weight"], None, 1, pad)) * G))
+    return x
+
+
+def rcnn_forward(sd, pre, x, training):
+    """RCNN_FeatureExtractor, modules/feature_extraction.py:50-97"""
+    p = pre + "ConvNet."
+    x = F.max_pool2d(F.relu(F.conv2d(x, sd[p + "0.weight"], sd[p + "0.bias"], 1, 1)), 2, 2)
+    x = F.max_pool2d(_grcl(sd, p + "3.", x, training), 2, 2)
+    x = F.max_pool2d(_grcl(sd, p + "5.", x, training), 2, (2, 1), (0, 1))
+    x = F.max_pool2d(_grcl(sd, p + "7.", x, training), 2, (2, 1), (0, 1))
+    x = F.relu(_bn(sd, p + "10.", F.conv2d(x, sd[p + "9.weight"], None, 1, 0), training))
+    _bn_tick(sd, p + "10.", training)
+    return x
+
+
 RESNET_LAYERS = (1, 2, 5, 3)  # feature_extraction.py:105
 
 
@@ -314,6 +343,8 @@ def extractor_forward(sd, pre, cfg, image, training, masks=None):
         x = vgg_forward(sd, pre + "FeatureExtraction.", x, training)
     elif cfg.FeatureExtraction == "ResNet":
         x = resnet_forward(sd, pre + "FeatureExtraction.", x, training)
+    elif cfg.FeatureExtraction == "RCNN":
+        x = rcnn_forward(sd, pre + "FeatureExtraction.", x, training)
     elif cfg.FeatureExtraction == "SVTR":
         x = svtr_forward(sd, pre + "FeatureExtraction.", x, training, masks)
     else:

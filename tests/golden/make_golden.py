@@ -297,6 +297,53 @@ def der(kind, classes, B, seed):
     return d
 
 
+def rcnn_model(B, seed):
+    """a single recogniser with the RCNN (gated recurrent conv) extractor, reference modules/feature_extraction.py:50-162 via
+    modules/model.py:44: train-mode forward + CTC loss + parameter gradients, eval-mode forward"""
+    from modules.model import Model
+    d = {}
+    opt = make_opt("crnn")
+    opt.FeatureExtraction = "RCNN"
+    net = Model(opt)
+    net.update_fc(opt.hidden_size, 40)
+    net.build_prediction(opt, 40)
+    sd0 = net.state_dict()
+    d["sd_keys"] = np.array(sorted(sd0.keys()))
+    d["sd_shapes"] = np.array([",".join(map(str, sd0[k].shape)) for k in sorted(sd0.keys())])
+    W.fill_state_dict(net.state_dict(), seed)
+    image = torch.from_numpy(W.smooth_image("input:image", (B, 4, 32, 256), seed))
+    words, chars = words_for(B, 36, seed)
+    conv = CTCLabelConverter(chars)
+    labels_index, labels_length = conv.encode(words, batch_max_length=25)
+    net.train()
+    out = net(image, None, True)
+    put(d, "train/feature", out["feature"])
+    put(d, "train/predict", out["predict"])
+    preds = out["predict"]
+    loss = torch.nn.CTCLoss(zero_infinity=True)(preds.log_softmax(2).permute(1, 0, 2), labels_index, torch.IntTensor([preds.size(1)] * B),
+                                                  labels_length)
+    d["train/loss"] = np.float64(loss.item())
+    net.zero_grad()
+    loss.backward()
+    named = dict(net.named_parameters())
+    keys = ["model.FeatureExtraction.ConvNet.0.weight", "model.FeatureExtraction.ConvNet.3.wgf_u.weight",
+            "model.FeatureExtraction.ConvNet.3.wr_x.weight", "model.FeatureExtraction.ConvNet.5.wf_u.weight",
+            "model.FeatureExtraction.ConvNet.5.GRCL.2.BN_Gx.weight", "model.FeatureExtraction.ConvNet.7.GRCL.4.BN_grx.bias",
+            "model.FeatureExtraction.ConvNet.7.wgr_x.weight", "model.FeatureExtraction.ConvNet.9.weight",
+            "model.SequenceModeling.0.rnn.weight_hh_l0", "fc.weight"]
+    d["grad_keys"] = np.array(keys)
+    for k in keys:
+        put(d, f"grad/{k}", named[k].grad)
+    put(d, "bn_running_var_after", net.state_dict()["model.FeatureExtraction.ConvNet.5.GRCL.1.BN_rx.running_var"], full=True)
+    W.fill_state_dict(net.state_dict(), seed)
+    net.eval()
+    with torch.no_grad():
+        o = net(image, None, False)
+        put(d, "eval/predict", o["predict"])
+        d["eval/argmax"] = o["predict"].max(2)[1].numpy()
+    return d
+
+
 def converters():
     d = {}
     chars = "abcdefghij klmno"   # includes a space duplicate, as real dictionaries may
@@ -328,6 +375,7 @@ if __name__ == "__main__":
         "crnn_mrn3_noise": lambda: run("crnn", (40, 70, 97), 2, 1, noise=True),
         "trba_mrn3_noise": lambda: run("trba", (41, 71, 98), 2, 2, noise=True),
         "svtr_mrn3_noise": lambda: run("svtr", (40, 70, 97), 2, 3, noise=True),
+        "rcnn_model": lambda: rcnn_model(2, 9),
         "converters": converters,
     }
     for name, fn in jobs.items():

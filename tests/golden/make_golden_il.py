@@ -438,6 +438,93 @@ def rehearsal_fixture():
     return d
 
 
+def data_manage_fixture():
+    """reference data/data_manage.py (Dataset_Manager, Val_Dataset, IndexConcatDataset) + data/dataset.py (AlignCollate[2],
+    ResizeNormalize) over in-memory datasets: what get_dataset() builds for every `memory` mode and the first batches it
+    yields under fixed numpy / torch seeds.  Shims: LmdbDataset -> in-memory samples (tests/helpers.py::fake_text_samples),
+    torchvision's ToTensor -> the same uint8 HWC -> float CHW / 255 conversion, the removed DataLoader-iterator .next()."""
+    import data.data_manage as ref_dm
+    import data.dataset as ref_ds
+    import PIL.Image
+    from torch.utils.data import Dataset
+    from torch.utils.data.dataloader import _BaseDataLoaderIter
+    from tests.helpers import fake_text_samples
+    _BaseDataLoaderIter.next = lambda self: self.__next__()
+
+    class ToTensor:
+        def __call__(self, img):
+            a = np.asarray(img, dtype=np.uint8)
+            return torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1))).float().div(255)
+    ref_ds.transforms.ToTensor = ToTensor
+
+    class FakeLmdb(Dataset):
+        def __init__(self, root, opt, mode="train"):
+            images, labels = fake_text_samples(root)
+            keep = [i for i, l in enumerate(labels) if len(l) <= opt.batch_max_length]      # LmdbDataset's length filter (:78-83)
+            self.items = [(images[i], labels[i]) for i in keep]
+
+        def __len__(self):
+            return len(self.items)
+
+        def __getitem__(self, i):
+            return PIL.Image.fromarray(self.items[i][0]).convert("RGBA"), self.items[i][1]
+    ref_dm.LmdbDataset = FakeLmdb
+
+    def fake_tree(root, opt, select_data="/", data_type="label", mode="train"):
+        from torch.utils.data import ConcatDataset
+        return ConcatDataset([FakeLmdb(root, opt, mode)]), "log"
+    ref_dm.hierarchical_dataset = fake_tree
+    d = {}
+    scenarios = [("mrn_random", "mrn", "random"), ("plain", "mrn", None), ("test_ch", "lwf", "test_ch"), ("large", "lwf", "large"),
+                 ("total", "lwf", "total"), ("halves", "lwf", "random")]
+    for name, il, memory in scenarios:
+        opt = learner_opt("crnn")
+        opt.__dict__.update(il=il, memory=memory, memory_num=40 if memory != "large" else 12, batch_size=6, workers=0, Aug="None",
+                            lan_list=["Chinese", "Latin", "Japanese"], select_data=["rootA", "rootB"])
+        np.random.seed(77)
+        torch.manual_seed(77)
+        with contextlib.redirect_stdout(io.StringIO()):
+            dm = ref_dm.Dataset_Manager(opt)
+            dm.select_data = opt.select_data
+            taski = 2
+            index_list = [np.random.choice(range(30), 40 // taski if memory != "large" else 12, replace=False) for _ in range(taski)]
+            out_index = dm.get_dataset(taski, memory=memory, index_list=index_list)
+            d[f"{name}/n_loaders"] = np.int64(len(dm.data_loader_list))
+            d[f"{name}/loader_dataset_lengths"] = np.array([len(l.dataset) for l in dm.data_loader_list], dtype=np.int64)
+            d[f"{name}/loader_batch_sizes"] = np.array([l.batch_size for l in dm.data_loader_list], dtype=np.int64)
+            mix = isinstance(dm.data_loader_list[0].collate_fn, ref_ds.AlignCollate2)
+            d[f"{name}/mix"] = np.bool_(mix)
+            for b in range(3):
+                got = dm.get_batch2() if mix else dm.get_batch()
+                d[f"{name}/batch{b}/labels"] = np.array(list(got[1]))
+                d[f"{name}/batch{b}/image_shape"] = np.array(got[0].shape)
+                d[f"{name}/batch{b}/image_sum"] = np.float64(got[0].double().sum().item())
+                d[f"{name}/batch{b}/image_probe"] = got[0][:, :, ::8, ::32].numpy().copy()
+                if mix:
+                    d[f"{name}/batch{b}/index"] = np.array([list(t) for t in got[2]], dtype=np.int64)
+            loader, n = dm.rehearsal_prev_model(taski)
+            d[f"{name}/prev_len"] = np.int64(n)
+    # validation side
+    opt = learner_opt("crnn")
+    opt.__dict__.update(batch_size=5, workers=0, Aug="None", lan_list=["Chinese", "Latin"], NED=True)
+    np.random.seed(78)
+    torch.manual_seed(78)
+    with contextlib.redirect_stdout(io.StringIO()):
+        vd = ref_dm.Val_Dataset(["valA/Chinese", "valA/Latin"], opt)
+        for name, loader in (("val/current", vd.create_dataset()), ("val/list", vd.create_list_dataset())):
+            d[f"{name}/len"] = np.int64(len(loader.dataset))
+            images, labels = next(iter(loader))
+            d[f"{name}/labels"] = np.array(list(labels))
+            d[f"{name}/image_sum"] = np.float64(images.double().sum().item())
+    # ResizeNormalize alone (BICUBIC resize to 256 x 32, [-1, 1])
+    img, _ = FakeLmdb("rootA/Latin", opt)[3]
+    t = ref_ds.ResizeNormalize((256, 32))(img)
+    d["resize/shape"] = np.array(t.shape)
+    d["resize/probe"] = t[:, ::4, ::16].numpy().copy()
+    d["resize/sum"] = np.float64(t.double().sum().item())
+    return d
+
+
 EOS_BIAS = 0.0
 
 
@@ -454,6 +541,7 @@ if __name__ == "__main__":
         "il_trba": lambda: il_fixture("trba"),
         "validation": validation_fixture,
         "rehearsal": rehearsal_fixture,
+        "data_manage": data_manage_fixture,
     }
     for name, fn in jobs.items():
         if args.only and args.only != name:

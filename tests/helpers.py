@@ -222,3 +222,21 @@ def crafted_validation_case(kind):
         batches.append((image, labels))
         logits.append(lg)
     return chars, batches, logits
+
+
+def fake_text_samples(path, seed=5):
+    """deterministic (images, labels) for a dataset directory path such as "rootA/Latin": RGBA uint8 crops of varying size and
+    labels over a small alphabet, a few of them longer than batch_max_length (the readers must filter those out)"""
+    lang = path.rstrip("/").split("/")[-1]
+    n = 37 + 11 * (sum(ord(c) for c in path) % 5)
+    alphabet = "abcdefghijklmnopqrstuvwxyz" + lang.lower()
+    images, labels = [], []
+    for i in range(n):
+        name = f"fake:{path}:{i}"
+        h = int(W.randint(name + ":h", (1,), 20, 41, seed)[0])
+        w = int(W.randint(name + ":w", (1,), 60, 201, seed)[0])
+        images.append((W.uniform(name, (h, w, 4), 0.0, 255.999, seed)).astype(np.uint8))
+        L = int(W.randint(name + ":len", (1,), 1, 31, seed)[0])          # up to 30 characters: some exceed 25
+        ids = W.randint(name + ":lab", (L,), 0, len(alphabet), seed)
+        labels.append("".join(alphabet[j] for j in ids))
+    return images, labels

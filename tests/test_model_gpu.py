@@ -705,3 +705,88 @@ def test_full_size_svtr_lockstep_matches_per_expert():
     assert_close("full-size logits", outs[0][0], outs[1][0], atol=2e-4, rtol=1e-4)
     assert_close("full-size routing weights", outs[0][1], outs[1][1], atol=2e-5, rtol=1e-4)
     assert_close("routing weights sum to 1", outs[0][1].sum(1), torch.ones(B), atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["crnn_mrn3", "trba_mrn3", "svtr_mrn3", "crnn_mrn3_noise"])
+def test_reduced_precision_mode_tolerance_and_agreement(name):
+    """ops.X3_PRODUCTS = 1 (bench.py --precision fp16): ONE fp16 product per term instead of the split-fp16 x3 of the parity mode,
+    fp32 accumulation and storage unchanged -- the reduced-precision mode BASELINE configs 2 ("bf16") and 5 ("fp16 MFMA") ask
+    for (fp16 keeps 11 significand bits where bf16 keeps 8).  It does NOT meet the 1e-4 band and is never the headline; this
+    pins what it does meet against the reference's golden outputs: routing weights within 2e-2, fused logits within 5e-2 of
+    their scale, the routing argmax and the greedy CTC strings / eval routing indices unchanged on these cases."""
+    from mrn_amd import ops
+    kind, classes, B, seed = CASES.get(name, ("trba", (41, 71, 98), 2, 2))
+    g = load_golden(name)
+    opt, net = build_net(kind, classes, g, seed)
+    image, words, chars, _ = det_inputs(kind, classes, B, seed, noise=name.endswith("_noise"))
+    conv, labels_index, _ = labels_for(kind, words, chars)
+    ctc = kind != "trba"
+    saved = ops.X3_PRODUCTS
+    try:
+        ops.X3_PRODUCTS = 1
+        net.train()
+        set_drop_masks(net, kind, B, seed, "stepB0", list(range(len(classes))))
+        with torch.no_grad():
+            out = net(image.cuda(), True, None if ctc else labels_index[:, :-1].cuda(), True)
+        w = out["index"].cpu().numpy()
+        err_w = np.abs(w - g["stepB/weights"]).max()
+        from tests.helpers import sub
+        ref_l = g["stepB/logits/sub"]
+        err_l = np.abs(sub(out["logits"])[0] - ref_l).max() / max(np.abs(ref_l).max(), 1e-6)
+        print(f"[reduced precision] {name}: routing weights max err {err_w:.2e}, fused logits max err / scale {err_l:.2e}")
+        assert err_w <= 2e-2 and err_l <= 5e-2, (err_w, err_l)
+        assert err_w > 1e-6                                   # it really is the reduced mode (x3 sits at ~1e-6 on CRNN)
+        assert np.array_equal(w.argmax(1), g["stepB/weights"].argmax(1))
+        reload(net, g, seed)
+        net.eval()
+        with torch.no_grad():
+            sos = None if ctc else torch.LongTensor(B).fill_(2).cuda()
+            oe = net(image.cuda(), True, sos, False)
+        assert np.array_equal(oe["index"].cpu().numpy(), g["eval/index"])
+        am = oe["logits"].max(2)[1].cpu().numpy()
+        agree = float((am == g["eval/argmax"]).mean())
+        print(f"[reduced precision] {name}: eval argmax agreement {agree:.4f}")
+        assert agree >= 0.97
+    finally:
+        ops.X3_PRODUCTS = saved
+
+
+def test_rcnn_extractor_vs_reference():
+    """RCNN_FeatureExtractor / GRCL / GRCL_unit (reference modules/feature_extraction.py:50-162) on the HIP path:
+    state_dict layout, train-mode forward (five BatchNorms per recurrent iteration, running statistics), CTC loss, parameter
+    gradients through the gated recurrence, eval-mode forward with bit-exact argmax -- all against the reference's outputs"""
+    from mrn_amd import functional as Fn
+    from mrn_amd.modules.model import Model
+    from mrn_amd.tools import weights as W
+    g = load_golden("rcnn_model")
+    opt = make_opt("crnn")
+    opt.FeatureExtraction = "RCNN"
+    B, seed = 2, 9
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = Model(opt)
+        net.update_fc(opt.hidden_size, 40)
+        net.build_prediction(opt, 40)
+    ref = {str(k): str(s) for k, s in zip(g["sd_keys"], g["sd_shapes"])}
+    assert {k: ",".join(map(str, v.shape)) for k, v in net.state_dict().items()} == ref
+    net.load_state_dict(golden_state_dict(g, seed), strict=True)
+    net = net.cuda().train()
+    image = torch.from_numpy(W.smooth_image("input:image", (B, 4, 32, 256), seed)).cuda()
+    chars = "".join(chr(0x4E00 + i) for i in range(36))
+    lens = W.randint("label_len", (B,), 1, 26, seed)
+    words = ["".join(chars[i] for i in W.randint(f"label_{b}", (int(lens[b]),), 0, 36, seed)) for b in range(B)]
+    conv, labels_index, labels_length = labels_for("crnn", words, chars)
+    out = net(image, None, True)
+    assert_sub_close(g, "train/feature", out["feature"], atol=1e-4)
+    assert_sub_close(g, "train/predict", out["predict"], atol=1e-4)
+    loss = Fn.ctc_loss(out["predict"], labels_index.cuda(), labels_length.cuda())
+    assert abs(loss.item() - float(g["train/loss"])) < 1e-4 * max(1.0, float(g["train/loss"]))
+    loss.backward()
+    for k in [str(s) for s in g["grad_keys"]]:
+        assert_sub_close(g, f"grad/{k}", net.get_parameter(k).grad, atol=1e-6, rtol=5e-3)
+    assert_close("running_var", net.state_dict()["model.FeatureExtraction.ConvNet.5.GRCL.1.BN_rx.running_var"], g["bn_running_var_after"], atol=1e-5)
+    net.load_state_dict(golden_state_dict(g, seed), strict=True)
+    net.eval()
+    with torch.no_grad():
+        oe = net(image, None, False)
+    assert_sub_close(g, "eval/predict", oe["predict"], atol=1e-4)
+    assert np.array_equal(oe["predict"].max(2)[1].cpu().numpy(), g["eval/argmax"])

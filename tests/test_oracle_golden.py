@@ -209,3 +209,34 @@ def test_trba_tps_conditioning_smooth_vs_noise():
     (sw, sl, _), (nw, nl, _) = bands["trba_mrn3"], bands["trba_mrn3_noise"]
     assert sw < 3e-4 and sl < 3e-4                       # smooth crops: the reference is ~1e-4 from exact arithmetic
     assert nw > 1e-3 and nl > 1e-3 and nw > 10 * sw      # white noise: the reference itself is > 1e-3 away
+
+
+def test_rcnn_extractor_model():
+    """RCNN (gated recurrent conv) extractor: the oracle's restatement against the reference's forward, loss and gradients"""
+    g = load_golden("rcnn_model")
+    cfg = O.Cfg("None", "RCNN", "BiLSTM", "CTC")
+    B, seed = 2, 9
+    from mrn_amd.tools import weights as W
+    image = torch.from_numpy(W.smooth_image("input:image", (B, 4, 32, 256), seed))
+    chars = "".join(chr(0x4E00 + i) for i in range(36))
+    lens = W.randint("label_len", (B,), 1, 26, seed)
+    words = ["".join(chars[i] for i in W.randint(f"label_{b}", (int(lens[b]),), 0, 36, seed)) for b in range(B)]
+    li, ll = O.CTCConverter(chars).encode(words, 25)
+    sd = golden_state_dict(g, seed)
+    keys = [str(k) for k in g["grad_keys"]]
+    for k in list(sd):
+        if k in ("Prediction.weight", "Prediction.bias"):
+            sd[k] = sd["fc." + k.split(".")[1]]
+    params = [sd[k].requires_grad_(True) for k in keys]
+    out = O.model_forward(sd, "", cfg, image, None, True, training=True)
+    assert_sub_close(g, "train/feature", out["feature"], atol=2e-5)
+    assert_sub_close(g, "train/predict", out["predict"], atol=2e-5)
+    loss = O.ctc_loss(out["predict"], li, ll)
+    assert abs(loss.item() - float(g["train/loss"])) < 1e-5 * max(1.0, float(g["train/loss"]))
+    for k, gr in zip(keys, torch.autograd.grad(loss, params)):
+        assert_sub_close(g, f"grad/{k}", gr, atol=1e-6, rtol=2e-3)
+    assert_close("running_var", sd["model.FeatureExtraction.ConvNet.5.GRCL.1.BN_rx.running_var"].detach(), g["bn_running_var_after"], atol=1e-6)
+    with torch.no_grad():
+        oe = O.model_forward(golden_state_dict(g, seed), "", cfg, image, None, False, training=False)
+    assert_sub_close(g, "eval/predict", oe["predict"], atol=2e-5)
+    assert np.array_equal(oe["predict"].max(2)[1].numpy(), g["eval/argmax"])

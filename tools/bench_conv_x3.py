@@ -47,7 +47,7 @@ def main():
             x = torch.stack(xs)
             x_hl = ops.split_hl32(x)
             w_hl, w_scale = ops.pack_weights_hl32(ws)
-            y, st = ops.conv2d_x3(x_hl, G, False, B, H, W, Cin, w_hl, w_scale, Cout, k, s, p, want_stats=True)
+            y, st = ops.conv2d_x3(x_hl, G, False, B, H, W, Cin, w_hl, w_scale, Cout, k, s, p, want_stats=True, products=ops.X3_PRODUCTS)
             err = serr = -1.0
             if check:
                 err = serr = 0.0
@@ -60,7 +60,7 @@ def main():
                     totr = sr.view(-1, 2, C).sum(0)
                     serr = max(serr, ((tot - totr).abs().max() / totr.abs().max()).item())
             flops = 2.0 * G * y.shape[1] * y.shape[2] * y.shape[3] * Cout * k[0] * k[1] * Cin
-            ms = timeit(lambda: ops.conv2d_x3(x_hl, G, False, B, H, W, Cin, w_hl, w_scale, Cout, k, s, p, want_stats=True), reps)
+            ms = timeit(lambda: ops.conv2d_x3(x_hl, G, False, B, H, W, Cin, w_hl, w_scale, Cout, k, s, p, want_stats=True, products=ops.X3_PRODUCTS), reps)
             if "--only-x3" in sys.argv:
                 print(f"conv G{G} B{B} {H}x{W} {Cin}->{Cout} k{k[0]}x{k[1]}: x3g {ms:8.3f} ms {flops / ms / 1e9:7.1f} TF", flush=True)
                 continue

@@ -23,9 +23,18 @@ for f in glob.glob("gpurun_out/$tag/p*/**/*counter_collection.csv", recursive=Tr
         a = agg[row["Counter_Name"]]
         a[0] += 1
         a[1] += float(row["Counter_Value"])
+dur = []
+for f in glob.glob("gpurun_out/$tag/p2/**/*kernel_trace.csv", recursive=True):      # the pass that carries GRBM_GUI_ACTIVE
+    for row in csv.DictReader(open(f)):
+        if "conv_x3_kernel" in row["Kernel_Name"]:
+            dur.append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
 with open("gpurun_out/$tag/pmc.txt", "w") as out:
     for k in sorted(agg):
         out.write(f"{k:40s} n={agg[k][0]:4d} avg={agg[k][1] / agg[k][0]:.6g}\n")
+    if dur and "GRBM_GUI_ACTIVE" in agg:
+        ns = sum(dur) / len(dur)
+        ga = agg["GRBM_GUI_ACTIVE"][1] / agg["GRBM_GUI_ACTIVE"][0]
+        out.write(f"kernel wall (same pass) {ns / 1e3:.1f} us; effective clock = GRBM_GUI_ACTIVE / wall = {ga / ns:.3f} GHz\n")
 print(open("gpurun_out/$tag/pmc.txt").read())
 PY
 rm -rf gpurun_out/$tag/p[0-9]
