@@ -9,7 +9,8 @@
  * Conventions
  *   - plain pointers and sizes only; all pointers are DEVICE pointers unless stated otherwise
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream)
- *   - the caller owns every buffer; the library allocates nothing and keeps no mutable global state
+ *   - the caller owns every buffer; the library allocates nothing and keeps no mutable global state (one exception: the RCCL
+ *     communicator created by an explicit mrn_comm_init)
  *   - return 0 on success, <0 library error, >0 hipError_t; text via mrn_last_error() (thread-local)
  *   - activations are fp32, NHWC (channels innermost); "rows" means all leading dims flattened
  */
@@ -401,6 +402,22 @@ int mrn_sgd_step_f32(float* p, float* g, float* buf, int64_t n, const float* nor
 /* torch.optim.Adadelta (il_modules/base.py:80-83: rho, eps): running averages square_avg / acc_delta zero-initialised by the caller */
 int mrn_adadelta_step_f32(float* p, float* g, float* square_avg, float* acc_delta, int64_t n, const float* norm_coef, float lr,
                           float rho, float eps, void* stream);
+
+/* ---- data-parallel collectives over RCCL / xGMI ------------------------------------------------------------------
+ * Replace the per-iteration replicate / scatter / gather / reduce of torch.nn.DataParallel (il_modules/base.py:68,
+ * il_modules/mrn.py:106,133) for one-process-per-GPU hosts: rank 0 calls mrn_comm_unique_id (HOST buffer of
+ * mrn_comm_unique_id_bytes() bytes) and distributes it, every rank calls mrn_comm_init with its HIP device current, then the flat
+ * gradient buckets go through mrn_allreduce_f32 (average = 1: mean over ranks) and freshly built models through mrn_broadcast_f32.
+ * RCCL is bound with dlopen at mrn_comm_init time (a process that already carries an RCCL shares it).  Device buffers, in place,
+ * asynchronous on `stream`. */
+int64_t mrn_comm_unique_id_bytes(void);
+int mrn_comm_unique_id(void* id_out);
+int mrn_comm_init(int rank, int world, const void* unique_id);
+int64_t mrn_comm_world(void);
+int64_t mrn_comm_rank(void);
+int mrn_allreduce_f32(float* buf, int64_t n, int average, void* stream);
+int mrn_broadcast_f32(float* buf, int64_t n, int root, void* stream);
+int mrn_comm_destroy(void);
 
 #ifdef __cplusplus
 }

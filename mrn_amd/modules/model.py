@@ -524,4 +524,10 @@ class MRNNet(nn.Module):
         return self
 
     def softargmax1d(self, input, beta=5):
-        raise NotImplementedError("fused into mrn_gate_tail_fwd_f32 (softmax(beta * route(x)))")
+        """softmax(beta * input) over the last axis (reference :495-496).  cross_forward has it fused into the gate-tail kernel
+        together with the `route` Linear; this stand-alone form runs the same kernel with a one-tap identity route."""
+        shape = input.shape
+        x = input.reshape(-1, 1, shape[-1])
+        one = torch.ones(1, 1, device=input.device, dtype=torch.float32)
+        zero = torch.zeros(1, device=input.device, dtype=torch.float32)
+        return GateTailFn.apply(x, one, zero, float(beta)).view(shape)

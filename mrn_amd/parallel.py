@@ -52,8 +52,78 @@ def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+# MRN_COMM=native: the gradient buckets go through the library's own RCCL entry points (include/mrn_hip.h: mrn_comm_init /
+# mrn_allreduce_f32, the path a non-PyTorch host uses) on a dedicated HIP stream; torch.distributed then only carries the 128-byte
+# rendezvous id.  Default: torch.distributed's RCCL binding.
+NATIVE_COMM = os.environ.get("MRN_COMM") == "native"
+_native = {"stream": None, "world": 0}
+
+
+def init_native_comm(rank_=None, world=None):
+    """create the library's RCCL communicator for this process (idempotent); the id travels through torch.distributed when there
+    is more than one rank"""
+    import ctypes
+    from ._lib import call
+    if _native["world"]:
+        return _native["world"]
+    rank_ = rank() if rank_ is None else rank_
+    world = world_size() if world is None else world
+    n = int(call("mrn_comm_unique_id_bytes"))
+    buf = ctypes.create_string_buffer(n)
+    if rank_ == 0:
+        call("mrn_comm_unique_id", buf)
+    if world > 1:
+        box = [buf.raw]
+        dist.broadcast_object_list(box, src=0)
+        buf = ctypes.create_string_buffer(box[0], n)
+    call("mrn_comm_init", rank_, world, buf)
+    _native["stream"] = torch.cuda.Stream()
+    _native["world"] = world
+    return world
+
+
+class _NativeWork:
+    """handle of a collective issued on the comm stream: wait() orders the current stream behind it"""
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
+
+
+def native_all_reduce(t, average=True):
+    """in place over the library's communicator, asynchronous: the comm stream waits for the producer stream, the returned handle
+    makes the consumer stream wait for the collective"""
+    from ._lib import call
+    st = _native["stream"]
+    st.wait_stream(torch.cuda.current_stream())
+    call("mrn_allreduce_f32", t.data_ptr(), t.numel(), int(average), st.cuda_stream)
+    t.record_stream(st)
+    ev = torch.cuda.Event()
+    ev.record(st)
+    return _NativeWork(ev)
+
+
+def native_broadcast(t, src=0):
+    from ._lib import call
+    st = _native["stream"]
+    st.wait_stream(torch.cuda.current_stream())
+    call("mrn_broadcast_f32", t.data_ptr(), t.numel(), int(src), st.cuda_stream)
+    t.record_stream(st)
+    torch.cuda.current_stream().wait_stream(st)
+    return t
+
+
 def _avg_inplace(t, async_op=False):
     """all-reduce average of t over the ranks; returns the work handle when async_op"""
+    if NATIVE_COMM and t.is_cuda:
+        init_native_comm()
+        work = native_all_reduce(t, average=True)
+        if async_op:
+            return work
+        work.wait()
+        return None
     if dist.get_backend() == "nccl":
         return dist.all_reduce(t, op=dist.ReduceOp.AVG, async_op=async_op)
     return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op)      # gloo has no AVG: the caller divides
@@ -64,9 +134,13 @@ def average_gradients(flat_grad):
     if world_size() == 1:
         return flat_grad
     _avg_inplace(flat_grad)
-    if dist.get_backend() != "nccl":
+    if not _averages_in_collective(flat_grad):
         flat_grad.div_(world_size())
     return flat_grad
+
+
+def _averages_in_collective(t):
+    return (NATIVE_COMM and t.is_cuda) or dist.get_backend() == "nccl"
 
 
 def broadcast_parameters(flat_param, src=0, params=None):
@@ -177,6 +251,6 @@ class BucketedAllReduce:
             self.next += 1
         for h in self.handles:
             h.wait()
-        if dist.get_backend() != "nccl":
+        if not _averages_in_collective(self.opt.grad):
             self.opt.grad.div_(world_size())
         self.handles = []

@@ -699,3 +699,47 @@ def test_sgd_and_adadelta_steps_vs_torch():
                 break
             for p, q in zip(ref_p, mine_p):
                 assert_close(f"{kind} step {it}", q.detach(), p.detach(), atol=1e-6, rtol=1e-5)
+
+
+def test_native_rccl_entry_points_single_rank():
+    """include/mrn_hip.h: mrn_comm_unique_id / mrn_comm_init / mrn_allreduce_f32 / mrn_broadcast_f32 / mrn_comm_destroy (RCCL bound
+    with dlopen at init time) on a one-rank communicator, through the stream plumbing the learners use with MRN_COMM=native.
+    (The multi-GPU collectives themselves can only run on the driver's 8-GPU node.)"""
+    from mrn_amd import _lib, parallel
+    assert parallel.init_native_comm(rank_=0, world=1) == 1
+    assert _lib.call("mrn_comm_world") == 1 and _lib.call("mrn_comm_rank") == 0
+    g = torch.randn(100003, device="cuda")
+    ref = g.clone()
+    parallel.native_all_reduce(g, average=True).wait()
+    parallel.native_all_reduce(g, average=False).wait()
+    parallel.native_broadcast(g, src=0)
+    torch.cuda.synchronize()
+    assert torch.equal(g, ref)
+    with pytest.raises(RuntimeError):
+        _lib.call("mrn_comm_init", 0, 1, __import__("ctypes").create_string_buffer(int(_lib.call("mrn_comm_unique_id_bytes"))))   # second communicator
+    _lib.call("mrn_comm_destroy")
+    parallel._native["world"] = 0
+    with pytest.raises(RuntimeError):
+        _lib.call("mrn_allreduce_f32", g.data_ptr(), g.numel(), 1, None)        # no communicator any more
+
+
+def test_softargmax1d_matches_torch():
+    """MRNNet.softargmax1d (reference modules/model.py:495-496): softmax(beta * x), forward and gradient"""
+    import contextlib
+    import io
+    import types
+    from mrn_amd.modules.model import MRNNet
+    opt = types.SimpleNamespace(Transformation="None", FeatureExtraction="VGG", SequenceModeling="BiLSTM", Prediction="CTC",
+                                num_fiducial=20, imgH=32, imgW=256, input_channel=4, output_channel=512, hidden_size=256, batch_max_length=25)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = MRNNet(opt)
+    x = torch.randn(7, 6)
+    ref_in = x.clone().requires_grad_(True)
+    ref = torch.softmax(5 * ref_in, -1)
+    up = torch.randn(7, 6)
+    (ref * up).sum().backward()
+    mine_in = x.clone().cuda().requires_grad_(True)
+    out = net.softargmax1d(mine_in, beta=5)
+    (out * up.cuda()).sum().backward()
+    assert_close("softargmax1d", out, ref.detach(), atol=1e-6, rtol=1e-5)
+    assert_close("softargmax1d grad", mine_in.grad, ref_in.grad, atol=1e-6, rtol=1e-4)
