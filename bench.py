@@ -31,11 +31,17 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0                         # MI355X_MICROARCH.md: de
 HBM_PEAK_GBS = 8000.0                                  # MI355X_MICROARCH.md: HBM3E peak (6.3 TB/s achievable on a float4 copy)
 
 
+PMC_SOURCE = ("static: profiles/r02_pmc.json -- separate rocprofv3 --pmc passes of this same command (tools/pmc_pass.sh), "
+              "FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE; counters cannot be read from inside the timed run")
+
+
 def pmc_traffic(kernel_name):
     """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes (profiles/r01_pmc.json, produced by
     tools/pmc_pass.sh on this same command): FETCH_SIZE x 2 (the gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE,
     both KiB counters.  None when the kernel has no entry (counters cannot be read from inside the timed run)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r02_pmc.json")
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "r01_pmc.json")
     if not os.path.exists(path):
         return None
     with open(path) as f:
@@ -143,6 +149,50 @@ def cpu_baseline(learner, opt, n_experts, batch=32, iters=3, max_threads=32, bud
             "sample": f"{len(times)} timed iteration(s) (+1 warm-up) of the same loop B at batch {batch}, fp32, torch-CPU oracle"}
 
 
+def build_loop_a_learner(opt, quiet=True):
+    """MRN task 0: ONE expert, everything trainable -- loop A (il_modules/mrn.py:225-279), the full forward + backward step"""
+    from mrn_amd.data.synthetic import synthetic_characters
+    from mrn_amd.il_modules.mrn import MRN
+    with contextlib.redirect_stdout(io.StringIO() if quiet else sys.stdout):
+        learner = MRN(opt)
+        learner.character = synthetic_characters(CLASSES_MLT19[0])
+        learner.converter = learner.build_converter()
+        learner.criterion = learner.build_criterion()
+        learner.build_model()
+        learner.build_optimizer(learner.count_param(), total_steps=10 ** 9)
+    return learner
+
+
+def time_loop_a(args, opt, rank, world, steps, warmup):
+    """loop A on the same synthetic crops: forward, loss, backward (bucketed all-reduce when N > 1), clip, Adam"""
+    from mrn_amd import parallel
+    from mrn_amd.data.synthetic import SyntheticTextLines
+    learner = build_loop_a_learner(opt, quiet=not args.verbose)
+    data = SyntheticTextLines(opt, seed=211 + rank)
+    data.set_characters(learner.character)
+    for _ in range(warmup):
+        learner.train_step(*data.get_batch())
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = learner.train_step(*data.get_batch())
+    torch.cuda.synchronize()
+    parallel.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=learner.device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    n_params = learner.optimizer.flat.numel()
+    del learner
+    torch.cuda.empty_cache()
+    return {"metric": f"text-line images/sec, loop A (train the newest {args.model.upper()} expert: fwd + bwd + clip + Adam) at 32x256",
+            "value": world * args.batch * steps / elapsed, "unit": "images/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps,
+            "warmup": warmup, "per_gpu_batch": args.batch, "trainable_parameters": n_params, "loss": float(loss.detach()),
+            "dtype": "f32 (trained convolutions as range-safe split-fp16 x3 products, fp32 accumulate)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,6 +213,9 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="do not issue batch n+1's expert forward before batch n's router phase")
     ap.add_argument("--serial", action="store_true", help="one lock-step group on one stream, no look-ahead (every kernel runs alone)")
     ap.add_argument("--no-isolated-pass", action="store_true", help="skip the 2 extra serialized steps that measure the dominant kernel alone")
+    ap.add_argument("--loop", default="b", choices=["a", "b"], help="b (default): the router phase over frozen experts, BASELINE's metric "
+                    "workload; a: train one expert (full forward + backward) -- printed as the main line instead")
+    ap.add_argument("--no-extra", action="store_true", help="do not append the short loop-A measurement under \"extra\"")
     args = ap.parse_args()
 
     from mrn_amd import ops, parallel
@@ -181,6 +234,15 @@ def main():
     else:
         ops.CONV_PRECISION = args.precision
     opt = make_opt(args.model, args.batch)
+    if args.loop == "a":
+        res = time_loop_a(args, opt, rank, world, args.steps, args.warmup)
+        if rank == 0:
+            res.update({"n_gpus": world, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
+                        "config": {"workload": f"MRN loop A: one {args.model.upper()} expert trained on 32x256x4 crops, random-init weights",
+                                   "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}"}})
+            print(json.dumps(res))
+        parallel.barrier()
+        return
     learner = build_learner(opt, args.experts, quiet=not args.verbose)
     learner.model.module.expert_streams = not args.no_streams
     if args.serial:
@@ -305,7 +367,7 @@ def main():
                 ach = per_launch / (avg_ms * 1e-3) / 1e12
                 kname, peak, per_flop = describe(kind)
                 rl.append({"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                           "traffic": pmc_traffic(kname), "algorithmic_bytes_per_launch": s_.get("total_bytes", 0.0) / s_["launches"],
+                           "traffic": pmc_traffic(kname), "traffic_source": PMC_SOURCE, "algorithmic_bytes_per_launch": s_.get("total_bytes", 0.0) / s_["launches"],
                            "kernel": kname, "mfma_flops_per_algorithmic_flop": per_flop,
                            "mfma_issue_frac": ach * per_flop / peak,
                            "launches_per_step": s_["launches"] / args.steps, "avg_launch_ms": avg_ms,
@@ -333,6 +395,15 @@ def main():
                 res["roofline_other_kernels"] = rl[1:] + hbm
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(learner, opt, args.experts)
+    extra = None
+    if not args.no_extra:                  # (every rank: loop A's train_step holds the gradient all-reduce)
+        del learner
+        pending.clear()
+        torch.cuda.empty_cache()
+        extra = time_loop_a(args, opt, rank, world, steps=5, warmup=2)
+    if rank == 0:
+        if extra is not None:
+            res["extra"] = {"loop_a": extra}
         print(json.dumps(res))
     parallel.barrier()
 

@@ -44,6 +44,9 @@ def main():
             torch.manual_seed(1)
             xs = [torch.rand(B, H, W, Cin, device="cuda") * 2 - 1 for _ in range(G)]
             ws = [(torch.rand(Cout, k[0], k[1], Cin, device="cuda") * 2 - 1) * 0.05 for _ in range(G)]
+            if os.environ.get("ZERO_INPUTS"):          # DVFS probe: same instruction stream, no operand toggling
+                xs = [t * 0 for t in xs]
+                ws = [t * 0 for t in ws] if os.environ["ZERO_INPUTS"] == "2" else ws
             x = torch.stack(xs)
             x_hl = ops.split_hl32(x)
             w_hl, w_scale = ops.pack_weights_hl32(ws)
