@@ -193,6 +193,55 @@ def time_loop_a(args, opt, rank, world, steps, warmup):
             "dtype": "f32 (trained convolutions as range-safe split-fp16 x3 products, fp32 accumulate)"}
 
 
+def time_der_step(args, opt, rank, world, steps, warmup):
+    """BASELINE config 5: DER (il_modules/der.py:208-290) on DERNet with `--experts` TRBA extractors -- the older ones frozen and in
+    eval mode (lock-step grouped forward), the newest one trained, main attention head over the 256 * N-wide concatenation,
+    auxiliary head on the newest 256 channels; loss = loss_clf."""
+    from mrn_amd import parallel
+    from mrn_amd.data.synthetic import SyntheticTextLines, synthetic_characters
+    from mrn_amd.il_modules.der import DER
+    with contextlib.redirect_stdout(io.StringIO() if not args.verbose else sys.stdout):
+        learner = DER(opt)
+        total = 0
+        for taski in range(args.experts):
+            total += CLASSES_MLT19[taski]
+            learner.character = synthetic_characters(total)
+            learner.converter = learner.build_converter()
+            if taski == 0:
+                learner.criterion = learner.build_criterion()
+                learner.build_model()
+            else:
+                learner.model = learner.model.module
+                learner._known_classes = learner._total_classes
+                learner.change_model()
+        for i in range(args.experts - 1):
+            for p in learner.model.module.model[i].parameters():
+                p.requires_grad = False
+        learner.build_optimizer(learner.count_param(), total_steps=10 ** 9)
+        learner.model_eval_and_train(args.experts - 1)
+    data = SyntheticTextLines(opt, seed=311 + rank)
+    data.set_characters(learner.character)
+    for _ in range(warmup):
+        learner.der_step(*data.get_batch())
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, aux = learner.der_step(*data.get_batch())
+    torch.cuda.synchronize()
+    parallel.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=learner.device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return {"metric": f"text-line images/sec, DER step ({args.model.upper()} x {args.experts} extractors, newest trained: fwd + bwd + clip + Adam) at 32x256",
+            "value": world * args.batch * steps / elapsed, "unit": "images/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps,
+            "warmup": warmup, "per_gpu_batch": args.batch, "trainable_parameters": learner.optimizer.flat.numel(),
+            "loss_clf": float(loss.detach()), "loss_aux": float(aux.detach()),
+            "dtype": "f32 (frozen extractors: split-fp16 x3; trained extractor: range-safe split-fp16 x3; fp32 accumulate)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -213,8 +262,9 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="do not issue batch n+1's expert forward before batch n's router phase")
     ap.add_argument("--serial", action="store_true", help="one lock-step group on one stream, no look-ahead (every kernel runs alone)")
     ap.add_argument("--no-isolated-pass", action="store_true", help="skip the 2 extra serialized steps that measure the dominant kernel alone")
-    ap.add_argument("--loop", default="b", choices=["a", "b"], help="b (default): the router phase over frozen experts, BASELINE's metric "
-                    "workload; a: train one expert (full forward + backward) -- printed as the main line instead")
+    ap.add_argument("--loop", default="b", choices=["a", "b", "der"], help="b (default): the router phase over frozen experts, BASELINE's "
+                    "metric workload; a: train one expert (full forward + backward); der: BASELINE config 5's DER step over --experts "
+                    "extractors -- a / der are printed as the main line instead")
     ap.add_argument("--no-extra", action="store_true", help="do not append the short loop-A measurement under \"extra\"")
     args = ap.parse_args()
 
@@ -234,11 +284,13 @@ def main():
     else:
         ops.CONV_PRECISION = args.precision
     opt = make_opt(args.model, args.batch)
-    if args.loop == "a":
-        res = time_loop_a(args, opt, rank, world, args.steps, args.warmup)
+    if args.loop in ("a", "der"):
+        res = (time_loop_a if args.loop == "a" else time_der_step)(args, opt, rank, world, args.steps, args.warmup)
         if rank == 0:
+            what = (f"MRN loop A: one {args.model.upper()} expert trained" if args.loop == "a"
+                    else f"DER step: DERNet over {args.experts} {args.model.upper()} extractors, newest trained")
             res.update({"n_gpus": world, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
-                        "config": {"workload": f"MRN loop A: one {args.model.upper()} expert trained on 32x256x4 crops, random-init weights",
+                        "config": {"workload": f"{what} on 32x256x4 crops, random-init weights",
                                    "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}"}})
             print(json.dumps(res))
         parallel.barrier()

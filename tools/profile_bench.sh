@@ -5,7 +5,7 @@ tag=$1; shift
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/$tag
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$tag/prof -o trace -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $R/gpurun_out/$tag/prof.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$tag/prof -o trace -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra "$@" > $R/gpurun_out/$tag/prof.log 2>&1
 cd $R
 python3 tools/rocprof_summary.py gpurun_out/$tag/prof/trace_results.db 3 > gpurun_out/$tag/summary.md 2>&1
 python3 tools/rocprof_timeline.py gpurun_out/$tag/prof/trace_results.db > gpurun_out/$tag/timeline.txt 2>&1
