@@ -13,6 +13,11 @@
  *     communicator created by an explicit mrn_comm_init)
  *   - return 0 on success, <0 library error, >0 hipError_t; text via mrn_last_error() (thread-local)
  *   - activations are fp32, NHWC (channels innermost); "rows" means all leading dims flattened
+ * Compiled-in limits (every shipped config of the reference sits inside them; a call outside returns an error, never a wrong
+ * result): recurrent kernels (LSTM layer, attention decoder) hidden_size == 256 (config/*.py: hidden_size=256), decoder context
+ * width D a multiple of 16 (forward) / of 256 (backward: DERNet concatenates 256-wide extractors); router fan-in / gate tail at most
+ * 8 experts (the reference trains 6 languages); TPS at most 61 fiducials (reference: 20); grouped-conv kernels Cin % 32 == 0 and
+ * kh*kw <= 32 (other layers run on the exact-fp32 kernels, Cin % 4 == 0).
  */
 #ifndef MRN_HIP_H
 #define MRN_HIP_H
@@ -105,6 +110,18 @@ int mrn_split_hl32_t_f32(const float* x, void* out, int64_t rows, int64_t rows_p
 int mrn_im2col_t_hl32_f32(const float* x, void* out, int B, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw,
                           int64_t rows_padded, int splits, const float* scale, void* stream);
 int mrn_pack_weight_hl32(const float* w_ohwi, void* out, int Cout, int taps, int Cin, const float* scale, void* stream);
+/* Convolution weight gradient of a 3x3 / stride 1 / pad 1 conv WITHOUT an im2col (loss.backward() through Conv2d, il_modules/mrn.py:260-261):
+ * mrn_transpose_oy_hl32_f32 writes x^T (or dy^T) as an HL32 matrix [C][ceil(B*H*W/32)][128 B] in image-row-major pixel order
+ * k = (y*B + b)*W + xx, shifted by shift_x along x with zero fill -- in that order a kernel-row offset is a whole number of lines
+ * and only the three horizontal shifts need their own copy (3x the activation instead of 9x);
+ * mrn_gemm_x3_windows_hl32 is the grouped split-fp16 x3 GEMM over K-WINDOWS of two such matrices: group g multiplies the window
+ * {a_off_bytes, w_off_bytes, n_lines} (device array of G records {int64, int64, int32, int32}) of every row pair,
+ * y [G][M][N]; one group per (split-K chunk, tap). */
+int mrn_transpose_oy_hl32_f32(const float* x, void* out, int B, int H, int W, int C, int shift_x, const float* scale, void* stream);
+int mrn_transpose_oy3_hl32_f32(const float* x, void* out, int B, int H, int W, int C, const float* scale, void* stream);   /* shifts -1, 0, +1 in one pass: out [3][C][lines][128 B] */
+int mrn_gemm_x3_windows_hl32(const void* a_hl, int64_t a_bytes, int a_pitch_lines, const void* w_hl, int64_t w_bytes,
+                             int w_pitch_lines, const void* windows, int G, int M, int N, const void* zero_page,
+                             const float* out_scale, const float* x_scale, float* y, int tile_m, int tile_n, void* stream);
 
 /* First convolution of the frozen experts' stacks (3x3, stride 1, padding 1, Cin = 4, Cout = 32 or 64: VGG conv 0
  * feature_extraction.py:19, ResNet conv0_1 :214, TPS localisation conv 1 transformation.py:60), G experts in one launch on the

@@ -34,6 +34,13 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
+// K-window of one group of a windowed GEMM (mrn_gemm_x3_windows_hl32): byte offsets of the window's first line inside the two
+// operand matrices and its length in K-steps (128-byte lines); rows are `a_pitch` / `w_pitch` lines apart
+struct X3Window {
+  long a_off, w_off;
+  int nk, pad;
+};
+
 struct ConvX3Params {
   const unsigned char* x;     // HL32 activation
   const unsigned char* w;     // HL32 weight
@@ -59,6 +66,9 @@ struct ConvX3Params {
   int wo_shift, bw_shift;
   unsigned kw_magic;          // ... and for kw (tap -> (ky, kx) once per K-step, on the scalar unit)
   int kw_shift;
+  const X3Window* win;        // windowed 1x1 GEMM: per-group operand windows (null: the regular grouped conv)
+  int a_pitch, w_pitch;       // ... row pitch of the two operand matrices in lines
+  int w_bytes;                // ... bytes of the whole weight-side matrix (x_bytes = the activation-side one)
 };
 
 // 16 bytes per lane, global (buffer descriptor + per-lane byte offset + wave-uniform offset) -> LDS (wave-uniform base + 16*lane)
@@ -167,7 +177,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
   }
   active = (unsigned)__builtin_amdgcn_readfirstlane((int)active);   // wave-uniform by construction: keeps the K-step iterator
   const int nact = __builtin_popcount(active);                      // (tap, channel block) and the DMA's scalar offset in SGPRs
-  const int nk = p.Cb * nact;
+  // operand bases / pitches / reduction length: the group's own tensors, or (windowed GEMM) a K-window of two shared matrices
+  int Cb = p.Cb, a_pitch = p.Cb, w_pitch = p.nk, a_bytes = p.x_bytes, w_bytes = (int)p.w_gstride;
+  long a_base = (long)(g / p.x_group_div) * p.x_gstride, w_base = (long)g * p.w_gstride;
+  if (p.win) {
+    const X3Window e = p.win[g];
+    Cb = e.nk; a_base = e.a_off; w_base = e.w_off;
+    a_pitch = p.a_pitch; w_pitch = p.w_pitch;
+    a_bytes = p.x_bytes - (int)e.a_off; w_bytes = p.w_bytes - (int)e.w_off;
+  }
+  const int nk = Cb * nact;
 
   // ---- DMA geometry: instruction j = i*8 + wave covers tile rows 8j .. 8j+7; lane -> row 8j + lane/8, LDS chunk lane&7.
   // Both operands go through buffer descriptors: per-lane 32-bit byte offset (VGPR) + wave-uniform K-step offset; an
@@ -176,8 +195,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
   int arow[NA];                     // byte offset of (pixel0 line + swizzled chunk) inside this group's activation (may be < 0)
   unsigned amask[NA];               // bit tap = this row's tap is inside the image
   int brow[NB];                     // byte offset of (weight row + swizzled chunk); rows beyond N re-read row N-1 (never stored)
-  const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x + (long)(g / p.x_group_div) * p.x_gstride, p.x_bytes);
-  const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.w + (long)g * p.w_gstride, (int)p.w_gstride);
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x + a_base, a_bytes);
+  const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.w + w_base, w_bytes);
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     const int row = (i * NW + wave) * 8 + lrow;
@@ -195,14 +214,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
       }
     }
     amask[i] = mask;
-    arow[i] = ((b * p.H + iy0) * p.W + ix0) * p.Cb * 128 + coff;
+    arow[i] = ((b * p.H + iy0) * p.W + ix0) * a_pitch * 128 + coff;
   }
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
     const int row = (i * NW + wave) * 8 + lrow;
     const int coff = (lch ^ ((row >> 1) & 7)) << 4;
     const int n = min(n0 + row, p.N - 1);
-    brow[i] = n * p.nk * 128 + coff;
+    brow[i] = n * w_pitch * 128 + coff;
   }
 
   // K-steps run channel-block outer, active-tap inner; (cb, tap) of the next tile to fetch is a wave-uniform iterator
@@ -210,7 +229,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
   unsigned it_rem = active;
   int it_tap = 0;
   auto issue_next = [&](unsigned char* st) {
-    if (it_rem == 0 && it_cb + 1 < p.Cb) {       // next channel block (after the last K-step the final tile is re-fetched
+    if (it_rem == 0 && it_cb + 1 < Cb) {       // next channel block (after the last K-step the final tile is re-fetched
       it_rem = active;                            //  into the idle stage, which keeps the loop body one basic block)
       ++it_cb;
     }
@@ -220,7 +239,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
     }
     const int tap = it_tap, cb = it_cb;
     const int ky = fast_div(tap, p.kw_magic, p.kw_shift), kx = tap - ky * p.kw;
-    const int aoff = ((ky * p.W + kx) * p.Cb + cb) * 128;
+    const int aoff = ((ky * p.W + kx) * a_pitch + cb) * 128;
 #ifdef MRN_PROBE_NO_DMA_A
     if (it_cb == 0 && tap == __builtin_ctz(active))      // (what-if probe, never in the product build: activations staged once)
 #endif
@@ -568,6 +587,105 @@ __global__ __launch_bounds__(256) void im2col_t_hl32_kernel(const Im2colT p) {
   }
 }
 
+// Transposed split in IMAGE-ROW-MAJOR pixel order, optionally shifted along x: NHWC fp32 x[b][y][xx][c] -> out[c][k / 32][hi 32 | lo 32]
+// with k = (y * B + b) * W + xx and element (c, k) = scale * x[b][y][xx + shift][c] (0 outside the row; k >= P: 0).  The operand layout
+// of the convolution weight gradient without an im2col (mrn_gemm_x3_windows_hl32): in this order a kernel-row offset ky - 1 is
+// a whole number of lines (B * W pixels) and only the THREE horizontal shifts need their own copy.  One block = 32 pixels x 32 channels.
+__global__ __launch_bounds__(256) void transpose_oy_hl32_kernel(const float* __restrict__ x, unsigned char* __restrict__ out, int B,
+                                                                int H, int W, int C, int shift, long P, long lines, long tiles_c,
+                                                                long ntiles, const float* __restrict__ scale) {
+  __shared__ float tile[32][33];
+  const float sc = scale ? scale[0] : 1.f;
+  const int t = threadIdx.x;
+  for (long id = blockIdx.x; id < ntiles; id += gridDim.x) {
+    const long kb = id / tiles_c;                 // 32-pixel block along k
+    const int c0 = (int)(id - kb * tiles_c) * 32;
+    {
+      const int r = t >> 3, c4 = (t & 7) * 4;
+      const long k = kb * 32 + r;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (k < P && c0 + c4 < C) {
+        const long row = k / W;                   // = y * B + b
+        const int xx = (int)(k - row * W) + shift;
+        const int y = (int)(row / B), b = (int)(row - (long)y * B);
+        if ((unsigned)xx < (unsigned)W) v = *reinterpret_cast<const f32x4*>(x + (((long)b * H + y) * W + xx) * C + c0 + c4);
+      }
+      tile[r][c4 + 0] = v[0] * sc; tile[r][c4 + 1] = v[1] * sc; tile[r][c4 + 2] = v[2] * sc; tile[r][c4 + 3] = v[3] * sc;
+    }
+    __syncthreads();
+    {
+      const int c = t >> 3, seg = t & 7;          // column c, pixels seg*4 .. +3
+      if (c0 + c < C) {
+        unsigned char* o = out + ((long)(c0 + c) * lines + kb) * 128 + seg * 8;
+        typedef _Float16 f16v4 __attribute__((ext_vector_type(4)));
+        f16v4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          _Float16 hh, ll;
+          split_h(tile[seg * 4 + e][c], hh, ll);
+          h[e] = hh; l[e] = ll;
+        }
+        *reinterpret_cast<f16v4*>(o) = h;
+        *reinterpret_cast<f16v4*>(o + 64) = l;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// The three horizontal shifts (-1, 0, +1) of transpose_oy_hl32_kernel from ONE read of the activation: out[s][c][k / 32][...] for
+// s = 0, 1, 2 (copy stride `copy_bytes`).  A block stages pixels k0 - 1 .. k0 + 32 (34 rows) x 32 channels.
+__global__ __launch_bounds__(256) void transpose_oy3_hl32_kernel(const float* __restrict__ x, unsigned char* __restrict__ out, int B,
+                                                                 int H, int W, int C, long P, long lines, long tiles_c, long ntiles,
+                                                                 long copy_bytes, const float* __restrict__ scale) {
+  __shared__ float tile[34][33];
+  __shared__ int xpos[34];
+  const float sc = scale ? scale[0] : 1.f;
+  const int t = threadIdx.x;
+  for (long id = blockIdx.x; id < ntiles; id += gridDim.x) {
+    const long kb = id / tiles_c;
+    const int c0 = (int)(id - kb * tiles_c) * 32;
+    for (int i = t; i < 34 * 8; i += 256) {
+      const int r = i >> 3, c4 = (i & 7) * 4;
+      const long k = kb * 32 + r - 1;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      int xx = -1000;
+      if (k >= 0 && k < P) {
+        const long row = k / W;
+        xx = (int)(k - row * W);
+        const int y = (int)(row / B), b = (int)(row - (long)y * B);
+        if (c0 + c4 < C) v = *reinterpret_cast<const f32x4*>(x + (((long)b * H + y) * W + xx) * C + c0 + c4);
+      }
+      if (c4 == 0) xpos[r] = xx;
+      tile[r][c4 + 0] = v[0] * sc; tile[r][c4 + 1] = v[1] * sc; tile[r][c4 + 2] = v[2] * sc; tile[r][c4 + 3] = v[3] * sc;
+    }
+    __syncthreads();
+    {
+      const int c = t >> 3, seg = t & 7;
+      if (c0 + c < C) {
+        typedef _Float16 f16v4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {              // shift = s - 1: destination pixel j takes source pixel j + shift of the SAME image row
+          f16v4 h, l;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int j = seg * 4 + e;             // destination row of the tile is j + 1, its source j + s
+            const int xd = xpos[j + 1];
+            const bool ok = xd >= 0 && (unsigned)(xd + s - 1) < (unsigned)W;
+            _Float16 hh, ll;
+            split_h(ok ? tile[j + s][c] : 0.f, hh, ll);
+            h[e] = hh; l[e] = ll;
+          }
+          unsigned char* o = out + s * copy_bytes + ((long)(c0 + c) * lines + kb) * 128 + seg * 8;
+          *reinterpret_cast<f16v4*>(o) = h;
+          *reinterpret_cast<f16v4*>(o + 64) = l;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // w [Cout][taps][Cin] fp32 (x scale[0]) -> [Cout][Cin/32][taps][hi 32 | lo 32]; one thread = 8 channels
 __global__ __launch_bounds__(256) void pack_weight_hl32_kernel(const float* __restrict__ w, unsigned char* __restrict__ out,
                                                                int Cout, int taps, int Cin, const float* __restrict__ scale) {
@@ -772,4 +890,65 @@ MRN_EXPORT int mrn_im2col_t_hl32_f32(const float* x, void* out, int B, int H, in
   hipLaunchKernelGGL(im2col_t_hl32_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p);
   MRN_LAUNCH_CHECK("im2col_t_hl32");
   return MRN_OK;
+}
+
+// x NHWC [B][H][W][C] fp32 -> transposed HL32 matrix [C][lines][128 B] (lines = ceil(B*H*W / 32)) in image-row-major pixel order
+// k = (y*B + b)*W + xx, shifted by shift_x pixels along x with zero fill: see transpose_oy_hl32_kernel
+MRN_EXPORT int mrn_transpose_oy_hl32_f32(const float* x, void* out, int B, int H, int W, int C, int shift_x, const float* scale,
+                                         void* stream) {
+  MRN_CHECK_ARG(x && out && C % 4 == 0 && B > 0 && H > 0 && W > 0, "mrn_transpose_oy_hl32_f32: bad operands");
+  const long P = (long)B * H * W, lines = (P + 31) / 32, tiles_c = (C + 31) / 32, ntiles = lines * tiles_c;
+  long grid = ntiles > 65536 ? 65536 : ntiles;
+  hipLaunchKernelGGL(transpose_oy_hl32_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, (unsigned char*)out, B, H, W,
+                     C, shift_x, P, lines, tiles_c, ntiles, scale);
+  MRN_LAUNCH_CHECK("transpose_oy_hl32");
+  return MRN_OK;
+}
+
+// the three copies shift_x = -1, 0, +1 of mrn_transpose_oy_hl32_f32 in one pass: out [3][C][lines][128 B]
+MRN_EXPORT int mrn_transpose_oy3_hl32_f32(const float* x, void* out, int B, int H, int W, int C, const float* scale, void* stream) {
+  MRN_CHECK_ARG(x && out && C % 4 == 0 && B > 0 && H > 0 && W > 0, "mrn_transpose_oy3_hl32_f32: bad operands");
+  const long P = (long)B * H * W, lines = (P + 31) / 32, tiles_c = (C + 31) / 32, ntiles = lines * tiles_c;
+  long grid = ntiles > 65536 ? 65536 : ntiles;
+  hipLaunchKernelGGL(transpose_oy3_hl32_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, (unsigned char*)out, B, H,
+                     W, C, P, lines, tiles_c, ntiles, (long)C * lines * 128, scale);
+  MRN_LAUNCH_CHECK("transpose_oy3_hl32");
+  return MRN_OK;
+}
+
+// Grouped GEMM over K-WINDOWS of two shared HL32 matrices on the conv_x3 kernel: for group g,
+//   y[g][m][n] = out_scale * sum over the window's K of A[m][a_off_g + k] * Wm[n][w_off_g + k]
+// a_hl: [M][a_pitch lines][128 B], w_hl: [N][w_pitch lines][128 B] (a_bytes / w_bytes their sizes); windows: DEVICE array of G
+// records {int64 a_off_bytes, int64 w_off_bytes, int32 n_lines, int32 pad}: where the window starts inside a row of each matrix
+// and how many 128-byte lines (32 K each) it spans (>= 1).  y [G][M][N] fp32.  out_scale / x_scale: {s, 1/s} of the two operands.
+// Used by the convolution weight gradient: A = dy^T, Wm = one of three x-shifted copies of x^T, one group per (split-K chunk, tap).
+MRN_EXPORT int mrn_gemm_x3_windows_hl32(const void* a_hl, int64_t a_bytes, int a_pitch_lines, const void* w_hl, int64_t w_bytes,
+                                        int w_pitch_lines, const void* windows, int G, int M, int N, const void* zero_page,
+                                        const float* out_scale, const float* x_scale, float* y, int tile_m, int tile_n, void* stream) {
+  MRN_CHECK_ARG(a_hl && w_hl && windows && zero_page && y && G >= 1 && M >= 1 && N >= 1, "mrn_gemm_x3_windows_hl32: bad operands");
+  MRN_CHECK_ARG(a_bytes < (1L << 31) && w_bytes < (1L << 31) && (uintptr_t)a_hl % 128 == 0 && (uintptr_t)w_hl % 128 == 0,
+                "mrn_gemm_x3_windows_hl32: operand matrices must be 128-byte aligned and below 2 GiB");
+  MRN_CHECK_ARG((tile_m == 256 && (tile_n == 256 || tile_n == 128 || tile_n == 64)) || (tile_m == 128 && tile_n == 128),
+                "mrn_gemm_x3_windows_hl32: tile must be 256x256, 256x128, 256x64 or 128x128");
+  ConvX3Params p;
+  memset(&p, 0, sizeof(p));
+  p.x = (const unsigned char*)a_hl; p.w = (const unsigned char*)w_hl; p.zero = (const unsigned char*)zero_page;
+  p.out_scale = nullptr; p.x_scale = x_scale; p.y = y;
+  p.win = (const X3Window*)windows; p.a_pitch = a_pitch_lines; p.w_pitch = w_pitch_lines;
+  p.x_bytes = (int)a_bytes; p.w_bytes = (int)w_bytes;
+  p.Cb = 1; p.taps = 1; p.nk = 1; p.x_group_div = 1;
+  p.G = G; p.M = M; p.N = N; p.y_ld = N; p.y_gstride = (long)M * N;
+  p.H = 1; p.W = 1; p.Ho = 1; p.Wo = 1; p.kh = 1; p.kw = 1; p.sh = 1; p.sw = 1;
+  p.BWo = M;
+  magic_div(1u, p.wo_magic, p.wo_shift);
+  magic_div((unsigned)p.BWo, p.bw_magic, p.bw_shift);
+  magic_div(1u, p.kw_magic, p.kw_shift);
+  // both operands carry their own power-of-two prescale: the epilogue multiplies by out_scale[g*2+1] * x_scale[1]; here ONE pair
+  // serves every group, so it is passed as a G-strided view of the same two floats by the caller when needed
+  p.out_scale = out_scale;
+  hipStream_t st = (hipStream_t)stream;
+  if (tile_n == 256) return launch_x3<4, 4, 2, 2>(p, st);
+  if (tile_m == 256 && tile_n == 64) return launch_x3<8, 1, 1, 2>(p, st);
+  if (tile_m == 256) return launch_x3<4, 2, 2, 2>(p, st);
+  return launch_x3<4, 2, 1, 2>(p, st);
 }

@@ -93,6 +93,7 @@ AUTO_SPLIT_MIN_K = 0
 #             subnormals; "bf16x3" amplifies 1e-5 forward differences through small-batch BatchNorm backward to ~3e-3.)
 TRAIN_CONV_PRECISION = os.environ.get("MRN_TRAIN_PRECISION", "fp16x3s")
 TRAIN_WGRAD_X3 = os.environ.get("MRN_TRAIN_WGRAD", "fp16x3s") == "fp16x3s"   # weight gradients on the same path
+WGRAD_WINDOWS = os.environ.get("MRN_WGRAD_WINDOWS", "1") == "1"   # 3x3 / s1 / p1 weight gradients without an im2col (A/B switch)
 LOCNET_CONV_PRECISION = None   # TPS localisation network: None = follow CONV_PRECISION ("f32" to pin it exact)
 AUTO_SPLIT_KIND = "fp16x3"   # arithmetic "auto" picks for the deep reductions ("fp16x3" | "bf16x3")
 USE_DMA_CONV = True          # pre-split activation + direct-to-LDS staging for the split-16-bit convs
@@ -384,6 +385,74 @@ def conv2d_wgrad_x3(dy, x, ksize, stride, padding, dy_scale=None, x_scale=None):
               out=part, x_group_div=taps)
     dw = colsum(part.view(S, taps * Cout * Cin)).view(taps, Cout, Cin) if S > 1 else part[0]
     return dw.permute(1, 0, 2).contiguous().view(Cout, kh, kw, Cin)
+
+
+_WINDOW_TABLES = {}
+
+
+def wgrad_windows_supported(dy, x, ksize, stride, padding):
+    """the im2col-free weight gradient covers 3x3 / stride 1 / pad 1 convs on maps at least two rows high whose image rows fill
+    whole 32-pixel lines (B * W % 32 == 0: every batch size that is a multiple of 32)"""
+    B, H, W, Cout = dy.shape
+    return (tuple(ksize) == (3, 3) and tuple(stride) == (1, 1) and tuple(padding) == (1, 1) and H >= 2 and (B * W) % 32 == 0
+            and Cout % 4 == 0 and x.shape[-1] % 4 == 0 and tuple(x.shape[:3]) == (B, H, W))
+
+
+def transpose_oy_hl32(x, shift, scale, out=None):
+    """NHWC fp32 [B,H,W,C] -> HL32 matrix [C][B*H*W/32][128 B] in image-row-major pixel order, shifted along x (zero fill)"""
+    B, H, W, C = x.shape
+    lines = (B * H * W + 31) // 32
+    if out is None:
+        out = torch.empty(C * lines * 128, device=x.device, dtype=torch.uint8)
+    call("mrn_transpose_oy_hl32_f32", _p(x), _p(out), B, H, W, C, int(shift), _p(scale), _stream())
+    return out
+
+
+def conv2d_wgrad_x3_windows(dy, x, dy_scale=None, x_scale=None):
+    """dW [Cout,3,3,Cin] of a 3x3 / stride 1 / pad 1 conv on the split-fp16 x3 path WITHOUT an im2col: dy^T and three x-shifted
+    copies of x^T in image-row-major pixel order (a kernel-row offset is then a whole number of 128-byte lines), one grouped GEMM
+    over (split-K chunk, tap) K-windows of those matrices, partial slabs reduced by a column-sum pass.  3x the activation is
+    written instead of the 9x of mrn_im2col_t_hl32_f32."""
+    B, H, W, Cout = dy.shape
+    Cin = x.shape[-1]
+    P = B * H * W
+    lines, bwl = P // 32, (B * W) // 32
+    dev = x.device
+    dy, x = dy.contiguous(), x.contiguous()
+    sd = dy_scale if dy_scale is not None else pow2_scale(dy)
+    sx = x_scale if x_scale is not None else pow2_scale(x)
+    a_hl = transpose_oy_hl32(dy, 0, sd)
+    per = Cin * lines * 128
+    w_hl = torch.empty(3 * per, device=dev, dtype=torch.uint8)
+    call("mrn_transpose_oy3_hl32_f32", _p(x), _p(w_hl), B, H, W, Cin, _p(sx), _stream())       # shifts -1, 0, +1 from one read
+    tiles = ((Cout + 255) // 256) * ((Cin + 255) // 256) * 9
+    S = max(1, min(512 // tiles if tiles < 512 else 1, max((lines - bwl) // 8, 1)))
+    key = (lines, bwl, Cin, S, dev)
+    tab = _WINDOW_TABLES.get(key)
+    if tab is None:
+        rows = []
+        for s_ in range(S):
+            for tap in range(9):
+                ky, kx = divmod(tap, 3)
+                lo = bwl if ky == 0 else 0                      # dy rows y >= 1 pair with x rows y - 1
+                hi = lines - bwl if ky == 2 else lines          # dy rows y <= H - 2 pair with x rows y + 1
+                L = hi - lo
+                start, end = lo + (L * s_) // S, lo + (L * (s_ + 1)) // S
+                assert end > start
+                rows.append([start * 128, (kx * Cin * lines + start + (ky - 1) * bwl) * 128, end - start])
+        tab = torch.tensor(rows, dtype=torch.int64).to(dev)
+        _WINDOW_TABLES[key] = tab
+    G = S * 9
+    part = torch.empty(S, 9, Cout, Cin, device=dev, dtype=torch.float32)
+    tile_m, tile_n = x3_tile(Cin, 32 * ((lines + S - 1) // S), M=Cout, G=G)
+    timed = CONV_TIMER is not None
+    t0 = CONV_TIMER.begin() if timed else None
+    call("mrn_gemm_x3_windows_hl32", _p(a_hl), Cout * lines * 128, lines, _p(w_hl), 3 * per, lines, _p(tab), G, Cout, Cin,
+         _p(_zero_page(dev)), _p(sx.view(1, 2).expand(G, 2).contiguous()), _p(sd), _p(part), tile_m, tile_n, _stream())
+    if timed:
+        CONV_TIMER.end(t0, 2.0 * 9 * Cout * Cin * P, "fp16x3/x3g%dx%d" % (tile_m, tile_n), 4.0 * (4 * P * Cin + P * Cout + G * Cout * Cin))
+    dw = colsum(part.view(S, 9 * Cout * Cin)).view(9, Cout, Cin) if S > 1 else part[0]
+    return dw.permute(1, 0, 2).contiguous().view(Cout, 3, 3, Cin)
 
 
 def pow2_scale(x, target=FP16_WEIGHT_PEAK):

@@ -743,3 +743,23 @@ def test_softargmax1d_matches_torch():
     (out * up.cuda()).sum().backward()
     assert_close("softargmax1d", out, ref.detach(), atol=1e-6, rtol=1e-5)
     assert_close("softargmax1d grad", mine_in.grad, ref_in.grad, atol=1e-6, rtol=1e-4)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(32, 4, 65, 64, 128), (64, 2, 16, 32, 64), (32, 8, 64, 128, 96)])
+def test_wgrad_without_im2col_matches_exact_fp32(B, H, W, Cin, Cout):
+    """mrn_transpose_oy_hl32_f32 + mrn_gemm_x3_windows_hl32 (3x3 / s1 / p1 weight gradient over K-windows of dy^T and three
+    x-shifted copies of x^T) against torch's conv weight gradient and against the im2col-based x3 path; gradient-sized dy"""
+    from mrn_amd import ops
+    g = torch.Generator().manual_seed(B + H + Cin)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    dy = torch.randn(B, H, W, Cout, generator=g) * 1e-4          # gradient magnitudes: the operands are prescaled on the device
+    ref = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).double(), (Cout, Cin, 3, 3), dy.permute(0, 3, 1, 2).double(),
+                                      stride=1, padding=1).permute(0, 2, 3, 1)                 # [Cout,3,3,Cin]
+    xd, dyd = x.cuda(), dy.cuda()
+    assert ops.wgrad_windows_supported(dyd, xd, (3, 3), (1, 1), (1, 1))
+    dw = ops.conv2d_wgrad_x3_windows(dyd, xd)
+    old = ops.conv2d_wgrad_x3(dyd, xd, (3, 3), (1, 1), (1, 1))
+    scale = ref.abs().max().item()
+    assert (dw.cpu().double() - ref).abs().max().item() <= 2e-6 * scale
+    assert (dw - old).abs().max().item() <= 2e-6 * scale
+    assert not ops.wgrad_windows_supported(dyd[:, :1], xd[:, :1], (3, 3), (1, 1), (1, 1))        # one-row maps: the im2col path
