@@ -63,7 +63,9 @@ int mrn_conv2d_nhwc_bf16split(const float* x, const void* w_hi, const void* w_lo
  * is good to ~2^-22 (fp32-rounding class).  The weight planes are then built with a power-of-two prescale
  * (mrn_pow2_scale_f32 -> device float[2] = {scale, 1/scale}; pass it to mrn_split_weight_bf16) and the same array
  * is passed as out_scale so the epilogue multiplies by 1/scale.  out_scale may be NULL (no scaling). */
-int mrn_pow2_scale_f32(const float* w, int64_t n, float target, float* scale, void* stream);
+/* workspace: two 32-bit device words zeroed ONCE by the caller; every call on the same stream may reuse them (the kernel's last
+ * block restores the zeros): running maximum + arrival ticket of the single launch */
+int mrn_pow2_scale_f32(const float* w, int64_t n, float target, float* scale, void* workspace, void* stream);
 /* Same product with the ACTIVATION pre-split too (x_hi / x_lo: bf16 NHWC planes from mrn_split_weight_bf16 on the fp32
  * tensor) and both operands staged by direct-to-LDS DMA (no staging registers, no conversion in the GEMM loop).
  * zero_page: >= 64 bytes of device zeros (source of padded taps).  Requires Cin % 8 == 0, (kh*kw*Cin) % 32 == 0. */

@@ -21,6 +21,7 @@
 // the 16-byte chunk index XOR-swizzled by (row >> 2) & 3, so the 16-lane groups of ds_read_b128 (16 rows, same
 // chunk) hit 16 distinct 16-byte slots; double-buffered, 64 KB + tap table -> two workgroups per CU.
 #include "common.hpp"
+#include <stdlib.h>
 #include "gemm.hpp"
 
 namespace {
@@ -474,9 +475,47 @@ __global__ void split_bf16_kernel(const float* __restrict__ w, unsigned short* _
 // scale[0] = 2^floor(log2(target / max|w|)), scale[1] = 1 / scale[0].  Three tiny launches, no workspace: scale[1] is
 // cleared, receives max|w| through atomicMax on its bit pattern (non-negative floats order like unsigned ints), and the
 // finalise kernel turns it into the pair.
-__global__ void pow2_clear_kernel(float* __restrict__ scale) { reinterpret_cast<unsigned*>(scale)[1] = 0u; }
+// ws: two words the caller zeroed ONCE ([0] = running max|w| as uint bits, [1] = arrival ticket), reusable by every later call on the
+// same stream: every block folds its maximum into ws[0] and takes a ticket; the LAST block to arrive turns the maximum into the
+// power-of-two pair {s, 1/s} and puts the two words back to zero (one launch instead of clear + max + finalise).
+__global__ __launch_bounds__(256) void pow2_scale_kernel(const float* __restrict__ w, long n, float target, float* __restrict__ scale,
+                                                         unsigned* __restrict__ ws) {
+  __shared__ float scratch[4];
+  float m = 0.f;
+  const long n4 = n >> 2;
+  const long stride = (long)gridDim.x * 256;
+  long i = blockIdx.x * 256L + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {          // four independent 16-byte loads in flight per lane
+    const f32x4 a = reinterpret_cast<const f32x4*>(w)[i], b = reinterpret_cast<const f32x4*>(w)[i + stride];
+    const f32x4 c = reinterpret_cast<const f32x4*>(w)[i + 2 * stride], d = reinterpret_cast<const f32x4*>(w)[i + 3 * stride];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m = fmaxf(fmaxf(m, fmaxf(fabsf(a[e]), fabsf(b[e]))), fmaxf(fabsf(c[e]), fabsf(d[e])));
+  }
+  for (; i < n4; i += stride) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(w)[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+  if (blockIdx.x == 0)
+    for (long j = (n4 << 2) + threadIdx.x; j < n; j += 256) m = fmaxf(m, fabsf(w[j]));
+  m = block_max<256>(m, scratch);
+  if (threadIdx.x == 0) {
+    if (!(m <= 0.f)) atomicMax(ws, __float_as_uint(m));                // NaN / inf pass through
+    __threadfence();
+    if (atomicAdd(ws + 1, 1u) == gridDim.x - 1) {                      // last arrival: every block's maximum is in
+      const float mm = __uint_as_float(atomicExch(ws, 0u));
+      atomicExch(ws + 1, 0u);
+      float sc = 1.f;
+      if (mm > 0.f && isfinite(mm)) sc = exp2f(floorf(log2f(target / mm)));
+      scale[0] = sc;
+      scale[1] = 1.f / sc;
+    }
+  }
+}
 
-__global__ __launch_bounds__(256) void pow2_amax_kernel(const float* __restrict__ w, long n, float* __restrict__ scale) {
+// the three-launch form (clear, maximum, finalise): the default; A/B partner: the single launch above (MRN_POW2_LAUNCHES=1)
+__global__ void pow2_clear_kernel(unsigned* __restrict__ ws) { ws[0] = 0u; }
+
+__global__ __launch_bounds__(256) void pow2_amax_kernel(const float* __restrict__ w, long n, unsigned* __restrict__ ws) {
   __shared__ float scratch[4];
   float m = 0.f;
   const long n4 = n >> 2;
@@ -487,11 +526,12 @@ __global__ __launch_bounds__(256) void pow2_amax_kernel(const float* __restrict_
   if (blockIdx.x == 0)
     for (long i = (n4 << 2) + threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(w[i]));
   m = block_max<256>(m, scratch);
-  if (threadIdx.x == 0 && !(m <= 0.f)) atomicMax(reinterpret_cast<unsigned*>(scale) + 1, __float_as_uint(m));   // NaN / inf pass through
+  if (threadIdx.x == 0 && !(m <= 0.f)) atomicMax(ws, __float_as_uint(m));
 }
 
-__global__ void pow2_finalize_kernel(float target, float* __restrict__ scale) {
-  const float m = scale[1];
+__global__ void pow2_finalize_kernel(float target, float* __restrict__ scale, unsigned* __restrict__ ws) {
+  const float m = __uint_as_float(ws[0]);
+  ws[0] = 0u;
   float s = 1.f;
   if (m > 0.f && isfinite(m)) s = exp2f(floorf(log2f(target / m)));
   scale[0] = s;
@@ -500,15 +540,28 @@ __global__ void pow2_finalize_kernel(float target, float* __restrict__ scale) {
 
 }  // namespace
 
-// scale[0] = largest power of two with scale*max|w| <= target, scale[1] = its inverse (both on the device)
-MRN_EXPORT int mrn_pow2_scale_f32(const float* w, int64_t n, float target, float* scale, void* stream) {
-  MRN_CHECK_ARG(w && scale && target > 0.f, "mrn_pow2_scale_f32: bad operands");
+// scale[0] = largest power of two with scale*max|w| <= target, scale[1] = its inverse (both on the device); workspace: two 32-bit
+// words zeroed once by the caller and then reusable by every call issued on the same stream.  One launch, no host sync.
+MRN_EXPORT int mrn_pow2_scale_f32(const float* w, int64_t n, float target, float* scale, void* workspace, void* stream) {
+  MRN_CHECK_ARG(w && scale && workspace && target > 0.f, "mrn_pow2_scale_f32: bad operands");
   MRN_CHECK_ARG((uintptr_t)w % 16 == 0, "mrn_pow2_scale_f32: operand must be 16-byte aligned");
-  long grid = (n / 4 + 255) / 256;
-  grid = grid < 1 ? 1 : (grid > 1024 ? 1024 : grid);
-  hipLaunchKernelGGL(pow2_clear_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, scale);
-  hipLaunchKernelGGL(pow2_amax_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, w, (long)n, scale);
-  hipLaunchKernelGGL(pow2_finalize_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, target, scale);
+  // default: clear + maximum + finalise.  The single self-resetting launch (MRN_POW2_LAUNCHES=1) measured no better on the same box
+  // (CRNN x 3 loop B 13.28-13.35 vs 13.04-13.26 ms/step, SVTR x 6 30.6 vs 30.1-30.3, TRBA loop A equal): its per-block ticket
+  // serialises on one address, the two extra launches hide behind neighbouring kernels.
+  static const bool three = !(getenv("MRN_POW2_LAUNCHES") && atoi(getenv("MRN_POW2_LAUNCHES")) == 1);
+  if (three) {
+    long g3 = (n / 4 + 255) / 256;
+    g3 = g3 < 1 ? 1 : (g3 > 1024 ? 1024 : g3);
+    hipLaunchKernelGGL(pow2_clear_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned*)workspace);
+    hipLaunchKernelGGL(pow2_amax_kernel, dim3((unsigned)g3), dim3(256), 0, (hipStream_t)stream, w, (long)n, (unsigned*)workspace);
+    hipLaunchKernelGGL(pow2_finalize_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, target, scale, (unsigned*)workspace);
+    MRN_LAUNCH_CHECK("pow2_scale");
+    return MRN_OK;
+  }
+  long grid = (n / 16 + 255) / 256;                      // (each lane keeps four float4 loads in flight)
+  grid = grid < 1 ? 1 : (grid > 512 ? 512 : grid);
+  hipLaunchKernelGGL(pow2_scale_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, w, (long)n, target, scale,
+                     (unsigned*)workspace);
   MRN_LAUNCH_CHECK("pow2_scale");
   return MRN_OK;
 }

@@ -101,6 +101,20 @@ DMA_MIN_CIN = 256            # below this the extra split pass costs more than t
 _ZERO_PAGES = {}
 
 
+_POW2_WS = {}
+
+
+def _pow2_ws():
+    """two zeroed words per (device, stream): the self-resetting workspace of mrn_pow2_scale_f32 (stream-ordered reuse)"""
+    st = torch.cuda.current_stream()
+    key = (st.device_index, st.cuda_stream)
+    ws = _POW2_WS.get(key)
+    if ws is None:
+        ws = torch.zeros(2, device=torch.device("cuda", st.device_index), dtype=torch.int32)
+        _POW2_WS[key] = ws
+    return ws.data_ptr()
+
+
 def _zero_page(device):
     z = _ZERO_PAGES.get(device)
     if z is None:
@@ -132,7 +146,7 @@ class PackedConvWeight:
             scale = None
             if half:
                 scale = torch.empty(2, device=dev, dtype=torch.float32)
-                call("mrn_pow2_scale_f32", _p(self.ohwi), n, FP16_WEIGHT_PEAK, _p(scale), _stream())
+                call("mrn_pow2_scale_f32", _p(self.ohwi), n, FP16_WEIGHT_PEAK, _p(scale), _pow2_ws(), _stream())
             call("mrn_split_weight_bf16", _p(self.ohwi), _p(hi), _p(lo), n, int(half), _p(scale), _stream())
             got = (hi, lo, scale)
             self._split[half] = got
@@ -460,7 +474,7 @@ def pow2_scale(x, target=FP16_WEIGHT_PEAK):
     _chk(x)
     assert x.is_contiguous()
     scale = torch.empty(2, device=x.device, dtype=torch.float32)
-    call("mrn_pow2_scale_f32", _p(x), x.numel(), float(target), _p(scale), _stream())
+    call("mrn_pow2_scale_f32", _p(x), x.numel(), float(target), _p(scale), _pow2_ws(), _stream())
     return scale
 
 
@@ -479,7 +493,7 @@ def pack_weights_hl32(ws, scale=None):
         _chk(w)
         assert tuple(w.shape) == (O, kh, kw, I) and w.is_contiguous()
         if not known:
-            call("mrn_pow2_scale_f32", _p(w), w.numel(), FP16_WEIGHT_PEAK, scale[g].data_ptr(), _stream())
+            call("mrn_pow2_scale_f32", _p(w), w.numel(), FP16_WEIGHT_PEAK, scale[g].data_ptr(), _pow2_ws(), _stream())
         call("mrn_pack_weight_hl32", _p(w), out.data_ptr() + g * per, O, kh * kw, I, scale[g].data_ptr(), _stream())
     return out, scale
 
