@@ -429,6 +429,14 @@ def main():
                            })
             rl.sort(key=lambda r: -r["kernel_share_of_step"])
             res["roofline"] = rl[0]
+            if rl[0]["kernel"].startswith("conv_x3_kernel<4, 4, 2, 2>"):
+                res["roofline"]["power_limit"] = {
+                    "statement": "this kernel is bound by the chip's power budget, not by its schedule: the same instruction stream "
+                                 "on its dominant shape runs 3.94 ms on random operands, 3.15 ms with zero activations, 2.80 ms with "
+                                 "zero activations and weights (673 algorithmic TFLOP/s = 0.27 of peak = 0.81 MFMA issue x 0.833 executed)",
+                    "effective_clock_ghz_under_profiler": 1.48, "peak_assumes_ghz": 2.4, "mfma_busy_at_effective_clock": 0.70,
+                    "source": "static: profiles/r02b_conv_x3_power_wall.md, profiles/r02a_conv_x3_dominant_shape_pmc.txt "
+                              "(tools/bench_conv_x3.py with ZERO_INPUTS, tools/pmc_conv_x3.sh)"}
             res["roofline"]["measured"] = ("timed region: HIP events per launch on the launch streams; two lock-step half-groups "
                                            "and the router phase of the previous batch share the GPU, so the rate is taken over "
                                            "the union of this kernel's launch intervals")
