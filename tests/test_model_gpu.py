@@ -790,3 +790,54 @@ def test_rcnn_extractor_vs_reference():
         oe = net(image, None, False)
     assert_sub_close(g, "eval/predict", oe["predict"], atol=1e-4)
     assert np.array_equal(oe["predict"].max(2)[1].cpu().numpy(), g["eval/argmax"])
+
+
+@pytest.mark.parametrize("arch", ["crnn", "svtr"])
+def test_full_size_loop_a_directional_derivative(arch):
+    """Loop A at BASELINE size (one expert, 256 crops, 2090 classes): a size-independent property of loss.backward() -- along the
+    normalised gradient direction d = g / |g| the central difference (L(theta + eps d) - L(theta - eps d)) / (2 eps) equals |g|.
+    Ties the whole backward (conv dgrad / weight gradient without im2col, BatchNorm, pooling, BiLSTM BPTT or SVTR attention, CTC) to
+    the forward at the size the bench runs.  Eval-free: BatchNorm in train mode on the same batch for all three evaluations."""
+    from mrn_amd import functional as Fn
+    from mrn_amd.modules.model import Model
+    from mrn_amd.tools import weights as W
+    opt = make_opt(arch)
+    C, B = 2090, 256
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = Model(opt)
+        net.update_fc(opt.hidden_size, C)
+        net.build_prediction(opt, C)
+    W.fill_state_dict(net.state_dict(), seed=41)
+    net = net.cuda().train()
+    if arch == "svtr":
+        from mrn_amd.modules.svtr import DropPath
+        for m in net.modules():
+            if isinstance(m, DropPath):
+                m.drop_prob = 0.0                      # (the three evaluations must see the same function)
+    image = torch.from_numpy(W.uniform("fullA", (B, 4, 32, 256), -1.0, 1.0, 5)).cuda()
+    labels = torch.from_numpy(W.randint("fullA_lab", (B, 25), 4, C, 5)).cuda()
+    lengths = torch.from_numpy(W.randint("fullA_len", (B,), 1, 26, 5)).int().cuda()
+    bn_state = {k: v.clone() for k, v in net.state_dict().items() if "running_" in k or "num_batches" in k}
+
+    def loss_at():
+        net.load_state_dict(bn_state, strict=False)
+        return Fn.ctc_loss(net(image, None, True)["predict"], labels, lengths)
+
+    params = [p for p in net.parameters() if p.requires_grad]
+    loss = loss_at()
+    loss.backward()
+    grads = [p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p) for p in params]
+    gnorm = float(torch.sqrt(sum((g.double() ** 2).sum() for g in grads)))
+    assert np.isfinite(gnorm) and gnorm > 0
+    eps = 2e-3
+    vals = []
+    with torch.no_grad():
+        for sign in (+1.0, -1.0):
+            for p, g in zip(params, grads):
+                p.add_(g, alpha=sign * eps / gnorm)
+            torch.autograd.graph.increment_version(params)
+            vals.append(float(loss_at()))
+            for p, g in zip(params, grads):
+                p.add_(g, alpha=-sign * eps / gnorm)
+    fd = (vals[0] - vals[1]) / (2 * eps)
+    assert abs(fd - gnorm) <= 2e-2 * gnorm, (fd, gnorm, float(loss))
