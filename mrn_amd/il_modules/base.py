@@ -112,6 +112,8 @@ class BaseLearner(object):
         else:
             raise ValueError(f"unknown optimizer '{name}' (sgd | adadelta | adam)")
         parallel.broadcast_parameters(self.optimizer.flat, params=self.optimizer.params)
+        if self.reducer is not None:
+            self.reducer.close()
         self.reducer = parallel.BucketedAllReduce(self.optimizer) if parallel.world_size() > 1 else None
         self.opt_step = 0
         if "super" in schedule:

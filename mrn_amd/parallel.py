@@ -200,7 +200,7 @@ class BucketedAllReduce:
         # walk the parameters backwards, closing a bucket when it reaches the capacity
         self.buckets = []          # (start, end) element ranges, bucket 0 = the tail of the buffer
         self.bucket_of = [0] * len(optimizer.params)
-        hi, count = n, 0
+        hi = n
         members = []
         for i in range(len(optimizer.params) - 1, -1, -1):
             members.append(i)
@@ -215,9 +215,15 @@ class BucketedAllReduce:
         for b in self.bucket_of:
             self.sizes[b] += 1
         self.active = False
-        for i, p in enumerate(optimizer.params):
-            p.register_post_accumulate_grad_hook(self._make_hook(i))
+        self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(optimizer.params)]
         self.launched_log = []     # bucket indices in launch order of the last step (tests)
+
+    def close(self):
+        """detach from the parameters (a learner builds a new optimiser -- and a new reducer -- for every task / step)"""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        self.active = False
 
     def _make_hook(self, i):
         def hook(_param):
