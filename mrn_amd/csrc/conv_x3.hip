@@ -112,6 +112,15 @@ __device__ __forceinline__ int row_to_pixel(const ConvX3Params& p, int m, int& o
   return (b * p.Ho + oy) * p.Wo + ox;
 }
 
+template <int WAVES_M, int WAVES_N, int WM, int WN, int NPROD>
+constexpr bool x3_hi_only() {
+  return NPROD == 1 && (WAVES_M * WM * 32) % (16 * WAVES_M * WAVES_N) == 0 && (WAVES_N * WN * 32) % (16 * WAVES_M * WAVES_N) == 0;
+}
+template <int WAVES_M, int WAVES_N, int WM, int WN, int NPROD>
+constexpr size_t x3_lds_bytes() {
+  return (size_t)(WAVES_M * WM * 32 + WAVES_N * WN * 32) * (x3_hi_only<WAVES_M, WAVES_N, WM, WN, NPROD>() ? 64 * 4 : 128 * 2);
+}
+
 // WAVES_M x WAVES_N waves; wave tile = (WM*32) x (WN*32); HL_OUT: the epilogue can also write the HL32 result (p.y_hl)
 // NPROD: 3 = split-fp16 x3 (lo*hi + hi*lo + hi*hi, 22-bit products: the parity mode); 1 = hi*hi only (plain fp16 products with fp32
 // accumulation -- the reduced-precision mode of BASELINE configs 2 and 5; the lo halves of the staged lines are not read)
@@ -119,8 +128,14 @@ template <int WAVES_M, int WAVES_N, int WM, int WN, bool HL_OUT = false, int NPR
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const ConvX3Params p) {
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
-  constexpr int NA = BM / (8 * NW), NB = BN / (8 * NW);   // DMA instructions per wave per K-step (8 rows each)
-  constexpr int STAGE = (BM + BN) * 128;
+  // HI_ONLY (one product, tiles whose rows divide evenly over the waves): only the hi half of every line is staged -- 64-byte LDS
+  // rows, 16 rows per DMA instruction, half the staging traffic and LDS footprint, which buys a four-deep ring instead of two stages
+  constexpr bool HI_ONLY = x3_hi_only<WAVES_M, WAVES_N, WM, WN, NPROD>();
+  constexpr int ROWB = HI_ONLY ? 64 : 128;                // LDS bytes per tile row
+  constexpr int RPI = HI_ONLY ? 16 : 8;                   // tile rows per DMA instruction (64 lanes x 16 bytes)
+  constexpr int NA = BM / (RPI * NW), NB = BN / (RPI * NW);   // DMA instructions per wave per K-step
+  constexpr int STAGE = (BM + BN) * ROWB;
+  constexpr int NSTAGE = HI_ONLY ? 4 : 2;
   extern __shared__ __attribute__((aligned(128))) unsigned char lds[];
 
   int lid = xcd_remap(blockIdx.x, gridDim.x);
@@ -191,7 +206,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
   // ---- DMA geometry: instruction j = i*8 + wave covers tile rows 8j .. 8j+7; lane -> row 8j + lane/8, LDS chunk lane&7.
   // Both operands go through buffer descriptors: per-lane 32-bit byte offset (VGPR) + wave-uniform K-step offset; an
   // offset beyond the descriptor's range returns zeros, which is how padded taps / rows beyond M are produced.
-  const int lrow = lane >> 3, lch = lane & 7;
+  const int lrow = HI_ONLY ? lane >> 2 : lane >> 3, lch = HI_ONLY ? lane & 3 : lane & 7;
   int arow[NA];                     // byte offset of (pixel0 line + swizzled chunk) inside this group's activation (may be < 0)
   unsigned amask[NA];               // bit tap = this row's tap is inside the image
   int brow[NB];                     // byte offset of (weight row + swizzled chunk); rows beyond N re-read row N-1 (never stored)
@@ -199,8 +214,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
   const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.w + w_base, w_bytes);
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
-    const int row = (i * NW + wave) * 8 + lrow;
-    const int coff = (lch ^ ((row >> 1) & 7)) << 4;
+    const int row = (i * NW + wave) * RPI + lrow;
+    const int coff = HI_ONLY ? (lch ^ ((row >> 2) & 3)) << 4 : (lch ^ ((row >> 1) & 7)) << 4;
     const int m = m0 + row;
     const bool ok = m < p.M;
     int oy, ox, b;
@@ -218,8 +233,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
   }
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
-    const int row = (i * NW + wave) * 8 + lrow;
-    const int coff = (lch ^ ((row >> 1) & 7)) << 4;
+    const int row = (i * NW + wave) * RPI + lrow;
+    const int coff = HI_ONLY ? (lch ^ ((row >> 2) & 3)) << 4 : (lch ^ ((row >> 1) & 7)) << 4;
     const int n = min(n0 + row, p.N - 1);
     brow[i] = n * w_pitch * 128 + coff;
   }
@@ -253,7 +268,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
     if (it_cb == 0 && tap == __builtin_ctz(active))      // (what-if probe, never in the product build: weights staged once)
 #endif
 #pragma unroll
-    for (int i = 0; i < NB; ++i) dma16(wr, st + BM * 128 + (i * NW + wave) * 1024, brow[i], boff);
+    for (int i = 0; i < NB; ++i) dma16(wr, st + BM * ROWB + (i * NW + wave) * 1024, brow[i], boff);
   };
 
   f32x16 acc[WM][WN];
@@ -266,14 +281,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
 
   // fragment read offsets: row = lane & 31 (+32 per fragment), logical chunk = plane*4 + ks*2 + (lane >> 5);
   // tile rows start at multiples of 32 so the swizzle key depends on the lane only
-  const int key = (lane >> 1) & 7;
-  const int rbase = (lane & 31) * 128;
+  // (HI_ONLY: 64-byte rows, four chunks, key = (row >> 2) & 3 -- the 16 lanes of one ds_read_b128 phase cover all 64 banks once)
+  const int key = HI_ONLY ? (lane >> 2) & 3 : (lane >> 1) & 7;
+  const int rbase = (lane & 31) * ROWB;
   int foff[2][2];   // [plane][ks]
 #pragma unroll
   for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) foff[pl][ks] = rbase + (((pl * 4 + ks * 2 + (lane >> 5)) ^ key) << 4);
-  const int abase = wm * WM * 32 * 128, bbase = BM * 128 + wn * WN * 32 * 128;
+    for (int ks = 0; ks < 2; ++ks) foff[pl][ks] = rbase + ((((HI_ONLY ? 0 : pl * 4) + ks * 2 + (lane >> 5)) ^ key) << 4);
+  constexpr int FRAG = 32 * ROWB;   // bytes of one 32-row fragment
+  const int abase = wm * WM * FRAG, bbase = BM * ROWB + wn * WN * FRAG;
 
   u32x4 ah[2][WM], al[2][WM], bh[2][WN], bl[2][WN];
   auto read_frags = [&](const unsigned char* cur, int ks) {
@@ -282,13 +299,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
 #endif
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
-      if constexpr (NPROD == 3) al[ks][i] = *reinterpret_cast<const u32x4*>(cur + abase + i * 4096 + foff[1][ks]);
-      ah[ks][i] = *reinterpret_cast<const u32x4*>(cur + abase + i * 4096 + foff[0][ks]);
+      if constexpr (NPROD == 3) al[ks][i] = *reinterpret_cast<const u32x4*>(cur + abase + i * FRAG + foff[1][ks]);
+      ah[ks][i] = *reinterpret_cast<const u32x4*>(cur + abase + i * FRAG + foff[0][ks]);
     }
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
-      bh[ks][j] = *reinterpret_cast<const u32x4*>(cur + bbase + j * 4096 + foff[0][ks]);
-      if constexpr (NPROD == 3) bl[ks][j] = *reinterpret_cast<const u32x4*>(cur + bbase + j * 4096 + foff[1][ks]);
+      bh[ks][j] = *reinterpret_cast<const u32x4*>(cur + bbase + j * FRAG + foff[0][ks]);
+      if constexpr (NPROD == 3) bl[ks][j] = *reinterpret_cast<const u32x4*>(cur + bbase + j * FRAG + foff[1][ks]);
     }
   };
   auto mmas = [&](int ks) {
@@ -314,7 +331,27 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
   // 410 TFLOP/s; a 3-stage ring with counted vmcnt + raw s_barrier on the 256x128 tile +2.7 %, which does not fit the
   // 160 KiB LDS at 256x256; single-stage 256x128 tiles with 4 waves and two workgroups per CU (occupancy instead of
   // software pipelining) 451 vs 478 TFLOP/s for the 256x256 double-buffered tile.)
-  if constexpr (NW == 16 && NPROD == 3) {
+  if constexpr (HI_ONLY) {
+    // one product per term: 8 MFMAs per wave per K-step cannot hide a barrier-to-barrier DMA round trip, so the tiles run
+    // through a four-deep ring -- three K-steps of DMA in flight, own arrivals counted with s_waitcnt vmcnt (a compile-time
+    // count: the iterator re-fetches the final tile once the reduction is exhausted, so every iteration issues the same DMAs)
+    constexpr int INFLIGHT = (NA + NB) * (NSTAGE - 2);
+    constexpr int WAITIMM = (INFLIGHT & 15) | (7 << 4) | (15 << 8) | ((INFLIGHT >> 4) << 14);   // vmcnt(INFLIGHT), others untouched
+    static_assert(INFLIGHT < 64, "vmcnt is six bits");
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s) issue_next(lds + s * STAGE);
+    for (int kt = 0; kt < nk; ++kt) {
+      __builtin_amdgcn_s_waitcnt(WAITIMM);   // own DMAs of tile kt have landed (the NSTAGE-2 younger tiles may still fly)
+      __builtin_amdgcn_s_barrier();          // ... everyone's have, and everyone has finished reading tile kt-1's stage
+      issue_next(lds + ((kt + NSTAGE - 1) % NSTAGE) * STAGE);
+      const unsigned char* cur = lds + (kt % NSTAGE) * STAGE;
+      read_frags(cur, 0);
+      read_frags(cur, 1);
+      mmas(0);
+      mmas(1);
+    }
+    __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));   // vmcnt(0): the re-fetches of the tail are not left in flight
+  } else if constexpr (NW == 16 && NPROD == 3) {
     // 16 waves x 64x64 (four waves per SIMD: 128 VGPRs each): only the hi x hi third of a K-step's second half is carried
     // across the barrier (16 fragment registers) -- the full skew of the 8-wave variants would need both fragment sets live
     // (36 spills inside the loop: 185 TFLOP/s).
@@ -742,7 +779,7 @@ int launch_x3(const ConvX3Params& p0, hipStream_t st) {
   p.tilesN = ceil_div(p.N, BN);
   p.tiles_per_row = (p.oy_major && p.BWo % BM == 0 && !env_flags().no_interleave) ? p.BWo / BM : 0;
   p.class_order = (p.tiles_per_row > 0 && p.Ho >= 3 && p.kh == 3 && p.ph == 1 && p.sh == 1 && !env_flags().no_class_order) ? 1 : 0;
-  const size_t ldsz = 2 * (size_t)(BM + BN) * 128;
+  const size_t ldsz = x3_lds_bytes<WAVES_M, WAVES_N, WM, WN, NPROD>();
   const long tiles = (long)p.G * p.tilesM * p.tilesN;
   static bool attr_set = false;      // (per instantiation: the attribute is sticky, one driver call instead of one per launch)
   if (!attr_set) {
