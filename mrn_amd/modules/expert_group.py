@@ -379,33 +379,31 @@ class BackboneGroup(_GroupedLinear):
         return x if as_act else x.f32.view(G, B, Wo, Cf)
 
 
-class HeadsGroup(_GroupedLinear):
-    """SequenceModeling + Prediction of G frozen experts in lock-step (BiLSTM x 2 + CTC Linear / teacher-forced attention
-    decoder): every Linear is a grouped split-fp16 x3 GEMM (csrc/conv_x3.hip with a 1x1 kernel), every recurrence ONE
-    launch for all experts (mrn_lstm_layer_fwd_grouped_f32 / mrn_attn_decoder_fwd_grouped_f32).  Replaces six concurrent
-    streams of 16-32-workgroup launches whose overlap was left to the hardware queues."""
+class SequenceGroup(_GroupedLinear):
+    """SequenceModeling of G frozen extractors in lock-step (BiLSTM x 2, or the SVTR-style single Linear): every Linear is a
+    grouped split-fp16 x3 GEMM (csrc/conv_x3.hip with a 1x1 kernel), every recurrence ONE launch for all extractors
+    (mrn_lstm_layer_fwd_grouped_f32).  Used on its own by DERNet (frozen old extractors, reference modules/model.py:223-254)
+    and as the first half of HeadsGroup."""
 
-    def __init__(self, experts):
-        self.experts = list(experts)        # Model modules
-        self.G = len(self.experts)
+    def __init__(self, extractors):
+        self.extractors = list(extractors)      # Model_Extractor modules
+        self.G = len(self.extractors)
         self._cache = {}
 
     @staticmethod
-    def supported(experts, is_train):
-        e0 = experts[0]
-        if len(experts) < 2 or e0.model.stages["Seq"] not in ("BiLSTM", "None"):
+    def sequence_supported(extractors):
+        e0 = extractors[0]
+        if len(extractors) < 2 or e0.stages["Seq"] not in ("BiLSTM", "None"):
             return False
-        if any(e.model.stages != e0.model.stages or e.stages != e0.stages for e in experts):
-            return False
-        if e0.stages["Pred"] == "Attn" and not is_train:       # greedy decoding feeds argmax back step by step: per expert
+        if any(e.stages != e0.stages for e in extractors):
             return False
         return ops.CONV_PRECISION in ("auto", "fp16x3") and ops.AUTO_SPLIT_KIND == "fp16x3"
 
-    def _bilstm(self, idx, x_hl, rows_shape, K):
-        """BidirectionalLSTM number idx of every expert: x [G, B*T, K] (HL32) -> [G,B,T,256] fp32"""
+    def _bilstm(self, idx, x_hl, rows_shape, K, **dst):
+        """BidirectionalLSTM number idx of every extractor: x [G, B*T, K] (HL32) -> [G,B,T,256] fp32 (or the strided `out`)"""
         G = self.G
         B, T = rows_shape
-        mods = [e.model.SequenceModeling[idx] for e in self.experts]
+        mods = [e.SequenceModeling[idx] for e in self.extractors]
         H = mods[0].hidden_size
         packed = [m._packed() for m in mods]                     # (w_ih [2*4H,in], w_hh frag-major [2,...], b_ih, b_hh)
         xproj = self._linear("ih%d" % idx, x_hl, B * T, K, [p[0] for p in packed], [p[2] for p in packed])
@@ -421,21 +419,49 @@ class HeadsGroup(_GroupedLinear):
             rec = ops.lstm_layer_x3_grouped(xproj.view(G, B, T, 2 * 4 * H), w_h, w_inv, b_hh, H, 2)
         else:
             rec = ops.lstm_layer_grouped(xproj.view(G, B, T, 2 * 4 * H), w_hh, b_hh, H, 2)
-        return self._linear("lin%d" % idx, ops.split_hl32(rec), B * T, 2 * H, [m.linear.weight for m in mods],
-                            [m.linear.bias for m in mods]).view(G, B, T, -1)
+        y = self._linear("lin%d" % idx, ops.split_hl32(rec), B * T, 2 * H, [m.linear.weight for m in mods],
+                         [m.linear.bias for m in mods], **dst)
+        return y if dst else y.view(G, B, T, -1)
+
+    def sequence(self, visual, out=None, out_row_stride=0, out_group_stride=0):
+        """visual: Act with the backbone features [G,B,1,T,C'] -> contextual features [G,B,T,hidden]; with `out` and the two
+        strides (floats) extractor g's rows land at out + g * out_group_stride + row * out_row_stride instead"""
+        _, B, _, T, Cf = visual.shape
+        x_hl = visual.hl if visual.hl is not None else ops.split_hl32(visual.f32)
+        dst = dict(out=out, out_row_stride=out_row_stride, out_group_stride=out_group_stride) if out is not None else {}
+        if self.extractors[0].stages["Seq"] == "BiLSTM":
+            y1 = self._bilstm(0, x_hl, (B, T), Cf)
+            return self._bilstm(1, ops.split_hl32(y1), (B, T), y1.shape[-1], **dst)      # [G,B,T,hidden]
+        lins = [e.SequenceModeling[0] for e in self.extractors]                      # Seq "None": one Linear (model.py sequence())
+        y = self._linear("seq", x_hl, B * T, Cf, [l.weight for l in lins], [l.bias for l in lins], **dst)
+        return y if out is not None else y.view(self.G, B, T, -1)
+
+
+class HeadsGroup(SequenceGroup):
+    """SequenceModeling + Prediction of G frozen experts in lock-step (BiLSTM x 2 + CTC Linear / teacher-forced attention
+    decoder): every Linear is a grouped split-fp16 x3 GEMM (csrc/conv_x3.hip with a 1x1 kernel), every recurrence ONE
+    launch for all experts (mrn_lstm_layer_fwd_grouped_f32 / mrn_attn_decoder_fwd_grouped_f32).  Replaces six concurrent
+    streams of 16-32-workgroup launches whose overlap was left to the hardware queues."""
+
+    def __init__(self, experts):
+        self.experts = list(experts)        # Model modules
+        super().__init__([e.model for e in self.experts])
+
+    @staticmethod
+    def supported(experts, is_train):
+        e0 = experts[0]
+        if not SequenceGroup.sequence_supported([e.model for e in experts]) or any(e.stages != e0.stages for e in experts):
+            return False
+        if e0.stages["Pred"] == "Attn" and not is_train:       # greedy decoding feeds argmax back step by step: per expert
+            return False
+        return True
 
     def run(self, visual, text, feats_out, logits_out):
         """visual: Act with the backbone features [G,B,1,T,C'] (HL32 and / or fp32); feats_out [B,T,G,hidden] (router
         layout, expert g -> slice [:, :, g, :]); logits_out: list of G [B,T_pred,C_g] views with padded rows."""
         G = self.G
         _, B, _, T, Cf = visual.shape
-        x_hl = visual.hl if visual.hl is not None else ops.split_hl32(visual.f32)
-        if self.experts[0].model.stages["Seq"] == "BiLSTM":
-            y1 = self._bilstm(0, x_hl, (B, T), Cf)
-            feat = self._bilstm(1, ops.split_hl32(y1), (B, T), y1.shape[-1])      # [G,B,T,hidden]
-        else:                                                                     # Seq "None": one Linear (model.py sequence())
-            lins = [e.model.SequenceModeling[0] for e in self.experts]
-            feat = self._linear("seq", x_hl, B * T, Cf, [l.weight for l in lins], [l.bias for l in lins]).view(G, B, T, -1)
+        feat = self.sequence(visual)                                              # [G,B,T,hidden]
         feats_out.copy_(feat.permute(1, 2, 0, 3))
         hidden = feat.shape[-1]
         feat_hl = ops.split_hl32(feat)

@@ -182,28 +182,38 @@ class DERNet(Model):
         image = to_nhwc(image).permute(0, 3, 1, 2)
         trainable = [needs_grad(ext, image) for ext in self.model]
         frozen = [i for i, t in enumerate(trainable) if not t]
-        visuals = {}
+        visuals, seq_done, buf = {}, set(), None
         if self.expert_grouping and len(frozen) >= 2:
             exts = [self.model[i] for i in frozen]
             key = tuple(id(e) for e in exts)
             if self._group is None or self._group[0] != key:
-                self._group = (key, expert_group.BackboneGroup(exts))
+                self._group = (key, expert_group.BackboneGroup(exts), expert_group.SequenceGroup(exts))
             if expert_group.supported(exts):
+                lockstep_seq = (expert_group.SequenceGroup.sequence_supported(exts)
+                                and frozen == list(range(frozen[0], frozen[0] + len(frozen))))
                 with torch.no_grad():
-                    stack = self._group[1].visual_all(image)
-                visuals = {i: stack[k] for k, i in enumerate(frozen)}
-        buf, outs = None, []
+                    stack = self._group[1].visual_all(image, as_act=lockstep_seq)
+                if lockstep_seq:           # BiLSTMs of the frozen extractors in lock-step too, written straight into their slices
+                    _, B, _, T, _ = stack.shape
+                    buf = torch.empty(B, T, self.feature_dim, device=image.device, dtype=torch.float32)
+                    with torch.no_grad():
+                        self._group[2].sequence(stack, out=buf[:, :, frozen[0] * self.out_dim:], out_row_stride=self.feature_dim,
+                                                out_group_stride=self.out_dim)
+                    seq_done = set(frozen)
+                else:
+                    visuals = {i: stack[k] for k, i in enumerate(frozen)}
+        outs = []
         for i, ext in enumerate(self.model):
             if trainable[i]:
                 outs.append(ext(image))
                 continue
             with torch.no_grad():
-                vis = visuals[i] if i in visuals else ext.visual(image)
-                if buf is None:
-                    buf = torch.empty(vis.shape[0], vis.shape[1], self.feature_dim, device=vis.device, dtype=torch.float32)
-                sl = buf[:, :, i * self.out_dim:(i + 1) * self.out_dim]
-                ext.sequence(vis, out=sl)
-                outs.append(sl)
+                if i not in seq_done:
+                    vis = visuals[i] if i in visuals else ext.visual(image)
+                    if buf is None:
+                        buf = torch.empty(vis.shape[0], vis.shape[1], self.feature_dim, device=vis.device, dtype=torch.float32)
+                    ext.sequence(vis, out=buf[:, :, i * self.out_dim:(i + 1) * self.out_dim])
+                outs.append(buf[:, :, i * self.out_dim:(i + 1) * self.out_dim])
         return buf if not any(trainable) else torch.cat(outs, -1)
 
     def _head(self, head, feat, text, is_train):
