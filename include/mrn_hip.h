@@ -264,7 +264,9 @@ int mrn_attn_decoder_fwd_grouped_f32(const void* const* Hb, const void* const* H
  * Weights transposed + fragment-major: w_h2hT (rows = input unit, K = H), w_ih_ctxT (rows = D index, K = 4H),
  * w_hhT (rows = hidden unit, K = 4H).  Outputs: dgates [B][S][4H] (gate pre-activations), dhp [B][S][H],
  * dHb [B][T][D] and dHproj [B][T][H] (must be zero-initialised; accumulated over the steps),
- * dwscore_part [ceil(B/16)][H].  D must equal hidden (256). */
+ * dwscore_part [mrn_attn_decoder_bwd_parts(B)][H] (one row per workgroup; the caller sums the rows).
+ * D must be a multiple of hidden (256). */
+int64_t mrn_attn_decoder_bwd_parts(int B);
 int mrn_attn_decoder_bwd_f32(const float* Hb, const float* Hproj, const float* alpha, const float* gates,
                              const float* cseq, const float* ctx, const float* hp, const float* dhid,
                              const float* w_score, const float* w_h2hT, const float* w_ih_ctxT, const float* w_hhT,

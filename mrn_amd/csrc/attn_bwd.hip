@@ -5,6 +5,7 @@
 // forward (rnn.hip): 16 samples per workgroup, 16 waves, wave w owns hidden units [16w, 16w+16); the transposed
 // recurrent weights stream fragment-major from L2.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -44,6 +45,7 @@ struct AttnBwdParams {
   const float *w_h2hT, *w_ih_ctxT, *w_hhT;
   float *dgates, *dhp, *dHb, *dHproj, *dws_part;
   int B, T, D, S;
+  int vb;      // samples per workgroup (16, 8 or 4): rows >= vb of the 16-row MFMA tile are treated like rows beyond the batch
 };
 
 __device__ __forceinline__ float fast_tanh(float x) {
@@ -63,7 +65,11 @@ __global__ __launch_bounds__(NTH) void attn_decoder_bwd_kernel(const AttnBwdPara
   float* sw_lds = al_lds + BT * T;           // [HID]
   float* red = sw_lds + HID;                 // [NW][HID] reduction of d w_score at the end
 
-  const int b0 = blockIdx.x * BT;
+  // every step re-reads / updates the workgroup's Hproj, Hb, dHproj, dHb slices (66 KB per sample each) through ONE CU's memory
+  // pipeline, so a batch that would occupy only a few CUs runs with fewer samples per workgroup (like the forward kernel's vb)
+  const int vb = p.vb;
+  const int b0 = blockIdx.x * vb;
+  const int Bend = min(p.B, b0 + vb);
   const int t_ = threadIdx.x, lane = t_ & 63, wave = t_ >> 6;
   const int col = lane & 15, rbase = (lane >> 4) * 4;
   const int j = wave * 16 + col;
@@ -73,6 +79,7 @@ __global__ __launch_bounds__(NTH) void attn_decoder_bwd_kernel(const AttnBwdPara
   const f32x4* w_h2h = reinterpret_cast<const f32x4*>(p.w_h2hT) + (long)wave * (HID / 16) * 64 + lane;
 
   for (int i = t_; i < HID; i += NTH) sw_lds[i] = p.w_score[i];
+  for (int i = t_; i < BT * HLD; i += NTH) dhp_lds[i] = 0.f;      // rows >= vb stay zero
   float dh_rec[4] = {0.f, 0.f, 0.f, 0.f}, dc_next[4] = {0.f, 0.f, 0.f, 0.f};
   f32x4 dws = {0.f, 0.f, 0.f, 0.f};          // d w_score for channels lane*4.. of this wave's sample
   __syncthreads();
@@ -81,18 +88,18 @@ __global__ __launch_bounds__(NTH) void attn_decoder_bwd_kernel(const AttnBwdPara
     // stage hp[s] and alpha[s] of the 16 samples
     for (int i = t_; i < BT * HID; i += NTH) {
       const int row = i / HID, c = i - row * HID, b = b0 + row;
-      hp_lds[row * HLD + c] = b < p.B ? p.hp[((long)b * p.S + s) * HID + c] : 0.f;
+      hp_lds[row * HLD + c] = b < Bend ? p.hp[((long)b * p.S + s) * HID + c] : 0.f;
     }
     for (int i = t_; i < BT * T; i += NTH) {
       const int row = i / T, t = i - row * T, b = b0 + row;
-      al_lds[i] = b < p.B ? p.alpha[((long)b * p.S + s) * T + t] : 0.f;
+      al_lds[i] = b < Bend ? p.alpha[((long)b * p.S + s) * T + t] : 0.f;
     }
     // (a) LSTMCell backward for (sample row, unit j)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = rbase + r, b = b0 + row;
       float di = 0.f, df = 0.f, dg = 0.f, dob = 0.f;
-      if (b < p.B) {
+      if (b < Bend) {
         const long base = (long)b * p.S + s;
         const float* gp = p.gates + base * 4 * HID + j;
         const float ig = gp[0], fg = gp[HID], gg = gp[2 * HID], og = gp[3 * HID];
@@ -136,16 +143,16 @@ __global__ __launch_bounds__(NTH) void attn_decoder_bwd_kernel(const AttnBwdPara
         for (int r = 0; r < 4; ++r) dctx_lds[(rbase + r) * HLD + j] = acc[0][r];
       }
       __syncthreads();
-      for (int pr0 = wave * 4; pr0 < BT * T; pr0 += NW * 4) {
+      for (int pr0 = wave * 4; pr0 < vb * T; pr0 += NW * 4) {
         f32x4 hv[4];
         int rows[4], ts[4];
         bool ok[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int pr = pr0 + u;
-          rows[u] = pr < BT * T ? pr / T : 0;
-          ts[u] = pr < BT * T ? pr - rows[u] * T : 0;
-          ok[u] = pr < BT * T && b0 + rows[u] < p.B;
+          rows[u] = pr < vb * T ? pr / T : 0;
+          ts[u] = pr < vb * T ? pr - rows[u] * T : 0;
+          ok[u] = pr < vb * T && b0 + rows[u] < Bend;
           hv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
           if (ok[u]) hv[u] = *reinterpret_cast<const f32x4*>(p.Hb + ((long)(b0 + rows[u]) * T + ts[u]) * p.D + blk * HID + lane * 4);
         }
@@ -168,7 +175,7 @@ __global__ __launch_bounds__(NTH) void attn_decoder_bwd_kernel(const AttnBwdPara
 #pragma unroll
           for (int u = 0; u < 4; ++u) sacc[u] += __shfl_xor(sacc[u], o);
         }
-        if (lane < 4 && pr0 + lane < BT * T) {
+        if (lane < 4 && pr0 + lane < vb * T) {
           const float v = lane == 0 ? sacc[0] : lane == 1 ? sacc[1] : lane == 2 ? sacc[2] : sacc[3];
           de_lds[pr0 + lane] = blk == 0 ? v : de_lds[pr0 + lane] + v;      // (the same wave owns this pair in every block)
         }
@@ -176,7 +183,7 @@ __global__ __launch_bounds__(NTH) void attn_decoder_bwd_kernel(const AttnBwdPara
       __syncthreads();
     }
     // (d) softmax backward: de = alpha * (dalpha - sum_t alpha*dalpha)   (wave per sample)
-    {
+    if (wave < vb) {
       const int row = wave;
       float dot = 0.f;
       for (int t = lane; t < T; t += 64) dot += al_lds[row * T + t] * de_lds[row * T + t];
@@ -184,16 +191,20 @@ __global__ __launch_bounds__(NTH) void attn_decoder_bwd_kernel(const AttnBwdPara
       for (int t = lane; t < T; t += 64) de_lds[row * T + t] = al_lds[row * T + t] * (de_lds[row * T + t] - dot);
     }
     __syncthreads();
-    // (e) through e = score . tanh(Hproj + hp): wave = sample, lane = 4 channels; dhp accumulates in registers
+    // (e) through e = score . tanh(Hproj + hp): NW / vb waves per sample (each a contiguous slice of the T positions), lane = 4
+    //     channels; dhp accumulates in registers and the slices of one sample meet in LDS
     {
-      const int row = wave, b = b0 + row;
+      const int wps = NW / vb;
+      const int row = wave % vb, part = wave / vb, b = b0 + row;
+      const int tchunk = (T + wps - 1) / wps;
+      const int t_end = min(T, (part + 1) * tchunk);
       f32x4 dhp = {0.f, 0.f, 0.f, 0.f};
-      if (b < p.B) {
+      if (b < Bend) {
         const f32x4 wv = *reinterpret_cast<const f32x4*>(sw_lds + lane * 4);
         const f32x4 pv = *reinterpret_cast<const f32x4*>(hp_lds + row * HLD + lane * 4);
-        int t = 0;
+        int t = part * tchunk;
 #pragma unroll 1
-        for (; t + 4 <= T; t += 4) {
+        for (; t + 4 <= t_end; t += 4) {
           f32x4 hv[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) hv[u] = *reinterpret_cast<const f32x4*>(p.Hproj + ((long)b * T + t + u) * HID + lane * 4);
@@ -213,7 +224,7 @@ __global__ __launch_bounds__(NTH) void attn_decoder_bwd_kernel(const AttnBwdPara
             *dst = o;
           }
         }
-        for (; t < T; ++t) {
+        for (; t < t_end; ++t) {
           const f32x4 hv = *reinterpret_cast<const f32x4*>(p.Hproj + ((long)b * T + t) * HID + lane * 4);
           const float de = de_lds[row * T + t];
           f32x4* dst = reinterpret_cast<f32x4*>(p.dHproj + ((long)b * T + t) * HID + lane * 4);
@@ -228,9 +239,22 @@ __global__ __launch_bounds__(NTH) void attn_decoder_bwd_kernel(const AttnBwdPara
           }
           *dst = o;
         }
-        *reinterpret_cast<f32x4*>(p.dhp + ((long)b * p.S + s) * HID + lane * 4) = dhp;
       }
-      *reinterpret_cast<f32x4*>(dhp_lds + row * HLD + lane * 4) = dhp;
+      if (wps > 1) {                      // (uniform across the workgroup)
+        *reinterpret_cast<f32x4*>(red + wave * HID + lane * 4) = dhp;
+        __syncthreads();
+        if (part == 0) {
+          for (int q = 1; q < wps; ++q) {
+            const f32x4 o = *reinterpret_cast<const f32x4*>(red + (row + q * vb) * HID + lane * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dhp[k] += o[k];
+          }
+        }
+      }
+      if (part == 0) {
+        if (b < Bend) *reinterpret_cast<f32x4*>(p.dhp + ((long)b * p.S + s) * HID + lane * 4) = dhp;
+        *reinterpret_cast<f32x4*>(dhp_lds + row * HLD + lane * 4) = dhp;
+      }
     }
     __syncthreads();
     // (f) dh_prev += dhp . W_h2h
@@ -349,6 +373,16 @@ __global__ __launch_bounds__(256) void tps_sample_bwd_kernel(const float* __rest
 
 }  // namespace
 
+// samples per workgroup of the decoder backward: the smallest of {4, 8, 16} that keeps the grid within 128 workgroups
+static int attn_bwd_vb(int B) {
+  static const int forced = getenv("MRN_ATTN_BWD_VB") ? atoi(getenv("MRN_ATTN_BWD_VB")) : 0;     // (A/B switch, read once)
+  if (forced == 4 || forced == 8 || forced == 16) return forced;
+  return ceil_div(B, 4) <= 128 ? 4 : ceil_div(B, 8) <= 128 ? 8 : 16;
+}
+
+// rows of the d w_score partial-sum buffer (= workgroups of mrn_attn_decoder_bwd_f32) for a batch of B
+MRN_EXPORT int64_t mrn_attn_decoder_bwd_parts(int B) { return B > 0 ? ceil_div(B, attn_bwd_vb(B)) : 0; }
+
 MRN_EXPORT int mrn_attn_decoder_bwd_f32(const float* Hb, const float* Hproj, const float* alpha, const float* gates,
                                         const float* cseq, const float* ctx, const float* hp, const float* dhid,
                                         const float* w_score, const float* w_h2hT, const float* w_ih_ctxT, const float* w_hhT,
@@ -364,11 +398,12 @@ MRN_EXPORT int mrn_attn_decoder_bwd_f32(const float* Hb, const float* Hproj, con
   p.w_score = w_score; p.w_h2hT = w_h2hT; p.w_ih_ctxT = w_ih_ctxT; p.w_hhT = w_hhT;
   p.dgates = dgates; p.dhp = dhp; p.dHb = dHb; p.dHproj = dHproj; p.dws_part = dwscore_part;
   p.B = B; p.T = T; p.D = D; p.S = S;
+  p.vb = attn_bwd_vb(B);
   const size_t lds = sizeof(float) * (BT * GLD + 3 * BT * HLD + 2 * BT * T + HID + NW * HID);
   MRN_CHECK_ARG(lds <= 160 * 1024, "mrn_attn_decoder_bwd_f32: LDS budget exceeded (T=%d)", T);
   static bool attr = false;
   if (!attr) { hipFuncSetAttribute((const void*)attn_decoder_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-  hipLaunchKernelGGL(attn_decoder_bwd_kernel, dim3(ceil_div(B, BT)), dim3(NTH), lds, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(attn_decoder_bwd_kernel, dim3(ceil_div(B, p.vb)), dim3(NTH), lds, (hipStream_t)stream, p);
   MRN_LAUNCH_CHECK("attn_decoder_bwd");
   return MRN_OK;
 }

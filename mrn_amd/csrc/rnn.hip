@@ -324,7 +324,7 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecGroup gr
   float* e_lds = ctx_lds + BT * CLD;       // [BT][T]
   float* sw_lds = e_lds + BT * T;          // [HID]
 
-  // vb = samples per workgroup (16, or 8 when the batch would otherwise occupy less than half of the CUs: every step
+  // vb = samples per workgroup (16, or 8 / 4 when the batch would otherwise occupy less than half of the CUs: every step
   // re-reads the workgroup's Hproj / Hb slices (66 KB per sample each), so more, smaller workgroups shorten the step);
   // rows >= vb of the 16-row MFMA tile are treated like rows beyond the batch
   const int vb = grp.vb;
@@ -612,7 +612,7 @@ static int attn_fill(AttnDecParams& p, const float* Hb, const float* Hproj, cons
 static int attn_launch(AttnDecGroup& grp, int groups, int D, int T, hipStream_t st) {
   grp.groups = groups;
   const int B = grp.g[0].B;
-  grp.vb = (groups * ceil_div(B, BT) <= 128 && B > 8) ? 8 : BT;
+  grp.vb = (groups * ceil_div(B, 4) <= 128 && B > 4) ? 4 : (groups * ceil_div(B, BT) <= 128 && B > 8) ? 8 : BT;
   grp.tiles = ceil_div(B, grp.vb);
   grp.pinned = groups > 1 && grp.tiles * ceil_div(groups, 8) <= 32;
   const size_t lds = sizeof(float) * (2 * BT * HLD + BT * (D + 4) + BT * T + HID);

@@ -1181,7 +1181,7 @@ def attn_decoder_bwd(Hb, Hproj, saves, dhid, w_score, w_h2hT, w_ih_ctxT, w_hhT, 
     dhp = torch.empty(B, S, hidden, device=dev, dtype=torch.float32)
     dHb = torch.zeros(B, T, D, device=dev, dtype=torch.float32)
     dHproj = torch.zeros(B, T, hidden, device=dev, dtype=torch.float32)
-    nwg = (B + 15) // 16
+    nwg = call("mrn_attn_decoder_bwd_parts", B)
     dws = torch.empty(nwg, hidden, device=dev, dtype=torch.float32)
     call("mrn_attn_decoder_bwd_f32", _p(Hb), _p(Hproj), _p(alpha), _p(gates), _p(cseq), _p(ctx), _p(hp), _p(dhid.contiguous()),
          _p(w_score), _p(w_h2hT), _p(w_ih_ctxT), _p(w_hhT), _p(dgates), _p(dhp), _p(dHb), _p(dHproj), _p(dws), B, T, D, S,

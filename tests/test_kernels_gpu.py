@@ -192,6 +192,41 @@ def test_attention_decoder(ops, is_train):
     assert np.array_equal(out.argmax(2).cpu().numpy(), ref.argmax(2).numpy())
 
 
+@pytest.mark.parametrize("B,D", [(37, 256), (21, 512), (3, 256)])
+def test_attention_decoder_backward(ops, B, D):
+    """BPTT through the 26 teacher-forced steps (attn_decoder_bwd_kernel, several workgroups with a ragged last one, D = 256
+    and the DERNet-style wider context) against autograd through the oracle's step loop (reference prediction.py:58-68,102-118)"""
+    from oracle import mrn_oracle as O
+    from mrn_amd.modules.prediction import Attention
+    import torch.nn as nn
+    T, Hd, C = 65, 256, 97
+    att = Attention(D, Hd, C, nn.Linear(Hd, C))
+    sd = {k: rnd(*v.shape, seed=140 + i, scale=0.08) for i, (k, v) in enumerate(att.state_dict().items())}
+    sd["char_embeddings.weight"] = rnd(C, 256, seed=177)
+    att.load_state_dict(sd)
+    Hb = rnd(B, T, D, seed=141)
+    text = torch.randint(0, C + 3, (B, 26), generator=torch.Generator().manual_seed(6))
+    text[:, 0] = 2
+    up = rnd(B, 26, C, seed=142)
+    osd = {"P." + k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    Hr = Hb.clone().requires_grad_(True)
+    ref = O.attention_forward(osd, "P.", Hr, text, True, 25, osd["P.generator.weight"], osd["P.generator.bias"])
+    (ref * up).sum().backward()
+    att = att.cuda()
+    Hc = cu(Hb).requires_grad_(True)
+    out = att(Hc, cu(text), True, 25)
+    (out * cu(up)).sum().backward()
+    assert_close("decoder logits", out, ref, atol=1e-4)
+    scale = Hr.grad.abs().max().item()
+    assert_close("decoder dH", Hc.grad, Hr.grad, atol=2e-4 * max(scale, 1.0))
+    for k, prm in att.named_parameters():
+        g_ref = osd["P." + k].grad
+        if g_ref is None:                      # generator.* aliases fc.* in the module's parameter list
+            continue
+        tol = 2e-4 * max(g_ref.abs().max().item(), 1.0)
+        assert_close("decoder d" + k, prm.grad, g_ref, atol=tol)
+
+
 def test_rowops(ops):
     R, C = 1000, 256
     x = rnd(R, 2 * C, seed=50)
