@@ -252,6 +252,16 @@ int mrn_lstm_layer_fwd_grouped_f32(const void* const* xproj, const void* const* 
 int mrn_lstm_layer_fwd_x3_grouped(const void* const* xproj, const void* const* w_hh, const void* const* w_inv,
                                   const void* const* b_hh, const void* const* out, int groups, int B, int T, int hidden,
                                   int ndir, void* stream);
+/* Weight-stationary form of mrn_lstm_layer_fwd_x3_grouped (same operands, bit-identical results): every (expert, direction) is
+ * spread over 16 workgroups that keep their 64 KiB slice of W_hh in LDS for the whole sequence and exchange h through
+ * `workspace` (mrn_lstm_cluster_workspace_bytes) once per step.  All mrn_lstm_cluster_workgroups(groups, B, ndir) workgroups of a
+ * launch must be co-resident (<= 256; keep concurrent launches within the chip): they wait on each other, with bounded spins --
+ * a workgroup whose peers never arrive writes NaN into its last output row instead of hanging. */
+int64_t mrn_lstm_cluster_workspace_bytes(int groups, int B, int ndir);
+int64_t mrn_lstm_cluster_workgroups(int groups, int B, int ndir);
+int mrn_lstm_layer_fwd_x3_cluster(const void* const* xproj, const void* const* w_hh, const void* const* w_inv,
+                                  const void* const* b_hh, const void* const* out, int groups, int B, int T, int hidden,
+                                  int ndir, void* workspace, int64_t workspace_bytes, void* stream);
 int mrn_attn_decoder_fwd_grouped_f32(const void* const* Hb, const void* const* Hproj, const void* const* eproj,
                                      int64_t eproj_stride_b, int64_t eproj_stride_s, const void* const* w_h2h,
                                      const void* const* b_h2h, const void* const* w_score, const void* const* w_ih_ctx,

@@ -416,7 +416,8 @@ class SequenceGroup(_GroupedLinear):
                 return (torch.stack([torch.stack([d[0] for d in p]) for p in packs]).contiguous(),
                         torch.stack([torch.cat([d[1] for d in p]) for p in packs]).contiguous())
             w_h, w_inv = self._cached("hh16_%d" % idx, [w for m in mods for w in (m.rnn.weight_hh_l0, m.rnn.weight_hh_l0_reverse)], build)
-            rec = ops.lstm_layer_x3_grouped(xproj.view(G, B, T, 2 * 4 * H), w_h, w_inv, b_hh, H, 2)
+            lstm = ops.lstm_layer_x3_cluster if ops.lstm_cluster_supported(G, B, 2) else ops.lstm_layer_x3_grouped
+            rec = lstm(xproj.view(G, B, T, 2 * 4 * H), w_h, w_inv, b_hh, H, 2)
         else:
             rec = ops.lstm_layer_grouped(xproj.view(G, B, T, 2 * 4 * H), w_hh, b_hh, H, 2)
         y = self._linear("lin%d" % idx, ops.split_hl32(rec), B * T, 2 * H, [m.linear.weight for m in mods],

@@ -723,6 +723,31 @@ def lstm_layer_x3_grouped(xproj, w_hh_h, w_inv, b_hh, hidden, ndir):
     return out
 
 
+LSTM_CLUSTER = os.environ.get("MRN_LSTM_CLUSTER", "0") == "1"    # opt-in: weight-stationary LSTM (measured slower than streaming, rnn.hip)
+LSTM_CLUSTER_MAX_WG = 128         # workgroups of one cluster launch (they spin on each other: two concurrent launches must fit)
+
+
+def lstm_cluster_supported(G, B, ndir):
+    return (LSTM_CLUSTER and B >= 64 and G * ndir <= 8
+            and call("mrn_lstm_cluster_workgroups", G, B, ndir) <= LSTM_CLUSTER_MAX_WG)
+
+
+def lstm_layer_x3_cluster(xproj, w_hh_h, w_inv, b_hh, hidden, ndir):
+    """lstm_layer_x3_grouped on the weight-stationary kernel (bit-identical results): W_hh slices stay in the LDS of 16 workgroups
+    per (expert, direction), h crosses the workgroups through a small exchange buffer every step"""
+    _chk(xproj, b_hh)
+    G, B, T, _ = xproj.shape
+    assert xproj.is_contiguous() and w_hh_h.is_contiguous() and w_inv.is_contiguous() and b_hh.is_contiguous()
+    out = torch.empty(G, B, T, ndir * hidden, device=xproj.device, dtype=torch.float32)
+    nbytes = call("mrn_lstm_cluster_workspace_bytes", G, B, ndir)
+    ws = torch.empty(nbytes, device=xproj.device, dtype=torch.uint8)
+    call("mrn_lstm_layer_fwd_x3_cluster", _ptr_array([xproj[g].data_ptr() for g in range(G)]),
+         _ptr_array([w_hh_h[g].data_ptr() for g in range(G)]), _ptr_array([w_inv[g].data_ptr() for g in range(G)]),
+         _ptr_array([b_hh[g].data_ptr() for g in range(G)]), _ptr_array([out[g].data_ptr() for g in range(G)]), G, B, T,
+         hidden, ndir, _p(ws), nbytes, _stream())
+    return out
+
+
 def lstm_layer_grouped(xproj, w_hh, b_hh, hidden, ndir):
     """xproj [G,B,T,ndir*4H], w_hh [G,ndir,...] (fragment-major stacks), b_hh [G,ndir*4H] -> [G,B,T,ndir*H], one launch"""
     _chk(xproj, w_hh, b_hh)

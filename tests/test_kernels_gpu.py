@@ -192,6 +192,24 @@ def test_attention_decoder(ops, is_train):
     assert np.array_equal(out.argmax(2).cpu().numpy(), ref.argmax(2).numpy())
 
 
+@pytest.mark.parametrize("G,B,T,ndir", [(3, 256, 65, 2), (2, 100, 63, 2), (1, 40, 9, 1)])
+def test_lstm_cluster_kernel_bit_identical_to_streaming(ops, G, B, T, ndir):
+    """the opt-in weight-stationary LSTM (16 workgroups per (expert, direction) exchanging h every step, rnn.hip) against the
+    streaming kernel the product uses: same MFMA order per accumulator -> identical bits; no NaN poison (no peer timed out)"""
+    H = 256
+    torch.manual_seed(G * 100 + B)
+    xproj = torch.randn(G, B, T, ndir * 4 * H, device="cuda")
+    packs = [[ops.pack_fragment_major_h(torch.randn(4 * H, H, device="cuda") * 0.06) for _ in range(ndir)] for _ in range(G)]
+    w_h = torch.stack([torch.stack([d[0] for d in p]) for p in packs]).contiguous()
+    w_inv = torch.stack([torch.cat([d[1] for d in p]) for p in packs]).contiguous()
+    b_hh = torch.randn(G, ndir * 4 * H, device="cuda") * 0.1
+    ref = ops.lstm_layer_x3_grouped(xproj, w_h, w_inv, b_hh, H, ndir)
+    out = ops.lstm_layer_x3_cluster(xproj, w_h, w_inv, b_hh, H, ndir)
+    torch.cuda.synchronize()
+    assert not torch.isnan(out).any()
+    assert torch.equal(out, ref)
+
+
 @pytest.mark.parametrize("B,D", [(37, 256), (21, 512), (3, 256)])
 def test_attention_decoder_backward(ops, B, D):
     """BPTT through the 26 teacher-forced steps (attn_decoder_bwd_kernel, several workgroups with a ragged last one, D = 256
