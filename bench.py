@@ -221,13 +221,28 @@ def time_der_step(args, opt, rank, world, steps, warmup):
         learner.model_eval_and_train(args.experts - 1)
     data = SyntheticTextLines(opt, seed=311 + rank)
     data.set_characters(learner.character)
+    # one batch of look-ahead, as DER._update runs it: the frozen extractors of batch n+1 are issued (side stream) before batch n
+    # trains the newest extractor; every timed step issues exactly one frozen forward and one training step
+    pending = []
+
+    def fetch():
+        image, labels = data.get_batch()
+        return image, labels, (learner.prefetch_frozen(image) if not args.serial else None)
+
+    def step():
+        if not pending:
+            pending.append(fetch())
+        image, labels, pre = pending.pop(0)
+        pending.append(fetch())
+        return learner.der_step(image, labels, prefetched=pre)
+
     for _ in range(warmup):
-        learner.der_step(*data.get_batch())
+        step()
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        loss, aux = learner.der_step(*data.get_batch())
+        loss, aux = step()
     torch.cuda.synchronize()
     parallel.barrier()
     elapsed = time.perf_counter() - t0

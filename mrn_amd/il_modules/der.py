@@ -69,13 +69,18 @@ class DER(BaseLearner):
             self._update(start_iter, taski, train_loader, valid_loader)
             self.model.module.weight_align(self._total_classes - self._known_classes)       # der.py:148
 
-    def der_step(self, image, labels):
+    def prefetch_frozen(self, image):
+        """issue the frozen extractors' forward of a FUTURE batch (DERNet.frozen_prefetch); pass the result to
+        der_step(..., prefetched=...).  Only the launch order changes, not the results."""
+        return self.model.module.frozen_prefetch(image)
+
+    def der_step(self, image, labels, prefetched=None):
         """one iteration of der.py:226-271"""
         labels_index, labels_length = self.converter.encode(labels, batch_max_length=self.opt.batch_max_length)
         if "CTC" in self.opt.Prediction:
-            output = self.model(image)
+            output = self.model(image, frozen=prefetched)
         else:
-            output = self.model(image, labels_index[:, :-1])
+            output = self.model(image, labels_index[:, :-1], frozen=prefetched)
         loss_clf = self.criterion(output["logits"], labels_index, labels_length)
         loss_aux = self.criterion(output["aux_logits"].detach(), labels_index, labels_length)   # logged only (:264-265)
         self.backward_and_step(loss_clf)
@@ -84,9 +89,20 @@ class DER(BaseLearner):
     def _update(self, start_iter, taski, train_loader, valid_loader):
         avg, clf_avg, aux_avg = Averager(), Averager(), Averager()
         start_time = time.time()
+        # one batch of look-ahead: the frozen extractors of batch n+1 run on a side stream while batch n trains the newest one
+        nxt = None
         for iteration in range(start_iter + 1, self.opt.num_iter + 1):
-            image, labels = train_loader.get_batch()
-            loss, aux = self.der_step(image.to(self.device), labels)
+            if nxt is None:
+                image, labels = train_loader.get_batch()
+                image, pre = image.to(self.device), None
+            else:
+                image, labels, pre = nxt
+            nxt = None
+            if taski > 0 and iteration < self.opt.num_iter and iteration % self.opt.val_interval != 0 and iteration != 1:
+                ni, nl = train_loader.get_batch()
+                ni = ni.to(self.device)
+                nxt = (ni, nl, self.prefetch_frozen(ni))
+            loss, aux = self.der_step(image, labels, prefetched=pre)
             avg.add(loss.detach())
             clf_avg.add(loss.detach())
             aux_avg.add(aux.detach())

@@ -8,6 +8,7 @@ MI355X-first differences that do not change results:
     MRNNet.cross_forward (:399-423) collapse into the DM-Router kernels plus one fan-in pass;
   * the input image is converted to NHWC once and shared by all experts.
 """
+import contextlib
 import copy
 import os
 
@@ -169,43 +170,95 @@ class DERNet(Model):
         self.aux_fc = None
         self.task_sizes = []
         self.expert_grouping = True         # frozen extractors run their conv backbones in lock-step
+        self.frozen_stream = True           # ... on their own HIP stream, side by side with the trained extractor's forward
         self._group = None
+        self._side = None
 
     @property
     def feature_dim(self):
         return 0 if self.out_dim is None else self.out_dim * len(self.model)
 
-    def _features(self, image):
-        """[B,T,out_dim*N]: frozen extractors write straight into their channel slice (no torch.cat pass); two or more
-        frozen extractors of one architecture run their conv backbones in lock-step (modules/expert_group.py)"""
+    def _frozen_lockstep(self, image):
+        """(frozen indices, BackboneGroup, SequenceGroup) when the frozen extractors can run conv backbones AND BiLSTMs in lock-step
+        and occupy one contiguous channel range of the feature buffer; else None"""
         from . import expert_group
-        image = to_nhwc(image).permute(0, 3, 1, 2)
         trainable = [needs_grad(ext, image) for ext in self.model]
         frozen = [i for i, t in enumerate(trainable) if not t]
-        visuals, seq_done, buf = {}, set(), None
-        if self.expert_grouping and len(frozen) >= 2:
-            exts = [self.model[i] for i in frozen]
-            key = tuple(id(e) for e in exts)
-            if self._group is None or self._group[0] != key:
-                self._group = (key, expert_group.BackboneGroup(exts), expert_group.SequenceGroup(exts))
-            if expert_group.supported(exts):
-                lockstep_seq = (expert_group.SequenceGroup.sequence_supported(exts)
-                                and frozen == list(range(frozen[0], frozen[0] + len(frozen))))
-                with torch.no_grad():
-                    stack = self._group[1].visual_all(image, as_act=lockstep_seq)
-                if lockstep_seq:           # BiLSTMs of the frozen extractors in lock-step too, written straight into their slices
-                    _, B, _, T, _ = stack.shape
-                    buf = torch.empty(B, T, self.feature_dim, device=image.device, dtype=torch.float32)
-                    with torch.no_grad():
-                        self._group[2].sequence(stack, out=buf[:, :, frozen[0] * self.out_dim:], out_row_stride=self.feature_dim,
-                                                out_group_stride=self.out_dim)
-                    seq_done = set(frozen)
+        if not (self.expert_grouping and len(frozen) >= 2):
+            return None
+        exts = [self.model[i] for i in frozen]
+        key = tuple(id(e) for e in exts)
+        if self._group is None or self._group[0] != key:
+            self._group = (key, expert_group.BackboneGroup(exts), expert_group.SequenceGroup(exts))
+        if not expert_group.supported(exts):
+            return None
+        if not (expert_group.SequenceGroup.sequence_supported(exts) and frozen == list(range(frozen[0], frozen[0] + len(frozen)))):
+            return (frozen, self._group[1], None)
+        return (frozen, self._group[1], self._group[2])
+
+    def _run_frozen(self, image, frozen, bg, sg):
+        """the frozen group's slices of a fresh [B,T,out_dim*N] feature buffer (current stream)"""
+        with torch.no_grad():
+            stack = bg.visual_all(image, as_act=True)
+            _, B, _, T, _ = stack.shape
+            buf = torch.empty(B, T, self.feature_dim, device=image.device, dtype=torch.float32)
+            sg.sequence(stack, out=buf[:, :, frozen[0] * self.out_dim:], out_row_stride=self.feature_dim, out_group_stride=self.out_dim)
+        return buf
+
+    def frozen_prefetch(self, image):
+        """Issue the FROZEN extractors' forward of a (future) batch on the side stream; pass the handle to
+        forward(..., frozen=handle).  They are frozen and in eval mode (reference il_modules/der.py:101-104,137-141), so their
+        features for batch n+1 do not depend on the update of batch n: only the launch order changes.  None when the frozen
+        extractors cannot run in lock-step (the caller then simply does not pass a handle)."""
+        image = to_nhwc(image).permute(0, 3, 1, 2)
+        plan = self._frozen_lockstep(image)
+        if plan is None or plan[2] is None or not (self.frozen_stream and image.is_cuda):
+            return None
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=image.device)
+        side = self._side
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            buf = self._run_frozen(image, *plan)
+            done = torch.cuda.Event()
+            done.record(side)
+        image.record_stream(side)
+        return {"buf": buf, "done": done, "batch": image.shape[0], "frozen": plan[0]}
+
+    def _features(self, image, frozen_handle=None):
+        """[B,T,out_dim*N]: frozen extractors write straight into their channel slice (no torch.cat pass); two or more
+        frozen extractors of one architecture run conv backbones and BiLSTMs in lock-step (modules/expert_group.py), on a side
+        stream next to the trained extractor's forward -- or earlier still, through frozen_prefetch()"""
+        image = to_nhwc(image).permute(0, 3, 1, 2)
+        trainable = [needs_grad(ext, image) for ext in self.model]
+        visuals, seq_done, buf, join = {}, set(), None, None
+        if frozen_handle is not None:
+            assert frozen_handle["batch"] == image.shape[0]
+            buf, join, seq_done = frozen_handle["buf"], frozen_handle["done"], set(frozen_handle["frozen"])
+        else:
+            plan = self._frozen_lockstep(image)
+            if plan is not None and plan[2] is not None:
+                # the frozen group is independent of the trained extractor until the heads: its (MFMA-bound) convolutions share
+                # the chip with the trained extractor's forward, whose BatchNorm / pooling passes are HBM-bound
+                if self.frozen_stream and any(trainable) and image.is_cuda:
+                    handle = self.frozen_prefetch(image)
+                    buf, join = handle["buf"], handle["done"]
                 else:
-                    visuals = {i: stack[k] for k, i in enumerate(frozen)}
+                    buf = self._run_frozen(image, *plan)
+                seq_done = set(plan[0])
+            elif plan is not None:
+                with torch.no_grad():
+                    stack = plan[1].visual_all(image)
+                visuals = {i: stack[k] for k, i in enumerate(plan[0])}
+        trained = {i: ext(image) for i, ext in enumerate(self.model) if trainable[i]}      # (main stream; the side stream runs)
+        if join is not None:
+            main = torch.cuda.current_stream()
+            main.wait_event(join)
+            buf.record_stream(main)
         outs = []
         for i, ext in enumerate(self.model):
             if trainable[i]:
-                outs.append(ext(image))
+                outs.append(trained[i])
                 continue
             with torch.no_grad():
                 if i not in seq_done:
@@ -223,8 +276,9 @@ class DERNet(Model):
             return ops.linear(feat, head.weight, head.bias)
         return head(feat if feat.is_contiguous() else feat.contiguous(), text, is_train, batch_max_length=self.opt.batch_max_length)
 
-    def forward(self, image, text=None, is_train=True):
-        feat = self._features(image)
+    def forward(self, image, text=None, is_train=True, frozen=None):
+        """frozen: optional handle of frozen_prefetch(image) (same batch)"""
+        feat = self._features(image, frozen)
         logits = self._head(self.Prediction, feat, text, is_train)
         aux = self._head(self.aux_Prediction, feat[:, :, -self.out_dim:], text, is_train)
         return {"logits": logits, "aux_logits": aux, "features": feat}
@@ -273,11 +327,13 @@ class DERNet(Model):
         self.model.eval()
 
     def copy(self):
-        group, self._group = self._group, None               # packed-weight caches are not copied
+        group, self._group = self._group, None               # packed-weight caches / the side stream are not copied
+        side, self._side = self._side, None
         try:
             return copy.deepcopy(self)
         finally:
             self._group = group
+            self._side = side
 
 
 class MRNNet(nn.Module):

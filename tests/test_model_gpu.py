@@ -631,6 +631,44 @@ def test_dernet_groups_frozen_extractors(train_mode):
     assert_close("der logits", outs[0][1], outs[1][1], atol=2e-5, rtol=1e-4)
 
 
+def test_dernet_frozen_side_stream_and_prefetch_are_bit_identical():
+    """DERNet's three ways to run the frozen lock-step group -- in line, on the side stream next to the trained extractor, and
+    ahead of time through frozen_prefetch() (DER._update's look-ahead) -- only change the launch order: identical bits, and the
+    trained extractor's gradients too"""
+    from mrn_amd.modules.model import DERNet
+    from mrn_amd.tools import weights as W
+    opt = make_opt("trba")
+    classes = (30, 45, 61)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = DERNet(opt)
+        for c in classes:
+            net.update_fc(256, c)
+        net.build_prediction(opt, classes[-1])
+        net.build_aux_prediction(opt, classes[-1])
+    W.fill_state_dict(net.state_dict(), seed=17)
+    net = net.cuda().train()
+    for ext in list(net.model)[:-1]:
+        ext.eval()
+        for p in ext.parameters():
+            p.requires_grad = False
+    image = torch.from_numpy(W.smooth_image("derp", (6, 4, 32, 256), 5)).cuda()
+    text = torch.randint(0, classes[-1], (6, 26), generator=torch.Generator().manual_seed(3)).cuda()
+    runs = []
+    for mode in ("inline", "side", "prefetch"):
+        net.zero_grad(set_to_none=True)
+        net.frozen_stream = mode != "inline"
+        handle = net.frozen_prefetch(image) if mode == "prefetch" else None
+        assert (handle is not None) == (mode == "prefetch")
+        o = net(image, text, True, frozen=handle)
+        (o["logits"].square().mean() + o["aux_logits"].square().mean()).backward()
+        torch.cuda.synchronize()
+        g = torch.cat([p.grad.flatten() for p in net.model[-1].parameters()])
+        runs.append((o["features"].detach().clone(), o["logits"].detach().clone(), g.clone()))
+    for r in runs[1:]:
+        for a, b in zip(runs[0], r):
+            assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("arch", ["trba", "crnn", "svtr"])
 def test_two_stream_half_groups_are_bit_identical(arch):
     """MRNNet with >= 4 experts splits them into two lock-step half-groups on two HIP streams (so one half's HBM-bound
