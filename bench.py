@@ -193,6 +193,58 @@ def time_loop_a(args, opt, rank, world, steps, warmup):
             "dtype": "f32 (trained convolutions as range-safe split-fp16 x3 products, fp32 accumulate)"}
 
 
+def time_il_step(args, opt, rank, world, steps, warmup):
+    """one task-1 iteration of LwF (lwf.py:52-95: new network forward + backward, frozen previous network forward,
+    KD term on the old classes) or EWC (ewc.py:73-104: classification loss + the quadratic Fisher penalty -- run with the penalty
+    the code intends, i.e. more work than the reference's identically-zero one) on one expert of `--model`"""
+    from mrn_amd import parallel
+    from mrn_amd.data.synthetic import SyntheticTextLines, synthetic_characters
+    from mrn_amd.il_modules.ewc import EWC
+    from mrn_amd.il_modules.lwf import LwF
+    data = SyntheticTextLines(opt, seed=411 + rank)
+    with contextlib.redirect_stdout(io.StringIO() if not args.verbose else sys.stdout):
+        learner = (LwF if args.loop == "lwf" else EWC)(opt)
+        learner.character = synthetic_characters(CLASSES_MLT19[0])
+        learner.converter = learner.build_converter()
+        learner.criterion = learner.build_criterion()
+        learner.build_model()
+        learner.build_optimizer(learner.count_param(), total_steps=10 ** 9)
+        data.set_characters(learner.character)
+        if args.loop == "ewc":
+            learner.reference_prefix_bug = False
+            learner.fisher_iterations = 1
+            learner.fisher = learner.getFisherDiagonal(data)
+            learner.mean = {n: p.clone().detach() for n, p in learner.model.named_parameters() if p.requires_grad}
+        learner.after_task()
+        learner.character = synthetic_characters(CLASSES_MLT19[0] + CLASSES_MLT19[1])
+        learner.converter = learner.build_converter()
+        learner.change_model()
+        learner.build_optimizer(learner.count_param(), total_steps=10 ** 9)
+        data.set_characters(learner.character)
+    step = learner.kd_step if args.loop == "lwf" else learner.ewc_step
+    for _ in range(warmup):
+        step(*data.get_batch())
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step(*data.get_batch())
+    torch.cuda.synchronize()
+    parallel.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=learner.device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = out[0] if isinstance(out, tuple) else out
+    what = "LwF step (new network fwd + bwd, frozen previous network fwd, KD on the old classes)" if args.loop == "lwf" else \
+        "EWC step (fwd + bwd + Fisher penalty over all parameters)"
+    return {"metric": f"text-line images/sec, {what}, {args.model.upper()}, task 1, at 32x256",
+            "value": world * args.batch * steps / elapsed, "unit": "images/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps,
+            "warmup": warmup, "per_gpu_batch": args.batch, "trainable_parameters": learner.optimizer.flat.numel(),
+            "loss": float(loss.detach()), "dtype": "f32 (trained convolutions as range-safe split-fp16 x3 products, fp32 accumulate)"}
+
+
 def time_der_step(args, opt, rank, world, steps, warmup):
     """BASELINE config 5: DER (il_modules/der.py:208-290) on DERNet with `--experts` TRBA extractors -- the older ones frozen and in
     eval mode (lock-step grouped forward), the newest one trained, main attention head over the 256 * N-wide concatenation,
@@ -277,9 +329,9 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="do not issue batch n+1's expert forward before batch n's router phase")
     ap.add_argument("--serial", action="store_true", help="one lock-step group on one stream, no look-ahead (every kernel runs alone)")
     ap.add_argument("--no-isolated-pass", action="store_true", help="skip the 2 extra serialized steps that measure the dominant kernel alone")
-    ap.add_argument("--loop", default="b", choices=["a", "b", "der"], help="b (default): the router phase over frozen experts, BASELINE's "
+    ap.add_argument("--loop", default="b", choices=["a", "b", "der", "lwf", "ewc"], help="b (default): the router phase over frozen experts, BASELINE's "
                     "metric workload; a: train one expert (full forward + backward); der: BASELINE config 5's DER step over --experts "
-                    "extractors -- a / der are printed as the main line instead")
+                    "extractors; lwf / ewc: config 5's auxiliary-loss learners, one task-1 step -- printed as the main line instead")
     ap.add_argument("--no-extra", action="store_true", help="do not append the short loop-A measurement under \"extra\"")
     args = ap.parse_args()
 
@@ -299,11 +351,13 @@ def main():
     else:
         ops.CONV_PRECISION = args.precision
     opt = make_opt(args.model, args.batch)
-    if args.loop in ("a", "der"):
-        res = (time_loop_a if args.loop == "a" else time_der_step)(args, opt, rank, world, args.steps, args.warmup)
+    if args.loop in ("a", "der", "lwf", "ewc"):
+        fn = {"a": time_loop_a, "der": time_der_step, "lwf": time_il_step, "ewc": time_il_step}[args.loop]
+        res = fn(args, opt, rank, world, args.steps, args.warmup)
         if rank == 0:
-            what = (f"MRN loop A: one {args.model.upper()} expert trained" if args.loop == "a"
-                    else f"DER step: DERNet over {args.experts} {args.model.upper()} extractors, newest trained")
+            what = {"a": f"MRN loop A: one {args.model.upper()} expert trained",
+                    "der": f"DER step: DERNet over {args.experts} {args.model.upper()} extractors, newest trained",
+                    "lwf": f"LwF task-1 step on one {args.model.upper()} network", "ewc": f"EWC task-1 step on one {args.model.upper()} network"}[args.loop]
             res.update({"n_gpus": world, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
                         "config": {"workload": f"{what} on 32x256x4 crops, random-init weights",
                                    "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}"}})

@@ -1,5 +1,6 @@
 """LwF learner (reference il_modules/lwf.py:26-114): tasks > 0 add a knowledge-distillation term against the frozen
 previous network: loss = 3 * KD(T=2 on the old classes) + loss_clf."""
+import contextlib
 import time
 
 import torch
@@ -20,14 +21,31 @@ class LwF(BaseLearner):
         self._old_network = self.model.copy().freeze()
         self._known_classes = self._total_classes
 
+    def _old_stream(self):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
+
     def kd_step(self, image, labels):
         """one iteration of lwf.py:52-95"""
         labels_index, labels_length = self.converter.encode(labels, batch_max_length=self.opt.batch_max_length)
         ctc = "CTC" in self.opt.Prediction
         text = None if ctc else labels_index[:, :-1]
-        preds = self.model(image, text, True)["predict"]
-        with torch.no_grad():                                 # frozen + eval-mode copy (Model.freeze(), model.py:191-197)
+        # the frozen + eval-mode copy (Model.freeze(), model.py:191-197) does not depend on the network being trained: its forward
+        # runs on a side stream next to the new network's (same results, only the launch order changes)
+        side = self._old_stream() if image.is_cuda else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+        with torch.no_grad(), (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
             old = self._old_network(image, text, True)["predict"]
+        preds = self.model(image, text, True)["predict"]
+        if side is not None:
+            main = torch.cuda.current_stream()
+            main.wait_stream(side)
+            old.record_stream(main)
+            image.record_stream(side)
+            if text is not None:
+                text.record_stream(side)
         loss_clf = self.criterion(preds, labels_index, labels_length)
         loss_kd = Fn.kd_loss(preds, old, 0 if ctc else 1, self._known_classes, T)          # [:, start_index:known] (:81-85)
         loss = self.kd_weight * loss_kd + loss_clf
