@@ -107,7 +107,8 @@ def cpu_baseline(learner, opt, n_experts, batch=32, iters=3, max_threads=32, bud
     host threads (capped: more threads only add synchronisation overhead at this size)."""
     from oracle import mrn_oracle as O
     from mrn_amd.data.synthetic import SyntheticTextLines
-    torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), max_threads)))   # more threads only add sync overhead at this size
+    from mrn_amd.tools.utils import host_cpu_budget
+    torch.set_num_threads(max(1, min(host_cpu_budget(), max_threads)))   # (affinity capped by the cgroup quota; more only adds sync overhead)
     sd = {k[len("module."):]: v.detach().cpu().clone() for k, v in learner.model.state_dict().items()}
     cfg = O.Cfg(opt.Transformation, opt.FeatureExtraction, opt.SequenceModeling, opt.Prediction)
     names = [n for n, p in learner.model.module.named_parameters() if p.requires_grad]
@@ -344,6 +345,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
     torch.cuda.set_device(local)
+    from mrn_amd.tools.utils import host_cpu_budget
+    torch.set_num_threads(max(1, host_cpu_budget() // max(1, world)))     # (PyTorch sizes its pools from the affinity mask, not the cgroup quota)
     torch.manual_seed(111)
 
     if args.precision == "fp16":

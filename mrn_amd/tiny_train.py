@@ -32,6 +32,7 @@ from .il_modules.joint import JointLearner
 from .il_modules.lwf import LwF
 from .il_modules.mrn import MRN
 from .il_modules.wa import WA
+from .tools.utils import host_cpu_budget
 
 LEARNERS = {"lwf": LwF, "wa": WA, "ewc": EWC, "der": DER, "mrn": MRN, "joint_mix": JointLearner, "joint_loader": JointLearner}
 
@@ -168,6 +169,7 @@ def main(argv=None):
     if not torch.cuda.is_available():
         raise SystemExit("mrn_amd.tiny_train needs an MI355X (there is no CPU fallback on the product path)")
     torch.cuda.set_device(local)
+    torch.set_num_threads(max(1, host_cpu_budget() // max(1, world)))     # (PyTorch sizes its pools from the affinity mask, not the quota)
     seed_everything(opt.manual_seed)
     opt.gpu_name = "_".join(torch.cuda.get_device_name().split())
     opt.num_gpu = world

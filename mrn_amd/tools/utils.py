@@ -98,3 +98,27 @@ def adjust_learning_rate(optimizer, iteration, opt):
             lr *= opt.lr_drop_rate
     for group in optimizer.param_groups:
         group["lr"] = lr
+
+
+def host_cpu_budget():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (containers often expose every core of
+    the host in the mask -- 256 on the MI355X boxes -- while the quota allows 16; PyTorch sizes its thread pools from the mask and
+    oversubscribes 16x, which made a 33 MB torch.cat take 40 ms)"""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                 # cgroup v2: "<quota> <period>" or "max <period>"
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:                                                      # cgroup v1
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                quota = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                period = int(f.read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return n
