@@ -94,11 +94,15 @@ int mrn_split_weight_bf16(const float* w, void* hi, void* lo, int64_t n, int hal
  * y_hl32 (optional, Cout % 32 == 0, dense rows): the result also (y != NULL) or only (y == NULL) as the HL32 operand of the
  * next GEMM -- fc1 + GELU -> fc2 of the SVTR Mlp (modules/svtr.py:46-67) without an operand-split pass in between.
  * products: 3 = split-fp16 x3 (22-bit products, the 1e-4 parity mode); 1 = hi x hi only: plain fp16 products with fp32
- * accumulation, the reduced-precision mode BASELINE configs 2 ("bf16") and 5 ("fp16 MFMA") ask for. */
+ * accumulation, the reduced-precision mode BASELINE configs 2 ("bf16") and 5 ("fp16 MFMA") ask for.
+ * ch_scale / ch_shift [G][Cout] (a pair, or both NULL): per-channel affine applied after the bias -- BatchNorm2d in EVAL mode
+ * (running statistics, mrn_bn_eval_affine_f32) folded into the epilogue, so a frozen eval-mode Conv2d -> BatchNorm2d -> (+ identity)
+ * -> ReLU (modules/feature_extraction.py:184-199) is ONE launch; residual_hl32: the identity as HL32 lines (needs y_hl32). */
 int mrn_conv2d_x3_hl32(const void* x_hl, const void* w_hl, const void* zero_page, const float* bias,
                        const float* residual, float* y, float* stats, const float* out_scale, const float* x_scale, int G, int64_t x_group_stride_bytes, int B, int H, int W,
                        int Cin, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int act, int tile_m, int tile_n,
-                       int64_t y_row_stride, int64_t y_group_stride, int x_group_div, void* y_hl32, int products, void* stream);
+                       int64_t y_row_stride, int64_t y_group_stride, int x_group_div, void* y_hl32, int products, const float* ch_scale,
+                       const float* ch_shift, const void* residual_hl32, void* stream);
 int64_t mrn_conv2d_x3_stats_floats(int G, int B, int Ho, int Wo, int Cout, int tile_m);
 int mrn_split_hl32_f32(const float* x, void* out, int64_t rows, int C, const float* scale, void* stream);
 /* transposed split for weight-gradient GEMMs (dW = dy^T x reduces over rows): x[rows][C] -> [splits][C][rows/splits/32][128 B],

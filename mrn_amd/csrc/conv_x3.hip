@@ -52,6 +52,9 @@ struct ConvX3Params {
   float* y;                   // [G][M][N], or null when only y_hl is wanted
   unsigned char* y_hl;        // the same result as HL32 lines [G][M][N/32][128 B] (dense rows, N % 32 == 0), or null
   float* stats;               // [G][tilesM][2][N] or null
+  const float* ch_scale;      // [G][N] per-channel affine applied after bias (eval-mode BatchNorm folded into the epilogue) or null
+  const float* ch_shift;      // [G][N] (with ch_scale)
+  const unsigned char* res_hl; // residual as HL32 lines (same geometry as y_hl), added before the activation, or null
   long x_gstride, w_gstride;  // bytes
   int x_group_div;            // activation group = g / x_group_div (weight-gradient GEMMs: one dy^T chunk serves all taps)
   long y_gstride, y_ld;       // output group stride / row pitch in floats
@@ -416,12 +419,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
   float* yg = p.y + (long)g * p.y_gstride;
   const float osc = (p.out_scale ? p.out_scale[g * 2 + 1] : 1.f) * (p.x_scale ? p.x_scale[1] : 1.f);
   const float* rg = p.res ? p.res + (long)g * p.y_gstride : nullptr;
-  float csum[WN], csq[WN], bn[WN];
+  float csum[WN], csq[WN], bn[WN], cs[WN], sh[WN];
 #pragma unroll
   for (int j = 0; j < WN; ++j) {
     csum[j] = csq[j] = 0.f;
     const int n = n0 + (wn * WN + j) * 32 + (lane & 31);
     bn[j] = (p.bias && n < p.N) ? p.bias[(long)g * p.N + n] : 0.f;
+    cs[j] = (p.ch_scale && n < p.N) ? p.ch_scale[(long)g * p.N + n] : 1.f;
+    sh[j] = (p.ch_scale && n < p.N) ? p.ch_shift[(long)g * p.N + n] : 0.f;
   }
 #pragma unroll
   for (int i = 0; i < WM; ++i) {
@@ -436,14 +441,19 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
         const int n = n0 + (wn * WN + j) * 32 + (lane & 31);
         if (n < p.N) {
           float v = acc[i][j][e] * osc + bn[j];
+          if (p.ch_scale) v = v * cs[j] + sh[j];             // eval-mode BatchNorm (running statistics): same expression as bn_apply
           if (rg) v += rg[pix * p.y_ld + n];
+          if (HL_OUT && p.res_hl) {
+            const unsigned char* rl = p.res_hl + ((long)g * p.y_gstride + pix * p.y_ld + (n & ~31)) * 4 + (n & 31) * 2;
+            v += (float)*reinterpret_cast<const _Float16*>(rl) + (float)*reinterpret_cast<const _Float16*>(rl + 64);
+          }
           csum[j] += v;
           csq[j] += v * v;
           if (p.act == 1) v = fmaxf(v, 0.f);
           else if (p.act == 2) v = gelu_fast(v);                                             // GELU (erf), SVTR Mlp
           if (!HL_OUT || p.y) yg[pix * p.y_ld + n] = v;
           if (HL_OUT && p.y_hl) {       // operand of the next GEMM: 32 lanes fill the hi half and the lo half of one 128-byte line
-            _Float16 h, l;
+            _Float16 h, l;               // (pairing neighbouring lanes' halves into 4-byte stores measured no better: SVTR x 6 -2 %)
             split_f16(v, h, l);
             unsigned char* line = p.y_hl + ((long)g * p.y_gstride + pix * p.y_ld + (n & ~31)) * 4 + (n & 31) * 2;
             *reinterpret_cast<_Float16*>(line) = h;
@@ -803,11 +813,14 @@ MRN_EXPORT int mrn_conv2d_x3_hl32(const void* x_hl, const void* w_hl, const void
                                   const float* x_scale, int G, int64_t x_group_stride_bytes, int B, int H,
                                   int W, int Cin, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int act,
                                   int tile_m, int tile_n, int64_t y_row_stride, int64_t y_group_stride, int x_group_div,
-                                  void* y_hl32, int products, void* stream) {
+                                  void* y_hl32, int products, const float* ch_scale, const float* ch_shift,
+                                  const void* residual_hl32, void* stream) {
   MRN_CHECK_ARG(x_hl && w_hl && zero_page && (y || y_hl32) && G >= 1, "mrn_conv2d_x3_hl32: bad operands");
   MRN_CHECK_ARG(!y_hl32 || (Cout % 32 == 0 && y_row_stride <= 0 && y_group_stride <= 0 && (uintptr_t)y_hl32 % 128 == 0),
                 "mrn_conv2d_x3_hl32: the HL32 result needs Cout %% 32 == 0 and dense rows");
   MRN_CHECK_ARG(Cin % 32 == 0 && kh * kw <= 32, "mrn_conv2d_x3_hl32: unsupported Cin=%d kernel=%dx%d", Cin, kh, kw);
+  MRN_CHECK_ARG((!ch_scale == !ch_shift) && (!residual_hl32 || (y_hl32 && (uintptr_t)residual_hl32 % 128 == 0)),
+                "mrn_conv2d_x3_hl32: ch_scale / ch_shift come as a pair; an HL32 residual needs the HL32 result (same geometry)");
   MRN_CHECK_ARG(products == 3 || products == 1, "mrn_conv2d_x3_hl32: products must be 3 (split-fp16 x3) or 1 (hi x hi), got %d", products);
   MRN_CHECK_ARG(((uintptr_t)x_hl % 128 == 0) && ((uintptr_t)w_hl % 128 == 0) && ((uintptr_t)zero_page % 16 == 0) &&
                     (x_group_stride_bytes % 128 == 0), "mrn_conv2d_x3_hl32: HL32 operands must be 128-byte aligned");
@@ -821,6 +834,7 @@ MRN_EXPORT int mrn_conv2d_x3_hl32(const void* x_hl, const void* w_hl, const void
   memset(&p, 0, sizeof(p));
   p.x = (const unsigned char*)x_hl; p.w = (const unsigned char*)w_hl; p.zero = (const unsigned char*)zero_page;
   p.bias = bias; p.out_scale = out_scale; p.x_scale = x_scale; p.res = residual; p.y = y; p.y_hl = (unsigned char*)y_hl32; p.stats = stats;
+  p.ch_scale = ch_scale; p.ch_shift = ch_shift; p.res_hl = (const unsigned char*)residual_hl32;
   p.Cb = Cin / 32; p.taps = kh * kw; p.nk = p.Cb * p.taps;
   p.x_gstride = x_group_stride_bytes; p.w_gstride = (long)Cout * p.nk * 128;
   p.x_group_div = x_group_div > 1 ? x_group_div : 1;

@@ -22,6 +22,7 @@ from .. import ops
 from ._nn import _pair, packed_weight, require_no_grad, to_nhwc
 
 
+EVAL_BN_FOLD = os.environ.get("MRN_EVAL_BN_FOLD", "1") != "0"      # eval-mode BatchNorm folded into the conv epilogue (A/B switch)
 RESIDUAL_FROM_F32 = bool(int(os.environ.get("MRN_RESIDUAL_F32", "0")))      # True: keep an fp32 copy of every identity-shortcut source (one extra 4 B/element write)
 
 
@@ -137,8 +138,38 @@ class BackboneGroup(_GroupedLinear):
         training = bns is not None and bns[0].training
         fuse_act = bns is None                       # no BatchNorm: bias + ReLU go into the conv epilogue
         act = ops.ACT_RELU if (fuse_act and relu) else ops.ACT_NONE
-        y = torch.empty(G, B, Ho, Wo, Cout, device=dev, dtype=torch.float32)
         stats = None
+        res = residual.f32 if residual is not None else None
+        res_hl = residual.hl if residual is not None and res is None else None
+        if (EVAL_BN_FOLD and bns is not None and not training and Cin % 32 == 0 and Cout >= 64 and Cout % 32 == 0
+                and (want_hl or res_hl is None)):
+            # frozen experts in EVAL mode (DERNet's old extractors, LwF's previous network, validation): the BatchNorm is a fixed
+            # per-channel affine, so conv -> BN -> (+ identity) -> ReLU -> operand split is ONE launch: the affine, the shortcut
+            # and the activation run in the conv epilogue, which writes the HL32 operand of the next layer directly
+            if x.hl is None:
+                assert x.f32 is not None
+                x.hl = ops.split_hl32(x.f32)
+            w_hl, w_scale = self._weights_hl(convs)
+            tensors = [t for b in bns for t in (b.weight, b.bias, b.running_mean, b.running_var)]
+
+            def affine():
+                ss = [ops.bn_eval_affine(b.weight, b.bias, b.running_mean, b.running_var, b.eps) for b in bns]
+                return torch.stack([a for a, _ in ss]).contiguous(), torch.stack([a for _, a in ss]).contiguous()
+            scale, shift = self._cached("bnaff%d" % id(bns[0]), tensors, affine)
+            fused = dict(bias=self._bias_stack(convs), act=ops.ACT_RELU if relu else ops.ACT_NONE, ch_scale=scale, ch_shift=shift,
+                         residual=res, residual_hl=res_hl, products=ops.X3_PRODUCTS)
+            if pool is not None:
+                assert res is None and res_hl is None
+                y, _ = ops.conv2d_x3(x.hl, G, x.shared, B, H, W, Cin, w_hl, w_scale, Cout, ksize, stride, padding, **fused)
+                f32, hl, (Hp, Wp) = ops.maxpool_grouped(y, pool[0], pool[1], pool[2], None, None, relu=False, want_f32=want_f32,
+                                                        want_hl=want_hl)
+                return Act((G, B, Hp, Wp, Cout), f32, hl)
+            got, _ = ops.conv2d_x3(x.hl, G, x.shared, B, H, W, Cin, w_hl, w_scale, Cout, ksize, stride, padding,
+                                   hl_only=want_hl and not want_f32, also_hl=want_hl and want_f32, **fused)
+            if want_hl and want_f32:
+                return Act((G, B, Ho, Wo, Cout), got[0], got[1])
+            return Act((G, B, Ho, Wo, Cout), None, got) if want_hl else Act((G, B, Ho, Wo, Cout), got, None)
+        y = torch.empty(G, B, Ho, Wo, Cout, device=dev, dtype=torch.float32)
         if Cin % 32 == 0 and Cout >= 64:
             if x.hl is None:
                 assert x.f32 is not None
@@ -170,8 +201,6 @@ class BackboneGroup(_GroupedLinear):
                 scale = torch.stack([s for s, _ in ss]).contiguous()
                 shift = torch.stack([s for _, s in ss]).contiguous()
         # identity shortcut: the fp32 tensor when it exists, else the HL32 image (hi + lo) the block input already has
-        res = residual.f32 if residual is not None else None
-        res_hl = residual.hl if residual is not None and res is None else None
         post_relu = relu and not fuse_act
         if pool is not None:
             assert res is None and res_hl is None

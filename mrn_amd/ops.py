@@ -500,18 +500,21 @@ def pack_weights_hl32(ws, scale=None):
 
 def conv2d_x3(x_hl, G, shared_input, B, H, W, Cin, w_hl, w_scale, Cout, ksize, stride=(1, 1), padding=(0, 0), bias=None,
               act=ACT_NONE, want_stats=False, out=None, out_row_stride=0, out_group_stride=0, residual=None, x_scale=None,
-              x_group_div=1, hl_only=False, products=3):
+              x_group_div=1, hl_only=False, products=3, ch_scale=None, ch_shift=None, residual_hl=None, also_hl=False):
     """Grouped conv on HL32 operands -> (y [G,B,Ho,Wo,Cout] fp32, stats or None).  With `out` and the two strides (floats)
     the rows of group g land at out.data_ptr + g * out_group_stride + row * out_row_stride.
-    hl_only: the result is written ONLY as the HL32 operand of the next GEMM (returned in place of y)."""
+    hl_only: the result is written ONLY as the HL32 operand of the next GEMM (returned in place of y); also_hl: fp32 AND HL32
+    (returned as the pair (y, y_hl)).  ch_scale / ch_shift [G,Cout]: eval-mode BatchNorm folded into the epilogue;
+    residual_hl: the identity shortcut as HL32 lines (needs an HL32 result)."""
     kh, kw = ksize
     Ho, Wo = conv_out_hw(H, W, ksize, stride, padding)
     dev = x_hl.device
     y_hl = None
-    if hl_only:
-        assert out is None and Cout % 32 == 0
-        y = None
+    if hl_only or also_hl:
+        assert (out is None or also_hl) and Cout % 32 == 0
         y_hl = torch.empty(G * B * Ho * Wo * Cout * 4, device=dev, dtype=torch.uint8)
+    if hl_only:
+        y = None
     else:
         y = out if out is not None else torch.empty(G, B, Ho, Wo, Cout, device=dev, dtype=torch.float32)
     tile_m, tile_n = x3_tile(Cout, kh * kw * Cin, M=B * Ho * Wo, G=G)
@@ -524,7 +527,7 @@ def conv2d_x3(x_hl, G, shared_input, B, H, W, Cin, w_hl, w_scale, Cout, ksize, s
     call("mrn_conv2d_x3_hl32", _p(x_hl), _p(w_hl), _p(_zero_page(dev)), _p(bias), _p(residual), _p(y), _p(stats), _p(w_scale),
          _p(x_scale), G, gstride,
          B, H, W, Cin, Cout, kh, kw, stride[0], stride[1], padding[0], padding[1], act, tile_m, tile_n, out_row_stride, out_group_stride,
-         x_group_div, _p(y_hl), int(products), _stream())
+         x_group_div, _p(y_hl), int(products), _p(ch_scale), _p(ch_shift), _p(residual_hl), _stream())
     if timed:
         # algorithmic bytes: every operand element once (HL32 = 4 B / element, like fp32) + the fp32 result
         nbytes = 4.0 * ((1 if shared_input else G) * B * H * W * Cin + G * Cout * kh * kw * Cin + G * B * Ho * Wo * Cout)
@@ -532,7 +535,7 @@ def conv2d_x3(x_hl, G, shared_input, B, H, W, Cin, w_hl, w_scale, Cout, ksize, s
         if TIMER_SHAPES:
             kind += "|G%d B%d %dx%d %d->%d k%dx%d s%d%d" % (G, B, H, W, Cin, Cout, kh, kw, stride[0], stride[1])
         CONV_TIMER.end(t0, 2.0 * G * B * Ho * Wo * Cout * kh * kw * Cin, kind, nbytes)
-    return (y_hl if hl_only else y), stats
+    return (y_hl if hl_only else ((y, y_hl) if also_hl else y)), stats
 
 
 def conv2d_x3_scaled(x, w_ohwi, bias, stride, padding, act=ACT_NONE, want_stats=False, sx=None):

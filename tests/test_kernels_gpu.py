@@ -678,6 +678,32 @@ def test_x3_linear_hl32_result(ops, G, rows, K, N, act):
     assert torch.equal(hl, ops.split_hl32(y))
 
 
+@pytest.mark.parametrize("shortcut", ["none", "f32", "hl32"])
+def test_conv_x3_epilogue_folds_eval_batchnorm_and_shortcut(ops, shortcut):
+    """mrn_conv2d_x3_hl32 with ch_scale / ch_shift (+ residual / residual_hl32, ReLU, fp32 and HL32 results): one launch gives
+    what conv -> mrn_bn_apply_grouped_f32 (eval-mode affine + identity + ReLU + operand split) gives in two
+    (reference modules/feature_extraction.py:184-199 in eval mode)"""
+    G, B, H, W, Cin, Cout = 3, 5, 4, 13, 64, 96
+    x = cu(rnd(G, B, H, W, Cin, seed=310))
+    ws = [cu(rnd(Cout, 3, 3, Cin, seed=311 + g, scale=0.04)) for g in range(G)]
+    scale, shift = cu(rnd(G, Cout, seed=315)) + 1.5, cu(rnd(G, Cout, seed=316))
+    res = cu(rnd(G, B, H, W, Cout, seed=317))
+    x_hl = ops.split_hl32(x)
+    w_hl, sw = ops.pack_weights_hl32(ws)
+    args = (x_hl, G, False, B, H, W, Cin, w_hl, sw, Cout, (3, 3), (1, 1), (1, 1))
+    y, _ = ops.conv2d_x3(*args)
+    res_hl = ops.split_hl32(res) if shortcut == "hl32" else None
+    ref_f32, ref_hl = ops.bn_apply_grouped(y.clone(), scale, shift, relu=True, residual=res if shortcut == "f32" else None,
+                                           want_f32=True, want_hl=True, residual_hl=res_hl)
+    (got_f32, got_hl), _ = ops.conv2d_x3(*args, act=ops.ACT_RELU, ch_scale=scale, ch_shift=shift,
+                                         residual=res if shortcut == "f32" else None, residual_hl=res_hl, also_hl=True)
+    assert_close("fused eval layer", got_f32, ref_f32, atol=1e-6, rtol=1e-6)
+    assert torch.equal(got_hl, ops.split_hl32(got_f32))
+    only_hl, _ = ops.conv2d_x3(*args, act=ops.ACT_RELU, ch_scale=scale, ch_shift=shift,
+                               residual=res if shortcut == "f32" else None, residual_hl=res_hl, hl_only=True)
+    assert torch.equal(only_hl, got_hl)
+
+
 @pytest.mark.parametrize("B,N,heads,H", [(3, 512, 2, 8), (2, 256, 4, 4), (3, 128, 8, 2), (2, 100, 2, 0), (2, 64, 8, 0)])
 def test_svtr_attention_backward(ops, B, N, heads, H):
     """SvtrAttentionFn (fused forward keeping the log-sum-exp + the two recomputing backward kernels) against torch autograd
