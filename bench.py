@@ -511,7 +511,7 @@ def main():
                     "effective_clock_ghz_under_profiler": 1.48, "peak_assumes_ghz": 2.4, "mfma_busy_at_effective_clock": 0.70,
                     "source": "static: profiles/r02b_conv_x3_power_wall.md, profiles/r02a_conv_x3_dominant_shape_pmc.txt "
                               "(tools/bench_conv_x3.py with ZERO_INPUTS, tools/pmc_conv_x3.sh)"}
-            res["roofline"]["measured"] = ("timed region: HIP events per launch on the launch streams; two lock-step half-groups "
+            res["roofline"]["measured"] = ("timed region: HIP events per launch on the launch streams; the lock-step sub-groups (three of two experts) "
                                            "and the router phase of the previous batch share the GPU, so the rate is taken over "
                                            "the union of this kernel's launch intervals")
             if isolated:

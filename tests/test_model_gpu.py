@@ -285,7 +285,7 @@ def test_full_size_trba6_loop_b_properties():
         net = build()
         with torch.no_grad():
             handle = net.experts_prefetch(image, text[:, :-1], True)
-            assert handle is not None and len(handle["parts"]) == 2
+            assert handle is not None and len(handle["parts"]) == 3          # six experts: three lock-step sub-groups
             fast = net(image, True, text[:, :-1], True, experts=handle)
         torch.cuda.synchronize()
         bn_fast = {k: v.clone() for k, v in net.state_dict().items() if "running_" in k}
