@@ -180,3 +180,49 @@ def test_config_loader_accepts_the_reference_layout(tmp_path):
     (tmp_path / "Latin" / "dict.txt").write_text("a\nb\na\nc\n")
     character, char = tiny_train.load_dict(str(tmp_path / "Latin"), {"z": 1})
     assert character == ["z", "a", "b", "c"]
+
+
+@pytest.mark.parametrize("optimizer", ["adam", "sgd"])
+def test_learner_step_matches_torch_clip_optimizer_onecycle(optimizer):
+    """a17 at learner level: BaseLearner.backward_and_step (global-norm clip to 5 -> flat Adam / SGD kernel -> OneCycle) against the
+    reference's own composition (il_modules/base.py:72-114,255-262: clip_grad_norm_ + torch.optim step + OneCycleLR.step) replayed
+    on the CPU with the gradients the HIP backward produced -- eight consecutive steps, every parameter within 2e-6 (Adam) / 1e-5 (SGD)"""
+    import bench
+    from mrn_amd.data.synthetic import SyntheticTextLines
+    from mrn_amd.tools import weights as W
+    torch.manual_seed(7)
+    opt = bench.make_opt("crnn", 8)
+    opt.optimizer, opt.num_iter, opt.lr = optimizer, 12, 0.02 if optimizer == "sgd" else 1e-3
+    opt.sgd_momentum, opt.sgd_weight_decay = 0.9, 5e-4
+    learner = bench.build_loop_a_learner(opt)
+    learner.build_optimizer(learner.count_param(), total_steps=opt.num_iter)
+    W.fill_state_dict(learner.model.state_dict(), seed=29)
+    torch.autograd.graph.increment_version(learner.optimizer.params)
+    params = learner.optimizer.params
+    ref = [torch.nn.Parameter(p.detach().cpu().clone()) for p in params]
+    if optimizer == "adam":
+        topt = torch.optim.Adam(ref, lr=opt.lr)
+    else:
+        topt = torch.optim.SGD(ref, lr=opt.lr, momentum=opt.sgd_momentum, weight_decay=opt.sgd_weight_decay)
+    sched = torch.optim.lr_scheduler.OneCycleLR(topt, max_lr=opt.lr, cycle_momentum=(optimizer == "sgd"), div_factor=20,
+                                                final_div_factor=1000, total_steps=opt.num_iter)
+    data = SyntheticTextLines(opt, seed=5)
+    data.set_characters(learner.character)
+    captured = {}
+    step_fn = learner.optimizer.step
+
+    def spy(*a, **k):                                   # the gradients the update is about to consume (after zero_grad + backward)
+        captured["g"] = [p.grad.detach().cpu().clone() for p in params]
+        return step_fn(*a, **k)
+    learner.optimizer.step = spy
+    for it in range(8):
+        learner.train_step(*data.get_batch())
+        for r, g in zip(ref, captured["g"]):
+            r.grad = g
+        torch.nn.utils.clip_grad_norm_(ref, opt.grad_clip)
+        topt.step()
+        sched.step()
+        for i, (p, r) in enumerate(zip(params, ref)):
+            err = (p.detach().cpu() - r.detach()).abs().max().item()
+            tol = 2e-6 if optimizer == "adam" else 1e-5            # (SGD at lr 0.02 with momentum moves parameters 20x further per step)
+            assert err <= tol * max(1.0, r.detach().abs().max().item()), (it, i, err)
