@@ -186,7 +186,7 @@ def test_config_loader_accepts_the_reference_layout(tmp_path):
 def test_learner_step_matches_torch_clip_optimizer_onecycle(optimizer):
     """a17 at learner level: BaseLearner.backward_and_step (global-norm clip to 5 -> flat Adam / SGD kernel -> OneCycle) against the
     reference's own composition (il_modules/base.py:72-114,255-262: clip_grad_norm_ + torch.optim step + OneCycleLR.step) replayed
-    on the CPU with the gradients the HIP backward produced -- eight consecutive steps, every parameter within 2e-6 (Adam) / 1e-5 (SGD)"""
+    on the CPU with the gradients the HIP backward produced -- eight consecutive steps, every parameter within 2e-6"""
     import bench
     from mrn_amd.data.synthetic import SyntheticTextLines
     from mrn_amd.tools import weights as W
@@ -219,10 +219,14 @@ def test_learner_step_matches_torch_clip_optimizer_onecycle(optimizer):
         learner.train_step(*data.get_batch())
         for r, g in zip(ref, captured["g"]):
             r.grad = g
-        torch.nn.utils.clip_grad_norm_(ref, opt.grad_clip)
+        # clip_grad_norm_ with the norm accumulated in float64: torch's CPU float32 vector_norm is itself off by 4e-5 relative on
+        # 9.3 M elements (the HIP norm kernel is within 2e-8 of the float64 value), which momentum SGD would amplify
+        total = torch.sqrt(sum(r.grad.double().pow(2).sum() for r in ref))
+        coef = min(1.0, opt.grad_clip / (float(total) + 1e-6))
+        for r in ref:
+            r.grad.mul_(coef)
         topt.step()
         sched.step()
         for i, (p, r) in enumerate(zip(params, ref)):
             err = (p.detach().cpu() - r.detach()).abs().max().item()
-            tol = 2e-6 if optimizer == "adam" else 1e-5            # (SGD at lr 0.02 with momentum moves parameters 20x further per step)
-            assert err <= tol * max(1.0, r.detach().abs().max().item()), (it, i, err)
+            assert err <= 2e-6 * max(1.0, r.detach().abs().max().item()), (it, i, err)
