@@ -33,7 +33,12 @@ class Criterion:
                 preds = preds.contiguous()
             return Fn.ctc_loss(preds, labels_index, labels_length)
         target = labels_index[:, 1:]                       # without [SOS]; CrossEntropyLoss(ignore_index=[PAD]), :134
-        return Fn.cross_entropy(preds, target, self.pad_index)
+        loss = Fn.cross_entropy(preds, target, self.pad_index)
+        if torch.is_grad_enabled():                        # N > 1: the mean over the GLOBAL batch's valid targets, as DataParallel
+            w = parallel.global_mean_weight((target != self.pad_index).sum())       # computes it on the gathered outputs
+            if w is not None:
+                loss = loss * w.view(loss.shape)
+        return loss
 
     def to(self, device):
         return self

@@ -175,6 +175,19 @@ def broadcast_module(module, src=0):
     torch.autograd.graph.increment_version(list(module.parameters()))      # (.data copies do not bump the parameters' versions)
 
 
+def global_mean_weight(n_local):
+    """DataParallel computes a mean loss over the GATHERED batch; a replica computes it over its own shard and the gradients are
+    averaged afterwards.  The two agree exactly when every shard has the same number of contributing items -- not so for
+    CrossEntropyLoss(ignore_index=[PAD]), whose valid-target count varies with the label lengths.  Returns the factor
+    n_local * world / sum_over_ranks(n_local) that turns this rank's shard mean into its share of the global mean (None: one rank)."""
+    if world_size() == 1:
+        return None
+    n = n_local.detach().to(torch.float32).reshape(1)
+    total = n.clone()
+    dist.all_reduce(total)                                    # SUM (one scalar per step)
+    return n * world_size() / total
+
+
 def barrier():
     if world_size() > 1:
         dist.barrier()

@@ -81,6 +81,25 @@ assert torch.equal(both[0], both[1]), "router parameters differ between the rank
 bf = [torch.zeros_like(frozen) for _ in range(world)]
 torch.distributed.all_gather(bf, frozen)
 assert torch.equal(bf[0], bf[1]), "frozen experts differ between the ranks (broadcast_module)"
+# CrossEntropyLoss(ignore_index=[PAD]) under data parallelism: this rank's loss, weighted by its share of the valid targets, has
+# the gradient (after the 1 / world average) of DataParallel's mean over the GATHERED batch (reference il_modules/base.py:68,134)
+from mrn_amd.il_modules.base import Criterion
+def shard(r):
+    g = torch.Generator().manual_seed(900 + r)
+    lg = torch.randn(6, 26, 40, generator=g)
+    tg = torch.randint(2, 40, (6, 27), generator=g)
+    for b in range(6):
+        tg[b, 3 + 4 * r + b:] = 1                       # [PAD] = 1 after a rank-dependent label length
+    return lg, tg
+lg, tg = shard(rank)
+mine = lg.cuda().requires_grad_(True)
+Criterion("Attn", pad_index=1)(mine, tg.cuda()).backward()
+allg = torch.cat([shard(r)[0] for r in range(world)]).requires_grad_(True)
+allt = torch.cat([shard(r)[1] for r in range(world)])
+torch.nn.functional.cross_entropy(allg.view(-1, 40), allt[:, 1:].reshape(-1), ignore_index=1).backward()
+want = allg.grad[6 * rank:6 * rank + 6]
+got = mine.grad.cpu() / world
+assert (got - want).abs().max().item() <= 1e-7 * max(1.0, want.abs().max().item()) + 1e-9, (got - want).abs().max().item()
 path = learner.checkpoint_path(2, 1)
 learner.save_checkpoint(2, 1)                        # rank 0 writes, the others return
 parallel.barrier()
