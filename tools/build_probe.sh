@@ -6,6 +6,7 @@ flag=$1
 src=${2:-conv_x3.hip}
 stem=${src%.hip}
 cd "$(dirname "$0")/.."
+mkdir -p tools/probe
 python -m mrn_amd.build > /dev/null
 /opt/rocm/bin/hipcc -x hip -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fvisibility=hidden -fno-gpu-rdc -Wno-unused-result -D$flag -I mrn_amd/csrc \
   $EXTRA -c mrn_amd/csrc/$src -o tools/probe/${stem}_$flag.o
