@@ -230,3 +230,48 @@ def test_learner_step_matches_torch_clip_optimizer_onecycle(optimizer):
         for i, (p, r) in enumerate(zip(params, ref)):
             err = (p.detach().cpu() - r.detach()).abs().max().item()
             assert err <= 2e-6 * max(1.0, r.detach().abs().max().item()), (it, i, err)
+
+
+def test_full_size_loop_b_pipeline_is_deterministic_and_order_independent():
+    """Soak of the three-stream loop-B schedule at BASELINE size (TRBA x 6, B = 256, ten routing steps): two pipelined runs (frozen
+    experts of batch n+1 issued on three side streams before batch n's router step) end in bit-identical losses, router parameters
+    and BatchNorm buffers -- no stream race -- and the same losses / parameters as the run that issues the experts inside the step"""
+    import bench
+    from mrn_amd.data.synthetic import SyntheticTextLines
+    from mrn_amd.tools import weights as W
+    from mrn_amd.tools.utils import to_device
+
+    def run(prefetch, steps=10):
+        torch.manual_seed(3)
+        opt = bench.make_opt("trba", 256)
+        learner = bench.build_learner(opt, 6)
+        W.fill_state_dict(learner.model.state_dict(), seed=11)
+        torch.autograd.graph.increment_version(list(learner.model.parameters()))
+        learner.prepare_routing(total_steps=10 ** 9)
+        data = SyntheticTextLines(opt, seed=9)
+        data.set_characters(learner.character)
+        pending, losses = [], []
+
+        def fetch():
+            image, labels, idx = data.get_batch2()
+            ix = to_device(torch.LongTensor(idx).squeeze())
+            return image, labels, ix, (learner.prefetch_experts(image, labels) if prefetch else None)
+        for _ in range(steps):
+            if not pending:
+                pending.append(fetch())
+            image, labels, ix, pre = pending.pop(0)
+            if prefetch:
+                pending.append(fetch())
+            lc, lt = learner.routing_step(image, labels, ix, prefetched=pre)
+            losses.append((float(lc.detach()), float(lt.detach())))
+        torch.cuda.synchronize()
+        bufs = torch.cat([b.float().reshape(-1) for b in learner.model.buffers()])
+        out = (losses, learner.optimizer.flat.clone(), bufs.clone())
+        del learner
+        torch.cuda.empty_cache()
+        return out
+    la, fa, ba = run(True)
+    lb, fb, bb = run(True)
+    assert la == lb and torch.equal(fa, fb) and torch.equal(ba, bb)
+    lc, fc, _ = run(False)                      # (its BatchNorm buffers have seen one batch less: the look-ahead batch)
+    assert la == lc and torch.equal(fa, fc)
