@@ -164,6 +164,14 @@ def build_loop_a_learner(opt, quiet=True):
     return learner
 
 
+def train_dtype():
+    from mrn_amd import ops
+    if ops.TRAIN_PRODUCTS == 1:
+        return ("fp16 (reduced-precision mode: ONE fp16 MFMA product per term in the trained and frozen convolutions, range-scaled operands, "
+                "fp32 accumulate and fp32 storage; router / head Linear layers on split-fp16 x3)")
+    return "f32 (trained and frozen convolutions as range-safe split-fp16 x3 products, fp32 accumulate)"
+
+
 def time_loop_a(args, opt, rank, world, steps, warmup):
     """loop A on the same synthetic crops: forward, loss, backward (bucketed all-reduce when N > 1), clip, Adam"""
     from mrn_amd import parallel
@@ -191,7 +199,7 @@ def time_loop_a(args, opt, rank, world, steps, warmup):
     return {"metric": f"text-line images/sec, loop A (train the newest {args.model.upper()} expert: fwd + bwd + clip + Adam) at 32x256",
             "value": world * args.batch * steps / elapsed, "unit": "images/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps,
             "warmup": warmup, "per_gpu_batch": args.batch, "trainable_parameters": n_params, "loss": float(loss.detach()),
-            "dtype": "f32 (trained convolutions as range-safe split-fp16 x3 products, fp32 accumulate)"}
+            "dtype": train_dtype()}
 
 
 def time_il_step(args, opt, rank, world, steps, warmup):
@@ -243,7 +251,7 @@ def time_il_step(args, opt, rank, world, steps, warmup):
     return {"metric": f"text-line images/sec, {what}, {args.model.upper()}, task 1, at 32x256",
             "value": world * args.batch * steps / elapsed, "unit": "images/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps,
             "warmup": warmup, "per_gpu_batch": args.batch, "trainable_parameters": learner.optimizer.flat.numel(),
-            "loss": float(loss.detach()), "dtype": "f32 (trained convolutions as range-safe split-fp16 x3 products, fp32 accumulate)"}
+            "loss": float(loss.detach()), "dtype": train_dtype()}
 
 
 def time_der_step(args, opt, rank, world, steps, warmup):
@@ -307,7 +315,7 @@ def time_der_step(args, opt, rank, world, steps, warmup):
             "value": world * args.batch * steps / elapsed, "unit": "images/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps,
             "warmup": warmup, "per_gpu_batch": args.batch, "trainable_parameters": learner.optimizer.flat.numel(),
             "loss_clf": float(loss.detach()), "loss_aux": float(aux.detach()),
-            "dtype": "f32 (frozen extractors: split-fp16 x3; trained extractor: range-safe split-fp16 x3; fp32 accumulate)"}
+            "dtype": train_dtype()}
 
 
 def main():
@@ -351,6 +359,7 @@ def main():
 
     if args.precision == "fp16":
         ops.X3_PRODUCTS = 1
+        ops.TRAIN_PRODUCTS = 1           # (--loop a / der / lwf / ewc: the trained convolutions too)
     else:
         ops.CONV_PRECISION = args.precision
     opt = make_opt(args.model, args.batch)

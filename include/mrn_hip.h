@@ -127,7 +127,8 @@ int mrn_transpose_oy_hl32_f32(const float* x, void* out, int B, int H, int W, in
 int mrn_transpose_oy3_hl32_f32(const float* x, void* out, int B, int H, int W, int C, const float* scale, void* stream);   /* shifts -1, 0, +1 in one pass: out [3][C][lines][128 B] */
 int mrn_gemm_x3_windows_hl32(const void* a_hl, int64_t a_bytes, int a_pitch_lines, const void* w_hl, int64_t w_bytes,
                              int w_pitch_lines, const void* windows, int G, int M, int N, const void* zero_page,
-                             const float* out_scale, const float* x_scale, float* y, int tile_m, int tile_n, void* stream);
+                             const float* out_scale, const float* x_scale, float* y, int tile_m, int tile_n, int products,
+                             void* stream);   /* products: 3 or 1, as in mrn_conv2d_x3_hl32 */
 
 /* First convolution of the frozen experts' stacks (3x3, stride 1, padding 1, Cin = 4, Cout = 32 or 64: VGG conv 0
  * feature_extraction.py:19, ResNet conv0_1 :214, TPS localisation conv 1 transformation.py:60), G experts in one launch on the

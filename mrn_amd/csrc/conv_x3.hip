@@ -975,8 +975,10 @@ MRN_EXPORT int mrn_transpose_oy3_hl32_f32(const float* x, void* out, int B, int 
 // Used by the convolution weight gradient: A = dy^T, Wm = one of three x-shifted copies of x^T, one group per (split-K chunk, tap).
 MRN_EXPORT int mrn_gemm_x3_windows_hl32(const void* a_hl, int64_t a_bytes, int a_pitch_lines, const void* w_hl, int64_t w_bytes,
                                         int w_pitch_lines, const void* windows, int G, int M, int N, const void* zero_page,
-                                        const float* out_scale, const float* x_scale, float* y, int tile_m, int tile_n, void* stream) {
+                                        const float* out_scale, const float* x_scale, float* y, int tile_m, int tile_n, int products,
+                                        void* stream) {
   MRN_CHECK_ARG(a_hl && w_hl && windows && zero_page && y && G >= 1 && M >= 1 && N >= 1, "mrn_gemm_x3_windows_hl32: bad operands");
+  MRN_CHECK_ARG(products == 3 || products == 1, "mrn_gemm_x3_windows_hl32: products must be 3 (split-fp16 x3) or 1 (hi x hi), got %d", products);
   MRN_CHECK_ARG(a_bytes < (1L << 31) && w_bytes < (1L << 31) && (uintptr_t)a_hl % 128 == 0 && (uintptr_t)w_hl % 128 == 0,
                 "mrn_gemm_x3_windows_hl32: operand matrices must be 128-byte aligned and below 2 GiB");
   MRN_CHECK_ARG((tile_m == 256 && (tile_n == 256 || tile_n == 128 || tile_n == 64)) || (tile_m == 128 && tile_n == 128),
@@ -998,6 +1000,12 @@ MRN_EXPORT int mrn_gemm_x3_windows_hl32(const void* a_hl, int64_t a_bytes, int a
   // serves every group, so it is passed as a G-strided view of the same two floats by the caller when needed
   p.out_scale = out_scale;
   hipStream_t st = (hipStream_t)stream;
+  if (products == 1) {
+    if (tile_n == 256) return launch_x3<4, 4, 2, 2, false, 1>(p, st);
+    if (tile_m == 256 && tile_n == 64) return launch_x3<8, 1, 1, 2, false, 1>(p, st);
+    if (tile_m == 256) return launch_x3<4, 2, 2, 2, false, 1>(p, st);
+    return launch_x3<4, 2, 1, 2, false, 1>(p, st);
+  }
   if (tile_n == 256) return launch_x3<4, 4, 2, 2>(p, st);
   if (tile_m == 256 && tile_n == 64) return launch_x3<8, 1, 1, 2>(p, st);
   if (tile_m == 256) return launch_x3<4, 2, 2, 2>(p, st);

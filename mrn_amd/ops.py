@@ -320,8 +320,11 @@ def conv2d_nhwc(x, w_ohwi, bias=None, stride=(1, 1), padding=(0, 0), act=ACT_NON
 # Products per term of the grouped conv / Linear of the FROZEN experts (conv_x3.hip): 3 = split-fp16 x3 (default: the 1e-4 parity
 # mode); 1 = hi x hi only, i.e. plain fp16 products with fp32 accumulation -- the reduced-precision mode of BASELINE configs 2
 # and 5 (bench.py --precision fp16; measured tolerance and routing agreement: tests/test_model_gpu.py::test_reduced_precision_*).
-# Callers on the TRAINED path (router Linear layers, loop-A convolutions, weight gradients) always pass products=3.
+# The router's and the heads' Linear layers always run 3 products (functional.x3_linear / x3_wgrad); the TRAINED convolutions (forward,
+# data gradient, weight gradient -- 95 % of a training step's flops) follow TRAIN_PRODUCTS: fp16 products with fp32 accumulation and
+# per-operand power-of-two range scaling, i.e. what mixed-precision training computes (BASELINE config 5 "fp16 MFMA").
 X3_PRODUCTS = 1 if os.environ.get("MRN_X3_PRODUCTS") == "1" else 3
+TRAIN_PRODUCTS = 1 if os.environ.get("MRN_TRAIN_PRODUCTS") == "1" else 3
 X3_SMALL_TILE_MAX_K = 1200     # measured on MI355X (tools/bench_conv_x3.py): +3.5 % at K = 1152, +7.6 % at K = 576
 
 
@@ -396,7 +399,7 @@ def conv2d_wgrad_x3(dy, x, ksize, stride, padding, dy_scale=None, x_scale=None):
     G = S * taps
     part = torch.empty(S, taps, Cout, Cin, device=x.device, dtype=torch.float32)
     conv2d_x3(a_hl, G, False, Cout, 1, 1, rps, w_hl, sx.view(1, 2).expand(G, 2).contiguous(), Cin, (1, 1), x_scale=sd,
-              out=part, x_group_div=taps)
+              out=part, x_group_div=taps, products=TRAIN_PRODUCTS)
     dw = colsum(part.view(S, taps * Cout * Cin)).view(taps, Cout, Cin) if S > 1 else part[0]
     return dw.permute(1, 0, 2).contiguous().view(Cout, kh, kw, Cin)
 
@@ -462,7 +465,7 @@ def conv2d_wgrad_x3_windows(dy, x, dy_scale=None, x_scale=None):
     timed = CONV_TIMER is not None
     t0 = CONV_TIMER.begin() if timed else None
     call("mrn_gemm_x3_windows_hl32", _p(a_hl), Cout * lines * 128, lines, _p(w_hl), 3 * per, lines, _p(tab), G, Cout, Cin,
-         _p(_zero_page(dev)), _p(sx.view(1, 2).expand(G, 2).contiguous()), _p(sd), _p(part), tile_m, tile_n, _stream())
+         _p(_zero_page(dev)), _p(sx.view(1, 2).expand(G, 2).contiguous()), _p(sd), _p(part), tile_m, tile_n, int(TRAIN_PRODUCTS), _stream())
     if timed:
         CONV_TIMER.end(t0, 2.0 * 9 * Cout * Cin * P, "fp16x3/x3g%dx%d" % (tile_m, tile_n), 4.0 * (4 * P * Cin + P * Cout + G * Cout * Cin))
     dw = colsum(part.view(S, 9 * Cout * Cin)).view(9, Cout, Cin) if S > 1 else part[0]
@@ -548,7 +551,7 @@ def conv2d_x3_scaled(x, w_ohwi, bias, stride, padding, act=ACT_NONE, want_stats=
         sx = pow2_scale(x)          # (callers that use x in several GEMMs compute it once: ConvBlockFn)
     w_hl, sw = pack_weights_hl32([w_ohwi.contiguous()])
     y, stats = conv2d_x3(split_hl32(x, sx), 1, False, B, H, W, Cin, w_hl, sw, Cout, (kh, kw), stride, padding, bias=bias, act=act,
-                         want_stats=want_stats, x_scale=sx)
+                         want_stats=want_stats, x_scale=sx, products=TRAIN_PRODUCTS)
     return y[0], stats
 
 
