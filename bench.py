@@ -465,6 +465,12 @@ def main():
                     return ("gemm_f32_kernel<2,2,2,2,16,true> (128x128x16 implicit-GEMM conv, v_mfma_f32_32x32x2_f32)",
                             FP32_MFMA_PEAK_TFLOPS, 1)
                 arith, staging = kind.split("/")
+                if staging.startswith("wino"):
+                    R = int(staging[4])
+                    return (f"conv_x3_kernel<2, 4, 2, 1, false, 3, {R}> (grouped 3x3 conv of all experts as 1-D Winograd F({R},3) along W: "
+                            f"128 column-groups x 128 channels x 32 tiles, {R + 2} component reductions folded into {R} output accumulators in "
+                            f"registers, {arith} on v_mfma_f32_32x32x16_f16, transformed HL32 operands staged by buffer_load...lds through a 4-stage ring)",
+                            BF16_MFMA_PEAK_TFLOPS, 3.0 * (R + 2) / (3 * R))
                 if staging.startswith("x3g"):
                     tile = staging[3:]
                     targs = {"256x256": "4, 4, 2, 2", "256x128": "4, 2, 2, 2", "128x128": "4, 2, 1, 2", "256x64": "8, 1, 1, 2"}[tile]

@@ -130,6 +130,26 @@ int mrn_gemm_x3_windows_hl32(const void* a_hl, int64_t a_bytes, int a_pitch_line
                              const float* out_scale, const float* x_scale, float* y, int tile_m, int tile_n, int products,
                              void* stream);   /* products: 3 or 1, as in mrn_conv2d_x3_hl32 */
 
+/* The 3x3 / stride 1 / pad 1 convolutions of the frozen experts' deep ResNet stages (16 of TRBA's 29, the 512 -> 512 layers on
+ * 4 x 65 maps: modules/feature_extraction.py:165-199,262-294) as 1-D Winograd F(R,3) along W on the same split-fp16 x3 kernel:
+ * R + 2 products per R output columns instead of 3R (R = 4: half the matrix work of the direct form; R = 2: two thirds).
+ *   mrn_pack_weight_wino_hl32      w [Cout][3][3][Cin] fp32 -> U [Cout][R+2][Cin/32][3 (ky)][128 B] = scale * G g per kernel
+ *                                  row (sum in double; the power-of-two row scales of G are undone by the kernel's A^T);
+ *   mrn_bn_apply_wino_grouped_f32  BatchNorm-apply (+ residual + ReLU) of the previous layer, as mrn_bn_apply_grouped_f32, writing
+ *                                  V [G][B][H][ceil(W/R)][R+2][C/32][128 B] = B^T applied to every group of R columns (+ halo,
+ *                                  zero outside the row) and optionally the plain fp32 (not aliasing y) / HL32 result;
+ *   mrn_conv2d_x3_wino_hl32        y [G][B][H][W][Cout] = A^T [ sum over (ky, Cin) of U_m V_m ] + bias (act 0 / 1), BatchNorm
+ *                                  partial statistics [G][ceil(B*H*ceil(W/R)/128)][2][Cout] (mrn_conv2d_x3_wino_stats_floats) or
+ *                                  NULL; out_scale [G][2] = the weight prescale {s, 1/s}; v_group_stride_bytes 0 = shared input. */
+int mrn_pack_weight_wino_hl32(const float* w_ohwi, void* out, int Cout, int Cin, int R, const float* scale, void* stream);
+int mrn_bn_apply_wino_grouped_f32(const float* y, const float* residual, const void* residual_hl32, const float* scale,
+                                  const float* shift, float* out_f32, void* out_hl32, void* out_wino, int G, int B, int H, int W,
+                                  int C, int R, int relu, void* stream);
+int64_t mrn_conv2d_x3_wino_stats_floats(int G, int B, int H, int W, int Cout, int R);
+int mrn_conv2d_x3_wino_hl32(const void* v_hl, const void* u_hl, const void* zero_page, const float* bias, float* y, float* stats,
+                            const float* out_scale, int G, int64_t v_group_stride_bytes, int B, int H, int W, int Cin, int Cout,
+                            int R, int act, void* stream);
+
 /* First convolution of the frozen experts' stacks (3x3, stride 1, padding 1, Cin = 4, Cout = 32 or 64: VGG conv 0
  * feature_extraction.py:19, ResNet conv0_1 :214, TPS localisation conv 1 transformation.py:60), G experts in one launch on the
  * exact-fp32 MFMA; x [Gx][B][H][W][4] with x_group_stride floats between groups (0: all experts read the same crops), w

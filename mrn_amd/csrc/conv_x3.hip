@@ -72,6 +72,7 @@ struct ConvX3Params {
   const X3Window* win;        // windowed 1x1 GEMM: per-group operand windows (null: the regular grouped conv)
   int a_pitch, w_pitch;       // ... row pitch of the two operand matrices in lines
   int w_bytes;                // ... bytes of the whole weight-side matrix (x_bytes = the activation-side one)
+  int wino_W;                 // Winograd F(R,3) along W (WINO = R instantiations): real output width; GEMM rows are groups of R pixels
 };
 
 // 16 bytes per lane, global (buffer descriptor + per-lane byte offset + wave-uniform offset) -> LDS (wave-uniform base + 16*lane)
@@ -119,15 +120,38 @@ template <int WAVES_M, int WAVES_N, int WM, int WN, int NPROD>
 constexpr bool x3_hi_only() {
   return NPROD == 1 && (WAVES_M * WM * 32) % (16 * WAVES_M * WAVES_N) == 0 && (WAVES_N * WN * 32) % (16 * WAVES_M * WAVES_N) == 0;
 }
-template <int WAVES_M, int WAVES_N, int WM, int WN, int NPROD>
+constexpr int X3_WINO_STAGES = 4;     // LDS ring depth of the Winograd instantiations (128 x 128 tiles: 32 KiB per stage)
+template <int WAVES_M, int WAVES_N, int WM, int WN, int NPROD, int WINO = 0>
 constexpr size_t x3_lds_bytes() {
-  return (size_t)(WAVES_M * WM * 32 + WAVES_N * WN * 32) * (x3_hi_only<WAVES_M, WAVES_N, WM, WN, NPROD>() ? 64 * 4 : 128 * 2);
+  return (size_t)(WAVES_M * WM * 32 + WAVES_N * WN * 32) *
+         (x3_hi_only<WAVES_M, WAVES_N, WM, WN, NPROD>() ? 64 * 4 : 128 * (WINO > 0 ? X3_WINO_STAGES : 2));
 }
 
 // WAVES_M x WAVES_N waves; wave tile = (WM*32) x (WN*32); HL_OUT: the epilogue can also write the HL32 result (p.y_hl)
 // NPROD: 3 = split-fp16 x3 (lo*hi + hi*lo + hi*hi, 22-bit products: the parity mode); 1 = hi*hi only (plain fp16 products with fp32
 // accumulation -- the reduced-precision mode of BASELINE configs 2 and 5; the lo halves of the staged lines are not read)
-template <int WAVES_M, int WAVES_N, int WM, int WN, bool HL_OUT = false, int NPROD = 3>
+// Winograd F(R,3) output transforms A^T [R][R+2] with the power-of-two row scales of the packed weight transform folded in
+// (pack_weight_wino_hl32_kernel multiplies row m of G by wino_gscale(R, m); column m here carries the inverse)
+template <int R> struct WinoAT;
+template <> struct WinoAT<2> {
+  static constexpr float at[2][4] = {{1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, -1.f}};
+};
+template <> struct WinoAT<4> {
+  static constexpr float at[4][6] = {{0.25f, 0.5f, 0.5f, 0.5f, 0.5f, 0.f},
+                                     {0.f, 0.5f, -0.5f, 1.f, -1.f, 0.f},
+                                     {0.f, 0.5f, 0.5f, 2.f, 2.f, 0.f},
+                                     {0.f, 0.5f, -0.5f, 4.f, -4.f, 1.f}};
+};
+
+// WINO = R > 0: 1-D Winograd F(R,3) along W for 3x3 / stride 1 / pad 1 convolutions.  The producer pass has already applied
+// the input transform B^T to every group of R output columns (mrn_bn_apply_wino_grouped_f32: NC = R + 2 components per group,
+// layout [b][y][group][component][Cin/32][128 B]) and the packed weights hold G g per kernel row ([Cout][component][Cin/32][ky]
+// lines), so to this kernel the layer IS a 3x1 convolution with NC * Cin input channels on a [H][ceil(W/R)] map -- the staging,
+// the tile order and the border-row skipping are unchanged -- except that the reduction is cut into NC component segments:
+// each segment's sum T_m is folded into the R output accumulators Y_r += A^T[r][m] * T_m in registers, and the epilogue writes
+// R pixels per GEMM row.  F(4,3): 6 products per 4 outputs instead of 12 -- half the MFMA work (and MFMA energy) of the direct
+// form; measured error against float64 on post-ReLU data 1.7x the direct x3 product's (8.9e-7 vs 5.4e-7 rms, tools/wino_numerics.py).
+template <int WAVES_M, int WAVES_N, int WM, int WN, bool HL_OUT = false, int NPROD = 3, int WINO = 0>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const ConvX3Params p) {
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
@@ -138,7 +162,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
   constexpr int RPI = HI_ONLY ? 16 : 8;                   // tile rows per DMA instruction (64 lanes x 16 bytes)
   constexpr int NA = BM / (RPI * NW), NB = BN / (RPI * NW);   // DMA instructions per wave per K-step
   constexpr int STAGE = (BM + BN) * ROWB;
-  constexpr int NSTAGE = HI_ONLY ? 4 : 2;
+  constexpr int NSTAGE = HI_ONLY ? 4 : 2;            // (the Winograd instantiations run their own ring: X3_WINO_STAGES)
   extern __shared__ __attribute__((aligned(128))) unsigned char lds[];
 
   int lid = xcd_remap(blockIdx.x, gridDim.x);
@@ -334,7 +358,80 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
   // 410 TFLOP/s; a 3-stage ring with counted vmcnt + raw s_barrier on the 256x128 tile +2.7 %, which does not fit the
   // 160 KiB LDS at 256x256; single-stage 256x128 tiles with 4 waves and two workgroups per CU (occupancy instead of
   // software pipelining) 451 vs 478 TFLOP/s for the 256x256 double-buffered tile.)
-  if constexpr (HI_ONLY) {
+  constexpr int WR = WINO > 0 ? WINO : 1;           // output pixels per GEMM row
+  f32x16 Y[WR][WM][WN];                              // Winograd: the R output accumulators (acc holds the component sum T_m)
+  if constexpr (WINO > 0) {
+#pragma unroll
+    for (int r = 0; r < WR; ++r)
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) Y[r][i][j][e] = 0.f;
+  }
+  if constexpr (WINO > 0) {
+    static_assert(NW == 8 && NPROD == 3 && !HL_OUT, "Winograd instantiations: 8 waves, x3 products, fp32 result");
+    constexpr int NC = WINO + 2;
+    // the skewed 8-wave schedule of the plain kernel; a component's last MFMAs (second half of its final K-step) retire right
+    // after the barrier of the next component's first tile, then T is folded into the outputs and cleared
+    const int KC = (Cb / NC) * nact;                 // K-steps per component (Cb = NC * Cin/32 here)
+    auto combine = [&](int m) {
+      float cf[WR];
+#pragma unroll
+      for (int r = 0; r < WR; ++r) cf[r] = WinoAT<WR>::at[r][m];
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+#pragma unroll
+          for (int r = 0; r < WR; ++r)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) Y[r][i][j][e] = fmaf(cf[r], acc[i][j][e], Y[r][i][j][e]);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        }
+    };
+    // With half the MFMAs per staged byte of the direct form a K-step is too short to cover a DMA round trip (the weight stream
+    // of 6 x Cin lines per output channel comes from beyond L2), so the tiles run through a ring of X3_WINO_STAGES stages: two K-steps
+    // of DMA stay in flight across the barrier, own arrivals counted with s_waitcnt vmcnt (compile-time count: the iterator re-fetches
+    // the final tile once the reduction is exhausted, so every iteration issues the same DMAs).
+    constexpr int NST = X3_WINO_STAGES;
+    constexpr int INFLIGHT = (NA + NB) * (NST - 2);
+    constexpr int WAITIMM = (INFLIGHT & 15) | (7 << 4) | (15 << 8) | ((INFLIGHT >> 4) << 14);   // vmcnt(INFLIGHT), others untouched
+    static_assert(INFLIGHT < 64, "vmcnt is six bits");
+#pragma unroll
+    for (int s_ = 0; s_ < NST - 1; ++s_) issue_next(lds + s_ * STAGE);
+    __builtin_amdgcn_s_waitcnt(WAITIMM);
+    __builtin_amdgcn_s_barrier();
+    read_frags(lds, 0);
+    issue_next(lds + (NST - 1) * STAGE);
+    read_frags(lds, 1);
+    mmas(0);
+    int kc = 1, comp = 0;                            // K-steps of the current component whose first half is issued
+    int st_cur = 1, st_free = 0;                     // ring positions of tile kt and of the stage tile kt-1 has left
+    for (int kt = 1; kt < nk; ++kt) {
+      __builtin_amdgcn_s_waitcnt(WAITIMM);           // own DMAs of tile kt have landed (the younger tiles may still fly)
+      __builtin_amdgcn_s_barrier();                  // ... everyone's have, and everyone holds tile kt-1's fragments in registers
+      const unsigned char* cur = lds + st_cur * STAGE;
+      read_frags(cur, 0);
+      issue_next(lds + st_free * STAGE);
+      st_free = st_cur;
+      st_cur = st_cur + 1 == NST ? 0 : st_cur + 1;
+      mmas(1);              // tile kt-1, second half
+      if (kc == KC) {       // ... which closed component `comp`
+        combine(comp);
+        ++comp;
+        kc = 0;
+      }
+      ++kc;
+      read_frags(cur, 1);
+      mmas(0);
+    }
+    mmas(1);
+    combine(NC - 1);
+    __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));   // vmcnt(0): the re-fetches of the tail are not left in flight
+  } else if constexpr (HI_ONLY) {
     // one product per term: 8 MFMAs per wave per K-step cannot hide a barrier-to-barrier DMA round trip, so the tiles run
     // through a four-deep ring -- three K-steps of DMA in flight, own arrivals counted with s_waitcnt vmcnt (a compile-time
     // count: the iterator re-fetches the final tile once the reduction is exhausted, so every iteration issues the same DMAs)
@@ -435,12 +532,19 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
       const int m = m0 + (wm * WM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
       if (m >= p.M) continue;
       int oy, ox, b;
-      const long pix = p.oy_major ? row_to_pixel(p, m, oy, ox, b) : m;
+      const long pix0 = (p.oy_major || WINO > 0) ? row_to_pixel(p, m, oy, ox, b) : m;
+#pragma unroll
+      for (int wr = 0; wr < WR; ++wr) {
+      long pix = pix0;
+      if constexpr (WINO > 0) {      // GEMM row = group of R output columns: this pass stores column R * group + wr
+        if (ox * WR + wr >= p.wino_W) continue;
+        pix = ((long)b * p.Ho + oy) * p.wino_W + ox * WR + wr;
+      }
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
         const int n = n0 + (wn * WN + j) * 32 + (lane & 31);
         if (n < p.N) {
-          float v = acc[i][j][e] * osc + bn[j];
+          float v = (WINO > 0 ? Y[wr][i][j][e] : acc[i][j][e]) * osc + bn[j];
           if (p.ch_scale) v = v * cs[j] + sh[j];             // eval-mode BatchNorm (running statistics): same expression as bn_apply
           if (rg) v += rg[pix * p.y_ld + n];
           if (HL_OUT && p.res_hl) {
@@ -460,6 +564,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
             *reinterpret_cast<_Float16*>(line + 64) = l;
           }
         }
+      }
       }
     }
   }
@@ -511,6 +616,8 @@ template __global__ void conv_x3_kernel<4, 2, 2, 2, true, 1>(const ConvX3Params)
 template __global__ void conv_x3_kernel<4, 2, 1, 2, true, 1>(const ConvX3Params);
 template __global__ void conv_x3_kernel<8, 1, 1, 2, true, 1>(const ConvX3Params);
 template __global__ void conv_x3_kernel<4, 4, 2, 2, true, 1>(const ConvX3Params);
+template __global__ void conv_x3_kernel<2, 4, 2, 1, false, 3, 4>(const ConvX3Params);     // Winograd F(4,3): 128 groups x 128 channels
+template __global__ void conv_x3_kernel<2, 4, 2, 1, false, 3, 2>(const ConvX3Params);     // Winograd F(2,3)
 
 // ---- producers of the HL32 layout -------------------------------------------------------------------------------
 __device__ __forceinline__ void split_h(float v, _Float16& h, _Float16& l) {
@@ -781,7 +888,7 @@ const EnvFlags& env_flags() {
   return f;
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, bool HL_OUT = false, int NPROD = 3>
+template <int WAVES_M, int WAVES_N, int WM, int WN, bool HL_OUT = false, int NPROD = 3, int WINO = 0>
 int launch_x3(const ConvX3Params& p0, hipStream_t st) {
   constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
   ConvX3Params p = p0;
@@ -789,14 +896,14 @@ int launch_x3(const ConvX3Params& p0, hipStream_t st) {
   p.tilesN = ceil_div(p.N, BN);
   p.tiles_per_row = (p.oy_major && p.BWo % BM == 0 && !env_flags().no_interleave) ? p.BWo / BM : 0;
   p.class_order = (p.tiles_per_row > 0 && p.Ho >= 3 && p.kh == 3 && p.ph == 1 && p.sh == 1 && !env_flags().no_class_order) ? 1 : 0;
-  const size_t ldsz = x3_lds_bytes<WAVES_M, WAVES_N, WM, WN, NPROD>();
+  const size_t ldsz = x3_lds_bytes<WAVES_M, WAVES_N, WM, WN, NPROD, WINO>();
   const long tiles = (long)p.G * p.tilesM * p.tilesN;
   static bool attr_set = false;      // (per instantiation: the attribute is sticky, one driver call instead of one per launch)
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_x3_kernel<WAVES_M, WAVES_N, WM, WN, HL_OUT, NPROD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);
+    (void)hipFuncSetAttribute((const void*)conv_x3_kernel<WAVES_M, WAVES_N, WM, WN, HL_OUT, NPROD, WINO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_x3_kernel<WAVES_M, WAVES_N, WM, WN, HL_OUT, NPROD>), dim3((unsigned)tiles), dim3(WAVES_M * WAVES_N * 64), ldsz, st, p);
+  hipLaunchKernelGGL((conv_x3_kernel<WAVES_M, WAVES_N, WM, WN, HL_OUT, NPROD, WINO>), dim3((unsigned)tiles), dim3(WAVES_M * WAVES_N * 64), ldsz, st, p);
   MRN_LAUNCH_CHECK("conv2d_x3_hl32");
   return MRN_OK;
 }
@@ -1010,4 +1117,113 @@ MRN_EXPORT int mrn_gemm_x3_windows_hl32(const void* a_hl, int64_t a_bytes, int a
   if (tile_m == 256 && tile_n == 64) return launch_x3<8, 1, 1, 2>(p, st);
   if (tile_m == 256) return launch_x3<4, 2, 2, 2>(p, st);
   return launch_x3<4, 2, 1, 2>(p, st);
+}
+
+// ---- Winograd F(R,3) along W: weight transform + the convolution entry point ----------------------------------------------------
+namespace {
+
+// rows of G (F(4,3): interpolation points 0, +-1, +-2, inf; F(2,3): 0, +-1, inf) times the power-of-two row scale whose inverse
+// WinoAT folds into A^T, so that every transformed row sum of |.| stays <= 1.5 and ONE per-tensor prescale serves all components
+__device__ __forceinline__ double wino_g(int R, int m, int kx) {
+  if (R == 2) {
+    const double g[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
+    return g[m][kx];
+  }
+  const double g[6][3] = {{1, 0, 0},
+                          {-1. / 3, -1. / 3, -1. / 3},
+                          {-1. / 3, 1. / 3, -1. / 3},
+                          {1. / 12, 1. / 6, 1. / 3},
+                          {1. / 12, -1. / 6, 1. / 3},
+                          {0, 0, 1}};
+  return g[m][kx];
+}
+
+// w [Cout][3][3][Cin] fp32 (OHWI) -> U [Cout][NC][Cin/32][3 (ky)][hi 32 | lo 32] with U_m = scale * sum_kx G[m][kx] * w[.][ky][kx][.],
+// the sum in double, split to hi + lo from the double; one thread = 8 channels of one (cout, component, ky)
+__global__ __launch_bounds__(256) void pack_weight_wino_hl32_kernel(const float* __restrict__ w, unsigned char* __restrict__ out,
+                                                                    int Cout, int Cin, int R, const float* __restrict__ scale) {
+  const double sc = scale ? (double)scale[0] : 1.0;
+  const int Cb = Cin >> 5, NC = R + 2;
+  const long n8 = (long)Cout * NC * 3 * (Cin >> 3);
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const int c8 = (int)(i % (Cin >> 3));
+    long r = i / (Cin >> 3);
+    const int ky = (int)(r % 3);
+    r /= 3;
+    const int m = (int)(r % NC);
+    const long o_ = r / NC;
+    const float* src = w + ((o_ * 3 + ky) * 3) * Cin + c8 * 8;       // [kx][Cin]
+    f16v8 h, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      double u = 0.0;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) u += wino_g(R, m, kx) * (double)src[kx * Cin + e];
+      u *= sc;
+      const _Float16 hh = (_Float16)u;
+      const _Float16 ll = (_Float16)(u - (double)hh);
+      h[e] = hh; l[e] = ll;
+    }
+    const int cb = c8 >> 2;
+    unsigned char* o = out + (((o_ * NC + m) * Cb + cb) * 3 + ky) * 128 + (c8 & 3) * 16;
+    *reinterpret_cast<f16v8*>(o) = h;
+    *reinterpret_cast<f16v8*>(o + 64) = l;
+  }
+}
+
+}  // namespace
+
+// w [Cout][3][3][Cin] fp32 -> Winograd-domain HL32 weight [Cout][R+2][Cin/32][3][128 B] of scale[0] * (G w) (R = 2 or 4)
+MRN_EXPORT int mrn_pack_weight_wino_hl32(const float* w_ohwi, void* out, int Cout, int Cin, int R, const float* scale, void* stream) {
+  MRN_CHECK_ARG(w_ohwi && out && Cin % 32 == 0 && (R == 2 || R == 4), "mrn_pack_weight_wino_hl32: bad operands (Cin=%d R=%d)", Cin, R);
+  const long n8 = (long)Cout * (R + 2) * 3 * (Cin / 8);
+  if (n8 == 0) return MRN_OK;
+  long grid = (n8 + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(pack_weight_wino_hl32_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, w_ohwi, (unsigned char*)out,
+                     Cout, Cin, R, scale);
+  MRN_LAUNCH_CHECK("pack_weight_wino_hl32");
+  return MRN_OK;
+}
+
+MRN_EXPORT int64_t mrn_conv2d_x3_wino_stats_floats(int G, int B, int H, int W, int Cout, int R) {
+  return (int64_t)G * ceil_div((long)B * H * ceil_div(W, R), 128) * 2 * Cout;
+}
+
+// Grouped 3x3 / stride 1 / pad 1 convolution as 1-D Winograd F(R,3) along W on the x3 kernel (see conv_x3_kernel, WINO):
+//   v_hl  [Gx][B][H][ceil(W/R)][R+2][Cin/32][128 B]   transformed activation (mrn_bn_apply_wino_grouped_f32)
+//   u_hl  [G][Cout][R+2][Cin/32][3][128 B]            transformed weight (mrn_pack_weight_wino_hl32), out_scale [G][2] its {s, 1/s}
+//   y     [G][B][H][W][Cout] fp32 = conv + bias (act 0 / 1), stats [G][mrn_conv2d_x3_wino_stats_floats / G] BatchNorm partials or NULL
+MRN_EXPORT int mrn_conv2d_x3_wino_hl32(const void* v_hl, const void* u_hl, const void* zero_page, const float* bias, float* y,
+                                       float* stats, const float* out_scale, int G, int64_t v_group_stride_bytes, int B, int H, int W,
+                                       int Cin, int Cout, int R, int act, void* stream) {
+  MRN_CHECK_ARG(v_hl && u_hl && zero_page && y && G >= 1 && (R == 2 || R == 4), "mrn_conv2d_x3_wino_hl32: bad operands");
+  MRN_CHECK_ARG(Cin % 32 == 0 && ((uintptr_t)v_hl % 128 == 0) && ((uintptr_t)u_hl % 128 == 0) && v_group_stride_bytes % 128 == 0,
+                "mrn_conv2d_x3_wino_hl32: HL32 operands must be 128-byte aligned, Cin %% 32 == 0 (Cin=%d)", Cin);
+  const int NC = R + 2, Wq = ceil_div(W, R);
+  MRN_CHECK_ARG(H > 0 && W > 0 && B >= 0, "mrn_conv2d_x3_wino_hl32: empty output");
+  MRN_CHECK_ARG((long)B * H * Wq * NC * Cin * 4 < (1L << 31) && (long)Cout * 3 * NC * Cin * 4 < (1L << 31),
+                "mrn_conv2d_x3_wino_hl32: one group's activation / weight must stay below 2 GiB (32-bit buffer offsets)");
+  ConvX3Params p;
+  memset(&p, 0, sizeof(p));
+  p.x = (const unsigned char*)v_hl; p.w = (const unsigned char*)u_hl; p.zero = (const unsigned char*)zero_page;
+  p.bias = bias; p.out_scale = out_scale; p.y = y; p.stats = stats;
+  p.Cb = NC * (Cin / 32); p.taps = 3; p.nk = p.Cb * 3;
+  p.x_gstride = v_group_stride_bytes; p.w_gstride = (long)Cout * p.nk * 128;
+  p.x_group_div = 1;
+  p.x_bytes = (int)((long)B * H * Wq * NC * Cin * 4);
+  p.G = G; p.M = B * H * Wq; p.N = Cout;
+  p.y_ld = Cout;
+  p.y_gstride = (long)B * H * W * Cout;
+  p.H = H; p.W = Wq; p.Ho = H; p.Wo = Wq; p.kh = 3; p.kw = 1; p.sh = 1; p.sw = 1; p.ph = 1; p.pw = 0; p.act = act;
+  p.wino_W = W;
+  if (p.M == 0) return MRN_OK;
+  p.oy_major = (H <= 8) ? 1 : 0;
+  if (env_flags().row_major) p.oy_major = 0;
+  p.BWo = B * Wq;
+  magic_div((unsigned)Wq, p.wo_magic, p.wo_shift);
+  magic_div((unsigned)p.BWo, p.bw_magic, p.bw_shift);
+  magic_div(1u, p.kw_magic, p.kw_shift);
+  if (R == 4) return launch_x3<2, 4, 2, 1, false, 3, 4>(p, (hipStream_t)stream);
+  return launch_x3<2, 4, 2, 1, false, 3, 2>(p, (hipStream_t)stream);
 }

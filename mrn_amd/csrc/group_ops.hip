@@ -136,6 +136,100 @@ __global__ __launch_bounds__(256) void bn_apply_grouped_kernel(const float* __re
   }
 }
 
+// The same pass as the producer of a Winograd F(R,3) convolution (conv_x3.hip, WINO): one lane = 8 channels of one GROUP of R
+// output columns of one image row.  It evaluates out = act(y * scale + shift (+ res)) on the group's R + 2 input columns
+// R*q - 1 .. R*q + R (zero outside the row: the convolution's padding), applies the input transform B^T in fp32 and writes the
+// R + 2 components as HL32 lines [image row][group][component][C/32][128 B]; the plain fp32 / HL32 results of the group's own R
+// columns are written too when asked for (identity-shortcut source of the next block).  Neighbouring groups re-read two
+// columns each (cache hits: they are processed by neighbouring waves).
+template <int R>
+__global__ __launch_bounds__(256) void bn_apply_wino_grouped_kernel(const float* __restrict__ y, const float* __restrict__ res,
+                                                                    const unsigned char* __restrict__ res_hl,
+                                                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                    float* __restrict__ out, unsigned char* __restrict__ out_hl,
+                                                                    unsigned char* __restrict__ out_v, long imgrows_per_group, int W,
+                                                                    int Wq, long n8, int C, int relu) {
+  constexpr int NC = R + 2;
+  const int C8 = C >> 3, Cb = C >> 5;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const int c8 = (int)(i % C8);
+    const long t = i / C8;                       // (image row, group)
+    const int q = (int)(t % Wq);
+    const long irow = t / Wq;                    // image row index over [G][B][H]
+    const int g = (int)(irow / imgrows_per_group);
+    F8 sc, sh;
+    if (scale) {
+      sc = load8(scale + (long)g * C + c8 * 8);
+      sh = load8(shift + (long)g * C + c8 * 8);
+    }
+    F8 d[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      const int x = R * q - 1 + j;
+      if ((unsigned)x < (unsigned)W) {
+        const long row = irow * W + x;
+        F8 v = load8(y + (row * C8 + c8) * 8);
+        if (scale) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v.a[e] = v.a[e] * sc.a[e] + sh.a[e];
+            v.b[e] = v.b[e] * sc.b[e] + sh.b[e];
+          }
+        }
+        if (res || res_hl) {
+          const F8 r = res ? load8(res + (row * C8 + c8) * 8) : load_hl(res_hl, row, C, c8);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v.a[e] += r.a[e];
+            v.b[e] += r.b[e];
+          }
+        }
+        if (relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v.a[e] = fmaxf(v.a[e], 0.f);
+            v.b[e] = fmaxf(v.b[e], 0.f);
+          }
+        }
+        if (j >= 1 && j <= R) {                  // the group's own columns
+          if (out) store8(out + (row * C8 + c8) * 8, v);
+          if (out_hl) store_hl(out_hl, row, C, c8, v);
+        }
+        d[j] = v;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[j].a[e] = d[j].b[e] = 0.f;
+      }
+    }
+    F8 m[NC];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      auto D = [&](int j) { return e < 4 ? d[j].a[e] : d[j].b[e - 4]; };
+      float r_[NC];
+      if constexpr (R == 2) {
+        r_[0] = D(0) - D(2);
+        r_[1] = D(1) + D(2);
+        r_[2] = D(2) - D(1);
+        r_[3] = D(1) - D(3);
+      } else {
+        r_[0] = 4.f * D(0) - 5.f * D(2) + D(4);
+        r_[1] = -4.f * (D(1) + D(2)) + D(3) + D(4);
+        r_[2] = 4.f * (D(1) - D(2)) - D(3) + D(4);
+        r_[3] = 2.f * (D(3) - D(1)) - D(2) + D(4);
+        r_[4] = 2.f * (D(1) - D(3)) - D(2) + D(4);
+        r_[5] = 4.f * D(1) - 5.f * D(3) + D(5);
+      }
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        if (e < 4) m[k].a[e] = r_[k];
+        else m[k].b[e - 4] = r_[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NC; ++k) store_hl(out_v, t * NC + k, C, c8, m[k]);
+  }
+}
+
 // NHWC max pooling over [G*B] images with the (scale, shift, relu) of group b / B fused on the input; padding = -inf
 __global__ __launch_bounds__(256) void maxpool_grouped_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, float* __restrict__ out,
@@ -310,6 +404,33 @@ MRN_EXPORT int mrn_bn_apply_grouped_f32(const float* y, const float* residual, c
                      (const unsigned char*)residual_hl32, scale, shift,
                      out_f32, (unsigned char*)out_hl32, (long)rows_per_group, n8, C, relu);
   MRN_LAUNCH_CHECK("bn_apply_grouped");
+  return MRN_OK;
+}
+
+// mrn_bn_apply_grouped_f32 as the producer of a Winograd F(R,3) convolution (mrn_conv2d_x3_wino_hl32): y [G][B][H][W][C];
+// out_wino [G][B][H][ceil(W/R)][R+2][C/32][128 B] receives B^T applied to out = act(y * scale + shift (+ residual)) per group of R
+// columns (zero padding outside the row); out_f32 (must NOT alias y: neighbouring groups re-read y) / out_hl32 optionally
+// receive the plain result.
+MRN_EXPORT int mrn_bn_apply_wino_grouped_f32(const float* y, const float* residual, const void* residual_hl32, const float* scale,
+                                             const float* shift, float* out_f32, void* out_hl32, void* out_wino, int G, int B, int H,
+                                             int W, int C, int R, int relu, void* stream) {
+  MRN_CHECK_ARG(y && out_wino && C % 32 == 0 && (!scale == !shift) && !(residual && residual_hl32) && (R == 2 || R == 4) &&
+                    out_f32 != y && (uintptr_t)out_wino % 128 == 0,
+                "mrn_bn_apply_wino_grouped_f32: bad operands (C=%d R=%d)", C, R);
+  const int Wq = (W + R - 1) / R;
+  const long n8 = (long)G * B * H * Wq * (C / 8);
+  if (n8 == 0) return MRN_OK;
+  long grid = (n8 + 255) / 256;
+  if (grid > 32768) grid = 32768;
+  if (R == 4)
+    hipLaunchKernelGGL(bn_apply_wino_grouped_kernel<4>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, y, residual,
+                       (const unsigned char*)residual_hl32, scale, shift, out_f32, (unsigned char*)out_hl32, (unsigned char*)out_wino,
+                       (long)B * H, W, Wq, n8, C, relu);
+  else
+    hipLaunchKernelGGL(bn_apply_wino_grouped_kernel<2>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, y, residual,
+                       (const unsigned char*)residual_hl32, scale, shift, out_f32, (unsigned char*)out_hl32, (unsigned char*)out_wino,
+                       (long)B * H, W, Wq, n8, C, relu);
+  MRN_LAUNCH_CHECK("bn_apply_wino_grouped");
   return MRN_OK;
 }
 

@@ -29,11 +29,13 @@ RESIDUAL_FROM_F32 = bool(int(os.environ.get("MRN_RESIDUAL_F32", "0")))      # Tr
 class Act:
     """A [G,B,H,W,C] activation stack: fp32 tensor and / or HL32 bytes.  shared=True: one [B,H,W,C] input for all groups."""
 
-    def __init__(self, shape, f32=None, hl=None, shared=False):
+    def __init__(self, shape, f32=None, hl=None, shared=False, wino=None, wino_R=0):
         self.shape = tuple(shape)          # (G, B, H, W, C)
         self.f32 = f32
         self.hl = hl
         self.shared = shared
+        self.wino = wino                   # Winograd-domain operand bytes [G][B][H][ceil(W/R)][R+2][C/32][128] (ops.bn_apply_wino_grouped)
+        self.wino_R = wino_R
 
 
 def _bn_modules(extractor):
@@ -111,6 +113,23 @@ class BackboneGroup(_GroupedLinear):
             self._wcache[id(convs[0])] = got
         return got[1]
 
+    def _weights_wino(self, convs, R):
+        key = tuple((c.weight.data_ptr(), c.weight._version) for c in convs) + (R,)
+        got = self._wcache.get(("wino", id(convs[0])))
+        if got is None or got[0] != key:
+            got = (key, ops.pack_weights_wino([packed_weight(c).ohwi for c in convs], R))
+            self._wcache[("wino", id(convs[0]))] = got
+        return got[1]
+
+    @staticmethod
+    def wino_for(conv, bns):
+        """R of the Winograd form this conv would run in when its input arrives as a Winograd-domain operand, else 0: 3x3 / stride 1
+        / pad 1, wide enough, and followed by a train-mode BatchNorm (the eval-mode fold keeps its one-launch direct form)"""
+        if bns is None or not bns[0].training:
+            return 0
+        ok = ops.wino_eligible(_pair(conv.kernel_size), _pair(conv.stride), _pair(conv.padding), conv.in_channels, conv.out_channels)
+        return ops.WINO_R if ok else 0
+
     def _bn_table(self, bns):
         key = tuple(t.data_ptr() for b in bns for t in (b.weight, b.bias, b.running_mean, b.running_var))
         got = self._bncache.get(id(bns[0]))
@@ -127,7 +146,9 @@ class BackboneGroup(_GroupedLinear):
         return torch.stack([c.bias.detach() for c in convs]).contiguous()
 
     # ---- one conv (+BN) (+residual) (+ReLU) (+pool) layer for all groups ----------------------------------------------
-    def layer(self, x, convs, bns=None, relu=True, residual=None, pool=None, want_f32=False, want_hl=True):
+    def layer(self, x, convs, bns=None, relu=True, residual=None, pool=None, want_f32=False, want_hl=True, want_wino=0):
+        """want_wino = R: the result also as the Winograd-domain operand of a following 3x3 conv (only from the BatchNorm-apply
+        pass, i.e. with bns and no pool); a layer whose INPUT carries x.wino and qualifies (wino_for) runs as F(R,3)"""
         G = self.G
         _, B, H, W, Cin = x.shape
         c0 = convs[0]
@@ -170,7 +191,11 @@ class BackboneGroup(_GroupedLinear):
                 return Act((G, B, Ho, Wo, Cout), got[0], got[1])
             return Act((G, B, Ho, Wo, Cout), None, got) if want_hl else Act((G, B, Ho, Wo, Cout), got, None)
         y = torch.empty(G, B, Ho, Wo, Cout, device=dev, dtype=torch.float32)
-        if Cin % 32 == 0 and Cout >= 64:
+        if x.wino is not None and x.wino_R == self.wino_for(c0, bns):
+            u_hl, u_scale = self._weights_wino(convs, x.wino_R)
+            _, stats = ops.conv2d_x3_wino(x.wino, G, x.shared, B, H, W, Cin, u_hl, u_scale, Cout, x.wino_R,
+                                          bias=self._bias_stack(convs), act=act, want_stats=training, out=y)
+        elif Cin % 32 == 0 and Cout >= 64:
             if x.hl is None:
                 assert x.f32 is not None
                 x.hl = ops.split_hl32(x.f32)
@@ -207,23 +232,30 @@ class BackboneGroup(_GroupedLinear):
             f32, hl, (Hp, Wp) = ops.maxpool_grouped(y, pool[0], pool[1], pool[2], scale, shift, relu=post_relu,
                                                     want_f32=want_f32, want_hl=want_hl)
             return Act((G, B, Hp, Wp, Cout), f32, hl)
-        if scale is None and res is None and res_hl is None and not post_relu and not want_hl:
+        if scale is None and res is None and res_hl is None and not post_relu and not want_hl and not want_wino:
             return Act((G, B, Ho, Wo, Cout), y, None)
+        if want_wino:
+            f32, hl, v = ops.bn_apply_wino_grouped(y, scale, shift, want_wino, relu=post_relu, residual=res, residual_hl=res_hl,
+                                                   want_f32=want_f32, want_hl=want_hl)
+            return Act((G, B, Ho, Wo, Cout), f32, hl, wino=v, wino_R=want_wino)
         f32, hl = ops.bn_apply_grouped(y, scale, shift, relu=post_relu, residual=res, want_f32=want_f32, want_hl=want_hl,
                                        residual_hl=res_hl)
         return Act((G, B, Ho, Wo, Cout), f32, hl)
 
     # ---- network programs ---------------------------------------------------------------------------------------
-    def _basic_block(self, x, blocks, next_needs_f32):
-        out = self.layer(x, [b.conv1 for b in blocks], [b.bn1 for b in blocks])
-        if blocks[0].downsample is not None:
+    def _basic_block(self, x, blocks, next_needs_f32, out_wino=0, out_hl=True):
+        """out_wino / out_hl: what the consumer of the block's result reads (a Winograd-form conv / the plain HL32 operand)"""
+        b0 = blocks[0]
+        w2 = self.wino_for(b0.conv2, [b.bn2 for b in blocks])
+        out = self.layer(x, [b.conv1 for b in blocks], [b.bn1 for b in blocks], want_wino=w2, want_hl=not w2)
+        if b0.downsample is not None:
             res = self.layer(x, [b.downsample[0] for b in blocks], [b.downsample[1] for b in blocks], relu=False,
                              want_f32=True, want_hl=False)
         else:
             res = x
             assert res.f32 is not None or res.hl is not None
         return self.layer(out, [b.conv2 for b in blocks], [b.bn2 for b in blocks], relu=True, residual=res,
-                          want_f32=next_needs_f32, want_hl=True)
+                          want_f32=next_needs_f32, want_hl=out_hl, want_wino=out_wino)
 
     def _batched_linear_f32(self, name, x, layers, act=ops.ACT_NONE):
         """x [G,R,K] fp32 -> [G,R,N]: y[g] = act(x[g] @ W_g^T + b_g) on the exact-fp32 GEMM, batch = expert"""
@@ -241,26 +273,39 @@ class BackboneGroup(_GroupedLinear):
         n0 = nets[0]
         p22, p2_21 = ((2, 2), (2, 2), (0, 0)), ((2, 2), (2, 1), (0, 1))
 
-        def stage(x, name):
+        def stage(x, name, after, after_bn):
+            """`after`: the conv that follows the stage (its Winograd eligibility decides what the last block emits)"""
             blocks = [list(getattr(n, name)) for n in nets]
             nb = len(blocks[0])
             for i in range(nb):
                 # identity shortcuts read the block input back from its HL32 image: no fp32 copy is ever written
-                x = self._basic_block(x, [b[i] for b in blocks], RESIDUAL_FROM_F32 and i + 1 < nb and blocks[0][i + 1].downsample is None)
+                if i + 1 < nb:      # the next block reads the plain operand (shortcut / 1x1 downsample) and, if it qualifies, the Winograd one
+                    nxt = [b[i + 1] for b in blocks]
+                    ow, oh = self.wino_for(nxt[0].conv1, [b.bn1 for b in nxt]), True
+                else:
+                    ow = self.wino_for(getattr(n0, after), [getattr(n, after_bn) for n in nets])
+                    oh = not ow
+                x = self._basic_block(x, [b[i] for b in blocks], RESIDUAL_FROM_F32 and i + 1 < nb and blocks[0][i + 1].downsample is None,
+                                      out_wino=ow, out_hl=oh)
             return x
+
+        def first_wino(name):
+            blk = [getattr(n, name)[0] for n in nets]
+            return self.wino_for(blk[0].conv1, [b.bn1 for b in blk])
 
         def first_block_identity(name):
             return RESIDUAL_FROM_F32 and getattr(n0, name)[0].downsample is None
 
         x = self.layer(x, [n.conv0_1 for n in nets], [n.bn0_1 for n in nets])
         x = self.layer(x, [n.conv0_2 for n in nets], [n.bn0_2 for n in nets], pool=p22, want_f32=first_block_identity("layer1"))
-        x = stage(x, "layer1")
+        x = stage(x, "layer1", "conv1", "bn1")
         x = self.layer(x, [n.conv1 for n in nets], [n.bn1 for n in nets], pool=p22, want_f32=first_block_identity("layer2"))
-        x = stage(x, "layer2")
+        x = stage(x, "layer2", "conv2", "bn2")
         x = self.layer(x, [n.conv2 for n in nets], [n.bn2 for n in nets], pool=p2_21, want_f32=first_block_identity("layer3"))
-        x = stage(x, "layer3")
-        x = self.layer(x, [n.conv3 for n in nets], [n.bn3 for n in nets], want_f32=first_block_identity("layer4"))
-        x = stage(x, "layer4")
+        x = stage(x, "layer3", "conv3", "bn3")
+        x = self.layer(x, [n.conv3 for n in nets], [n.bn3 for n in nets], want_f32=first_block_identity("layer4"),
+                       want_wino=first_wino("layer4"))
+        x = stage(x, "layer4", "conv4_1", "bn4_1")
         x = self.layer(x, [n.conv4_1 for n in nets], [n.bn4_1 for n in nets])
         return self.layer(x, [n.conv4_2 for n in nets], [n.bn4_2 for n in nets], want_f32=not last_hl, want_hl=last_hl)
 

@@ -541,6 +541,78 @@ def conv2d_x3(x_hl, G, shared_input, B, H, W, Cin, w_hl, w_scale, Cout, ksize, s
     return (y_hl if hl_only else ((y, y_hl) if also_hl else y)), stats
 
 
+# 1-D Winograd F(R,3) along W for the frozen experts' 3x3 / stride 1 / pad 1 convolutions with Cin >= WINO_MIN_CIN whose input
+# comes from a train-mode BatchNorm-apply pass (csrc/conv_x3.hip WINO, csrc/group_ops.hip): R = 4 halves the matrix work of
+# the dominant 512 -> 512 layers.  MRN_WINO=0 switches it off (A/B), MRN_WINO=2 selects F(2,3).
+WINO_R = int(os.environ.get("MRN_WINO", "4"))
+WINO_MIN_CIN = int(os.environ.get("MRN_WINO_MIN_CIN", "256"))
+
+
+def wino_eligible(ksize, stride, padding, Cin, Cout):
+    return (WINO_R in (2, 4) and tuple(ksize) == (3, 3) and tuple(stride) == (1, 1) and tuple(padding) == (1, 1)
+            and Cin % 32 == 0 and Cin >= WINO_MIN_CIN and Cout >= 64 and X3_PRODUCTS == 3)
+
+
+def pack_weights_wino(ws, R, scale=None):
+    """list of G [O,3,3,I] fp32 weights -> (Winograd-domain HL32 stack bytes [G][O][R+2][I/32][3][128], scale [G,2])"""
+    O, kh, kw, I = ws[0].shape
+    assert (kh, kw) == (3, 3)
+    G = len(ws)
+    dev = ws[0].device
+    per = O * (R + 2) * 3 * I * 4
+    out = torch.empty(G * per, device=dev, dtype=torch.uint8)
+    known = scale is not None
+    if not known:
+        scale = torch.empty(G, 2, device=dev, dtype=torch.float32)
+    for g, w in enumerate(ws):
+        _chk(w)
+        assert tuple(w.shape) == (O, 3, 3, I) and w.is_contiguous()
+        if not known:
+            call("mrn_pow2_scale_f32", _p(w), w.numel(), FP16_WEIGHT_PEAK, scale[g].data_ptr(), _pow2_ws(), _stream())
+        call("mrn_pack_weight_wino_hl32", _p(w), out.data_ptr() + g * per, O, I, R, scale[g].data_ptr(), _stream())
+    return out, scale
+
+
+def bn_apply_wino_grouped(y, scale, shift, R, relu=True, residual=None, residual_hl=None, want_f32=False, want_hl=False):
+    """y [G,B,H,W,C] fp32 -> (fp32 result (a NEW tensor) or None, HL32 bytes or None, Winograd-domain operand bytes
+    [G][B][H][ceil(W/R)][R+2][C/32][128])"""
+    G, B, H, W, C = y.shape
+    Wq = (W + R - 1) // R
+    out = torch.empty_like(y) if want_f32 else None
+    out_hl = torch.empty(y.numel() * 4, device=y.device, dtype=torch.uint8) if want_hl else None
+    v = torch.empty(G * B * H * Wq * (R + 2) * C * 4, device=y.device, dtype=torch.uint8)
+    t0 = CONV_TIMER.begin() if CONV_TIMER is not None else None
+    call("mrn_bn_apply_wino_grouped_f32", _p(y), _p(residual), _p(residual_hl), _p(scale), _p(shift), _p(out), _p(out_hl), _p(v),
+         G, B, H, W, C, R, int(bool(relu)), _stream())
+    if t0 is not None:       # algorithmic bytes: every input / output element once; the transformed operand is (R+2)/R elements per element
+        n_io = 1 + int(residual is not None or residual_hl is not None) + int(want_f32) + int(want_hl)
+        CONV_TIMER.end(t0, 0.0, "hbm/bn_apply_wino_grouped", 4.0 * y.numel() * n_io + 4.0 * G * B * H * Wq * (R + 2) * C)
+    return out, out_hl, v
+
+
+def conv2d_x3_wino(v_hl, G, shared_input, B, H, W, Cin, u_hl, u_scale, Cout, R, bias=None, act=ACT_NONE, want_stats=False, out=None):
+    """3x3 / stride 1 / pad 1 grouped conv on Winograd-domain operands -> (y [G,B,H,W,Cout] fp32, stats or None)"""
+    dev = v_hl.device
+    y = out if out is not None else torch.empty(G, B, H, W, Cout, device=dev, dtype=torch.float32)
+    stats = None
+    if want_stats:
+        stats = torch.empty(call("mrn_conv2d_x3_wino_stats_floats", G, B, H, W, Cout, R), device=dev, dtype=torch.float32)
+    Wq = (W + R - 1) // R
+    gstride = 0 if shared_input else B * H * Wq * (R + 2) * Cin * 4
+    timed = CONV_TIMER is not None
+    t0 = CONV_TIMER.begin() if timed else None
+    call("mrn_conv2d_x3_wino_hl32", _p(v_hl), _p(u_hl), _p(_zero_page(dev)), _p(bias), _p(y), _p(stats), _p(u_scale), G, gstride,
+         B, H, W, Cin, Cout, R, act, _stream())
+    if timed:
+        # algorithmic flops = the convolution's (2 * 9 * Cin per output element); the kernel executes (R+2)/(3R) of them as MFMA products
+        nbytes = 4.0 * ((1 if shared_input else G) * B * H * Wq * (R + 2) * Cin + G * Cout * 3 * (R + 2) * Cin + G * B * H * W * Cout)
+        kind = "fp16x3/wino%dg128x128" % R
+        if TIMER_SHAPES:
+            kind += "|G%d B%d %dx%d %d->%d k3x3 s11" % (G, B, H, W, Cin, Cout)
+        CONV_TIMER.end(t0, 2.0 * G * B * H * W * Cout * 9 * Cin, kind, nbytes)
+    return y, stats
+
+
 def conv2d_x3_scaled(x, w_ohwi, bias, stride, padding, act=ACT_NONE, want_stats=False, sx=None):
     """one convolution on the grouped x3 kernel with per-call operand scaling: x fp32 [B,H,W,Cin] (Cin % 32 == 0),
     w_ohwi fp32 [O,kh,kw,I] -> (y [B,Ho,Wo,O], stats or None)"""

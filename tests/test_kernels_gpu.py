@@ -842,3 +842,74 @@ def test_wgrad_without_im2col_matches_exact_fp32(B, H, W, Cin, Cout):
     assert (dw.cpu().double() - ref).abs().max().item() <= 2e-6 * scale
     assert (dw - old).abs().max().item() <= 2e-6 * scale
     assert not ops.wgrad_windows_supported(dyd[:, :1], xd[:, :1], (3, 3), (1, 1), (1, 1))        # one-row maps: the im2col path
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Winograd F(R,3) form of the frozen experts' 3x3 convolutions (conv_x3.hip WINO, group_ops.hip producer)
+# ---------------------------------------------------------------------------------------------------------
+WINO_CONVS = [
+    # G, B, H, W, Cin, Cout, shortcut ("none" | "f32" | "hl32"), relu
+    (2, 3, 4, 65, 64, 128, "hl32", True),        # W not a multiple of R: the last group is partly outside the row
+    (3, 2, 8, 64, 32, 96, "none", True),         # whole groups; Cout not a tile multiple; taller map
+    (1, 5, 1, 9, 64, 64, "f32", False),          # one image row: both kernel-row neighbours in the padding; signed inputs
+    (2, 32, 4, 65, 64, 160, "hl32", True),       # several row tiles, tiles straddle image rows
+    (6, 2, 4, 65, 512, 512, "none", True),       # the dominant TRBA shape
+    (2, 64, 4, 64, 32, 128, "none", True),       # B * ceil(W/R) a multiple of the tile height: class-ordered tile schedule
+    (3, 16, 3, 32, 64, 128, "hl32", True),       #   (R = 4: 16 * 8 = 128) one interior row
+]
+
+
+@pytest.mark.parametrize("R", [4, 2])
+@pytest.mark.parametrize("cfg", WINO_CONVS)
+def test_winograd_conv_matches_direct(ops, cfg, R):
+    """mrn_bn_apply_wino_grouped_f32 -> mrn_conv2d_x3_wino_hl32 (+ mrn_pack_weight_wino_hl32) against torch:
+    relu(y * scale + shift (+ shortcut)) -> conv2d(3x3, pad 1) + bias per group, the fused BatchNorm partial statistics, and
+    the plain fp32 / HL32 by-products of the producer pass"""
+    G, B, H, W, Cin, Cout, shortcut, relu = cfg
+    yprev = rnd(G, B, H, W, Cin, seed=300)
+    scale, shift = rnd(G, Cin, seed=301) + 1.5, rnd(G, Cin, seed=302) * 0.5
+    res = rnd(G, B, H, W, Cin, seed=303) if shortcut != "none" else None
+    ws = [rnd(Cout, Cin, 3, 3, seed=310 + g, scale=(2.0 / (Cin * 9)) ** 0.5) for g in range(G)]
+    bias = rnd(G, Cout, seed=320)
+    a = yprev.double() * scale.double()[:, None, None, None, :] + shift.double()[:, None, None, None, :]
+    if res is not None:
+        a = a + res.double()
+    if relu:
+        a = a.clamp_min(0)
+    refs = [F.conv2d(a[g].permute(0, 3, 1, 2), ws[g].double(), bias[g].double(), 1, 1) for g in range(G)]
+    resd = cu(res) if res is not None else None
+    f32, hl, v = ops.bn_apply_wino_grouped(cu(yprev), cu(scale), cu(shift), R, relu=relu,
+                                           residual=resd if shortcut == "f32" else None,
+                                           residual_hl=ops.split_hl32(resd) if shortcut == "hl32" else None, want_f32=True, want_hl=True)
+    tol = 4e-6 if shortcut == "hl32" else 1e-6       # an HL32 shortcut carries 22 bits
+    assert_close("producer fp32 result", f32, a.float(), atol=tol, rtol=tol)
+    hv = hl.view(torch.float16).view(-1, Cin // 32, 2, 32).float()
+    assert_close("producer HL32 result", (hv[:, :, 0] + hv[:, :, 1]).reshape(f32.shape), f32, atol=1e-6, rtol=2e-7)
+    u_hl, u_scale = ops.pack_weights_wino([cu(w.permute(0, 2, 3, 1).contiguous()) for w in ws], R)
+    y, stats = ops.conv2d_x3_wino(v, G, False, B, H, W, Cin, u_hl, u_scale, Cout, R, bias=cu(bias), want_stats=True)
+    for g in range(G):
+        assert_close(f"winograd F({R},3) conv g{g}", y[g].permute(0, 3, 1, 2), refs[g].float(), atol=3e-5, rtol=1e-5)
+    tot = stats.view(G, -1, 2, Cout).sum(1)
+    assert_close("fused column sums", tot[:, 0], y.double().sum((1, 2, 3)).float(), atol=1e-3, rtol=2e-5)
+    assert_close("fused column sums of squares", tot[:, 1], (y.double() ** 2).sum((1, 2, 3)).float(), atol=1e-3, rtol=2e-5)
+    # ReLU in the epilogue, no statistics
+    y1, _ = ops.conv2d_x3_wino(v, G, False, B, H, W, Cin, u_hl, u_scale, Cout, R, bias=cu(bias), act=1)
+    assert torch.equal(y1, y.clamp_min(0))
+
+
+def test_winograd_full_size_dominant_shape_properties(ops):
+    """BASELINE-size check of the Winograd form of the dominant layer (6 experts x 256 images, 4x65 maps, 512 -> 512) against the
+    direct split-fp16 x3 kernel on the same post-ReLU activations, and of the fused statistics"""
+    G, B, H, W, C, R = 6, 256, 4, 65, 512, 4
+    torch.manual_seed(5)
+    ypre = torch.randn(G, B, H, W, C, device="cuda")
+    ws = [(torch.rand(C, 3, 3, C, device="cuda") * 2 - 1) * 0.02 for _ in range(G)]
+    _, hl, v = ops.bn_apply_wino_grouped(ypre, None, None, R, relu=True, want_hl=True)
+    w_hl, w_scale = ops.pack_weights_hl32(ws)
+    yd, _ = ops.conv2d_x3(hl, G, False, B, H, W, C, w_hl, w_scale, C, (3, 3), (1, 1), (1, 1))
+    u_hl, u_scale = ops.pack_weights_wino(ws, R)
+    yw, stats = ops.conv2d_x3_wino(v, G, False, B, H, W, C, u_hl, u_scale, C, R, want_stats=True)
+    assert_close("full-size winograd vs direct x3", yw, yd, atol=2e-5, rtol=1e-5)
+    tot = stats.view(G, -1, 2, C).sum(1)
+    assert_close("fused column sums", tot[:, 0], yw.sum((1, 2, 3)), atol=2e-2, rtol=2e-5)
+    assert_close("fused column sums of squares", tot[:, 1], (yw * yw).sum((1, 2, 3)), atol=2e-2, rtol=2e-5)
