@@ -31,7 +31,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0                         # MI355X_MICROARCH.md: de
 HBM_PEAK_GBS = 8000.0                                  # MI355X_MICROARCH.md: HBM3E peak (6.3 TB/s achievable on a float4 copy)
 
 
-PMC_SOURCE = ("static: profiles/r02_pmc.json -- separate rocprofv3 --pmc passes of this same command (tools/pmc_pass.sh), "
+PMC_SOURCE = ("static: profiles/r03_pmc.json -- separate rocprofv3 --pmc passes of this same command (tools/pmc_pass.sh), "
               "FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE; counters cannot be read from inside the timed run")
 
 
@@ -39,10 +39,11 @@ def pmc_traffic(kernel_name):
     """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes (profiles/r01_pmc.json, produced by
     tools/pmc_pass.sh on this same command): FETCH_SIZE x 2 (the gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE,
     both KiB counters.  None when the kernel has no entry (counters cannot be read from inside the timed run)."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc.json")
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "r01_pmc.json")
-    if not os.path.exists(path):
+    for name in ("r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            break
+    else:
         return None
     with open(path) as f:
         pmc = json.load(f)
@@ -150,6 +151,113 @@ def cpu_baseline(learner, opt, n_experts, batch=32, iters=3, max_threads=32, bud
             "sample": f"{len(times)} timed iteration(s) (+1 warm-up) of the same loop B at batch {batch}, fp32, torch-CPU oracle"}
 
 
+def power_probe(ops, R, launches=3):
+    """The dominant layer shape (6 experts x 256 crops, 4x65 maps, 512 -> 512 3x3) alone, `launches` launches each on random
+    operands, on zero activations and on zero activations AND weights: identical instruction stream, geometry and memory traffic,
+    so the differences are what the chip's power management does with the clock (MI355X_MICROARCH.md, DVFS give-back).
+    R > 0: the Winograd F(R,3) form the step runs; 0: the direct split-fp16 x3 kernel."""
+    G, B, H, W, C = 6, 256, 4, 65, 512
+    dev = torch.device("cuda", torch.cuda.current_device())
+    gen = torch.Generator(device=dev).manual_seed(7)
+    ypre = torch.randn(G, B, H, W, C, device=dev, generator=gen)
+    ws = [(torch.rand(C, 3, 3, C, device=dev, generator=gen) * 2 - 1) * 0.02 for _ in range(G)]
+    out = {}
+    for name, za, zw in (("random_ms", False, False), ("zero_act_ms", True, False), ("zero_all_ms", True, True)):
+        y_ = torch.zeros_like(ypre) if za else ypre
+        ws_ = [torch.zeros_like(w) for w in ws] if zw else ws
+        if R:
+            u_hl, u_scale = ops.pack_weights_wino(ws_, R)
+            _, _, v = ops.bn_apply_wino_grouped(y_, None, None, R, relu=True)
+            fn = lambda: ops.conv2d_x3_wino(v, G, False, B, H, W, C, u_hl, u_scale, C, R, want_stats=True)      # noqa: E731
+        else:
+            w_hl, w_scale = ops.pack_weights_hl32(ws_)
+            _, hl = ops.bn_apply_grouped(y_.clone(), None, None, relu=True, want_f32=False, want_hl=True)
+            fn = lambda: ops.conv2d_x3(hl, G, False, B, H, W, C, w_hl, w_scale, C, (3, 3), (1, 1), (1, 1), want_stats=True)   # noqa: E731
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(launches):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        out[name] = e0.elapsed_time(e1) / launches
+        del fn
+    gflop = 2.0 * G * B * H * W * C * 9 * C / 1e9
+    out.update({"shape": "G6 B256 4x65 512->512 3x3 (%s)" % ("Winograd F(%d,3)" % R if R else "direct"), "launches_each": launches,
+                "algorithmic_gflop_per_launch": gflop, "random_tflops": gflop / out["random_ms"], "zero_all_tflops": gflop / out["zero_all_ms"],
+                "measured": "live, after the timed region: HIP events around back-to-back launches of the same kernel on one stream"})
+    return out
+
+
+def comm_telemetry(reducer, world, dev, step_ms):
+    """N > 1: what the gradient exchange looked like -- did RCCL see `world` ranks, how many bytes per step, what the exchange costs
+    standalone, and how much of it the compute stream actually waited for (events around BucketedAllReduce.finish())"""
+    import torch.distributed as dist
+    ids = [torch.zeros(1, device=dev, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(ids, torch.tensor([dist.get_rank()], device=dev, dtype=torch.int64))
+    out = {"backend": dist.get_backend(), "ranks_seen": sorted(int(t.item()) for t in ids)}
+    try:
+        out["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as e:          # (gloo-only builds)
+        out["rccl_version"] = f"unavailable ({type(e).__name__})"
+    if reducer is not None:
+        out["allreduce_bytes_per_step"] = reducer.bytes_per_step()
+        out["buckets"] = len(reducer.buckets)
+        exposed = [a.elapsed_time(b) for a, b in reducer.exposed]
+        out["allreduce_ms_per_step"] = reducer.standalone_ms()
+        if exposed:
+            out["exposed_ms_per_step"] = sum(exposed) / len(exposed)
+            out["overlap_frac"] = max(0.0, 1.0 - out["exposed_ms_per_step"] / max(out["allreduce_ms_per_step"], 1e-9))
+        out["measured"] = ("allreduce_ms_per_step: the step's buckets all-reduced back to back on an otherwise idle GPU (HIP events); "
+                           "exposed_ms_per_step: HIP events on the compute stream around the wait for the outstanding buckets inside the timed "
+                           "steps; overlap_frac = 1 - exposed / standalone")
+    return out
+
+
+def cpu_baseline_loop_a(learner, opt, batch=32, max_threads=32, budget_s=45.0):
+    """loop A (il_modules/mrn.py:225-279: forward, loss, backward, clip, Adam of ONE expert) on the CPU oracle at batch 32:
+    1 warm-up + up to 2 timed iterations inside the time budget (TRBA: ~10 s per iteration)"""
+    from oracle import mrn_oracle as O
+    from mrn_amd.data.synthetic import SyntheticTextLines
+    from mrn_amd.tools.utils import host_cpu_budget
+    torch.set_num_threads(max(1, min(host_cpu_budget(), max_threads)))
+    sd = {k[len("module."):]: v.detach().cpu().clone() for k, v in learner.model.state_dict().items()}
+    cfg = O.Cfg(opt.Transformation, opt.FeatureExtraction, opt.SequenceModeling, opt.Prediction)
+    names = [n for n, p in learner.model.module.named_parameters() if p.requires_grad and n.startswith("model.0.")]
+    params = [sd[n].requires_grad_(True) for n in names]
+    state = [{"m": torch.zeros_like(p), "v": torch.zeros_like(p)} for p in params]
+    o2 = types.SimpleNamespace(**vars(opt))
+    o2.batch_size = batch
+    data = SyntheticTextLines(o2, device=torch.device("cpu"))
+    data.set_characters(learner.character)
+    conv = O.CTCConverter(learner.character) if opt.Prediction == "CTC" else O.AttnConverter(learner.character)
+    times, spent = [], 0.0
+    for it in range(3):
+        image, labels = data.get_batch()
+        li, ll = conv.encode(labels, 25)
+        t0 = time.time()
+        masks = None
+        if opt.FeatureExtraction == "SVTR":
+            masks = [torch.bernoulli(torch.full((batch,), 1.0 - float(dp))) for dp in O.SVTR_DROP_PATH if dp > 0 for _ in range(2)]
+        out = O.model_forward(sd, "model.0.", cfg, image, None if opt.Prediction == "CTC" else li[:, :-1], True, training=True, masks=masks)
+        loss = O.ctc_loss(out["predict"], li, ll) if opt.Prediction == "CTC" else O.attn_ce_loss(out["predict"], li)
+        grads = torch.autograd.grad(loss, params, allow_unused=True)
+        with torch.no_grad():
+            keep = [(p, g, s_) for p, g, s_ in zip(params, grads, state) if g is not None]
+            O.clip_and_adam([k[0] for k in keep], [k[1] for k in keep], [k[2] for k in keep], 2.5e-5, it + 1)
+        dt = time.time() - t0
+        spent += dt
+        if it > 0 or dt > budget_s / 2:
+            times.append(dt)
+        if spent + dt > budget_s:
+            break
+    sec = sum(times) / len(times)
+    return {"value": batch / sec, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port", "cpu": cpu_model_string(),
+            "sample": f"{len(times)} timed iteration(s) of the same loop A (one {opt.FeatureExtraction} expert: fwd + bwd + clip + Adam) at batch {batch}, "
+                      f"fp32, torch-CPU oracle"}
+
+
 def build_loop_a_learner(opt, quiet=True):
     """MRN task 0: ONE expert, everything trainable -- loop A (il_modules/mrn.py:225-279), the full forward + backward step"""
     from mrn_amd.data.synthetic import synthetic_characters
@@ -172,15 +280,86 @@ def train_dtype():
     return "f32 (trained and frozen convolutions as range-safe split-fp16 x3 products, fp32 accumulate)"
 
 
-def time_loop_a(args, opt, rank, world, steps, warmup):
+def describe_kernel(kind):
+    """KernelTimer kind -> (kernel description, peak TFLOP/s of its MFMA dtype, MFMA flops executed per algorithmic flop)"""
+    if kind == "f32":
+        return ("gemm_f32_kernel<2,2,2,2,16,true> (128x128x16 implicit-GEMM conv, v_mfma_f32_32x32x2_f32)", FP32_MFMA_PEAK_TFLOPS, 1)
+    if kind.startswith("gemm_f32"):
+        return ("gemm_f32_kernel (exact-fp32 MFMA GEMM, v_mfma_f32_32x32x2_f32)", FP32_MFMA_PEAK_TFLOPS, 1)
+    arith, staging = kind.split("/")
+    if staging.startswith("wino"):
+        R = int(staging[4])
+        return (f"conv_x3_kernel<2, 4, 2, 1, false, 3, {R}> (grouped 3x3 conv of all experts as 1-D Winograd F({R},3) along W: "
+                f"128 column-groups x 128 channels x 32 tiles, {R + 2} component reductions folded into {R} output accumulators in "
+                f"registers, {arith} on v_mfma_f32_32x32x16_f16, transformed HL32 operands staged by buffer_load...lds through a 3-stage ring)",
+                BF16_MFMA_PEAK_TFLOPS, 3.0 * (R + 2) / (3 * R))
+    if staging.startswith("x3g"):
+        tile = staging[3:]
+        targs = {"256x256": "4, 4, 2, 2", "256x128": "4, 2, 2, 2", "128x128": "4, 2, 1, 2", "256x64": "8, 1, 1, 2"}[tile]
+        nprod = 3 if arith == "fp16x3" else 1
+        return (f"conv_x3_kernel<{targs}{', false, 1' if nprod == 1 else ''}> (grouped {tile}x32 implicit-GEMM conv / Linear over "
+                f"all experts, {arith} on v_mfma_f32_32x32x16_f16, HL32 operands staged by buffer_load...lds)",
+                BF16_MFMA_PEAK_TFLOPS, nprod)
+    nsplit = 3 if arith.endswith("x3") else 1
+    kern = "conv_bf16_dma_kernel" if staging == "dma" else "conv_bf16_kernel"
+    half = "true" if arith.startswith("fp16") else "false"
+    inst = "v_mfma_f32_32x32x16_f16" if arith.startswith("fp16") else "v_mfma_f32_32x32x16_bf16"
+    return (f"{kern}<{nsplit},{half}> (128x128x32 implicit-GEMM conv, {arith} on {inst}, "
+            f"{'pre-split operands staged by global_load_lds' if staging == 'dma' else 'activation split in registers'})",
+            BF16_MFMA_PEAK_TFLOPS, nsplit)
+
+
+def roofline_entries(kinds, steps, elapsed_s):
+    """KernelTimer.summary() -> (MFMA-bound entries sorted by share of the step, HBM-bound entries)"""
+    rl, hbm = [], []
+    for kind, s_ in kinds.items():
+        if kind.startswith("hbm/"):
+            # HBM-bound pass: algorithmic bytes / union of its launch intervals against the 8 TB/s HBM3E peak
+            gbs = s_["total_bytes"] / (s_["union_ms"] * 1e-3) / 1e9
+            what = {"bn_apply_grouped": "BatchNorm-apply + residual + ReLU over all experts, fp32 in, HL32 split-fp16 operand out",
+                    "bn_apply_wino_grouped": "BatchNorm-apply + residual + ReLU + Winograd input transform B^T over all experts, fp32 in, "
+                                             "transformed HL32 operand (6 components per 4 columns) [+ plain HL32] out"}.get(kind[4:], kind[4:])
+            hbm.append({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                        "traffic": pmc_traffic(kind[4:] + "_kernel"), "kernel": f"{kind[4:]}_kernel ({what})",
+                        "algorithmic_bytes_per_launch": s_["total_bytes"] / s_["launches"],
+                        "launches_per_step": s_["launches"] / steps, "avg_launch_ms": s_["union_ms"] / s_["launches"],
+                        "avg_launch_ms_raw_event": s_["total_ms"] / s_["launches"],
+                        "kernel_share_of_step": s_["union_ms"] / (elapsed_s * 1e3)})
+            continue
+        per_launch = s_["total_flops"] / s_["launches"]
+        raw_ms = s_["total_ms"] / s_["launches"]          # per-launch HIP-event time (what rocprofv3 reports)
+        # lock-step sub-groups run on separate streams, so launches of this kernel share the GPU most of the
+        # time: the rate is taken over the UNION of the launch intervals (= raw time when nothing overlaps)
+        avg_ms = s_["union_ms"] / s_["launches"]
+        ach = per_launch / (avg_ms * 1e-3) / 1e12
+        kname, peak, per_flop = describe_kernel(kind)
+        rl.append({"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                   "traffic": pmc_traffic(kname), "traffic_source": PMC_SOURCE,
+                   "algorithmic_bytes_per_launch": s_.get("total_bytes", 0.0) / s_["launches"],
+                   "kernel": kname, "mfma_flops_per_algorithmic_flop": per_flop,
+                   "mfma_issue_frac": ach * per_flop / peak,
+                   "launches_per_step": s_["launches"] / steps, "avg_launch_ms": avg_ms,
+                   "avg_launch_ms_raw_event": raw_ms, "launch_overlap": s_["total_ms"] / s_["union_ms"],
+                   "algorithmic_gflop_per_launch": per_launch / 1e9,
+                   "kernel_share_of_step": s_["union_ms"] / (elapsed_s * 1e3)})
+    rl.sort(key=lambda r: -r["kernel_share_of_step"])
+    return rl, hbm
+
+
+def time_loop_a(args, opt, rank, world, steps, warmup, with_cpu_baseline=False):
     """loop A on the same synthetic crops: forward, loss, backward (bucketed all-reduce when N > 1), clip, Adam"""
-    from mrn_amd import parallel
+    from mrn_amd import ops, parallel
     from mrn_amd.data.synthetic import SyntheticTextLines
     learner = build_loop_a_learner(opt, quiet=not args.verbose)
     data = SyntheticTextLines(opt, seed=211 + rank)
     data.set_characters(learner.character)
     for _ in range(warmup):
         learner.train_step(*data.get_batch())
+    reducer = getattr(learner, "reducer", None)
+    if reducer is not None:
+        reducer.record, reducer.exposed = True, []
+    if not args.no_kernel_timer:
+        ops.CONV_TIMER = ops.KernelTimer()
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -189,17 +368,31 @@ def time_loop_a(args, opt, rank, world, steps, warmup):
     torch.cuda.synchronize()
     parallel.barrier()
     elapsed = time.perf_counter() - t0
+    timer, ops.CONV_TIMER = ops.CONV_TIMER, None
     if world > 1:
         t = torch.tensor([elapsed], device=learner.device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     n_params = learner.optimizer.flat.numel()
+    res = {"metric": f"text-line images/sec, loop A (train the newest {args.model.upper()} expert: fwd + bwd + clip + Adam) at 32x256",
+           "value": world * args.batch * steps / elapsed, "unit": "images/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps,
+           "warmup": warmup, "per_gpu_batch": args.batch, "trainable_parameters": n_params, "loss": float(loss.detach()),
+           "dtype": train_dtype()}
+    if timer is not None and timer.spans:
+        rl, hbm = roofline_entries(timer.summary(), steps, elapsed)
+        if rl:
+            res["roofline"] = rl[0]
+            res["roofline"]["measured"] = ("timed region: HIP events per launch on the launch stream (forward, data-gradient and weight-gradient "
+                                           "GEMMs of the trained convolutions run on this kernel family); rate over the union of the launch intervals")
+            if len(rl) > 1 or hbm:
+                res["roofline_other_kernels"] = rl[1:4] + hbm
+    if world > 1:
+        res["comm"] = comm_telemetry(reducer, world, learner.device, elapsed / steps * 1e3)
+    if with_cpu_baseline and world == 1 and rank == 0:
+        res["cpu_baseline"] = cpu_baseline_loop_a(learner, opt)
     del learner
     torch.cuda.empty_cache()
-    return {"metric": f"text-line images/sec, loop A (train the newest {args.model.upper()} expert: fwd + bwd + clip + Adam) at 32x256",
-            "value": world * args.batch * steps / elapsed, "unit": "images/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps,
-            "warmup": warmup, "per_gpu_batch": args.batch, "trainable_parameters": n_params, "loss": float(loss.detach()),
-            "dtype": train_dtype()}
+    return res
 
 
 def time_il_step(args, opt, rank, world, steps, warmup):
@@ -342,6 +535,7 @@ def main():
                     "metric workload; a: train one expert (full forward + backward); der: BASELINE config 5's DER step over --experts "
                     "extractors; lwf / ewc: config 5's auxiliary-loss learners, one task-1 step -- printed as the main line instead")
     ap.add_argument("--no-extra", action="store_true", help="do not append the short loop-A measurement under \"extra\"")
+    ap.add_argument("--no-power-probe", action="store_true", help="skip the live zero-operand probe of the dominant layer shape")
     args = ap.parse_args()
 
     from mrn_amd import ops, parallel
@@ -365,7 +559,8 @@ def main():
     opt = make_opt(args.model, args.batch)
     if args.loop in ("a", "der", "lwf", "ewc"):
         fn = {"a": time_loop_a, "der": time_der_step, "lwf": time_il_step, "ewc": time_il_step}[args.loop]
-        res = fn(args, opt, rank, world, args.steps, args.warmup)
+        kw = {"with_cpu_baseline": not args.no_cpu_baseline} if args.loop == "a" else {}
+        res = fn(args, opt, rank, world, args.steps, args.warmup, **kw)
         if rank == 0:
             what = {"a": f"MRN loop A: one {args.model.upper()} expert trained",
                     "der": f"DER step: DERNet over {args.experts} {args.model.upper()} extractors, newest trained",
@@ -403,6 +598,9 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    reducer = getattr(learner, "reducer", None)
+    if reducer is not None:
+        reducer.record, reducer.exposed = True, []
     if not args.no_kernel_timer:
         ops.CONV_TIMER = ops.KernelTimer()
     parallel.barrier()
@@ -437,6 +635,12 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
+    comm = comm_telemetry(reducer, world, dev, elapsed / args.steps * 1e3) if world > 1 else None
+    # live power probe of the dominant layer shape (rank 0, TRBA x3 mode only: the shape is TRBA's)
+    probe = None
+    if rank == 0 and timer is not None and not args.no_power_probe and args.model == "trba" and ops.X3_PRODUCTS == 3 \
+            and ops.CONV_PRECISION in ("auto", "fp16x3"):
+        probe = power_probe(ops, ops.WINO_R if ops.WINO_R in (2, 4) else 0)
 
     if rank == 0:
         res = {
@@ -459,73 +663,10 @@ def main():
                        "loss_clf": loss_clf.detach().item(), "loss_taski": loss_t.detach().item()},
         }
         if timer is not None and timer.spans:
-            kinds = timer.summary()
-            def describe(kind):
-                if kind == "f32":
-                    return ("gemm_f32_kernel<2,2,2,2,16,true> (128x128x16 implicit-GEMM conv, v_mfma_f32_32x32x2_f32)",
-                            FP32_MFMA_PEAK_TFLOPS, 1)
-                arith, staging = kind.split("/")
-                if staging.startswith("wino"):
-                    R = int(staging[4])
-                    return (f"conv_x3_kernel<2, 4, 2, 1, false, 3, {R}> (grouped 3x3 conv of all experts as 1-D Winograd F({R},3) along W: "
-                            f"128 column-groups x 128 channels x 32 tiles, {R + 2} component reductions folded into {R} output accumulators in "
-                            f"registers, {arith} on v_mfma_f32_32x32x16_f16, transformed HL32 operands staged by buffer_load...lds through a 4-stage ring)",
-                            BF16_MFMA_PEAK_TFLOPS, 3.0 * (R + 2) / (3 * R))
-                if staging.startswith("x3g"):
-                    tile = staging[3:]
-                    targs = {"256x256": "4, 4, 2, 2", "256x128": "4, 2, 2, 2", "128x128": "4, 2, 1, 2", "256x64": "8, 1, 1, 2"}[tile]
-                    nprod = 3 if arith == "fp16x3" else 1
-                    return (f"conv_x3_kernel<{targs}{', false, 1' if nprod == 1 else ''}> (grouped {tile}x32 implicit-GEMM conv / Linear over "
-                            f"all experts, {arith} on v_mfma_f32_32x32x16_f16, HL32 operands staged by buffer_load...lds)",
-                            BF16_MFMA_PEAK_TFLOPS, nprod)
-                nsplit = 3 if arith.endswith("x3") else 1
-                kern = "conv_bf16_dma_kernel" if staging == "dma" else "conv_bf16_kernel"
-                half = "true" if arith.startswith("fp16") else "false"
-                inst = "v_mfma_f32_32x32x16_f16" if arith.startswith("fp16") else "v_mfma_f32_32x32x16_bf16"
-                return (f"{kern}<{nsplit},{half}> (128x128x32 implicit-GEMM conv, {arith} on {inst}, "
-                        f"{'pre-split operands staged by global_load_lds' if staging == 'dma' else 'activation split in registers'})",
-                        BF16_MFMA_PEAK_TFLOPS, nsplit)
-            rl, hbm = [], []
-            for kind, s_ in kinds.items():
-                if kind.startswith("hbm/"):
-                    # HBM-bound pass: algorithmic bytes / union of its launch intervals against the 8 TB/s HBM3E peak
-                    gbs = s_["total_bytes"] / (s_["union_ms"] * 1e-3) / 1e9
-                    hbm.append({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                                "traffic": pmc_traffic(kind[4:] + "_kernel"), "kernel": kind[4:] + "_kernel (BatchNorm-apply + "
-                                "residual + ReLU over all experts, fp32 in, HL32 split-fp16 operand out)",
-                                "algorithmic_bytes_per_launch": s_["total_bytes"] / s_["launches"],
-                                "launches_per_step": s_["launches"] / args.steps, "avg_launch_ms": s_["union_ms"] / s_["launches"],
-                                "avg_launch_ms_raw_event": s_["total_ms"] / s_["launches"],
-                                "kernel_share_of_step": s_["union_ms"] / (elapsed * 1e3)})
-                    continue
-                per_launch = s_["total_flops"] / s_["launches"]
-                raw_ms = s_["total_ms"] / s_["launches"]          # per-launch HIP-event time (what rocprofv3 reports)
-                # two lock-step half-groups run on two streams, so two launches of this kernel share the GPU most of the
-                # time: the rate is taken over the UNION of the launch intervals (= raw time when nothing overlaps)
-                avg_ms = s_["union_ms"] / s_["launches"]
-                ach = per_launch / (avg_ms * 1e-3) / 1e12
-                kname, peak, per_flop = describe(kind)
-                rl.append({"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                           "traffic": pmc_traffic(kname), "traffic_source": PMC_SOURCE, "algorithmic_bytes_per_launch": s_.get("total_bytes", 0.0) / s_["launches"],
-                           "kernel": kname, "mfma_flops_per_algorithmic_flop": per_flop,
-                           "mfma_issue_frac": ach * per_flop / peak,
-                           "launches_per_step": s_["launches"] / args.steps, "avg_launch_ms": avg_ms,
-                           "avg_launch_ms_raw_event": raw_ms, "launch_overlap": s_["total_ms"] / s_["union_ms"],
-                           "algorithmic_gflop_per_launch": per_launch / 1e9,
-                           "kernel_share_of_step": s_["union_ms"] / (elapsed * 1e3),
-                           })
-            rl.sort(key=lambda r: -r["kernel_share_of_step"])
+            rl, hbm = roofline_entries(timer.summary(), args.steps, elapsed)
             res["roofline"] = rl[0]
-            if rl[0]["kernel"].startswith("conv_x3_kernel<4, 4, 2, 2>"):
-                res["roofline"]["power_limit"] = {
-                    "statement": "this kernel is bound by the chip's power budget, not by its schedule: the same instruction stream "
-                                 "on its dominant shape runs 3.94 ms on random operands, 3.15 ms with zero activations, 2.80 ms with "
-                                 "zero activations and weights (673 algorithmic TFLOP/s = 0.27 of peak = 0.81 MFMA issue x 0.833 executed); "
-                                 "isolated it issues 3 x 486 = 1458 MFMA-TFLOP/s on random operands, above the 1247 TFLOP/s the platform "
-                                 "guide (MI355X_MICROARCH.md, DVFS give-back) reports for its dense bf16 attention kernel on random data",
-                    "effective_clock_ghz_under_profiler": 1.48, "peak_assumes_ghz": 2.4, "mfma_busy_at_effective_clock": 0.70,
-                    "source": "static: profiles/r02b_conv_x3_power_wall.md, profiles/r02a_conv_x3_dominant_shape_pmc.txt "
-                              "(tools/bench_conv_x3.py with ZERO_INPUTS, tools/pmc_conv_x3.sh)"}
+            if probe is not None:
+                res["roofline"]["power_probe"] = probe
             res["roofline"]["measured"] = ("timed region: HIP events per launch on the launch streams; the lock-step sub-groups (three of two experts) "
                                            "and the router phase of the previous batch share the GPU, so the rate is taken over "
                                            "the union of this kernel's launch intervals")
@@ -534,7 +675,7 @@ def main():
                 i_ = isolated[k]
                 ms = i_["total_ms"] / i_["launches"]
                 ach = i_["total_flops"] / i_["launches"] / (ms * 1e-3) / 1e12
-                kname, peak, per_flop = describe(k)
+                kname, peak, per_flop = describe_kernel(k)
                 res["roofline"]["isolated"] = {
                     "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "mfma_issue_frac": ach * per_flop / peak,
                     "avg_launch_ms": ms, "launches_per_step": i_["launches"] / 2, "kernel": kname.split(" (")[0],
@@ -542,6 +683,8 @@ def main():
                                 "no look-ahead: each launch has the GPU to itself (python bench.py --serial reproduces it)"}
             if len(rl) > 1 or hbm:
                 res["roofline_other_kernels"] = rl[1:] + hbm
+        if comm is not None:
+            res["comm"] = comm
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(learner, opt, args.experts)
     extra = None
@@ -549,7 +692,7 @@ def main():
         del learner
         pending.clear()
         torch.cuda.empty_cache()
-        extra = time_loop_a(args, opt, rank, world, steps=5, warmup=2)
+        extra = time_loop_a(args, opt, rank, world, steps=5, warmup=2, with_cpu_baseline=not args.no_cpu_baseline)
     if rank == 0:
         if extra is not None:
             res["extra"] = {"loop_a": extra}

@@ -170,6 +170,9 @@ int mrn_conv3x3_c4_grouped_f32(const float* x, const float* w_ohwi, const float*
  * modules/feature_extraction.py:171-199,222-294; modules/transformation.py:69-81. */
 int mrn_bn_finalize_grouped_f32(const float* partials, int G, int nblk, int C, int64_t count, const void* const* ptrs,
                                 float momentum, float eps, float* scale, float* shift, void* stream);
+/* eval-mode BatchNorm2d (modules/feature_extraction.py:171-197 under model.eval()) of G modules folded to per-channel affines
+ * scale / shift [G][C] from the modules' CURRENT running statistics, through the same [4][G] pointer table */
+int mrn_bn_eval_affine_grouped_f32(const void* const* ptrs, int G, int C, float eps, float* scale, float* shift, void* stream);
 int mrn_bn_apply_grouped_f32(const float* y, const float* residual, const void* residual_hl32, const float* scale,
                              const float* shift, float* out_f32, void* out_hl32, int G, int64_t rows_per_group, int C,
                              int relu, void* stream);

@@ -120,7 +120,15 @@ template <int WAVES_M, int WAVES_N, int WM, int WN, int NPROD>
 constexpr bool x3_hi_only() {
   return NPROD == 1 && (WAVES_M * WM * 32) % (16 * WAVES_M * WAVES_N) == 0 && (WAVES_N * WN * 32) % (16 * WAVES_M * WAVES_N) == 0;
 }
-constexpr int X3_WINO_STAGES = 4;     // LDS ring depth of the Winograd instantiations (128 x 128 tiles: 32 KiB per stage)
+// LDS ring depth of the Winograd instantiations (128 x 128 tiles: 32 KiB per stage).  Measured on the dominant shape, same box
+// (tools/bench_wino.py, what-if builds of tools/build_probe.sh): 2 stages 3.49 ms, 3 stages 2.89, 4 stages 2.99, 5 stages 3.07
+#if defined(MRN_WINO_STAGES_4)
+constexpr int X3_WINO_STAGES = 4;
+#elif defined(MRN_WINO_STAGES_5)
+constexpr int X3_WINO_STAGES = 5;
+#else
+constexpr int X3_WINO_STAGES = 3;
+#endif
 template <int WAVES_M, int WAVES_N, int WM, int WN, int NPROD, int WINO = 0>
 constexpr size_t x3_lds_bytes() {
   return (size_t)(WAVES_M * WM * 32 + WAVES_N * WN * 32) *
@@ -393,7 +401,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
         }
     };
     // With half the MFMAs per staged byte of the direct form a K-step is too short to cover a DMA round trip (the weight stream
-    // of 6 x Cin lines per output channel comes from beyond L2), so the tiles run through a ring of X3_WINO_STAGES stages: two K-steps
+    // of 6 x Cin lines per output channel comes from beyond L2), so the tiles run through a ring of X3_WINO_STAGES stages: NST - 2 K-steps
     // of DMA stay in flight across the barrier, own arrivals counted with s_waitcnt vmcnt (compile-time count: the iterator re-fetches
     // the final tile once the reduction is exhausted, so every iteration issues the same DMAs).
     constexpr int NST = X3_WINO_STAGES;

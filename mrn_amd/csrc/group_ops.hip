@@ -83,6 +83,22 @@ __global__ __launch_bounds__(256) void bn_finalize_grouped_kernel(const float* _
   }
 }
 
+// eval-mode BatchNorm of G modules folded to (scale, shift) [G][C] from the CURRENT running statistics, through the same
+// pointer table as bn_finalize_grouped_kernel (same arithmetic as bn_eval_affine_kernel, spatial.hip)
+__global__ __launch_bounds__(256) void bn_eval_affine_grouped_kernel(const float* const* __restrict__ ptrs, int G, int C, float eps,
+                                                                     float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+  if (c >= C) return;
+  const float* gamma = ptrs[0 * G + g];
+  const float* beta = ptrs[1 * G + g];
+  const float* run_mean = ptrs[2 * G + g];
+  const float* run_var = ptrs[3 * G + g];
+  const float invstd = 1.f / sqrtf(run_var[c] + eps);
+  const float sc = (gamma ? gamma[c] : 1.f) * invstd;
+  scale[(long)g * C + c] = sc;
+  shift[(long)g * C + c] = (beta ? beta[c] : 0.f) - run_mean[c] * sc;
+}
+
 // 8 consecutive channels of row `row` from an HL32 image: value = hi + lo
 __device__ __forceinline__ F8 load_hl(const unsigned char* hl, long row, int C, int c8) {
   const unsigned char* o = hl + (row * (C >> 5) + (c8 >> 2)) * 128 + (c8 & 3) * 16;
@@ -384,6 +400,18 @@ MRN_EXPORT int mrn_bn_finalize_grouped_f32(const float* partials, int G, int nbl
   hipLaunchKernelGGL(bn_finalize_grouped_kernel, dim3((C + 3) / 4, G), dim3(256), 0, (hipStream_t)stream, partials, nblk, C,
                      (long)count, (const float* const*)ptrs, G, momentum, eps, scale, shift);
   MRN_LAUNCH_CHECK("bn_finalize_grouped");
+  return MRN_OK;
+}
+
+// Eval-mode BatchNorm2d of G modules as per-channel affines: scale[g] = gamma / sqrt(running_var + eps), shift[g] = beta -
+// running_mean * scale, read from the modules' CURRENT buffers through the [4][G] pointer table of mrn_bn_finalize_grouped_f32
+// (gamma / beta entries may be NULL; running_mean / running_var must not).  Same arithmetic as mrn_bn_eval_affine_f32.
+MRN_EXPORT int mrn_bn_eval_affine_grouped_f32(const void* const* ptrs, int G, int C, float eps, float* scale, float* shift,
+                                              void* stream) {
+  MRN_CHECK_ARG(ptrs && scale && shift && G >= 1 && C >= 1, "mrn_bn_eval_affine_grouped_f32: bad operands");
+  hipLaunchKernelGGL(bn_eval_affine_grouped_kernel, dim3((C + 255) / 256, G), dim3(256), 0, (hipStream_t)stream,
+                     (const float* const*)ptrs, G, C, eps, scale, shift);
+  MRN_LAUNCH_CHECK("bn_eval_affine_grouped");
   return MRN_OK;
 }
 

@@ -444,9 +444,14 @@ __global__ __launch_bounds__(NTH) void lstm_cluster_x3_kernel(const LstmClusterG
       CL_TICK(5)
     }
     if (step + 1 < T) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // own stores have left the CU (vmcnt(0)) ...
+      // Publish protocol (MI355X_MICROARCH.md, hand-off forms): the h tile leaves as agent-scope (sc1, write-through) stores;
+      // every wave drains ITS stores with an explicit s_waitcnt vmcnt(0) -- a workgroup-scope release fence lowers to
+      // s_waitcnt lgkmcnt(0) only on gfx950, and the compiler may drop a vmcnt wait it can prove redundant, so the wait is
+      // inline asm -- then the barrier makes that true for the whole workgroup, then one lane bumps the agent-scope arrival
+      // counter.  The consumers poll the counter relaxed and read h with agent-scope (sc1) loads, which bypass their L1.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       CL_TICK(6)
-      __syncthreads();                                           // ... everyone's have
+      __syncthreads();                                           // ... everyone's stores have left the CU
       CL_TICK(2)
       if (t_ == 0) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       CL_TICK(3)

@@ -78,9 +78,15 @@ class DeviceStager:
 
 
 class Dataset_Manager(object):
-    def __init__(self, opt, open_dataset=None, device=None):
+    def __init__(self, opt, open_dataset=None, device=None, rank=0, world=1):
         """open_dataset(path, opt, mode) -> Dataset of (PIL RGBA image, label): defaults to the LMDB / NPZ leaf reader; tests and
-        array-backed pipelines pass their own.  device: where batches are staged (None: cuda when available, else no staging)"""
+        array-backed pipelines pass their own.  device: where batches are staged (None: cuda when available, else no staging).
+        rank / world: data parallelism (one process per GPU, mrn_amd/parallel.py).  torch.nn.DataParallel scatters ONE loader's batch of
+        opt.batch_size over the GPUs (reference il_modules/base.py:68); here every rank owns its loaders, so with world > 1 each rank
+        draws batch_size // world samples per loader from its OWN shuffle order (a torch.Generator seeded manual_seed + rank): the
+        ranks see different samples and the global batch stays opt.batch_size.  The numpy seed stays common, so the rehearsal-memory
+        index sets agree between the ranks.  world == 1 leaves everything as it was (global RNG, full batch)."""
+        self.rank, self.world = int(rank), max(1, int(world))
         self.data_list = []
         self.data_loader_list = []
         self.dataloader_iter_list = []
@@ -176,7 +182,13 @@ class Dataset_Manager(object):
         return ConcatDataset(dataset_list)
 
     def _loader(self, dataset, batch_size, collate):
-        loader = DataLoader(dataset, batch_size=self.opt.batch_size if batch_size is None else batch_size, shuffle=True,
+        bs = self.opt.batch_size if batch_size is None else batch_size
+        gen = None
+        if self.world > 1:
+            bs = max(1, bs // self.world)
+            gen = torch.Generator()
+            gen.manual_seed(int(getattr(self.opt, "manual_seed", 0)) + 7919 * (self.rank + 1) + 104729 * len(self.data_loader_list))
+        loader = DataLoader(dataset, batch_size=bs, shuffle=True, generator=gen,
                             num_workers=int(self.opt.workers), collate_fn=collate, pin_memory=False, drop_last=False)
         self.data_loader_list.append(loader)
         self.dataloader_iter_list.append(iter(loader))

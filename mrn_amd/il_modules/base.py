@@ -308,7 +308,9 @@ class BaseLearner(object):
             return
         path = self.checkpoint_path(taski, step)
         os.makedirs(os.path.dirname(path), exist_ok=True)
-        torch.save(self.model.state_dict(), path)
+        tmp = path + ".tmp%d" % os.getpid()
+        torch.save(self.model.state_dict(), tmp)
+        os.replace(tmp, path)                    # readers (other ranks, a resumed run) never see a partly written file
 
     def load_checkpoint(self, path):
         """reference `self.model.load_state_dict(torch.load(path), strict=True)` (base.py:193, :375); both TPS-buffer key
@@ -321,6 +323,7 @@ class BaseLearner(object):
         """base.py:363-423: reload the task's saved checkpoint, evaluate every test set.  valid_datas: iterable of evaluation
         loaders, or LMDB roots when an LMDB reader is available (mrn_amd.data.dataset.hierarchical_dataset)"""
         path = self.checkpoint_path(taski, step)
+        parallel.barrier()                           # rank 0's last save_checkpoint() of the task is on disk before any rank looks
         if os.path.exists(path):
             self.load_checkpoint(path)
         accs, neds = [], []

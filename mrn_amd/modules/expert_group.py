@@ -171,12 +171,10 @@ class BackboneGroup(_GroupedLinear):
                 assert x.f32 is not None
                 x.hl = ops.split_hl32(x.f32)
             w_hl, w_scale = self._weights_hl(convs)
-            tensors = [t for b in bns for t in (b.weight, b.bias, b.running_mean, b.running_var)]
-
-            def affine():
-                ss = [ops.bn_eval_affine(b.weight, b.bias, b.running_mean, b.running_var, b.eps) for b in bns]
-                return torch.stack([a for a, _ in ss]).contiguous(), torch.stack([a for _, a in ss]).contiguous()
-            scale, shift = self._cached("bnaff%d" % id(bns[0]), tensors, affine)
+            # the affine is rebuilt from the CURRENT running statistics on every call (one launch through the pointer table): the
+            # statistics are updated by kernels through raw pointers while the experts run in train mode between two validations,
+            # so nothing keyed on tensor versions may cache it
+            scale, shift = ops.bn_eval_affine_grouped(self._bn_table(bns), G, Cout, bns[0].eps)
             fused = dict(bias=self._bias_stack(convs), act=ops.ACT_RELU if relu else ops.ACT_NONE, ch_scale=scale, ch_shift=shift,
                          residual=res, residual_hl=res_hl, products=ops.X3_PRODUCTS)
             if pool is not None:
@@ -222,9 +220,7 @@ class BackboneGroup(_GroupedLinear):
                 scale, shift = ops.bn_finalize_grouped(stats, G, Cout, B * Ho * Wo, self._bn_table(bns), mom, bns[0].eps)
                 self._nbt += [b.num_batches_tracked for b in bns if b.num_batches_tracked is not None]
             else:
-                ss = [ops.bn_eval_affine(b.weight, b.bias, b.running_mean, b.running_var, b.eps) for b in bns]
-                scale = torch.stack([s for s, _ in ss]).contiguous()
-                shift = torch.stack([s for _, s in ss]).contiguous()
+                scale, shift = ops.bn_eval_affine_grouped(self._bn_table(bns), G, Cout, bns[0].eps)
         # identity shortcut: the fp32 tensor when it exists, else the HL32 image (hi + lo) the block input already has
         post_relu = relu and not fuse_act
         if pool is not None:

@@ -545,7 +545,7 @@ def conv2d_x3(x_hl, G, shared_input, B, H, W, Cin, w_hl, w_scale, Cout, ksize, s
 # comes from a train-mode BatchNorm-apply pass (csrc/conv_x3.hip WINO, csrc/group_ops.hip): R = 4 halves the matrix work of
 # the dominant 512 -> 512 layers.  MRN_WINO=0 switches it off (A/B), MRN_WINO=2 selects F(2,3).
 WINO_R = int(os.environ.get("MRN_WINO", "4"))
-WINO_MIN_CIN = int(os.environ.get("MRN_WINO_MIN_CIN", "256"))
+WINO_MIN_CIN = int(os.environ.get("MRN_WINO_MIN_CIN", "128"))
 
 
 def wino_eligible(ksize, stride, padding, Cin, Cout):
@@ -652,6 +652,14 @@ def bn_finalize_grouped(stats, G, C, count, ptr_table, momentum, eps):
     nblk = stats.numel() // (2 * C * G)
     call("mrn_bn_finalize_grouped_f32", _p(stats), G, nblk, C, count, _p(ptr_table), float(momentum), float(eps), _p(scale),
          _p(shift), _stream())
+    return scale, shift
+
+
+def bn_eval_affine_grouped(ptr_table, G, C, eps):
+    """eval-mode BatchNorm of G modules -> (scale [G,C], shift [G,C]) from their current running statistics (one launch)"""
+    scale = torch.empty(G, C, device=ptr_table.device, dtype=torch.float32)
+    shift = torch.empty(G, C, device=ptr_table.device, dtype=torch.float32)
+    call("mrn_bn_eval_affine_grouped_f32", _p(ptr_table), G, C, float(eps), _p(scale), _p(shift), _stream())
     return scale, shift
 
 

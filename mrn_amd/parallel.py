@@ -230,6 +230,8 @@ class BucketedAllReduce:
         self.active = False
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(optimizer.params)]
         self.launched_log = []     # bucket indices in launch order of the last step (tests)
+        self.record = False        # bench.py telemetry: HIP events around the part of finish() the compute stream has to wait for
+        self.exposed = []          # [(event, event)] per step while record is set
 
     def close(self):
         """detach from the parameters (a learner builds a new optimiser -- and a new reducer -- for every task / step)"""
@@ -265,6 +267,10 @@ class BucketedAllReduce:
 
     def finish(self):
         self.active = False
+        e0 = None
+        if self.record and self.opt.grad.is_cuda:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         while self.next < len(self.buckets):
             self._launch(self.next)
             self.next += 1
@@ -272,4 +278,27 @@ class BucketedAllReduce:
             h.wait()
         if not _averages_in_collective(self.opt.grad):
             self.opt.grad.div_(world_size())
+        if e0 is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.exposed.append((e0, e1))
         self.handles = []
+
+    def bytes_per_step(self):
+        return 4 * sum(hi - lo for lo, hi in self.buckets)
+
+    def standalone_ms(self, reps=3):
+        """the same buckets all-reduced back to back with nothing else on the GPU (after a synchronize): what one step's gradient
+        exchange costs when none of it is hidden behind backward"""
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        keep = self.opt.grad.clone()
+        e0.record()
+        for _ in range(reps):
+            hs = [_avg_inplace(self.opt.grad[lo:hi], async_op=True) for lo, hi in self.buckets]
+            for h in hs:
+                h.wait()
+        e1.record()
+        torch.cuda.synchronize()
+        self.opt.grad.copy_(keep)
+        return e0.elapsed_time(e1) / reps

@@ -63,8 +63,12 @@ def validation(model, criterion, evaluation_loader, converter, opt, val_choose="
         length_of_data += batch_size
         image = image_tensors.to(dev)
         labels_index, labels_length = converter.encode(labels, batch_max_length=opt.batch_max_length)
+        if image.is_cuda:
+            torch.cuda.synchronize()                 # the launches are asynchronous: infer_time is forward time, not host issue time
         start = time.time()
         preds = _forward(model, image, opt, converter, val_choose)
+        if image.is_cuda:
+            torch.cuda.synchronize()
         infer_time += time.time() - start
         if criterion is not None:               # the learners' Criterion (il_modules/base.py): CTC or CE(ignore [PAD]) :178-207
             cost = criterion(preds, labels_index, labels_length)

@@ -95,7 +95,7 @@ def train(opt, log, data=None):
     if data is None:
         from .data.data_manage import Dataset_Manager, Val_Dataset
         from .data.dataset import AlignCollate
-        data_manager = Dataset_Manager(opt)
+        data_manager = Dataset_Manager(opt, rank=parallel.rank(), world=parallel.world_size())      # every rank its own shard
         AlignCollate_valid = AlignCollate(opt, mode="test")
     else:
         data_manager, fixed_valid, characters, test_loaders = data

@@ -125,3 +125,32 @@ def test_npz_leaf_round_trip_and_label_filter(tmp_path):
     with pytest.raises(ImportError):
         from mrn_amd.data.dataset import LmdbDataset
         LmdbDataset(str(leaf), opt)                                                # lmdb is not installed in this image
+
+
+def test_ranks_draw_different_shards_of_the_global_batch():
+    """data parallelism (mrn_amd/tiny_train.py with N > 1 ranks): every rank's Dataset_Manager yields batch_size // world samples
+    per loader from its own shuffle order -- the ranks' batches differ, the rehearsal-memory subsets (numpy seed) agree, and
+    world == 1 keeps the full batch"""
+    from mrn_amd.data.data_manage import Dataset_Manager
+    opt = make_opt(il="mrn", memory="random", memory_num=40, batch_size=8, manual_seed=111)
+    batches, loaders = [], []
+    for rank in (0, 1):
+        np.random.seed(77)
+        torch.manual_seed(77)
+        with contextlib.redirect_stdout(io.StringIO()):
+            dm = Dataset_Manager(opt, open_dataset=open_fake, device=torch.device("cpu"), rank=rank, world=2)
+            dm.select_data = opt.select_data
+            index_list = [np.random.choice(range(30), 20, replace=False) for _ in range(2)]
+            dm.get_dataset(2, memory="random", index_list=index_list)
+            batches.append([dm.get_batch2() for _ in range(2)])
+            loaders.append(dm.data_loader_list)
+    assert [l.batch_size for l in loaders[0]] == [l.batch_size for l in loaders[1]] == [4] * len(loaders[0])
+    assert [len(l.dataset) for l in loaders[0]] == [len(l.dataset) for l in loaders[1]]          # same rehearsal subsets
+    (img0, lab0, _), (img1, lab1, _) = batches[0][0], batches[1][0]
+    assert img0.shape == img1.shape and img0.shape[0] == 4 * len(loaders[0])
+    assert list(lab0) != list(lab1) and not torch.equal(img0, img1), "both ranks drew the same first batch"
+    with contextlib.redirect_stdout(io.StringIO()):
+        dm = Dataset_Manager(opt, open_dataset=open_fake, device=torch.device("cpu"))
+        dm.select_data = opt.select_data
+        dm.get_dataset(2, memory="random", index_list=index_list)
+    assert [l.batch_size for l in dm.data_loader_list] == [8] * len(dm.data_loader_list)

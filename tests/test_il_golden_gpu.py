@@ -320,3 +320,105 @@ def test_full_size_dernet_trba6_properties():
     for k, v in frozen_before.items():
         assert torch.equal(v, after[k]), k
     assert float((net.aux_fc.weight.grad if net.aux_fc.weight.grad is not None else torch.zeros(1)).abs().max()) == 0.0
+
+
+SEEDS2 = {"wa": (51, 52), "joint": (53, 54)}
+
+
+def _check_movement(g, pre, taski, learner, seeds, kind):
+    sd = {k.replace("module.", ""): v for k, v in learner.model.state_dict().items()}
+    for k in [str(s) for s in g[f"{pre}t{taski}/param_keys"]]:
+        init = torch.from_numpy(W.det_param(W.canonical_key(k), tuple(sd[k].shape), seeds[taski])).to(sd[k].device)
+        moved = (sd[k] - init).detach().cpu().double().numpy().reshape(-1)
+        step_ = max(1, moved.size // 1024)
+        s = moved[::step_][:1024]
+        r = g[f"{pre}t{taski}/delta/{k}/sub"].astype(np.float64)
+        l2 = np.linalg.norm(s - r) / max(np.linalg.norm(r), 1e-30)       # (relative L2: see test_il_flow_vs_reference)
+        assert l2 <= (0.5 if kind == "trba" else 0.1), (k, l2)
+
+
+@pytest.mark.parametrize("kind", ["crnn", "trba"])
+def test_wa_flow_vs_reference(tmp_path, kind):
+    """Two tasks of the WA learner (reference il_modules/wa.py:29-116) driven like the reference class was for
+    tests/golden/il2_*.npz (make_golden_il2.py): per-iteration losses (loss_clf + 2 * KD in task 1), the KD terms, BOTH
+    weight_align() calls of task 1 (end of _update_representation: gamma and the rescaled classifier rows; after_task(): gamma 1
+    on the already aligned rows), parameter movement, class bookkeeping, checkpoints, validations."""
+    from mrn_amd.il_modules.wa import WA
+    g = load_golden(f"il2_{kind}")
+    pre = "wa/"
+    os.chdir(tmp_path)
+    opt = learner_opt(kind)
+    seeds = SEEDS2["wa"]
+    train = DetLoader(2, f"il2:{kind}:wa", 61)
+    valid = DetLoader(2, f"il2:{kind}:wa:val", 62)
+    sink = io.StringIO()
+    steps, fc_snaps = [], []
+    with contextlib.redirect_stdout(sink):
+        learner = hooked(WA, seeds)(opt)
+        record(learner, "train_step", steps)
+        record(learner, "kd_step", steps)
+        for taski in range(2):
+            chars = chars_upto(taski)
+            train.set_characters(chars)
+            valid.set_characters(chars)
+            n0 = len(steps)
+            if taski == 1:
+                net = learner.model.module if hasattr(learner.model, "module") else learner.model
+            learner.incremental_train(taski, chars, train, valid)
+            got = steps[n0:]
+            rel_close([s[0] for s in got], g[f"{pre}t{taski}/losses"], 2e-4)
+            if taski == 1:
+                rel_close([s[1] for s in got], g[pre + "t1/kd"], 2e-4)
+                fc_snaps.append(learner.model.module.fc.weight.detach().cpu().numpy().copy()[::7, ::5])
+            _check_movement(g, pre, taski, learner, seeds, kind)
+            learner.after_task()
+            if taski == 1:
+                fc_snaps.append(learner.model.fc.weight.detach().cpu().numpy().copy()[::7, ::5])
+            assert learner._known_classes == int(g[f"{pre}t{taski}/known_classes"])
+            if taski == 0:
+                W.fill_state_dict(learner._old_network.state_dict(), 57)
+                assert learner._old_network.training == bool(g[pre + "old_network_training"])
+    gam = [float(l.split("=")[1]) for l in sink.getvalue().splitlines() if l.startswith("alignweights,gamma=")]
+    rel_close(gam, g[pre + "t1/weight_align_gamma"], 1e-4)
+    # classifier rows after each alignment (the trained rows carry the Adam-step conditioning of _check_movement: compare the
+    # alignment itself through the ratio after / before, and the aligned matrix loosely)
+    for i, snap in enumerate(fc_snaps):
+        ref_after = g[f"{pre}t1/align{i}/fc_after"]
+        assert snap.shape == ref_after.shape
+        assert np.abs(snap - ref_after).max() <= 2e-4 * max(1.0, np.abs(ref_after).max())
+    assert sink.getvalue().count("Current_score") == int(g[pre + "n_valid_calls"])
+    assert sorted(os.listdir(f"./saved_models/{opt.exp_name}")) == [str(s) for s in g[pre + "checkpoints"]]
+
+
+@pytest.mark.parametrize("kind", ["crnn", "trba"])
+def test_joint_flow_vs_reference(tmp_path, kind):
+    """Two rounds of JointLearner (reference il_modules/joint.py:9-105; the second after change_model() grew the classifier):
+    per-iteration losses, parameter movement, checkpoints, validations, and the empty score lists incremental_train() returns when
+    no test interval is reached"""
+    from mrn_amd.il_modules.joint import JointLearner
+    g = load_golden(f"il2_{kind}")
+    pre = "joint/"
+    os.chdir(tmp_path)
+    opt = learner_opt(kind)
+    opt.saved_model = ""
+    seeds = SEEDS2["joint"]
+    train = DetLoader(2, f"il2:{kind}:joint", 63)
+    valid = DetLoader(2, f"il2:{kind}:joint:val", 64)
+    sink = io.StringIO()
+    steps = []
+    with contextlib.redirect_stdout(sink):
+        learner = hooked(JointLearner, seeds)(opt)
+        record(learner, "train_step", steps)
+        for taski in range(2):
+            chars = chars_upto(taski)
+            train.set_characters(chars)
+            valid.set_characters(chars)
+            n0 = len(steps)
+            best, ned = learner.incremental_train(taski, chars, train, valid, None, None)
+            assert [len(best), len(ned)] == list(g[f"{pre}t{taski}/returned_lengths"])
+            rel_close([s[0] for s in steps[n0:]], g[f"{pre}t{taski}/losses"], 2e-4)
+            _check_movement(g, pre, taski, learner, seeds, kind)
+            learner.after_task()
+            assert learner._known_classes == int(g[f"{pre}t{taski}/known_classes"])
+    assert sink.getvalue().count("Current_score") == int(g[pre + "n_valid_calls"])
+    assert sorted(os.listdir(f"./saved_models/{opt.exp_name}")) == [str(s) for s in g[pre + "checkpoints"]]

@@ -340,6 +340,102 @@ def test_full_size_trba6_loop_b_properties():
         del net
 
 
+@pytest.mark.parametrize("crops", ["smooth", "noise"])
+def test_trba6_batch32_full_class_counts_vs_oracle(crops):
+    """The headline configuration against the CPU ORACLE (not against another HIP schedule): TRBA x 6 experts with the bench's
+    class counts 2091 ... 5374, 32 crops, the production schedule (three lock-step sub-groups on three streams, Winograd F(4,3) +
+    split-fp16 x3 convolutions).  Smooth crops: routing weights and fused logits within 1e-4 of the fp32 oracle -- or, where the
+    fp32 oracle itself is further than that from float64 arithmetic (the TPS grid's conditioning), within 3x that band -- routing
+    argmax and eval routing / greedy indices bit-exact, the gradients of all router tensors of one loop-B step within 2e-3.
+    U(-1,1) noise (bench.py's distribution): inside the conditioning band, indices bit-exact where the float64 margin clears it."""
+    from mrn_amd import functional as Fn
+    from mrn_amd.modules.model import MRNNet
+    from mrn_amd.tools import weights as W
+    from oracle import mrn_oracle as O
+    from tests.helpers import oracle_dtype
+    opt = make_opt("trba")
+    classes = (2091, 2311, 4039, 5199, 5272, 5374)
+    B, I = 32, len(classes)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = MRNNet(opt)
+        for c in classes:
+            net.update_fc(256, c)
+            net.build_prediction(opt, c)
+    W.fill_state_dict(net.state_dict(), seed=37)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    net = net.cuda().train()
+    for n, p in net.named_parameters():
+        p.requires_grad = not n.startswith("model.")
+    if crops == "smooth":
+        image = torch.from_numpy(W.smooth_image("b32_trba", (B, 4, 32, 256), 5))
+    else:
+        image = torch.from_numpy(W.uniform("b32_trba", (B, 4, 32, 256), -1.0, 1.0, 5))
+    text = torch.from_numpy(W.randint("b32_text", (B, 27), 4, classes[-1], 5))
+    text[:, 0] = 2
+    domain = torch.from_numpy(W.randint("b32_dom", (B,), 0, 2, 5))
+    cfg = O.Cfg("TPS", "ResNet", "BiLSTM", "Attn")
+    # ---- oracle: fp32 (the reference's arithmetic) with autograd through the router, and float64 (the conditioning yardstick)
+    names = [n for n in sd if not n.startswith("model.") and sd[n].is_floating_point()]
+    sd32 = {k: v.clone() for k, v in sd.items()}
+    for n in names:
+        sd32[n].requires_grad_(True)
+    out32 = O.mrn_forward(sd32, cfg, I, image, True, text[:, :-1], True, training=True)
+    loss32 = 15 * O.attn_ce_loss(out32["logits"], text) + torch.nn.functional.cross_entropy(out32["index"], domain)
+    g32 = torch.autograd.grad(loss32, [sd32[n] for n in names])
+    with oracle_dtype(torch.float64) as od, torch.no_grad():
+        out64 = O.mrn_forward(od.cast(sd), cfg, I, image.double(), True, text[:, :-1], True, training=True)
+    w32, l32 = out32["index"].detach(), out32["logits"].detach()
+    band_w = float((w32.double() - out64["index"]).abs().max())
+    band_l = float((l32.double() - out64["logits"]).abs().max())
+    # ---- HIP, production schedule
+    handle = None
+    with torch.no_grad():
+        handle = net.experts_prefetch(image.cuda(), text[:, :-1].cuda(), True)
+    assert handle is not None and len(handle["parts"]) == 3
+    out = net(image.cuda(), True, text[:, :-1].cuda(), True, experts=handle)
+    loss = 15 * Fn.cross_entropy(out["logits"], text[:, 1:].cuda(), 1) + Fn.cross_entropy(out["index"], domain.cuda(), -100)
+    loss.backward()
+    w, lg = out["index"].detach().cpu(), out["logits"].detach().cpu()
+    ew, el = float((w - w32).abs().max()), float((lg - l32).abs().max())
+    ew64, el64 = float((w.double() - out64["index"]).abs().max()), float((lg.double() - out64["logits"]).abs().max())
+    scale_l = float(l32.abs().max())
+    if crops == "smooth":
+        assert ew <= max(1e-4, 3 * band_w), (ew, band_w)
+        assert el <= max(1e-4 * max(1.0, scale_l), 3 * band_l), (el, band_l, scale_l)
+    else:
+        assert band_w > 5e-4           # the premise on noise: the fp32 reference arithmetic itself is far from exact
+        assert ew64 <= 2 * band_w and el64 <= 2 * band_l, (ew64, band_w, el64, band_l)
+        assert ew <= 3 * band_w and el <= 3 * band_l, (ew, band_w, el, band_l)
+    assert abs(float(loss) - float(loss32)) <= (1e-4 if crops == "smooth" else 3 * band_l) * max(1.0, abs(float(loss32)))
+    # routing argmax: bit-exact on every sample whose float64 top-2 margin clears the band
+    top2 = out64["index"].sort(1, descending=True)[0]
+    clear = (top2[:, 0] - top2[:, 1]) > 10 * max(band_w, 1e-5)
+    assert int(clear.sum()) >= (B if crops == "smooth" else B // 2)
+    assert torch.equal(w.argmax(1)[clear], w32.argmax(1)[clear]) and torch.equal(w.argmax(1)[clear], out64["index"].argmax(1)[clear])
+    # one loop-B step's gradients of every router tensor
+    mine = dict(net.named_parameters())
+    for n, gr in zip(names, g32):
+        if float(gr.abs().mean()) < 1e-7:
+            continue          # route.bias: shift-invariant under softmax, its gradient is round-off noise
+        tol = 2e-3 if crops == "smooth" else max(2e-3, 30 * band_w)
+        _grad_check(n, mine[n].grad, gr, rel_l2=tol, rel_max=5 * tol)
+    # ---- eval routing + greedy decoding (test.py:validation's model call): integer outputs
+    with torch.no_grad():      # (sd32: its BatchNorm running statistics took the same one train-mode update as the HIP modules')
+        oe32 = O.mrn_forward({k: v.detach() for k, v in sd32.items()}, cfg, I, image, True, torch.LongTensor(B).fill_(2), False,
+                             training=False)
+    net.eval()
+    with torch.no_grad():
+        oe = net(image.cuda(), True, torch.LongTensor(B).fill_(2).cuda(), False)
+    if crops == "smooth":
+        assert torch.equal(oe["index"].cpu(), oe32["index"])
+        assert torch.equal(oe["logits"].max(2)[1].cpu(), oe32["logits"].max(2)[1])
+    else:       # on noise a sub-band eval margin may flip a routing decision: demand agreement on a clear majority and exact
+        same = oe["index"].cpu() == oe32["index"]          # greedy strings wherever the routing agrees
+        assert float(same.float().mean()) >= 0.9
+        am, am32 = oe["logits"].max(2)[1].cpu(), oe32["logits"].max(2)[1]
+        assert float((am[same] == am32[same]).float().mean()) >= 0.99
+
+
 def _grad_check(name, mine, ref, rel_l2=2e-3, rel_max=2e-3):
     a = mine.detach().cpu().double().numpy()
     b = ref.detach().double().numpy()
@@ -598,6 +694,56 @@ def test_grouped_backbones_match_per_expert_path(arch, train_mode):
             assert torch.equal(bna[k], bnb[k]), k
         else:
             assert_close(k, bna[k], bnb[k], atol=1e-6, rtol=2e-5)
+
+
+@pytest.mark.parametrize("arch", ["crnn", "trba"])
+def test_eval_fold_follows_running_statistics_updated_in_train_mode(arch):
+    """validation -> train-mode steps -> validation on ONE BackboneGroup (MRN loop B validates at iteration 1 and again later while
+    the frozen experts keep running train-mode BatchNorm, reference il_modules/mrn.py:107,379,401): the eval-mode BatchNorm folded
+    into the conv epilogue must use the CURRENT running statistics, which kernels update through raw pointers (no version bump).
+    Checked against the per-expert path run through the same sequence."""
+    import contextlib
+    import io
+    import types
+    from mrn_amd.modules.model import MRNNet
+    from mrn_amd.tools import weights as W
+    stages = dict(trba=("TPS", "ResNet", "BiLSTM", "Attn"), crnn=("None", "VGG", "BiLSTM", "CTC"))[arch]
+    opt = types.SimpleNamespace(Transformation=stages[0], FeatureExtraction=stages[1], SequenceModeling=stages[2],
+                                Prediction=stages[3], num_fiducial=20, imgH=32, imgW=256, input_channel=4, output_channel=512,
+                                hidden_size=256, batch_max_length=25)
+    classes = (30, 45, 61)
+    B = 4
+    images = [torch.from_numpy(W.smooth_image("fold%d" % i, (B, 4, 32, 256), 3 + i)).cuda() * (1.0 + 0.5 * i) for i in range(3)]
+    text = torch.from_numpy(W.randint("fold_text", (B, 26), 4, classes[-1], 3)).cuda()
+    text[:, 0] = 2
+    txt = text if stages[3] == "Attn" else None
+    outs = []
+    for grouping in (True, False):
+        with contextlib.redirect_stdout(io.StringIO()):
+            net = MRNNet(opt)
+            for c in classes:
+                net.update_fc(256, c)
+                net.build_prediction(opt, c)
+        W.fill_state_dict(net.state_dict(), seed=13)
+        net = net.cuda()
+        for p in net.parameters():
+            p.requires_grad = False
+        net.expert_grouping = grouping
+        with torch.no_grad():
+            net.eval()
+            first = net(images[0], True, txt, True)["logits"].clone()
+            net.train()
+            for im in images[1:]:
+                net(im, True, txt, True)          # running statistics move (momentum 0.1, different input scales)
+            net.eval()
+            second = net(images[0], True, txt, True)
+        outs.append((first, second["logits"].clone(), second["index"].clone()))
+    (fa, sa, wa), (fb, sb, wb) = outs
+    tol = 2e-4 if arch == "trba" else 2e-6
+    assert float((sb - fb).abs().max()) > 100 * tol, "the sequence must move the eval-mode outputs for the test to mean anything"
+    assert_close("eval logits before the train-mode steps", fa, fb, atol=10 * tol, rtol=1e-4)
+    assert_close("eval logits after the train-mode steps", sa, sb, atol=10 * tol, rtol=1e-4)
+    assert_close("eval routing weights after the train-mode steps", wa, wb, atol=tol, rtol=1e-4)
 
 
 @pytest.mark.parametrize("train_mode", [True, False])

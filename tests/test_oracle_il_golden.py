@@ -153,3 +153,48 @@ def test_trba_dernet():
         oe = O.dernet_forward(dict(golden_state_dict(g, 8)), cfg, 2, image, torch.LongTensor(2).fill_(2), False, training=False)
         assert_sub_close(g, "eval/logits", oe["logits"], atol=1e-4)
         assert np.array_equal(oe["logits"].max(2)[1].numpy(), g["eval/argmax"])
+
+
+@pytest.mark.parametrize("kind", ["crnn", "trba"])
+def test_first_iteration_losses_of_wa_and_joint(kind):
+    """tests/golden/il2_*.npz (the reference's WA and JointLearner driven by make_golden_il2.py) against the oracle: iteration 1 of
+    every task is a pure function of the seeds.  WA task 1: loss_clf + 2 * KD (wa.py:81-88, the LwF step with lamda = 2); Joint:
+    the canonical loss of base.py:242-250 on a freshly grown classifier."""
+    g = load_golden(f"il2_{kind}")
+    nsp = 4 if kind == "crnn" else 5
+    c0, c1 = NCHARS[0] + nsp, NCHARS[0] + NCHARS[1] + nsp
+    pred = "CTC" if kind == "crnn" else "Attn"
+    with torch.no_grad():
+        for which, tag, seeds, lseed in (("wa", f"il2:{kind}:wa", (51, 52), 61), ("joint", f"il2:{kind}:joint", (53, 54), 63)):
+            sd, _ = model_state(kind, c0, seeds[0])
+            loader = DetLoader(2, tag, lseed)
+            loader.set_characters(chars_upto(0))
+            image, words = loader.get_batch()
+            _, loss, _, _ = first_loss(kind, sd, image, words, chars_upto(0))
+            ref = float(g[f"{which}/t0/losses"][0])
+            assert abs(float(loss) - ref) <= 1e-4 * max(1.0, abs(ref)), (which, float(loss), ref)
+            # task 1, iteration 1 (two training batches consumed by task 0)
+            sd_new, _ = model_state(kind, c1, seeds[1])
+            loader.set_characters(chars_upto(1))
+            loader.count = 2
+            image, words = loader.get_batch()
+            new, loss1, li, ll = first_loss(kind, sd_new, image, words, chars_upto(1))
+            ref1 = float(g[f"{which}/t1/losses"][0])
+            if which == "joint":
+                assert abs(float(loss1) - ref1) <= 1e-4 * max(1.0, abs(ref1)), (float(loss1), ref1)
+                continue
+            sd_old, _ = model_state(kind, c0, 57)
+            old = O.model_forward(sd_old, "", cfg_for(kind), image, None if kind == "crnn" else li[:, :-1], True, training=False)["predict"]
+            total, kd, _ = O.lwf_step_loss(new, old, li, ll, pred, c0, lamda=2.0)
+            assert tuple(g["wa/kd_shape"]) == (new.shape[0] * new.shape[1], c0 - (0 if kind == "crnn" else 1))
+            assert abs(float(kd) - float(g["wa/t1/kd"][0])) <= 1e-4 * max(1.0, float(g["wa/t1/kd"][0]))
+            assert abs(float(total) - ref1) <= 1e-4 * max(1.0, abs(ref1)), (float(total), ref1)
+    # weight_align (modules/model.py:166-174): gamma = mean old-row norm / mean new-row norm, reproduced from the stored rows
+    for i in range(2):
+        before, after = g[f"wa/t1/align{i}/fc_before"], g[f"wa/t1/align{i}/fc_after"]
+        inc = int(g[f"wa/t1/align{i}/increment"])
+        rows = np.arange(c1)[::7]
+        new_rows = rows >= c1 - inc
+        ratio = after[new_rows] / np.where(before[new_rows] == 0, 1, before[new_rows])
+        assert np.allclose(ratio[before[new_rows] != 0], float(g["wa/t1/weight_align_gamma"][i]), rtol=2e-5)
+        assert np.array_equal(after[~new_rows], before[~new_rows])

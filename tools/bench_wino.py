@@ -31,7 +31,7 @@ def timeit(fn, reps):
 
 def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-    groups = [int(g) for g in sys.argv[2].split(",")] if len(sys.argv) > 2 else [2, 6]
+    groups = [int(g) for g in sys.argv[2].split(",")] if len(sys.argv) > 2 and sys.argv[2][0] != "-" else [2, 6]
     zero = os.environ.get("ZERO_INPUTS")
     for (B, H, W, Cin, Cout) in SHAPES:
         for G in groups:
@@ -43,6 +43,12 @@ def main():
                 ws = [t * 0 for t in ws] if zero == "2" else ws
             sc = torch.ones(G, Cin, device="cuda")
             sh = torch.zeros(G, Cin, device="cuda")
+            if "--only-wino" in sys.argv:        # PMC passes (tools/pmc_kernel.sh): nothing but F(4,3) launches of this shape
+                u_hl, u_scale = ops.pack_weights_wino(ws, 4)
+                _, _, v = ops.bn_apply_wino_grouped(ypre, sc, sh, 4, relu=True)
+                ms = timeit(lambda: ops.conv2d_x3_wino(v, G, False, B, H, W, Cin, u_hl, u_scale, Cout, 4, want_stats=True), reps)
+                print(f"G{G} B{B} {H}x{W} {Cin}->{Cout}: F(4,3) {ms:7.3f} ms", flush=True)
+                continue
             w_hl, w_scale = ops.pack_weights_hl32(ws)
             _, hl = ops.bn_apply_grouped(ypre.clone(), sc, sh, relu=True, want_f32=False, want_hl=True)
             yd, _ = ops.conv2d_x3(hl, G, False, B, H, W, Cin, w_hl, w_scale, Cout, (3, 3), (1, 1), (1, 1), want_stats=True)

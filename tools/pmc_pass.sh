@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/$tag/p$i -o p -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timer --no-extra > $R/gpurun_out/$tag/p$i.log 2>&1
+  timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/$tag/p$i -o p -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timer --no-extra --no-power-probe > $R/gpurun_out/$tag/p$i.log 2>&1
 done
 cd $R
 python3 - <<PY

@@ -1,11 +1,12 @@
 #!/bin/bash
 # usage (on the GPU box, from the repo root): bash tools/profile_bench.sh <tag> [bench args...]
-# rocprofv3 kernel trace of bench.py (1 warm-up + 2 timed steps) summarised to gpurun_out/<tag>/summary.md
+# rocprofv3 kernel trace of bench.py (1 warm-up + 2 timed steps = 3 steps in the trace: the isolated pass and the power probe are
+# switched off so that the step count of the summary is exact) summarised to gpurun_out/<tag>/summary.md
 tag=$1; shift
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/$tag
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$tag/prof -o trace -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra "$@" > $R/gpurun_out/$tag/prof.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$tag/prof -o trace -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra --no-isolated-pass --no-power-probe "$@" > $R/gpurun_out/$tag/prof.log 2>&1
 cd $R
 python3 tools/rocprof_summary.py gpurun_out/$tag/prof/trace_results.db 3 > gpurun_out/$tag/summary.md 2>&1
 python3 tools/rocprof_timeline.py gpurun_out/$tag/prof/trace_results.db > gpurun_out/$tag/timeline.txt 2>&1
