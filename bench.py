@@ -48,7 +48,10 @@ def pmc_traffic(kernel_name):
     with open(path) as f:
         pmc = json.load(f)
     key = kernel_name.split(" (")[0]
-    ent = pmc.get("kernels", {}).get(key)
+    kernels = pmc.get("kernels", {})
+    ent = kernels.get(key)
+    if ent is None:          # (template arguments the description leaves out: bn_apply_wino_grouped_kernel<4>)
+        ent = next((v for k, v in kernels.items() if k.startswith(key + "<")), None)
     return None if ent is None else ent["hbm_bytes_per_launch"]
 
 

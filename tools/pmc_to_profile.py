@@ -28,7 +28,7 @@ def main():
         h, ms = d.get("TCC_HIT_sum", {}).get(k), d.get("TCC_MISS_sum", {}).get(k)
         if h and ms and h["sum"] + ms["sum"] > 0:
             ent["l2_hit_rate"] = h["sum"] / (h["sum"] + ms["sum"])
-        out["kernels"][k.replace("void ", "").split("(")[0].replace(", false, 3>", ">").replace(", false>", ">")] = ent      # (HL_OUT = false, NPROD = 3: the default variant)
+        out["kernels"][k.replace("void ", "").split("(")[0].replace(", false, 3, 0>", ">").replace(", false, 3>", ">").replace(", false>", ">")] = ent      # (HL_OUT = false, NPROD = 3, WINO = 0: the default variant)
     json.dump(out, sys.stdout, indent=1)
 
 
