@@ -140,15 +140,18 @@ int mrn_gemm_x3_windows_hl32(const void* a_hl, int64_t a_bytes, int a_pitch_line
  *                                  zero outside the row) and optionally the plain fp32 (not aliasing y) / HL32 result;
  *   mrn_conv2d_x3_wino_hl32        y [G][B][H][W][Cout] = A^T [ sum over (ky, Cin) of U_m V_m ] + bias (act 0 / 1), BatchNorm
  *                                  partial statistics [G][ceil(B*H*ceil(W/R)/128)][2][Cout] (mrn_conv2d_x3_wino_stats_floats) or
- *                                  NULL; out_scale [G][2] = the weight prescale {s, 1/s}; v_group_stride_bytes 0 = shared input. */
+ *                                  NULL; out_scale [G][2] = the weight prescale {s, 1/s}; v_group_stride_bytes 0 = shared input.
+ * Trained layers (loop A, il_modules/mrn.py:225-279: forward and data-gradient convolutions) run the same three entry points with
+ * G = 1 and per-operand power-of-two range scales: `prescale` of the producer pass = `x_scale` of the convolution = {s, 1/s} of the
+ * activation (or gradient) operand from mrn_pow2_scale_f32. */
 int mrn_pack_weight_wino_hl32(const float* w_ohwi, void* out, int Cout, int Cin, int R, const float* scale, void* stream);
 int mrn_bn_apply_wino_grouped_f32(const float* y, const float* residual, const void* residual_hl32, const float* scale,
                                   const float* shift, float* out_f32, void* out_hl32, void* out_wino, int G, int B, int H, int W,
-                                  int C, int R, int relu, void* stream);
+                                  int C, int R, int relu, const float* prescale, void* stream);
 int64_t mrn_conv2d_x3_wino_stats_floats(int G, int B, int H, int W, int Cout, int R);
 int mrn_conv2d_x3_wino_hl32(const void* v_hl, const void* u_hl, const void* zero_page, const float* bias, float* y, float* stats,
-                            const float* out_scale, int G, int64_t v_group_stride_bytes, int B, int H, int W, int Cin, int Cout,
-                            int R, int act, void* stream);
+                            const float* out_scale, const float* x_scale, int G, int64_t v_group_stride_bytes, int B, int H, int W,
+                            int Cin, int Cout, int R, int act, void* stream);
 
 /* First convolution of the frozen experts' stacks (3x3, stride 1, padding 1, Cin = 4, Cout = 32 or 64: VGG conv 0
  * feature_extraction.py:19, ResNet conv0_1 :214, TPS localisation conv 1 transformation.py:60), G experts in one launch on the

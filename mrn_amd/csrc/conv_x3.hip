@@ -1202,9 +1202,10 @@ MRN_EXPORT int64_t mrn_conv2d_x3_wino_stats_floats(int G, int B, int H, int W, i
 //   v_hl  [Gx][B][H][ceil(W/R)][R+2][Cin/32][128 B]   transformed activation (mrn_bn_apply_wino_grouped_f32)
 //   u_hl  [G][Cout][R+2][Cin/32][3][128 B]            transformed weight (mrn_pack_weight_wino_hl32), out_scale [G][2] its {s, 1/s}
 //   y     [G][B][H][W][Cout] fp32 = conv + bias (act 0 / 1), stats [G][mrn_conv2d_x3_wino_stats_floats / G] BatchNorm partials or NULL
+//   x_scale {s, 1/s} of an activation operand that was transformed as s * B^T(x) (trained layers), or NULL
 MRN_EXPORT int mrn_conv2d_x3_wino_hl32(const void* v_hl, const void* u_hl, const void* zero_page, const float* bias, float* y,
-                                       float* stats, const float* out_scale, int G, int64_t v_group_stride_bytes, int B, int H, int W,
-                                       int Cin, int Cout, int R, int act, void* stream) {
+                                       float* stats, const float* out_scale, const float* x_scale, int G, int64_t v_group_stride_bytes,
+                                       int B, int H, int W, int Cin, int Cout, int R, int act, void* stream) {
   MRN_CHECK_ARG(v_hl && u_hl && zero_page && y && G >= 1 && (R == 2 || R == 4), "mrn_conv2d_x3_wino_hl32: bad operands");
   MRN_CHECK_ARG(Cin % 32 == 0 && ((uintptr_t)v_hl % 128 == 0) && ((uintptr_t)u_hl % 128 == 0) && v_group_stride_bytes % 128 == 0,
                 "mrn_conv2d_x3_wino_hl32: HL32 operands must be 128-byte aligned, Cin %% 32 == 0 (Cin=%d)", Cin);
@@ -1215,7 +1216,7 @@ MRN_EXPORT int mrn_conv2d_x3_wino_hl32(const void* v_hl, const void* u_hl, const
   ConvX3Params p;
   memset(&p, 0, sizeof(p));
   p.x = (const unsigned char*)v_hl; p.w = (const unsigned char*)u_hl; p.zero = (const unsigned char*)zero_page;
-  p.bias = bias; p.out_scale = out_scale; p.y = y; p.stats = stats;
+  p.bias = bias; p.out_scale = out_scale; p.x_scale = x_scale; p.y = y; p.stats = stats;
   p.Cb = NC * (Cin / 32); p.taps = 3; p.nk = p.Cb * 3;
   p.x_gstride = v_group_stride_bytes; p.w_gstride = (long)Cout * p.nk * 128;
   p.x_group_div = 1;

@@ -164,8 +164,10 @@ __global__ __launch_bounds__(256) void bn_apply_wino_grouped_kernel(const float*
                                                                     const float* __restrict__ scale, const float* __restrict__ shift,
                                                                     float* __restrict__ out, unsigned char* __restrict__ out_hl,
                                                                     unsigned char* __restrict__ out_v, long imgrows_per_group, int W,
-                                                                    int Wq, long n8, int C, int relu) {
+                                                                    int Wq, long n8, int C, int relu,
+                                                                    const float* __restrict__ prescale) {
   constexpr int NC = R + 2;
+  const float ps = prescale ? prescale[0] : 1.f;     // power-of-two range scale of a trained layer's operand (B^T is linear: applied once, after it)
   const int C8 = C >> 3, Cb = C >> 5;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
     const int c8 = (int)(i % C8);
@@ -237,8 +239,8 @@ __global__ __launch_bounds__(256) void bn_apply_wino_grouped_kernel(const float*
       }
 #pragma unroll
       for (int k = 0; k < NC; ++k) {
-        if (e < 4) m[k].a[e] = r_[k];
-        else m[k].b[e - 4] = r_[k];
+        if (e < 4) m[k].a[e] = r_[k] * ps;
+        else m[k].b[e - 4] = r_[k] * ps;
       }
     }
 #pragma unroll
@@ -441,7 +443,7 @@ MRN_EXPORT int mrn_bn_apply_grouped_f32(const float* y, const float* residual, c
 // receive the plain result.
 MRN_EXPORT int mrn_bn_apply_wino_grouped_f32(const float* y, const float* residual, const void* residual_hl32, const float* scale,
                                              const float* shift, float* out_f32, void* out_hl32, void* out_wino, int G, int B, int H,
-                                             int W, int C, int R, int relu, void* stream) {
+                                             int W, int C, int R, int relu, const float* prescale, void* stream) {
   MRN_CHECK_ARG(y && out_wino && C % 32 == 0 && (!scale == !shift) && !(residual && residual_hl32) && (R == 2 || R == 4) &&
                     out_f32 != y && (uintptr_t)out_wino % 128 == 0,
                 "mrn_bn_apply_wino_grouped_f32: bad operands (C=%d R=%d)", C, R);
@@ -453,11 +455,11 @@ MRN_EXPORT int mrn_bn_apply_wino_grouped_f32(const float* y, const float* residu
   if (R == 4)
     hipLaunchKernelGGL(bn_apply_wino_grouped_kernel<4>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, y, residual,
                        (const unsigned char*)residual_hl32, scale, shift, out_f32, (unsigned char*)out_hl32, (unsigned char*)out_wino,
-                       (long)B * H, W, Wq, n8, C, relu);
+                       (long)B * H, W, Wq, n8, C, relu, prescale);
   else
     hipLaunchKernelGGL(bn_apply_wino_grouped_kernel<2>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, y, residual,
                        (const unsigned char*)residual_hl32, scale, shift, out_f32, (unsigned char*)out_hl32, (unsigned char*)out_wino,
-                       (long)B * H, W, Wq, n8, C, relu);
+                       (long)B * H, W, Wq, n8, C, relu, prescale);
   MRN_LAUNCH_CHECK("bn_apply_wino_grouped");
   return MRN_OK;
 }

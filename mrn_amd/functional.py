@@ -345,7 +345,7 @@ class ConvBlockFn(torch.autograd.Function):
         ctx.wpacked = w
         # one max|x| pass serves the forward conv and the weight gradient (both split x with the same power-of-two scale)
         x3s = precision == "fp16x3s" and x.shape[-1] % 32 == 0
-        ctx.x_scale = sx = ops.pow2_scale(x.contiguous()) if x3s else None
+        ctx.x_scale = sx = ops.pow2_scale(x.contiguous(), ops.TRAIN_OPERAND_PEAK) if x3s else None
         if bn is None:
             y, _ = ops.conv2d_nhwc(x, w, bias, stride, padding, act=ops.ACT_RELU if relu else ops.ACT_NONE, precision=precision,
                                    x_scale=sx)
@@ -382,7 +382,7 @@ class ConvBlockFn(torch.autograd.Function):
                 dbias = ops.colsum(dy.view(-1, dy.shape[-1]))
         dx = None
         dy = dy.contiguous()
-        sd = ops.pow2_scale(dy) if precision == "fp16x3s" else None          # shared by the data and weight gradients
+        sd = ops.pow2_scale(dy, ops.TRAIN_OPERAND_PEAK) if precision == "fp16x3s" else None   # shared by the data and weight gradients
         if ctx.needs_input_grad[0]:
             wt = ops.pack_dgrad_weight(w.ohwi)
             dx = ops.conv2d_dgrad(dy, wt, (x.shape[1], x.shape[2]), stride, padding, precision=precision, dy_scale=sd)

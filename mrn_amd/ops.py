@@ -546,6 +546,11 @@ def conv2d_x3(x_hl, G, shared_input, B, H, W, Cin, w_hl, w_scale, Cout, ksize, s
 # the dominant 512 -> 512 layers.  MRN_WINO=0 switches it off (A/B), MRN_WINO=2 selects F(2,3).
 WINO_R = int(os.environ.get("MRN_WINO", "4"))
 WINO_MIN_CIN = int(os.environ.get("MRN_WINO_MIN_CIN", "128"))
+TRAIN_WINO = os.environ.get("MRN_TRAIN_WINO", "1") == "1"      # the trained convolutions of loop A too (forward + data gradient)
+# range target of the power-of-two scale of a TRAINED convolution's activation / gradient operand: the Winograd input transform B^T
+# amplifies an operand by up to 10x (row sums of |B^T|, F(4,3)), so its prescale leaves a factor 16 of fp16 headroom below the 16384
+# the plain split aims at (the weight side needs none: the folded row scales keep |G g| <= 1.17 max|g|)
+TRAIN_OPERAND_PEAK = 16384.0 / 16 if TRAIN_WINO else 16384.0
 
 
 def wino_eligible(ksize, stride, padding, Cin, Cout):
@@ -573,7 +578,7 @@ def pack_weights_wino(ws, R, scale=None):
     return out, scale
 
 
-def bn_apply_wino_grouped(y, scale, shift, R, relu=True, residual=None, residual_hl=None, want_f32=False, want_hl=False):
+def bn_apply_wino_grouped(y, scale, shift, R, relu=True, residual=None, residual_hl=None, want_f32=False, want_hl=False, prescale=None):
     """y [G,B,H,W,C] fp32 -> (fp32 result (a NEW tensor) or None, HL32 bytes or None, Winograd-domain operand bytes
     [G][B][H][ceil(W/R)][R+2][C/32][128])"""
     G, B, H, W, C = y.shape
@@ -583,14 +588,15 @@ def bn_apply_wino_grouped(y, scale, shift, R, relu=True, residual=None, residual
     v = torch.empty(G * B * H * Wq * (R + 2) * C * 4, device=y.device, dtype=torch.uint8)
     t0 = CONV_TIMER.begin() if CONV_TIMER is not None else None
     call("mrn_bn_apply_wino_grouped_f32", _p(y), _p(residual), _p(residual_hl), _p(scale), _p(shift), _p(out), _p(out_hl), _p(v),
-         G, B, H, W, C, R, int(bool(relu)), _stream())
+         G, B, H, W, C, R, int(bool(relu)), _p(prescale), _stream())
     if t0 is not None:       # algorithmic bytes: every input / output element once; the transformed operand is (R+2)/R elements per element
         n_io = 1 + int(residual is not None or residual_hl is not None) + int(want_f32) + int(want_hl)
         CONV_TIMER.end(t0, 0.0, "hbm/bn_apply_wino_grouped", 4.0 * y.numel() * n_io + 4.0 * G * B * H * Wq * (R + 2) * C)
     return out, out_hl, v
 
 
-def conv2d_x3_wino(v_hl, G, shared_input, B, H, W, Cin, u_hl, u_scale, Cout, R, bias=None, act=ACT_NONE, want_stats=False, out=None):
+def conv2d_x3_wino(v_hl, G, shared_input, B, H, W, Cin, u_hl, u_scale, Cout, R, bias=None, act=ACT_NONE, want_stats=False, out=None,
+                   x_scale=None):
     """3x3 / stride 1 / pad 1 grouped conv on Winograd-domain operands -> (y [G,B,H,W,Cout] fp32, stats or None)"""
     dev = v_hl.device
     y = out if out is not None else torch.empty(G, B, H, W, Cout, device=dev, dtype=torch.float32)
@@ -601,7 +607,7 @@ def conv2d_x3_wino(v_hl, G, shared_input, B, H, W, Cin, u_hl, u_scale, Cout, R, 
     gstride = 0 if shared_input else B * H * Wq * (R + 2) * Cin * 4
     timed = CONV_TIMER is not None
     t0 = CONV_TIMER.begin() if timed else None
-    call("mrn_conv2d_x3_wino_hl32", _p(v_hl), _p(u_hl), _p(_zero_page(dev)), _p(bias), _p(y), _p(stats), _p(u_scale), G, gstride,
+    call("mrn_conv2d_x3_wino_hl32", _p(v_hl), _p(u_hl), _p(_zero_page(dev)), _p(bias), _p(y), _p(stats), _p(u_scale), _p(x_scale), G, gstride,
          B, H, W, Cin, Cout, R, act, _stream())
     if timed:
         # algorithmic flops = the convolution's (2 * 9 * Cin per output element); the kernel executes (R+2)/(3R) of them as MFMA products
@@ -620,7 +626,16 @@ def conv2d_x3_scaled(x, w_ohwi, bias, stride, padding, act=ACT_NONE, want_stats=
     Cout, kh, kw, _ = w_ohwi.shape
     x = x.contiguous()
     if sx is None:
-        sx = pow2_scale(x)          # (callers that use x in several GEMMs compute it once: ConvBlockFn)
+        sx = pow2_scale(x, TRAIN_OPERAND_PEAK)          # (callers that use x in several GEMMs compute it once: ConvBlockFn)
+    if TRAIN_WINO and TRAIN_PRODUCTS == 3 and wino_eligible((kh, kw), stride, padding, Cin, Cout):
+        # Winograd F(R,3) along W, as for the frozen experts (conv_x3.hip WINO): the operand pass applies B^T to sx * x in place of the
+        # plain split, the weights are re-transformed with the step's values.  Serves the forward AND the data-gradient convolutions of
+        # loop A (conv2d_dgrad arrives here with the flipped weights and the gradient's own range scale).
+        R = WINO_R
+        _, _, v = bn_apply_wino_grouped(x.view(1, B, H, W, Cin), None, None, R, relu=False, prescale=sx)
+        u_hl, su = pack_weights_wino([w_ohwi.contiguous()], R)
+        y, stats = conv2d_x3_wino(v, 1, False, B, H, W, Cin, u_hl, su, Cout, R, bias=bias, act=act, want_stats=want_stats, x_scale=sx)
+        return y[0], stats
     w_hl, sw = pack_weights_hl32([w_ohwi.contiguous()])
     y, stats = conv2d_x3(split_hl32(x, sx), 1, False, B, H, W, Cin, w_hl, sw, Cout, (kh, kw), stride, padding, bias=bias, act=act,
                          want_stats=want_stats, x_scale=sx, products=TRAIN_PRODUCTS)

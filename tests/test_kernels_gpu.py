@@ -913,3 +913,21 @@ def test_winograd_full_size_dominant_shape_properties(ops):
     tot = stats.view(G, -1, 2, C).sum(1)
     assert_close("fused column sums", tot[:, 0], yw.sum((1, 2, 3)), atol=2e-2, rtol=2e-5)
     assert_close("fused column sums of squares", tot[:, 1], (yw * yw).sum((1, 2, 3)), atol=2e-2, rtol=2e-5)
+
+
+@pytest.mark.parametrize("magnitude", [1.0, 1e-5, 300.0])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(3, 8, 64, 128, 256), (3, 4, 64, 512, 512), (2, 4, 65, 128, 128)])
+def test_trained_conv_winograd_range_safe(ops, B, H, W, Cin, Cout, magnitude):
+    """loop A's trained convolutions on the Winograd form (ops.conv2d_x3_scaled with TRAIN_WINO: forward and data gradient): the
+    operand's power-of-two range scale leaves the factor 16 of fp16 headroom the input transform B^T needs (row sums of |B^T| up
+    to 10), so gradient-sized (1e-5) and large (300) operands keep 22-bit products"""
+    assert ops.TRAIN_WINO and ops.TRAIN_OPERAND_PEAK == 1024.0
+    x = cu(rnd(B, H, W, Cin, seed=400) * 3 * magnitude)
+    w = cu(rnd(Cout, 3, 3, Cin, seed=401, scale=(2.0 / (9 * Cin)) ** 0.5))
+    bias = cu(rnd(Cout, seed=402) * magnitude)
+    y, stats = ops.conv2d_x3_scaled(x, w, bias, (1, 1), (1, 1), act=ops.ACT_NONE, want_stats=True)
+    ref = F.conv2d(x.cpu().double().permute(0, 3, 1, 2), w.cpu().double().permute(0, 3, 1, 2), bias.cpu().double(), 1, 1).permute(0, 2, 3, 1)
+    scale = float(ref.abs().max())
+    assert float((y.cpu().double() - ref).abs().max()) <= 1e-5 * scale
+    tot = stats.view(-1, 2, Cout).sum(0)
+    assert_close("fused column sums", tot[0] / scale, (ref.sum((0, 1, 2)) / scale).float(), atol=2e-3, rtol=1e-4)
