@@ -446,20 +446,22 @@ class MRNNet(nn.Module):
             ready = torch.cuda.Event()
             ready.record(main)
             streams = self._streams(len(halves), dev)
+            # the router's [B,P,I,C] feature tensor is allocated ONCE (issuing stream's pool) and every sub-group writes its experts'
+            # slice of it: no concatenation launch when the router phase adopts the outputs
+            feats = torch.empty(B, self.patch, I, self.out_dim, device=dev, dtype=torch.float32)
             parts = []
             for (lo, hi, bg, hg), st in zip(halves, streams):
                 st.wait_event(ready)
                 with torch.cuda.stream(st):
-                    f = torch.empty(B, self.patch, hi - lo, self.out_dim, device=dev, dtype=torch.float32)
                     lg = [ops.padded_rows(B, T_pred, e.fc.out_features, dev) for e in list(self.model)[lo:hi]]
-                    hg.run(bg.visual_all(img, as_act=True), text, f, lg)
+                    hg.run(bg.visual_all(img, as_act=True), text, feats[:, :, lo:hi, :], lg)
                     done = torch.cuda.Event()
                     done.record(st)
-                for t in (img, image, text):
+                for t in (img, image, text, feats):
                     if t is not None:
                         t.record_stream(st)
-                parts.append((f, lg, done))
-            return {"parts": parts, "batch": B}
+                parts.append((lg, done))
+            return {"parts": parts, "batch": B, "feats": feats}
 
     def _experts_and_gate(self, image, text, is_train, experts=None):
         I = len(self.model)
@@ -469,15 +471,14 @@ class MRNNet(nn.Module):
             # outputs of experts_prefetch(): wait for the two half-groups, adopt their buffers on this stream
             assert experts["batch"] == B
             main = torch.cuda.current_stream()
-            fs, logits = [], []
-            for f, lg, done in experts["parts"]:
+            logits = []
+            for lg, done in experts["parts"]:
                 main.wait_event(done)
-                f.record_stream(main)
                 for l in lg:
                     l.record_stream(main)
-                fs.append(f)
                 logits += lg
-            feats = torch.cat(fs, dim=2)
+            feats = experts["feats"]
+            feats.record_stream(main)
             r = self.dm_router[0].forward_l2(feats)
             r = LinearFn.apply(r.view(B * self.patch, I * self.out_dim), self.channel_route.weight, self.channel_route.bias)
             return logits, r.view(B, self.patch, I)
