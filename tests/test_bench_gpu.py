@@ -52,6 +52,13 @@ def test_bench_two_ranks_control_flow():
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 32 and d["config"]["parallelism"] == "dp2"
     assert "cpu_baseline" not in d          # reported at N = 1 only
+    # comm telemetry of the N > 1 line: did the backend see both ranks, what one step's gradient exchange moves and costs
+    for line in (d, d["extra"]["loop_a"]):
+        c = line["comm"]
+        assert c["backend"] == "gloo" and c["ranks_seen"] == [0, 1] and "rccl_version" in c
+        assert c["allreduce_bytes_per_step"] > 0 and c["buckets"] >= 1 and c["allreduce_ms_per_step"] > 0
+        assert c["exposed_ms_per_step"] >= 0 and 0.0 <= c["overlap_frac"] <= 1.0
+    assert d["comm"]["allreduce_bytes_per_step"] < d["extra"]["loop_a"]["comm"]["allreduce_bytes_per_step"]     # router only vs a whole expert
 
 
 DP_WORKER = r"""
