@@ -148,6 +148,11 @@ int mrn_pack_weight_wino_hl32(const float* w_ohwi, void* out, int Cout, int Cin,
 int mrn_bn_apply_wino_grouped_f32(const float* y, const float* residual, const void* residual_hl32, const float* scale,
                                   const float* shift, float* out_f32, void* out_hl32, void* out_wino, int G, int B, int H, int W,
                                   int C, int R, int relu, const float* prescale, void* stream);
+/* ... and MaxPool2d (mrn_maxpool_grouped_f32: BatchNorm-apply + ReLU fused on the input) as such a producer: the pooled map's groups of
+ * R columns through B^T -> out_wino [G][B][Ho][ceil(Wo/R)][R+2][C/32][128 B]; the plain pooled fp32 / HL32 result optionally */
+int mrn_maxpool_wino_grouped_f32(const float* x, const float* scale, const float* shift, int relu, float* out_f32, void* out_hl32,
+                                 void* out_wino, int G, int B, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw,
+                                 int R, void* stream);
 int64_t mrn_conv2d_x3_wino_stats_floats(int G, int B, int H, int W, int Cout, int R);
 int mrn_conv2d_x3_wino_hl32(const void* v_hl, const void* u_hl, const void* zero_page, const float* bias, float* y, float* stats,
                             const float* out_scale, const float* x_scale, int G, int64_t v_group_stride_bytes, int B, int H, int W,

@@ -305,6 +305,106 @@ __global__ __launch_bounds__(256) void maxpool_grouped_kernel(const float* __res
   }
 }
 
+// maxpool_grouped_kernel as the producer of a Winograd F(R,3) convolution: one lane = 8 channels of one group of R POOLED columns of
+// one pooled row; the R + 2 pooled values (own columns + one halo column each side, zero outside the row) go through B^T and leave as
+// HL32 component lines [pooled row][group][component][C/32][128 B], the plain fp32 / HL32 pooled result of the own columns too if asked
+template <int R>
+__global__ __launch_bounds__(256) void maxpool_wino_grouped_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                                   const float* __restrict__ shift, float* __restrict__ out,
+                                                                   unsigned char* __restrict__ out_hl, unsigned char* __restrict__ out_v,
+                                                                   int relu, int B, long n8, int H, int W, int C, int Ho, int Wo, int Wq,
+                                                                   int kh, int kw, int sh, int sw, int ph, int pw) {
+  constexpr int NC = R + 2;
+  const int C8 = C >> 3;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const int c8 = (int)(i % C8);
+    const long t = i / C8;                       // (pooled row over [G*B][Ho], group)
+    const int q = (int)(t % Wq);
+    const long prow = t / Wq;
+    const int oy = (int)(prow % Ho);
+    const long b = prow / Ho;
+    const int g = (int)(b / B);
+    F8 sc, sf;
+    if (scale) {
+      sc = load8(scale + (long)g * C + c8 * 8);
+      sf = load8(shift + (long)g * C + c8 * 8);
+    }
+    F8 d[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      const int ox = R * q - 1 + j;
+      if ((unsigned)ox < (unsigned)Wo) {
+        F8 m;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m.a[e] = m.b[e] = -INFINITY;
+        for (int ky = 0; ky < kh; ++ky) {
+          const int iy = oy * sh - ph + ky;
+          if ((unsigned)iy >= (unsigned)H) continue;
+          for (int kx = 0; kx < kw; ++kx) {
+            const int ix = ox * sw - pw + kx;
+            if ((unsigned)ix >= (unsigned)W) continue;
+            F8 v = load8(x + (((b * H + iy) * W + ix) * (long)C8 + c8) * 8);
+            if (scale) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                v.a[e] = v.a[e] * sc.a[e] + sf.a[e];
+                v.b[e] = v.b[e] * sc.b[e] + sf.b[e];
+              }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              m.a[e] = fmaxf(m.a[e], v.a[e]);
+              m.b[e] = fmaxf(m.b[e], v.b[e]);
+            }
+          }
+        }
+        if (relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            m.a[e] = fmaxf(m.a[e], 0.f);
+            m.b[e] = fmaxf(m.b[e], 0.f);
+          }
+        }
+        if (j >= 1 && j <= R) {
+          const long row = prow * Wo + ox;
+          if (out) store8(out + (row * C8 + c8) * 8, m);
+          if (out_hl) store_hl(out_hl, row, C, c8, m);
+        }
+        d[j] = m;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[j].a[e] = d[j].b[e] = 0.f;
+      }
+    }
+    F8 m_[NC];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      auto D = [&](int j) { return e < 4 ? d[j].a[e] : d[j].b[e - 4]; };
+      float r_[NC];
+      if constexpr (R == 2) {
+        r_[0] = D(0) - D(2);
+        r_[1] = D(1) + D(2);
+        r_[2] = D(2) - D(1);
+        r_[3] = D(1) - D(3);
+      } else {
+        r_[0] = 4.f * D(0) - 5.f * D(2) + D(4);
+        r_[1] = -4.f * (D(1) + D(2)) + D(3) + D(4);
+        r_[2] = 4.f * (D(1) - D(2)) - D(3) + D(4);
+        r_[3] = 2.f * (D(3) - D(1)) - D(2) + D(4);
+        r_[4] = 2.f * (D(1) - D(3)) - D(2) + D(4);
+        r_[5] = 4.f * D(1) - 5.f * D(3) + D(5);
+      }
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        if (e < 4) m_[k].a[e] = r_[k];
+        else m_[k].b[e - 4] = r_[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NC; ++k) store_hl(out_v, t * NC + k, C, c8, m_[k]);
+  }
+}
+
 // SVTR mixing blocks of G lock-step experts (modules/svtr.py:200-204, :298-305): t = x + drop[r / rows_per_drop] * branch
 // (the DropPath-scaled residual add of the PREVIOUS half block; branch NULL: t = x), optionally written back as the new
 // fp32 residual stream, then y = LayerNorm(t; gamma[g], beta[g]) with g = r / rows_per_group (gamma NULL: y = t), written
@@ -479,6 +579,31 @@ MRN_EXPORT int mrn_maxpool_grouped_f32(const float* x, const float* scale, const
   hipLaunchKernelGGL(maxpool_grouped_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, scale, shift, out_f32,
                      (unsigned char*)out_hl32, relu, B, n8, H, W, C, Ho, Wo, kh, kw, sh, sw, ph, pw);
   MRN_LAUNCH_CHECK("maxpool_grouped");
+  return MRN_OK;
+}
+
+// mrn_maxpool_grouped_f32 as the producer of a Winograd F(R,3) convolution: out_wino [G][B][Ho][ceil(Wo/R)][R+2][C/32][128 B]
+// receives B^T applied to the pooled map per group of R pooled columns (zero padding outside the row); out_f32 / out_hl32 optionally
+// the plain pooled result (C % 32 == 0)
+MRN_EXPORT int mrn_maxpool_wino_grouped_f32(const float* x, const float* scale, const float* shift, int relu, float* out_f32,
+                                            void* out_hl32, void* out_wino, int G, int B, int H, int W, int C, int kh, int kw, int sh,
+                                            int sw, int ph, int pw, int R, void* stream) {
+  MRN_CHECK_ARG(x && out_wino && C % 32 == 0 && (!scale == !shift) && (R == 2 || R == 4) && (uintptr_t)out_wino % 128 == 0,
+                "mrn_maxpool_wino_grouped_f32: bad operands (C=%d R=%d)", C, R);
+  const int Ho = (H + 2 * ph - kh) / sh + 1, Wo = (W + 2 * pw - kw) / sw + 1;
+  MRN_CHECK_ARG(Ho > 0 && Wo > 0, "mrn_maxpool_wino_grouped_f32: empty output");
+  const int Wq = (Wo + R - 1) / R;
+  const long n8 = (long)G * B * Ho * Wq * (C / 8);
+  if (n8 == 0) return MRN_OK;
+  long grid = (n8 + 255) / 256;
+  if (grid > 32768) grid = 32768;
+  if (R == 4)
+    hipLaunchKernelGGL(maxpool_wino_grouped_kernel<4>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, scale, shift, out_f32,
+                       (unsigned char*)out_hl32, (unsigned char*)out_wino, relu, B, n8, H, W, C, Ho, Wo, Wq, kh, kw, sh, sw, ph, pw);
+  else
+    hipLaunchKernelGGL(maxpool_wino_grouped_kernel<2>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, scale, shift, out_f32,
+                       (unsigned char*)out_hl32, (unsigned char*)out_wino, relu, B, n8, H, W, C, Ho, Wo, Wq, kh, kw, sh, sw, ph, pw);
+  MRN_LAUNCH_CHECK("maxpool_wino_grouped");
   return MRN_OK;
 }
 

@@ -225,6 +225,10 @@ class BackboneGroup(_GroupedLinear):
         post_relu = relu and not fuse_act
         if pool is not None:
             assert res is None and res_hl is None
+            if want_wino:
+                f32, hl, v, (Hp, Wp) = ops.maxpool_wino_grouped(y, pool[0], pool[1], pool[2], want_wino, scale, shift, relu=post_relu,
+                                                                want_f32=want_f32, want_hl=want_hl)
+                return Act((G, B, Hp, Wp, Cout), f32, hl, wino=v, wino_R=want_wino)
             f32, hl, (Hp, Wp) = ops.maxpool_grouped(y, pool[0], pool[1], pool[2], scale, shift, relu=post_relu,
                                                     want_f32=want_f32, want_hl=want_hl)
             return Act((G, B, Hp, Wp, Cout), f32, hl)
@@ -295,9 +299,11 @@ class BackboneGroup(_GroupedLinear):
         x = self.layer(x, [n.conv0_1 for n in nets], [n.bn0_1 for n in nets])
         x = self.layer(x, [n.conv0_2 for n in nets], [n.bn0_2 for n in nets], pool=p22, want_f32=first_block_identity("layer1"))
         x = stage(x, "layer1", "conv1", "bn1")
-        x = self.layer(x, [n.conv1 for n in nets], [n.bn1 for n in nets], pool=p22, want_f32=first_block_identity("layer2"))
+        x = self.layer(x, [n.conv1 for n in nets], [n.bn1 for n in nets], pool=p22, want_f32=first_block_identity("layer2"),
+                       want_wino=first_wino("layer2"))
         x = stage(x, "layer2", "conv2", "bn2")
-        x = self.layer(x, [n.conv2 for n in nets], [n.bn2 for n in nets], pool=p2_21, want_f32=first_block_identity("layer3"))
+        x = self.layer(x, [n.conv2 for n in nets], [n.bn2 for n in nets], pool=p2_21, want_f32=first_block_identity("layer3"),
+                       want_wino=first_wino("layer3"))
         x = stage(x, "layer3", "conv3", "bn3")
         x = self.layer(x, [n.conv3 for n in nets], [n.bn3 for n in nets], want_f32=first_block_identity("layer4"),
                        want_wino=first_wino("layer4"))

@@ -704,6 +704,19 @@ def maxpool_grouped(x, kernel, stride, padding, scale=None, shift=None, relu=Fal
     return out, out_hl, (Ho, Wo)
 
 
+def maxpool_wino_grouped(x, kernel, stride, padding, R, scale=None, shift=None, relu=False, want_f32=False, want_hl=False):
+    """x [G,B,H,W,C] -> (fp32 [G,B,Ho,Wo,C] or None, HL32 bytes or None, Winograd-domain operand bytes of the pooled map, (Ho, Wo))"""
+    G, B, H, W, C = x.shape
+    Ho, Wo = conv_out_hw(H, W, kernel, stride, padding)
+    Wq = (Wo + R - 1) // R
+    out = torch.empty(G, B, Ho, Wo, C, device=x.device, dtype=torch.float32) if want_f32 else None
+    out_hl = torch.empty(G * B * Ho * Wo * C * 4, device=x.device, dtype=torch.uint8) if want_hl else None
+    v = torch.empty(G * B * Ho * Wq * (R + 2) * C * 4, device=x.device, dtype=torch.uint8)
+    call("mrn_maxpool_wino_grouped_f32", _p(x), _p(scale), _p(shift), int(bool(relu)), _p(out), _p(out_hl), _p(v), G, B, H, W, C,
+         kernel[0], kernel[1], stride[0], stride[1], padding[0], padding[1], R, _stream())
+    return out, out_hl, v, (Ho, Wo)
+
+
 def bn_finalize(stats, C, count, gamma, beta, running_mean, running_var, momentum, eps, save=False):
     dev = stats.device
     scale = torch.empty(C, device=dev, dtype=torch.float32)

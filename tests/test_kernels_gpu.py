@@ -931,3 +931,17 @@ def test_trained_conv_winograd_range_safe(ops, B, H, W, Cin, Cout, magnitude):
     assert float((y.cpu().double() - ref).abs().max()) <= 1e-5 * scale
     tot = stats.view(-1, 2, Cout).sum(0)
     assert_close("fused column sums", tot[0] / scale, (ref.sum((0, 1, 2)) / scale).float(), atol=2e-3, rtol=1e-4)
+
+
+@pytest.mark.parametrize("G,B,H,W,C,pool", [(2, 3, 8, 128, 64, ((2, 2), (2, 2), (0, 0))), (3, 2, 8, 64, 32, ((2, 2), (2, 1), (0, 1))),
+                                            (1, 2, 4, 18, 64, ((2, 1), (2, 1), (0, 0)))])
+def test_maxpool_winograd_producer(ops, G, B, H, W, C, pool):
+    """mrn_maxpool_wino_grouped_f32 (BatchNorm-apply + ReLU + MaxPool2d + Winograd input transform in one pass) against the two-pass
+    form: mrn_maxpool_grouped_f32, then the transform of the pooled map by mrn_bn_apply_wino_grouped_f32 -- bit-identical operands"""
+    x = cu(rnd(G, B, H, W, C, seed=500))
+    scale, shift = cu(rnd(G, C, seed=501) + 1.5), cu(rnd(G, C, seed=502) * 0.5)
+    pf, ph, _ = ops.maxpool_grouped(x, pool[0], pool[1], pool[2], scale, shift, relu=True, want_f32=True, want_hl=True)
+    _, _, v_ref = ops.bn_apply_wino_grouped(pf, None, None, 4, relu=False)
+    f32, hl, v, (Ho, Wo) = ops.maxpool_wino_grouped(x, pool[0], pool[1], pool[2], 4, scale, shift, relu=True, want_f32=True, want_hl=True)
+    assert (Ho, Wo) == tuple(pf.shape[2:4])
+    assert torch.equal(f32, pf) and torch.equal(hl, ph) and torch.equal(v, v_ref)
