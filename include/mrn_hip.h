@@ -366,6 +366,13 @@ int mrn_softmax_rows_bwd_f32(const float* p, float* dp, int64_t rows, int N, voi
 int mrn_add_layernorm_grouped_f32(const float* x, const float* branch, const float* drop, int64_t rows_per_drop,
                                   const float* gamma, const float* beta, int64_t rows_per_group, float* sum_out, float* y_f32,
                                   void* y_hl32, int64_t rows, int C, float eps, void* stream);
+/* The Mlp of an SVTR mixing block (modules/svtr.py:46-67: fc1 -> GELU -> fc2) of G lock-step experts in ONE kernel, split-fp16 x3
+ * products, the 4C-wide hidden activation kept in registers (chained MFMAs on the transposed problem, tokens on the N axis; the fc2
+ * weights come with the hidden index of every 32-block permuted to the MFMA result layout: position 16 s + 8 h + j holds unit
+ * (j & 3) + 8 (2 s + (j >> 2)) + 4 h).  x_hl [rows][C/32][128 B] = the HL32 LayerNorm output; w1_hl [G][4C][C/32][128 B], w2_hl
+ * [G][C][4C/32][128 B] (mrn_pack_weight_hl32), s1 / s2 [G][2] their prescales, b1 [G][4C], b2 [G][C]; y [rows][C] fp32.  C = 64 | 128. */
+int mrn_svtr_mlp_x3_f32(const void* x_hl, const void* w1_hl, const float* s1, const float* b1, const void* w2_hl, const float* s2,
+                        const float* b2, float* y, int64_t rows, int64_t rows_per_group, int G, int C, void* stream);
 /* Fused multi-head attention of the SVTR mixing blocks (head dimension 32), inference path of the frozen experts:
  * out[b][n][h*32 + :] = softmax_m(scale * q[b][n][h] . k[b][m][h] + mask[n][m]) @ v[b][m][h]; qkv [B][N][3*C] (q | k | v,
  * C = heads * 32), mask [N][N] additive and SYMMETRIC (SVTR's local window mask) or NULL, out [B][N][C] fp32 and / or

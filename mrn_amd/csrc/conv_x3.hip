@@ -480,6 +480,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
         for (int j = 0; j < WN; ++j) acc[i][j] = mma(ah[ks][i], bh[ks][j], acc[i][j]);
     };
     issue_next(lds);
+    __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));   // vmcnt(0)
     __syncthreads();
     read_frags(lds, 0);
     issue_next(lds + STAGE);
@@ -487,7 +488,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
     mmas(0);
     mmas_cross(1);
     for (int kt = 1; kt < nk; ++kt) {
-      __syncthreads();      // own DMAs of tile kt retired (vmcnt(0)) + everyone has read both halves of tile kt-1's stage
+      __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));   // own DMAs of tile kt retired: vmcnt(0), spelled out (hipcc may drop it from __syncthreads())
+      __syncthreads();      // ... + everyone has read both halves of tile kt-1's stage
       const unsigned char* cur = lds + (kt & 1) * STAGE;
       read_frags(cur, 0);
       issue_next(lds + ((kt + 1) & 1) * STAGE);
@@ -497,19 +499,22 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
       mmas_cross(1);
     }
     mmas_hh(1);
+    __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));   // vmcnt(0): the re-fetched tail tile has landed before the epilogue reuses LDS
   } else {
     // 8-wave variants: the MFMAs are skewed by half a K-step against the barrier -- when a wave leaves the barrier of tile
     // kt it still owes the second half (ks = 1) of tile kt-1, whose fragments are already in registers, so the burst of
     // fragment reads that all waves issue right after the barrier is covered by MFMAs instead of starving the matrix pipes
     // (128x128 tile 311 -> 335 TFLOP/s, 256x64 186 -> 194, 8-wave 256x256 438 -> 454).
     issue_next(lds);
+    __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));   // vmcnt(0)
     __syncthreads();
     read_frags(lds, 0);
     issue_next(lds + STAGE);
     read_frags(lds, 1);
     mmas(0);
     for (int kt = 1; kt < nk; ++kt) {
-      __syncthreads();      // own DMAs of tile kt retired (vmcnt(0)) + everyone has read both halves of tile kt-1's stage
+      __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));   // own DMAs of tile kt retired: vmcnt(0), spelled out (hipcc may drop it from __syncthreads())
+      __syncthreads();      // ... + everyone has read both halves of tile kt-1's stage
       const unsigned char* cur = lds + (kt & 1) * STAGE;
       read_frags(cur, 0);
       issue_next(lds + ((kt + 1) & 1) * STAGE);
@@ -518,6 +523,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
       mmas(0);
     }
     mmas(1);
+    __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));   // vmcnt(0): the re-fetched tail tile has landed before the epilogue reuses LDS
   }
 
   // ---- epilogue: scale, bias, BatchNorm partial statistics, activation, store ------------------------------
@@ -577,7 +583,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
     }
   }
   if (p.stats) {
-    __syncthreads();      // (also drains any DMA still in flight: vmcnt(0))
+    __syncthreads();      // (every main-loop variant has drained its DMAs with an explicit vmcnt(0) before the epilogue)
     float* red = reinterpret_cast<float*>(lds);   // [WAVES_M][2][BN]
 #pragma unroll
     for (int j = 0; j < WN; ++j) {

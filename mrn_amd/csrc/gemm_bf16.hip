@@ -365,7 +365,8 @@ __global__ __launch_bounds__(NT) void conv_bf16_dma_kernel(const GemmParams p, c
 
   const int nk = p.K / BKB;
   issue_tile(0, lds);
-  __syncthreads();          // drains the DMA queue (vmcnt(0)) before the barrier releases
+  __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));   // vmcnt(0), spelled out: hipcc may drop the DMA wait from __syncthreads()
+  __syncthreads();
 
   const int ra_ = wm * 64 + (lane & 31), rb_ = wn * 64 + (lane & 31);
   for (int kt = 0; kt < nk; ++kt) {
@@ -397,6 +398,7 @@ __global__ __launch_bounds__(NT) void conv_bf16_dma_kernel(const GemmParams p, c
           acc[i][j] = mma16<HALF>(ah[i], bh[j], acc[i][j]);
         }
     }
+    __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));   // own DMAs of the next tile have landed (vmcnt(0))
     __syncthreads();
   }
 

@@ -1,0 +1,224 @@
+// Fused Mlp of an SVTR mixing block for G lock-step frozen experts (reference modules/svtr.py:46-67: fc1 -> GELU -> fc2), one kernel,
+// the 4C-wide hidden activation never leaves the registers.
+//
+// Arithmetic is the grouped Linear path's (conv_x3.hip): split-fp16 x3 products (lo*hi + hi*lo + hi*hi, 22 significand bits) on
+// v_mfma_f32_32x32x16_f16 with fp32 accumulation, weights prescaled by a per-tensor power of two, bias and GELU in fp32, the hidden
+// activation re-split to hi + lo before the second product.
+//
+// Formulation: everything is computed TRANSPOSED, tokens on the MFMA N axis.  A wave owns 32 tokens; their C input channels sit in
+// registers as the B operand for the whole kernel.  For every block of 32 hidden units
+//     H^T[32 hidden x 32 tokens] = W1[32 x C] . X^T[C x 32]          (A = W1 rows from LDS, B = the token fragments)
+// lands in the MFMA result layout: lane = token (lane & 31), register e = hidden unit (e & 3) + 8 (e >> 2) + 4 (lane >> 5).  The B
+// operand of the second product needs, per lane, 8 consecutive reduction indices -- and registers e = 8s .. 8s+7 ARE a valid set of 8
+// if the reduction index of fc2 is permuted accordingly (position p = 16 s + 8 h + j of a 32-unit block <-> unit (j & 3) + 8 (2 s + (j >> 2)) + 4 h).
+// So bias + GELU + hi/lo split happen in place and the registers feed
+//     Y^T[C x 32 tokens] += W2'[C x 32 hidden] . H^T                  (A = permuted W2 rows from LDS, B = the registers just written)
+// without any cross-lane movement or LDS round trip of the hidden tensor: the chained-MFMA form.  The 8 waves of a workgroup (256
+// tokens) share the weight slabs of a hidden block (W1: 32 rows x C, W2': C rows x 32) through a double-buffered LDS ring filled by
+// direct-to-LDS DMA; the weights of one expert (8 C^2 x 4 bytes: 128 KiB at C = 64, 512 KiB at C = 128) are re-read per 256 tokens from L2.
+// HBM traffic: the HL32 input once (4 B / element), the fp32 branch output once -- against 10 x that for fc1 and fc2 as two GEMMs.
+// C = 64 and 128 (SVTR stages 1 and 2): at C = 256 the token fragments (128 registers) and the output accumulators (128) do not fit.
+#include "common.hpp"
+
+namespace {
+
+typedef _Float16 f16v8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+struct MlpParams {
+  const unsigned char* x_hl;      // [rows][C/32][128 B] LayerNorm output (HL32)
+  const unsigned char* w1;        // [G][4C][C/32][128 B]
+  const unsigned char* w2;        // [G][C][4C/32][128 B], hidden index permuted inside every 32-block (see above)
+  const float* b1;                // [G][4C]
+  const float* b2;                // [G][C]
+  const float* s1;                // [G][2] {s, 1/s} of W1
+  const float* s2;                // [G][2]
+  float* y;                       // [rows][C]
+  long rows, rows_per_group;
+  int tiles_per_group;
+};
+
+__device__ __forceinline__ f32x16 mma(const u32x4 a, const u32x4 b, const f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16v8*>(&a), *reinterpret_cast<const f16v8*>(&b), c, 0, 0, 0);
+}
+
+template <int C>
+__global__ __launch_bounds__(512) void svtr_mlp_kernel(const MlpParams p) {
+  constexpr int NW = 8, CB = C / 32, KB = C / 16, HID = 4 * C, NH = HID / 32, OC = C / 32;
+  constexpr int W1_SLAB = CB * 32 * 128;            // 32 hidden rows x C channels, [channel block][row][128 B]
+  constexpr int W2_SLAB = C * 128;                  // C output rows x one 32-hidden line
+  constexpr int SLAB = W1_SLAB + W2_SLAB;
+  constexpr int N1 = W1_SLAB / 1024, N2 = W2_SLAB / 1024;        // 1-KiB DMA instructions per slab part
+  static_assert((N1 + N2) % NW == 0, "slab DMA instructions divide over the waves");
+  constexpr int NDMA = (N1 + N2) / NW;
+  extern __shared__ __attribute__((aligned(128))) unsigned char lds[];
+  float* b1_lds = reinterpret_cast<float*>(lds + 2 * SLAB);     // [HID]
+
+  const int g = blockIdx.x / p.tiles_per_group, tile = blockIdx.x % p.tiles_per_group;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int half = lane >> 5, tok_l = lane & 31;
+  const long row0 = (long)g * p.rows_per_group + (long)tile * 256 + wave * 32;
+  const long row_end = min((long)(g + 1) * p.rows_per_group, p.rows);
+  const long row = row0 + tok_l;
+  const bool ok = row < row_end;
+
+  // ---- this wave's tokens as MFMA B-operand fragments: k-block kb (16 channels) = 16-byte chunk (kb & 1) * 2 + half of the hi / lo
+  // half-line of channel block kb >> 1
+  u32x4 xh[KB], xl[KB];
+  {
+    const unsigned char* xr = p.x_hl + row * (long)CB * 128;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const int off = (kb >> 1) * 128 + (((kb & 1) * 2 + half) << 4);
+      xh[kb] = ok ? *reinterpret_cast<const u32x4*>(xr + off) : u32x4{0u, 0u, 0u, 0u};
+      xl[kb] = ok ? *reinterpret_cast<const u32x4*>(xr + off + 64) : u32x4{0u, 0u, 0u, 0u};
+    }
+  }
+  for (int i = t; i < HID; i += 512) b1_lds[i] = p.b1[(long)g * HID + i];
+
+  // ---- weight slabs through LDS: DMA instruction d (0 .. N1+N2-1) moves 8 rows x 128 B; lane -> row 8 d' + lane / 8, chunk lane & 7,
+  // source chunk XOR-swizzled with (row >> 1) & 7 as in conv_x3.hip (conflict-free ds_read_b128 fragment reads)
+  const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w1 + (long)g * HID * CB * 128), 0, HID * CB * 128, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w2 + (long)g * C * NH * 128), 0, C * NH * 128, 0x00020000);
+  auto issue = [&](int hs, unsigned char* buf) {
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) {
+      const int d = i * NW + wave;
+      if (d < N1) {                                 // W1: LDS [cb][32 rows]; source row = hs * 32 + r, line cb
+        const int cb = d / 4, r = (d % 4) * 8 + (lane >> 3);
+        const int coff = ((lane & 7) ^ ((r >> 1) & 7)) << 4;
+        const int voff = ((hs * 32 + r) * CB + cb) * 128 + coff;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_ptr_t)(buf + d * 1024), 16, voff, 0, 0, 0);
+      } else {                                      // W2': LDS [C rows]; source row r, line hs
+        const int d2 = d - N1, r = d2 * 8 + (lane >> 3);
+        const int coff = ((lane & 7) ^ ((r >> 1) & 7)) << 4;
+        const int voff = (r * NH + hs) * 128 + coff;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r2, (lds_ptr_t)(buf + W1_SLAB + d2 * 1024), 16, voff, 0, 0, 0);
+      }
+    }
+  };
+  // fragment read offsets inside a 32-row block: row = lane & 31, logical chunk = plane * 4 + ks * 2 + half, swizzled
+  const int key = (lane >> 1) & 7;
+  int foff[2][2];
+#pragma unroll
+  for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) foff[pl][ks] = tok_l * 128 + (((pl * 4 + ks * 2 + half) ^ key) << 4);
+
+  f32x16 out[OC];
+#pragma unroll
+  for (int o = 0; o < OC; ++o)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) out[o][e] = 0.f;
+  const float inv1 = p.s1 ? p.s1[g * 2 + 1] : 1.f, inv2 = p.s2 ? p.s2[g * 2 + 1] : 1.f;
+
+  issue(0, lds);
+  for (int hs = 0; hs < NH; ++hs) {
+    // own DMAs of slab hs retired -- spelled out: hipcc drops the vmcnt wait of __syncthreads() here (LDS-DMA is not a load it
+    // orders behind the barrier; seen as stale slabs in 1 of ~10^4 workgroups at two workgroups per CU) -- then everyone's have, and
+    // everyone is done with the other buffer
+    __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));              // vmcnt(0)
+    __syncthreads();
+    const unsigned char* cur = lds + (hs & 1) * SLAB;
+    if (hs + 1 < NH) issue(hs + 1, lds + ((hs + 1) & 1) * SLAB);
+    // ---- fc1 for 32 hidden units
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const unsigned char* blk = cur + (kb >> 1) * 4096;
+      const u32x4 wl = *reinterpret_cast<const u32x4*>(blk + foff[1][kb & 1]);
+      const u32x4 wh = *reinterpret_cast<const u32x4*>(blk + foff[0][kb & 1]);
+      acc = mma(wh, xl[kb], acc);                   // (x_lo * w_hi, x_hi * w_lo, x_hi * w_hi: the order of conv_x3.hip)
+      acc = mma(wl, xh[kb], acc);
+      acc = mma(wh, xh[kb], acc);
+    }
+    // ---- bias, GELU, split: registers 8 s .. 8 s + 7 become the B operand of k half s of the second product
+    u32x4 hh[2], hl[2];
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+      f16v8 vh, vl;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int e = s_ * 8 + j;
+        const int unit = (e & 3) + 8 * (e >> 2) + 4 * half;
+        const float v = gelu_fast(acc[e] * inv1 + b1_lds[hs * 32 + unit]);
+        _Float16 a, b;
+        split_f16(v, a, b);
+        vh[j] = a;
+        vl[j] = b;
+      }
+      hh[s_] = __builtin_bit_cast(u32x4, vh);
+      hl[s_] = __builtin_bit_cast(u32x4, vl);
+    }
+    // ---- fc2 partial sums over these 32 hidden units
+    const unsigned char* w2b = cur + W1_SLAB;
+#pragma unroll
+    for (int o = 0; o < OC; ++o) {
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) {
+        const u32x4 wl = *reinterpret_cast<const u32x4*>(w2b + o * 4096 + foff[1][s_]);
+        const u32x4 wh = *reinterpret_cast<const u32x4*>(w2b + o * 4096 + foff[0][s_]);
+        out[o] = mma(wh, hl[s_], out[o]);
+        out[o] = mma(wl, hh[s_], out[o]);
+        out[o] = mma(wh, hh[s_], out[o]);
+      }
+    }
+  }
+  // ---- epilogue: registers 4 k .. 4 k + 3 of an output block are channels 32 o + 8 k + 4 half + 0 .. 3 of token lane & 31
+  if (ok) {
+    float* yr = p.y + row * C;
+#pragma unroll
+    for (int o = 0; o < OC; ++o)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = o * 32 + 8 * k + 4 * half;
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.b2 + (long)g * C + c);
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = out[o][4 * k + j] * inv2 + b[j];
+        *reinterpret_cast<f32x4*>(yr + c) = v;
+      }
+  }
+}
+
+template <int C>
+int launch_mlp(const MlpParams& p, int G, hipStream_t st) {
+  constexpr size_t ldsz = 2 * ((C / 32) * 32 * 128 + C * 128) + 4 * C * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)svtr_mlp_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((svtr_mlp_kernel<C>), dim3((unsigned)(G * p.tiles_per_group)), dim3(512), ldsz, st, p);
+  MRN_LAUNCH_CHECK("svtr_mlp_x3");
+  return MRN_OK;
+}
+
+}  // namespace
+
+// y[r] = fc2(GELU(fc1(x[r]))) for the rows of G lock-step experts (group = r / rows_per_group), SVTR Mlp (modules/svtr.py:46-67).
+//   x_hl  [rows][C/32][128 B]            HL32 input (the LayerNorm output of mrn_add_layernorm_grouped_f32)
+//   w1_hl [G][4C][C/32][128 B]           fc1 weights, mrn_pack_weight_hl32 of [4C][1][C]; s1 [G][2] their {s, 1/s}; b1 [G][4C]
+//   w2_hl [G][C][4C/32][128 B]           fc2 weights packed from [C][1][4C] with the hidden index of every 32-block permuted:
+//                                        position p = 16 s + 8 h + j holds unit (j & 3) + 8 (2 s + (j >> 2)) + 4 h; s2, b2 [G][C]
+//   y     [rows][C] fp32
+// C = 64 or 128.
+MRN_EXPORT int mrn_svtr_mlp_x3_f32(const void* x_hl, const void* w1_hl, const float* s1, const float* b1, const void* w2_hl,
+                                   const float* s2, const float* b2, float* y, int64_t rows, int64_t rows_per_group, int G, int C,
+                                   void* stream) {
+  MRN_CHECK_ARG(x_hl && w1_hl && w2_hl && b1 && b2 && y && G >= 1 && rows_per_group >= 1 && rows <= (int64_t)G * rows_per_group,
+                "mrn_svtr_mlp_x3_f32: bad operands");
+  MRN_CHECK_ARG(C == 64 || C == 128, "mrn_svtr_mlp_x3_f32: C must be 64 or 128 (got %d)", C);
+  MRN_CHECK_ARG((uintptr_t)x_hl % 128 == 0 && (uintptr_t)w1_hl % 128 == 0 && (uintptr_t)w2_hl % 128 == 0 && (uintptr_t)y % 16 == 0,
+                "mrn_svtr_mlp_x3_f32: operands must be 128-byte (HL32) / 16-byte (y) aligned");
+  if (rows == 0) return MRN_OK;
+  MlpParams p;
+  p.x_hl = (const unsigned char*)x_hl; p.w1 = (const unsigned char*)w1_hl; p.w2 = (const unsigned char*)w2_hl;
+  p.b1 = b1; p.b2 = b2; p.s1 = s1; p.s2 = s2; p.y = y;
+  p.rows = rows; p.rows_per_group = rows_per_group;
+  p.tiles_per_group = (int)((rows_per_group + 255) / 256);
+  return C == 64 ? launch_mlp<64>(p, G, (hipStream_t)stream) : launch_mlp<128>(p, G, (hipStream_t)stream);
+}

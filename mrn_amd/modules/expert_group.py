@@ -124,8 +124,8 @@ class BackboneGroup(_GroupedLinear):
     @staticmethod
     def wino_for(conv, bns):
         """R of the Winograd form this conv would run in when its input arrives as a Winograd-domain operand, else 0: 3x3 / stride 1
-        / pad 1, wide enough, and followed by a train-mode BatchNorm (the eval-mode fold keeps its one-launch direct form)"""
-        if bns is None or not bns[0].training:
+        / pad 1, wide enough, and NOT followed by an eval-mode BatchNorm (that fold keeps its one-launch direct form)"""
+        if bns is not None and not bns[0].training:
             return 0
         ok = ops.wino_eligible(_pair(conv.kernel_size), _pair(conv.stride), _pair(conv.padding), conv.in_channels, conv.out_channels)
         return ops.WINO_R if ok else 0
@@ -315,15 +315,19 @@ class BackboneGroup(_GroupedLinear):
         nets = [e.FeatureExtraction.ConvNet for e in self.experts]
         p22, p21 = ((2, 2), (2, 2), (0, 0)), ((2, 1), (2, 1), (0, 0))
 
-        def L(x, i, bn=None, pool=None, last=False):
+        def L(x, i, bn=None, pool=None, last=False, nxt=None):
+            """nxt = (conv index, bn index or None) of the layer that consumes the result: decides the operand form it is written in"""
+            ww = 0
+            if nxt is not None:
+                ww = self.wino_for(nets[0][nxt[0]], None if nxt[1] is None else [n[nxt[1]] for n in nets])
             return self.layer(x, [n[i] for n in nets], None if bn is None else [n[bn] for n in nets], pool=pool,
-                              want_f32=last and not last_hl, want_hl=not last or last_hl)
-        x = L(x, 0, pool=p22)
-        x = L(x, 3, pool=p22)
-        x = L(x, 6)
-        x = L(x, 8, pool=p21)
-        x = L(x, 11, bn=12)
-        x = L(x, 14, bn=15, pool=p21)
+                              want_f32=last and not last_hl, want_hl=(not last or last_hl) and not ww, want_wino=ww)
+        x = L(x, 0, pool=p22, nxt=(3, None))
+        x = L(x, 3, pool=p22, nxt=(6, None))
+        x = L(x, 6, nxt=(8, None))
+        x = L(x, 8, pool=p21, nxt=(11, 12))
+        x = L(x, 11, bn=12, nxt=(14, 15))
+        x = L(x, 14, bn=15, pool=p21, nxt=(18, None))
         return L(x, 18, last=True)
 
     # ---- SVTR: tokens [G*B, N, C] fp32 residual stream, every Linear one grouped x3 GEMM ------------------------------------
@@ -366,10 +370,23 @@ class BackboneGroup(_GroupedLinear):
         drop2 = self._drop_scales(blks, B, x.device)
         g2, b2 = self._ln_params(name + ".ln2", [b.norm2 for b in blks])
         x, _, y_hl = ops.add_layernorm_grouped(x, br.view(G * B, N, C), drop1, N, g2, b2, rows, b0.norm2.eps, want_sum=True)
+        Ch = blks[0].mlp.fc1.out_features
+        if ops.SVTR_FUSED_MLP and C in (64, 128) and Ch == 4 * C and ops.X3_PRODUCTS == 3:
+            # fc1 -> GELU -> fc2 in one kernel: the 4C-wide hidden tensor stays in registers (csrc/svtr_mlp.hip)
+            fc1s, fc2s = [b.mlp.fc1 for b in blks], [b.mlp.fc2 for b in blks]
+
+            def build():
+                w1, s1 = ops.pack_weights_hl32([m.weight.detach().contiguous().view(Ch, 1, 1, C) for m in fc1s])
+                perm = ops.mlp_hidden_permutation(Ch, x.device)
+                w2, s2 = ops.pack_weights_hl32([m.weight.detach().index_select(1, perm).contiguous().view(C, 1, 1, Ch) for m in fc2s])
+                return (w1, s1, torch.stack([m.bias.detach() for m in fc1s]).contiguous(), w2, s2,
+                        torch.stack([m.bias.detach() for m in fc2s]).contiguous())
+            w1, s1, b1_, w2, s2, b2_ = self._cached(name + ".mlp", [t_ for m in fc1s + fc2s for t_ in (m.weight, m.bias)], build)
+            br = ops.svtr_mlp_fused(y_hl, G * rows, rows, G, C, w1, s1, b1_, w2, s2, b2_)
+            return x, (br.view(G * B, N, C), drop2)
         # fc1 + GELU lands straight in the HL32 layout fc2 reads: the 4C-wide hidden tensor crosses HBM once each way
         hdn_hl = self._linear(name + ".fc1", y_hl, rows, C, [b.mlp.fc1.weight for b in blks], [b.mlp.fc1.bias for b in blks],
                               act=ops.ACT_GELU, hl_only=True)
-        Ch = blks[0].mlp.fc1.out_features
         br = self._linear(name + ".fc2", hdn_hl, rows, Ch, [b.mlp.fc2.weight for b in blks], [b.mlp.fc2.bias for b in blks])
         return x, (br.view(G * B, N, C), drop2)
 

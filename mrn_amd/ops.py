@@ -1440,6 +1440,37 @@ def add_layernorm_grouped(x, branch=None, drop=None, rows_per_drop=1, gamma=None
     return t, y, hl
 
 
+SVTR_FUSED_MLP = os.environ.get("MRN_SVTR_MLP", "fused") == "fused"     # fc1 -> GELU -> fc2 of the frozen SVTR experts in one kernel (C <= 128)
+_MLP_PERM = {}
+
+
+def mlp_hidden_permutation(hidden, device):
+    """index tensor P with packed_w2[:, p] = w2[:, P[p]]: inside every 32-block, position 16 s + 8 h + j holds unit
+    (j & 3) + 8 (2 s + (j >> 2)) + 4 h -- the order in which the MFMA result registers of fc1 present the hidden units to fc2"""
+    key = (hidden, device)
+    got = _MLP_PERM.get(key)
+    if got is None:
+        idx = []
+        for blk in range(hidden // 32):
+            for pos in range(32):
+                s_, h, j = pos >> 4, (pos >> 3) & 1, pos & 7
+                idx.append(blk * 32 + (j & 3) + 8 * (2 * s_ + (j >> 2)) + 4 * h)
+        got = torch.tensor(idx, dtype=torch.int64, device=device)
+        _MLP_PERM[key] = got
+    return got
+
+
+def svtr_mlp_fused(x_hl, rows, rows_per_group, G, C, w1_hl, s1, b1, w2_hl, s2, b2):
+    """y [rows, C] = fc2(GELU(fc1(x))) per group (mrn_svtr_mlp_x3_f32); w2_hl packed from the hidden-permuted fc2 weights"""
+    y = torch.empty(rows, C, device=x_hl.device, dtype=torch.float32)
+    t0 = CONV_TIMER.begin() if CONV_TIMER is not None else None
+    call("mrn_svtr_mlp_x3_f32", _p(x_hl), _p(w1_hl), _p(s1), _p(b1), _p(w2_hl), _p(s2), _p(b2), _p(y), rows, rows_per_group, G, C,
+         _stream())
+    if t0 is not None:
+        CONV_TIMER.end(t0, 2.0 * 2 * rows * C * 4 * C, "fp16x3/svtrmlp", 4.0 * (2 * rows * C + 2 * G * 4 * C * C))
+    return y
+
+
 def residual_scale_rows(x, branch, scale, rows_per_group, out=None):
     """x + scale[group] * branch on [rows, C] (contiguous)"""
     assert x.is_contiguous() and branch.is_contiguous()

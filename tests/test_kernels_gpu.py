@@ -945,3 +945,51 @@ def test_maxpool_winograd_producer(ops, G, B, H, W, C, pool):
     f32, hl, v, (Ho, Wo) = ops.maxpool_wino_grouped(x, pool[0], pool[1], pool[2], 4, scale, shift, relu=True, want_f32=True, want_hl=True)
     assert (Ho, Wo) == tuple(pf.shape[2:4])
     assert torch.equal(f32, pf) and torch.equal(hl, ph) and torch.equal(v, v_ref)
+
+
+@pytest.mark.parametrize("C,G,rows_pg", [(64, 3, 700), (128, 2, 515), (64, 1, 256), (128, 6, 31)])
+def test_svtr_fused_mlp_matches_two_gemms(ops, C, G, rows_pg):
+    """mrn_svtr_mlp_x3_f32 (fc1 -> GELU -> fc2 of G experts in one kernel, hidden activation in registers, chained MFMAs on the
+    transposed problem with the hidden-permuted fc2 weights) against torch float64 and against the two grouped x3 GEMMs it replaces"""
+    Ch = 4 * C
+    x = rnd(G * rows_pg, C, seed=600) * 2
+    w1 = [rnd(Ch, C, seed=601 + g, scale=(1.0 / C) ** 0.5) for g in range(G)]
+    w2 = [rnd(C, Ch, seed=611 + g, scale=(1.0 / Ch) ** 0.5) for g in range(G)]
+    b1, b2 = rnd(G, Ch, seed=620) * 0.2, rnd(G, C, seed=621) * 0.2
+    xd = x.double().view(G, rows_pg, C)
+    ref = torch.stack([F.gelu(xd[g] @ w1[g].double().t() + b1[g].double()) @ w2[g].double().t() + b2[g].double() for g in range(G)])
+    x_hl = ops.split_hl32(cu(x))
+    w1_hl, s1 = ops.pack_weights_hl32([cu(w).view(Ch, 1, 1, C).contiguous() for w in w1])
+    perm = ops.mlp_hidden_permutation(Ch, torch.device("cuda"))
+    w2_hl, s2 = ops.pack_weights_hl32([cu(w).index_select(1, perm).contiguous().view(C, 1, 1, Ch) for w in w2])
+    y = ops.svtr_mlp_fused(x_hl, G * rows_pg, rows_pg, G, C, w1_hl, s1, cu(b1), w2_hl, s2, cu(b2))
+    assert_close("fused SVTR Mlp vs float64", y.view(G, rows_pg, C), ref.float(), atol=2e-5, rtol=1e-5)
+    # the path it replaces: fc1 + GELU -> HL32, fc2 (same products, another summation order inside fc2)
+    w2n_hl, s2n = ops.pack_weights_hl32([cu(w).view(C, 1, 1, Ch).contiguous() for w in w2])
+    h_hl, _ = ops.conv2d_x3(x_hl, G, False, rows_pg, 1, 1, C, w1_hl, s1, Ch, (1, 1), bias=cu(b1), act=ops.ACT_GELU, hl_only=True)
+    y2, _ = ops.conv2d_x3(h_hl, G, False, rows_pg, 1, 1, Ch, w2n_hl, s2n, C, (1, 1), bias=cu(b2))
+    assert_close("fused vs two GEMMs", y.view(G, rows_pg, C), y2.view(G, rows_pg, C), atol=2e-6, rtol=2e-6)
+
+
+def test_svtr_fused_mlp_full_size_no_stale_slabs(ops):
+    """mrn_svtr_mlp_x3_f32 at SVTR stage-1 size (two experts x 131072 tokens, C = 64: two workgroups per CU, 1024 of them), several
+    launches against the two-GEMM path: every row must agree.  Pins the LDS-DMA ordering inside the kernel's slab ring -- hipcc drops
+    the vmcnt wait from a plain __syncthreads() there, which showed as stale weight slabs in a few workgroups per launch."""
+    C, G, rpg = 64, 2, 131072
+    Ch = 4 * C
+    torch.manual_seed(11)
+    x = torch.randn(G * rpg, C, device="cuda")
+    w1 = [torch.randn(Ch, C, device="cuda") * C ** -0.5 for _ in range(G)]
+    w2 = [torch.randn(C, Ch, device="cuda") * Ch ** -0.5 for _ in range(G)]
+    b1, b2 = torch.randn(G, Ch, device="cuda") * 0.2, torch.randn(G, C, device="cuda") * 0.2
+    x_hl = ops.split_hl32(x)
+    w1_hl, s1 = ops.pack_weights_hl32([w.view(Ch, 1, 1, C).contiguous() for w in w1])
+    perm = ops.mlp_hidden_permutation(Ch, x.device)
+    w2_hl, s2 = ops.pack_weights_hl32([w.index_select(1, perm).contiguous().view(C, 1, 1, Ch) for w in w2])
+    w2n_hl, s2n = ops.pack_weights_hl32([w.view(C, 1, 1, Ch).contiguous() for w in w2])
+    h_hl, _ = ops.conv2d_x3(x_hl, G, False, rpg, 1, 1, C, w1_hl, s1, Ch, (1, 1), bias=b1, act=ops.ACT_GELU, hl_only=True)
+    y2, _ = ops.conv2d_x3(h_hl, G, False, rpg, 1, 1, Ch, w2n_hl, s2n, C, (1, 1), bias=b2)
+    for _ in range(6):
+        y = ops.svtr_mlp_fused(x_hl, G * rpg, rpg, G, C, w1_hl, s1, b1, w2_hl, s2, b2)
+        bad = ((y.view(-1, C) - y2.view(-1, C)).abs().max(1)[0] > 1e-4).sum()
+        assert int(bad) == 0, int(bad)
