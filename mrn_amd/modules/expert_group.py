@@ -23,6 +23,9 @@ from ._nn import _pair, packed_weight, require_no_grad, to_nhwc
 
 
 EVAL_BN_FOLD = os.environ.get("MRN_EVAL_BN_FOLD", "1") != "0"      # eval-mode BatchNorm folded into the conv epilogue (A/B switch)
+# eval-mode layers that qualify for the Winograd form run conv (F(4,3)) + a producer pass with the running-statistics affine instead of
+# the one-launch direct conv with the BatchNorm folded into its epilogue (A/B switch)
+EVAL_WINO = os.environ.get("MRN_EVAL_WINO", "1") != "0"
 RESIDUAL_FROM_F32 = bool(int(os.environ.get("MRN_RESIDUAL_F32", "0")))      # True: keep an fp32 copy of every identity-shortcut source (one extra 4 B/element write)
 
 
@@ -125,7 +128,7 @@ class BackboneGroup(_GroupedLinear):
     def wino_for(conv, bns):
         """R of the Winograd form this conv would run in when its input arrives as a Winograd-domain operand, else 0: 3x3 / stride 1
         / pad 1, wide enough, and NOT followed by an eval-mode BatchNorm (that fold keeps its one-launch direct form)"""
-        if bns is not None and not bns[0].training:
+        if bns is not None and not bns[0].training and not EVAL_WINO:
             return 0
         ok = ops.wino_eligible(_pair(conv.kernel_size), _pair(conv.stride), _pair(conv.padding), conv.in_channels, conv.out_channels)
         return ops.WINO_R if ok else 0
@@ -162,8 +165,9 @@ class BackboneGroup(_GroupedLinear):
         stats = None
         res = residual.f32 if residual is not None else None
         res_hl = residual.hl if residual is not None and res is None else None
+        use_wino = x.wino is not None and x.wino_R == self.wino_for(c0, bns)
         if (EVAL_BN_FOLD and bns is not None and not training and Cin % 32 == 0 and Cout >= 64 and Cout % 32 == 0
-                and (want_hl or res_hl is None)):
+                and (want_hl or res_hl is None) and not use_wino and not want_wino):
             # frozen experts in EVAL mode (DERNet's old extractors, LwF's previous network, validation): the BatchNorm is a fixed
             # per-channel affine, so conv -> BN -> (+ identity) -> ReLU -> operand split is ONE launch: the affine, the shortcut
             # and the activation run in the conv epilogue, which writes the HL32 operand of the next layer directly
@@ -189,7 +193,7 @@ class BackboneGroup(_GroupedLinear):
                 return Act((G, B, Ho, Wo, Cout), got[0], got[1])
             return Act((G, B, Ho, Wo, Cout), None, got) if want_hl else Act((G, B, Ho, Wo, Cout), got, None)
         y = torch.empty(G, B, Ho, Wo, Cout, device=dev, dtype=torch.float32)
-        if x.wino is not None and x.wino_R == self.wino_for(c0, bns):
+        if use_wino:
             u_hl, u_scale = self._weights_wino(convs, x.wino_R)
             _, stats = ops.conv2d_x3_wino(x.wino, G, x.shared, B, H, W, Cin, u_hl, u_scale, Cout, x.wino_R,
                                           bias=self._bias_stack(convs), act=act, want_stats=training, out=y)
