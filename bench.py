@@ -514,6 +514,41 @@ def time_der_step(args, opt, rank, world, steps, warmup):
             "dtype": train_dtype()}
 
 
+def time_loop_b_short(args, opt, steps, warmup):
+    """the headline workload (loop B, pipelined) for a few steps under the CURRENT arithmetic switches: the reduced-precision line"""
+    from mrn_amd import ops
+    from mrn_amd.data.synthetic import SyntheticTextLines
+    from mrn_amd.tools.utils import to_device
+    learner = build_learner(opt, args.experts, quiet=not args.verbose)
+    data = SyntheticTextLines(opt, seed=111)
+    data.set_characters(learner.character)
+
+    def fetch():
+        image, labels, idx = data.get_batch2()
+        indexs = to_device(torch.LongTensor(idx).squeeze())
+        pre = learner.prefetch_experts(image, labels)
+        return image, labels, indexs, pre if (pre is not None and pre[0] is not None) else None
+    pending = [fetch()]
+
+    def step():
+        image, labels, indexs, pre = pending.pop()
+        pending.append(fetch())
+        return learner.routing_step(image, labels, indexs, prefetched=pre)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    pending.clear()
+    del learner
+    return {"metric": "text-line images/sec (fwd+bwd) at 32x256, TRBA+MRN 6 experts, REDUCED precision (not the headline)",
+            "value": args.batch * steps / elapsed, "unit": "images/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": warmup,
+            "dtype": "fp16 (one fp16 MFMA product per term, fp32 accumulate and storage)" if ops.X3_PRODUCTS == 1 else "f32 x3"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -539,6 +574,7 @@ def main():
                     "extractors; lwf / ewc: config 5's auxiliary-loss learners, one task-1 step -- printed as the main line instead")
     ap.add_argument("--no-extra", action="store_true", help="do not append the short loop-A measurement under \"extra\"")
     ap.add_argument("--no-power-probe", action="store_true", help="skip the live zero-operand probe of the dominant layer shape")
+    ap.add_argument("--no-reduced", action="store_true", help="skip the short reduced-precision lines (extra.fp16_loop_b / extra.fp16_der)")
     args = ap.parse_args()
 
     from mrn_amd import ops, parallel
@@ -663,7 +699,10 @@ def main():
                                    f"(train-mode BN) + DM-Router fwd/bwd + clip + Adam, 32x256x4 crops, random-init weights",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "classes": [sum(CLASSES_MLT19[:i + 1]) + (5 if args.model == "trba" else 4) for i in range(args.experts)],
-                       "loss_clf": loss_clf.detach().item(), "loss_taski": loss_t.detach().item()},
+                       "loss_clf": loss_clf.detach().item(), "loss_taski": loss_t.detach().item(),
+                       "reduced_precision_note": "BASELINE configs 2 (\"bf16\") and 5 (\"fp16 MFMA\") are served by ONE reduced mode: one fp16 "
+                                                 "product per term, fp32 accumulate (fp16 keeps 11 significand bits where bf16 keeps 8, same MFMA "
+                                                 "rate); bench.py --precision fp16, and extra.fp16_loop_b / extra.fp16_der in this line"},
         }
         if timer is not None and timer.spans:
             rl, hbm = roofline_entries(timer.summary(), args.steps, elapsed)
@@ -691,14 +730,29 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(learner, opt, args.experts)
     extra = None
+    reduced = {}
     if not args.no_extra:                  # (every rank: loop A's train_step holds the gradient all-reduce)
         del learner
         pending.clear()
         torch.cuda.empty_cache()
         extra = time_loop_a(args, opt, rank, world, steps=5, warmup=2, with_cpu_baseline=not args.no_cpu_baseline)
+        if world == 1 and args.model == "trba" and args.precision == "auto" and not args.no_reduced:
+            # the reduced-precision mode BASELINE configs 2 ("bf16") and 5 ("fp16 MFMA") name, driver-timed in the default run: ONE fp16
+            # product per term (fp16 keeps 11 significand bits where bf16 keeps 8; same MFMA rate), fp32 accumulate -- short lines
+            saved = (ops.X3_PRODUCTS, ops.TRAIN_PRODUCTS)
+            ops.X3_PRODUCTS = ops.TRAIN_PRODUCTS = 1
+            try:
+                reduced["fp16_loop_b"] = time_loop_b_short(args, opt, steps=3, warmup=2)
+                torch.cuda.empty_cache()
+                reduced["fp16_der"] = {k: v for k, v in time_der_step(args, opt, rank, world, 3, 2).items()
+                                       if k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype")}
+            finally:
+                ops.X3_PRODUCTS, ops.TRAIN_PRODUCTS = saved
+            torch.cuda.empty_cache()
     if rank == 0:
         if extra is not None:
             res["extra"] = {"loop_a": extra}
+            res["extra"].update(reduced)
         print(json.dumps(res))
     parallel.barrier()
 
