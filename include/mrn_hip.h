@@ -125,6 +125,12 @@ int mrn_pack_weight_hl32(const float* w_ohwi, void* out, int Cout, int taps, int
  * y [G][M][N]; one group per (split-K chunk, tap). */
 int mrn_transpose_oy_hl32_f32(const float* x, void* out, int B, int H, int W, int C, int shift_x, const float* scale, void* stream);
 int mrn_transpose_oy3_hl32_f32(const float* x, void* out, int B, int H, int W, int C, const float* scale, void* stream);   /* shifts -1, 0, +1 in one pass: out [3][C][lines][128 B] */
+/* ... and in the Winograd domain (F(4,3) along W): both operands transformed per group of 4 columns while they are transposed
+ * (mode 0: the layer input through B^T, mode 1: the output gradient through A; out [6][C][ceil(B*H*ceil(W/4)/32)][128 B] in
+ * image-row-major group order), 18 K-windows (component x kernel row) of a quarter of the length on mrn_gemm_x3_windows_hl32, then
+ * dW[ky][kx] = sum_m G[m][kx] dU_m[ky] over the split-K slabs (mrn_wino_wgrad_finish_f32): half the matrix work of the 9-window form */
+int mrn_transpose_oy_wino_hl32_f32(const float* t, void* out, int B, int H, int W, int C, int mode, const float* scale, void* stream);
+int mrn_wino_wgrad_finish_f32(const float* part, float* dw, int S, int Cout, int Cin, void* stream);
 int mrn_gemm_x3_windows_hl32(const void* a_hl, int64_t a_bytes, int a_pitch_lines, const void* w_hl, int64_t w_bytes,
                              int w_pitch_lines, const void* windows, int G, int M, int N, const void* zero_page,
                              const float* out_scale, const float* x_scale, float* y, int tile_m, int tile_n, int products,

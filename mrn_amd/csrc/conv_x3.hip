@@ -854,6 +854,112 @@ __global__ __launch_bounds__(256) void transpose_oy3_hl32_kernel(const float* __
   }
 }
 
+// Transposed operands of the Winograd-domain weight gradient (mrn_conv_wgrad_wino...): NHWC fp32 t[b][y][xx][c] -> out[m][c][kq / 32][hi 32 | lo 32]
+// over GROUPS of 4 columns in image-row-major order kq = (y * B + b) * Wq + q (Wq = ceil(W / 4)), six components m per group:
+//   MODE 0 (the layer input x):       V_m  = sum_j B^T[m][j] * x[.., 4q - 1 + j]   (j = 0..5, zero outside the row)
+//   MODE 1 (the output gradient dy):  dY_m = sum_r A^T[r][m] * dy[.., 4q + r]      (r = 0..3, zero beyond W)
+// times scale[0].  With these, dU_m[ky] = sum over groups of dY_m (x) V_m (row-shifted by ky - 1) and dW[ky][kx] = sum_m G[m][kx] dU_m[ky]:
+// 18 K-windows of length P/4 instead of 9 of length P -- half the matrix work -- and ONE 1.5x copy of x^T instead of three shifted copies.
+// One block = 32 groups x 32 channels through LDS.
+template <int MODE>
+__global__ __launch_bounds__(256) void transpose_oy_wino_hl32_kernel(const float* __restrict__ x, unsigned char* __restrict__ out, int B, int H,
+                                                                     int W, int Wq, int C, long Pq, long lines, long tiles_c, long ntiles,
+                                                                     const float* __restrict__ scale) {
+  constexpr int NCOL = MODE == 0 ? 6 : 4;
+  __shared__ float tile[32 * NCOL][33];
+  const float sc = scale ? scale[0] : 1.f;
+  const int t = threadIdx.x;
+  for (long id = blockIdx.x; id < ntiles; id += gridDim.x) {
+    const long kb = id / tiles_c;
+    const int c0 = (int)(id - kb * tiles_c) * 32;
+    for (int i = t; i < 32 * NCOL * 8; i += 256) {
+      const int rr = i >> 3, c4 = (i & 7) * 4;          // rr = group-in-block * NCOL + column
+      const int gq = rr / NCOL, j = rr - gq * NCOL;
+      const long kq = kb * 32 + gq;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (kq < Pq && c0 + c4 < C) {
+        const long row = kq / Wq;                        // = y * B + b
+        const int q = (int)(kq - row * Wq);
+        const int xx = 4 * q + j - (MODE == 0 ? 1 : 0);
+        const int y = (int)(row / B), b = (int)(row - (long)y * B);
+        if ((unsigned)xx < (unsigned)W) v = *reinterpret_cast<const f32x4*>(x + (((long)b * H + y) * W + xx) * C + c0 + c4);
+      }
+      tile[rr][c4 + 0] = v[0]; tile[rr][c4 + 1] = v[1]; tile[rr][c4 + 2] = v[2]; tile[rr][c4 + 3] = v[3];
+    }
+    __syncthreads();
+    {
+      const int c = t >> 3, seg = t & 7;                 // channel c, groups seg*4 .. +3 of the block
+      if (c0 + c < C) {
+        typedef _Float16 f16v4 __attribute__((ext_vector_type(4)));
+        f16v4 h[6], l[6];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int gq = seg * 4 + e;
+          float m_[6];
+          if constexpr (MODE == 0) {
+            const float d0 = tile[gq * 6 + 0][c], d1 = tile[gq * 6 + 1][c], d2 = tile[gq * 6 + 2][c], d3 = tile[gq * 6 + 3][c],
+                        d4 = tile[gq * 6 + 4][c], d5 = tile[gq * 6 + 5][c];
+            m_[0] = 4.f * d0 - 5.f * d2 + d4;
+            m_[1] = -4.f * (d1 + d2) + d3 + d4;
+            m_[2] = 4.f * (d1 - d2) - d3 + d4;
+            m_[3] = 2.f * (d3 - d1) - d2 + d4;
+            m_[4] = 2.f * (d1 - d3) - d2 + d4;
+            m_[5] = 4.f * d1 - 5.f * d3 + d5;
+          } else {
+            const float y0 = tile[gq * 4 + 0][c], y1 = tile[gq * 4 + 1][c], y2 = tile[gq * 4 + 2][c], y3 = tile[gq * 4 + 3][c];
+            m_[0] = y0;                                  // columns of A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+            m_[1] = y0 + y1 + y2 + y3;
+            m_[2] = y0 - y1 + y2 - y3;
+            m_[3] = y0 + 2.f * y1 + 4.f * y2 + 8.f * y3;
+            m_[4] = y0 - 2.f * y1 + 4.f * y2 - 8.f * y3;
+            m_[5] = y3;
+          }
+#pragma unroll
+          for (int k = 0; k < 6; ++k) {
+            _Float16 hh, ll;
+            split_h(m_[k] * sc, hh, ll);
+            h[k][e] = hh; l[k][e] = ll;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          unsigned char* o = out + (((long)k * C + c0 + c) * lines + kb) * 128 + seg * 8;
+          *reinterpret_cast<f16v4*>(o) = h[k];
+          *reinterpret_cast<f16v4*>(o + 64) = l[k];
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// dW [Cout][3][3][Cin] = sum over split-K chunks s and components m of G[m][kx] * part[s][m * 3 + ky][co][ci]  (G of F(4,3), unfolded)
+__global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, long CC, int Cin) {
+  const float G[6][3] = {{0.25f, 0.f, 0.f}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
+                         {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < CC; i += (long)gridDim.x * 256) {      // i = co * Cin + ci
+    const long co = i / Cin;
+    const int ci = (int)(i - co * Cin);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      float u[6];
+#pragma unroll
+      for (int m = 0; m < 6; ++m) {
+        float a = 0.f;
+        for (int s_ = 0; s_ < S; ++s_) a += part[((long)s_ * 18 + m * 3 + ky) * CC + i];
+        u[m] = a;
+      }
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        float v = 0.f;
+#pragma unroll
+        for (int m = 0; m < 6; ++m) v += G[m][kx] * u[m];
+        dw[((co * 3 + ky) * 3 + kx) * Cin + ci] = v;
+      }
+    }
+  }
+}
+
 // w [Cout][taps][Cin] fp32 (x scale[0]) -> [Cout][Cin/32][taps][hi 32 | lo 32]; one thread = 8 channels
 __global__ __launch_bounds__(256) void pack_weight_hl32_kernel(const float* __restrict__ w, unsigned char* __restrict__ out,
                                                                int Cout, int taps, int Cin, const float* __restrict__ scale) {
@@ -1085,6 +1191,36 @@ MRN_EXPORT int mrn_transpose_oy3_hl32_f32(const float* x, void* out, int B, int 
   hipLaunchKernelGGL(transpose_oy3_hl32_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, (unsigned char*)out, B, H,
                      W, C, P, lines, tiles_c, ntiles, (long)C * lines * 128, scale);
   MRN_LAUNCH_CHECK("transpose_oy3_hl32");
+  return MRN_OK;
+}
+
+// The two operand passes and the final reduction of the Winograd-domain weight gradient of a 3x3 / stride 1 / pad 1 convolution
+// (transpose_oy_wino_hl32_kernel, wino_wgrad_finish_kernel): t NHWC [B][H][W][C] fp32 -> out [6][C][ceil(B*H*ceil(W/4) / 32)][128 B];
+// mode 0 = layer input (B^T over 6 columns), mode 1 = output gradient (A over 4 columns).
+MRN_EXPORT int mrn_transpose_oy_wino_hl32_f32(const float* t, void* out, int B, int H, int W, int C, int mode, const float* scale,
+                                              void* stream) {
+  MRN_CHECK_ARG(t && out && C % 4 == 0 && B > 0 && H > 0 && W > 0 && (mode == 0 || mode == 1), "mrn_transpose_oy_wino_hl32_f32: bad operands");
+  const int Wq = (W + 3) / 4;
+  const long Pq = (long)B * H * Wq, lines = (Pq + 31) / 32, tiles_c = (C + 31) / 32, ntiles = lines * tiles_c;
+  long grid = ntiles > 65536 ? 65536 : ntiles;
+  if (mode == 0)
+    hipLaunchKernelGGL(transpose_oy_wino_hl32_kernel<0>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, t, (unsigned char*)out, B,
+                       H, W, Wq, C, Pq, lines, tiles_c, ntiles, scale);
+  else
+    hipLaunchKernelGGL(transpose_oy_wino_hl32_kernel<1>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, t, (unsigned char*)out, B,
+                       H, W, Wq, C, Pq, lines, tiles_c, ntiles, scale);
+  MRN_LAUNCH_CHECK("transpose_oy_wino_hl32");
+  return MRN_OK;
+}
+
+// part [S][18][Cout][Cin] (group (m, ky) = m * 3 + ky of split-K chunk s, from mrn_gemm_x3_windows_hl32) -> dW [Cout][3][3][Cin]
+MRN_EXPORT int mrn_wino_wgrad_finish_f32(const float* part, float* dw, int S, int Cout, int Cin, void* stream) {
+  MRN_CHECK_ARG(part && dw && S >= 1 && Cout >= 1 && Cin >= 1, "mrn_wino_wgrad_finish_f32: bad operands");
+  const long CC = (long)Cout * Cin;
+  long grid = (CC + 255) / 256;
+  if (grid > 16384) grid = 16384;
+  hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, part, dw, S, CC, Cin);
+  MRN_LAUNCH_CHECK("wino_wgrad_finish");
   return MRN_OK;
 }
 

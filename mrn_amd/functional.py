@@ -390,7 +390,9 @@ class ConvBlockFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             kh, kw = w.shape[1], w.shape[2]
             if precision == "fp16x3s" and x.shape[-1] % 4 == 0 and ops.TRAIN_WGRAD_X3:
-                if ops.WGRAD_WINDOWS and ops.wgrad_windows_supported(dy, x, (kh, kw), stride, padding):
+                if ops.wgrad_wino_supported(dy, x, (kh, kw), stride, padding):
+                    dw = ops.unpack_conv_weight(ops.conv2d_wgrad_x3_wino(dy, x, dy_scale=sd, x_scale=ctx.x_scale))
+                elif ops.WGRAD_WINDOWS and ops.wgrad_windows_supported(dy, x, (kh, kw), stride, padding):
                     dw = ops.unpack_conv_weight(ops.conv2d_wgrad_x3_windows(dy, x, dy_scale=sd, x_scale=ctx.x_scale))
                 else:
                     dw = ops.unpack_conv_weight(ops.conv2d_wgrad_x3(dy, x, (kh, kw), stride, padding, dy_scale=sd, x_scale=ctx.x_scale))

@@ -472,6 +472,67 @@ def conv2d_wgrad_x3_windows(dy, x, dy_scale=None, x_scale=None):
     return dw.permute(1, 0, 2).contiguous().view(Cout, 3, 3, Cin)
 
 
+TRAIN_WGRAD_WINO = os.environ.get("MRN_TRAIN_WGRAD_WINO", "1") == "1"     # weight gradients of the Winograd-eligible trained layers in the Winograd domain
+
+
+def wgrad_wino_supported(dy, x, ksize, stride, padding):
+    """the Winograd-domain weight gradient covers what the forward's Winograd form covers, on maps at least two rows high whose image rows
+    fill whole 32-group lines (B * ceil(W / 4) % 32 == 0), with operands range-scaled for the transforms (TRAIN_OPERAND_PEAK)"""
+    B, H, W, Cout = dy.shape
+    Cin = x.shape[-1]
+    return (TRAIN_WGRAD_WINO and TRAIN_WINO and WINO_R == 4 and TRAIN_PRODUCTS == 3 and wino_eligible(ksize, stride, padding, Cin, Cout)
+            and H >= 2 and (B * ((W + 3) // 4)) % 32 == 0 and Cout % 4 == 0 and tuple(x.shape[:3]) == (B, H, W))
+
+
+def conv2d_wgrad_x3_wino(dy, x, dy_scale=None, x_scale=None):
+    """dW [Cout,3,3,Cin] of a 3x3 / stride 1 / pad 1 conv in the Winograd domain (F(4,3) along W): dU_m[ky] = sum over column groups of
+    (A dy)_m (x) (B^T x)_m shifted by ky - 1 image rows -- 18 K-windows of a quarter of the pixel count on the grouped x3 GEMM -- then
+    dW[ky][kx] = sum_m G[m][kx] dU_m[ky].  Half the matrix work of conv2d_wgrad_x3_windows and 3x instead of 4x the operand bytes."""
+    B, H, W, Cout = dy.shape
+    Cin = x.shape[-1]
+    Wq = (W + 3) // 4
+    Pq = B * H * Wq
+    lines, bwl = Pq // 32, (B * Wq) // 32
+    dev = x.device
+    dy, x = dy.contiguous(), x.contiguous()
+    sd = dy_scale if dy_scale is not None else pow2_scale(dy, TRAIN_OPERAND_PEAK)
+    sx = x_scale if x_scale is not None else pow2_scale(x, TRAIN_OPERAND_PEAK)
+    a_bytes, w_bytes = 6 * Cout * lines * 128, 6 * Cin * lines * 128
+    a_hl = torch.empty(a_bytes, device=dev, dtype=torch.uint8)
+    w_hl = torch.empty(w_bytes, device=dev, dtype=torch.uint8)
+    call("mrn_transpose_oy_wino_hl32_f32", _p(dy), _p(a_hl), B, H, W, Cout, 1, _p(sd), _stream())
+    call("mrn_transpose_oy_wino_hl32_f32", _p(x), _p(w_hl), B, H, W, Cin, 0, _p(sx), _stream())
+    tiles = ((Cout + 255) // 256) * ((Cin + 255) // 256) * 18
+    S = max(1, min(512 // tiles if tiles < 512 else 1, max((lines - bwl) // 8, 1)))
+    key = ("wino", lines, bwl, Cin, Cout, S, dev)
+    tab = _WINDOW_TABLES.get(key)
+    if tab is None:
+        rows = []
+        for s_ in range(S):
+            for m in range(6):
+                for ky in range(3):
+                    lo = bwl if ky == 0 else 0                      # dy rows y >= 1 pair with x rows y - 1
+                    hi = lines - bwl if ky == 2 else lines          # dy rows y <= H - 2 pair with x rows y + 1
+                    L = hi - lo
+                    start, end = lo + (L * s_) // S, lo + (L * (s_ + 1)) // S
+                    assert end > start
+                    rows.append([(m * Cout * lines + start) * 128, (m * Cin * lines + start + (ky - 1) * bwl) * 128, end - start])
+        tab = torch.tensor(rows, dtype=torch.int64).to(dev)
+        _WINDOW_TABLES[key] = tab
+    G = S * 18
+    part = torch.empty(S, 18, Cout, Cin, device=dev, dtype=torch.float32)
+    tile_m, tile_n = x3_tile(Cin, 32 * ((lines + S - 1) // S), M=Cout, G=G)
+    timed = CONV_TIMER is not None
+    t0 = CONV_TIMER.begin() if timed else None
+    call("mrn_gemm_x3_windows_hl32", _p(a_hl), a_bytes, lines, _p(w_hl), w_bytes, lines, _p(tab), G, Cout, Cin,
+         _p(_zero_page(dev)), _p(sx.view(1, 2).expand(G, 2).contiguous()), _p(sd), _p(part), tile_m, tile_n, int(TRAIN_PRODUCTS), _stream())
+    if timed:
+        CONV_TIMER.end(t0, 2.0 * 9 * Cout * Cin * B * H * W, "fp16x3/x3g%dx%d" % (tile_m, tile_n), 4.0 * (6 * Pq * (Cin + Cout) + G * Cout * Cin))
+    dw = torch.empty(Cout, 3, 3, Cin, device=dev, dtype=torch.float32)
+    call("mrn_wino_wgrad_finish_f32", _p(part), _p(dw), S, Cout, Cin, _stream())
+    return dw
+
+
 def pow2_scale(x, target=FP16_WEIGHT_PEAK):
     """device float[2] = {s, 1/s}, s = the largest power of two with s * max|x| <= target (no host sync)"""
     _chk(x)

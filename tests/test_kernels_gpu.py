@@ -993,3 +993,25 @@ def test_svtr_fused_mlp_full_size_no_stale_slabs(ops):
         y = ops.svtr_mlp_fused(x_hl, G * rpg, rpg, G, C, w1_hl, s1, b1, w2_hl, s2, b2)
         bad = ((y.view(-1, C) - y2.view(-1, C)).abs().max(1)[0] > 1e-4).sum()
         assert int(bad) == 0, int(bad)
+
+
+@pytest.mark.parametrize("magnitude", [1e-4, 30.0])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(32, 4, 65, 128, 128), (64, 2, 16, 128, 160), (32, 8, 64, 256, 128), (256, 4, 65, 128, 256)])
+def test_wgrad_in_the_winograd_domain(B, H, W, Cin, Cout, magnitude):
+    """mrn_transpose_oy_wino_hl32_f32 (both operands transformed per group of 4 columns while transposed) + 18 K-windows on
+    mrn_gemm_x3_windows_hl32 + mrn_wino_wgrad_finish_f32 against torch's conv weight gradient in float64 and against the 9-window
+    form; gradient-sized and large dy (range-scaled operands, factor-16 headroom for the transforms)"""
+    from mrn_amd import ops
+    g = torch.Generator().manual_seed(B + H + Cin)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    dy = torch.randn(B, H, W, Cout, generator=g) * magnitude
+    ref = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).double(), (Cout, Cin, 3, 3), dy.permute(0, 3, 1, 2).double(),
+                                      stride=1, padding=1).permute(0, 2, 3, 1)                 # [Cout,3,3,Cin]
+    xd, dyd = x.cuda(), dy.cuda()
+    assert ops.wgrad_wino_supported(dyd, xd, (3, 3), (1, 1), (1, 1))
+    dw = ops.conv2d_wgrad_x3_wino(dyd, xd)
+    scale = ref.abs().max().item()
+    assert (dw.cpu().double() - ref).abs().max().item() <= 8e-6 * scale
+    if ops.wgrad_windows_supported(dyd, xd, (3, 3), (1, 1), (1, 1)):
+        assert (dw - ops.conv2d_wgrad_x3_windows(dyd, xd)).abs().max().item() <= 8e-6 * scale
+    assert not ops.wgrad_wino_supported(dyd[:5], xd[:5], (3, 3), (1, 1), (1, 1))                  # 5 * ceil(W/4) groups: not whole lines
