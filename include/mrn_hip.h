@@ -66,6 +66,9 @@ int mrn_conv2d_nhwc_bf16split(const float* x, const void* w_hi, const void* w_lo
 /* workspace: two 32-bit device words zeroed ONCE by the caller; every call on the same stream may reuse them (the kernel's last
  * block restores the zeros): running maximum + arrival ticket of the single launch */
 int mrn_pow2_scale_f32(const float* w, int64_t n, float target, float* scale, void* workspace, void* stream);
+/* the same scale from maxima a producer pass already folded into `workspace` (amax_ws of mrn_scale_shift_act_f32 /
+ * mrn_bn_bwd_apply_f32: 64 32-bit words zeroed once, slot = block % 64): saves the extra read of the tensor; the words are put back to zero */
+int mrn_pow2_finalize_f32(float target, float* scale, void* workspace, void* stream);
 /* Same product with the ACTIVATION pre-split too (x_hi / x_lo: bf16 NHWC planes from mrn_split_weight_bf16 on the fp32
  * tensor) and both operands staged by direct-to-LDS DMA (no staging registers, no conversion in the GEMM loop).
  * zero_page: >= 64 bytes of device zeros (source of padded taps).  Requires Cin % 8 == 0, (kh*kw*Cin) % 32 == 0. */
@@ -215,7 +218,7 @@ int mrn_bn_bwd_reduce_f32(const float* dz, const float* z, const float* y, const
                           float* partials, int64_t rows, int C, int relu, void* stream);
 int mrn_bn_bwd_apply_f32(const float* dz, const float* z, const float* y, const float* mean, const float* invstd,
                          const float* gamma, const float* sums, float* dy, float* dres, int64_t rows, int C, int relu,
-                         void* stream);
+                         void* amax_ws, void* stream);   /* amax_ws (optional): max|dy| folded in */
 /* MaxPool2d backward: dx (zero-initialised) += dy at the first maximum of each window */
 int mrn_maxpool_bwd_nhwc_f32(const float* dy, const float* x, float* dx_zeroed, int B, int H, int W, int C, int kh, int kw,
                              int sh, int sw, int ph, int pw, void* stream);
@@ -240,7 +243,7 @@ int mrn_bn_eval_affine_f32(const float* gamma, const float* beta, const float* r
 /* y = act(x * scale[c] + shift[c] + residual): BatchNorm apply + residual add + activation in one pass
  * (BasicBlock tail, modules/feature_extraction.py:184-199; relu = 1 ReLU, 2 GELU for SVTR's PatchEmbed). In place allowed. */
 int mrn_scale_shift_act_f32(const float* x, const float* residual, float* y, const float* scale,
-                            const float* shift, int64_t rows, int C, int relu, void* stream);
+                            const float* shift, int64_t rows, int C, int relu, void* amax_ws, void* stream);   /* amax_ws (optional): max|y| folded in, see mrn_pow2_finalize_f32 */
 /* NHWC max pooling (padding = -inf), optional fused (scale, shift, relu) on the input.
  * modules/feature_extraction.py:22,25,30,41,234,246,260; modules/transformation.py:71-79. */
 int mrn_maxpool_nhwc_f32(const float* x, float* y, const float* scale, const float* shift, int relu,

@@ -99,9 +99,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ sums,  // [2][C]: sum g, sum g*xhat
                                                            float* __restrict__ dy, float* __restrict__ dres, long rows, int C,
-                                                           int relu, float inv_n) {
+                                                           int relu, float inv_n, unsigned* __restrict__ amax_ws) {
   const int C4 = C >> 2;
   const long n4 = rows * C4;
+  float mx = 0.f;                                      // max |dy| of this lane (amax_ws: the range scale of the data / weight gradients)
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
     const int cq = (int)(i % C4);
     f32x4 g = reinterpret_cast<const f32x4*>(dz)[i];
@@ -125,6 +126,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     }
     reinterpret_cast<f32x4*>(dy)[i] = o;
     if (dres) reinterpret_cast<f32x4*>(dres)[i] = g;
+    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+  }
+  if (amax_ws) {                       // one atomic per BLOCK, spread over 64 slots (thousands of same-address atomics would serialise)
+    __shared__ float wmax[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      mx = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+      if (!(mx <= 0.f)) atomicMax(amax_ws + (blockIdx.x & 63), __float_as_uint(mx));
+    }      // (NaN / inf pass through, as mrn_pow2_scale_f32)
   }
 }
 
@@ -288,11 +301,11 @@ MRN_EXPORT int mrn_bn_bwd_reduce_f32(const float* dz, const float* z, const floa
 
 MRN_EXPORT int mrn_bn_bwd_apply_f32(const float* dz, const float* z, const float* y, const float* mean, const float* invstd,
                                     const float* gamma, const float* sums, float* dy, float* dres, int64_t rows, int C,
-                                    int relu, void* stream) {
+                                    int relu, void* amax_ws, void* stream) {
   MRN_CHECK_ARG(dz && y && mean && invstd && gamma && sums && dy && (!relu || z) && C % 4 == 0, "mrn_bn_bwd_apply_f32: bad operands");
   if (rows == 0) return MRN_OK;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(rows * (C / 4), 1024)), dim3(256), 0, (hipStream_t)stream, dz, z, y, mean,
-                     invstd, gamma, sums, dy, dres, (long)rows, C, relu, 1.f / (float)rows);
+                     invstd, gamma, sums, dy, dres, (long)rows, C, relu, 1.f / (float)rows, (unsigned*)amax_ws);
   MRN_LAUNCH_CHECK("bn_bwd_apply");
   return MRN_OK;
 }

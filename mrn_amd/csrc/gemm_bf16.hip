@@ -540,6 +540,20 @@ __global__ void pow2_finalize_kernel(float target, float* __restrict__ scale, un
   scale[1] = 1.f / s;
 }
 
+// the producers that fold max|.| into their own pass spread their per-block atomics over 64 slots: one wave folds and clears them
+__global__ __launch_bounds__(64) void pow2_finalize64_kernel(float target, float* __restrict__ scale, unsigned* __restrict__ ws) {
+  float m = __uint_as_float(ws[threadIdx.x]);
+  ws[threadIdx.x] = 0u;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if (threadIdx.x == 0) {
+    float s = 1.f;
+    if (m > 0.f && isfinite(m)) s = exp2f(floorf(log2f(target / m)));
+    scale[0] = s;
+    scale[1] = 1.f / s;
+  }
+}
+
 }  // namespace
 
 // scale[0] = largest power of two with scale*max|w| <= target, scale[1] = its inverse (both on the device); workspace: two 32-bit
@@ -565,6 +579,16 @@ MRN_EXPORT int mrn_pow2_scale_f32(const float* w, int64_t n, float target, float
   hipLaunchKernelGGL(pow2_scale_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, w, (long)n, target, scale,
                      (unsigned*)workspace);
   MRN_LAUNCH_CHECK("pow2_scale");
+  return MRN_OK;
+}
+
+// second half of mrn_pow2_scale_f32 for producers that folded max|.| into their own pass (mrn_scale_shift_act_f32 / mrn_bn_bwd_apply_f32
+// with amax_ws = a 64-word workspace zeroed once: per-block maxima land in slot blockIdx % 64): scale = {s, 1/s} from the maximum over
+// the 64 slots, which are put back to zero
+MRN_EXPORT int mrn_pow2_finalize_f32(float target, float* scale, void* workspace, void* stream) {
+  MRN_CHECK_ARG(scale && workspace && target > 0.f, "mrn_pow2_finalize_f32: bad operands");
+  hipLaunchKernelGGL(pow2_finalize64_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, target, scale, (unsigned*)workspace);
+  MRN_LAUNCH_CHECK("pow2_finalize");
   return MRN_OK;
 }
 

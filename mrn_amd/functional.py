@@ -345,7 +345,13 @@ class ConvBlockFn(torch.autograd.Function):
         ctx.wpacked = w
         # one max|x| pass serves the forward conv and the weight gradient (both split x with the same power-of-two scale)
         x3s = precision == "fp16x3s" and x.shape[-1] % 32 == 0
-        ctx.x_scale = sx = ops.pow2_scale(x.contiguous(), ops.TRAIN_OPERAND_PEAK) if x3s else None
+        # (the producer of x may have folded max|x| into its own pass: ops.scale_shift_act(range_target=...) of the previous block)
+        sx = None
+        if x3s:
+            sx = ops.cached_scale(x) if x.is_contiguous() else None
+            if sx is None:
+                sx = ops.pow2_scale(x.contiguous(), ops.TRAIN_OPERAND_PEAK)
+        ctx.x_scale = sx
         if bn is None:
             y, _ = ops.conv2d_nhwc(x, w, bias, stride, padding, act=ops.ACT_RELU if relu else ops.ACT_NONE, precision=precision,
                                    x_scale=sx)
@@ -361,7 +367,9 @@ class ConvBlockFn(torch.autograd.Function):
         if bn.num_batches_tracked is not None:
             bn.num_batches_tracked.add_(1)
         z = torch.empty_like(y)
-        ops.scale_shift_act(y, scale, shift, relu=relu, residual=residual, out=z)
+        # z is (almost always) the operand of the next trained convolution: its range scale comes out of this pass
+        ops.scale_shift_act(y, scale, shift, relu=relu, residual=residual, out=z,
+                            range_target=ops.TRAIN_OPERAND_PEAK if (precision == "fp16x3s" and z.shape[-1] % 32 == 0) else None)
         ctx.save_for_backward(x, z if relu else None, y, mean, invstd, gamma)
         return z
 
@@ -372,8 +380,13 @@ class ConvBlockFn(torch.autograd.Function):
         w = ctx.wpacked
         dz = dz.contiguous()
         dgamma = dbeta = dres = dbias = None
+        sd = None
         if has_bn:
-            dy, dgamma, dbeta, dres = ops.bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres=has_res)
+            if precision == "fp16x3s":      # max|dy| folded into the apply pass: the range scale shared by the data and weight gradients
+                dy, dgamma, dbeta, dres, sd = ops.bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres=has_res,
+                                                         range_target=ops.TRAIN_OPERAND_PEAK)
+            else:
+                dy, dgamma, dbeta, dres = ops.bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres=has_res)
             if ctx.needs_input_grad[2]:       # a conv bias in front of train-mode BatchNorm (SVTR PatchEmbed) cancels in the
                 dbias = torch.zeros(dy.shape[-1], device=dy.device, dtype=torch.float32)     # mean: its gradient is exactly 0
         else:
@@ -382,7 +395,8 @@ class ConvBlockFn(torch.autograd.Function):
                 dbias = ops.colsum(dy.view(-1, dy.shape[-1]))
         dx = None
         dy = dy.contiguous()
-        sd = ops.pow2_scale(dy, ops.TRAIN_OPERAND_PEAK) if precision == "fp16x3s" else None   # shared by the data and weight gradients
+        if sd is None and precision == "fp16x3s":
+            sd = ops.pow2_scale(dy, ops.TRAIN_OPERAND_PEAK)                                   # shared by the data and weight gradients
         if ctx.needs_input_grad[0]:
             wt = ops.pack_dgrad_weight(w.ohwi)
             dx = ops.conv2d_dgrad(dy, wt, (x.shape[1], x.shape[2]), stride, padding, precision=precision, dy_scale=sd)

@@ -4,6 +4,7 @@ PyTorch is used here only for device memory (caching allocator), the current HIP
 arithmetic operation is a call into libmrn_hip.so.  All tensors must be fp32 CUDA tensors.
 """
 import os
+import weakref
 
 import torch
 
@@ -112,6 +113,20 @@ def _pow2_ws():
     if ws is None:
         ws = torch.zeros(2, device=torch.device("cuda", st.device_index), dtype=torch.int32)
         _POW2_WS[key] = ws
+    return ws.data_ptr()
+
+
+_AMAX_WS = {}
+
+
+def _amax_ws():
+    """64 zeroed words per (device, stream): the slots producers fold per-block maxima into (mrn_pow2_finalize_f32 clears them)"""
+    st = torch.cuda.current_stream()
+    key = (st.device_index, st.cuda_stream)
+    ws = _AMAX_WS.get(key)
+    if ws is None:
+        ws = torch.zeros(64, device=torch.device("cuda", st.device_index), dtype=torch.int32)
+        _AMAX_WS[key] = ws
     return ws.data_ptr()
 
 
@@ -799,12 +814,37 @@ def bn_eval_affine(gamma, beta, running_mean, running_var, eps):
     return scale, shift
 
 
-def scale_shift_act(x, scale, shift, relu=True, residual=None, out=None):
+# Range scales of tensors whose producer pass folded max|.| into its own sweep: id(tensor) -> (weak reference, device {s, 1/s}).  An
+# entry is put by the producer (scale_shift_act(range_target=...)) and popped by the consumer (cached_scale), which takes it only if
+# the weak reference still points at the very tensor object it was asked about -- a recycled id or address can never match.
+_SCALE_CACHE = {}
+FUSED_AMAX = os.environ.get("MRN_FUSED_AMAX", "1") == "1"
+
+
+def cached_scale(x):
+    e = _SCALE_CACHE.pop(id(x), None)
+    return e[1] if (e is not None and e[0]() is x) else None
+
+
+def clear_scale_cache():
+    _SCALE_CACHE.clear()
+
+
+def scale_shift_act(x, scale, shift, relu=True, residual=None, out=None, range_target=None):
+    """range_target: also fold max|out| into the pass and keep the power-of-two range scale {s, 1/s} (s * max|out| <= range_target)
+    for the consumer (cached_scale): saves the extra read of the tensor mrn_pow2_scale_f32 would make"""
     C = x.shape[-1]
     rows = x.numel() // C
     if out is None:
         out = x
-    call("mrn_scale_shift_act_f32", _p(x), _p(residual), _p(out), _p(scale), _p(shift), rows, C, int(relu), _stream())
+    ws = _amax_ws() if (range_target is not None and FUSED_AMAX) else None
+    call("mrn_scale_shift_act_f32", _p(x), _p(residual), _p(out), _p(scale), _p(shift), rows, C, int(relu), ws, _stream())
+    if ws is not None:
+        sc = torch.empty(2, device=x.device, dtype=torch.float32)
+        call("mrn_pow2_finalize_f32", float(range_target), _p(sc), ws, _stream())
+        if len(_SCALE_CACHE) > 256:
+            clear_scale_cache()                      # (entries nobody asked for: eval-mode consumers, non-conv consumers)
+        _SCALE_CACHE[id(out)] = (weakref.ref(out), sc)
     return out
 
 
@@ -1328,8 +1368,9 @@ def unpack_conv_weight(g_ohwi):
     return out
 
 
-def bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres=False):
-    """BatchNorm2d(train) backward with fused ReLU mask -> (dy, dgamma, dbeta, dres or None)"""
+def bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres=False, range_target=None):
+    """BatchNorm2d(train) backward with fused ReLU mask -> (dy, dgamma, dbeta, dres or None[, range scale of dy]); range_target: max|dy|
+    is folded into the apply pass and the power-of-two scale {s, 1/s} with s * max|dy| <= range_target is returned as a fifth value"""
     C = y.shape[-1]
     rows = y.numel() // C
     nblk = call("mrn_bn_bwd_blocks", rows)
@@ -1338,9 +1379,16 @@ def bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres=False):
     sums = colsum(part)                     # [2C]: sum g, sum g*xhat
     dy = torch.empty_like(y)
     dres = torch.empty_like(y) if want_dres else None
+    ws = _amax_ws() if (range_target is not None and FUSED_AMAX) else None
     call("mrn_bn_bwd_apply_f32", _p(dz), _p(z), _p(y), _p(mean), _p(invstd), _p(gamma), _p(sums), _p(dy), _p(dres), rows, C,
-         int(relu), _stream())
-    return dy, sums[C:], sums[:C], dres
+         int(relu), ws, _stream())
+    if range_target is None:
+        return dy, sums[C:], sums[:C], dres
+    if ws is None:
+        return dy, sums[C:], sums[:C], dres, pow2_scale(dy, range_target)
+    sc = torch.empty(2, device=y.device, dtype=torch.float32)
+    call("mrn_pow2_finalize_f32", float(range_target), _p(sc), ws, _stream())
+    return dy, sums[C:], sums[:C], dres, sc
 
 
 def maxpool_bwd(dy, x, kernel, stride, padding):
