@@ -933,30 +933,31 @@ __global__ __launch_bounds__(256) void transpose_oy_wino_hl32_kernel(const float
   }
 }
 
-// dW [Cout][3][3][Cin] = sum over split-K chunks s and components m of G[m][kx] * part[s][m * 3 + ky][co][ci]  (G of F(4,3), unfolded)
-__global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, long CC, int Cin) {
+// dW [Cout][3][3][Cin] = sum over split-K chunks s and components m of G[m][kx] * part[s][m * 3 + ky][co][ci]  (G of F(4,3), unfolded);
+// one lane = 4 consecutive input channels (Cin % 4 == 0): 18 S independent 16-byte streams per lane, split-K chunk outermost
+__global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, long CC4, int Cin4) {
   const float G[6][3] = {{0.25f, 0.f, 0.f}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
                          {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < CC; i += (long)gridDim.x * 256) {      // i = co * Cin + ci
-    const long co = i / Cin;
-    const int ci = (int)(i - co * Cin);
+  const f32x4* p4 = reinterpret_cast<const f32x4*>(part);
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < CC4; i += (long)gridDim.x * 256) {      // i = (co * Cin + ci) / 4
+    const long co = i / Cin4;
+    const int c4 = (int)(i - co * Cin4);
+    f32x4 u[18];
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      float u[6];
+    for (int k = 0; k < 18; ++k) u[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s_ = 0; s_ < S; ++s_) {
 #pragma unroll
-      for (int m = 0; m < 6; ++m) {
-        float a = 0.f;
-        for (int s_ = 0; s_ < S; ++s_) a += part[((long)s_ * 18 + m * 3 + ky) * CC + i];
-        u[m] = a;
-      }
+      for (int k = 0; k < 18; ++k) u[k] += p4[((long)s_ * 18 + k) * CC4 + i];
+    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
-        float v = 0.f;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int m = 0; m < 6; ++m) v += G[m][kx] * u[m];
-        dw[((co * 3 + ky) * 3 + kx) * Cin + ci] = v;
+        for (int m = 0; m < 6; ++m) v += G[m][kx] * u[m * 3 + ky];
+        reinterpret_cast<f32x4*>(dw)[((co * 3 + ky) * 3 + kx) * Cin4 + c4] = v;
       }
-    }
   }
 }
 
@@ -1215,11 +1216,11 @@ MRN_EXPORT int mrn_transpose_oy_wino_hl32_f32(const float* t, void* out, int B, 
 
 // part [S][18][Cout][Cin] (group (m, ky) = m * 3 + ky of split-K chunk s, from mrn_gemm_x3_windows_hl32) -> dW [Cout][3][3][Cin]
 MRN_EXPORT int mrn_wino_wgrad_finish_f32(const float* part, float* dw, int S, int Cout, int Cin, void* stream) {
-  MRN_CHECK_ARG(part && dw && S >= 1 && Cout >= 1 && Cin >= 1, "mrn_wino_wgrad_finish_f32: bad operands");
-  const long CC = (long)Cout * Cin;
-  long grid = (CC + 255) / 256;
+  MRN_CHECK_ARG(part && dw && S >= 1 && Cout >= 1 && Cin >= 4 && Cin % 4 == 0, "mrn_wino_wgrad_finish_f32: bad operands (Cin %% 4 == 0)");
+  const long CC4 = (long)Cout * Cin / 4;
+  long grid = (CC4 + 255) / 256;
   if (grid > 16384) grid = 16384;
-  hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, part, dw, S, CC, Cin);
+  hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, part, dw, S, CC4, Cin / 4);
   MRN_LAUNCH_CHECK("wino_wgrad_finish");
   return MRN_OK;
 }
