@@ -382,6 +382,21 @@ int mrn_add_layernorm_grouped_f32(const float* x, const float* branch, const flo
  * [G][C][4C/32][128 B] (mrn_pack_weight_hl32), s1 / s2 [G][2] their prescales, b1 [G][4C], b2 [G][C]; y [rows][C] fp32.  C = 64 | 128. */
 int mrn_svtr_mlp_x3_f32(const void* x_hl, const void* w1_hl, const float* s1, const float* b1, const void* w2_hl, const float* s2,
                         const float* b2, float* y, int64_t rows, int64_t rows_per_group, int G, int C, void* stream);
+/* The attention half of an SVTR mixing block (modules/svtr.py:196-201 `x = x + drop_path(mixer(norm1(x)))`, Attention :90-152) of G
+ * lock-step frozen experts in ONE kernel (group = image / imgs_per_group):
+ *   t = x + drop_prev[img] * pending;  x_out = t + drop1[img] * proj(attention(qkv(LayerNorm1(t))));  y_hl = HL32(LayerNorm2(x_out))
+ * x, pending, x_out [imgs][N][C] fp32 (pending / drop_prev / drop1 may be NULL); g1, b1, g2, b2 [G][C]; wqkv_hl [G][3C][C/32][128 B]
+ * (mrn_pack_weight_hl32 of [3C][1][C]) with prescale sqkv [G][2] and bias bqkv [G][3C] or NULL; mask_bits [N][ceil(N/32)] visibility
+ * bits of the local mixer's 0 / -inf mask or NULL; wproj_hl [G][C][C/32][128 B] packed with the input channel of every 32-block (head)
+ * permuted to the MFMA result layout (position 16 s + 8 h + j holds channel (j & 3) + 8 (2 s + (j >> 2)) + 4 h), sproj [G][2], bproj
+ * [G][C]; y_hl [imgs * N][C/32][128 B] is the operand of mrn_svtr_mlp_x3_f32.  Split-fp16 x3 products throughout; q | k | v, the
+ * probabilities and the context never leave registers / LDS.  Supported: C = 64 with N <= 512, C = 128 with N <= 256 (N <= 128:
+ * imgs_per_group even); otherwise MRN_ERR_UNSUPPORTED (the caller runs the unfused chain). */
+int mrn_svtr_mixer_x3_f32(const float* x, const float* pending, const float* drop_prev, const float* g1, const float* b1, float eps1,
+                          const void* wqkv_hl, const float* sqkv, const float* bqkv, const void* mask_bits, float scale,
+                          const void* wproj_hl, const float* sproj, const float* bproj, const float* drop1, const float* g2,
+                          const float* b2, float eps2, float* x_out, void* y_hl, int imgs, int imgs_per_group, int N, int C,
+                          void* stream);
 /* Fused multi-head attention of the SVTR mixing blocks (head dimension 32), inference path of the frozen experts:
  * out[b][n][h*32 + :] = softmax_m(scale * q[b][n][h] . k[b][m][h] + mask[n][m]) @ v[b][m][h]; qkv [B][N][3*C] (q | k | v,
  * C = heads * 32), mask [N][N] additive and SYMMETRIC (SVTR's local window mask) or NULL, out [B][N][C] fp32 and / or

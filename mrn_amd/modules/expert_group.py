@@ -364,16 +364,33 @@ class BackboneGroup(_GroupedLinear):
         drop1 = self._drop_scales(blks, B, x.device)          # same draw order as Block.forward: mixer branch, then MLP branch
         g1, b1 = self._ln_params(name + ".ln1", [b.norm1 for b in blks])
         br, dr = pending if pending is not None else (None, None)
-        t, _, y_hl = ops.add_layernorm_grouped(x, br, dr, N, g1, b1, rows, b0.norm1.eps, want_sum=br is not None)
-        x = t if t is not None else x
-        qkv = self._linear(name + ".qkv", y_hl, rows, C, [b.mixer.qkv.weight for b in blks],
-                           [b.mixer.qkv.bias for b in blks] if mixer.qkv.bias is not None else None)
-        ctx_hl = ops.svtr_attention(qkv.view(G * B, N, 3 * C), mixer.num_heads, mixer.scale, mixer.mask, want_f32=False, want_hl=True,
-                                    x3=ops.SVTR_ATTENTION_X3)
-        br = self._linear(name + ".proj", ctx_hl, rows, C, [b.mixer.proj.weight for b in blks], [b.mixer.proj.bias for b in blks])
-        drop2 = self._drop_scales(blks, B, x.device)
-        g2, b2 = self._ln_params(name + ".ln2", [b.norm2 for b in blks])
-        x, _, y_hl = ops.add_layernorm_grouped(x, br.view(G * B, N, C), drop1, N, g2, b2, rows, b0.norm2.eps, want_sum=True)
+        if mixer.num_heads * 32 == C and ops.svtr_mixer_supported(N, C, B, mixer.mask):
+            # LayerNorm1 -> qkv -> attention -> proj -> + residual -> LayerNorm2 in one kernel (csrc/svtr_mixer.hip)
+            qkvs, projs = [b.mixer.qkv for b in blks], [b.mixer.proj for b in blks]
+
+            def build_mixer():
+                wq, sq = ops.pack_weights_hl32([m.weight.detach().contiguous().view(3 * C, 1, 1, C) for m in qkvs])
+                perm = ops.mlp_hidden_permutation(C, x.device)
+                wp, sp = ops.pack_weights_hl32([m.weight.detach().index_select(1, perm).contiguous().view(C, 1, 1, C) for m in projs])
+                bq = torch.stack([m.bias.detach() for m in qkvs]).contiguous() if qkvs[0].bias is not None else None
+                return wq, sq, bq, wp, sp, torch.stack([m.bias.detach() for m in projs]).contiguous()
+            wq, sq, bq, wp, sp, bp = self._cached(name + ".mixer", [t_ for m in qkvs + projs for t_ in (m.weight, m.bias) if t_ is not None],
+                                                  build_mixer)
+            drop2 = self._drop_scales(blks, B, x.device)
+            g2, b2 = self._ln_params(name + ".ln2", [b.norm2 for b in blks])
+            x, y_hl = ops.svtr_mixer_fused(x, br, dr, g1, b1, b0.norm1.eps, wq, sq, bq, mixer.mask, mixer.scale, wp, sp, bp, drop1,
+                                           g2, b2, b0.norm2.eps, B)
+        else:
+            t, _, y_hl = ops.add_layernorm_grouped(x, br, dr, N, g1, b1, rows, b0.norm1.eps, want_sum=br is not None)
+            x = t if t is not None else x
+            qkv = self._linear(name + ".qkv", y_hl, rows, C, [b.mixer.qkv.weight for b in blks],
+                               [b.mixer.qkv.bias for b in blks] if mixer.qkv.bias is not None else None)
+            ctx_hl = ops.svtr_attention(qkv.view(G * B, N, 3 * C), mixer.num_heads, mixer.scale, mixer.mask, want_f32=False, want_hl=True,
+                                        x3=ops.SVTR_ATTENTION_X3)
+            br = self._linear(name + ".proj", ctx_hl, rows, C, [b.mixer.proj.weight for b in blks], [b.mixer.proj.bias for b in blks])
+            drop2 = self._drop_scales(blks, B, x.device)
+            g2, b2 = self._ln_params(name + ".ln2", [b.norm2 for b in blks])
+            x, _, y_hl = ops.add_layernorm_grouped(x, br.view(G * B, N, C), drop1, N, g2, b2, rows, b0.norm2.eps, want_sum=True)
         Ch = blks[0].mlp.fc1.out_features
         if ops.SVTR_FUSED_MLP and C in (64, 128) and Ch == 4 * C and ops.X3_PRODUCTS == 3:
             # fc1 -> GELU -> fc2 in one kernel: the 4C-wide hidden tensor stays in registers (csrc/svtr_mlp.hip)

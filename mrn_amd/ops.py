@@ -1580,6 +1580,38 @@ def svtr_mlp_fused(x_hl, rows, rows_per_group, G, C, w1_hl, s1, b1, w2_hl, s2, b
     return y
 
 
+SVTR_FUSED_MIXER = os.environ.get("MRN_SVTR_MIXER", "fused") == "fused"   # LN1 -> qkv -> attention -> proj -> +residual -> LN2 in one kernel
+
+
+def svtr_mixer_supported(N, C, imgs_per_group, mask):
+    """shapes mrn_svtr_mixer_x3_f32 takes (SVTR stages 1 and 2 at 32 x 100 and 32 x 256 crops); mask: None or a 0 / -inf additive mask"""
+    if not (SVTR_FUSED_MIXER and X3_PRODUCTS == 3):
+        return False
+    if not ((C == 64 and 96 < N <= 512) or (C == 128 and 48 < N <= 256 and (N > 128 or imgs_per_group % 2 == 0))):
+        return False
+    return mask is None or _mask_bits(mask) is not None
+
+
+def svtr_mixer_fused(x, pending, drop_prev, g1, b1, eps1, wqkv_hl, sqkv, bqkv, mask, scale, wproj_hl, sproj, bproj, drop1, g2, b2, eps2,
+                     imgs_per_group):
+    """x [imgs, N, C] -> (x_out [imgs, N, C], y_hl HL32 bytes of LayerNorm2(x_out)): the attention half of a mixing block
+    (mrn_svtr_mixer_x3_f32); wproj_hl packed from the input-permuted proj weights (mlp_hidden_permutation(C))"""
+    _chk(x, pending, drop_prev, g1, b1, bqkv, bproj, drop1, g2, b2)
+    imgs, N, C = x.shape
+    assert x.is_contiguous() and (pending is None or (pending.is_contiguous() and pending.numel() == x.numel()))
+    x_out = torch.empty_like(x)
+    y_hl = torch.empty(x.numel() * 4, device=x.device, dtype=torch.uint8)
+    bits = _mask_bits(mask) if mask is not None else None
+    t0 = CONV_TIMER.begin() if CONV_TIMER is not None else None
+    call("mrn_svtr_mixer_x3_f32", _p(x), _p(pending), _p(drop_prev), _p(g1), _p(b1), float(eps1), _p(wqkv_hl), _p(sqkv), _p(bqkv),
+         _p(bits), float(scale), _p(wproj_hl), _p(sproj), _p(bproj), _p(drop1), _p(g2), _p(b2), float(eps2), _p(x_out), _p(y_hl),
+         imgs, imgs_per_group, N, C, _stream())
+    if t0 is not None:
+        rows = imgs * N
+        CONV_TIMER.end(t0, 2.0 * rows * C * 4 * C + 4.0 * rows * N * C, "fp16x3/svtrmixer", 4.0 * rows * C * (4 if pending is not None else 3))
+    return x_out, y_hl
+
+
 def residual_scale_rows(x, branch, scale, rows_per_group, out=None):
     """x + scale[group] * branch on [rows, C] (contiguous)"""
     assert x.is_contiguous() and branch.is_contiguous()

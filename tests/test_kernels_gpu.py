@@ -995,6 +995,113 @@ def test_svtr_fused_mlp_full_size_no_stale_slabs(ops):
         assert int(bad) == 0, int(bad)
 
 
+def _mixer_case(C, N, G, B, masked, bias, with_pending, seed=700):
+    from mrn_amd.modules.svtr import local_attention_mask
+    heads = C // 32
+    imgs = G * B
+    t = {"x": rnd(imgs, N, C, seed=seed) * 1.5, "pend": rnd(imgs, N, C, seed=seed + 1) if with_pending else None,
+         "g1": rnd(G, C, seed=seed + 2) * 0.3 + 1.0, "b1": rnd(G, C, seed=seed + 3) * 0.2,
+         "g2": rnd(G, C, seed=seed + 4) * 0.3 + 1.0, "b2": rnd(G, C, seed=seed + 5) * 0.2,
+         "wqkv": [rnd(3 * C, C, seed=seed + 10 + g, scale=(1.0 / C) ** 0.5) * 1.5 for g in range(G)],
+         "bqkv": rnd(G, 3 * C, seed=seed + 20) * 0.3 if bias else None,
+         "wproj": [rnd(C, C, seed=seed + 30 + g, scale=(1.0 / C) ** 0.5) for g in range(G)], "bproj": rnd(G, C, seed=seed + 40) * 0.2}
+    gen = torch.Generator().manual_seed(seed)
+    t["dprev"] = ((torch.rand(imgs, generator=gen) > 0.3).float() / 0.7) if with_pending else None
+    t["d1"] = (torch.rand(imgs, generator=gen) > 0.3).float() / 0.7
+    H = {200: 8, 100: 4, 224: 8, 128: 4, 193: 1, 97: 1, 512: 8, 256: 4, 300: 4, 250: 1, 160: 4}[N]
+    t["mask"] = local_attention_mask(H, N // H, 7, 11) if masked else None
+    return t, heads
+
+
+def _mixer_reference(t, C, N, G, B, heads):
+    """float64: t = x + d_prev * pending; x_out = t + d1 * proj(attention(qkv(LN1(t)))); y2 = LN2(x_out)"""
+    x = t["x"].double()
+    if t["pend"] is not None:
+        x = x + t["dprev"].double()[:, None, None] * t["pend"].double()
+    outs, ys = [], []
+    for g in range(G):
+        xg = x[g * B:(g + 1) * B]
+        y = F.layer_norm(xg, (C,), t["g1"][g].double(), t["b1"][g].double(), 1e-6)
+        qkv = y @ t["wqkv"][g].double().t()
+        if t["bqkv"] is not None:
+            qkv = qkv + t["bqkv"][g].double()
+        q, k, v = [u.reshape(B, N, heads, 32).permute(0, 2, 1, 3) for u in qkv.split(C, dim=2)]
+        s = (q @ k.transpose(-1, -2)) * 32 ** -0.5
+        if t["mask"] is not None:
+            s = s + t["mask"].double()
+        ctx = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B, N, C)
+        br = ctx @ t["wproj"][g].double().t() + t["bproj"][g].double()
+        xo = xg + t["d1"][g * B:(g + 1) * B].double()[:, None, None] * br
+        outs.append(xo)
+        ys.append(F.layer_norm(xo, (C,), t["g2"][g].double(), t["b2"][g].double(), 1e-6))
+    return torch.cat(outs), torch.cat(ys)
+
+
+def _mixer_run(ops, t, C, N, G, B):
+    dev = torch.device("cuda")
+    wq, sq = ops.pack_weights_hl32([cu(w).view(3 * C, 1, 1, C).contiguous() for w in t["wqkv"]])
+    perm = ops.mlp_hidden_permutation(C, dev)
+    wp, sp = ops.pack_weights_hl32([cu(w).index_select(1, perm).contiguous().view(C, 1, 1, C) for w in t["wproj"]])
+    o = lambda v: cu(v) if v is not None else None
+    return ops.svtr_mixer_fused(cu(t["x"]), o(t["pend"]), o(t["dprev"]), cu(t["g1"]), cu(t["b1"]), 1e-6, wq, sq, o(t["bqkv"]), o(t["mask"]),
+                                32 ** -0.5, wp, sp, cu(t["bproj"]), cu(t["d1"]), cu(t["g2"]), cu(t["b2"]), 1e-6, B)
+
+
+@pytest.mark.parametrize("C,N,G,B,masked,bias,with_pending", [(64, 200, 2, 3, True, True, True), (64, 200, 1, 5, False, False, False),
+                                                              (128, 100, 2, 4, True, True, True), (128, 100, 3, 2, False, True, False),
+                                                              (64, 224, 1, 2, False, True, True), (64, 193, 1, 2, False, True, False),
+                                                              (128, 128, 1, 2, False, False, True), (128, 97, 1, 2, False, True, True),
+                                                              (64, 512, 2, 3, True, True, True), (64, 512, 1, 2, False, False, False),
+                                                              (64, 300, 1, 3, True, True, True), (64, 250, 1, 2, False, True, True),
+                                                              (128, 256, 2, 3, True, True, True), (128, 160, 1, 3, True, False, False)])
+def test_svtr_fused_mixer(ops, C, N, G, B, masked, bias, with_pending):
+    """mrn_svtr_mixer_x3_f32 (LayerNorm1 -> qkv -> local / global attention -> proj -> DropPath-scaled residual -> LayerNorm2 of G
+    experts in one kernel) against float64 torch (modules/svtr.py:90-152, :196-201) and against the unfused chain it replaces"""
+    t, heads = _mixer_case(C, N, G, B, masked, bias, with_pending)
+    x_ref, y_ref = _mixer_reference(t, C, N, G, B, heads)
+    assert ops.svtr_mixer_supported(N, C, B, cu(t["mask"]) if masked else None)
+    x_out, y_hl = _mixer_run(ops, t, C, N, G, B)
+    assert_close("fused mixer: residual stream vs float64", x_out, x_ref.float(), atol=2e-5, rtol=1e-5)
+    assert_close("fused mixer: LayerNorm2 operand vs float64", _hl32_to_f32(y_hl, G * B * N, C).view(G * B, N, C), y_ref.float(), atol=4e-5, rtol=1e-5)
+    # the chain it replaces
+    o = lambda v: cu(v) if v is not None else None
+    rows = B * N
+    tt, _, hl = ops.add_layernorm_grouped(cu(t["x"]), o(t["pend"]), o(t["dprev"]), N, cu(t["g1"]), cu(t["b1"]), rows, 1e-6, want_sum=with_pending)
+    xs = tt if tt is not None else cu(t["x"])
+    wq, sq = ops.pack_weights_hl32([cu(w).view(3 * C, 1, 1, C).contiguous() for w in t["wqkv"]])
+    wp, sp = ops.pack_weights_hl32([cu(w).view(C, 1, 1, C).contiguous() for w in t["wproj"]])
+    qkv, _ = ops.conv2d_x3(hl, G, False, rows, 1, 1, C, wq, sq, 3 * C, (1, 1), bias=o(t["bqkv"]))
+    ctx = ops.svtr_attention(qkv.view(G * B, N, 3 * C), heads, 32 ** -0.5, o(t["mask"]), want_f32=False, want_hl=True, x3=True)
+    br, _ = ops.conv2d_x3(ctx, G, False, rows, 1, 1, C, wp, sp, C, (1, 1), bias=cu(t["bproj"]))
+    x2, y2, hl2 = ops.add_layernorm_grouped(xs, br.view(G * B, N, C), cu(t["d1"]), N, cu(t["g2"]), cu(t["b2"]), rows, 1e-6, want_sum=True, want_f32=True)
+    assert_close("fused mixer vs unfused chain: residual stream", x_out, x2, atol=4e-6, rtol=2e-6)
+
+
+def test_svtr_fused_mixer_full_size(ops):
+    """the supported shapes (32 x 100 and 32 x 256 crops) at the headline's size (6 experts x 256 images), three launches each: every image must agree with the unfused
+    chain (pins the slab ring / K-V tile barriers at full occupancy)"""
+    for C, N in ((64, 200), (128, 100), (64, 512), (128, 256)):
+        G, B = 6, 256
+        heads = C // 32
+        t, _ = _mixer_case(C, N, G, B, True, True, True, seed=800 + C)
+        o = lambda v: cu(v) if v is not None else None
+        rows = B * N
+        tt, _, hl = ops.add_layernorm_grouped(cu(t["x"]), o(t["pend"]), o(t["dprev"]), N, cu(t["g1"]), cu(t["b1"]), rows, 1e-6, want_sum=True)
+        wq, sq = ops.pack_weights_hl32([cu(w).view(3 * C, 1, 1, C).contiguous() for w in t["wqkv"]])
+        wp, sp = ops.pack_weights_hl32([cu(w).view(C, 1, 1, C).contiguous() for w in t["wproj"]])
+        qkv, _ = ops.conv2d_x3(hl, G, False, rows, 1, 1, C, wq, sq, 3 * C, (1, 1), bias=o(t["bqkv"]))
+        ctx = ops.svtr_attention(qkv.view(G * B, N, 3 * C), heads, 32 ** -0.5, o(t["mask"]), want_f32=False, want_hl=True, x3=True)
+        br, _ = ops.conv2d_x3(ctx, G, False, rows, 1, 1, C, wp, sp, C, (1, 1), bias=cu(t["bproj"]))
+        x2, _, hl2 = ops.add_layernorm_grouped(tt, br.view(G * B, N, C), cu(t["d1"]), N, cu(t["g2"]), cu(t["b2"]), rows, 1e-6, want_sum=True)
+        y2 = _hl32_to_f32(hl2, G * rows, C)
+        for _ in range(3):
+            x_out, y_hl = _mixer_run(ops, t, C, N, G, B)
+            bad = ((x_out - x2).abs().amax((1, 2)) > 1e-4).sum()
+            assert int(bad) == 0, (C, int(bad))
+            bad = ((_hl32_to_f32(y_hl, G * rows, C) - y2).abs().amax(1) > 2e-4).sum()
+            assert int(bad) == 0, (C, int(bad))
+
+
 @pytest.mark.parametrize("magnitude", [1e-4, 30.0])
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(32, 4, 65, 128, 128), (64, 2, 16, 128, 160), (32, 8, 64, 256, 128), (256, 4, 65, 128, 256)])
 def test_wgrad_in_the_winograd_domain(B, H, W, Cin, Cout, magnitude):
