@@ -42,6 +42,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 constexpr float LOG2E_F = 1.4426950408889634f;
 constexpr float PBIAS = 12.f;       // probabilities carry 2^12 (cancelled by 1 / l): small ones stay out of fp16's subnormal range
 constexpr float OPSCALE = 64.f;     // q, k, v are split as 64 * x (attention.hip)
+constexpr float SINV = 1.f / (OPSCALE * OPSCALE);
 
 struct MixerParams {
   const float* x;                 // [imgs][N][C] residual stream
@@ -69,7 +70,7 @@ __device__ __forceinline__ f32x16 mma(const u32x4 a, const u32x4 b, const f32x16
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16v8*>(&a), *reinterpret_cast<const f16v8*>(&b), c, 0, 0, 0);
 }
 
-template <int C, int NT, int IMG, int CHUNKS>
+template <int C, int NT, int IMG, int CHUNKS, int RING>
 __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerParams p) {
   static_assert(CHUNKS == 1 || (CHUNKS == 2 && IMG == 1), "key chunks: one image per workgroup");
   constexpr int NW = NT * IMG, CB = C / 32, KB = C / 16, HEADS = C / 32, OC = C / 32;
@@ -77,12 +78,14 @@ __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerPa
   constexpr int SLAB = C * 128;                      // one weight slab: 32 rows x C channels, or C rows x 32 channels
   constexpr int NDMA = SLAB / 1024;                  // 1-KiB DMA instructions per slab
   constexpr int DMA_ROUNDS = (NDMA + NW - 1) / NW;
+  // RING slabs in the LDS ring: RING - 1 in flight ahead of the one being consumed
+  constexpr int TOTAL = STEPS * HEADS;
   constexpr int TILE = 32 * 128;                     // one K (or V^T) tile: 32 lines of [hi 32 | lo 32]
   extern __shared__ __attribute__((aligned(128))) unsigned char lds[];
   unsigned char* lds_k = lds;                        // [IMG * NT] tiles, line = key
   unsigned char* lds_v = lds + IMG * NT * TILE;      // [IMG * NT] tiles, line = d, slots = the tile's keys in score-register order
-  unsigned char* slab0 = lds + 2 * IMG * NT * TILE;  // two slabs
-  float* bias_lds = reinterpret_cast<float*>(slab0 + 2 * SLAB);      // [3C]
+  unsigned char* slab0 = lds + 2 * IMG * NT * TILE;  // RING slabs
+  float* bias_lds = reinterpret_cast<float*>(slab0 + RING * SLAB);   // [3C]
 
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int half = lane >> 5, l31 = lane & 31;
@@ -122,7 +125,11 @@ __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerPa
       }
     }
   };
-  issue(0, slab0);
+#pragma unroll
+  for (int i = 0; i < RING - 1; ++i)
+    if (i < TOTAL) issue(i, slab0 + i * SLAB);
+  // DMA instructions of one slab that THIS wave issues (they divide unevenly when NDMA % NW != 0)
+  const int my_dma = (NDMA % NW == 0 || wave < NDMA % NW) ? DMA_ROUNDS : DMA_ROUNDS - 1;
 
   // ---- t = x + drop_prev * pending, LayerNorm1, split: MFMA fragments of one token per lane pair, k-block kb = channels
   // 16 kb + 8 half .. + 7 of token lane & 31
@@ -194,13 +201,19 @@ __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerPa
   unsigned char* my_v = lds_v + (wi * NT + ti) * TILE;
   const unsigned* brow = p.mask_bits ? p.mask_bits + (long)(tok < p.N ? tok : 0) * ((p.N + 31) / 32) : nullptr;
 
-  // every slab step starts the same way: own DMAs of this slab retired (spelled out: hipcc does not order LDS-DMA behind
-  // __syncthreads()), then everyone's have and everyone is done with the other buffer; the next slab starts streaming
+  // every slab step starts the same way: own DMAs of this slab retired -- a counted wait: the younger slabs of the ring stay in
+  // flight (spelled out: hipcc does not order LDS-DMA behind __syncthreads()) -- then everyone's have and everyone is done with the
+  // slab consumed one step ago, whose buffer takes the slab RING - 1 steps ahead
   auto next_slab = [&](int step) -> const unsigned char* {
-    __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));              // vmcnt(0)
+    const int younger = min(RING - 2, TOTAL - 1 - step) * my_dma;      // this wave's DMA instructions issued after slab `step`'s
+    if (RING > 2 && younger >= 4) __builtin_amdgcn_s_waitcnt((4 & 15) | (7 << 4) | (15 << 8));
+    else if (younger == 3) __builtin_amdgcn_s_waitcnt(3 | (7 << 4) | (15 << 8));
+    else if (younger == 2) __builtin_amdgcn_s_waitcnt(2 | (7 << 4) | (15 << 8));
+    else if (younger == 1) __builtin_amdgcn_s_waitcnt(1 | (7 << 4) | (15 << 8));
+    else __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));
     __syncthreads();
-    if (step + 1 < STEPS * HEADS) issue(step + 1, slab0 + ((step + 1) & 1) * SLAB);
-    return slab0 + (step & 1) * SLAB;
+    if (step + RING - 1 < TOTAL) issue(step + RING - 1, slab0 + ((step + RING - 1) % RING) * SLAB);
+    return slab0 + (step % RING) * SLAB;
   };
   // W . y^T (weights as the A operand): lane = token, register e = row (e & 3) + 8 (e >> 2) + 4 half of the slab
   auto w_times_y = [&](const unsigned char* cur, const u32x4* fh, const u32x4* fl) -> f32x16 {
@@ -305,8 +318,6 @@ __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerPa
 #pragma unroll
           for (int m = 0; m < 2; ++m) s = mma(kh[m], qh[m], s);
         }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) s[e] *= 1.f / (OPSCALE * OPSCALE);
         if (brow) {
 #pragma unroll
           for (int e = 0; e < 16; ++e)
@@ -321,7 +332,7 @@ __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerPa
 #pragma unroll
         for (int e = 1; e < 16; ++e) mx = fmaxf(mx, s[e]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
+        const float m_new = fmaxf(m_run, mx * SINV);             // (the scores carry OPSCALE^2: folded into the exponent's FMA)
         const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
         const float corr = __builtin_amdgcn_exp2f(m_run - m_safe);
         const float mb = m_safe - PBIAS;
@@ -332,7 +343,7 @@ __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerPa
           f16v8 vh, vl;
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            const float pe = __builtin_amdgcn_exp2f(s[8 * m + j] - mb);
+            const float pe = __builtin_amdgcn_exp2f(fmaf(s[8 * m + j], SINV, -mb));
             psum += pe;
             _Float16 a, b;
             split_f16(pe, a, b);
@@ -431,12 +442,22 @@ __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerPa
   }
 
   // ---- epilogue: registers 4 k .. 4 k + 3 of block oc are channels 32 oc + 8 k + 4 half + 0 .. 3 of token lane & 31:
-  // x_out = t + drop1 * (branch + bias), LayerNorm2 on the registers, HL32 lines for the Mlp kernel
-  if (ok) {
+  // x_out = t + drop1 * (branch + bias), LayerNorm2 on the registers, HL32 lines for the Mlp kernel.  A lane holds 16-byte pieces of
+  // one token's row: stored directly, every instruction would scatter 64 pieces over 64 rows (measured: a third of the kernel's
+  // time).  The wave's 32 rows go through a private LDS tile instead (the K / V tiles and the slab ring are free now) and leave as
+  // whole rows, 1 KiB contiguous per store instruction.
+  {
+    constexpr int ROWB = C * 4 + 16;                 // padded row: conflict-free 16-byte column writes
+    constexpr int LPR = C * 4 / 16, RPI = 64 / LPR;  // lanes per row, rows per store instruction
+    __syncthreads();                                 // every wave is done with the K / V tiles and the last slab
+    unsigned char* stg = lds + wave * (32 * ROWB);
+    const int tbase = (qc * NT + ti) * 32;
+    const int nvalid = img < p.imgs ? min(32, max(0, p.N - tbase)) : 0;
+    const long row0 = (long)(img < p.imgs ? img : img0) * p.N + tbase;
+    const int rr = lane / LPR, cc = (lane % LPR) * 16;
     const float* xr = p.x + row * C;
     const float* pr = p.pend ? p.pend + row * C : nullptr;
-    const float d1 = p.drop1 ? p.drop1[img] : 1.f;
-    float* xo = p.x_out + row * C;
+    const float d1 = p.drop1 ? p.drop1[img < p.imgs ? img : img0] : 1.f;
     float s = 0.f;
 #pragma unroll
     for (int oc = 0; oc < OC; ++oc)
@@ -457,8 +478,16 @@ __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerPa
           out[oc][4 * k + j] = v[j];
           s += v[j];
         }
-        *reinterpret_cast<f32x4*>(xo + c) = v;
+        *reinterpret_cast<f32x4*>(stg + l31 * ROWB + c * 4) = v;
       }
+    {
+#pragma unroll
+      for (int i = 0; i < 32 / RPI; ++i) {
+        const int r = i * RPI + rr;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(stg + r * ROWB + cc);
+        if (r < nvalid) *reinterpret_cast<f32x4*>(reinterpret_cast<unsigned char*>(p.x_out + (row0 + r) * C) + cc) = v;
+      }
+    }
     s += __shfl_xor(s, 32);
     const float mean = s / (float)C;
     float q = 0.f;
@@ -468,7 +497,6 @@ __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerPa
       for (int e = 0; e < 16; ++e) { const float d = out[oc][e] - mean; q += d * d; }
     q += __shfl_xor(q, 32);
     const float rstd = 1.f / sqrtf(q / (float)C + p.eps2);
-    unsigned char* yr = p.y_hl + row * (long)CB * 128;
 #pragma unroll
     for (int oc = 0; oc < OC; ++oc)
 #pragma unroll
@@ -484,22 +512,31 @@ __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerPa
           hi[j] = a;
           lo[j] = b;
         }
-        unsigned char* line = yr + oc * 128 + (8 * k + 4 * half) * 2;
+        unsigned char* line = stg + l31 * ROWB + oc * 128 + (8 * k + 4 * half) * 2;      // the row's HL32 lines: [hi 32 | lo 32] per block
         *reinterpret_cast<f16v4*>(line) = hi;
         *reinterpret_cast<f16v4*>(line + 64) = lo;
       }
+    {
+#pragma unroll
+      for (int i = 0; i < 32 / RPI; ++i) {
+        const int r = i * RPI + rr;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(stg + r * ROWB + cc);
+        if (r < nvalid) *reinterpret_cast<u32x4*>(p.y_hl + (row0 + r) * (long)CB * 128 + cc) = v;
+      }
+    }
   }
 }
 
-template <int C, int NT, int IMG, int CHUNKS>
+template <int C, int NT, int IMG, int CHUNKS, int RING>
 int launch_mixer(const MixerParams& p, hipStream_t st) {
-  constexpr size_t ldsz = 2 * IMG * NT * 32 * 128 + 2 * C * 128 + 3 * C * sizeof(float);
+  constexpr size_t ring = 2 * IMG * NT * 32 * 128 + RING * C * 128 + 3 * C * sizeof(float), stage = (size_t)NT * IMG * 32 * (C * 4 + 16);
+  constexpr size_t ldsz = ring > stage ? ring : stage;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)svtr_mixer_kernel<C, NT, IMG, CHUNKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);
+    (void)hipFuncSetAttribute((const void*)svtr_mixer_kernel<C, NT, IMG, CHUNKS, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);
     attr_set = true;
   }
-  hipLaunchKernelGGL((svtr_mixer_kernel<C, NT, IMG, CHUNKS>), dim3((unsigned)((p.imgs + IMG - 1) / IMG * CHUNKS)), dim3(NT * IMG * 64), ldsz, st, p);
+  hipLaunchKernelGGL((svtr_mixer_kernel<C, NT, IMG, CHUNKS, RING>), dim3((unsigned)((p.imgs + IMG - 1) / IMG * CHUNKS)), dim3(NT * IMG * 64), ldsz, st, p);
   MRN_LAUNCH_CHECK("svtr_mixer_x3");
   return MRN_OK;
 }
@@ -540,6 +577,6 @@ MRN_EXPORT int mrn_svtr_mixer_x3_f32(const float* x, const float* pending, const
   p.drop1 = drop1; p.g2 = g2; p.b2 = b2; p.x_out = x_out; p.y_hl = (unsigned char*)y_hl;
   p.imgs = imgs; p.imgs_per_group = imgs_per_group; p.N = N; p.scale = scale; p.eps1 = eps1; p.eps2 = eps2;
   const hipStream_t st = (hipStream_t)stream;
-  if (C == 64) return N <= 224 ? launch_mixer<64, 7, 1, 1>(p, st) : N <= 256 ? launch_mixer<64, 8, 1, 1>(p, st) : launch_mixer<64, 8, 1, 2>(p, st);
-  return N <= 128 ? launch_mixer<128, 4, 2, 1>(p, st) : launch_mixer<128, 8, 1, 1>(p, st);
+  if (C == 64) return N <= 224 ? launch_mixer<64, 7, 1, 1, 4>(p, st) : N <= 256 ? launch_mixer<64, 8, 1, 1, 4>(p, st) : launch_mixer<64, 8, 1, 2, 4>(p, st);
+  return N <= 128 ? launch_mixer<128, 4, 2, 1, 4>(p, st) : launch_mixer<128, 8, 1, 1, 4>(p, st);
 }
