@@ -343,6 +343,7 @@ class ConvBlockFn(torch.autograd.Function):
         stride, padding = _pair(conv.stride), _pair(conv.padding)
         ctx.geom = (stride, padding, relu, precision, bn is not None, residual is not None)
         ctx.wpacked = w
+        ctx.conv = conv
         # one max|x| pass serves the forward conv and the weight gradient (both split x with the same power-of-two scale)
         x3s = precision == "fp16x3s" and x.shape[-1] % 32 == 0
         # (the producer of x may have folded max|x| into its own pass: ops.scale_shift_act(range_target=...) of the previous block)
@@ -397,21 +398,33 @@ class ConvBlockFn(torch.autograd.Function):
         dy = dy.contiguous()
         if sd is None and precision == "fp16x3s":
             sd = ops.pow2_scale(dy, ops.TRAIN_OPERAND_PEAK)                                   # shared by the data and weight gradients
-        if ctx.needs_input_grad[0]:
-            wt = ops.pack_dgrad_weight(w.ohwi)
-            dx = ops.conv2d_dgrad(dy, wt, (x.shape[1], x.shape[2]), stride, padding, precision=precision, dy_scale=sd)
-        dw = None
-        if ctx.needs_input_grad[1]:
+
+        def weight_gradient():                                                               # -> [O,kh,kw,I]
             kh, kw = w.shape[1], w.shape[2]
             if precision == "fp16x3s" and x.shape[-1] % 4 == 0 and ops.TRAIN_WGRAD_X3:
                 if ops.wgrad_wino_supported(dy, x, (kh, kw), stride, padding):
-                    dw = ops.unpack_conv_weight(ops.conv2d_wgrad_x3_wino(dy, x, dy_scale=sd, x_scale=ctx.x_scale))
-                elif ops.WGRAD_WINDOWS and ops.wgrad_windows_supported(dy, x, (kh, kw), stride, padding):
-                    dw = ops.unpack_conv_weight(ops.conv2d_wgrad_x3_windows(dy, x, dy_scale=sd, x_scale=ctx.x_scale))
-                else:
-                    dw = ops.unpack_conv_weight(ops.conv2d_wgrad_x3(dy, x, (kh, kw), stride, padding, dy_scale=sd, x_scale=ctx.x_scale))
+                    return ops.conv2d_wgrad_x3_wino(dy, x, dy_scale=sd, x_scale=ctx.x_scale)
+                if ops.WGRAD_WINDOWS and ops.wgrad_windows_supported(dy, x, (kh, kw), stride, padding):
+                    return ops.conv2d_wgrad_x3_windows(dy, x, dy_scale=sd, x_scale=ctx.x_scale)
+                return ops.conv2d_wgrad_x3(dy, x, (kh, kw), stride, padding, dy_scale=sd, x_scale=ctx.x_scale)
+            return ops.conv2d_wgrad(dy, x, (kh, kw), stride, padding)
+        dw = None
+        if ctx.needs_input_grad[1]:
+            wgrad = ctx.conv.weight.grad
+            if (ops.WGRAD_SIDE_STREAM and ops.GRAD_DIRECT and wgrad is not None and wgrad.is_contiguous() and wgrad.dtype == torch.float32
+                    and torch.is_grad_enabled() is False):
+                # off the critical path: second stream, accumulated straight into the parameter's gradient (ops.side_stream_begin)
+                side = ops.side_stream_begin()
+                with torch.cuda.stream(side):
+                    ops.unpack_conv_weight(weight_gradient(), out=wgrad, accumulate=True)
+                for t_ in (dy, x, sd, ctx.x_scale):
+                    if t_ is not None:
+                        t_.record_stream(side)
             else:
-                dw = ops.unpack_conv_weight(ops.conv2d_wgrad(dy, x, (kh, kw), stride, padding))
+                dw = ops.unpack_conv_weight(weight_gradient())
+        if ctx.needs_input_grad[0]:
+            wt = ops.pack_dgrad_weight(w.ohwi)
+            dx = ops.conv2d_dgrad(dy, wt, (x.shape[1], x.shape[2]), stride, padding, precision=precision, dy_scale=sd)
         return dx, dw, dbias, dgamma, dbeta, dres, None
 
 

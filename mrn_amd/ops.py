@@ -1361,11 +1361,53 @@ def conv2d_wgrad(dy, x, ksize, stride, padding):
     return dw.view(Cout, kh, kw, Cin)
 
 
-def unpack_conv_weight(g_ohwi):
+def unpack_conv_weight(g_ohwi, out=None, accumulate=False):
+    """[O,kh,kw,I] -> the parameter's [O,I,kh,kw] layout; out / accumulate: added into an existing gradient buffer"""
     O, kh, kw, I = g_ohwi.shape
-    out = torch.empty(O, I, kh, kw, device=g_ohwi.device, dtype=torch.float32)
-    call("mrn_unpack_conv_weight_f32", _p(g_ohwi.contiguous()), _p(out), O, I, kh, kw, 0, _stream())
+    if out is None:
+        out = torch.empty(O, I, kh, kw, device=g_ohwi.device, dtype=torch.float32)
+        accumulate = False
+    assert out.is_contiguous() and tuple(out.shape) == (O, I, kh, kw)
+    call("mrn_unpack_conv_weight_f32", _p(g_ohwi.contiguous()), _p(out), O, I, kh, kw, int(bool(accumulate)), _stream())
     return out
+
+
+# ---- weight gradients off the critical path --------------------------------------------------------------------------------
+# loss.backward() of a trained expert is a chain: BatchNorm backward -> data gradient -> the previous layer's BatchNorm backward ...
+# The weight gradient of a layer (two operand transposes, the K-window GEMM, the fold back to [O,I,kh,kw]) hangs off that chain.
+# With WGRAD_SIDE_STREAM it is issued on a second HIP stream and ACCUMULATED straight into the parameter's .grad (the flat gradient
+# of optim.FlatOptimizer), so its many short launches fill the tails of the chain's kernels; the backward pass's final callback
+# joins the two streams before anyone reads a gradient.  Off while a bucketed all-reduce counts post-accumulate hooks (N > 1).
+WGRAD_SIDE_STREAM = os.environ.get("MRN_WGRAD_STREAM", "1") == "1"
+GRAD_DIRECT = True
+_SIDE_STREAMS = {}
+_SIDE_PENDING = [False]
+
+
+def side_stream():
+    dev = torch.cuda.current_device()
+    st = _SIDE_STREAMS.get(dev)
+    if st is None:
+        st = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+    return st
+
+
+def join_side_stream():
+    """the current stream waits for everything issued on the side stream (called once at the end of a backward pass)"""
+    if _SIDE_PENDING[0]:
+        _SIDE_PENDING[0] = False
+        torch.cuda.current_stream().wait_stream(side_stream())
+
+
+def side_stream_begin():
+    """-> the side stream, ordered behind everything issued so far on the current stream; the first use inside a backward pass queues
+    the join as that pass's final callback"""
+    st = side_stream()
+    st.wait_stream(torch.cuda.current_stream())
+    if not _SIDE_PENDING[0]:
+        _SIDE_PENDING[0] = True
+        torch.autograd.Variable._execution_engine.queue_callback(join_side_stream)
+    return st
 
 
 def bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres=False, range_target=None):

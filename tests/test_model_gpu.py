@@ -622,6 +622,45 @@ def test_loop_a_trba_gradients_vs_oracle():
         assert e_hip <= max(3.0 * e_ref, 2e-3), f"{n}: HIP vs f64 {e_hip:.2e}, torch-f32 vs f64 {e_ref:.2e}"
 
 
+def test_loop_a_weight_gradients_on_the_side_stream_match():
+    """ops.WGRAD_SIDE_STREAM: the trained convolutions' weight gradients issued on a second stream and accumulated straight into the
+    flat gradient (functional.ConvBlockFn.backward) give the flat gradient of the single-stream autograd path (to its run-to-run noise), also when
+    gradients accumulate over two backward passes; the backward pass's final callback has joined the streams before .grad is read."""
+    from mrn_amd import functional as Fn
+    from mrn_amd import ops
+    from mrn_amd.optim import FlatAdam
+    kind, classes, B, seed = "trba", (41,), 3, 6
+    g = load_golden("trba_mrn3")
+    opt, net = build_net(kind, (41, 71, 98), g, 2)
+    image, words, chars, _ = det_inputs(kind, classes, B, seed)
+    conv, labels_index, labels_length = labels_for(kind, words, chars)
+    net.train()
+    for n, p in net.named_parameters():
+        p.requires_grad = n.startswith("model.0.")
+    fo = FlatAdam([p for p in net.parameters() if p.requires_grad], lr=1e-3)
+    bn_state = {k: v.clone() for k, v in net.state_dict().items() if "running" in k or "num_batches" in k}
+
+    def flat_grad(side, passes):
+        net.load_state_dict(bn_state, strict=False)
+        ops.WGRAD_SIDE_STREAM = side
+        fo.zero_grad()
+        for _ in range(passes):
+            preds = net.model[0](image.cuda(), labels_index[:, :-1].cuda(), True)["predict"]
+            Fn.cross_entropy(preds, labels_index[:, 1:].cuda(), 1).backward()
+        return fo.grad.clone()
+    keep = ops.WGRAD_SIDE_STREAM
+    try:
+        for passes in (1, 2):
+            ref, ref2 = flat_grad(False, passes), flat_grad(False, passes)
+            got = flat_grad(True, passes)
+            assert float(ref.abs().max()) > 0
+            noise = float((ref - ref2).abs().max())          # run-to-run (atomic reductions in the recurrent / loss kernels)
+            print("side stream: max |grad| %.3e, run-to-run %.3e, side vs main %.3e" % (float(ref.abs().max()), noise, float((ref - got).abs().max())))
+            assert float((ref - got).abs().max()) <= max(4 * noise, 1e-7 * float(ref.abs().max()))
+    finally:
+        ops.WGRAD_SIDE_STREAM = keep
+
+
 def test_dernet_vs_golden():
     """DERNet (reference modules/model.py:203-312) forward in DER's training configuration + weight_align"""
     from mrn_amd.modules.model import DERNet

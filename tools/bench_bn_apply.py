@@ -33,6 +33,14 @@ def main():
                              ("res + hl", dict(residual=res, want_f32=False, want_hl=True), 3 * n)]:
             ms = timeit(lambda: ops.bn_apply_grouped(y, scale, shift, relu=True, **kw))
             print(f"bn_apply {H}x{W}x{C} {name:16s} {ms:7.3f} ms  {nb / ms / 1e6:7.0f} GB/s")
+        if C >= 128:
+            Wq = (W + 3) // 4
+            nv = G * B * H * Wq * 6 * C * 4
+            res_hl = ops.split_hl32(res)
+            for name, kw, nb in [("wino only", dict(), n + nv), ("wino + res(hl) + hl", dict(residual_hl=res_hl, want_hl=True), 3 * n + nv),
+                                 ("wino + res(f32) + f32", dict(residual=res, want_f32=True), 3 * n + nv)]:
+                ms = timeit(lambda: ops.bn_apply_wino_grouped(y, scale, shift, 4, relu=True, **kw))
+                print(f"bn_apply_wino {H}x{W}x{C} {name:22s} {ms:7.3f} ms  {nb / ms / 1e6:7.0f} GB/s")
         if H >= 8:
             ms = timeit(lambda: ops.maxpool_grouped(y, (2, 2), (2, 2), (0, 0), scale, shift, relu=True, want_f32=False, want_hl=True))
             print(f"maxpool  {H}x{W}x{C} -> hl          {ms:7.3f} ms  {(n + n / 4) / ms / 1e6:7.0f} GB/s")
