@@ -397,6 +397,19 @@ int mrn_svtr_mixer_x3_f32(const float* x, const float* pending, const float* dro
                           const void* wproj_hl, const float* sproj, const float* bproj, const float* drop1, const float* g2,
                           const float* b2, float eps2, float* x_out, void* y_hl, int imgs, int imgs_per_group, int N, int C,
                           void* stream);
+/* A whole SVTR mixing block (modules/svtr.py:154-204 Block.forward, both residual branches) of G lock-step frozen experts in ONE kernel:
+ * mrn_svtr_mixer_x3_f32 followed, on the same registers, by the Mlp half of mrn_svtr_mlp_x3_f32:
+ *   t = x + drop_prev * pending;  u = t + drop1 * proj(attention(qkv(LayerNorm1(t))));  x_out = u + drop2 * fc2(GELU(fc1(LayerNorm2(u))))
+ * Arguments as mrn_svtr_mixer_x3_f32 (no y_hl) plus w1_hl [G][4C][C/32][128 B] (fc1 packed from [4C][1][C] with the INPUT channel of every
+ * 32-block permuted: position 16 s + 8 h + j holds channel (j & 3) + 8 (2 s + (j >> 2)) + 4 h), s1 [G][2], bm1 [G][4C]; w2_hl
+ * [G][C][4C/32][128 B] (fc2, hidden index permuted the same way, as for mrn_svtr_mlp_x3_f32), s2 [G][2], bm2 [G][C]; drop2 [imgs] or NULL.
+ * x_out must not alias x or pending.  Same supported shapes as mrn_svtr_mixer_x3_f32. */
+int mrn_svtr_block_x3_f32(const float* x, const float* pending, const float* drop_prev, const float* g1, const float* b1, float eps1,
+                          const void* wqkv_hl, const float* sqkv, const float* bqkv, const void* mask_bits, float scale,
+                          const void* wproj_hl, const float* sproj, const float* bproj, const float* drop1, const float* g2,
+                          const float* b2, float eps2, const void* w1_hl, const float* s1, const float* bm1, const void* w2_hl,
+                          const float* s2, const float* bm2, const float* drop2, float* x_out, int imgs, int imgs_per_group, int N,
+                          int C, void* stream);
 /* Fused multi-head attention of the SVTR mixing blocks (head dimension 32), inference path of the frozen experts:
  * out[b][n][h*32 + :] = softmax_m(scale * q[b][n][h] . k[b][m][h] + mask[n][m]) @ v[b][m][h]; qkv [B][N][3*C] (q | k | v,
  * C = heads * 32), mask [N][N] additive and SYMMETRIC (SVTR's local window mask) or NULL, out [B][N][C] fp32 and / or

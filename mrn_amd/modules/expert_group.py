@@ -378,6 +378,21 @@ class BackboneGroup(_GroupedLinear):
                                                   build_mixer)
             drop2 = self._drop_scales(blks, B, x.device)
             g2, b2 = self._ln_params(name + ".ln2", [b.norm2 for b in blks])
+            Ch = blks[0].mlp.fc1.out_features
+            if ops.SVTR_FUSED_BLOCK and ops.SVTR_FUSED_MLP and Ch == 4 * C:
+                # ... and the Mlp half on the same registers: the whole Block.forward is one launch
+                fc1s, fc2s = [b.mlp.fc1 for b in blks], [b.mlp.fc2 for b in blks]
+
+                def build_block():
+                    pc, ph = ops.mlp_hidden_permutation(C, x.device), ops.mlp_hidden_permutation(Ch, x.device)
+                    w1, s1 = ops.pack_weights_hl32([m.weight.detach().index_select(1, pc).contiguous().view(Ch, 1, 1, C) for m in fc1s])
+                    w2, s2 = ops.pack_weights_hl32([m.weight.detach().index_select(1, ph).contiguous().view(C, 1, 1, Ch) for m in fc2s])
+                    return (w1, s1, torch.stack([m.bias.detach() for m in fc1s]).contiguous(), w2, s2,
+                            torch.stack([m.bias.detach() for m in fc2s]).contiguous())
+                w1, s1, b1_, w2, s2, b2_ = self._cached(name + ".block", [t_ for m in fc1s + fc2s for t_ in (m.weight, m.bias)], build_block)
+                x = ops.svtr_block_fused(x, br, dr, g1, b1, b0.norm1.eps, wq, sq, bq, mixer.mask, mixer.scale, wp, sp, bp, drop1,
+                                         g2, b2, b0.norm2.eps, w1, s1, b1_, w2, s2, b2_, drop2, B)
+                return x, None
             x, y_hl = ops.svtr_mixer_fused(x, br, dr, g1, b1, b0.norm1.eps, wq, sq, bq, mixer.mask, mixer.scale, wp, sp, bp, drop1,
                                            g2, b2, b0.norm2.eps, B)
         else:
@@ -431,7 +446,8 @@ class BackboneGroup(_GroupedLinear):
             for i in range(len(blocks[0])):
                 x, pending = self._svtr_block("svtr%d.%d" % (si, i), x, pending, [b[i] for b in blocks], B, N)
             # SubSample (:298-305): fold the last residual add, 3x3 stride-(2,1) conv, LayerNorm
-            _, _, hl = ops.add_layernorm_grouped(x, pending[0], pending[1], N, want_sum=False, want_f32=False, want_hl=True)
+            pb, pd = pending if pending is not None else (None, None)      # (None: the last block ran as one fused launch)
+            _, _, hl = ops.add_layernorm_grouped(x, pb, pd, N, want_sum=False, want_f32=False, want_hl=True)
             subs = [getattr(n, "sub_sample%d" % (si + 1)) for n in nets]
             y = self.layer(Act((G, B, H, W, C), None, hl), [s.conv for s in subs], None, relu=False, want_f32=True, want_hl=False)
             _, _, H, W, C = y.shape

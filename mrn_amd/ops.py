@@ -1654,6 +1654,32 @@ def svtr_mixer_fused(x, pending, drop_prev, g1, b1, eps1, wqkv_hl, sqkv, bqkv, m
     return x_out, y_hl
 
 
+# ... and the Mlp half in the same kernel (whole Block.forward, mrn_svtr_block_x3_f32): built, parity-tested, and measured SLOWER than the two
+# half-block kernels (C = 128, 256 tokens: 1038 vs 965 us; C = 64, 512 tokens: 1162 vs 1072 us per block of 6 x 256 images) -- the
+# attention half runs one 8-wave workgroup per CU at 256 registers, and the Mlp phase inherits that occupancy, while the stand-alone Mlp
+# kernel (96 registers) runs two workgroups per CU; the 3 tensor passes it saves do not pay for that.  Opt-in: MRN_SVTR_BLOCK=fused.
+SVTR_FUSED_BLOCK = os.environ.get("MRN_SVTR_BLOCK", "half") == "fused"
+
+
+def svtr_block_fused(x, pending, drop_prev, g1, b1, eps1, wqkv_hl, sqkv, bqkv, mask, scale, wproj_hl, sproj, bproj, drop1, g2, b2, eps2,
+                     w1_hl, s1, bm1, w2_hl, s2, bm2, drop2, imgs_per_group):
+    """x [imgs, N, C] -> the residual stream after one whole mixing block (mrn_svtr_block_x3_f32); w1_hl packed from the input-permuted
+    fc1 weights, w2_hl from the hidden-permuted fc2 weights, wproj_hl from the input-permuted proj weights (mlp_hidden_permutation)"""
+    _chk(x, pending, drop_prev, g1, b1, bqkv, bproj, drop1, g2, b2, bm1, bm2, drop2)
+    imgs, N, C = x.shape
+    assert x.is_contiguous() and (pending is None or (pending.is_contiguous() and pending.numel() == x.numel()))
+    x_out = torch.empty_like(x)
+    bits = _mask_bits(mask) if mask is not None else None
+    t0 = CONV_TIMER.begin() if CONV_TIMER is not None else None
+    call("mrn_svtr_block_x3_f32", _p(x), _p(pending), _p(drop_prev), _p(g1), _p(b1), float(eps1), _p(wqkv_hl), _p(sqkv), _p(bqkv),
+         _p(bits), float(scale), _p(wproj_hl), _p(sproj), _p(bproj), _p(drop1), _p(g2), _p(b2), float(eps2), _p(w1_hl), _p(s1), _p(bm1),
+         _p(w2_hl), _p(s2), _p(bm2), _p(drop2), _p(x_out), imgs, imgs_per_group, N, C, _stream())
+    if t0 is not None:
+        rows = imgs * N
+        CONV_TIMER.end(t0, 2.0 * rows * C * 12 * C + 4.0 * rows * N * C, "fp16x3/svtrblock", 4.0 * rows * C * (3 if pending is not None else 2))
+    return x_out
+
+
 def residual_scale_rows(x, branch, scale, rows_per_group, out=None):
     """x + scale[group] * branch on [rows, C] (contiguous)"""
     assert x.is_contiguous() and branch.is_contiguous()

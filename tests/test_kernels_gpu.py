@@ -1077,6 +1077,73 @@ def test_svtr_fused_mixer(ops, C, N, G, B, masked, bias, with_pending):
     assert_close("fused mixer vs unfused chain: residual stream", x_out, x2, atol=4e-6, rtol=2e-6)
 
 
+@pytest.mark.parametrize("C,N,G,B,masked,bias,with_pending", [(64, 200, 2, 3, True, True, True), (128, 100, 2, 4, True, True, False),
+                                                              (64, 512, 2, 3, True, True, False), (64, 250, 1, 2, False, True, True),
+                                                              (128, 256, 2, 3, True, True, True), (128, 160, 1, 3, False, False, False)])
+def test_svtr_fused_block(ops, C, N, G, B, masked, bias, with_pending):
+    """mrn_svtr_block_x3_f32 (a whole mixing block -- attention half and Mlp half -- of G experts in one kernel) against float64 torch
+    (modules/svtr.py:154-204) and against the two half-block kernels it chains"""
+    t, heads = _mixer_case(C, N, G, B, masked, bias, with_pending, seed=900)
+    Ch = 4 * C
+    w1 = [rnd(Ch, C, seed=950 + g, scale=(1.0 / C) ** 0.5) for g in range(G)]
+    w2 = [rnd(C, Ch, seed=960 + g, scale=(1.0 / Ch) ** 0.5) for g in range(G)]
+    bm1, bm2 = rnd(G, Ch, seed=970) * 0.2, rnd(G, C, seed=971) * 0.2
+    d2 = (torch.rand(G * B, generator=torch.Generator().manual_seed(5)) > 0.3).float() / 0.7
+    x_ref, y_ref = _mixer_reference(t, C, N, G, B, heads)
+    ref = torch.cat([x_ref[g * B:(g + 1) * B] + d2[g * B:(g + 1) * B].double()[:, None, None] *
+                     (F.gelu(y_ref[g * B:(g + 1) * B] @ w1[g].double().t() + bm1[g].double()) @ w2[g].double().t() + bm2[g].double())
+                     for g in range(G)])
+    dev = torch.device("cuda")
+    o = lambda v: cu(v) if v is not None else None
+    wq, sq = ops.pack_weights_hl32([cu(w).view(3 * C, 1, 1, C).contiguous() for w in t["wqkv"]])
+    pc, ph = ops.mlp_hidden_permutation(C, dev), ops.mlp_hidden_permutation(Ch, dev)
+    wp, sp = ops.pack_weights_hl32([cu(w).index_select(1, pc).contiguous().view(C, 1, 1, C) for w in t["wproj"]])
+    w1p, s1 = ops.pack_weights_hl32([cu(w).index_select(1, pc).contiguous().view(Ch, 1, 1, C) for w in w1])
+    w1n, s1n = ops.pack_weights_hl32([cu(w).view(Ch, 1, 1, C).contiguous() for w in w1])
+    w2p, s2 = ops.pack_weights_hl32([cu(w).index_select(1, ph).contiguous().view(C, 1, 1, Ch) for w in w2])
+    mask = o(t["mask"])
+    out = ops.svtr_block_fused(cu(t["x"]), o(t["pend"]), o(t["dprev"]), cu(t["g1"]), cu(t["b1"]), 1e-6, wq, sq, o(t["bqkv"]), mask, 32 ** -0.5,
+                               wp, sp, cu(t["bproj"]), cu(t["d1"]), cu(t["g2"]), cu(t["b2"]), 1e-6, w1p, s1, cu(bm1), w2p, s2, cu(bm2), cu(d2), B)
+    assert_close("fused block vs float64", out, ref.float(), atol=4e-5, rtol=1e-5)
+    # the two half-block kernels
+    x_mid, y_hl = ops.svtr_mixer_fused(cu(t["x"]), o(t["pend"]), o(t["dprev"]), cu(t["g1"]), cu(t["b1"]), 1e-6, wq, sq, o(t["bqkv"]), mask,
+                                       32 ** -0.5, wp, sp, cu(t["bproj"]), cu(t["d1"]), cu(t["g2"]), cu(t["b2"]), 1e-6, B)
+    br = ops.svtr_mlp_fused(y_hl, G * B * N, B * N, G, C, w1n, s1n, cu(bm1), w2p, s2, cu(bm2))
+    two = x_mid + cu(d2)[:, None, None] * br.view(G * B, N, C)
+    assert_close("fused block vs mixer + Mlp kernels", out, two, atol=4e-6, rtol=2e-6)
+
+
+def test_svtr_fused_block_full_size(ops):
+    """the whole-block kernel at the headline's sizes (6 experts x 256 images; 32 x 100 and 32 x 256 crops), three launches each: every
+    image must agree with the two half-block kernels (pins the slab rings, the K / V tile barriers and the re-read of the block's own
+    first store at full occupancy)"""
+    dev = torch.device("cuda")
+    for C, N in ((64, 200), (128, 100), (64, 512), (128, 256)):
+        G, B = 6, 256
+        Ch = 4 * C
+        t, _ = _mixer_case(C, N, G, B, True, True, True, seed=1000 + C)
+        w1 = [rnd(Ch, C, seed=1050 + g, scale=(1.0 / C) ** 0.5) for g in range(G)]
+        w2 = [rnd(C, Ch, seed=1060 + g, scale=(1.0 / Ch) ** 0.5) for g in range(G)]
+        bm1, bm2 = cu(rnd(G, Ch, seed=1070) * 0.2), cu(rnd(G, C, seed=1071) * 0.2)
+        d2 = cu((torch.rand(G * B, generator=torch.Generator().manual_seed(6)) > 0.3).float() / 0.7)
+        o = lambda v: cu(v) if v is not None else None
+        wq, sq = ops.pack_weights_hl32([cu(w).view(3 * C, 1, 1, C).contiguous() for w in t["wqkv"]])
+        pc, ph = ops.mlp_hidden_permutation(C, dev), ops.mlp_hidden_permutation(Ch, dev)
+        wp, sp = ops.pack_weights_hl32([cu(w).index_select(1, pc).contiguous().view(C, 1, 1, C) for w in t["wproj"]])
+        w1p, s1 = ops.pack_weights_hl32([cu(w).index_select(1, pc).contiguous().view(Ch, 1, 1, C) for w in w1])
+        w1n, s1n = ops.pack_weights_hl32([cu(w).view(Ch, 1, 1, C).contiguous() for w in w1])
+        w2p, s2 = ops.pack_weights_hl32([cu(w).index_select(1, ph).contiguous().view(C, 1, 1, Ch) for w in w2])
+        args = (cu(t["x"]), o(t["pend"]), o(t["dprev"]), cu(t["g1"]), cu(t["b1"]), 1e-6, wq, sq, o(t["bqkv"]), o(t["mask"]), 32 ** -0.5, wp, sp,
+                cu(t["bproj"]), cu(t["d1"]), cu(t["g2"]), cu(t["b2"]), 1e-6)
+        x_mid, y_hl = ops.svtr_mixer_fused(*args, B)
+        br = ops.svtr_mlp_fused(y_hl, G * B * N, B * N, G, C, w1n, s1n, bm1, w2p, s2, bm2)
+        two = x_mid + d2[:, None, None] * br.view(G * B, N, C)
+        for _ in range(3):
+            out = ops.svtr_block_fused(*args, w1p, s1, bm1, w2p, s2, bm2, d2, B)
+            bad = ((out - two).abs().amax((1, 2)) > 2e-4).sum()
+            assert int(bad) == 0, (C, N, int(bad))
+
+
 def test_svtr_fused_mixer_full_size(ops):
     """the supported shapes (32 x 100 and 32 x 256 crops) at the headline's size (6 experts x 256 images), three launches each: every image must agree with the unfused
     chain (pins the slab ring / K-V tile barriers at full occupancy)"""
