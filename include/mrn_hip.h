@@ -297,6 +297,16 @@ int mrn_lstm_layer_fwd_grouped_f32(const void* const* xproj, const void* const* 
 int mrn_lstm_layer_fwd_x3_grouped(const void* const* xproj, const void* const* w_hh, const void* const* w_inv,
                                   const void* const* b_hh, const void* const* out, int groups, int B, int T, int hidden,
                                   int ndir, void* stream);
+/* The same layers as ONE SMALL KERNEL PER TIME STEP replayed from a HIP graph (csrc/lstm_steps.hip): a step is a grid over (expert,
+ * direction, 128-sample tile, 32-unit tile), so all CUs pull W_hh at once instead of one CU per 16 samples streaming all of it; the
+ * step kernels read their buffer pointers from a device-side argument block, so one instantiated graph per (stream, T, grid) serves
+ * every call.  w_hl[g]: [ndir][4H][H/32][128 B] = mrn_pack_weight_hl32 of W_hh [4H][1][H] per direction, w_inv[g]: device float[ndir];
+ * workspace: mrn_lstm_steps_workspace_bytes bytes (h ping-pong planes + cell state), 128-byte aligned, no initialisation needed.
+ * groups <= 8, hidden == 256.  Same arithmetic as mrn_lstm_layer_fwd_x3_grouped. */
+int64_t mrn_lstm_steps_workspace_bytes(int groups, int B, int ndir);
+int mrn_lstm_layer_fwd_x3_steps(const void* const* xproj, const void* const* w_hl, const void* const* w_inv,
+                                const void* const* b_hh, const void* const* out, int groups, int B, int T, int hidden, int ndir,
+                                void* workspace, int64_t workspace_bytes, void* stream);
 /* Weight-stationary form of mrn_lstm_layer_fwd_x3_grouped (same operands, bit-identical results): every (expert, direction) is
  * spread over 16 workgroups that keep their 64 KiB slice of W_hh in LDS for the whole sequence and exchange h through
  * `workspace` (mrn_lstm_cluster_workspace_bytes) once per step.  All mrn_lstm_cluster_workgroups(groups, B, ndir) workgroups of a

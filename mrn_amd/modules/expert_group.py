@@ -539,7 +539,14 @@ class SequenceGroup(_GroupedLinear):
         xproj = self._linear("ih%d" % idx, x_hl, B * T, K, [p[0] for p in packed], [p[2] for p in packed])
         w_hh = self._cached("hh%d" % idx, [p[1] for p in packed], lambda: torch.stack([p[1] for p in packed]).contiguous())
         b_hh = self._cached("bhh%d" % idx, [p[3] for p in packed], lambda: torch.stack([p[3] for p in packed]).contiguous())
-        if ops.RECURRENT_X3:
+        if ops.RECURRENT_X3 and ops.LSTM_STEPS and H == 256:
+            # one kernel per time step over all CUs, replayed from a HIP graph (csrc/lstm_steps.hip): W_hh as HL32 stacks (cached)
+            def build_steps():
+                packs = [ops.pack_lstm_steps_weights([m.rnn.weight_hh_l0, m.rnn.weight_hh_l0_reverse]) for m in mods]
+                return torch.stack([p[0] for p in packs]).contiguous(), torch.stack([p[1] for p in packs]).contiguous()
+            w_s, w_sinv = self._cached("hhst_%d" % idx, [w for m in mods for w in (m.rnn.weight_hh_l0, m.rnn.weight_hh_l0_reverse)], build_steps)
+            rec = ops.lstm_layer_x3_steps(xproj.view(G, B, T, 2 * 4 * H), w_s, w_sinv, b_hh, H, 2)
+        elif ops.RECURRENT_X3:
             # recurrent product on the f16 MFMA: W_hh pre-split into a fragment-major fp16 stream (cached), h split in LDS
             def build():
                 packs = [[ops.pack_fragment_major_h(w) for w in (m.rnn.weight_hh_l0, m.rnn.weight_hh_l0_reverse)] for m in mods]

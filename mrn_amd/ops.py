@@ -963,6 +963,39 @@ def lstm_layer_x3_cluster(xproj, w_hh_h, w_inv, b_hh, hidden, ndir):
     return out
 
 
+# frozen experts' LSTM layers as per-time-step kernels replayed from a HIP graph (csrc/lstm_steps.hip): built, parity-tested, measured
+# (tools/bench_lstm.py, B = 256, T = 65, us per step, persistent streaming kernel -> step kernels): G = 1 13.0 -> 16.6, G = 3 17.2 -> 18.3,
+# G = 6 22.3 -> 19.9.  A graph node costs 1.6 us, but a step is still a chain of dependent latencies (argument block, h / xproj loads,
+# eight slab barriers, pointwise, stores) of ~15 us, and the traffic-optimal tile leaves 16 workgroups per (expert, direction).  The
+# lock-step groups of the headline run G = 2 per stream, where the persistent kernel wins: opt-in (MRN_LSTM_STEPS=1).
+LSTM_STEPS = os.environ.get("MRN_LSTM_STEPS", "0") == "1"
+
+
+def pack_lstm_steps_weights(w_hh_dirs):
+    """list over directions of W_hh [4H, H] fp32 -> (HL32 stack [ndir][4H][H/32][128 B] bytes, inverse prescales [ndir])"""
+    H = w_hh_dirs[0].shape[1]
+    w_hl, sc = pack_weights_hl32([w.detach().contiguous().view(4 * H, 1, 1, H) for w in w_hh_dirs])
+    return w_hl, sc[:, 1].contiguous()
+
+
+def lstm_layer_x3_steps(xproj, w_hl, w_inv, b_hh, hidden, ndir):
+    """xproj [G,B,T,ndir*4H]; w_hl [G, bytes] HL32 stacks and w_inv [G,ndir] (pack_lstm_steps_weights per expert), b_hh [G,ndir*4H]
+    -> [G,B,T,ndir*H]: mrn_lstm_layer_fwd_x3_steps (one kernel per time step, replayed from a HIP graph)"""
+    _chk(xproj, b_hh)
+    G, B, T, _ = xproj.shape
+    assert xproj.is_contiguous() and w_hl.is_contiguous() and w_inv.is_contiguous() and b_hh.is_contiguous()
+    out = torch.empty(G, B, T, ndir * hidden, device=xproj.device, dtype=torch.float32)
+    for g0 in range(0, G, 8):
+        n = min(8, G - g0)
+        nbytes = call("mrn_lstm_steps_workspace_bytes", n, B, ndir)
+        ws = torch.empty(nbytes, device=xproj.device, dtype=torch.uint8)
+        rng = range(g0, g0 + n)
+        call("mrn_lstm_layer_fwd_x3_steps", _ptr_array([xproj[g].data_ptr() for g in rng]), _ptr_array([w_hl[g].data_ptr() for g in rng]),
+             _ptr_array([w_inv[g].data_ptr() for g in rng]), _ptr_array([b_hh[g].data_ptr() for g in rng]),
+             _ptr_array([out[g].data_ptr() for g in rng]), n, B, T, hidden, ndir, _p(ws), nbytes, _stream())
+    return out
+
+
 def lstm_layer_grouped(xproj, w_hh, b_hh, hidden, ndir):
     """xproj [G,B,T,ndir*4H], w_hh [G,ndir,...] (fragment-major stacks), b_hh [G,ndir*4H] -> [G,B,T,ndir*H], one launch"""
     _chk(xproj, w_hh, b_hh)

@@ -558,6 +558,24 @@ def test_lstm_recurrence_on_f16_mfma(ops):
     assert_close("lstm on the f16 MFMA", out, ref, atol=2e-6, rtol=1e-5)
 
 
+@pytest.mark.parametrize("G,B,T,ndir", [(3, 19, 29, 2), (1, 256, 65, 2), (6, 130, 7, 2), (2, 128, 5, 1), (9, 40, 4, 2)])
+def test_lstm_step_kernels_from_a_graph(ops, G, B, T, ndir):
+    """mrn_lstm_layer_fwd_x3_steps (one kernel per time step over (expert, direction, 128-sample tile, 32-unit tile), replayed from a
+    HIP graph whose nodes read a device-side argument block) against the exact-fp32 recurrent kernel and the persistent x3 kernel;
+    several calls on one stream reuse the instantiated graph with other buffers"""
+    Hd = 256
+    ws = [[cu(rnd(4 * Hd, Hd, seed=341 + 2 * g + d, scale=(1 + g % 3) / 16.0)) for d in range(ndir)] for g in range(G)]
+    b_hh = cu(rnd(G, ndir * 4 * Hd, seed=350, scale=1 / 16.0))
+    w_f32 = torch.stack([torch.stack([ops.pack_fragment_major(w) for w in p]) for p in ws]).contiguous()
+    packs = [ops.pack_lstm_steps_weights(p) for p in ws]
+    w_hl, w_inv = torch.stack([p[0] for p in packs]).contiguous(), torch.stack([p[1] for p in packs]).contiguous()
+    for rep in range(2):
+        xproj = cu(rnd(G, B, T, ndir * 4 * Hd, seed=340 + rep, scale=0.7))
+        ref = ops.lstm_layer_grouped(xproj, w_f32, b_hh, Hd, ndir)
+        out = ops.lstm_layer_x3_steps(xproj, w_hl, w_inv, b_hh, Hd, ndir)
+        assert_close("lstm step kernels vs exact fp32", out, ref, atol=2e-6, rtol=1e-5)
+
+
 def test_full_size_dominant_conv_properties(ops):
     """BASELINE-size check of the dominant kernel (6 experts x 256 images, 4x65 maps, 512->512 3x3) through properties that
     do not need a CPU reference: agreement with the exact-fp32 MFMA kernel, homogeneity under power-of-two scaling

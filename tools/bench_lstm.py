@@ -36,6 +36,14 @@ def main():
         b_hh = torch.randn(G, 2 * 4 * H, device="cuda") * 0.1
         ref = ops.lstm_layer_x3_grouped(xproj, w_h, w_inv, b_hh, H, 2)
         ms_old = timeit(lambda: ops.lstm_layer_x3_grouped(xproj, w_h, w_inv, b_hh, H, 2), reps)
+        spk = [ops.pack_lstm_steps_weights(pair) for pair in ws]
+        w_s, w_sinv = torch.stack([p[0] for p in spk]).contiguous(), torch.stack([p[1] for p in spk]).contiguous()
+        out_s = ops.lstm_layer_x3_steps(xproj, w_s, w_sinv, b_hh, H, 2)
+        ms_steps = timeit(lambda: ops.lstm_layer_x3_steps(xproj, w_s, w_sinv, b_hh, H, 2), reps)
+        print(f"G{G} B{B} T{T}: streaming {ms_old:.3f} ms ({ms_old * 1e3 / T:.1f} us/step) | step kernels from a graph {ms_steps:.3f} ms "
+              f"({ms_steps * 1e3 / T:.1f} us/step), max |diff| {(out_s - ref).abs().max().item():.2e}", flush=True)
+        if "--steps-only" in sys.argv:
+            continue
         if ops.call("mrn_lstm_cluster_workgroups", G, B, 2) > 256:
             print(f"G{G} B{B} T{T}: streaming {ms_old:.3f} ms | cluster: does not fit")
             continue
