@@ -14,7 +14,7 @@ import torch
 import torch.nn.init as init
 
 from .. import functional as Fn
-from .. import parallel
+from .. import ops, parallel
 from ..modules.model import Model
 from ..optim import FlatAdadelta, FlatAdam, FlatSGD, OneCycle
 from ..test import validation
@@ -157,9 +157,11 @@ class BaseLearner(object):
         self.optimizer.zero_grad()
         if self.reducer is not None:
             self.reducer.begin()
-        loss.backward()
-        if self.reducer is not None:
+            loss.backward()               # (the buckets count post-accumulate hooks: every gradient goes through autograd's accumulation)
             self.reducer.finish()
+        else:
+            with ops.direct_gradients():  # weight gradients of the trained convolutions: second stream, straight into the flat gradient
+                loss.backward()
         if after_reduce is not None:
             after_reduce()
         momentum = None

@@ -1410,11 +1410,28 @@ def unpack_conv_weight(g_ohwi, out=None, accumulate=False):
 # The weight gradient of a layer (two operand transposes, the K-window GEMM, the fold back to [O,I,kh,kw]) hangs off that chain.
 # With WGRAD_SIDE_STREAM it is issued on a second HIP stream and ACCUMULATED straight into the parameter's .grad (the flat gradient
 # of optim.FlatOptimizer), so its many short launches fill the tails of the chain's kernels; the backward pass's final callback
-# joins the two streams before anyone reads a gradient.  Off while a bucketed all-reduce counts post-accumulate hooks (N > 1).
+# joins the two streams before anyone reads a gradient.  Only inside `with ops.direct_gradients():` (the learners' backward_and_step when no bucketed all-reduce counts
+# post-accumulate hooks, i.e. N = 1).
 WGRAD_SIDE_STREAM = os.environ.get("MRN_WGRAD_STREAM", "1") == "1"
-GRAD_DIRECT = True
+GRAD_DIRECT = False                 # set by direct_gradients(): only a caller that runs loss.backward() INTO .grad may skip autograd's accumulation
 _SIDE_STREAMS = {}
 _SIDE_PENDING = [False]
+
+
+class direct_gradients:
+    """with ops.direct_gradients(): loss.backward() -- inside, backward functions may accumulate a parameter's gradient into its .grad
+    themselves (and return None for it).  Not for torch.autograd.grad(), which wants the gradients returned: hence opt-in per call
+    (il_modules/base.py backward_and_step without a bucketed all-reduce)."""
+
+    def __enter__(self):
+        global GRAD_DIRECT
+        self.prev, GRAD_DIRECT = GRAD_DIRECT, True
+        return self
+
+    def __exit__(self, *exc):
+        global GRAD_DIRECT
+        GRAD_DIRECT = self.prev
+        return False
 
 
 def side_stream():

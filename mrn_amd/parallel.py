@@ -254,8 +254,6 @@ class BucketedAllReduce:
         self.handles = []
         self.launched_log = []
         self.active = True
-        from . import ops
-        ops.GRAD_DIRECT = False        # the buckets count post-accumulate hooks: every gradient goes through autograd's accumulation
 
     def _launch(self, b):
         lo, hi = self.buckets[b]
@@ -269,8 +267,6 @@ class BucketedAllReduce:
 
     def finish(self):
         self.active = False
-        from . import ops
-        ops.GRAD_DIRECT = True
         e0 = None
         if self.record and self.opt.grad.is_cuda:
             e0 = torch.cuda.Event(enable_timing=True)
