@@ -122,6 +122,25 @@ def linear_wgrad(dy, x, sd=None, sx=None):
     return ops.colsum(part.view(S, N * K)).view(N, K)
 
 
+def side_param_grads(params, compute, used):
+    """params: the Parameters a backward function owes gradients (None entries allowed); compute() -> their gradients in the same
+    order.  Inside `with ops.direct_gradients()` (loss.backward() into the flat gradient, N = 1) the gradients are computed on the side
+    stream and ADDED into each parameter's .grad there -- off the backward chain, filling the idle CUs next to the recurrent kernels
+    (ops.side_stream_begin; the backward pass's final callback joins the streams) -- and None is returned for every parameter.
+    `used`: the tensors compute() reads (kept alive for the side stream).  Otherwise: just compute()."""
+    ok = (ops.WGRAD_SIDE_STREAM and ops.GRAD_DIRECT and not torch.is_grad_enabled() and
+          all(p is None or (p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32) for p in params))
+    if not ok:
+        return list(compute())
+    side = ops.side_stream_begin()
+    with torch.cuda.stream(side):
+        for p, g in zip(params, compute()):
+            if p is not None and g is not None:
+                p.grad.add_(g.reshape(p.grad.shape))
+    ops.side_stream_keep(used)
+    return [None] * len(params)
+
+
 class LinearFn(torch.autograd.Function):
     """y = x W^T + b over (strided) rows."""
 
@@ -129,6 +148,7 @@ class LinearFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.params = (weight, bias)
         return ops.linear(x, weight, bias)
 
     @staticmethod
@@ -136,8 +156,9 @@ class LinearFn(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
         dx = linear_dgrad(dy, weight).view(x.shape) if ctx.needs_input_grad[0] else None
-        dw = linear_wgrad(dy, x) if ctx.needs_input_grad[1] else None
-        db = ops.colsum(dy) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        need_w, need_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        dw, db = side_param_grads([ctx.params[0] if need_w else None, ctx.params[1] if need_b else None],
+                                  lambda: (linear_wgrad(dy, x) if need_w else None, ops.colsum(dy) if need_b else None), (dy, x))
         return dx, dw, db
 
 
@@ -417,9 +438,7 @@ class ConvBlockFn(torch.autograd.Function):
                 side = ops.side_stream_begin()
                 with torch.cuda.stream(side):
                     ops.unpack_conv_weight(weight_gradient(), out=wgrad, accumulate=True)
-                for t_ in (dy, x, sd, ctx.x_scale):
-                    if t_ is not None:
-                        t_.record_stream(side)
+                ops.side_stream_keep((dy, x, sd, ctx.x_scale))
             else:
                 dw = ops.unpack_conv_weight(weight_gradient())
         if ctx.needs_input_grad[0]:
@@ -553,6 +572,7 @@ class BiLSTMFn(torch.autograd.Function):
         out, gates, cseq = ops.lstm_layer(xproj, w_hh, b_hh, H, 2, save=True)
         ctx.save_for_backward(x, w_ih, w_hh_f, w_hh_r, out, gates, cseq)
         ctx.H = H
+        ctx.params = (w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r)
         return out
 
     @staticmethod
@@ -564,15 +584,19 @@ class BiLSTMFn(torch.autograd.Function):
         dg = ops.lstm_layer_bwd(dout, gates, cseq, w_hhT, H, 2)              # [B,T,2,4H]
         dg2 = dg.view(B * T, 8 * H)
         dx = linear_dgrad(dg2, w_ih).view(x.shape) if ctx.needs_input_grad[0] else None
-        dw_ih = linear_wgrad(dg2, x.view(B * T, -1))                           # [8H, in]
-        db = ops.colsum(dg2)                                                   # d b_ih = d b_hh
-        # h_{t-1} in each direction's own time order (data movement only)
-        hprev = torch.zeros(B, T, 2, H, device=out.device, dtype=torch.float32)
-        hprev[:, 1:, 0, :] = out[:, :-1, :H]
-        hprev[:, :-1, 1, :] = out[:, 1:, H:]
-        dw_hh_f = linear_wgrad(dg[:, :, 0, :], hprev[:, :, 0, :])
-        dw_hh_r = linear_wgrad(dg[:, :, 1, :], hprev[:, :, 1, :])
-        return (dx, dw_ih[:4 * H], dw_hh_f, db[:4 * H], db[:4 * H], dw_ih[4 * H:], dw_hh_r, db[4 * H:], db[4 * H:])
+
+        def param_grads():
+            dw_ih = linear_wgrad(dg2, x.view(B * T, -1))                       # [8H, in]
+            db = ops.colsum(dg2)                                               # d b_ih = d b_hh
+            # h_{t-1} in each direction's own time order (data movement only)
+            hprev = torch.zeros(B, T, 2, H, device=out.device, dtype=torch.float32)
+            hprev[:, 1:, 0, :] = out[:, :-1, :H]
+            hprev[:, :-1, 1, :] = out[:, 1:, H:]
+            dw_hh_f = linear_wgrad(dg[:, :, 0, :], hprev[:, :, 0, :])
+            dw_hh_r = linear_wgrad(dg[:, :, 1, :], hprev[:, :, 1, :])
+            return (dw_ih[:4 * H], dw_hh_f, db[:4 * H], db[:4 * H], dw_ih[4 * H:], dw_hh_r, db[4 * H:], db[4 * H:])
+        # (the parameter gradients hang off the chain: with direct gradients they overlap the next recurrent kernel's idle CUs)
+        return (dx, *side_param_grads(list(ctx.params), param_grads, (dg, x, out)))
 
 
 class LinearReluFn(torch.autograd.Function):
@@ -582,6 +606,7 @@ class LinearReluFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         y = ops.linear(x, weight, bias, act=ops.ACT_RELU)
         ctx.save_for_backward(x, weight, y)
+        ctx.params = (weight, bias)
         return y
 
     @staticmethod
@@ -589,7 +614,8 @@ class LinearReluFn(torch.autograd.Function):
         x, weight, y = ctx.saved_tensors
         g = ops.ew_rows(ops.EW_RELU_BWD, y, dy.contiguous())
         dx = linear_dgrad(g, weight).view(x.shape) if ctx.needs_input_grad[0] else None
-        return dx, linear_wgrad(g, x), ops.colsum(g)
+        dw, db = side_param_grads(list(ctx.params), lambda: (linear_wgrad(g, x), ops.colsum(g)), (g, x))
+        return dx, dw, db
 
 
 class AvgPoolFn(torch.autograd.Function):
@@ -640,6 +666,7 @@ class AttnDecoderFn(torch.autograd.Function):
         probs = ops.linear(hid, gen_w, gen_b)
         ctx.save_for_backward(batch_H, Hproj, emb, hid, i2h_w, h2h_w, score_w, w_ih, w_hh, gen_w, tok, *saves)
         ctx.dims = (Hd, D, num_class, S)
+        ctx.params = (i2h_w, h2h_w, h2h_b, score_w, w_ih, w_hh, b_ih, b_hh, emb_w, gen_w, gen_b)
         return probs
 
     @staticmethod
@@ -648,28 +675,32 @@ class AttnDecoderFn(torch.autograd.Function):
         Hd, D, num_class, S = ctx.dims
         B, T, _ = batch_H.shape
         dprobs = dprobs.contiguous()
-        dgen_w, dgen_b = linear_wgrad(dprobs, hid), ops.colsum(dprobs)
         dhid = linear_dgrad(dprobs, gen_w).view(B, S, Hd)
         dgates, dhp, dHb, dHproj, dws = ops.attn_decoder_bwd(
             batch_H, Hproj, (alpha, gates, cseq, cx, hp), dhid, score_w,
             ops.pack_fragment_major(h2h_w.t().contiguous()), ops.pack_fragment_major(w_ih[:, :D].t().contiguous()),
             ops.pack_fragment_major(w_hh.t().contiguous()), Hd)
-        hprev = torch.zeros(B, S, Hd, device=hid.device, dtype=torch.float32)
-        hprev[:, 1:] = hid[:, :-1]                                      # h_{s-1} (data movement)
-        dg2 = dgates.view(B * S, 4 * Hd)
-        dw_ih = torch.empty_like(w_ih)
-        dw_ih[:, :D] = linear_wgrad(dg2, cx)
-        dw_ih[:, D:] = linear_wgrad(dg2, emb)
-        dw_hh = linear_wgrad(dg2, hprev)
-        db = ops.colsum(dg2)
-        dh2h_w, dh2h_b = linear_wgrad(dhp, hprev), ops.colsum(dhp.view(B * S, Hd))
-        demb = linear_dgrad(dg2, w_ih[:, D:])
-        demb_w = ops.embed_scatter_add(tok, demb.view(B, S, -1), num_class)
-        di2h_w = linear_wgrad(dHproj, batch_H)
+
+        def param_grads():            # order of ctx.params: i2h_w, h2h_w, h2h_b, score_w, w_ih, w_hh, b_ih, b_hh, emb_w, gen_w, gen_b
+            dgen_w, dgen_b = linear_wgrad(dprobs, hid), ops.colsum(dprobs)
+            hprev = torch.zeros(B, S, Hd, device=hid.device, dtype=torch.float32)
+            hprev[:, 1:] = hid[:, :-1]                                  # h_{s-1} (data movement)
+            dg2 = dgates.view(B * S, 4 * Hd)
+            dw_ih = torch.empty_like(w_ih)
+            dw_ih[:, :D] = linear_wgrad(dg2, cx)
+            dw_ih[:, D:] = linear_wgrad(dg2, emb)
+            dw_hh = linear_wgrad(dg2, hprev)
+            db = ops.colsum(dg2)
+            dh2h_w, dh2h_b = linear_wgrad(dhp, hprev), ops.colsum(dhp.view(B * S, Hd))
+            demb = linear_dgrad(dg2, w_ih[:, D:])
+            demb_w = ops.embed_scatter_add(tok, demb.view(B, S, -1), num_class)
+            di2h_w = linear_wgrad(dHproj, batch_H)
+            return (di2h_w, dh2h_w, dh2h_b, dws.view_as(score_w), dw_ih, dw_hh, db, db, demb_w, dgen_w, dgen_b)
+        grads = side_param_grads(list(ctx.params), param_grads, (dprobs, hid, dgates, cx, emb, dhp, dHproj, batch_H, dws, w_ih, tok))
         dH = None
         if ctx.needs_input_grad[0]:
             dH = linear_dgrad(dHproj, i2h_w, out=dHb.view(B * T, D), accumulate=True).view(B, T, D)
-        return (dH, None, di2h_w, dh2h_w, dh2h_b, dws.view_as(score_w), dw_ih, dw_hh, db, db, demb_w, dgen_w, dgen_b, None)
+        return (dH, None, *grads, None)
 
 
 class KDLossFn(torch.autograd.Function):
@@ -709,6 +740,7 @@ class TrainLinearFn(torch.autograd.Function):
         sx = ops.pow2_scale(x2) if ctx.x3 else None
         y, sw = x3_linear(x2, weight, bias, sx=sx, want_sw=True) if ctx.x3 else (ops.linear(x2, weight, bias), None)
         ctx.save_for_backward(x, weight, sx, sw)          # (sw: max|W| is the same for W^T in the data gradient)
+        ctx.params = (weight, bias)
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
@@ -717,8 +749,10 @@ class TrainLinearFn(torch.autograd.Function):
         dy2 = dy.contiguous().view(-1, dy.shape[-1])
         sd = ops.pow2_scale(dy2) if (ctx.x3 or x3_eligible(dy2, x.shape[-1], dy2.shape[1])) else None
         dx = linear_dgrad(dy2, weight, sd=sd, sw=sw).view(x.shape) if ctx.needs_input_grad[0] else None
-        dw = linear_wgrad(dy2, x.view(-1, x.shape[-1]), sd, sx) if ctx.needs_input_grad[1] else None
-        db = ops.colsum(dy2) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        need_w, need_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        dw, db = side_param_grads([ctx.params[0] if need_w else None, ctx.params[1] if need_b else None],
+                                  lambda: (linear_wgrad(dy2, x.view(-1, x.shape[-1]), sd, sx) if need_w else None,
+                                           ops.colsum(dy2) if need_b else None), (dy2, x, sd, sx))
         return dx, dw, db
 
 

@@ -1416,6 +1416,7 @@ WGRAD_SIDE_STREAM = os.environ.get("MRN_WGRAD_STREAM", "1") == "1"
 GRAD_DIRECT = False                 # set by direct_gradients(): only a caller that runs loss.backward() INTO .grad may skip autograd's accumulation
 _SIDE_STREAMS = {}
 _SIDE_PENDING = [False]
+_SIDE_KEEP = []                     # tensors the side stream still reads, held until the join (see side_stream_keep)
 
 
 class direct_gradients:
@@ -1447,6 +1448,17 @@ def join_side_stream():
     if _SIDE_PENDING[0]:
         _SIDE_PENDING[0] = False
         torch.cuda.current_stream().wait_stream(side_stream())
+    _SIDE_KEEP.clear()
+
+
+def side_stream_keep(tensors):
+    """hold references to what the side stream reads until the join.  record_stream() only keeps a FREED block from being reused; a
+    gradient that autograd still owns can be ACCUMULATED INTO IN PLACE on the main stream once our reference is gone (InputBuffer adds in
+    place when it holds the last reference) -- seen as NaN weights after one SVTR step.  With a reference held, autograd sums out of place."""
+    for t in tensors:
+        if t is not None:
+            _SIDE_KEEP.append(t)
+            t.record_stream(side_stream())
 
 
 def side_stream_begin():
