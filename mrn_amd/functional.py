@@ -6,6 +6,8 @@ features are written straight into slice [:, :, i, :], the reference's three rea
 (modules/dm_router.py:58,61,63,65 and modules/model.py:402) disappear, and the only token-order dependence --
 the spatial-gating weight over the (domain, patch) axis -- is absorbed by permuting that small weight.
 """
+import weakref
+
 import torch
 
 from . import ops
@@ -365,6 +367,8 @@ class ConvBlockFn(torch.autograd.Function):
         ctx.geom = (stride, padding, relu, precision, bn is not None, residual is not None)
         ctx.wpacked = w
         ctx.conv = conv
+        if id(conv) not in ops.TRAINED_CONVS:
+            ops.TRAINED_CONVS[id(conv)] = (weakref.ref(conv), stride, padding)
         # one max|x| pass serves the forward conv and the weight gradient (both split x with the same power-of-two scale)
         x3s = precision == "fp16x3s" and x.shape[-1] % 32 == 0
         # (the producer of x may have folded max|x| into its own pass: ops.scale_shift_act(range_target=...) of the previous block)
@@ -442,7 +446,7 @@ class ConvBlockFn(torch.autograd.Function):
             else:
                 dw = ops.unpack_conv_weight(weight_gradient())
         if ctx.needs_input_grad[0]:
-            wt = ops.pack_dgrad_weight(w.ohwi)
+            wt = ops.trained_dgrad_weight(w.ohwi)
             dx = ops.conv2d_dgrad(dy, wt, (x.shape[1], x.shape[2]), stride, padding, precision=precision, dy_scale=sd)
         return dx, dw, dbias, dgamma, dbeta, dres, None
 

@@ -172,6 +172,7 @@ class BaseLearner(object):
             lr = self.optimizer.param_groups[0]["lr"]
         self.optimizer.step(lr=lr, max_norm=self.opt.grad_clip, momentum=momentum)
         self.opt_step += 1
+        ops.prepack_trained()             # next step's weight operands of the trained convolutions, on the side stream
 
     optimizer_step = backward_and_step
 

@@ -4,6 +4,8 @@ shapes and default initialisation are the reference's); their math runs through 
 Activations travel between stages as ordinary torch tensors with the reference's logical NCHW shape but
 channels_last (NHWC) memory, which is what the kernels consume.
 """
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -35,14 +37,22 @@ def _pair(v):
     return (v, v) if isinstance(v, int) else tuple(v)
 
 
+_PACKED = weakref.WeakKeyDictionary()      # module -> (key, packed weight, event, stream): kept off the module (deepcopy of a model)
+
+
 def packed_weight(conv):
     """[O,I,kh,kw] parameter -> cached [O,kh,kw,I] device tensor (re-packed when the parameter changes)."""
     w = conv.weight
     key = (w.data_ptr(), w._version, w.device)
-    cache = getattr(conv, "_mrn_packed", None)
+    cache = _PACKED.get(conv)
     if cache is None or cache[0] != key:
-        cache = (key, ops.pack_conv_weight(w.detach()))
-        conv._mrn_packed = cache
+        ev = torch.cuda.Event()                      # (the build may run on the side stream: ops.prepack_trained)
+        packed = ops.pack_conv_weight(w.detach())
+        ev.record(torch.cuda.current_stream())
+        cache = (key, packed, ev, torch.cuda.current_stream())
+        _PACKED[conv] = cache
+    elif cache[3] != torch.cuda.current_stream():
+        torch.cuda.current_stream().wait_event(cache[2])
     return cache[1]
 
 

@@ -695,6 +695,82 @@ def conv2d_x3_wino(v_hl, G, shared_input, B, H, W, Cin, u_hl, u_scale, Cout, R, 
     return y, stats
 
 
+# ---- the trained convolutions' weight operands, packed ahead of use -------------------------------------------------------
+# A trained layer re-packs its weights every step: [O,I,kh,kw] -> OHWI, max|w| -> power-of-two scale, the HL32 / Winograd-domain stack, and
+# the same again for the flipped data-gradient weights -- ~300 short launches per TRBA step, each in front of the convolution that
+# needs it.  prepack_trained() (called by the learners right after the optimiser step) runs all of them on the side stream for the
+# layers registered by ConvBlockFn, one event per layer; the consumers below find the operands by (source tensor, version) and wait
+# on the event.  A miss (first step, a layer that changed since) just packs in place, as before.
+TRAIN_PREPACK = os.environ.get("MRN_TRAIN_PREPACK", "1") == "1"
+_PREPACKED = {}                     # key -> (value, event, source tensor kept alive)
+TRAINED_CONVS = {}                  # id(conv) -> (weakref to the module, stride, padding), filled by functional.ConvBlockFn.forward
+
+
+def _memo(key, src, build):
+    got = _PREPACKED.get(key)
+    if got is not None:
+        if got[1] is not None:
+            torch.cuda.current_stream().wait_event(got[1])
+        return got[0]
+    return build()
+
+
+def _wkey(kind, t, *extra):
+    return (kind, t.data_ptr(), t._version, tuple(t.shape)) + extra
+
+
+def trained_weight_operand(w_ohwi, stride, padding):
+    """-> ("wino", Winograd-domain stack, scale) or ("hl32", HL32 stack, scale) of one trained layer's [O,kh,kw,I] weights"""
+    Cout, kh, kw, Cin = w_ohwi.shape
+    wino = TRAIN_WINO and TRAIN_PRODUCTS == 3 and wino_eligible((kh, kw), stride, padding, Cin, Cout)
+
+    def build():
+        w = w_ohwi.contiguous()
+        return ("wino",) + tuple(pack_weights_wino([w], WINO_R)) if wino else ("hl32",) + tuple(pack_weights_hl32([w]))
+    return _memo(_wkey("op", w_ohwi, wino, WINO_R), w_ohwi, build)
+
+
+def trained_dgrad_weight(w_ohwi):
+    """pack_dgrad_weight of a trained layer (found prepacked, or built in place)"""
+    return _memo(_wkey("dgrad", w_ohwi), w_ohwi, lambda: pack_dgrad_weight(w_ohwi))
+
+
+def prepack_trained():
+    """issue every registered trained layer's weight packing for the coming step on the side stream (see above)"""
+    if not (TRAIN_PREPACK and WGRAD_SIDE_STREAM and TRAINED_CONVS):
+        return
+    from .modules._nn import packed_weight
+    side = side_stream()
+    side.wait_stream(torch.cuda.current_stream())          # the optimiser step wrote the weights on this stream
+    with torch.cuda.stream(side):
+        _PREPACKED.clear()
+        for cid, (ref, stride, padding) in list(TRAINED_CONVS.items()):
+            conv = ref()
+            if conv is None or not conv.weight.requires_grad:
+                del TRAINED_CONVS[cid]
+                continue
+            w = packed_weight(conv).ohwi
+            kh, kw = w.shape[1], w.shape[2]
+            new = {}
+            if w.shape[-1] % 32 == 0:                        # (what conv2d_nhwc sends to conv2d_x3_scaled)
+                Cout, _, _, Cin = w.shape
+                wino = TRAIN_WINO and TRAIN_PRODUCTS == 3 and wino_eligible((kh, kw), stride, padding, Cin, Cout)
+                wc = w.contiguous()
+                new[_wkey("op", w, wino, WINO_R)] = (("wino",) + tuple(pack_weights_wino([wc], WINO_R)) if wino
+                                                     else ("hl32",) + tuple(pack_weights_hl32([wc])), w)
+            wt = pack_dgrad_weight(w)
+            new[_wkey("dgrad", w)] = (wt, w)
+            if wt.ohwi.shape[-1] % 32 == 0:
+                dpad = (kh - 1 - padding[0], kw - 1 - padding[1])
+                wino = TRAIN_WINO and TRAIN_PRODUCTS == 3 and wino_eligible((kh, kw), (1, 1), dpad, wt.ohwi.shape[-1], wt.ohwi.shape[0])
+                new[_wkey("op", wt.ohwi, wino, WINO_R)] = (("wino",) + tuple(pack_weights_wino([wt.ohwi], WINO_R)) if wino
+                                                           else ("hl32",) + tuple(pack_weights_hl32([wt.ohwi])), wt.ohwi)
+            ev = torch.cuda.Event()
+            ev.record(side)
+            for k, (val, src) in new.items():
+                _PREPACKED[k] = (val, ev, src)
+
+
 def conv2d_x3_scaled(x, w_ohwi, bias, stride, padding, act=ACT_NONE, want_stats=False, sx=None):
     """one convolution on the grouped x3 kernel with per-call operand scaling: x fp32 [B,H,W,Cin] (Cin % 32 == 0),
     w_ohwi fp32 [O,kh,kw,I] -> (y [B,Ho,Wo,O], stats or None)"""
@@ -703,16 +779,15 @@ def conv2d_x3_scaled(x, w_ohwi, bias, stride, padding, act=ACT_NONE, want_stats=
     x = x.contiguous()
     if sx is None:
         sx = pow2_scale(x, TRAIN_OPERAND_PEAK)          # (callers that use x in several GEMMs compute it once: ConvBlockFn)
-    if TRAIN_WINO and TRAIN_PRODUCTS == 3 and wino_eligible((kh, kw), stride, padding, Cin, Cout):
+    kind, w_hl, sw = trained_weight_operand(w_ohwi, stride, padding)
+    if kind == "wino":
         # Winograd F(R,3) along W, as for the frozen experts (conv_x3.hip WINO): the operand pass applies B^T to sx * x in place of the
         # plain split, the weights are re-transformed with the step's values.  Serves the forward AND the data-gradient convolutions of
         # loop A (conv2d_dgrad arrives here with the flipped weights and the gradient's own range scale).
         R = WINO_R
         _, _, v = bn_apply_wino_grouped(x.view(1, B, H, W, Cin), None, None, R, relu=False, prescale=sx)
-        u_hl, su = pack_weights_wino([w_ohwi.contiguous()], R)
-        y, stats = conv2d_x3_wino(v, 1, False, B, H, W, Cin, u_hl, su, Cout, R, bias=bias, act=act, want_stats=want_stats, x_scale=sx)
+        y, stats = conv2d_x3_wino(v, 1, False, B, H, W, Cin, w_hl, sw, Cout, R, bias=bias, act=act, want_stats=want_stats, x_scale=sx)
         return y[0], stats
-    w_hl, sw = pack_weights_hl32([w_ohwi.contiguous()])
     y, stats = conv2d_x3(split_hl32(x, sx), 1, False, B, H, W, Cin, w_hl, sw, Cout, (kh, kw), stride, padding, bias=bias, act=act,
                          want_stats=want_stats, x_scale=sx, products=TRAIN_PRODUCTS)
     return y[0], stats
