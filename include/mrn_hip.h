@@ -297,6 +297,11 @@ int mrn_lstm_layer_fwd_grouped_f32(const void* const* xproj, const void* const* 
 int mrn_lstm_layer_fwd_x3_grouped(const void* const* xproj, const void* const* w_hh, const void* const* w_inv,
                                   const void* const* b_hh, const void* const* out, int groups, int B, int T, int hidden,
                                   int ndir, void* stream);
+/* One layer being TRAINED, forward with the recurrent product as split-fp16 x3 (il_modules/mrn.py:232-269 through
+ * modules/sequence_modeling.py:7-21): mrn_lstm_layer_fwd_x3_grouped for one network plus the saves mrn_lstm_layer_bwd_f32 reads
+ * (gates_out [B][T][ndir][4H] post-activation gates, c_out [B][T][ndir][H]). */
+int mrn_lstm_layer_fwd_x3_save(const float* xproj, const void* w_hh, const float* w_inv, const float* b_hh, float* out,
+                               float* gates_out, float* c_out, int B, int T, int hidden, int ndir, void* stream);
 /* The same layers as ONE SMALL KERNEL PER TIME STEP replayed from a HIP graph (csrc/lstm_steps.hip): a step is a grid over (expert,
  * direction, 128-sample tile, 32-unit tile), so all CUs pull W_hh at once instead of one CU per 16 samples streaming all of it; the
  * step kernels read their buffer pointers from a device-side argument block, so one instantiated graph per (stream, T, grid) serves

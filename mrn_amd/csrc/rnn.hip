@@ -212,6 +212,8 @@ __device__ __forceinline__ void store_h_split(_Float16* hi, _Float16* lo, int id
 
 struct LstmX3Params {
   const float* xproj; const unsigned char* w_hh; const float* w_inv; const float* b_hh; float* out;
+  float* gates_out;   // optional training saves, as in LstmParams: [B][T][ndir][4H] post-activation gates
+  float* c_out;       //                                          [B][T][ndir][H] cell state
 };
 struct LstmX3Group {
   LstmX3Params g[MAX_GROUPS];
@@ -227,6 +229,8 @@ __global__ __launch_bounds__(NTH) void lstm_layer_x3_kernel(const LstmX3Group gr
   const float* __restrict__ xproj = grp.g[gi].xproj;
   const float* __restrict__ b_hh = grp.g[gi].b_hh;
   float* __restrict__ out = grp.g[gi].out;
+  float* __restrict__ gates_out = grp.g[gi].gates_out;
+  float* __restrict__ c_out = grp.g[gi].c_out;
   const int B = grp.B, T = grp.T, ndir = grp.ndir;
   const int dir = set - gi * grp.ndir;
   const int b0 = (grp.pinned ? (int)((blockIdx.x / 8) % grp.tiles) : (int)blockIdx.x % grp.tiles) * BT;
@@ -267,7 +271,15 @@ __global__ __launch_bounds__(NTH) void lstm_layer_x3_kernel(const LstmX3Group gr
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = rbase + r, b = b0 + row;
-      if (b < B) out[((long)b * T + t) * (ndir * HID) + dir * HID + j] = h[r];
+      if (b < B) {
+        out[((long)b * T + t) * (ndir * HID) + dir * HID + j] = h[r];
+        if (gates_out) {
+          const long base = ((long)b * T + t) * ndir + dir;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) gates_out[base * 4 * HID + g * HID + j] = act[g][r];
+          c_out[base * HID + j] = c[r];
+        }
+      }
       store_h_split(h_hi[cur ^ 1], h_lo[cur ^ 1], row * LDH + j, b < B ? h[r] : 0.f);
     }
     __syncthreads();
@@ -794,6 +806,26 @@ MRN_EXPORT int mrn_lstm_layer_fwd_x3_grouped(const void* const* xproj, const voi
     hipLaunchKernelGGL(lstm_layer_x3_kernel, dim3(blocks), dim3(NTH), 0, (hipStream_t)stream, grp);
     MRN_LAUNCH_CHECK("lstm_layer_x3");
   }
+  return MRN_OK;
+}
+
+// One layer being TRAINED with the recurrent product as split-fp16 x3 (the arithmetic of the trained convolutions, fp16x3s): the
+// forward of mrn_lstm_layer_fwd_x3_grouped for one network, plus the saves mrn_lstm_layer_bwd_f32 reads (gates [B][T][ndir][4H]
+// post-activation, cseq [B][T][ndir][H]).  Half the time per step of the exact-fp32 kernel (96 MFMAs of 16 cycles instead of 256 of 32).
+MRN_EXPORT int mrn_lstm_layer_fwd_x3_save(const float* xproj, const void* w_hh, const float* w_inv, const float* b_hh, float* out,
+                                          float* gates_out, float* c_out, int B, int T, int hidden, int ndir, void* stream) {
+  MRN_CHECK_ARG(xproj && w_hh && w_inv && out && gates_out && c_out, "mrn_lstm_layer_fwd_x3_save: null operand");
+  MRN_CHECK_ARG(hidden == HID, "mrn_lstm_layer_fwd_x3_save: hidden=%d unsupported (library is built for %d)", hidden, HID);
+  MRN_CHECK_ARG(ndir == 1 || ndir == 2, "mrn_lstm_layer_fwd_x3_save: ndir=%d", ndir);
+  if (B == 0 || T == 0) return MRN_OK;
+  LstmX3Group grp;
+  memset(&grp, 0, sizeof(grp));
+  grp.g[0] = LstmX3Params{xproj, (const unsigned char*)w_hh, w_inv, b_hh, out, gates_out, c_out};
+  grp.tiles = ceil_div(B, BT); grp.B = B; grp.T = T; grp.ndir = ndir;
+  grp.nsets = ndir;
+  grp.pinned = 0;
+  hipLaunchKernelGGL(lstm_layer_x3_kernel, dim3(grp.nsets * grp.tiles), dim3(NTH), 0, (hipStream_t)stream, grp);
+  MRN_LAUNCH_CHECK("lstm_layer_x3_save");
   return MRN_OK;
 }
 

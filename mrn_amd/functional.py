@@ -570,10 +570,16 @@ class BiLSTMFn(torch.autograd.Function):
         w_ih = torch.cat([w_ih_f, w_ih_r], 0)
         b_ih = torch.cat([b_ih_f, b_ih_r], 0)
         b_hh = torch.cat([b_hh_f, b_hh_r], 0)
-        w_hh = torch.stack([ops.pack_fragment_major(w_hh_f), ops.pack_fragment_major(w_hh_r)], 0)
         x = x.contiguous()
         xproj = ops.linear(x, w_ih, b_ih)
-        out, gates, cseq = ops.lstm_layer(xproj, w_hh, b_hh, H, 2, save=True)
+        if ops.TRAIN_LSTM_X3 and H == 256:
+            # recurrent product as split-fp16 x3 (the trained convolutions' arithmetic): half the time per step of the exact-fp32 MFMA
+            packs = [ops.pack_fragment_major_h(w.detach()) for w in (w_hh_f, w_hh_r)]
+            out, gates, cseq = ops.lstm_layer_x3_save(xproj, torch.stack([p_[0] for p_ in packs]).contiguous(),
+                                                      torch.cat([p_[1] for p_ in packs]).contiguous(), b_hh, H, 2)
+        else:
+            w_hh = torch.stack([ops.pack_fragment_major(w_hh_f), ops.pack_fragment_major(w_hh_r)], 0)
+            out, gates, cseq = ops.lstm_layer(xproj, w_hh, b_hh, H, 2, save=True)
         ctx.save_for_backward(x, w_ih, w_hh_f, w_hh_r, out, gates, cseq)
         ctx.H = H
         ctx.params = (w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r)

@@ -982,6 +982,22 @@ def lstm_layer(xproj, w_hh, b_hh, hidden, ndir, save=False):
     return (out, gates, cseq) if save else out
 
 
+TRAIN_LSTM_X3 = os.environ.get("MRN_TRAIN_LSTM_X3", "1") == "1"   # trained LSTM layers: forward recurrent product as split-fp16 x3 (half the step time)
+
+
+def lstm_layer_x3_save(xproj, w_hh_h, w_inv, b_hh, hidden, ndir):
+    """training forward on the f16 MFMA: xproj [B,T,ndir*4H], w_hh_h [ndir,...] fp16 streams + w_inv [ndir] (pack_fragment_major_h per
+    direction), b_hh [ndir*4H] -> (out [B,T,ndir*H], gates [B,T,ndir,4H], cseq [B,T,ndir,H]) as ops.lstm_layer(save=True)"""
+    _chk(xproj, b_hh)
+    B, T, _ = xproj.shape
+    assert xproj.is_contiguous() and w_hh_h.is_contiguous() and w_inv.is_contiguous()
+    out = torch.empty(B, T, ndir * hidden, device=xproj.device, dtype=torch.float32)
+    gates = torch.empty(B, T, ndir, 4 * hidden, device=xproj.device, dtype=torch.float32)
+    cseq = torch.empty(B, T, ndir, hidden, device=xproj.device, dtype=torch.float32)
+    call("mrn_lstm_layer_fwd_x3_save", _p(xproj), _p(w_hh_h), _p(w_inv), _p(b_hh), _p(out), _p(gates), _p(cseq), B, T, hidden, ndir, _stream())
+    return out, gates, cseq
+
+
 def _ptr_array(ptrs):
     import ctypes
     return (ctypes.c_void_p * len(ptrs))(*ptrs)
