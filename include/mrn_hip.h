@@ -274,6 +274,12 @@ int mrn_lstm_layer_fwd_f32(const float* xproj, const float* w_hh, const float* b
  * units, K = 4*hidden); dgates receives the gradient of the gate pre-activations (dW_ih, dW_hh, db, dx follow as GEMMs). */
 int mrn_lstm_layer_bwd_f32(const float* dout, const float* gates, const float* cseq, const float* w_hhT, float* dgates,
                            int B, int T, int hidden, int ndir, void* stream);
+/* The same backward pass with the recurrent product dh = dgates . W_hh as split-fp16 x3 on the f16 MFMA (the step of the exact-fp32
+ * kernel is bound by its 256 MFMAs per wave): w_hhT_h = per direction the fragment-major fp16 hi / lo stream of W_hh^T [H][4H], w_inv
+ * device float[ndir] = 1 / its prescale, gscale device float[2] = {s, 1/s}, s a power of two bringing max|dout| to ~16
+ * (mrn_pow2_scale_f32(dout, target 16): the gate gradients are split as s * dgate). */
+int mrn_lstm_layer_bwd_x3(const float* dout, const float* gates, const float* cseq, const void* w_hhT_h, const float* w_inv,
+                          const float* gscale, float* dgates, int B, int T, int hidden, int ndir, void* stream);
 
 /* Attention decoder, S steps in one launch (modules/prediction.py:58-68 teacher forced; :78-86 greedy when
  * called with S = 1 and carried h_state/c_state).  Hb [B][T][D], Hproj = i2h(Hb) [B][T][hidden],

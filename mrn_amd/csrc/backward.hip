@@ -242,6 +242,90 @@ __global__ __launch_bounds__(NTH) void lstm_layer_bwd_kernel(const float* __rest
   }
 }
 
+// ---- the same backward pass with the recurrent product dh_rec = dgates . W_hh as split-fp16 x3 on v_mfma_f32_16x16x32_f16: the gate
+// gradients are written to LDS as two fp16 planes of gscale * dgate (gscale: a power of two from max|dout|, the gradients are 1e-3 ..
+// 1e-8-sized), W_hh^T comes as the fragment-major hi / lo stream of ops.pack_fragment_major_h with its own prescale.  96 MFMAs of 16
+// cycles per wave and step instead of 256 of 32 on the exact-fp32 pipe: the step was bound by them (4 waves per SIMD).
+typedef _Float16 f16v8h __attribute__((ext_vector_type(8)));
+constexpr int GLDH = 4 * HID + 8;     // fp16 LDS row (halves)
+
+__global__ __launch_bounds__(NTH) void lstm_layer_bwd_x3_kernel(const float* __restrict__ dout, const float* __restrict__ gates,
+                                                                const float* __restrict__ cseq, const unsigned char* __restrict__ w_hhT,
+                                                                const float* __restrict__ w_inv, const float* __restrict__ gscale,
+                                                                float* __restrict__ dgates, int B, int T, int ndir) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 dgh_lds[];   // [2 planes][BT][GLDH]
+  _Float16* dg_hi = dgh_lds;
+  _Float16* dg_lo = dgh_lds + BT * GLDH;
+  const int dir = blockIdx.y;
+  const int b0 = blockIdx.x * BT;
+  const int t_ = threadIdx.x, lane = t_ & 63, wave = t_ >> 6;
+  const int col = lane & 15, rbase = (lane >> 4) * 4;
+  const int j = wave * 16 + col;
+  constexpr int Q = 4 * HID / 32;
+  const f16v8h* wp = reinterpret_cast<const f16v8h*>(w_hhT + (long)dir * HID * 4 * HID * 4) + ((long)wave * Q * 64 + lane) * 2;
+  const float gs = gscale[0];
+  const float unscale = w_inv[dir] * gscale[1];
+  float dh_rec[4] = {0.f, 0.f, 0.f, 0.f}, dc_next[4] = {0.f, 0.f, 0.f, 0.f};
+
+  for (int step = T - 1; step >= 0; --step) {
+    const int t = dir == 0 ? step : T - 1 - step;
+    const int tp = dir == 0 ? t - 1 : t + 1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = rbase + r, b = b0 + row;
+      float di = 0.f, df = 0.f, dg = 0.f, dob = 0.f;
+      if (b < B) {
+        const long base = ((long)b * T + t) * ndir + dir;
+        const float* gp = gates + base * 4 * HID + j;
+        const float ig = gp[0], fg = gp[HID], gg = gp[2 * HID], og = gp[3 * HID];
+        const float ct = cseq[base * HID + j];
+        const float cp = step > 0 ? cseq[(((long)b * T + tp) * ndir + dir) * HID + j] : 0.f;
+        const float dh = dout[((long)b * T + t) * (ndir * HID) + dir * HID + j] + dh_rec[r];
+        const float tc = tanhf(ct);
+        dob = dh * tc * og * (1.f - og);
+        const float dc = dc_next[r] + dh * og * (1.f - tc * tc);
+        di = dc * gg * ig * (1.f - ig);
+        df = dc * cp * fg * (1.f - fg);
+        dg = dc * ig * (1.f - gg * gg);
+        dc_next[r] = dc * fg;
+        float* dp = dgates + base * 4 * HID + j;
+        dp[0] = di; dp[HID] = df; dp[2 * HID] = dg; dp[3 * HID] = dob;
+      }
+      const float v4[4] = {di * gs, df * gs, dg * gs, dob * gs};
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        _Float16 hh, ll;
+        split_f16(v4[g], hh, ll);
+        dg_hi[row * GLDH + g * HID + j] = hh;
+        dg_lo[row * GLDH + g * HID + j] = ll;
+      }
+    }
+    __syncthreads();
+    if (step > 0) {
+      // dh_rec[b][j] = sum_n dgate[b][n] * W_hh[n][j]
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const int n = lane & 15, kg = lane >> 4;
+      const _Float16* ah = dg_hi + n * GLDH + kg * 8;
+      const _Float16* al = dg_lo + n * GLDH + kg * 8;
+      f16v8h wh = wp[0], wl = wp[1];
+#pragma unroll 1
+      for (int q = 0; q < Q; ++q) {
+        const int qn = (q + 1 < Q) ? q + 1 : q;
+        const f16v8h nh = wp[(long)qn * 128], nl = wp[(long)qn * 128 + 1];
+        const f16v8h xh = *reinterpret_cast<const f16v8h*>(ah + q * 32), xl = *reinterpret_cast<const f16v8h*>(al + q * 32);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, wh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wh, acc, 0, 0, 0);
+        wh = nh;
+        wl = nl;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dh_rec[r] = acc[r] * unscale;
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 static inline int ew_grid(long n, int per_block) {
@@ -319,6 +403,23 @@ MRN_EXPORT int mrn_maxpool_bwd_nhwc_f32(const float* dy, const float* x, float* 
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(n, 512)), dim3(256), 0, (hipStream_t)stream, dy, x, dx_zeroed, B, H, W, C,
                      Ho, Wo, kh, kw, sh, sw, ph, pw);
   MRN_LAUNCH_CHECK("maxpool_bwd");
+  return MRN_OK;
+}
+
+// mrn_lstm_layer_bwd_f32 with the recurrent product as split-fp16 x3: w_hhT_h = per direction the fragment-major fp16 hi / lo stream of
+// W_hh^T [H][4H] (ops.pack_fragment_major_h), w_inv device float[ndir] = 1 / its prescale, gscale device float[2] = {s, 1/s} with a power
+// of two s that brings max|dout| to ~16 (mrn_pow2_scale_f32: the gate gradients are split as s * dgate; fp16 keeps a factor 4096 of headroom)
+MRN_EXPORT int mrn_lstm_layer_bwd_x3(const float* dout, const float* gates, const float* cseq, const void* w_hhT_h, const float* w_inv,
+                                     const float* gscale, float* dgates, int B, int T, int hidden, int ndir, void* stream) {
+  MRN_CHECK_ARG(dout && gates && cseq && w_hhT_h && w_inv && gscale && dgates, "mrn_lstm_layer_bwd_x3: null operand");
+  MRN_CHECK_ARG(hidden == HID && (ndir == 1 || ndir == 2), "mrn_lstm_layer_bwd_x3: hidden=%d ndir=%d unsupported", hidden, ndir);
+  if (B == 0 || T == 0) return MRN_OK;
+  const size_t lds = sizeof(_Float16) * 2 * BT * GLDH;
+  static bool attr = false;
+  if (!attr) { hipFuncSetAttribute((const void*)lstm_layer_bwd_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  hipLaunchKernelGGL(lstm_layer_bwd_x3_kernel, dim3(ceil_div(B, BT), ndir), dim3(NTH), lds, (hipStream_t)stream, dout, gates, cseq,
+                     (const unsigned char*)w_hhT_h, w_inv, gscale, dgates, B, T, ndir);
+  MRN_LAUNCH_CHECK("lstm_layer_bwd_x3");
   return MRN_OK;
 }
 

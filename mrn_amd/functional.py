@@ -590,8 +590,13 @@ class BiLSTMFn(torch.autograd.Function):
         x, w_ih, w_hh_f, w_hh_r, out, gates, cseq = ctx.saved_tensors
         H = ctx.H
         B, T, _ = out.shape
-        w_hhT = torch.stack([ops.pack_fragment_major(w_hh_f.t().contiguous()), ops.pack_fragment_major(w_hh_r.t().contiguous())], 0)
-        dg = ops.lstm_layer_bwd(dout, gates, cseq, w_hhT, H, 2)              # [B,T,2,4H]
+        if ops.TRAIN_LSTM_X3 and H == 256:
+            packs = [ops.pack_fragment_major_h(w.detach().t().contiguous()) for w in (w_hh_f, w_hh_r)]
+            dg = ops.lstm_layer_bwd_x3(dout, gates, cseq, torch.stack([p_[0] for p_ in packs]).contiguous(),
+                                       torch.cat([p_[1] for p_ in packs]).contiguous(), H, 2)               # [B,T,2,4H]
+        else:
+            w_hhT = torch.stack([ops.pack_fragment_major(w_hh_f.t().contiguous()), ops.pack_fragment_major(w_hh_r.t().contiguous())], 0)
+            dg = ops.lstm_layer_bwd(dout, gates, cseq, w_hhT, H, 2)          # [B,T,2,4H]
         dg2 = dg.view(B * T, 8 * H)
         dx = linear_dgrad(dg2, w_ih).view(x.shape) if ctx.needs_input_grad[0] else None
 

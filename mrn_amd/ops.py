@@ -1124,6 +1124,18 @@ def lstm_layer_bwd(dout, gates, cseq, w_hhT, hidden, ndir):
     return dgates
 
 
+def lstm_layer_bwd_x3(dout, gates, cseq, w_hhT_h, w_inv, hidden, ndir):
+    """lstm_layer_bwd with the recurrent product as split-fp16 x3: w_hhT_h [ndir,...] fp16 streams + w_inv [ndir] =
+    pack_fragment_major_h(W_hh.t()) per direction; the gate gradients are range-scaled by a power of two from max|dout|"""
+    B, T, _ = dout.shape
+    dout = dout.contiguous()
+    assert w_hhT_h.is_contiguous() and w_inv.is_contiguous()
+    gs = pow2_scale(dout, 16.0)
+    dgates = torch.empty(B, T, ndir, 4 * hidden, device=dout.device, dtype=torch.float32)
+    call("mrn_lstm_layer_bwd_x3", _p(dout), _p(gates), _p(cseq), _p(w_hhT_h), _p(w_inv), _p(gs), _p(dgates), B, T, hidden, ndir, _stream())
+    return dgates
+
+
 def embed_gather(idx, table, num_class, out=None):
     """idx [B,S] int64 (any row stride), table [C,E] -> [B,S,E] with cut_unknown semantics"""
     assert idx.dtype == torch.int64 and idx.stride(1) == 1

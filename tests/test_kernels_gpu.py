@@ -558,6 +558,32 @@ def test_lstm_recurrence_on_f16_mfma(ops):
     assert_close("lstm on the f16 MFMA", out, ref, atol=2e-6, rtol=1e-5)
 
 
+@pytest.mark.parametrize("B,T,mag", [(19, 29, 1.0), (256, 65, 1e-5), (37, 12, 300.0)])
+def test_lstm_training_kernels_on_f16_mfma(ops, B, T, mag):
+    """mrn_lstm_layer_fwd_x3_save / mrn_lstm_layer_bwd_x3 (training forward with saves and backward through time, recurrent products as
+    split-fp16 x3; the gate gradients range-scaled by a power of two) against the exact-fp32 kernels, for gradient-sized and large dout"""
+    Hd, ndir = 256, 2
+    xproj = cu(rnd(B, T, ndir * 4 * Hd, seed=440, scale=0.7))
+    ws = [cu(rnd(4 * Hd, Hd, seed=441 + d, scale=1 / 16.0)) for d in range(ndir)]
+    b_hh = cu(rnd(ndir * 4 * Hd, seed=450, scale=1 / 16.0))
+    w_f32 = torch.stack([ops.pack_fragment_major(w) for w in ws]).contiguous()
+    ref_out, ref_gates, ref_c = ops.lstm_layer(xproj, w_f32, b_hh, Hd, ndir, save=True)
+    packs = [ops.pack_fragment_major_h(w) for w in ws]
+    out, gates, cseq = ops.lstm_layer_x3_save(xproj, torch.stack([p[0] for p in packs]).contiguous(), torch.cat([p[1] for p in packs]).contiguous(),
+                                             b_hh, Hd, ndir)
+    assert_close("x3 training forward: out", out, ref_out, atol=2e-6, rtol=1e-5)
+    assert_close("x3 training forward: gates", gates, ref_gates, atol=2e-6, rtol=1e-5)
+    assert_close("x3 training forward: cell state", cseq, ref_c, atol=4e-6, rtol=1e-5)
+    dout = cu(rnd(B, T, ndir * Hd, seed=460)) * mag
+    wT_f32 = torch.stack([ops.pack_fragment_major(w.t().contiguous()) for w in ws]).contiguous()
+    ref_dg = ops.lstm_layer_bwd(dout, ref_gates, ref_c, wT_f32, Hd, ndir)
+    packsT = [ops.pack_fragment_major_h(w.t().contiguous()) for w in ws]
+    dg = ops.lstm_layer_bwd_x3(dout, ref_gates, ref_c, torch.stack([p[0] for p in packsT]).contiguous(),
+                               torch.cat([p[1] for p in packsT]).contiguous(), Hd, ndir)
+    scale = float(ref_dg.abs().max())
+    assert float((dg - ref_dg).abs().max()) <= 2e-6 * scale, (float((dg - ref_dg).abs().max()), scale)
+
+
 @pytest.mark.parametrize("G,B,T,ndir", [(3, 19, 29, 2), (1, 256, 65, 2), (6, 130, 7, 2), (2, 128, 5, 1), (9, 40, 4, 2)])
 def test_lstm_step_kernels_from_a_graph(ops, G, B, T, ndir):
     """mrn_lstm_layer_fwd_x3_steps (one kernel per time step over (expert, direction, 128-sample tile, 32-unit tile), replayed from a
