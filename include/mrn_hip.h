@@ -358,6 +358,20 @@ int mrn_tps_grid_sample_bwd_f32(const float* img_nhwc, const float* cprime, cons
                                 int Hr, int Wr, int F, void* stream);
 /* AdaptiveAvgPool2d(1) backward: dx[b][p][c] = dy[b][c] / HW */
 int mrn_avgpool_bwd_nhwc_f32(const float* dy, float* dx, int B, int HW, int C, void* stream);
+/* The same decoders with the three recurrent products (h2h, W_ih[:, :D] on the context, W_hh) as split-fp16 x3 on the f16 MFMA: on the
+ * exact-fp32 pipe they are 30 us of a step.  w_h2h / w_ih_ctx / w_hh: fragment-major fp16 hi / lo streams with a power-of-two prescale
+ * (mrn_amd/ops.py::pack_fragment_major_h), w_inv: device float[3] = 1 / prescale of each (HOST array of such pointers in the grouped
+ * form).  D % 32 == 0.  Other arguments as mrn_attn_decoder_fwd_f32 / mrn_attn_decoder_fwd_grouped_f32. */
+int mrn_attn_decoder_fwd_x3(const float* Hb, const float* Hproj, const float* eproj, int64_t eproj_stride_b, int64_t eproj_stride_s,
+                            const void* w_h2h, const float* b_h2h, const float* w_score, const void* w_ih_ctx, const void* w_hh,
+                            const float* w_inv, const float* b_hh, float* hid, int64_t hid_stride_b, int64_t hid_stride_s,
+                            float* h_state, float* c_state, float* alpha_out, float* gates_out, float* c_out, float* ctx_out,
+                            float* hp_out, int B, int T, int D, int S, int hidden, void* stream);
+int mrn_attn_decoder_fwd_x3_grouped(const void* const* Hb, const void* const* Hproj, const void* const* eproj, int64_t eproj_stride_b,
+                                    int64_t eproj_stride_s, const void* const* w_h2h, const void* const* b_h2h,
+                                    const void* const* w_score, const void* const* w_ih_ctx, const void* const* w_hh,
+                                    const void* const* w_inv, const void* const* b_hh, const void* const* hid, int64_t hid_stride_b,
+                                    int64_t hid_stride_s, int groups, int B, int T, int D, int S, int hidden, void* stream);
 /* out[b][s][:] = table[cut_unknown(idx[b][s])][:]  (modules/prediction.py:35-36,61) */
 int mrn_embed_gather_f32(const int64_t* idx, int64_t idx_stride, const float* table, float* out, int B, int S,
                          int E, int num_class, void* stream);

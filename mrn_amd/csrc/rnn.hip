@@ -167,12 +167,12 @@ constexpr int LDH = HID + 8;   // fp16 LDS row (halves): 528 B, 16 rows hit 16 d
 //   Wp[(((wave*NG + g)*Q + q)*64 + lane)*2 + {0: hi, 1: lo}] = 8 halves W[g*HID + 16*wave + (lane&15)][32q + 8*(lane>>4) .. +7]
 template <int NG>
 __device__ __forceinline__ void mma_rows_h(f32x4 (&acc)[NG], const _Float16* __restrict__ a_hi, const _Float16* __restrict__ a_lo,
-                                           const unsigned char* __restrict__ Wp, int K, int wave, int lane) {
+                                           const unsigned char* __restrict__ Wp, int K, int wave, int lane, int ld = LDH) {
   const int n = lane & 15, kg = lane >> 4;
   const int Q = K / 32;
   const f16v8* wp = reinterpret_cast<const f16v8*>(Wp) + ((long)wave * NG * Q * 64 + lane) * 2;
-  const _Float16* ah = a_hi + n * LDH + kg * 8;
-  const _Float16* al = a_lo + n * LDH + kg * 8;
+  const _Float16* ah = a_hi + n * ld + kg * 8;
+  const _Float16* al = a_lo + n * ld + kg * 8;
   f16v8 wh[NG], wl[NG];
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
@@ -504,6 +504,7 @@ struct AttnDecParams {
   const float* w_hh;                // [4H][HID], fragment-major (w_h2h too)
   const float* b_hh;                // optional [4H] (eproj already carries b_ih)
   float* hid;
+  const float* w_inv;               // x3 form only: device float[3] = 1 / prescale of w_h2h, w_ih, w_hh (then fragment-major fp16 hi / lo streams)
   float* h_state; float* c_state;   // optional [B][HID] carried state (nullptr: start from zero, do not store)
   float* alpha_out;                 // optional [B][S][T]
   float* gates_out; float* c_out;   // optional training saves: [B][S][4H] post-activation gates, [B][S][H] cell state
@@ -523,6 +524,11 @@ struct AttnDecGroup {
   int tiles, groups, pinned, vb;
 };
 
+// X3: the three recurrent products (h2h, W_ih[:, :D] on the context, W_hh) as split-fp16 x3 on v_mfma_f32_16x16x32_f16 -- h and the
+// context live in LDS as fp16 hi / lo planes, the weights come as fragment-major hi / lo streams with a power-of-two prescale
+// (ops.pack_fragment_major_h).  On the exact-fp32 pipe those products are 30 us of a step (576 MFMAs of 32 cycles per wave, four
+// waves per SIMD); as x3 216 MFMAs of 16 cycles.
+template <bool X3>
 __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecGroup grp) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // one expert's recurrent weights (2.3 MiB) stay in one XCD's L2: all tiles of a group run on XCD (group % 8)
@@ -531,11 +537,17 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecGroup gr
   const AttnDecParams p = grp.g[gi];
   const int D = p.D, T = p.T;
   const int CLD = D + 4;
-  float* h_lds = lds;                      // [BT][HLD]
-  float* hp_lds = h_lds + BT * HLD;        // [BT][HLD]
-  float* ctx_lds = hp_lds + BT * HLD;      // [BT][CLD]
-  float* e_lds = ctx_lds + BT * CLD;       // [BT][T]
+  const int CLDH = D + 8;                  // x3: fp16 row of the context planes
+  float* h_lds = lds;                      // [BT][HLD]                     (x3: two fp16 planes [BT][LDH])
+  float* hp_lds = X3 ? lds + (2 * BT * LDH) / 2 : h_lds + BT * HLD;        // [BT][HLD]
+  float* ctx_lds = hp_lds + BT * HLD;      // [BT][CLD]                     (x3: two fp16 planes [BT][CLDH])
+  float* e_lds = X3 ? ctx_lds + (2 * BT * CLDH) / 2 : ctx_lds + BT * CLD;  // [BT][T]
   float* sw_lds = e_lds + BT * T;          // [HID]
+  _Float16* h_hi = reinterpret_cast<_Float16*>(h_lds);
+  _Float16* h_lo = h_hi + BT * LDH;
+  _Float16* c_hi = reinterpret_cast<_Float16*>(ctx_lds);
+  _Float16* c_lo = c_hi + BT * CLDH;
+  const float inv_h2h = X3 ? p.w_inv[0] : 1.f, inv_ih = X3 ? p.w_inv[1] : 1.f, inv_hh = X3 ? p.w_inv[2] : 1.f;
 
   // vb = samples per workgroup (16, or 8 / 4 when the batch would otherwise occupy less than half of the CUs: every step
   // re-reads the workgroup's Hproj / Hb slices (66 KB per sample each), so more, smaller workgroups shorten the step);
@@ -547,12 +559,21 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecGroup gr
   const int col = lane & 15, rbase = (lane >> 4) * 4;
   const int j = wave * 16 + col;
 
-  for (int i = t_; i < BT * HLD; i += NTH) {
-    const int row = i / HLD, jj = i - row * HLD;
-    const int b = b0 + row;
-    h_lds[i] = (p.h_state && b < Bend && jj < HID) ? p.h_state[(long)b * HID + jj] : 0.f;
+  if constexpr (X3) {
+    for (int i = t_; i < BT * LDH; i += NTH) {
+      const int row = i / LDH, jj = i - row * LDH;
+      const int b = b0 + row;
+      store_h_split(h_hi, h_lo, i, (p.h_state && b < Bend && jj < HID) ? p.h_state[(long)b * HID + jj] : 0.f);
+    }
+    for (int i = t_; i < BT * HLD + BT * CLDH + BT * T; i += NTH) hp_lds[i] = 0.f;   // hp, ctx planes, e: rows >= vb stay zero
+  } else {
+    for (int i = t_; i < BT * HLD; i += NTH) {
+      const int row = i / HLD, jj = i - row * HLD;
+      const int b = b0 + row;
+      h_lds[i] = (p.h_state && b < Bend && jj < HID) ? p.h_state[(long)b * HID + jj] : 0.f;
+    }
+    for (int i = t_; i < BT * (HLD + CLD + T); i += NTH) hp_lds[i] = 0.f;     // hp, ctx, e: rows >= vb stay zero
   }
-  for (int i = t_; i < BT * (HLD + CLD + T); i += NTH) hp_lds[i] = 0.f;     // hp, ctx, e: rows >= vb stay zero
   for (int i = t_; i < HID; i += NTH) sw_lds[i] = p.w_score[i];
   float bh[4], c[4];
 #pragma unroll
@@ -563,6 +584,7 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecGroup gr
     c[r] = (p.c_state && b < Bend) ? p.c_state[(long)b * HID + j] : 0.f;
   }
   const float bj = p.b_h2h[j];
+  float hlast[4] = {0.f, 0.f, 0.f, 0.f};        // h of the last step (the carried state, exact also when LDS holds the fp16 planes)
   __syncthreads();
 
   for (int step = 0; step < p.S; ++step) {
@@ -578,10 +600,11 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecGroup gr
     // (1) hp = h2h(h) + bias
     {
       f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
-      mma_rows<1>(acc, h_lds, HLD, p.w_h2h, HID, wave, lane);
+      if constexpr (X3) mma_rows_h<1>(acc, h_hi, h_lo, reinterpret_cast<const unsigned char*>(p.w_h2h), HID, wave, lane);
+      else mma_rows<1>(acc, h_lds, HLD, p.w_h2h, HID, wave, lane);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float v = acc[0][r] + bj;
+        const float v = acc[0][r] * inv_h2h + bj;
         hp_lds[(rbase + r) * HLD + j] = v;
         const int b = b0 + rbase + r;
         if (p.hp_out && b < Bend) p.hp_out[((long)b * p.S + step) * HID + j] = v;
@@ -675,7 +698,12 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecGroup gr
           for (int k = 0; k < 4; ++k) a[k] = fmaf(w, v[k], a[k]);
         }
       }
-      *reinterpret_cast<f32x4*>(ctx_lds + row * CLD + c4 * 4) = a;
+      if constexpr (X3) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) store_h_split(c_hi, c_lo, row * CLDH + c4 * 4 + k, a[k]);
+      } else {
+        *reinterpret_cast<f32x4*>(ctx_lds + row * CLD + c4 * 4) = a;
+      }
       if (p.ctx_out && b < Bend) *reinterpret_cast<f32x4*>(p.ctx_out + ((long)b * p.S + step) * D + c4 * 4) = a;
     }
     __syncthreads();
@@ -684,8 +712,18 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecGroup gr
       f32x4 acc[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-      mma_rows<4>(acc, ctx_lds, CLD, p.w_ih, D, wave, lane);
-      mma_rows<4>(acc, h_lds, HLD, p.w_hh, HID, wave, lane);
+      if constexpr (X3) {
+        mma_rows_h<4>(acc, c_hi, c_lo, reinterpret_cast<const unsigned char*>(p.w_ih), D, wave, lane, CLDH);
+        const float ratio = inv_ih / inv_hh;            // (powers of two: exact)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] *= ratio;
+        mma_rows_h<4>(acc, h_hi, h_lo, reinterpret_cast<const unsigned char*>(p.w_hh), HID, wave, lane);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] *= inv_hh;
+      } else {
+        mma_rows<4>(acc, ctx_lds, CLD, p.w_ih, D, wave, lane);
+        mma_rows<4>(acc, h_lds, HLD, p.w_hh, HID, wave, lane);
+      }
       __syncthreads();  // every wave has finished reading h_lds
       float h[4], act[4][4];
       lstm_pointwise(acc, xg, bh, c, h, act);
@@ -701,7 +739,9 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecGroup gr
             p.c_out[base * HID + j] = c[r];
           }
         }
-        h_lds[row * HLD + j] = b < Bend ? h[r] : 0.f;
+        if constexpr (X3) store_h_split(h_hi, h_lo, row * LDH + j, b < Bend ? h[r] : 0.f);
+        else h_lds[row * HLD + j] = b < Bend ? h[r] : 0.f;
+        hlast[r] = h[r];
       }
     }
     __syncthreads();
@@ -712,7 +752,7 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecGroup gr
     for (int r = 0; r < 4; ++r) {
       const int row = rbase + r, b = b0 + row;
       if (b < Bend) {
-        p.h_state[(long)b * HID + j] = h_lds[row * HLD + j];
+        p.h_state[(long)b * HID + j] = hlast[r];
         p.c_state[(long)b * HID + j] = c[r];
       }
     }
@@ -891,11 +931,18 @@ static int attn_launch(AttnDecGroup& grp, int groups, int D, int T, hipStream_t 
   grp.vb = (groups * ceil_div(B, 4) <= 128 && B > 4) ? 4 : (groups * ceil_div(B, BT) <= 128 && B > 8) ? 8 : BT;
   grp.tiles = ceil_div(B, grp.vb);
   grp.pinned = groups > 1 && grp.tiles * ceil_div(groups, 8) <= 32;
-  const size_t lds = sizeof(float) * (2 * BT * HLD + BT * (D + 4) + BT * T + HID);
+  const bool x3 = grp.g[0].w_inv != nullptr;
+  const size_t lds = sizeof(float) * (2 * BT * HLD + BT * (D + 4) + BT * T + HID) + (x3 ? 1024 : 0);
   MRN_CHECK_ARG(lds <= 160 * 1024, "mrn_attn_decoder_fwd: LDS budget exceeded (D=%d T=%d)", D, T);
-  if (lds > 64 * 1024)
-    hipFuncSetAttribute((const void*)attn_decoder_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(attn_decoder_kernel, dim3(grp.pinned ? 8 * ceil_div(groups, 8) * grp.tiles : groups * grp.tiles), dim3(NTH), lds, st, grp);
+  MRN_CHECK_ARG(!x3 || D % 32 == 0, "mrn_attn_decoder_fwd (x3): D=%d must be a multiple of 32", D);
+  const dim3 grid(grp.pinned ? 8 * ceil_div(groups, 8) * grp.tiles : groups * grp.tiles);
+  if (x3) {
+    if (lds > 64 * 1024) hipFuncSetAttribute((const void*)attn_decoder_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(attn_decoder_kernel<true>, grid, dim3(NTH), lds, st, grp);
+  } else {
+    if (lds > 64 * 1024) hipFuncSetAttribute((const void*)attn_decoder_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(attn_decoder_kernel<false>, grid, dim3(NTH), lds, st, grp);
+  }
   MRN_LAUNCH_CHECK("attn_decoder");
   return MRN_OK;
 }
@@ -947,6 +994,63 @@ MRN_EXPORT int mrn_attn_decoder_fwd_grouped_f32(const void* const* Hb, const voi
       attn_fill(grp.g[i], (const float*)Hb[g], (const float*)Hproj[g], (const float*)eproj[g], eproj_stride_b, eproj_stride_s,
                 (const float*)w_h2h[g], (const float*)b_h2h[g], (const float*)w_score[g], (const float*)w_ih_ctx[g],
                 (const float*)w_hh[g], b_hh ? (const float*)b_hh[g] : nullptr, (float*)hid[g], hid_stride_b, hid_stride_s, B, T, D, S);
+    }
+    grp.tiles = ceil_div(B, BT);
+    const int rc = attn_launch(grp, n, D, T, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  return MRN_OK;
+}
+
+// The same decoders with the three recurrent products as split-fp16 x3: w_h2h / w_ih_ctx / w_hh are the fragment-major fp16 hi / lo
+// streams of ops.pack_fragment_major_h, w_inv a device float[3] = 1 / prescale of each (per group in the grouped form).  D % 32 == 0.
+MRN_EXPORT int mrn_attn_decoder_fwd_x3(const float* Hb, const float* Hproj, const float* eproj, int64_t eproj_stride_b,
+                                       int64_t eproj_stride_s, const void* w_h2h, const float* b_h2h, const float* w_score,
+                                       const void* w_ih_ctx, const void* w_hh, const float* w_inv, const float* b_hh, float* hid,
+                                       int64_t hid_stride_b, int64_t hid_stride_s, float* h_state, float* c_state, float* alpha_out,
+                                       float* gates_out, float* c_out, float* ctx_out, float* hp_out, int B, int T, int D, int S,
+                                       int hidden, void* stream) {
+  MRN_CHECK_ARG(Hb && Hproj && eproj && w_h2h && b_h2h && w_score && w_ih_ctx && w_hh && w_inv && hid, "mrn_attn_decoder_fwd_x3: null operand");
+  MRN_CHECK_ARG(hidden == HID, "mrn_attn_decoder_fwd_x3: hidden=%d unsupported (library is built for %d)", hidden, HID);
+  MRN_CHECK_ARG(D % 32 == 0 && D > 0, "mrn_attn_decoder_fwd_x3: D=%d must be a multiple of 32", D);
+  MRN_CHECK_ARG((h_state == nullptr) == (c_state == nullptr), "mrn_attn_decoder_fwd_x3: h_state/c_state must come together");
+  if (B == 0 || S == 0) return MRN_OK;
+  MRN_CHECK_ARG(!gates_out || (c_out && ctx_out && hp_out && alpha_out), "mrn_attn_decoder_fwd_x3: training saves must all be given");
+  AttnDecGroup grp;
+  memset(&grp, 0, sizeof(grp));
+  AttnDecParams& p = grp.g[0];
+  attn_fill(p, Hb, Hproj, eproj, eproj_stride_b, eproj_stride_s, (const float*)w_h2h, b_h2h, w_score, (const float*)w_ih_ctx,
+            (const float*)w_hh, b_hh, hid, hid_stride_b, hid_stride_s, B, T, D, S);
+  p.w_inv = w_inv;
+  p.h_state = h_state; p.c_state = c_state;
+  p.alpha_out = alpha_out; p.gates_out = gates_out; p.c_out = c_out; p.ctx_out = ctx_out; p.hp_out = hp_out;
+  grp.tiles = ceil_div(B, BT);
+  return attn_launch(grp, 1, D, T, (hipStream_t)stream);
+}
+
+MRN_EXPORT int mrn_attn_decoder_fwd_x3_grouped(const void* const* Hb, const void* const* Hproj, const void* const* eproj,
+                                               int64_t eproj_stride_b, int64_t eproj_stride_s, const void* const* w_h2h,
+                                               const void* const* b_h2h, const void* const* w_score, const void* const* w_ih_ctx,
+                                               const void* const* w_hh, const void* const* w_inv, const void* const* b_hh,
+                                               const void* const* hid, int64_t hid_stride_b, int64_t hid_stride_s, int groups, int B,
+                                               int T, int D, int S, int hidden, void* stream) {
+  MRN_CHECK_ARG(Hb && Hproj && eproj && w_h2h && b_h2h && w_score && w_ih_ctx && w_hh && w_inv && hid && groups >= 1,
+                "mrn_attn_decoder_fwd_x3_grouped: null operand");
+  MRN_CHECK_ARG(hidden == HID, "mrn_attn_decoder_fwd_x3_grouped: hidden=%d unsupported (library is built for %d)", hidden, HID);
+  MRN_CHECK_ARG(D % 32 == 0 && D > 0, "mrn_attn_decoder_fwd_x3_grouped: D=%d must be a multiple of 32", D);
+  if (B == 0 || S == 0) return MRN_OK;
+  for (int g0 = 0; g0 < groups; g0 += MAX_GROUPS) {
+    const int n = groups - g0 < MAX_GROUPS ? groups - g0 : MAX_GROUPS;
+    AttnDecGroup grp;
+    memset(&grp, 0, sizeof(grp));
+    for (int i = 0; i < n; ++i) {
+      const int g = g0 + i;
+      MRN_CHECK_ARG(Hb[g] && Hproj[g] && eproj[g] && w_h2h[g] && b_h2h[g] && w_score[g] && w_ih_ctx[g] && w_hh[g] && w_inv[g] && hid[g],
+                    "mrn_attn_decoder_fwd_x3_grouped: null operand in group %d", g);
+      attn_fill(grp.g[i], (const float*)Hb[g], (const float*)Hproj[g], (const float*)eproj[g], eproj_stride_b, eproj_stride_s,
+                (const float*)w_h2h[g], (const float*)b_h2h[g], (const float*)w_score[g], (const float*)w_ih_ctx[g],
+                (const float*)w_hh[g], b_hh ? (const float*)b_hh[g] : nullptr, (float*)hid[g], hid_stride_b, hid_stride_s, B, T, D, S);
+      grp.g[i].w_inv = (const float*)w_inv[g];
     }
     grp.tiles = ceil_div(B, BT);
     const int rc = attn_launch(grp, n, D, T, (hipStream_t)stream);

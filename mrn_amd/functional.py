@@ -676,8 +676,12 @@ class AttnDecoderFn(torch.autograd.Function):
         tok = text[:, :S]
         emb = ops.embed_gather(tok, emb_w, num_class)
         eproj = ops.linear(emb, w_ih[:, D:], b_ih)
-        hid, saves = ops.attn_decoder_train(batch_H, Hproj, eproj, ops.pack_fragment_major(h2h_w), h2h_b, score_w,
-                                            ops.pack_fragment_major(w_ih[:, :D]), ops.pack_fragment_major(w_hh), b_hh, Hd)
+        if ops.DECODER_X3 and D % 32 == 0 and Hd == 256:
+            a, b_, c_, w_inv = ops.pack_decoder_x3(h2h_w, w_ih, w_hh, D)
+            hid, saves = ops.attn_decoder_train(batch_H, Hproj, eproj, a, h2h_b, score_w, b_, c_, b_hh, Hd, w_inv=w_inv)
+        else:
+            hid, saves = ops.attn_decoder_train(batch_H, Hproj, eproj, ops.pack_fragment_major(h2h_w), h2h_b, score_w,
+                                                ops.pack_fragment_major(w_ih[:, :D]), ops.pack_fragment_major(w_hh), b_hh, Hd)
         probs = ops.linear(hid, gen_w, gen_b)
         ctx.save_for_backward(batch_H, Hproj, emb, hid, i2h_w, h2h_w, score_w, w_ih, w_hh, gen_w, tok, *saves)
         ctx.dims = (Hd, D, num_class, S)

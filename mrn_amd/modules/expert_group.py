@@ -618,10 +618,12 @@ class HeadsGroup(SequenceGroup):
                 ops.embed_gather(text[:, :S], h.char_embeddings.weight, h.num_class, out=emb[g])
             eproj = self._linear("emb", ops.split_hl32(emb), B * S, E, [c.rnn.weight_ih[:, D:] for c in cells],
                                  [c.rnn.bias_ih for c in cells]).view(G, B, S, -1)
-            packed = [h._packed() for h in heads]                 # fragment-major (w_h2h, w_ih[:, :D], w_hh)
+            x3 = heads[0].x3_ok()
+            packed = [h._packed_x3() if x3 else h._packed() for h in heads]    # fragment-major (w_h2h, w_ih[:, :D], w_hh[, w_inv])
             hid = ops.attn_decoder_grouped(feat, Hproj, eproj, [p[0] for p in packed], [c.h2h.bias for c in cells],
                                            [c.score.weight for c in cells], [p[1] for p in packed], [p[2] for p in packed],
-                                           [c.rnn.bias_hh for c in cells], cells[0].hidden_size)
+                                           [c.rnn.bias_hh for c in cells], cells[0].hidden_size,
+                                           w_inv=[p[3] for p in packed] if x3 else None)
             src_hl, rows, K = ops.split_hl32(hid), B * S, hid.shape[-1]
             gens = [h.generator for h in heads]
         per = rows * K * 4                                         # HL32 bytes of one expert's generator input

@@ -51,11 +51,29 @@ class Attention(nn.Module):
             self._mrn_packed = cache
         return cache[1]
 
+    def _packed_x3(self):
+        """the same three streams as fp16 hi / lo fragment-major splits + their inverse prescales (ops.pack_decoder_x3), cached"""
+        cell = self.attention_cell
+        ps = (cell.h2h.weight, cell.rnn.weight_ih, cell.rnn.weight_hh)
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        cache = getattr(self, "_mrn_packed_x3", None)
+        if cache is None or cache[0] != key:
+            with torch.no_grad():
+                cache = (key, ops.pack_decoder_x3(ps[0], ps[1], ps[2], cell.input_size))
+            self._mrn_packed_x3 = cache
+        return cache[1]
+
+    def x3_ok(self):
+        return ops.DECODER_X3 and self.attention_cell.input_size % 32 == 0 and self.hidden_size == 256
+
     def _decode(self, batch_H, Hproj, eproj, hid=None, h=None, c=None):
         cell = self.attention_cell
-        w_h2h, w_ih_ctx, w_hh = self._packed()
+        if self.x3_ok():
+            w_h2h, w_ih_ctx, w_hh, w_inv = self._packed_x3()
+        else:
+            (w_h2h, w_ih_ctx, w_hh), w_inv = self._packed(), None
         return ops.attn_decoder(batch_H, Hproj, eproj, w_h2h, cell.h2h.bias, cell.score.weight,
-                                w_ih_ctx, w_hh, cell.rnn.bias_hh, self.hidden_size, hid=hid, h_state=h, c_state=c)
+                                w_ih_ctx, w_hh, cell.rnn.bias_hh, self.hidden_size, hid=hid, h_state=h, c_state=c, w_inv=w_inv)
 
     def forward(self, batch_H, text, is_train=True, batch_max_length=25, out=None):
         """batch_H [B,T,D]; text [B,S] (teacher forcing) or [B] of [SOS] (greedy) -> logits [B,S,num_class].

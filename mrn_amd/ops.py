@@ -1099,7 +1099,7 @@ def lstm_layer_grouped(xproj, w_hh, b_hh, hidden, ndir):
     return out
 
 
-def attn_decoder_grouped(Hb, Hproj, eproj, w_h2h, b_h2h, w_score, w_ih, w_hh, b_hh, hidden):
+def attn_decoder_grouped(Hb, Hproj, eproj, w_h2h, b_h2h, w_score, w_ih, w_hh, b_hh, hidden, w_inv=None):
     """Hb [G,B,T,D], Hproj [G,B,T,H], eproj [G,B,S,4H]; the weight arguments are lists of G tensors -> hid [G,B,S,H]"""
     _chk(Hb, Hproj, eproj)
     G, B, T, D = Hb.shape
@@ -1109,10 +1109,24 @@ def attn_decoder_grouped(Hb, Hproj, eproj, w_h2h, b_h2h, w_score, w_ih, w_hh, b_
 
     def arr(ts):
         return _ptr_array([t.data_ptr() for t in ts])
+    if w_inv is not None:          # x3 form: the weight lists hold pack_fragment_major_h streams, w_inv a list of device float[3]
+        call("mrn_attn_decoder_fwd_x3_grouped", arr(Hb), arr(Hproj), arr(eproj), eproj.stride(1), eproj.stride(2), arr(w_h2h),
+             arr(b_h2h), arr(w_score), arr(w_ih), arr(w_hh), arr(w_inv), arr(b_hh), arr(hid), hid.stride(1), hid.stride(2), G, B, T, D, S,
+             hidden, _stream())
+        return hid
     call("mrn_attn_decoder_fwd_grouped_f32", arr(Hb), arr(Hproj), arr(eproj), eproj.stride(1), eproj.stride(2), arr(w_h2h),
          arr(b_h2h), arr(w_score), arr(w_ih), arr(w_hh), arr(b_hh), arr(hid), hid.stride(1), hid.stride(2), G, B, T, D, S,
          hidden, _stream())
     return hid
+
+
+DECODER_X3 = os.environ.get("MRN_DECODER_X3", "1") == "1"     # attention decoder: the three recurrent products as split-fp16 x3
+
+
+def pack_decoder_x3(w_h2h, w_ih, w_hh, D):
+    """(h2h.weight [H,H], rnn.weight_ih [4H, D+E], rnn.weight_hh [4H,H]) -> (three pack_fragment_major_h streams, w_inv float[3])"""
+    a, b, c = pack_fragment_major_h(w_h2h.detach()), pack_fragment_major_h(w_ih.detach()[:, :D].contiguous()), pack_fragment_major_h(w_hh.detach())
+    return a[0], b[0], c[0], torch.cat([a[1], b[1], c[1]]).contiguous()
 
 
 def lstm_layer_bwd(dout, gates, cseq, w_hhT, hidden, ndir):
@@ -1149,15 +1163,22 @@ def embed_gather(idx, table, num_class, out=None):
 
 
 def attn_decoder(Hb, Hproj, eproj, w_h2h, b_h2h, w_score, w_ih, w_hh, b_hh, hidden, hid=None, h_state=None,
-                 c_state=None, want_alpha=False):
-    """w_h2h, w_ih (= W_ih[:, :D]) and w_hh must be pack_fragment_major()'d"""
-    _chk(Hb, Hproj, eproj, w_h2h, b_h2h, w_score, w_ih, w_hh, b_hh)
+                 c_state=None, want_alpha=False, w_inv=None):
+    """w_h2h, w_ih (= W_ih[:, :D]) and w_hh must be pack_fragment_major()'d -- or, with w_inv, the fp16 streams of pack_decoder_x3"""
+    _chk(Hb, Hproj, eproj, b_h2h, w_score, b_hh)
+    if w_inv is None:
+        _chk(w_h2h, w_ih, w_hh)
     B, T, D = Hb.shape
     S = eproj.shape[1]
     if hid is None:
         hid = torch.empty(B, S, hidden, device=Hb.device, dtype=torch.float32)
     alpha = torch.empty(B, S, T, device=Hb.device, dtype=torch.float32) if want_alpha else None
     assert eproj.stride(2) == 1 and hid.stride(2) == 1 and w_ih.is_contiguous() and w_hh.is_contiguous()
+    if w_inv is not None:          # x3 form (pack_decoder_x3)
+        call("mrn_attn_decoder_fwd_x3", _p(Hb), _p(Hproj), _p(eproj), eproj.stride(0), eproj.stride(1), _p(w_h2h),
+             _p(b_h2h), _p(w_score), _p(w_ih), _p(w_hh), _p(w_inv), _p(b_hh), _p(hid), hid.stride(0), hid.stride(1),
+             _p(h_state), _p(c_state), _p(alpha), None, None, None, None, B, T, D, S, hidden, _stream())
+        return (hid, alpha) if want_alpha else hid
     call("mrn_attn_decoder_fwd_f32", _p(Hb), _p(Hproj), _p(eproj), eproj.stride(0), eproj.stride(1), _p(w_h2h),
          _p(b_h2h), _p(w_score), _p(w_ih), _p(w_hh), _p(b_hh), _p(hid), hid.stride(0), hid.stride(1),
          _p(h_state), _p(c_state), _p(alpha), None, None, None, None, B, T, D, S, hidden, _stream())
@@ -1609,8 +1630,8 @@ def maxpool_bwd(dy, x, kernel, stride, padding):
 # ---------------------------------------------------------------------------------------------------------
 # attention decoder / TPS backward
 # ---------------------------------------------------------------------------------------------------------
-def attn_decoder_train(Hb, Hproj, eproj, w_h2h, b_h2h, w_score, w_ih, w_hh, b_hh, hidden):
-    """teacher-forced forward that also returns what the backward needs: (hid, saves)"""
+def attn_decoder_train(Hb, Hproj, eproj, w_h2h, b_h2h, w_score, w_ih, w_hh, b_hh, hidden, w_inv=None):
+    """teacher-forced forward that also returns what the backward needs: (hid, saves); w_inv: the x3 form (pack_decoder_x3)"""
     B, T, D = Hb.shape
     S = eproj.shape[1]
     dev = Hb.device
@@ -1620,6 +1641,11 @@ def attn_decoder_train(Hb, Hproj, eproj, w_h2h, b_h2h, w_score, w_ih, w_hh, b_hh
     cseq = torch.empty(B, S, hidden, device=dev, dtype=torch.float32)
     ctx = torch.empty(B, S, D, device=dev, dtype=torch.float32)
     hp = torch.empty(B, S, hidden, device=dev, dtype=torch.float32)
+    if w_inv is not None:
+        call("mrn_attn_decoder_fwd_x3", _p(Hb), _p(Hproj), _p(eproj), eproj.stride(0), eproj.stride(1), _p(w_h2h),
+             _p(b_h2h), _p(w_score), _p(w_ih), _p(w_hh), _p(w_inv), _p(b_hh), _p(hid), hid.stride(0), hid.stride(1), None, None,
+             _p(alpha), _p(gates), _p(cseq), _p(ctx), _p(hp), B, T, D, S, hidden, _stream())
+        return hid, (alpha, gates, cseq, ctx, hp)
     call("mrn_attn_decoder_fwd_f32", _p(Hb), _p(Hproj), _p(eproj), eproj.stride(0), eproj.stride(1), _p(w_h2h),
          _p(b_h2h), _p(w_score), _p(w_ih), _p(w_hh), _p(b_hh), _p(hid), hid.stride(0), hid.stride(1), None, None,
          _p(alpha), _p(gates), _p(cseq), _p(ctx), _p(hp), B, T, D, S, hidden, _stream())
