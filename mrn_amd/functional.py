@@ -561,22 +561,32 @@ class MaxPoolFn(torch.autograd.Function):
         return ops.maxpool_bwd(dy, x, *ctx.geom), None, None, None
 
 
+def _pack_lstm_h(w_f, w_r):
+    packs = [ops.pack_fragment_major_h(w.detach()) for w in (w_f, w_r)]
+    return torch.stack([p_[0] for p_ in packs]).contiguous(), torch.cat([p_[1] for p_ in packs]).contiguous()
+
+
+def _pack_lstm_hT(w_f, w_r):
+    packs = [ops.pack_fragment_major_h(w.detach().t().contiguous()) for w in (w_f, w_r)]
+    return torch.stack([p_[0] for p_ in packs]).contiguous(), torch.cat([p_[1] for p_ in packs]).contiguous()
+
+
 class BiLSTMFn(torch.autograd.Function):
     """nn.LSTM(bidirectional=True, batch_first=True) forward + backward through time on the HIP kernels."""
 
     @staticmethod
     def forward(ctx, x, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
         H = w_hh_f.shape[1]
-        w_ih = torch.cat([w_ih_f, w_ih_r], 0)
-        b_ih = torch.cat([b_ih_f, b_ih_r], 0)
-        b_hh = torch.cat([b_hh_f, b_hh_r], 0)
+        # (the repacks of a step's weights come from ops.train_pack: issued on the side stream ahead of use from the second step on)
+        w_ih, b_ih, b_hh = ops.train_pack("lstm_cat", (w_ih_f, w_ih_r, b_ih_f, b_ih_r, b_hh_f, b_hh_r),
+                                          lambda a, b, c, d, e, f: (torch.cat([a.detach(), b.detach()], 0), torch.cat([c.detach(), d.detach()], 0),
+                                                                    torch.cat([e.detach(), f.detach()], 0)))
         x = x.contiguous()
         xproj = ops.linear(x, w_ih, b_ih)
         if ops.TRAIN_LSTM_X3 and H == 256:
             # recurrent product as split-fp16 x3 (the trained convolutions' arithmetic): half the time per step of the exact-fp32 MFMA
-            packs = [ops.pack_fragment_major_h(w.detach()) for w in (w_hh_f, w_hh_r)]
-            out, gates, cseq = ops.lstm_layer_x3_save(xproj, torch.stack([p_[0] for p_ in packs]).contiguous(),
-                                                      torch.cat([p_[1] for p_ in packs]).contiguous(), b_hh, H, 2)
+            w_h, w_inv = ops.train_pack("lstm_fwd_x3", (w_hh_f, w_hh_r), _pack_lstm_h)
+            out, gates, cseq = ops.lstm_layer_x3_save(xproj, w_h, w_inv, b_hh, H, 2)
         else:
             w_hh = torch.stack([ops.pack_fragment_major(w_hh_f), ops.pack_fragment_major(w_hh_r)], 0)
             out, gates, cseq = ops.lstm_layer(xproj, w_hh, b_hh, H, 2, save=True)
@@ -591,9 +601,8 @@ class BiLSTMFn(torch.autograd.Function):
         H = ctx.H
         B, T, _ = out.shape
         if ops.TRAIN_LSTM_X3 and H == 256:
-            packs = [ops.pack_fragment_major_h(w.detach().t().contiguous()) for w in (w_hh_f, w_hh_r)]
-            dg = ops.lstm_layer_bwd_x3(dout, gates, cseq, torch.stack([p_[0] for p_ in packs]).contiguous(),
-                                       torch.cat([p_[1] for p_ in packs]).contiguous(), H, 2)               # [B,T,2,4H]
+            w_hT, w_invT = ops.train_pack("lstm_bwd_x3", (ctx.params[1], ctx.params[5]), _pack_lstm_hT)
+            dg = ops.lstm_layer_bwd_x3(dout, gates, cseq, w_hT, w_invT, H, 2)                                 # [B,T,2,4H]
         else:
             w_hhT = torch.stack([ops.pack_fragment_major(w_hh_f.t().contiguous()), ops.pack_fragment_major(w_hh_r.t().contiguous())], 0)
             dg = ops.lstm_layer_bwd(dout, gates, cseq, w_hhT, H, 2)          # [B,T,2,4H]
@@ -663,6 +672,17 @@ class TPSSampleFn(torch.autograd.Function):
         return None, ops.tps_grid_sample_bwd(img, cprime, inv_delta_c, p_hat, dout), None, None, None
 
 
+def _pack_decoder_x3(h2h_w, w_ih, w_hh, emb_w):
+    """(the context width D of an AttentionCell is rnn.weight_ih's width minus the embedding width)"""
+    return ops.pack_decoder_x3(h2h_w, w_ih, w_hh, w_ih.shape[1] - emb_w.shape[1])
+
+
+def _pack_decoder_T(h2h_w, w_ih, w_hh, emb_w):
+    D = w_ih.shape[1] - emb_w.shape[1]
+    return (ops.pack_fragment_major(h2h_w.detach().t().contiguous()), ops.pack_fragment_major(w_ih.detach()[:, :D].t().contiguous()),
+            ops.pack_fragment_major(w_hh.detach().t().contiguous()))
+
+
 class AttnDecoderFn(torch.autograd.Function):
     """Teacher-forced Attention.forward (modules/prediction.py:58-68) with its full backward."""
 
@@ -677,7 +697,7 @@ class AttnDecoderFn(torch.autograd.Function):
         emb = ops.embed_gather(tok, emb_w, num_class)
         eproj = ops.linear(emb, w_ih[:, D:], b_ih)
         if ops.DECODER_X3 and D % 32 == 0 and Hd == 256:
-            a, b_, c_, w_inv = ops.pack_decoder_x3(h2h_w, w_ih, w_hh, D)
+            a, b_, c_, w_inv = ops.train_pack("dec_fwd_x3", (h2h_w, w_ih, w_hh, emb_w), _pack_decoder_x3)
             hid, saves = ops.attn_decoder_train(batch_H, Hproj, eproj, a, h2h_b, score_w, b_, c_, b_hh, Hd, w_inv=w_inv)
         else:
             hid, saves = ops.attn_decoder_train(batch_H, Hproj, eproj, ops.pack_fragment_major(h2h_w), h2h_b, score_w,
@@ -695,10 +715,8 @@ class AttnDecoderFn(torch.autograd.Function):
         B, T, _ = batch_H.shape
         dprobs = dprobs.contiguous()
         dhid = linear_dgrad(dprobs, gen_w).view(B, S, Hd)
-        dgates, dhp, dHb, dHproj, dws = ops.attn_decoder_bwd(
-            batch_H, Hproj, (alpha, gates, cseq, cx, hp), dhid, score_w,
-            ops.pack_fragment_major(h2h_w.t().contiguous()), ops.pack_fragment_major(w_ih[:, :D].t().contiguous()),
-            ops.pack_fragment_major(w_hh.t().contiguous()), Hd)
+        pT = ops.train_pack("dec_bwd", (ctx.params[1], ctx.params[4], ctx.params[5], ctx.params[8]), _pack_decoder_T)
+        dgates, dhp, dHb, dHproj, dws = ops.attn_decoder_bwd(batch_H, Hproj, (alpha, gates, cseq, cx, hp), dhid, score_w, pT[0], pT[1], pT[2], Hd)
 
         def param_grads():            # order of ctx.params: i2h_w, h2h_w, h2h_b, score_w, w_ih, w_hh, b_ih, b_hh, emb_w, gen_w, gen_b
             dgen_w, dgen_b = linear_wgrad(dprobs, hid), ops.colsum(dprobs)

@@ -719,6 +719,25 @@ def _wkey(kind, t, *extra):
     return (kind, t.data_ptr(), t._version, tuple(t.shape)) + extra
 
 
+_PACK_REGISTRY = {}                 # (kind, ids of the parameters) -> (weakrefs to them, build): what prepack_trained() re-runs every step
+
+
+def train_pack(kind, params, build):
+    """build(*params) for the CURRENT values of `params` (Parameters of a layer being trained): a repack of recurrent / decoder weights
+    that the step needs in front of a kernel.  Found prepacked on the side stream -> wait for its event; otherwise built in place and
+    registered, so that prepack_trained() issues it ahead of use from the next step on."""
+    key = (kind,) + tuple((p.data_ptr(), p._version) for p in params)
+    got = _PREPACKED.get(key)
+    if got is not None:
+        if got[1] is not None:
+            torch.cuda.current_stream().wait_event(got[1])
+        return got[0]
+    val = build(*params)
+    if TRAIN_PREPACK and all(isinstance(p, torch.nn.Parameter) for p in params):
+        _PACK_REGISTRY[(kind,) + tuple(id(p) for p in params)] = (tuple(weakref.ref(p) for p in params), build)
+    return val
+
+
 def trained_weight_operand(w_ohwi, stride, padding):
     """-> ("wino", Winograd-domain stack, scale) or ("hl32", HL32 stack, scale) of one trained layer's [O,kh,kw,I] weights"""
     Cout, kh, kw, Cin = w_ohwi.shape
@@ -737,7 +756,7 @@ def trained_dgrad_weight(w_ohwi):
 
 def prepack_trained():
     """issue every registered trained layer's weight packing for the coming step on the side stream (see above)"""
-    if not (TRAIN_PREPACK and WGRAD_SIDE_STREAM and TRAINED_CONVS):
+    if not (TRAIN_PREPACK and WGRAD_SIDE_STREAM and (TRAINED_CONVS or _PACK_REGISTRY)):
         return
     from .modules._nn import packed_weight
     side = side_stream()
@@ -769,6 +788,16 @@ def prepack_trained():
             ev.record(side)
             for k, (val, src) in new.items():
                 _PREPACKED[k] = (val, ev, src)
+        for rk, (refs, build) in list(_PACK_REGISTRY.items()):
+            ps = [r() for r in refs]
+            if any(p_ is None or not p_.requires_grad for p_ in ps):
+                del _PACK_REGISTRY[rk]
+                continue
+            with torch.no_grad():
+                val = build(*ps)
+            ev = torch.cuda.Event()
+            ev.record(side)
+            _PREPACKED[(rk[0],) + tuple((p_.data_ptr(), p_._version) for p_ in ps)] = (val, ev, ps)
 
 
 def conv2d_x3_scaled(x, w_ohwi, bias, stride, padding, act=ACT_NONE, want_stats=False, sx=None):
