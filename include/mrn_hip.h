@@ -219,7 +219,10 @@ int mrn_bn_bwd_reduce_f32(const float* dz, const float* z, const float* y, const
 int mrn_bn_bwd_apply_f32(const float* dz, const float* z, const float* y, const float* mean, const float* invstd,
                          const float* gamma, const float* sums, float* dy, float* dres, int64_t rows, int C, int relu,
                          void* amax_ws, void* stream);   /* amax_ws (optional): max|dy| folded in */
-/* MaxPool2d backward: dx (zero-initialised) += dy at the first maximum of each window */
+/* MaxPool2d backward: dx (zero-initialised) += dy at the first maximum of each window.  When mrn_maxpool_bwd_writes_all(...) is 1
+ * (non-overlapping windows that tile the map: kernel == stride, no padding, H % kh == 0, W % kw == 0, C % 4 == 0) every element of dx is
+ * WRITTEN by the call -- no atomics, and the caller may skip the zero fill. */
+int64_t mrn_maxpool_bwd_writes_all(int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw);
 int mrn_maxpool_bwd_nhwc_f32(const float* dy, const float* x, float* dx_zeroed, int B, int H, int W, int C, int kh, int kw,
                              int sh, int sw, int ph, int pw, void* stream);
 

@@ -170,6 +170,42 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
   }
 }
 
+// Non-overlapping windows that tile the map exactly (kernel == stride, no padding, H % kh == 0, W % kw == 0: the 2 x 2 / 2 pools of the
+// ResNet and TPS stacks): every input element belongs to exactly one window, so a thread owning (window, 4 channels) WRITES its kh x kw
+// input positions -- dy at the first maximum, 0 elsewhere -- and neither the zero fill of dx nor atomics are needed.
+__global__ __launch_bounds__(256) void maxpool_bwd_disjoint_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                   float* __restrict__ dx, int B, int H, int W, int C, int kh, int kw) {
+  const int Ho = H / kh, Wo = W / kw, C4 = C >> 2;
+  const long n = (long)B * Ho * Wo * C4;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int c4 = (int)(i % C4);
+    long r = i / C4;
+    const int ox = (int)(r % Wo);
+    r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int b = (int)(r / Ho);
+    const f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
+    const long base = (((long)b * H + (long)oy * kh) * W + (long)ox * kw) * C + c4 * 4;
+    f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int at[4] = {0, 0, 0, 0};
+    for (int ky = 0; ky < kh; ++ky)
+      for (int kx = 0; kx < kw; ++kx) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + base + ((long)ky * W + kx) * C);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (v[j] > best[j] || (ky == 0 && kx == 0)) { best[j] = v[j]; at[j] = ky * kw + kx; }     // first maximum in scan order, as torch
+      }
+    for (int ky = 0; ky < kh; ++ky)
+      for (int kx = 0; kx < kw; ++kx) {
+        const int k = ky * kw + kx;
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = at[j] == k ? g[j] : 0.f;
+        *reinterpret_cast<f32x4*>(dx + base + ((long)ky * W + kx) * C) = o;
+      }
+  }
+}
+
 // ---- LSTM backward through time ------------------------------------------------------------------------
 constexpr int HID = 256, BT = 16, NW = 16, NTH = NW * 64;
 constexpr int GLD = 4 * HID + 4;
@@ -394,12 +430,23 @@ MRN_EXPORT int mrn_bn_bwd_apply_f32(const float* dz, const float* z, const float
   return MRN_OK;
 }
 
+// 1 when mrn_maxpool_bwd_nhwc_f32 writes EVERY element of dx itself (non-overlapping windows tiling the map): the caller may skip the zero fill
+MRN_EXPORT int64_t mrn_maxpool_bwd_writes_all(int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw) {
+  return kh == sh && kw == sw && ph == 0 && pw == 0 && H % kh == 0 && W % kw == 0 && C % 4 == 0;
+}
+
 MRN_EXPORT int mrn_maxpool_bwd_nhwc_f32(const float* dy, const float* x, float* dx_zeroed, int B, int H, int W, int C, int kh,
                                         int kw, int sh, int sw, int ph, int pw, void* stream) {
   MRN_CHECK_ARG(dy && x && dx_zeroed, "mrn_maxpool_bwd_nhwc_f32: null operand");
   const int Ho = (H + 2 * ph - kh) / sh + 1, Wo = (W + 2 * pw - kw) / sw + 1;
   const long n = (long)B * Ho * Wo * C;
   if (n <= 0) return MRN_OK;
+  if (mrn_maxpool_bwd_writes_all(H, W, C, kh, kw, sh, sw, ph, pw) && (uintptr_t)dy % 16 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)dx_zeroed % 16 == 0) {
+    hipLaunchKernelGGL(maxpool_bwd_disjoint_kernel, dim3(ew_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, dy, x, dx_zeroed, B, H, W,
+                       C, kh, kw);
+    MRN_LAUNCH_CHECK("maxpool_bwd");
+    return MRN_OK;
+  }
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(n, 512)), dim3(256), 0, (hipStream_t)stream, dy, x, dx_zeroed, B, H, W, C,
                      Ho, Wo, kh, kw, sh, sw, ph, pw);
   MRN_LAUNCH_CHECK("maxpool_bwd");

@@ -1650,7 +1650,9 @@ def bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres=False, range_target=No
 
 def maxpool_bwd(dy, x, kernel, stride, padding):
     B, H, W, C = x.shape
-    dx = torch.zeros_like(x)
+    x = x.contiguous()
+    writes_all = call("mrn_maxpool_bwd_writes_all", H, W, C, kernel[0], kernel[1], stride[0], stride[1], padding[0], padding[1])
+    dx = torch.empty_like(x) if writes_all else torch.zeros_like(x)      # (non-overlapping windows: the kernel writes every element)
     call("mrn_maxpool_bwd_nhwc_f32", _p(dy.contiguous()), _p(x), _p(dx), B, H, W, C, kernel[0], kernel[1], stride[0], stride[1],
          padding[0], padding[1], _stream())
     return dx

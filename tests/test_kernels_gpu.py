@@ -134,6 +134,21 @@ def test_maxpool_and_avgpool(ops, k, s, p):
     assert_close("avgpool", ops.avgpool_nhwc(xn), x.mean((2, 3)), atol=1e-6)
 
 
+@pytest.mark.parametrize("k,s,p,H,W,C", [((2, 2), (2, 2), (0, 0), 16, 8, 32), ((2, 2), (2, 2), (0, 0), 15, 8, 32), ((2, 2), (2, 1), (0, 1), 16, 8, 32),
+                                           ((2, 1), (2, 1), (0, 0), 16, 9, 36), ((2, 2), (2, 2), (0, 0), 8, 8, 33)])
+def test_maxpool_backward(ops, k, s, p, H, W, C):
+    """mrn_maxpool_bwd_nhwc_f32 against torch autograd: the non-atomic form for windows that tile the map (no zero fill: every element
+    written, first maximum on ties) and the atomic form for overlapping / ragged ones"""
+    x = rnd(3, C, H, W, seed=29)
+    x[:, :, 0:2, 0:2] = 0.25                                  # ties: the first maximum in scan order takes the gradient
+    xr = x.clone().requires_grad_(True)
+    y = F.max_pool2d(xr, k, s, p)
+    dy = rnd(*y.shape, seed=30)
+    y.backward(dy)
+    dx = ops.maxpool_bwd(cu(dy.permute(0, 2, 3, 1).contiguous()), cu(x.permute(0, 2, 3, 1).contiguous()), k, s, p)
+    assert_close("maxpool backward", dx.permute(0, 3, 1, 2), xr.grad, atol=1e-6, rtol=0)
+
+
 def test_tps_grid_sample(ops):
     from oracle.mrn_oracle import tps_constants
     from mrn_amd.tools.weights import fiducial_bias
