@@ -47,5 +47,23 @@ class BidirectionalLSTM(nn.Module):
             return y
         w_ih, w_hh, b_ih, b_hh = self._packed()
         xproj = ops.linear(input, w_ih, b_ih)
-        rec = ops.lstm_layer(xproj, w_hh, b_hh, self.hidden_size, 2)
+        if ops.RECURRENT_X3 and self.hidden_size == 256:
+            # inference: the recurrent product as split-fp16 x3, as the lock-step groups run it (half the step time of the exact-fp32 MFMA)
+            w_h, w_inv = self._packed_x3()
+            rec = ops.lstm_layer_x3_grouped(xproj.unsqueeze(0), w_h, w_inv, b_hh.unsqueeze(0), self.hidden_size, 2)[0]
+        else:
+            rec = ops.lstm_layer(xproj, w_hh, b_hh, self.hidden_size, 2)
         return ops.linear(rec, self.linear.weight, self.linear.bias, out=out)
+
+    def _packed_x3(self):
+        r = self.rnn
+        ps = (r.weight_hh_l0, r.weight_hh_l0_reverse)
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        cache = getattr(self, "_mrn_packed_x3", None)
+        if cache is None or cache[0] != key:
+            with torch.no_grad():
+                packs = [ops.pack_fragment_major_h(w) for w in ps]
+                cache = (key, (torch.stack([p_[0] for p_ in packs]).unsqueeze(0).contiguous(),
+                               torch.cat([p_[1] for p_ in packs]).unsqueeze(0).contiguous()))
+            self._mrn_packed_x3 = cache
+        return cache[1]
