@@ -351,6 +351,13 @@ int mrn_attn_decoder_bwd_f32(const float* Hb, const float* Hproj, const float* a
                              const float* w_score, const float* w_h2hT, const float* w_ih_ctxT, const float* w_hhT,
                              float* dgates, float* dhp, float* dHb, float* dHproj, float* dwscore_part,
                              int B, int T, int D, int S, int hidden, void* stream);
+/* The same backward pass with its three transposed recurrent products (dgates . W_ih_ctx, dgates . W_hh, dhp . W_h2h) as split-fp16 x3:
+ * w_h2hT / w_ih_ctxT / w_hhT = fragment-major fp16 hi / lo streams of the transposed weights (ops.pack_fragment_major_h), w_inv device
+ * float[3] of their inverse prescales, gscale device float[2] = {s, 1/s}, s a power of two bringing max|dhid| to ~16. */
+int mrn_attn_decoder_bwd_x3(const float* Hb, const float* Hproj, const float* alpha, const float* gates, const float* cseq,
+                            const float* ctx, const float* hp, const float* dhid, const float* w_score, const void* w_h2hT,
+                            const void* w_ih_ctxT, const void* w_hhT, const float* w_inv, const float* gscale, float* dgates, float* dhp,
+                            float* dHb, float* dHproj, float* dwscore_part, int B, int T, int D, int S, int hidden, void* stream);
 /* dtable[cut_unknown(idx[b][s])][:] += demb[b][s][:]  (nn.Embedding backward, modules/prediction.py:61) */
 int mrn_embed_scatter_add_f32(const int64_t* idx, int64_t idx_stride, const float* demb, float* dtable, int B, int S,
                               int E, int num_class, void* stream);

@@ -40,12 +40,43 @@ __device__ __forceinline__ void mma_shared_a(f32x4 (&acc)[G], const float* __res
   }
 }
 
+// the same with the A rows as fp16 hi / lo planes (halves, row stride ld) and fragment-major fp16 hi / lo weight streams
+// (ops.pack_fragment_major_h): split-fp16 x3 on v_mfma_f32_16x16x32_f16, Q32 = K / 32 steps
+typedef _Float16 f16v8b __attribute__((ext_vector_type(8)));
+template <int G>
+__device__ __forceinline__ void mma_shared_a_h(f32x4 (&acc)[G], const _Float16* __restrict__ a_hi, const _Float16* __restrict__ a_lo, int ld,
+                                               const f16v8b* const (&wp)[G], int Q32, int lane) {
+  const _Float16* ah = a_hi + (lane & 15) * ld + (lane >> 4) * 8;
+  const _Float16* al = a_lo + (lane & 15) * ld + (lane >> 4) * 8;
+  f16v8b wh[G], wl[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) { wh[g] = wp[g][0]; wl[g] = wp[g][1]; }
+#pragma unroll 1
+  for (int q = 0; q < Q32; ++q) {
+    f16v8b nh[G], nl[G];
+    const long qn = (q + 1 < Q32) ? q + 1 : q;
+#pragma unroll
+    for (int g = 0; g < G; ++g) { nh[g] = wp[g][qn * 128]; nl[g] = wp[g][qn * 128 + 1]; }
+    const f16v8b xh = *reinterpret_cast<const f16v8b*>(ah + q * 32), xl = *reinterpret_cast<const f16v8b*>(al + q * 32);
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, wh[g], acc[g], 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wl[g], acc[g], 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wh[g], acc[g], 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < G; ++g) { wh[g] = nh[g]; wl[g] = nl[g]; }
+  }
+}
+
 struct AttnBwdParams {
   const float *Hb, *Hproj, *alpha, *gates, *cseq, *ctx, *hp, *dhid, *w_score;
   const float *w_h2hT, *w_ih_ctxT, *w_hhT;
   float *dgates, *dhp, *dHb, *dHproj, *dws_part;
   int B, T, D, S;
   int vb;      // samples per workgroup (16, 8 or 4): rows >= vb of the 16-row MFMA tile are treated like rows beyond the batch
+  const float* w_inv;     // x3 form: device float[3] = 1 / prescale of W_h2h^T, W_ih_ctx^T, W_hh^T (then fp16 hi / lo fragment-major streams)
+  const float* gscale;    // x3 form: device float[2] = {s, 1/s}: the gate / hp gradients are split as s * value
 };
 
 __device__ __forceinline__ float fast_tanh(float x) {
@@ -53,13 +84,23 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return 1.f - 2.f / (e + 1.f);
 }
 
+// X3: the three transposed products (dgates . W_ih_ctx, dgates . W_hh, dhp . W_h2h) as split-fp16 x3 -- the gate / hp gradients live in
+// LDS as fp16 hi / lo planes of gscale * value.  On the exact-fp32 pipe they are 30 us of a step (576 MFMAs of 32 cycles per wave).
+constexpr int GLDH = 4 * HID + 8, HLDH = HID + 8;   // fp16 rows (halves)
+template <bool X3>
 __global__ __launch_bounds__(NTH) void attn_decoder_bwd_kernel(const AttnBwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int T = p.T;
-  float* dg_lds = lds;                       // [BT][GLD]   gate gradients (A operand of the two transposed products)
-  float* dctx_lds = dg_lds + BT * GLD;       // [BT][HLD]
-  float* dhp_lds = dctx_lds + BT * HLD;      // [BT][HLD]
-  float* hp_lds = dhp_lds + BT * HLD;        // [BT][HLD]
+  float* dg_lds = lds;                       // [BT][GLD]   gate gradients (A operand of the two transposed products)   (x3: 2 fp16 planes [BT][GLDH])
+  float* dctx_lds = X3 ? lds + (2 * BT * GLDH) / 2 : dg_lds + BT * GLD;       // [BT][HLD]
+  float* dhp_lds = dctx_lds + BT * HLD;      // [BT][HLD]                                                            (x3: 2 fp16 planes [BT][HLDH])
+  float* hp_lds = X3 ? dhp_lds + (2 * BT * HLDH) / 2 : dhp_lds + BT * HLD;        // [BT][HLD]
+  _Float16* dg_hi = reinterpret_cast<_Float16*>(dg_lds);
+  _Float16* dg_lo = dg_hi + BT * GLDH;
+  _Float16* dhp_hi = reinterpret_cast<_Float16*>(dhp_lds);
+  _Float16* dhp_lo = dhp_hi + BT * HLDH;
+  const float gs = X3 ? p.gscale[0] : 1.f, gsi = X3 ? p.gscale[1] : 1.f;
+  const float un_h2h = X3 ? p.w_inv[0] * gsi : 1.f, un_ih = X3 ? p.w_inv[1] * gsi : 1.f, un_hh = X3 ? p.w_inv[2] * gsi : 1.f;
   float* de_lds = hp_lds + BT * HLD;         // [BT][T]
   float* al_lds = de_lds + BT * T;           // [BT][T]
   float* sw_lds = al_lds + BT * T;           // [HID]
@@ -77,9 +118,13 @@ __global__ __launch_bounds__(NTH) void attn_decoder_bwd_kernel(const AttnBwdPara
   const f32x4* w_ctx = reinterpret_cast<const f32x4*>(p.w_ih_ctxT) + (long)wave * (p.D / HID) * (4 * HID / 16) * 64 + lane;
   const f32x4* w_hh = reinterpret_cast<const f32x4*>(p.w_hhT) + (long)wave * (4 * HID / 16) * 64 + lane;
   const f32x4* w_h2h = reinterpret_cast<const f32x4*>(p.w_h2hT) + (long)wave * (HID / 16) * 64 + lane;
+  // x3 streams: [wave][block][K / 32 steps][64 lanes][hi 8 | lo 8 halves]
+  const f16v8b* w_ctx_h = reinterpret_cast<const f16v8b*>(p.w_ih_ctxT) + ((long)wave * (p.D / HID) * (4 * HID / 32) * 64 + lane) * 2;
+  const f16v8b* w_hh_h = reinterpret_cast<const f16v8b*>(p.w_hhT) + ((long)wave * (4 * HID / 32) * 64 + lane) * 2;
+  const f16v8b* w_h2h_h = reinterpret_cast<const f16v8b*>(p.w_h2hT) + ((long)wave * (HID / 32) * 64 + lane) * 2;
 
   for (int i = t_; i < HID; i += NTH) sw_lds[i] = p.w_score[i];
-  for (int i = t_; i < BT * HLD; i += NTH) dhp_lds[i] = 0.f;      // rows >= vb stay zero
+  for (int i = t_; i < (X3 ? (2 * BT * HLDH) / 2 : BT * HLD); i += NTH) dhp_lds[i] = 0.f;      // rows >= vb stay zero
   float dh_rec[4] = {0.f, 0.f, 0.f, 0.f}, dc_next[4] = {0.f, 0.f, 0.f, 0.f};
   f32x4 dws = {0.f, 0.f, 0.f, 0.f};          // d w_score for channels lane*4.. of this wave's sample
   __syncthreads();
@@ -116,8 +161,19 @@ __global__ __launch_bounds__(NTH) void attn_decoder_bwd_kernel(const AttnBwdPara
         float* dp = p.dgates + base * 4 * HID + j;
         dp[0] = di; dp[HID] = df; dp[2 * HID] = dg; dp[3 * HID] = dob;
       }
-      float* l = dg_lds + row * GLD + j;
-      l[0] = di; l[HID] = df; l[2 * HID] = dg; l[3 * HID] = dob;
+      if constexpr (X3) {
+        const float v4[4] = {di * gs, df * gs, dg * gs, dob * gs};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          _Float16 hh, ll;
+          split_f16(v4[g], hh, ll);
+          dg_hi[row * GLDH + g * HID + j] = hh;
+          dg_lo[row * GLDH + g * HID + j] = ll;
+        }
+      } else {
+        float* l = dg_lds + row * GLD + j;
+        l[0] = di; l[HID] = df; l[2 * HID] = dg; l[3 * HID] = dob;
+      }
     }
     __syncthreads();
     // (b) + (c), one 256-column block of the context at a time (D = 256 * G: DERNet's main head attends over the G
@@ -128,19 +184,29 @@ __global__ __launch_bounds__(NTH) void attn_decoder_bwd_kernel(const AttnBwdPara
     for (int blk = 0; blk < G; ++blk) {
       if (blk == 0) {
         f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-        const f32x4* const wp[2] = {w_ctx, w_hh};
-        mma_shared_a<2>(acc, dg_lds, GLD, wp, 4 * HID / 16, lane);
+        if constexpr (X3) {
+          const f16v8b* const wp[2] = {w_ctx_h, w_hh_h};
+          mma_shared_a_h<2>(acc, dg_hi, dg_lo, GLDH, wp, 4 * HID / 32, lane);
+        } else {
+          const f32x4* const wp[2] = {w_ctx, w_hh};
+          mma_shared_a<2>(acc, dg_lds, GLD, wp, 4 * HID / 16, lane);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          dctx_lds[(rbase + r) * HLD + j] = acc[0][r];
-          dh_rec[r] = acc[1][r];
+          dctx_lds[(rbase + r) * HLD + j] = acc[0][r] * un_ih;
+          dh_rec[r] = acc[1][r] * un_hh;
         }
       } else {
         f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
-        const f32x4* const wp[1] = {w_ctx + (long)blk * (4 * HID / 16) * 64};
-        mma_shared_a<1>(acc, dg_lds, GLD, wp, 4 * HID / 16, lane);
+        if constexpr (X3) {
+          const f16v8b* const wp[1] = {w_ctx_h + (long)blk * (4 * HID / 32) * 64 * 2};
+          mma_shared_a_h<1>(acc, dg_hi, dg_lo, GLDH, wp, 4 * HID / 32, lane);
+        } else {
+          const f32x4* const wp[1] = {w_ctx + (long)blk * (4 * HID / 16) * 64};
+          mma_shared_a<1>(acc, dg_lds, GLD, wp, 4 * HID / 16, lane);
+        }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dctx_lds[(rbase + r) * HLD + j] = acc[0][r];
+        for (int r = 0; r < 4; ++r) dctx_lds[(rbase + r) * HLD + j] = acc[0][r] * un_ih;
       }
       __syncthreads();
       for (int pr0 = wave * 4; pr0 < vb * T; pr0 += NW * 4) {
@@ -253,17 +319,32 @@ __global__ __launch_bounds__(NTH) void attn_decoder_bwd_kernel(const AttnBwdPara
       }
       if (part == 0) {
         if (b < Bend) *reinterpret_cast<f32x4*>(p.dhp + ((long)b * p.S + s) * HID + lane * 4) = dhp;
-        *reinterpret_cast<f32x4*>(dhp_lds + row * HLD + lane * 4) = dhp;
+        if constexpr (X3) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            _Float16 hh, ll;
+            split_f16(dhp[k] * gs, hh, ll);
+            dhp_hi[row * HLDH + lane * 4 + k] = hh;
+            dhp_lo[row * HLDH + lane * 4 + k] = ll;
+          }
+        } else {
+          *reinterpret_cast<f32x4*>(dhp_lds + row * HLD + lane * 4) = dhp;
+        }
       }
     }
     __syncthreads();
     // (f) dh_prev += dhp . W_h2h
     if (s > 0) {
       f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
-      const f32x4* const wp[1] = {w_h2h};
-      mma_shared_a<1>(acc, dhp_lds, HLD, wp, HID / 16, lane);
+      if constexpr (X3) {
+        const f16v8b* const wp[1] = {w_h2h_h};
+        mma_shared_a_h<1>(acc, dhp_hi, dhp_lo, HLDH, wp, HID / 32, lane);
+      } else {
+        const f32x4* const wp[1] = {w_h2h};
+        mma_shared_a<1>(acc, dhp_lds, HLD, wp, HID / 16, lane);
+      }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) dh_rec[r] += acc[0][r];
+      for (int r = 0; r < 4; ++r) dh_rec[r] += acc[0][r] * un_h2h;
     }
     __syncthreads();
   }
@@ -380,6 +461,22 @@ static int attn_bwd_vb(int B) {
   return ceil_div(B, 4) <= 128 ? 4 : ceil_div(B, 8) <= 128 ? 8 : 16;
 }
 
+static int attn_bwd_launch(const AttnBwdParams& p, hipStream_t st) {
+  const bool x3 = p.w_inv != nullptr;
+  const size_t lds = sizeof(float) * (BT * GLD + 3 * BT * HLD + 2 * BT * p.T + HID + NW * HID) + (x3 ? 1024 : 0);
+  MRN_CHECK_ARG(lds <= 160 * 1024, "mrn_attn_decoder_bwd: LDS budget exceeded (T=%d)", p.T);
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)attn_decoder_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)attn_decoder_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  if (x3) hipLaunchKernelGGL(attn_decoder_bwd_kernel<true>, dim3(ceil_div(p.B, p.vb)), dim3(NTH), lds, st, p);
+  else hipLaunchKernelGGL(attn_decoder_bwd_kernel<false>, dim3(ceil_div(p.B, p.vb)), dim3(NTH), lds, st, p);
+  MRN_LAUNCH_CHECK("attn_decoder_bwd");
+  return MRN_OK;
+}
+
 // rows of the d w_score partial-sum buffer (= workgroups of mrn_attn_decoder_bwd_f32) for a batch of B
 MRN_EXPORT int64_t mrn_attn_decoder_bwd_parts(int B) { return B > 0 ? ceil_div(B, attn_bwd_vb(B)) : 0; }
 
@@ -399,13 +496,32 @@ MRN_EXPORT int mrn_attn_decoder_bwd_f32(const float* Hb, const float* Hproj, con
   p.dgates = dgates; p.dhp = dhp; p.dHb = dHb; p.dHproj = dHproj; p.dws_part = dwscore_part;
   p.B = B; p.T = T; p.D = D; p.S = S;
   p.vb = attn_bwd_vb(B);
-  const size_t lds = sizeof(float) * (BT * GLD + 3 * BT * HLD + 2 * BT * T + HID + NW * HID);
-  MRN_CHECK_ARG(lds <= 160 * 1024, "mrn_attn_decoder_bwd_f32: LDS budget exceeded (T=%d)", T);
-  static bool attr = false;
-  if (!attr) { hipFuncSetAttribute((const void*)attn_decoder_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-  hipLaunchKernelGGL(attn_decoder_bwd_kernel, dim3(ceil_div(B, p.vb)), dim3(NTH), lds, (hipStream_t)stream, p);
-  MRN_LAUNCH_CHECK("attn_decoder_bwd");
-  return MRN_OK;
+  p.w_inv = nullptr; p.gscale = nullptr;
+  return attn_bwd_launch(p, (hipStream_t)stream);
+}
+
+// mrn_attn_decoder_bwd_f32 with the three transposed recurrent products as split-fp16 x3: w_h2hT / w_ih_ctxT / w_hhT are the fragment-major
+// fp16 hi / lo streams of W_h2h^T [H][H], W_ih[:, :D]^T [D][4H], W_hh^T [H][4H] (ops.pack_fragment_major_h), w_inv a device float[3] of
+// their inverse prescales, gscale a device float[2] = {s, 1/s} with a power of two s bringing max|dhid| to ~16 (the gate and hp gradients
+// are split as s * value).
+MRN_EXPORT int mrn_attn_decoder_bwd_x3(const float* Hb, const float* Hproj, const float* alpha, const float* gates, const float* cseq,
+                                       const float* ctx, const float* hp, const float* dhid, const float* w_score, const void* w_h2hT,
+                                       const void* w_ih_ctxT, const void* w_hhT, const float* w_inv, const float* gscale, float* dgates,
+                                       float* dhp, float* dHb, float* dHproj, float* dwscore_part, int B, int T, int D, int S, int hidden,
+                                       void* stream) {
+  MRN_CHECK_ARG(Hb && Hproj && alpha && gates && cseq && ctx && hp && dhid && w_score && w_h2hT && w_ih_ctxT && w_hhT && w_inv && gscale &&
+                    dgates && dhp && dHb && dHproj && dwscore_part, "mrn_attn_decoder_bwd_x3: null operand");
+  MRN_CHECK_ARG(hidden == HID && D >= HID && D % HID == 0,
+                "mrn_attn_decoder_bwd_x3: needs hidden == %d and D a multiple of it (got D=%d hidden=%d)", HID, D, hidden);
+  if (B == 0 || S == 0) return MRN_OK;
+  AttnBwdParams p;
+  p.Hb = Hb; p.Hproj = Hproj; p.alpha = alpha; p.gates = gates; p.cseq = cseq; p.ctx = ctx; p.hp = hp; p.dhid = dhid;
+  p.w_score = w_score; p.w_h2hT = (const float*)w_h2hT; p.w_ih_ctxT = (const float*)w_ih_ctxT; p.w_hhT = (const float*)w_hhT;
+  p.dgates = dgates; p.dhp = dhp; p.dHb = dHb; p.dHproj = dHproj; p.dws_part = dwscore_part;
+  p.B = B; p.T = T; p.D = D; p.S = S;
+  p.vb = attn_bwd_vb(B);
+  p.w_inv = w_inv; p.gscale = gscale;
+  return attn_bwd_launch(p, (hipStream_t)stream);
 }
 
 MRN_EXPORT int mrn_embed_scatter_add_f32(const int64_t* idx, int64_t idx_stride, const float* demb, float* dtable, int B, int S,

@@ -683,6 +683,14 @@ def _pack_decoder_T(h2h_w, w_ih, w_hh, emb_w):
             ops.pack_fragment_major(w_hh.detach().t().contiguous()))
 
 
+def _pack_decoder_T_x3(h2h_w, w_ih, w_hh, emb_w):
+    D = w_ih.shape[1] - emb_w.shape[1]
+    a = ops.pack_fragment_major_h(h2h_w.detach().t().contiguous())
+    b = ops.pack_fragment_major_h(w_ih.detach()[:, :D].t().contiguous())
+    c = ops.pack_fragment_major_h(w_hh.detach().t().contiguous())
+    return a[0], b[0], c[0], torch.cat([a[1], b[1], c[1]]).contiguous()
+
+
 class AttnDecoderFn(torch.autograd.Function):
     """Teacher-forced Attention.forward (modules/prediction.py:58-68) with its full backward."""
 
@@ -715,8 +723,13 @@ class AttnDecoderFn(torch.autograd.Function):
         B, T, _ = batch_H.shape
         dprobs = dprobs.contiguous()
         dhid = linear_dgrad(dprobs, gen_w).view(B, S, Hd)
-        pT = ops.train_pack("dec_bwd", (ctx.params[1], ctx.params[4], ctx.params[5], ctx.params[8]), _pack_decoder_T)
-        dgates, dhp, dHb, dHproj, dws = ops.attn_decoder_bwd(batch_H, Hproj, (alpha, gates, cseq, cx, hp), dhid, score_w, pT[0], pT[1], pT[2], Hd)
+        if ops.DECODER_X3 and Hd == 256:
+            pT = ops.train_pack("dec_bwd_x3", (ctx.params[1], ctx.params[4], ctx.params[5], ctx.params[8]), _pack_decoder_T_x3)
+            dgates, dhp, dHb, dHproj, dws = ops.attn_decoder_bwd(batch_H, Hproj, (alpha, gates, cseq, cx, hp), dhid, score_w, pT[0], pT[1], pT[2],
+                                                                 Hd, w_inv=pT[3])
+        else:
+            pT = ops.train_pack("dec_bwd", (ctx.params[1], ctx.params[4], ctx.params[5], ctx.params[8]), _pack_decoder_T)
+            dgates, dhp, dHb, dHproj, dws = ops.attn_decoder_bwd(batch_H, Hproj, (alpha, gates, cseq, cx, hp), dhid, score_w, pT[0], pT[1], pT[2], Hd)
 
         def param_grads():            # order of ctx.params: i2h_w, h2h_w, h2h_b, score_w, w_ih, w_hh, b_ih, b_hh, emb_w, gen_w, gen_b
             dgen_w, dgen_b = linear_wgrad(dprobs, hid), ops.colsum(dprobs)

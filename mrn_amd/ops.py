@@ -1683,8 +1683,9 @@ def attn_decoder_train(Hb, Hproj, eproj, w_h2h, b_h2h, w_score, w_ih, w_hh, b_hh
     return hid, (alpha, gates, cseq, ctx, hp)
 
 
-def attn_decoder_bwd(Hb, Hproj, saves, dhid, w_score, w_h2hT, w_ih_ctxT, w_hhT, hidden):
-    """-> dgates [B,S,4H], dhp [B,S,H], dHb [B,T,D], dHproj [B,T,H], dw_score [H]"""
+def attn_decoder_bwd(Hb, Hproj, saves, dhid, w_score, w_h2hT, w_ih_ctxT, w_hhT, hidden, w_inv=None):
+    """-> dgates [B,S,4H], dhp [B,S,H], dHb [B,T,D], dHproj [B,T,H], dw_score [H]; w_inv: the x3 form (the three weights as
+    pack_fragment_major_h streams of the transposes, w_inv float[3])"""
     alpha, gates, cseq, ctx, hp = saves
     B, T, D = Hb.shape
     S = alpha.shape[1]
@@ -1695,9 +1696,16 @@ def attn_decoder_bwd(Hb, Hproj, saves, dhid, w_score, w_h2hT, w_ih_ctxT, w_hhT, 
     dHproj = torch.zeros(B, T, hidden, device=dev, dtype=torch.float32)
     nwg = call("mrn_attn_decoder_bwd_parts", B)
     dws = torch.empty(nwg, hidden, device=dev, dtype=torch.float32)
-    call("mrn_attn_decoder_bwd_f32", _p(Hb), _p(Hproj), _p(alpha), _p(gates), _p(cseq), _p(ctx), _p(hp), _p(dhid.contiguous()),
-         _p(w_score), _p(w_h2hT), _p(w_ih_ctxT), _p(w_hhT), _p(dgates), _p(dhp), _p(dHb), _p(dHproj), _p(dws), B, T, D, S,
-         hidden, _stream())
+    dhid = dhid.contiguous()
+    if w_inv is not None:
+        gs = pow2_scale(dhid, 16.0)
+        call("mrn_attn_decoder_bwd_x3", _p(Hb), _p(Hproj), _p(alpha), _p(gates), _p(cseq), _p(ctx), _p(hp), _p(dhid),
+             _p(w_score), _p(w_h2hT), _p(w_ih_ctxT), _p(w_hhT), _p(w_inv), _p(gs), _p(dgates), _p(dhp), _p(dHb), _p(dHproj), _p(dws), B, T, D, S,
+             hidden, _stream())
+    else:
+        call("mrn_attn_decoder_bwd_f32", _p(Hb), _p(Hproj), _p(alpha), _p(gates), _p(cseq), _p(ctx), _p(hp), _p(dhid),
+             _p(w_score), _p(w_h2hT), _p(w_ih_ctxT), _p(w_hhT), _p(dgates), _p(dhp), _p(dHb), _p(dHproj), _p(dws), B, T, D, S,
+             hidden, _stream())
     return dgates, dhp, dHb, dHproj, (colsum(dws) if nwg > 1 else dws[0])
 
 
