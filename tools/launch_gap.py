@@ -1,5 +1,11 @@
-import sys, time, torch
-sys.path.insert(0, "/root/repo")
+"""cost of a dependent tiny-kernel launch: plain launches through the Python binding vs nodes of a replayed HIP graph"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mrn_amd import ops
 x = torch.zeros(64, device="cuda")
 sc = torch.empty(2, device="cuda")
