@@ -455,6 +455,14 @@ int mrn_svtr_block_x3_f32(const float* x, const float* pending, const float* dro
                           const float* b2, float eps2, const void* w1_hl, const float* s1, const float* bm1, const void* w2_hl,
                           const float* s2, const float* bm2, const float* drop2, float* x_out, int imgs, int imgs_per_group, int N,
                           int C, void* stream);
+/* Attention-only form for the wide stage (C = 256, SVTR stage 3: the proj accumulators of mrn_svtr_mixer_x3_f32 do not fit next to the token
+ * fragments): t = x + drop_prev * pending (written to t_out when pending is given); ctx_hl = HL32(attention(qkv(LayerNorm1(t)))), the
+ * operand of the (unfused) proj Linear -- the residual add and LayerNorm2 follow as mrn_add_layernorm_grouped_f32.  Saves the LayerNorm
+ * pass and the qkv round trip (modules/svtr.py:130-152 behind :200's norm1).  C = 256, N <= 128, imgs_per_group a multiple of 2 (N > 64) or
+ * 4; otherwise MRN_ERR_UNSUPPORTED.  Other arguments as mrn_svtr_mixer_x3_f32. */
+int mrn_svtr_attention_block_x3_f32(const float* x, const float* pending, const float* drop_prev, const float* g1, const float* b1,
+                                    float eps1, const void* wqkv_hl, const float* sqkv, const float* bqkv, const void* mask_bits,
+                                    float scale, float* t_out, void* ctx_hl, int imgs, int imgs_per_group, int N, int C, void* stream);
 /* Fused multi-head attention of the SVTR mixing blocks (head dimension 32), inference path of the frozen experts:
  * out[b][n][h*32 + :] = softmax_m(scale * q[b][n][h] . k[b][m][h] + mask[n][m]) @ v[b][m][h]; qkv [B][N][3*C] (q | k | v,
  * C = heads * 32), mask [N][N] additive and SYMMETRIC (SVTR's local window mask) or NULL, out [B][N][C] fp32 and / or

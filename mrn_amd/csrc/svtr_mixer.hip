@@ -78,11 +78,15 @@ __device__ __forceinline__ f32x16 mma(const u32x4 a, const u32x4 b, const f32x16
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16v8*>(&a), *reinterpret_cast<const f16v8*>(&b), c, 0, 0, 0);
 }
 
-template <int C, int NT, int IMG, int CHUNKS, int RING, bool MLP>
+// ATTN: attention only -- LayerNorm1 -> qkv -> attention, the context leaves as the HL32 operand of an unfused proj Linear (p.y_hl) and,
+// when a pending branch was folded in, t = x + drop_prev * pending as the residual stream (p.x_out).  For C = 256 (SVTR stage 3), where
+// the proj accumulators of the full form do not fit the register file next to the token fragments.
+template <int C, int NT, int IMG, int CHUNKS, int RING, bool MLP, bool ATTN = false>
 __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerParams p) {
   static_assert(CHUNKS == 1 || (CHUNKS == 2 && IMG == 1), "key chunks: one image per workgroup");
+  static_assert(!ATTN || (CHUNKS == 1 && !MLP), "attention-only form: one key chunk");
   constexpr int NW = NT * IMG, CB = C / 32, KB = C / 16, HEADS = C / 32, OC = C / 32;
-  constexpr int STEPS = 2 + 2 * CHUNKS;              // weight slabs per head: (Wk, Wv) per key chunk, Wq, Wproj
+  constexpr int STEPS = (ATTN ? 1 : 2) + 2 * CHUNKS; // weight slabs per head: (Wk, Wv) per key chunk, Wq, Wproj (not in the attention-only form)
   constexpr int SLAB = C * 128;                      // one weight slab: 32 rows x C channels, or C rows x 32 channels
   constexpr int NDMA = SLAB / 1024;                  // 1-KiB DMA instructions per slab
   constexpr int DMA_ROUNDS = (NDMA + NW - 1) / NW;
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerPa
   const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)(p.wproj + (long)g * C * CB * 128), 0, C * CB * 128, 0x00020000);
   auto issue = [&](int step, unsigned char* buf) {
     const int h = step / STEPS, sh = step % STEPS;
-    const int ty = sh == STEPS - 1 ? 3 : sh == 2 ? 2 : sh < 2 ? sh : sh - 3;      // 0: Wk, 1: Wv, 2: Wq, 3: Wproj
+    const int ty = (!ATTN && sh == STEPS - 1) ? 3 : sh == 2 ? 2 : sh < 2 ? sh : sh - 3;      // 0: Wk, 1: Wv, 2: Wq, 3: Wproj
 #pragma unroll
     for (int i = 0; i < DMA_ROUNDS; ++i) {
       const int d = i * NW + wave;
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerPa
   // ---- t = x + drop_prev * pending, LayerNorm1, split: MFMA fragments of one token per lane pair, k-block kb = channels
   // 16 kb + 8 half .. + 7 of token lane & 31
   const float ds = (p.pend && p.drop_prev) ? p.drop_prev[img < p.imgs ? img : img0] : 1.f;
-  auto load_ln1 = [&](long r, bool valid, u32x4* fh, u32x4* fl) {
+  auto load_ln1 = [&](long r, bool valid, u32x4* fh, u32x4* fl, bool store_t = false) {
     float v[KB][8];
     const float* xr = p.x + r * C;
     const float* pr = p.pend ? p.pend + r * C : nullptr;
@@ -157,6 +161,10 @@ __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerPa
         const f32x4 pa = *reinterpret_cast<const f32x4*>(pr + c), pb = *reinterpret_cast<const f32x4*>(pr + c + 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { v[kb][j] = fmaf(ds, pa[j], v[kb][j]); v[kb][4 + j] = fmaf(ds, pb[j], v[kb][4 + j]); }
+      }
+      if (store_t && valid) {                      // attention-only form: the folded residual stream t = x + drop_prev * pending
+        *reinterpret_cast<f32x4*>(p.x_out + r * C + c) = f32x4{v[kb][0], v[kb][1], v[kb][2], v[kb][3]};
+        *reinterpret_cast<f32x4*>(p.x_out + r * C + c + 4) = f32x4{v[kb][4], v[kb][5], v[kb][6], v[kb][7]};
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) s += v[kb][j];
@@ -189,7 +197,7 @@ __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerPa
     }
   };
   u32x4 xh[KB], xl[KB];
-  load_ln1(row, ok, xh, xl);
+  load_ln1(row, ok, xh, xl, ATTN && p.pend != nullptr && p.x_out != nullptr);
 
   // fragment offsets inside a 32-line tile / slab block: line = lane & 31, logical chunk = plane * 4 + ks * 2 + half, swizzled
   const int key = (l31 >> 1) & 7;
@@ -416,6 +424,27 @@ __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerPa
       load_ln1((long)(img < p.imgs ? img : img0) * p.N + (tok2 < p.N ? tok2 : 0), tok2 < p.N && img < p.imgs, th, tl);
       kv_tiles(step0 + 3, h, th, tl);
     }
+    if constexpr (ATTN) {
+      // ---- attention-only form: the head's context (normalised, split) leaves as line (row, head) of the proj Linear's HL32 operand;
+      // the next head's first slab barrier is where every wave is done with this head's K / V tiles
+      if (ok) {
+        const float inv = l_run > 0.f ? 1.f / (l_run * OPSCALE) : 0.f;
+        unsigned char* line = p.y_hl + (row * (long)HEADS + h) * 128;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          f16v4 hi, lo;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            _Float16 a, b;
+            split_f16(o[4 * k + j] * inv, a, b);
+            hi[j] = a;
+            lo[j] = b;
+          }
+          *reinterpret_cast<f16v4*>(line + (8 * k + 4 * half) * 2) = hi;
+          *reinterpret_cast<f16v4*>(line + 64 + (8 * k + 4 * half) * 2) = lo;
+        }
+      }
+    } else
     // ---- branch^T += Wproj[:, head h] . O^T: the context registers (normalised, split in place) are the B operand
     {
       const unsigned char* cur = next_slab(step0 + STEPS - 1);  // (its barrier publishes the other chunk's tiles / frees the own chunk's)
@@ -454,7 +483,7 @@ __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerPa
   // one token's row: stored directly, every instruction would scatter 64 pieces over 64 rows (measured: a third of the kernel's
   // time).  The wave's 32 rows go through a private LDS tile instead (the K / V tiles and the slab ring are free now) and leave as
   // whole rows, 1 KiB contiguous per store instruction.
-  {
+  if constexpr (!ATTN) {
     constexpr int ROWB = C * 4 + 16;                 // padded row: conflict-free 16-byte column writes
     constexpr int LPR = C * 4 / 16, RPI = 64 / LPR;  // lanes per row, rows per store instruction
     __syncthreads();                                 // every wave is done with the K / V tiles and the last slab
@@ -652,18 +681,19 @@ __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerPa
   }
 }
 
-template <int C, int NT, int IMG, int CHUNKS, int RING, bool MLP>
+template <int C, int NT, int IMG, int CHUNKS, int RING, bool MLP, bool ATTN = false>
 int launch_mixer(const MixerParams& p, hipStream_t st) {
   static_assert(!MLP || RING == 4, "the Mlp half double-buffers its slab pairs in a four-slab ring");
-  constexpr size_t ring = 2 * IMG * NT * 32 * 128 + RING * C * 128 + 4 * C * sizeof(float), stage = (size_t)NT * IMG * 32 * (C * 4 + 16);
+  constexpr size_t ring = 2 * IMG * NT * 32 * 128 + RING * C * 128 + 4 * C * sizeof(float), stage = ATTN ? 0 : (size_t)NT * IMG * 32 * (C * 4 + 16);
   constexpr size_t ldsz = ring > stage ? ring : stage;
+  static_assert(ldsz <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)svtr_mixer_kernel<C, NT, IMG, CHUNKS, RING, MLP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);
+    (void)hipFuncSetAttribute((const void*)svtr_mixer_kernel<C, NT, IMG, CHUNKS, RING, MLP, ATTN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);
     attr_set = true;
   }
-  hipLaunchKernelGGL((svtr_mixer_kernel<C, NT, IMG, CHUNKS, RING, MLP>), dim3((unsigned)((p.imgs + IMG - 1) / IMG * CHUNKS)), dim3(NT * IMG * 64), ldsz, st, p);
-  MRN_LAUNCH_CHECK(MLP ? "svtr_block_x3" : "svtr_mixer_x3");
+  hipLaunchKernelGGL((svtr_mixer_kernel<C, NT, IMG, CHUNKS, RING, MLP, ATTN>), dim3((unsigned)((p.imgs + IMG - 1) / IMG * CHUNKS)), dim3(NT * IMG * 64), ldsz, st, p);
+  MRN_LAUNCH_CHECK(MLP ? "svtr_block_x3" : ATTN ? "svtr_attention_block_x3" : "svtr_mixer_x3");
   return MRN_OK;
 }
 
@@ -749,4 +779,32 @@ MRN_EXPORT int mrn_svtr_block_x3_f32(const float* x, const float* pending, const
   p.w1 = (const unsigned char*)w1_hl; p.w2 = (const unsigned char*)w2_hl; p.s1 = s1; p.s2 = s2; p.bm1 = bm1; p.bm2 = bm2; p.drop2 = drop2;
   p.imgs = imgs; p.imgs_per_group = imgs_per_group; p.N = N; p.scale = scale; p.eps1 = eps1; p.eps2 = eps2;
   return dispatch_mixer<true>(p, C, (hipStream_t)stream);
+}
+
+// Attention-only form for the wide stage (C = 256, SVTR stage 3; reference modules/svtr.py:130-152 behind :200's norm1):
+//   t = x + drop_prev * pending  (written to t_out when pending is given);  ctx = attention(qkv(LayerNorm1(t)))
+// ctx_hl [imgs * N][C/32][128 B] is the HL32 operand of the (unfused) proj Linear; the residual add and LayerNorm2 follow as
+// mrn_add_layernorm_grouped_f32.  Saves the LayerNorm pass and the qkv round trip of the unfused chain.  C = 256, N <= 128,
+// imgs_per_group a multiple of 2 (N > 64) or 4 (N <= 64).  Other arguments as mrn_svtr_mixer_x3_f32.
+MRN_EXPORT int mrn_svtr_attention_block_x3_f32(const float* x, const float* pending, const float* drop_prev, const float* g1, const float* b1,
+                                               float eps1, const void* wqkv_hl, const float* sqkv, const float* bqkv, const void* mask_bits,
+                                               float scale, float* t_out, void* ctx_hl, int imgs, int imgs_per_group, int N, int C,
+                                               void* stream) {
+  MRN_CHECK_ARG(x && g1 && b1 && wqkv_hl && ctx_hl && imgs >= 0 && imgs_per_group >= 1 && (!pending || t_out),
+                "mrn_svtr_attention_block_x3_f32: bad operands");
+  MRN_CHECK_ARG((uintptr_t)wqkv_hl % 128 == 0 && (uintptr_t)ctx_hl % 128 == 0 && (uintptr_t)x % 16 == 0 && (!pending || (uintptr_t)pending % 16 == 0) &&
+                    (!t_out || (uintptr_t)t_out % 16 == 0), "mrn_svtr_attention_block_x3_f32: operands must be 128-byte (HL32) / 16-byte (fp32) aligned");
+  const bool ok = C == 256 && N >= 1 && N <= 128 && imgs_per_group % (N <= 64 ? 4 : 2) == 0;
+  if (!ok) {
+    mrn_set_error("mrn_svtr_attention_block_x3_f32: unsupported shape C=%d N=%d imgs_per_group=%d", C, N, imgs_per_group);
+    return MRN_ERR_UNSUPPORTED;
+  }
+  if (imgs == 0) return MRN_OK;
+  MixerParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = x; p.pend = pending; p.drop_prev = drop_prev; p.g1 = g1; p.b1 = b1; p.wqkv = (const unsigned char*)wqkv_hl; p.sqkv = sqkv;
+  p.bqkv = bqkv; p.mask_bits = (const unsigned*)mask_bits; p.x_out = t_out; p.y_hl = (unsigned char*)ctx_hl;
+  p.imgs = imgs; p.imgs_per_group = imgs_per_group; p.N = N; p.scale = scale; p.eps1 = eps1; p.eps2 = eps1;
+  const hipStream_t st = (hipStream_t)stream;
+  return N <= 64 ? launch_mixer<256, 2, 4, 1, 2, false, true>(p, st) : launch_mixer<256, 4, 2, 1, 2, false, true>(p, st);
 }

@@ -396,12 +396,22 @@ class BackboneGroup(_GroupedLinear):
             x, y_hl = ops.svtr_mixer_fused(x, br, dr, g1, b1, b0.norm1.eps, wq, sq, bq, mixer.mask, mixer.scale, wp, sp, bp, drop1,
                                            g2, b2, b0.norm2.eps, B)
         else:
-            t, _, y_hl = ops.add_layernorm_grouped(x, br, dr, N, g1, b1, rows, b0.norm1.eps, want_sum=br is not None)
-            x = t if t is not None else x
-            qkv = self._linear(name + ".qkv", y_hl, rows, C, [b.mixer.qkv.weight for b in blks],
-                               [b.mixer.qkv.bias for b in blks] if mixer.qkv.bias is not None else None)
-            ctx_hl = ops.svtr_attention(qkv.view(G * B, N, 3 * C), mixer.num_heads, mixer.scale, mixer.mask, want_f32=False, want_hl=True,
-                                        x3=ops.SVTR_ATTENTION_X3)
+            if mixer.num_heads * 32 == C and ops.svtr_attention_block_supported(N, C, B, mixer.mask):
+                # stage 3 (C = 256): LayerNorm1 -> qkv -> attention in one kernel, proj and the rest unfused (csrc/svtr_mixer.hip ATTN form)
+                qkvs = [b.mixer.qkv for b in blks]
+
+                def build_qkv():
+                    wq, sq = ops.pack_weights_hl32([m.weight.detach().contiguous().view(3 * C, 1, 1, C) for m in qkvs])
+                    return wq, sq, torch.stack([m.bias.detach() for m in qkvs]).contiguous() if qkvs[0].bias is not None else None
+                wq, sq, bq = self._cached(name + ".attnblk", [t_ for m in qkvs for t_ in (m.weight, m.bias) if t_ is not None], build_qkv)
+                x, ctx_hl = ops.svtr_attention_block_fused(x, br, dr, g1, b1, b0.norm1.eps, wq, sq, bq, mixer.mask, mixer.scale, B)
+            else:
+                t, _, y_hl = ops.add_layernorm_grouped(x, br, dr, N, g1, b1, rows, b0.norm1.eps, want_sum=br is not None)
+                x = t if t is not None else x
+                qkv = self._linear(name + ".qkv", y_hl, rows, C, [b.mixer.qkv.weight for b in blks],
+                                   [b.mixer.qkv.bias for b in blks] if mixer.qkv.bias is not None else None)
+                ctx_hl = ops.svtr_attention(qkv.view(G * B, N, 3 * C), mixer.num_heads, mixer.scale, mixer.mask, want_f32=False, want_hl=True,
+                                            x3=ops.SVTR_ATTENTION_X3)
             br = self._linear(name + ".proj", ctx_hl, rows, C, [b.mixer.proj.weight for b in blks], [b.mixer.proj.bias for b in blks])
             drop2 = self._drop_scales(blks, B, x.device)
             g2, b2 = self._ln_params(name + ".ln2", [b.norm2 for b in blks])

@@ -1910,6 +1910,34 @@ def svtr_block_fused(x, pending, drop_prev, g1, b1, eps1, wqkv_hl, sqkv, bqkv, m
     return x_out
 
 
+SVTR_ATTN_BLOCK = os.environ.get("MRN_SVTR_ATTN_BLOCK", "1") == "1"      # stage 3 (C = 256): LayerNorm1 -> qkv -> attention in one kernel
+
+
+def svtr_attention_block_supported(N, C, imgs_per_group, mask):
+    """shapes mrn_svtr_attention_block_x3_f32 takes (SVTR stage 3: C = 256)"""
+    if not (SVTR_FUSED_MIXER and SVTR_ATTN_BLOCK and X3_PRODUCTS == 3 and C == 256 and 16 < N <= 128 and imgs_per_group % (4 if N <= 64 else 2) == 0):
+        return False
+    return mask is None or _mask_bits(mask) is not None
+
+
+def svtr_attention_block_fused(x, pending, drop_prev, g1, b1, eps1, wqkv_hl, sqkv, bqkv, mask, scale, imgs_per_group):
+    """x [imgs, N, 256] -> (t = x + drop_prev * pending (x itself without a pending branch), HL32 bytes of attention(qkv(LayerNorm1(t)))):
+    LayerNorm1 -> qkv -> attention of a mixing block in one kernel (mrn_svtr_attention_block_x3_f32); proj and the rest stay unfused"""
+    _chk(x, pending, drop_prev, g1, b1, bqkv)
+    imgs, N, C = x.shape
+    assert x.is_contiguous() and (pending is None or (pending.is_contiguous() and pending.numel() == x.numel()))
+    t = torch.empty_like(x) if pending is not None else None
+    ctx_hl = torch.empty(x.numel() * 4, device=x.device, dtype=torch.uint8)
+    bits = _mask_bits(mask) if mask is not None else None
+    t0 = CONV_TIMER.begin() if CONV_TIMER is not None else None
+    call("mrn_svtr_attention_block_x3_f32", _p(x), _p(pending), _p(drop_prev), _p(g1), _p(b1), float(eps1), _p(wqkv_hl), _p(sqkv), _p(bqkv),
+         _p(bits), float(scale), _p(t), _p(ctx_hl), imgs, imgs_per_group, N, C, _stream())
+    if t0 is not None:
+        rows = imgs * N
+        CONV_TIMER.end(t0, 2.0 * rows * C * 3 * C + 4.0 * rows * N * C, "fp16x3/svtrattn", 4.0 * rows * C * (4 if pending is not None else 2))
+    return (t if t is not None else x), ctx_hl
+
+
 def residual_scale_rows(x, branch, scale, rows_per_group, out=None):
     """x + scale[group] * branch on [rows, C] (contiguous)"""
     assert x.is_contiguous() and branch.is_contiguous()

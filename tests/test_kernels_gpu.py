@@ -1203,6 +1203,45 @@ def test_svtr_fused_block_full_size(ops):
             assert int(bad) == 0, (C, N, int(bad))
 
 
+@pytest.mark.parametrize("N,G,B,masked,bias,with_pending", [(128, 2, 4, False, True, True), (128, 1, 2, True, True, False), (50, 2, 4, False, False, True),
+                                                          (100, 1, 6, True, True, True), (64, 1, 4, False, True, False)])
+def test_svtr_fused_attention_block_c256(ops, N, G, B, masked, bias, with_pending):
+    """mrn_svtr_attention_block_x3_f32 (stage 3, C = 256: LayerNorm1 -> qkv -> attention in one kernel, the context as the HL32 operand of
+    the proj Linear, t = x + drop * pending as the residual stream) against float64 torch and the unfused chain"""
+    from mrn_amd.modules.svtr import local_attention_mask
+    C, heads = 256, 8
+    imgs = G * B
+    x, pend = rnd(imgs, N, C, seed=1100) * 1.5, rnd(imgs, N, C, seed=1101) if with_pending else None
+    g1, b1 = rnd(G, C, seed=1102) * 0.3 + 1.0, rnd(G, C, seed=1103) * 0.2
+    wqkv = [rnd(3 * C, C, seed=1110 + g, scale=(1.0 / C) ** 0.5) * 1.5 for g in range(G)]
+    bqkv = rnd(G, 3 * C, seed=1120) * 0.3 if bias else None
+    dprev = ((torch.rand(imgs, generator=torch.Generator().manual_seed(9)) > 0.3).float() / 0.7) if with_pending else None
+    H = {128: 2, 100: 4, 50: 2, 64: 2}[N]
+    mask = local_attention_mask(H, N // H, 7, 11) if masked else None
+    t_ref = x.double() + (dprev.double()[:, None, None] * pend.double() if with_pending else 0)
+    ctx_ref = []
+    for g in range(G):
+        y = F.layer_norm(t_ref[g * B:(g + 1) * B], (C,), g1[g].double(), b1[g].double(), 1e-6)
+        qkv = y @ wqkv[g].double().t() + (bqkv[g].double() if bias else 0)
+        q, k, v = [u.reshape(B, N, heads, 32).permute(0, 2, 1, 3) for u in qkv.split(C, dim=2)]
+        s_ = (q @ k.transpose(-1, -2)) * 32 ** -0.5
+        if masked:
+            s_ = s_ + mask.double()
+        ctx_ref.append((torch.softmax(s_, -1) @ v).permute(0, 2, 1, 3).reshape(B, N, C))
+    ctx_ref = torch.cat(ctx_ref)
+    o = lambda v: cu(v) if v is not None else None
+    wq, sq = ops.pack_weights_hl32([cu(w).view(3 * C, 1, 1, C).contiguous() for w in wqkv])
+    assert ops.svtr_attention_block_supported(N, C, B, o(mask))
+    t, ctx_hl = ops.svtr_attention_block_fused(cu(x), o(pend), o(dprev), cu(g1), cu(b1), 1e-6, wq, sq, o(bqkv), o(mask), 32 ** -0.5, B)
+    assert_close("attention block: residual stream", t, t_ref.float(), atol=1e-6, rtol=1e-6)
+    assert_close("attention block: context vs float64", _hl32_to_f32(ctx_hl, imgs * N, C).view(imgs, N, C), ctx_ref.float(), atol=2e-5, rtol=1e-5)
+    # the unfused chain
+    tt, _, hl = ops.add_layernorm_grouped(cu(x), o(pend), o(dprev), N, cu(g1), cu(b1), B * N, 1e-6, want_sum=with_pending)
+    qkv, _ = ops.conv2d_x3(hl, G, False, B * N, 1, 1, C, wq, sq, 3 * C, (1, 1), bias=o(bqkv))
+    ctx2 = ops.svtr_attention(qkv.view(imgs, N, 3 * C), heads, 32 ** -0.5, o(mask), want_f32=False, want_hl=True, x3=True)
+    assert_close("attention block vs unfused chain", _hl32_to_f32(ctx_hl, imgs * N, C), _hl32_to_f32(ctx2, imgs * N, C), atol=4e-6, rtol=2e-6)
+
+
 def test_svtr_fused_mixer_full_size(ops):
     """the supported shapes (32 x 100 and 32 x 256 crops) at the headline's size (6 experts x 256 images), three launches each: every image must agree with the unfused
     chain (pins the slab ring / K-V tile barriers at full occupancy)"""
