@@ -25,6 +25,7 @@ from ._nn import _pair, packed_weight, require_no_grad, to_nhwc
 EVAL_BN_FOLD = os.environ.get("MRN_EVAL_BN_FOLD", "1") != "0"      # eval-mode BatchNorm folded into the conv epilogue (A/B switch)
 # eval-mode layers that qualify for the Winograd form run conv (F(4,3)) + a producer pass with the running-statistics affine instead of
 # the one-launch direct conv with the BatchNorm folded into its epilogue (A/B switch)
+TPS_WINO = os.environ.get("MRN_TPS_WINO", "1") == "1"          # TPS localisation network: convs 3 and 4 on the Winograd form
 EVAL_WINO = os.environ.get("MRN_EVAL_WINO", "1") != "0"
 RESIDUAL_FROM_F32 = bool(int(os.environ.get("MRN_RESIDUAL_F32", "0")))      # True: keep an fp32 copy of every identity-shortcut source (one extra 4 B/element write)
 
@@ -476,9 +477,11 @@ class BackboneGroup(_GroupedLinear):
         loc = [t.LocalizationNetwork for t in tps]
         pool = ((2, 2), (2, 2), (0, 0))
         x = Act((G, B, H, W, C), image, None, shared=True)
-        x = self.layer(x, [l.conv[0] for l in loc], [l.conv[1] for l in loc], pool=pool)
-        x = self.layer(x, [l.conv[4] for l in loc], [l.conv[5] for l in loc], pool=pool)
-        x = self.layer(x, [l.conv[8] for l in loc], [l.conv[9] for l in loc], pool=pool)
+        # (the pooling pass in front of a 3x3 conv with Cin >= 128 writes the Winograd-domain operand: conv 3 and conv 4 run as F(4,3))
+        w2, w3, w4 = (self.wino_for(loc[0].conv[i], [l.conv[i + 1] for l in loc]) if TPS_WINO else 0 for i in (4, 8, 12))
+        x = self.layer(x, [l.conv[0] for l in loc], [l.conv[1] for l in loc], pool=pool, want_wino=w2, want_hl=not w2)
+        x = self.layer(x, [l.conv[4] for l in loc], [l.conv[5] for l in loc], pool=pool, want_wino=w3, want_hl=not w3)
+        x = self.layer(x, [l.conv[8] for l in loc], [l.conv[9] for l in loc], pool=pool, want_wino=w4, want_hl=not w4)
         x = self.layer(x, [l.conv[12] for l in loc], [l.conv[13] for l in loc], want_f32=True, want_hl=False)
         out = torch.empty(G, B, tps[0].I_r_size[0], tps[0].I_r_size[1], C, device=image.device, dtype=torch.float32)
         _, _, Hl, Wl, Cl = x.shape
