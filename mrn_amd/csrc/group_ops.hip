@@ -140,11 +140,17 @@ __global__ __launch_bounds__(256) void bn_apply_grouped_kernel(const float* __re
         v.b[e] += r.b[e];
       }
     }
-    if (relu) {
+    if (relu == 1) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         v.a[e] = fmaxf(v.a[e], 0.f);
         v.b[e] = fmaxf(v.b[e], 0.f);
+      }
+    } else if (relu == 2) {   // GELU (erf), SVTR PatchEmbed (modules/svtr.py:227-233), as mrn_scale_shift_act_f32
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v.a[e] = 0.5f * v.a[e] * (1.f + erff(v.a[e] * 0.70710678118654752440f));
+        v.b[e] = 0.5f * v.b[e] * (1.f + erff(v.b[e] * 0.70710678118654752440f));
       }
     }
     if (out) store8(out + i * 8, v);

@@ -25,6 +25,7 @@ from ._nn import _pair, packed_weight, require_no_grad, to_nhwc
 EVAL_BN_FOLD = os.environ.get("MRN_EVAL_BN_FOLD", "1") != "0"      # eval-mode BatchNorm folded into the conv epilogue (A/B switch)
 # eval-mode layers that qualify for the Winograd form run conv (F(4,3)) + a producer pass with the running-statistics affine instead of
 # the one-launch direct conv with the BatchNorm folded into its epilogue (A/B switch)
+SVTR_GROUPED_EMBED = os.environ.get("MRN_SVTR_EMBED", "grouped") == "grouped"      # SVTR PatchEmbed of the frozen experts in lock-step
 TPS_WINO = os.environ.get("MRN_TPS_WINO", "1") == "1"          # TPS localisation network: convs 3 and 4 on the Winograd form
 EVAL_WINO = os.environ.get("MRN_EVAL_WINO", "1") != "0"
 RESIDUAL_FROM_F32 = bool(int(os.environ.get("MRN_RESIDUAL_F32", "0")))      # True: keep an fp32 copy of every identity-shortcut source (one extra 4 B/element write)
@@ -150,9 +151,13 @@ class BackboneGroup(_GroupedLinear):
         return torch.stack([c.bias.detach() for c in convs]).contiguous()
 
     # ---- one conv (+BN) (+residual) (+ReLU) (+pool) layer for all groups ----------------------------------------------
-    def layer(self, x, convs, bns=None, relu=True, residual=None, pool=None, want_f32=False, want_hl=True, want_wino=0):
+    def layer(self, x, convs, bns=None, relu=True, residual=None, pool=None, want_f32=False, want_hl=True, want_wino=0, gelu=False):
         """want_wino = R: the result also as the Winograd-domain operand of a following 3x3 conv (only from the BatchNorm-apply
-        pass, i.e. with bns and no pool); a layer whose INPUT carries x.wino and qualifies (wino_for) runs as F(R,3)"""
+        pass, i.e. with bns and no pool); a layer whose INPUT carries x.wino and qualifies (wino_for) runs as F(R,3).
+        gelu: BatchNorm -> GELU instead of ReLU (SVTR PatchEmbed; plain BatchNorm-apply pass only)"""
+        if gelu:
+            assert bns is not None and bns[0].training and pool is None and not want_wino and residual is None
+            relu = True
         G = self.G
         _, B, H, W, Cin = x.shape
         c0 = convs[0]
@@ -243,8 +248,8 @@ class BackboneGroup(_GroupedLinear):
             f32, hl, v = ops.bn_apply_wino_grouped(y, scale, shift, want_wino, relu=post_relu, residual=res, residual_hl=res_hl,
                                                    want_f32=want_f32, want_hl=want_hl)
             return Act((G, B, Ho, Wo, Cout), f32, hl, wino=v, wino_R=want_wino)
-        f32, hl = ops.bn_apply_grouped(y, scale, shift, relu=post_relu, residual=res, want_f32=want_f32, want_hl=want_hl,
-                                       residual_hl=res_hl)
+        f32, hl = ops.bn_apply_grouped(y, scale, shift, relu=2 if (gelu and post_relu) else post_relu, residual=res, want_f32=want_f32,
+                                       want_hl=want_hl, residual_hl=res_hl)
         return Act((G, B, Ho, Wo, Cout), f32, hl)
 
     # ---- network programs ---------------------------------------------------------------------------------------
@@ -447,10 +452,20 @@ class BackboneGroup(_GroupedLinear):
         H, W = n0.HW
         N, C = H * W, n0.embed_dim[0]
         x = torch.empty(G * B, N, C, device=image.device, dtype=torch.float32)
-        for g, n in enumerate(nets):
-            # PatchEmbed (Cin = 4 and 32: exact-fp32 convs + BatchNorm + GELU, as on the per-expert path) + position embedding
-            tok = n.patch_embed(logical)
-            ops.ew_rows(ops.EW_ADD, tok.view(B, N * C), n.pos_embed.view(1, N * C).expand(B, N * C), out=x[g * B:(g + 1) * B].view(B, N * C))
+        pes = [n.patch_embed for n in nets]
+        if SVTR_GROUPED_EMBED and all(p_.proj[1].training for p_ in pes) and C % 32 == 0 and C >= 64:
+            # PatchEmbed in lock-step: conv 1 (Cin = 4, stride 2: exact fp32 per expert into one stack) and conv 2 (Cin = 32 -> the grouped
+            # split-fp16 x3 kernel) each followed by ONE grouped BatchNorm finalise + apply-with-GELU pass
+            a = self.layer(Act((G, B, image.shape[1], image.shape[2], image.shape[3]), image, None, shared=True),
+                           [p_.proj[0] for p_ in pes], [p_.proj[1] for p_ in pes], gelu=True)
+            tok = self.layer(a, [p_.proj[3] for p_ in pes], [p_.proj[4] for p_ in pes], gelu=True, want_f32=True, want_hl=False).f32
+            for g, n in enumerate(nets):
+                ops.ew_rows(ops.EW_ADD, tok[g].view(B, N * C), n.pos_embed.view(1, N * C).expand(B, N * C), out=x[g * B:(g + 1) * B].view(B, N * C))
+        else:
+            for g, n in enumerate(nets):
+                # PatchEmbed (Cin = 4 and 32: exact-fp32 convs + BatchNorm + GELU, as on the per-expert path) + position embedding
+                tok = n.patch_embed(logical)
+                ops.ew_rows(ops.EW_ADD, tok.view(B, N * C), n.pos_embed.view(1, N * C).expand(B, N * C), out=x[g * B:(g + 1) * B].view(B, N * C))
         for si in range(3):
             blocks = [list(getattr(n, "blocks%d" % (si + 1))) for n in nets]
             pending = None

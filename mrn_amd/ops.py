@@ -866,7 +866,7 @@ def bn_apply_grouped(y, scale, shift, relu=True, residual=None, want_f32=True, w
     t0 = CONV_TIMER.begin() if CONV_TIMER is not None else None
     call("mrn_bn_apply_grouped_f32", _p(y), _p(residual), _p(residual_hl), _p(scale), _p(shift), _p(y) if want_f32 else None,
          _p(out_hl), G, rows,
-         C, int(bool(relu)), _stream())
+         C, 2 if relu == 2 else int(bool(relu)), _stream())          # (relu = 2: GELU)
     if t0 is not None:       # algorithmic bytes: every input / output element once (fp32 and HL32 are both 4 B / element)
         n_io = 1 + int(residual is not None or residual_hl is not None) + int(want_f32) + int(want_hl)
         CONV_TIMER.end(t0, 0.0, "hbm/bn_apply_grouped", 4.0 * y.numel() * n_io)
