@@ -749,6 +749,15 @@ def main():
             finally:
                 ops.X3_PRODUCTS, ops.TRAIN_PRODUCTS = saved
             torch.cuda.empty_cache()
+            # the other recogniser families of BASELINE.json's configs (2: CRNN x 3 experts, 4: SVTR), same loop B, short lines:
+            # driver-timed evidence for the kernels only they exercise (VGG stack, fused SVTR mixing blocks, CTC heads)
+            for key, model, n_exp in (("crnn3_loop_b", "crnn", 3), ("svtr6_loop_b", "svtr", 6)):
+                a2 = argparse.Namespace(**vars(args))
+                a2.model, a2.experts = model, n_exp
+                line = time_loop_b_short(a2, make_opt(model, args.batch), steps=5, warmup=4)
+                line["metric"] = f"text-line images/sec (fwd+bwd) at 32x256, {model.upper()}+MRN {n_exp} experts (not the headline)"
+                reduced[key] = line
+                torch.cuda.empty_cache()
     if rank == 0:
         if extra is not None:
             res["extra"] = {"loop_a": extra}
