@@ -166,7 +166,7 @@ __global__ __launch_bounds__(NTH) void attn_decoder_bwd_kernel(const AttnBwdPara
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           _Float16 hh, ll;
-          split_f16(v4[g], hh, ll);
+          split_f16_sat(v4[g], hh, ll);
           dg_hi[row * GLDH + g * HID + j] = hh;
           dg_lo[row * GLDH + g * HID + j] = ll;
         }
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(NTH) void attn_decoder_bwd_kernel(const AttnBwdPara
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             _Float16 hh, ll;
-            split_f16(dhp[k] * gs, hh, ll);
+            split_f16_sat(dhp[k] * gs, hh, ll);
             dhp_hi[row * HLDH + lane * 4 + k] = hh;
             dhp_lo[row * HLDH + lane * 4 + k] = ll;
           }

@@ -331,7 +331,7 @@ __global__ __launch_bounds__(NTH) void lstm_layer_bwd_x3_kernel(const float* __r
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         _Float16 hh, ll;
-        split_f16(v4[g], hh, ll);
+        split_f16_sat(v4[g], hh, ll);
         dg_hi[row * GLDH + g * HID + j] = hh;
         dg_lo[row * GLDH + g * HID + j] = ll;
       }

@@ -62,6 +62,14 @@ __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
   lo = (_Float16)(x - (float)hi);
 }
 
+// the same for range-scaled GRADIENT operands (BPTT gate gradients, scaled by a power of two from max|dout|): saturate at the
+// fp16 range instead of hi = inf, lo = -inf (NaN products) when back-propagation through time grows them past the headroom --
+// the exact-fp32 kernels give large finite gradients there, which the global-norm clip then handles
+__device__ __forceinline__ void split_f16_sat(float x, _Float16& hi, _Float16& lo) {
+  x = fminf(fmaxf(x, -65504.f), 65504.f);
+  split_f16(x, hi, lo);
+}
+
 // GELU(x) = x * Phi(x) with erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute on erf, so <= 0.75e-7 * |x| on the
 // result: below one fp32 ulp of the activations that matter): one v_rcp, one v_exp and 7 FMAs instead of the branchy ~45
 // instruction erff of the device library -- the GELU of the SVTR Mlp runs in a GEMM epilogue (64 elements per thread).

@@ -33,9 +33,9 @@ __device__ __forceinline__ void store_hl(unsigned char* out, long row, int C, in
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     _Float16 hh, ll;
-    split_f16(v.a[e], hh, ll);
-    h[e] = hh; l[e] = ll;
-    split_f16(v.b[e], hh, ll);
+    split_f16_sat(v.a[e], hh, ll);       // (saturating: an activation beyond the fp16 range -- 6.5e4 plain, 6.5e3 under B^T of F(4,3) --
+    h[e] = hh; l[e] = ll;                //  stays finite instead of hi = inf, lo = -inf -> NaN products)
+    split_f16_sat(v.b[e], hh, ll);
     h[4 + e] = hh; l[4 + e] = ll;
   }
   unsigned char* o = out + (row * (C >> 5) + (c8 >> 2)) * 128 + (c8 & 3) * 16;

@@ -23,7 +23,9 @@ __global__ __launch_bounds__(256) void sqsum_partial_kernel(const float* __restr
   if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
 
-// out[0] = total L2 norm, out[1] = clip coefficient min(1, max_norm / (norm + 1e-6))
+// out[0] = total L2 norm, out[1] = clip coefficient min(1, max_norm / (norm + 1e-6)).  A non-finite norm (an overflowed
+// gradient) makes the update kernels skip the step: torch's clip_grad_norm_ + Adam would write NaN into every parameter
+// from which no later step recovers; parameters, moments and the step count's bias correction stay as they were.
 __global__ __launch_bounds__(256) void norm_finalize_kernel(const float* __restrict__ part, int nblk, float max_norm,
                                                             float* __restrict__ out) {
   __shared__ float scratch[4];
@@ -42,6 +44,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
                                                    float* __restrict__ v, long n, const float* __restrict__ norm_coef,
                                                    float step_size, float beta1, float beta2, float bc2_sqrt, float eps) {
   const float coef = norm_coef ? norm_coef[1] : 1.f;
+  if (norm_coef && !(norm_coef[0] <= 3.0e38f)) return;      // non-finite gradient norm: the step is skipped (see norm_finalize_kernel)
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const float gi = g[i] * coef;
     g[i] = gi;                                           // clip_grad_norm_ scales .grad in place
@@ -59,6 +62,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ buf, long n,
                                                   const float* __restrict__ norm_coef, float lr, float momentum, float weight_decay) {
   const float coef = norm_coef ? norm_coef[1] : 1.f;
+  if (norm_coef && !(norm_coef[0] <= 3.0e38f)) return;      // non-finite gradient norm: the step is skipped (see norm_finalize_kernel)
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const float gc = g[i] * coef;
     g[i] = gc;
@@ -76,6 +80,7 @@ __global__ __launch_bounds__(256) void adadelta_kernel(float* __restrict__ p, fl
                                                        float* __restrict__ acc, long n, const float* __restrict__ norm_coef,
                                                        float lr, float rho, float eps) {
   const float coef = norm_coef ? norm_coef[1] : 1.f;
+  if (norm_coef && !(norm_coef[0] <= 3.0e38f)) return;      // non-finite gradient norm: the step is skipped (see norm_finalize_kernel)
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const float gc = g[i] * coef;
     g[i] = gc;

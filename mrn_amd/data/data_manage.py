@@ -185,6 +185,9 @@ class Dataset_Manager(object):
         bs = self.opt.batch_size if batch_size is None else batch_size
         gen = None
         if self.world > 1:
+            if bs % self.world:          # the global batch silently changes otherwise (truncation; max(1, ..) can even inflate it)
+                print(f"[Dataset_Manager] per-loader batch {bs} is not divisible by the {self.world} ranks: every rank draws "
+                      f"{max(1, bs // self.world)}, global batch {max(1, bs // self.world) * self.world} instead of {bs}")
             bs = max(1, bs // self.world)
             gen = torch.Generator()
             gen.manual_seed(int(getattr(self.opt, "manual_seed", 0)) + 7919 * (self.rank + 1) + 104729 * len(self.data_loader_list))

@@ -140,6 +140,7 @@ def side_param_grads(params, compute, used):
             if p is not None and g is not None:
                 p.grad.add_(g.reshape(p.grad.shape))
     ops.side_stream_keep(used)
+    ops.direct_done(params)
     return [None] * len(params)
 
 
@@ -151,6 +152,7 @@ class LinearFn(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         ctx.params = (weight, bias)
+        ops.note_param_uses(ctx.params, any(ctx.needs_input_grad))
         return ops.linear(x, weight, bias)
 
     @staticmethod
@@ -367,6 +369,7 @@ class ConvBlockFn(torch.autograd.Function):
         ctx.geom = (stride, padding, relu, precision, bn is not None, residual is not None)
         ctx.wpacked = w
         ctx.conv = conv
+        ops.note_param_uses((conv.weight,), any(ctx.needs_input_grad))
         if id(conv) not in ops.TRAINED_CONVS:
             ops.TRAINED_CONVS[id(conv)] = (weakref.ref(conv), stride, padding)
         # one max|x| pass serves the forward conv and the weight gradient (both split x with the same power-of-two scale)
@@ -443,6 +446,7 @@ class ConvBlockFn(torch.autograd.Function):
                 with torch.cuda.stream(side):
                     ops.unpack_conv_weight(weight_gradient(), out=wgrad, accumulate=True)
                 ops.side_stream_keep((dy, x, sd, ctx.x_scale))
+                ops.direct_done((ctx.conv.weight,))
             else:
                 dw = ops.unpack_conv_weight(weight_gradient())
         if ctx.needs_input_grad[0]:
@@ -593,6 +597,7 @@ class BiLSTMFn(torch.autograd.Function):
         ctx.save_for_backward(x, w_ih, w_hh_f, w_hh_r, out, gates, cseq)
         ctx.H = H
         ctx.params = (w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r)
+        ops.note_param_uses(ctx.params, any(ctx.needs_input_grad))
         return out
 
     @staticmethod
@@ -631,6 +636,7 @@ class LinearReluFn(torch.autograd.Function):
         y = ops.linear(x, weight, bias, act=ops.ACT_RELU)
         ctx.save_for_backward(x, weight, y)
         ctx.params = (weight, bias)
+        ops.note_param_uses(ctx.params, any(ctx.needs_input_grad))
         return y
 
     @staticmethod
@@ -714,6 +720,7 @@ class AttnDecoderFn(torch.autograd.Function):
         ctx.save_for_backward(batch_H, Hproj, emb, hid, i2h_w, h2h_w, score_w, w_ih, w_hh, gen_w, tok, *saves)
         ctx.dims = (Hd, D, num_class, S)
         ctx.params = (i2h_w, h2h_w, h2h_b, score_w, w_ih, w_hh, b_ih, b_hh, emb_w, gen_w, gen_b)
+        ops.note_param_uses(ctx.params, any(ctx.needs_input_grad))
         return probs
 
     @staticmethod
@@ -791,6 +798,7 @@ class TrainLinearFn(torch.autograd.Function):
         y, sw = x3_linear(x2, weight, bias, sx=sx, want_sw=True) if ctx.x3 else (ops.linear(x2, weight, bias), None)
         ctx.save_for_backward(x, weight, sx, sw)          # (sw: max|W| is the same for W^T in the data gradient)
         ctx.params = (weight, bias)
+        ops.note_param_uses(ctx.params, any(ctx.needs_input_grad))
         return y.view(*x.shape[:-1], N)
 
     @staticmethod

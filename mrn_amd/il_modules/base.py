@@ -155,12 +155,16 @@ class BaseLearner(object):
         """zero_grad, backward (gradient buckets all-reduced while it runs), clip, update, schedule.  `after_reduce`: hook that
         adds replica-independent terms to the averaged flat gradient (the EWC penalty depends on the parameters only)."""
         self.optimizer.zero_grad()
+        # parameter gradients of the trained layers: second stream, straight into the flat gradient (ops.direct_gradients); with N > 1
+        # ranks the buckets count autograd's post-accumulate hooks AND the side stream's completions (notify), so the data-parallel
+        # step runs the same schedule as the single-GPU one
         if self.reducer is not None:
             self.reducer.begin()
-            loss.backward()               # (the buckets count post-accumulate hooks: every gradient goes through autograd's accumulation)
+            with ops.direct_gradients(notify=self.reducer.param_ready):
+                loss.backward()
             self.reducer.finish()
         else:
-            with ops.direct_gradients():  # weight gradients of the trained convolutions: second stream, straight into the flat gradient
+            with ops.direct_gradients():
                 loss.backward()
         if after_reduce is not None:
             after_reduce()

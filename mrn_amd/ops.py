@@ -1563,10 +1563,12 @@ def unpack_conv_weight(g_ohwi, out=None, accumulate=False):
 # The weight gradient of a layer (two operand transposes, the K-window GEMM, the fold back to [O,I,kh,kw]) hangs off that chain.
 # With WGRAD_SIDE_STREAM it is issued on a second HIP stream and ACCUMULATED straight into the parameter's .grad (the flat gradient
 # of optim.FlatOptimizer), so its many short launches fill the tails of the chain's kernels; the backward pass's final callback
-# joins the two streams before anyone reads a gradient.  Only inside `with ops.direct_gradients():` (the learners' backward_and_step when no bucketed all-reduce counts
-# post-accumulate hooks, i.e. N = 1).
+# joins the two streams before anyone reads a gradient.  Only inside `with ops.direct_gradients():` (the learners' backward_and_step; with
+# N > 1 ranks the bucketed all-reduce is told about every completed parameter through direct_gradients(notify=...)).
 WGRAD_SIDE_STREAM = os.environ.get("MRN_WGRAD_STREAM", "1") == "1"
 GRAD_DIRECT = False                 # set by direct_gradients(): only a caller that runs loss.backward() INTO .grad may skip autograd's accumulation
+_GRAD_NOTIFY = [None]               # direct_gradients(notify=...): called with a Parameter once ALL its side-stream accumulations are issued
+_PARAM_USES = {}                    # id(Parameter) -> forward uses (by functions that may accumulate directly) not yet matched by a backward
 _SIDE_STREAMS = {}
 _SIDE_PENDING = [False]
 _SIDE_KEEP = []                     # tensors the side stream still reads, held until the join (see side_stream_keep)
@@ -1575,17 +1577,57 @@ _SIDE_KEEP = []                     # tensors the side stream still reads, held 
 class direct_gradients:
     """with ops.direct_gradients(): loss.backward() -- inside, backward functions may accumulate a parameter's gradient into its .grad
     themselves (and return None for it).  Not for torch.autograd.grad(), which wants the gradients returned: hence opt-in per call
-    (il_modules/base.py backward_and_step without a bucketed all-reduce)."""
+    (il_modules/base.py backward_and_step).  `notify(param)`: autograd's post-accumulate hooks never see such a gradient, so a bucketed
+    all-reduce (parallel.BucketedAllReduce, N > 1) passes its param_ready here; it is called when the LAST forward use of the parameter
+    has had its accumulation issued on the side stream (note_param_uses counts the uses).  On exit -- also when backward raised -- the
+    streams are joined and the references the side stream held are dropped."""
+
+    def __init__(self, notify=None):
+        self.notify = notify
 
     def __enter__(self):
         global GRAD_DIRECT
         self.prev, GRAD_DIRECT = GRAD_DIRECT, True
+        self.prev_notify, _GRAD_NOTIFY[0] = _GRAD_NOTIFY[0], self.notify
         return self
 
     def __exit__(self, *exc):
         global GRAD_DIRECT
         GRAD_DIRECT = self.prev
+        _GRAD_NOTIFY[0] = self.prev_notify
+        _PARAM_USES.clear()
+        join_side_stream()           # (normally done by the backward pass's final callback; an exception inside backward skips that)
         return False
+
+
+def note_param_uses(params, recording=True):
+    """forward of a function whose backward may accumulate these parameters' gradients on the side stream: one more use to wait for
+    before the parameter counts as complete (a recurrent conv layer applies one weight several times).  `recording`: the call is
+    being recorded by autograd (any(ctx.needs_input_grad); grad mode itself is off inside a Function's forward)"""
+    if recording:
+        for p in params:
+            if p is not None and p.requires_grad:
+                _PARAM_USES[id(p)] = _PARAM_USES.get(id(p), 0) + 1
+
+
+DIRECT_STATS = {"parameters": 0}    # side-stream accumulations issued (tests / bench telemetry)
+
+
+def direct_done(params):
+    """the side-stream accumulation of one use of each of `params` has been issued"""
+    notify = _GRAD_NOTIFY[0]
+    for p in params:
+        if p is None:
+            continue
+        DIRECT_STATS["parameters"] += 1
+        n = _PARAM_USES.get(id(p), 1) - 1
+        _PARAM_USES[id(p)] = n
+        if n == 0 and notify is not None:
+            notify(p)
+
+
+def side_stream_pending():
+    return _SIDE_PENDING[0]
 
 
 def side_stream():
@@ -1650,10 +1692,13 @@ def bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres=False, range_target=No
 
 def maxpool_bwd(dy, x, kernel, stride, padding):
     B, H, W, C = x.shape
-    x = x.contiguous()
-    writes_all = call("mrn_maxpool_bwd_writes_all", H, W, C, kernel[0], kernel[1], stride[0], stride[1], padding[0], padding[1])
-    dx = torch.empty_like(x) if writes_all else torch.zeros_like(x)      # (non-overlapping windows: the kernel writes every element)
-    call("mrn_maxpool_bwd_nhwc_f32", _p(dy.contiguous()), _p(x), _p(dx), B, H, W, C, kernel[0], kernel[1], stride[0], stride[1],
+    x, dy = x.contiguous(), dy.contiguous()
+    # non-overlapping windows: the kernel writes every element of dx -- but only its 16-byte-aligned form does (an offset view falls
+    # back to the accumulating kernel, which needs zeros): the pointers are part of the decision
+    writes_all = (call("mrn_maxpool_bwd_writes_all", H, W, C, kernel[0], kernel[1], stride[0], stride[1], padding[0], padding[1])
+                  and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0)
+    dx = torch.empty_like(x) if writes_all else torch.zeros_like(x)
+    call("mrn_maxpool_bwd_nhwc_f32", _p(dy), _p(x), _p(dx), B, H, W, C, kernel[0], kernel[1], stride[0], stride[1],
          padding[0], padding[1], _stream())
     return dx
 

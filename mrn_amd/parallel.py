@@ -228,6 +228,7 @@ class BucketedAllReduce:
         for b in self.bucket_of:
             self.sizes[b] += 1
         self.active = False
+        self.index_of = {id(p): i for i, p in enumerate(optimizer.params)}
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(optimizer.params)]
         self.launched_log = []     # bucket indices in launch order of the last step (tests)
         self.record = False        # bench.py telemetry: HIP events around the part of finish() the compute stream has to wait for
@@ -248,6 +249,14 @@ class BucketedAllReduce:
                 self._launch_ready()
         return hook
 
+    def param_ready(self, param):
+        """ops.direct_gradients(notify=...): a parameter whose gradient never passes autograd's accumulation -- it is ADDED into the
+        flat gradient on the side stream (functional.side_param_grads, ConvBlockFn.backward) -- has had its last accumulation issued"""
+        i = self.index_of.get(id(param))
+        if self.active and i is not None:
+            self.pending[self.bucket_of[i]] -= 1
+            self._launch_ready()
+
     def begin(self):
         self.pending = list(self.sizes)
         self.next = 0
@@ -257,7 +266,19 @@ class BucketedAllReduce:
 
     def _launch(self, b):
         lo, hi = self.buckets[b]
-        self.handles.append(_avg_inplace(self.opt.grad[lo:hi], async_op=True))
+        side = None
+        if self.opt.grad.is_cuda:
+            from . import ops
+            if ops.side_stream_pending():
+                side = ops.side_stream()
+        if side is None:
+            self.handles.append(_avg_inplace(self.opt.grad[lo:hi], async_op=True))
+        else:
+            # part of this bucket was accumulated on the side stream: issue the collective from there, behind those kernels AND
+            # behind what the main stream has produced so far (the collective is ordered after the stream it is launched from)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self.handles.append(_avg_inplace(self.opt.grad[lo:hi], async_op=True))
         self.launched_log.append(b)
 
     def _launch_ready(self):

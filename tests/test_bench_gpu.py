@@ -43,10 +43,10 @@ def test_bench_single_process_line():
 
 def test_bench_two_ranks_control_flow():
     _fresh_process_only()
-    env = dict(os.environ, MRN_DIST_BACKEND="gloo", MRN_SHARE_DEVICE="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", "bench.py", "--gpus", "2", "--model", "crnn", "--experts", "3", "--batch", "16", "--steps", "2",
-           "--warmup", "1"]
+    # the DRIVER's command: bare `python bench.py --gpus 2 ...`, no launcher -- bench.py starts its own ranks as child processes
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(MRN_DIST_BACKEND="gloo", MRN_SHARE_DEVICE="1")
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--model", "crnn", "--experts", "3", "--batch", "16", "--steps", "2", "--warmup", "1"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)     # (a timeout FAILS the test)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     d = _last_json(r.stdout)
@@ -59,6 +59,15 @@ def test_bench_two_ranks_control_flow():
         assert c["allreduce_bytes_per_step"] > 0 and c["buckets"] >= 1 and c["allreduce_ms_per_step"] > 0
         assert c["exposed_ms_per_step"] >= 0 and 0.0 <= c["overlap_frac"] <= 1.0
     assert d["comm"]["allreduce_bytes_per_step"] < d["extra"]["loop_a"]["comm"]["allreduce_bytes_per_step"]     # router only vs a whole expert
+    # N > 1 runs the single-GPU schedule: parameter gradients on the side stream, the buckets told through direct_gradients(notify=)
+    assert d["extra"]["loop_a"]["comm"]["side_stream_parameters_per_step"] > 0
+
+
+def test_bench_refuses_a_mismatched_world():
+    """under a launcher (RANK set) --gpus must equal WORLD_SIZE; nothing touches the GPU before the check"""
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stdout + r.stderr)
 
 
 DP_WORKER = r"""
@@ -113,6 +122,56 @@ parallel.barrier()
 assert os.path.exists(path) == True
 open(os.path.join(os.environ["MRN_OUT"], f"dp_ok_{rank}"), "w").write("ok")
 """
+
+
+DP_LOOP_A_WORKER = r"""
+import os, sys, torch
+sys.path.insert(0, os.environ["MRN_ROOT"])
+import bench
+from mrn_amd import ops, parallel
+from mrn_amd.data.synthetic import SyntheticTextLines
+rank, world, local = parallel.init_distributed()
+torch.cuda.set_device(0)
+torch.manual_seed(7 + 31 * rank)                    # replicas are BUILT differently: the broadcasts must equalise them
+model = os.environ["MRN_MODEL"]
+opt = bench.make_opt(model, 8)
+learner = bench.build_loop_a_learner(opt)
+assert learner.reducer is not None and ops.WGRAD_SIDE_STREAM
+data = SyntheticTextLines(opt, seed=50 + rank)      # every rank its own shard
+data.set_characters(learner.character)
+n_params = len(learner.optimizer.params)
+for it in range(3):
+    before = ops.DIRECT_STATS["parameters"]
+    learner.train_step(*data.get_batch())
+    side = ops.DIRECT_STATS["parameters"] - before
+    # the side stream carried (nearly) every parameter gradient, and every bucket was still launched exactly once, in order
+    assert side >= 0.8 * n_params, (side, n_params)
+    assert learner.reducer.launched_log == list(range(len(learner.reducer.buckets))), learner.reducer.launched_log
+torch.cuda.synchronize()
+flat = learner.optimizer.flat.detach().cpu()
+assert torch.isfinite(flat).all()
+both = [torch.zeros_like(flat) for _ in range(world)]
+torch.distributed.all_gather(both, flat)
+assert torch.equal(both[0], both[1]), "trained parameters differ between the ranks after three loop-A steps"
+open(os.path.join(os.environ["MRN_OUT"], f"dpa_ok_{rank}"), "w").write("ok")
+"""
+
+
+@pytest.mark.parametrize("model", ["crnn", "trba", "svtr"])
+def test_two_ranks_loop_a_side_stream_identical_parameters(tmp_path, model):
+    """loop A under data parallelism keeps the single-GPU schedule: parameter gradients are accumulated on the
+    side stream and the bucketed all-reduce is told through direct_gradients(notify=); after three steps on different shards the
+    two ranks' flat parameter buffers are bit-identical (reference: DataParallel at il_modules/base.py:68)"""
+    _fresh_process_only()
+    script = tmp_path / "dp_loop_a_worker.py"
+    script.write_text(DP_LOOP_A_WORKER)
+    env = dict(os.environ, MRN_ROOT=ROOT, MRN_OUT=str(tmp_path), MRN_DIST_BACKEND="gloo", MRN_SHARE_DEVICE="1", MRN_MODEL=model,
+               MRN_BUCKET_MB="4")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(29561 + ["crnn", "trba", "svtr"].index(model)), str(script)], cwd=tmp_path,
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert (tmp_path / "dpa_ok_0").exists() and (tmp_path / "dpa_ok_1").exists()
 
 
 def test_two_ranks_routing_steps_identical_parameters(tmp_path):

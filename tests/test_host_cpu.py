@@ -176,6 +176,49 @@ for step in range(2):
     torch.distributed.all_gather(both, mine)
     assert torch.allclose(g, (both[0] + both[1]) / 2, atol=1e-7)
     assert float(opt.view_of(g, [i for i, q in enumerate(opt.params) if q is unused][0]).abs().max()) == 0.0   # unused parameter: zeros travel
+# direct accumulation (ops.direct_gradients(notify=red.param_ready)): a backward function ADDS the weight gradients of the Linear layers
+# into .grad itself and returns None, so no post-accumulate hook fires for them -- the reducer is told through the notify callback,
+# once per parameter after its LAST use (the last Linear is applied twice: a recurrent layer's weight)
+from mrn_amd import ops
+class DirectLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.params = (w, b)
+        ops.note_param_uses(ctx.params, any(ctx.needs_input_grad))
+        return x @ w.t() + b
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        assert ops.GRAD_DIRECT
+        ctx.params[0].grad.add_(dy.t() @ x)
+        ops.direct_done((ctx.params[0],))
+        return dy @ w, None, dy.sum(0)                 # (the bias goes through autograd: hooks and notifications mix inside a bucket)
+def forward(x):
+    h = torch.relu(net[1](DirectLinear.apply(x, net[0].weight, net[0].bias)))
+    h = torch.relu(DirectLinear.apply(h, net[3].weight, net[3].bias))
+    h = torch.relu(DirectLinear.apply(h, net[3].weight, net[3].bias))        # the same weight again
+    return DirectLinear.apply(h, net[5].weight, net[5].bias)
+for step in range(2):
+    torch.manual_seed(70 + 10 * step + rank)
+    x, y = torch.randn(16, 40), torch.randn(16, 7)
+    opt.zero_grad()
+    red.begin()
+    with ops.direct_gradients(notify=red.param_ready):
+        ((forward(x) - y) ** 2).mean().backward()
+    assert not ops._PARAM_USES and ops._GRAD_NOTIFY[0] is None
+    # every bucket but the one holding the never-used parameter completed DURING backward
+    assert red.next >= len(red.buckets) - 1, (red.next, len(red.buckets))
+    red.finish()
+    assert red.launched_log == list(range(len(red.buckets))), red.launched_log
+    g = opt.grad.clone()
+    opt.zero_grad()
+    with ops.direct_gradients():
+        ((forward(x) - y) ** 2).mean().backward()
+    mine = opt.grad.clone()
+    both = [torch.zeros_like(mine) for _ in range(2)]
+    torch.distributed.all_gather(both, mine)
+    assert torch.allclose(g, (both[0] + both[1]) / 2, atol=1e-7), (g - (both[0] + both[1]) / 2).abs().max()
 parallel.barrier()
 open(os.path.join(os.environ["MRN_OUT"], f"bok_{rank}"), "w").write("ok")
 """

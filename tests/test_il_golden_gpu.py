@@ -59,6 +59,30 @@ def record(learner, name, out):
     setattr(learner, name, wrapped)
 
 
+_F64 = {}
+MOVEMENT_FACTOR, MOVEMENT_FLOOR = 2.0, 5e-3
+
+
+def _assert_movement(kind, name, k, mine, ref32):
+    """parameter movement of a task's optimiser steps (1024-element subsample).  CRNN: within 10 % relative L2 of the reference's
+    fp32 run.  TRBA: the float64 yardstick -- tests/golden/il_trba_f64.npz holds the SAME reference flow run in float64 arithmetic
+    (make_golden_il_f64.py); the reference's own fp32 run is 12-35 % (relative L2) away from it on the ResNet / TPS tensors (Adam turns
+    fp32 round-off of near-zero gradients into +-lr steps) and 5e-5 ... 5e-3 on the recurrent / head tensors, and the HIP movement
+    must be as close to the float64 run as MOVEMENT_FACTOR x the reference's fp32 run is (floor MOVEMENT_FLOOR)."""
+    if kind != "trba":
+        l2 = np.linalg.norm(mine - ref32) / max(np.linalg.norm(ref32), 1e-30)
+        assert l2 <= 0.1, (k, l2)
+        return
+    if not _F64:
+        _F64.update(load_golden("il_trba_f64"))
+    r64 = _F64[name].astype(np.float64)
+    n64 = max(np.linalg.norm(r64), 1e-30)
+    e_ref = np.linalg.norm(ref32 - r64) / n64
+    e_hip = np.linalg.norm(mine - r64) / n64
+    print(f"movement {name}: HIP vs f64 {e_hip:.3e}, reference fp32 vs f64 {e_ref:.3e}")
+    assert e_hip <= max(MOVEMENT_FACTOR * e_ref, MOVEMENT_FLOOR), f"{name}: HIP vs f64 {e_hip:.3e}, reference fp32 vs f64 {e_ref:.3e}"
+
+
 def rel_close(a, b, rtol):
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     assert a.shape == b.shape, (a.shape, b.shape)
@@ -68,6 +92,22 @@ def rel_close(a, b, rtol):
 @pytest.mark.parametrize("kind", ["crnn", "trba"])
 @pytest.mark.parametrize("which", ["lwf", "ewc", "der"])
 def test_il_flow_vs_reference(tmp_path, kind, which):
+    _il_flow(tmp_path, kind, which)
+
+
+def test_il_flow_crnn_ewc_direct_products(tmp_path):
+    """the same EWC flow with the trained convolutions on the DIRECT split-fp16 x3 products (MRN_TRAIN_WINO=0): the Fisher diagonal
+    after two Adam steps keeps the 2 % band; the Winograd form of the trained convolutions (the default, above) is held to 4 %"""
+    from mrn_amd import ops
+    saved = (ops.TRAIN_WINO, ops.TRAIN_OPERAND_PEAK)
+    ops.TRAIN_WINO, ops.TRAIN_OPERAND_PEAK = False, 16384.0
+    try:
+        _il_flow(tmp_path, "crnn", "ewc", crnn_fisher_tol=0.02)
+    finally:
+        ops.TRAIN_WINO, ops.TRAIN_OPERAND_PEAK = saved
+
+
+def _il_flow(tmp_path, kind, which, crnn_fisher_tol=0.04):
     """Two tasks of LwF / EWC / DER driven through incremental_train() / after_task() exactly like the reference learners
     were when the fixture was generated: per-iteration losses, KD terms, Fisher diagonals (incl. the positional blend of
     task 1), the reference's identically-zero EWC penalty, weight_align gamma, parameter movement, checkpoints written."""
@@ -133,8 +173,7 @@ def test_il_flow_vs_reference(tmp_path, kind, which):
                 r = g[name + "/sub"].astype(np.float64)
                 # Adam normalises every element's update to ~lr, so elements whose gradient is ~0 move with an essentially
                 # random sign (fp32 conditioning, see tests/helpers.py::assert_sub_l2): compare in L2 terms
-                l2 = np.linalg.norm(s - r) / max(np.linalg.norm(r), 1e-30)
-                assert l2 <= (0.5 if kind == "trba" else 0.1), (k, l2)
+                _assert_movement(kind, f"{pre}t{taski}/delta/{k}/sub", k, s, r)
             if which == "ewc":
                 fk = [str(s) for s in g[f"{pre}t{taski}/fisher_keys"]]
                 assert list(learner.fisher.keys()) == fk
@@ -156,7 +195,7 @@ def test_il_flow_vs_reference(tmp_path, kind, which):
                     # sign-normalised updates amplify product-level differences (below 2 % with the direct x3 products, 2.6 % with the
                     # Winograd form of the trained convolutions; the step-free gradients stay within 2e-3 of the oracle,
                     # test_loop_a_crnn_gradients_vs_oracle, the step-free Fisher within 1 %, test_fisher_diagonal_vs_reference)
-                    assert l2 <= (0.6 if loose else 0.15 if kind == "trba" else 0.04), (k, l2)
+                    assert l2 <= (0.6 if loose else 0.15 if kind == "trba" else crnn_fisher_tol), (k, l2)
             learner.after_task()
             assert learner._known_classes == int(g[f"{pre}t{taski}/known_classes"])
             if which == "lwf" and taski == 0:
@@ -337,8 +376,7 @@ def _check_movement(g, pre, taski, learner, seeds, kind):
         step_ = max(1, moved.size // 1024)
         s = moved[::step_][:1024]
         r = g[f"{pre}t{taski}/delta/{k}/sub"].astype(np.float64)
-        l2 = np.linalg.norm(s - r) / max(np.linalg.norm(r), 1e-30)       # (relative L2: see test_il_flow_vs_reference)
-        assert l2 <= (0.5 if kind == "trba" else 0.1), (k, l2)
+        _assert_movement(kind, f"{pre}t{taski}/delta/{k}/sub", k, s, r)
 
 
 @pytest.mark.parametrize("kind", ["crnn", "trba"])

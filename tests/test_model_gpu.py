@@ -584,15 +584,18 @@ def _oracle_trba_grads(g, image, labels_index, dtype):
     return names, grads, out.detach(), loss.detach()
 
 
-def test_loop_a_trba_gradients_vs_oracle():
+@pytest.mark.parametrize("B,factor,floor", [(3, 3.0, 2e-3), (32, 2.0, 1e-3)])
+def test_loop_a_trba_gradients_vs_oracle(B, factor, floor):
     """loop A on a TRBA expert (TPS + ResNet + BiLSTM + attention decoder): every parameter gradient of loss.backward().
+    B = 32 is BASELINE config 1's batch: BatchNorm statistics over 32 x H x W samples are well conditioned there, so the band is the
+    tighter max(2 x the reference's own fp32-vs-f64 error, 1e-3) per tensor.
 
     This 29-conv / small-batch-BatchNorm case is ill-conditioned in fp32: the oracle's own float32 gradients differ
     from its float64 gradients by ~2.5e-2 (median over parameters).  The HIP gradients are therefore judged against the
     float64 oracle and must be at least as close to it as 3x the reference's own fp32 arithmetic (the recurrent /
     decoder parameters, which are well conditioned, land at 1e-5..3e-4)."""
     from mrn_amd import functional as Fn
-    kind, classes, B, seed = "trba", (41,), 3, 6
+    kind, classes, seed = "trba", (41,), 6
     g = load_golden("trba_mrn3")
     opt, net = build_net(kind, (41, 71, 98), g, 2)
     image, words, chars, _ = det_inputs(kind, classes, B, seed)
@@ -619,7 +622,7 @@ def test_loop_a_trba_gradients_vs_oracle():
         ref64 = a64.numpy()
         e_ref = rel(a32.double().numpy(), ref64)
         e_hip = rel(mine[n].grad.detach().cpu().double().numpy(), ref64)
-        assert e_hip <= max(3.0 * e_ref, 2e-3), f"{n}: HIP vs f64 {e_hip:.2e}, torch-f32 vs f64 {e_ref:.2e}"
+        assert e_hip <= max(factor * e_ref, floor), f"{n}: HIP vs f64 {e_hip:.2e}, torch-f32 vs f64 {e_ref:.2e}"
 
 
 @pytest.mark.parametrize("kind,B", [("trba", 3), ("crnn", 3), ("svtr", 3), ("svtr", 24)])
@@ -1146,17 +1149,21 @@ def test_rcnn_extractor_vs_reference():
     assert np.array_equal(oe["predict"].max(2)[1].cpu().numpy(), g["eval/argmax"])
 
 
-@pytest.mark.parametrize("arch", ["crnn", "svtr"])
+@pytest.mark.parametrize("arch", ["crnn", "svtr", "trba"])
 def test_full_size_loop_a_directional_derivative(arch):
     """Loop A at BASELINE size (one expert, 256 crops, 2090 classes): a size-independent property of loss.backward() -- along the
     normalised gradient direction d = g / |g| the central difference (L(theta + eps d) - L(theta - eps d)) / (2 eps) equals |g|.
     Ties the whole backward (conv dgrad / weight gradient without im2col, BatchNorm, pooling, BiLSTM BPTT or SVTR attention, CTC) to
-    the forward at the size the bench runs.  Eval-free: BatchNorm in train mode on the same batch for all three evaluations."""
+    the forward at the size the bench runs.  Eval-free: BatchNorm in train mode on the same batch for all three evaluations.
+    TRBA (the north-star family: TPS sampler, Winograd forward / data / weight gradients of the ResNet, x3 BPTT, the attention
+    decoder's backward at 4 samples per workgroup, side-stream parameter gradients) runs it with the CE loss of the Attn head on a
+    fixed teacher-forcing text."""
     from mrn_amd import functional as Fn
+    from mrn_amd import ops
     from mrn_amd.modules.model import Model
     from mrn_amd.tools import weights as W
     opt = make_opt(arch)
-    C, B = 2090, 256
+    C, B = (2091 if arch == "trba" else 2090), 256
     with contextlib.redirect_stdout(io.StringIO()):
         net = Model(opt)
         net.update_fc(opt.hidden_size, C)
@@ -1173,13 +1180,26 @@ def test_full_size_loop_a_directional_derivative(arch):
     lengths = torch.from_numpy(W.randint("fullA_len", (B,), 1, 26, 5)).int().cuda()
     bn_state = {k: v.clone() for k, v in net.state_dict().items() if "running_" in k or "num_batches" in k}
 
+    if arch == "trba":                                 # [SOS] text [EOS] [PAD]...: AttnLabelConverter.encode's layout (tools/utils.py)
+        ln = lengths.long().clamp(max=25)
+        pos = torch.arange(27, device="cuda")[None, :]
+        index = torch.cat([torch.full((B, 1), 2, device="cuda"), labels.long().clamp(min=5), torch.ones(B, 1, dtype=torch.long, device="cuda")], 1)
+        index = torch.where(pos == ln[:, None] + 1, torch.full_like(index, 3), index)
+        index = torch.where(pos > ln[:, None] + 1, torch.ones_like(index), index)
+
     def loss_at():
         net.load_state_dict(bn_state, strict=False)
+        if arch == "trba":
+            return Fn.cross_entropy(net(image, index[:, :-1], True)["predict"], index[:, 1:], 1)
         return Fn.ctc_loss(net(image, None, True)["predict"], labels, lengths)
 
     params = [p for p in net.parameters() if p.requires_grad]
+    from mrn_amd.optim import FlatAdam
+    fo = FlatAdam(params, lr=1e-3)                     # the learners' flat parameter / gradient buffers (the side stream adds into .grad)
+    fo.zero_grad()
     loss = loss_at()
-    loss.backward()
+    with ops.direct_gradients():                       # (the learners' backward_and_step: parameter gradients on the side stream)
+        loss.backward()
     grads = [p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p) for p in params]
     gnorm = float(torch.sqrt(sum((g.double() ** 2).sum() for g in grads)))
     assert np.isfinite(gnorm) and gnorm > 0
