@@ -303,13 +303,14 @@ def describe_kernel(kind):
         return (f"conv_x3_kernel<{targs}{', false, 1' if nprod == 1 else ''}> (grouped {tile}x32 implicit-GEMM conv / Linear over "
                 f"all experts, {arith} on v_mfma_f32_32x32x16_f16, HL32 operands staged by buffer_load...lds)",
                 BF16_MFMA_PEAK_TFLOPS, nprod)
-    nsplit = 3 if arith.endswith("x3") else 1
-    kern = "conv_bf16_dma_kernel" if staging == "dma" else "conv_bf16_kernel"
-    half = "true" if arith.startswith("fp16") else "false"
-    inst = "v_mfma_f32_32x32x16_f16" if arith.startswith("fp16") else "v_mfma_f32_32x32x16_bf16"
-    return (f"{kern}<{nsplit},{half}> (128x128x32 implicit-GEMM conv, {arith} on {inst}, "
-            f"{'pre-split operands staged by global_load_lds' if staging == 'dma' else 'activation split in registers'})",
-            BF16_MFMA_PEAK_TFLOPS, nsplit)
+    svtr = {"svtrmlp": "svtr_mlp_kernel (fc1 -> GELU -> fc2 of an SVTR mixing block over all experts, hidden activation in registers)",
+            "svtrmixer": "svtr_mixer_kernel (LayerNorm1 -> qkv -> local / global attention -> proj -> residual -> LayerNorm2 of an SVTR mixing "
+                         "block over all experts, chained MFMAs, K / V through LDS)",
+            "svtrattn": "svtr_mixer_kernel<256, ..., ATTN> (stage 3: LayerNorm1 -> qkv -> attention, context out as the proj operand)",
+            "svtrblock3": "svtr_tail_kernel<256> (stage 3: proj -> residual -> LayerNorm2 -> fc1 -> GELU -> fc2 -> residual)"}
+    if staging in svtr:
+        return (svtr[staging] + f", {arith} on v_mfma_f32_32x32x16_f16", BF16_MFMA_PEAK_TFLOPS, 3)
+    raise ValueError(f"unknown KernelTimer kind {kind!r}")
 
 
 def roofline_entries(kinds, steps, elapsed_s):
@@ -580,11 +581,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--verbose", action="store_true")
-    ap.add_argument("--precision", default="auto", choices=["auto", "f32", "fp16x3", "bf16x3", "fp16"],
+    ap.add_argument("--precision", default="auto", choices=["auto", "f32", "fp16x3", "fp16"],
                     help="arithmetic of the frozen experts' convolutions / Linear layers: auto = split-fp16 x3 (22-bit products, keeps "
                          "the 1e-4 parity band: the headline); fp16 = ONE fp16 product per term on the same grouped kernels (the "
-                         "reduced-precision mode of BASELINE configs 2 and 5: a separate line, never the headline); f32 / bf16x3: "
-                         "the per-expert kernels (mrn_amd/ops.py: CONV_PRECISION)")
+                         "reduced-precision mode of BASELINE configs 2 and 5: a separate line, never the headline); f32: "
+                         "the per-expert exact-fp32 MFMA kernel (mrn_amd/ops.py: CONV_PRECISION)")
     ap.add_argument("--no-streams", action="store_true", help="run the experts sequentially on one stream")
     ap.add_argument("--no-pipeline", action="store_true", help="do not issue batch n+1's expert forward before batch n's router phase")
     ap.add_argument("--serial", action="store_true", help="one lock-step group on one stream, no look-ahead (every kernel runs alone)")
@@ -718,8 +719,7 @@ def main():
             "dtype": "fp16 (one fp16 MFMA product per term, fp32 accumulate and fp32 storage: reduced-precision mode, NOT the headline)"
             if ops.X3_PRODUCTS == 1 else
             {"auto": "f32 (convs with Cout>64 as split-fp16 x3 MFMA products, 22-bit significand, fp32 accumulate)",
-             "f32": "f32", "fp16x3": "fp16x3 (split-fp16 MFMA, fp32 accumulate)",
-             "bf16x3": "bf16x3 (split-bf16 MFMA, fp32 accumulate)"}[ops.CONV_PRECISION],
+             "f32": "f32", "fp16x3": "fp16x3 (split-fp16 MFMA, fp32 accumulate)"}[ops.CONV_PRECISION],
             "data": "synthetic",
             "config": {"workload": f"MRN loop B (router phase): {args.model.upper()} x {args.experts} frozen experts "
                                    f"(train-mode BN) + DM-Router fwd/bwd + clip + Adam, 32x256x4 crops, random-init weights",

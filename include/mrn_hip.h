@@ -52,32 +52,13 @@ int mrn_conv2d_nhwc_f32(const float* x, const float* w_ohwi, const float* bias, 
                         int act, void* stream);
 int64_t mrn_conv2d_stats_floats(int B, int Ho, int Wo, int Cout);
 
-/* The same convolution on the bf16 MFMA pipe with split operands: every fp32 operand is x = hi + lo (two bf16),
- * product = hi*hi + hi*lo + lo*hi, fp32 accumulate (nsplit 3: fp32-class accuracy, inside the 1e-4 parity band);
- * nsplit 1 keeps hi*hi only (plain bf16 operands).  w_hi / w_lo: bf16 [Cout][kh*kw*Cin] from mrn_split_weight_bf16.
- * Requires Cin % 4 == 0 and (kh*kw*Cin) % 32 == 0. */
-int mrn_conv2d_nhwc_bf16split(const float* x, const void* w_hi, const void* w_lo, const float* bias, float* y,
-                              float* stats, int B, int H, int W, int Cin, int Cout, int kh, int kw, int sh, int sw,
-                              int ph, int pw, int act, int nsplit, int half, const float* out_scale, void* stream);
-/* half = 1 selects fp16 halves (v_mfma_f32_32x32x16_f16): hi + lo then carries 22 significand bits and each product
- * is good to ~2^-22 (fp32-rounding class).  The weight planes are then built with a power-of-two prescale
- * (mrn_pow2_scale_f32 -> device float[2] = {scale, 1/scale}; pass it to mrn_split_weight_bf16) and the same array
- * is passed as out_scale so the epilogue multiplies by 1/scale.  out_scale may be NULL (no scaling). */
-/* workspace: two 32-bit device words zeroed ONCE by the caller; every call on the same stream may reuse them (the kernel's last
- * block restores the zeros): running maximum + arrival ticket of the single launch */
+/* Power-of-two range scale of a split-fp16 operand: scale = device float[2] = {s, 1/s}, s the largest power of two with
+ * s * max|w| <= target (weights of the frozen experts: target 2^14; both operands of a trained layer per call).  Computed on the
+ * device, no host synchronisation.  workspace: two 32-bit device words owned by the calling stream. */
 int mrn_pow2_scale_f32(const float* w, int64_t n, float target, float* scale, void* workspace, void* stream);
 /* the same scale from maxima a producer pass already folded into `workspace` (amax_ws of mrn_scale_shift_act_f32 /
  * mrn_bn_bwd_apply_f32: 64 32-bit words zeroed once, slot = block % 64): saves the extra read of the tensor; the words are put back to zero */
 int mrn_pow2_finalize_f32(float target, float* scale, void* workspace, void* stream);
-/* Same product with the ACTIVATION pre-split too (x_hi / x_lo: bf16 NHWC planes from mrn_split_weight_bf16 on the fp32
- * tensor) and both operands staged by direct-to-LDS DMA (no staging registers, no conversion in the GEMM loop).
- * zero_page: >= 64 bytes of device zeros (source of padded taps).  Requires Cin % 8 == 0, (kh*kw*Cin) % 32 == 0. */
-int mrn_conv2d_nhwc_bf16split_dma(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo,
-                                  const void* zero_page, const float* bias, float* y, float* stats, int B, int H, int W,
-                                  int Cin, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int act, int nsplit,
-                                  int half, const float* out_scale, void* stream);
-/* fp32 [n] -> 16-bit hi[n], lo[n] with hi = r16(s x), lo = r16(s x - hi); half = 0 bf16, 1 fp16; s = scale[0] or 1 */
-int mrn_split_weight_bf16(const float* w, void* hi, void* lo, int64_t n, int half, const float* scale, void* stream);
 
 /* Grouped split-fp16 x3 convolution on 256-wide tiles (the router phase runs the G frozen experts' backbones in
  * lock-step: il_modules/mrn.py:323-337 calls every expert on the same batch; modules/model.py:399-401).
@@ -311,26 +292,6 @@ int mrn_lstm_layer_fwd_x3_grouped(const void* const* xproj, const void* const* w
  * (gates_out [B][T][ndir][4H] post-activation gates, c_out [B][T][ndir][H]). */
 int mrn_lstm_layer_fwd_x3_save(const float* xproj, const void* w_hh, const float* w_inv, const float* b_hh, float* out,
                                float* gates_out, float* c_out, int B, int T, int hidden, int ndir, void* stream);
-/* The same layers as ONE SMALL KERNEL PER TIME STEP replayed from a HIP graph (csrc/lstm_steps.hip): a step is a grid over (expert,
- * direction, 128-sample tile, 32-unit tile), so all CUs pull W_hh at once instead of one CU per 16 samples streaming all of it; the
- * step kernels read their buffer pointers from a device-side argument block, so one instantiated graph per (stream, T, grid) serves
- * every call.  w_hl[g]: [ndir][4H][H/32][128 B] = mrn_pack_weight_hl32 of W_hh [4H][1][H] per direction, w_inv[g]: device float[ndir];
- * workspace: mrn_lstm_steps_workspace_bytes bytes (h ping-pong planes + cell state), 128-byte aligned, no initialisation needed.
- * groups <= 8, hidden == 256.  Same arithmetic as mrn_lstm_layer_fwd_x3_grouped. */
-int64_t mrn_lstm_steps_workspace_bytes(int groups, int B, int ndir);
-int mrn_lstm_layer_fwd_x3_steps(const void* const* xproj, const void* const* w_hl, const void* const* w_inv,
-                                const void* const* b_hh, const void* const* out, int groups, int B, int T, int hidden, int ndir,
-                                void* workspace, int64_t workspace_bytes, void* stream);
-/* Weight-stationary form of mrn_lstm_layer_fwd_x3_grouped (same operands, bit-identical results): every (expert, direction) is
- * spread over 16 workgroups that keep their 64 KiB slice of W_hh in LDS for the whole sequence and exchange h through
- * `workspace` (mrn_lstm_cluster_workspace_bytes) once per step.  All mrn_lstm_cluster_workgroups(groups, B, ndir) workgroups of a
- * launch must be co-resident (<= 256; keep concurrent launches within the chip): they wait on each other, with bounded spins --
- * a workgroup whose peers never arrive writes NaN into its last output row instead of hanging. */
-int64_t mrn_lstm_cluster_workspace_bytes(int groups, int B, int ndir);
-int64_t mrn_lstm_cluster_workgroups(int groups, int B, int ndir);
-int mrn_lstm_layer_fwd_x3_cluster(const void* const* xproj, const void* const* w_hh, const void* const* w_inv,
-                                  const void* const* b_hh, const void* const* out, int groups, int B, int T, int hidden,
-                                  int ndir, void* workspace, int64_t workspace_bytes, void* stream);
 int mrn_attn_decoder_fwd_grouped_f32(const void* const* Hb, const void* const* Hproj, const void* const* eproj,
                                      int64_t eproj_stride_b, int64_t eproj_stride_s, const void* const* w_h2h,
                                      const void* const* b_h2h, const void* const* w_score, const void* const* w_ih_ctx,
@@ -442,19 +403,6 @@ int mrn_svtr_mixer_x3_f32(const float* x, const float* pending, const float* dro
                           const void* wproj_hl, const float* sproj, const float* bproj, const float* drop1, const float* g2,
                           const float* b2, float eps2, float* x_out, void* y_hl, int imgs, int imgs_per_group, int N, int C,
                           void* stream);
-/* A whole SVTR mixing block (modules/svtr.py:154-204 Block.forward, both residual branches) of G lock-step frozen experts in ONE kernel:
- * mrn_svtr_mixer_x3_f32 followed, on the same registers, by the Mlp half of mrn_svtr_mlp_x3_f32:
- *   t = x + drop_prev * pending;  u = t + drop1 * proj(attention(qkv(LayerNorm1(t))));  x_out = u + drop2 * fc2(GELU(fc1(LayerNorm2(u))))
- * Arguments as mrn_svtr_mixer_x3_f32 (no y_hl) plus w1_hl [G][4C][C/32][128 B] (fc1 packed from [4C][1][C] with the INPUT channel of every
- * 32-block permuted: position 16 s + 8 h + j holds channel (j & 3) + 8 (2 s + (j >> 2)) + 4 h), s1 [G][2], bm1 [G][4C]; w2_hl
- * [G][C][4C/32][128 B] (fc2, hidden index permuted the same way, as for mrn_svtr_mlp_x3_f32), s2 [G][2], bm2 [G][C]; drop2 [imgs] or NULL.
- * x_out must not alias x or pending.  Same supported shapes as mrn_svtr_mixer_x3_f32. */
-int mrn_svtr_block_x3_f32(const float* x, const float* pending, const float* drop_prev, const float* g1, const float* b1, float eps1,
-                          const void* wqkv_hl, const float* sqkv, const float* bqkv, const void* mask_bits, float scale,
-                          const void* wproj_hl, const float* sproj, const float* bproj, const float* drop1, const float* g2,
-                          const float* b2, float eps2, const void* w1_hl, const float* s1, const float* bm1, const void* w2_hl,
-                          const float* s2, const float* bm2, const float* drop2, float* x_out, int imgs, int imgs_per_group, int N,
-                          int C, void* stream);
 /* Attention-only form for the wide stage (C = 256, SVTR stage 3: the proj accumulators of mrn_svtr_mixer_x3_f32 do not fit next to the token
  * fragments): t = x + drop_prev * pending (written to t_out when pending is given); ctx_hl = HL32(attention(qkv(LayerNorm1(t)))), the
  * operand of the (unfused) proj Linear -- the residual add and LayerNorm2 follow as mrn_add_layernorm_grouped_f32.  Saves the LayerNorm

@@ -287,205 +287,9 @@ __global__ __launch_bounds__(NTH) void lstm_layer_x3_kernel(const LstmX3Group gr
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Weight-stationary variant of the frozen experts' LSTM layer: the time step of lstm_layer_x3_kernel is bound by ONE CU
-// streaming the whole W_hh (1 MiB as hi + lo fp16) from L2, 18.6 us per step whatever the batch tile.  Here a "set" (expert,
-// direction) is spread over CL_NS = 16 workgroups: slice s keeps the 64 KiB of W_hh that produce hidden units [16s, 16s+16) of
-// all four gates in LDS for the whole sequence and computes them for ALL samples (16 waves x 16-sample tiles, <= 256 per chunk);
-// what travels per step is h instead of W: every workgroup writes its 16 units of h (hi / lo fp16 planes) to an exchange
-// buffer, arrives on a per-set counter (release), waits until all 16 slices have arrived (acquire) and reads the full h tile
-// of its waves back as MFMA A-fragments (16 KiB per wave).  The 16 workgroups of a set share an XCD (blockIdx % 8), so the
-// exchange stays in that XCD's L2; correctness does not depend on it (agent-scope fences).  All workgroups of a launch must
-// be co-resident (they spin on each other): the launcher bounds the grid, and every spin is bounded -- a workgroup that waits
-// longer than CL_SPIN_LIMIT polls gives up, and poisons its output with NaN instead of hanging the device.
-// MEASURED (MI355X, B = 256, T = 65; tools/bench_lstm.py, results bit-identical to the streaming kernel): G = 3: 22.3 us / step
-// against 17.1 streaming, G = 6: 23.9 against 22.4 -- the hand-over is what costs: agent-scope loads of the 256 KiB of h miss in
-// L2 (8 us), an agent-scope acquire fence instead is worse (27 us / step), and only an L1-only invalidate that ASSUMES XCD
-// co-location gets below the streaming kernel (14.5 us).  So this is NOT the default (ops.LSTM_CLUSTER, MRN_LSTM_CLUSTER=1 opts in).
-// ---------------------------------------------------------------------------------------------
-constexpr int CL_NS = 16;
-constexpr int CL_ROWS = NW * 16;          // samples per workgroup
-constexpr int CL_SPIN_LIMIT = 1 << 21;
-
-// eight halves of the h exchange buffer, read at agent scope (two 64-bit sc1 loads: they bypass the CU's L1 and stay coherent
-// across XCDs -- at the price of missing in L2 as well, 8 us per step; see the what-if build below)
-__device__ __forceinline__ f16v8 load_h8(const unsigned char* p) {
-#ifdef MRN_CL_INV_SC0
-  return *reinterpret_cast<const f16v8*>(p);       // (what-if build: plain loads after an L1-only invalidate)
-#else
-  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-  u64x2 v;
-  v[0] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  v[1] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p + 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return __builtin_bit_cast(f16v8, v);
-#endif
-}
-
-struct LstmClusterGroup {
-  LstmX3Params g[MAX_GROUPS];
-  int B, T, ndir, nsets, chunks;
-  int* flags;                // [nsets * chunks] arrival counters, zeroed by the launcher
-  unsigned char* hx;         // [2 parities][nsets][B][16 slices][hi 16 | lo 16] fp16
-};
-
-__global__ __launch_bounds__(NTH) void lstm_cluster_x3_kernel(const LstmClusterGroup grp) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char wlds[];   // [hi | lo][4 gates][8 k-steps][64 lanes][16 B]
-  __shared__ int bad;
-  // blockIdx = ((set_hi * chunks + chunk) * CL_NS + slice) * 8 + xcd with set = set_hi * 8 + xcd
-  int rest = blockIdx.x >> 3;
-  const int slice = rest % CL_NS;
-  rest /= CL_NS;
-  const int chunk = rest % grp.chunks;
-  const int set = (rest / grp.chunks) * 8 + (int)(blockIdx.x & 7);
-  if (set >= grp.nsets) return;
-  const int B = grp.B, T = grp.T, ndir = grp.ndir;
-  const int gi = set / ndir, dir = set - gi * ndir;
-  const float* __restrict__ xproj = grp.g[gi].xproj;
-  float* __restrict__ out = grp.g[gi].out;
-  const int t_ = threadIdx.x, lane = t_ & 63, wave = t_ >> 6;
-  const int col = lane & 15, rbase = (lane >> 4) * 4, kg = lane >> 4;
-  const int j = slice * 16 + col;
-  const int b0 = chunk * CL_ROWS + wave * 16;
-  const bool active = b0 < B;                                  // wave-uniform
-  const float inv = grp.g[gi].w_inv[dir];
-
-  {   // this slice's 64 KiB of W_hh: the fragment-major stream of "wave" `slice` of the streaming kernel, planes separated
-    const unsigned char* src = grp.g[gi].w_hh + ((long)dir * 16 + slice) * 65536;
-    for (int i = t_; i < 2048; i += NTH) {
-      *reinterpret_cast<u32x4*>(wlds + i * 16) = *reinterpret_cast<const u32x4*>(src + i * 32);
-      *reinterpret_cast<u32x4*>(wlds + 32768 + i * 16) = *reinterpret_cast<const u32x4*>(src + i * 32 + 16);
-    }
-  }
-  if (t_ == 0) bad = 0;
-  float c[4] = {0.f, 0.f, 0.f, 0.f}, bh[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) bh[g] = grp.g[gi].b_hh ? grp.g[gi].b_hh[dir * 4 * HID + g * HID + j] : 0.f;
-  int* flag = grp.flags + set * grp.chunks + chunk;
-  __syncthreads();
-
-#ifdef MRN_CL_PROFILE
-  long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tk = __builtin_readcyclecounter();      // (what-if build only: phase clocks of workgroup 0)
-#define CL_TICK(i) { const long now_ = __builtin_readcyclecounter(); prof[i] += now_ - tk; tk = now_; }
-#else
-#define CL_TICK(i)
-#endif
-  for (int step = 0; step < T; ++step) {
-    const int t = dir == 0 ? step : T - 1 - step;
-    float xg[4][4];
-    if (active) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int b = b0 + rbase + r;
-        const float* xp = xproj + ((long)(b < B ? b : b0) * T + t) * (ndir * 4 * HID) + dir * 4 * HID + j;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) xg[g][r] = xp[g * HID];
-      }
-    }
-    f32x4 acc[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (step > 0) {                                             // (h_0 = 0: the first step has no recurrent product)
-      if (t_ == 0) {
-        const int want = CL_NS * step;
-        int it = 0;
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-          if (++it > CL_SPIN_LIMIT) { bad = 1; break; }
-          __builtin_amdgcn_s_sleep(1);
-        }
-      }
-      __syncthreads();
-#ifdef MRN_CL_INV_SC0
-      // (what-if build, NOT the product: drop only the CU's L1 and read through the XCD's L2 -- 14.5 instead of 22 us per step, but
-      // valid only while all 16 workgroups of a set really share an XCD, which nothing in the programming model guarantees.
-      // An agent-scope acquire fence (buffer_inv sc1) instead of agent-scope loads is correct everywhere and costs 27 us.)
-      asm volatile("buffer_inv sc0" ::: "memory");
-#endif
-      CL_TICK(0)
-      if (active) {
-        const int n = lane & 15;
-        // exchange layout [sample][slice][hi 16 units | lo 16 units]: K-step q, lane group kg -> slice 2q + kg / 2, half kg & 1
-        const unsigned char* hp = grp.hx + ((((long)(step & 1) * grp.nsets + set) * B) + (b0 + n < B ? b0 + n : b0)) * 1024 +
-                                  (kg >> 1) * 64 + (kg & 1) * 16;
-        f16v8 ah[8], al[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          ah[q] = load_h8(hp + q * 128);
-          al[q] = load_h8(hp + q * 128 + 32);
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const f16v8 wh = *reinterpret_cast<const f16v8*>(wlds + ((g * 8 + q) * 64 + lane) * 16);
-            const f16v8 wl = *reinterpret_cast<const f16v8*>(wlds + 32768 + ((g * 8 + q) * 64 + lane) * 16);
-            acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[q], wh, acc[g], 0, 0, 0);
-            acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[q], wl, acc[g], 0, 0, 0);
-            acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[q], wh, acc[g], 0, 0, 0);
-          }
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g] *= inv;              // undo the power-of-two weight prescale (exact)
-      }
-    }
-    CL_TICK(1)
-    if (active) {
-      float h[4], act[4][4];
-      lstm_pointwise(acc, xg, bh, c, h, act);
-      CL_TICK(4)
-      // the wave's 16 x 16 tile leaves through LDS so that every lane issues ONE 16-byte store per destination (2-byte
-      // write-through stores cost ~300 cycles per instruction): lane -> row lane / 4, 16-byte segment lane % 4
-      unsigned char* tile = wlds + 65536 + wave * 2048;            // [16 rows][hi 32 B | lo 32 B] + [16 rows][16 floats]
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        _Float16 hh, hl;
-        split_f16(h[r], hh, hl);
-        *reinterpret_cast<_Float16*>(tile + (rbase + r) * 64 + col * 2) = hh;
-        *reinterpret_cast<_Float16*>(tile + (rbase + r) * 64 + 32 + col * 2) = hl;
-        *reinterpret_cast<float*>(tile + 1024 + (rbase + r) * 64 + col * 4) = h[r];
-      }
-      // (same wave writes and reads: the LDS accesses of one wave complete in order)
-      const int row = lane >> 2, seg = lane & 3, b = b0 + row;
-      if (b < B) {
-        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-        const u64x2 v = *reinterpret_cast<const u64x2*>(tile + lane * 16);
-        unsigned char* hw = grp.hx + ((((long)((step + 1) & 1) * grp.nsets + set) * B) + b) * 1024 + slice * 64 + seg * 16;
-        __hip_atomic_store(reinterpret_cast<unsigned long long*>(hw), v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(reinterpret_cast<unsigned long long*>(hw + 8), v[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *reinterpret_cast<f32x4*>(out + ((long)b * T + t) * (ndir * HID) + dir * HID + slice * 16 + seg * 4) =
-            *reinterpret_cast<const f32x4*>(tile + 1024 + lane * 16);
-      }
-      CL_TICK(5)
-    }
-    if (step + 1 < T) {
-      // Publish protocol (MI355X_MICROARCH.md, hand-off forms): the h tile leaves as agent-scope (sc1, write-through) stores;
-      // every wave drains ITS stores with an explicit s_waitcnt vmcnt(0) -- a workgroup-scope release fence lowers to
-      // s_waitcnt lgkmcnt(0) only on gfx950, and the compiler may drop a vmcnt wait it can prove redundant, so the wait is
-      // inline asm -- then the barrier makes that true for the whole workgroup, then one lane bumps the agent-scope arrival
-      // counter.  The consumers poll the counter relaxed and read h with agent-scope (sc1) loads, which bypass their L1.
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      CL_TICK(6)
-      __syncthreads();                                           // ... everyone's stores have left the CU
-      CL_TICK(2)
-      if (t_ == 0) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      CL_TICK(3)
-    }
-  }
-#ifdef MRN_CL_PROFILE
-  if (blockIdx.x == 0 && t_ == 0) {
-    long* o = reinterpret_cast<long*>(grp.flags + 128);
-    for (int i = 0; i < 8; ++i) o[i] = prof[i];
-  }
-#endif
-  __syncthreads();
-  if (bad && active) {                                          // a peer never arrived: make the failure visible, do not hang
-    const int tl = dir == 0 ? T - 1 : 0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int b = b0 + rbase + r;
-      if (b < B) out[((long)b * T + tl) * (ndir * HID) + dir * HID + j] = __builtin_nanf("");
-    }
-  }
-}
+// (A weight-stationary variant -- W_hh slices in the LDS of 16 workgroups per (expert, direction), h exchanged through L2 every step --
+// was built, bit-identical and measured slower in round 2: G = 3 22.3 us / step against 17.1 streaming, G = 6 23.9 against 22.4; the
+// hand-over of h at agent scope costs more than streaming W_hh.  Removed in round 4; DESIGN.md section 7 keeps the measurements.)
 
 // ---------------------------------------------------------------------------------------------
 // Attention decoder, all S steps in one launch (reference recomputes i2h(H) every step and issues ~10
@@ -867,49 +671,6 @@ MRN_EXPORT int mrn_lstm_layer_fwd_x3_save(const float* xproj, const void* w_hh, 
   grp.pinned = 0;
   hipLaunchKernelGGL(lstm_layer_x3_kernel, dim3(grp.nsets * grp.tiles), dim3(NTH), 0, (hipStream_t)stream, grp);
   MRN_LAUNCH_CHECK("lstm_layer_x3_save");
-  return MRN_OK;
-}
-
-// Bytes of the workspace of mrn_lstm_layer_fwd_x3_cluster (arrival counters + the double-buffered h exchange)
-MRN_EXPORT int64_t mrn_lstm_cluster_workspace_bytes(int groups, int B, int ndir) {
-  return 1024 + 2L * groups * ndir * B * 1024;
-}
-
-// Workgroups of one mrn_lstm_layer_fwd_x3_cluster launch (all of them must be co-resident: at most 256, one per CU)
-MRN_EXPORT int64_t mrn_lstm_cluster_workgroups(int groups, int B, int ndir) {
-  return (int64_t)groups * ndir * CL_NS * ceil_div(B, CL_ROWS);
-}
-
-// Weight-stationary form of mrn_lstm_layer_fwd_x3_grouped (same operands and results): W_hh slices live in the LDS of 16
-// workgroups per (expert, direction), h is exchanged through `workspace` every step.  groups * ndir <= 8 per launch.
-MRN_EXPORT int mrn_lstm_layer_fwd_x3_cluster(const void* const* xproj, const void* const* w_hh, const void* const* w_inv,
-                                             const void* const* b_hh, const void* const* out, int groups, int B, int T,
-                                             int hidden, int ndir, void* workspace, int64_t workspace_bytes, void* stream) {
-  MRN_CHECK_ARG(xproj && w_hh && w_inv && out && workspace && groups >= 1, "mrn_lstm_layer_fwd_x3_cluster: null operand");
-  MRN_CHECK_ARG(hidden == HID, "mrn_lstm_layer_fwd_x3_cluster: hidden=%d unsupported (library is built for %d)", hidden, HID);
-  MRN_CHECK_ARG(ndir == 1 || ndir == 2, "mrn_lstm_layer_fwd_x3_cluster: ndir=%d", ndir);
-  MRN_CHECK_ARG(groups <= MAX_GROUPS && mrn_lstm_cluster_workgroups(groups, B, ndir) <= 256,
-                "mrn_lstm_layer_fwd_x3_cluster: %d groups x %d directions x B=%d needs more than 256 co-resident workgroups", groups, ndir, B);
-  MRN_CHECK_ARG(workspace_bytes >= mrn_lstm_cluster_workspace_bytes(groups, B, ndir) && (uintptr_t)workspace % 16 == 0,
-                "mrn_lstm_layer_fwd_x3_cluster: workspace too small or misaligned");
-  if (B == 0 || T == 0) return MRN_OK;
-  LstmClusterGroup grp;
-  memset(&grp, 0, sizeof(grp));
-  for (int i = 0; i < groups; ++i) {
-    MRN_CHECK_ARG(xproj[i] && w_hh[i] && w_inv[i] && out[i], "mrn_lstm_layer_fwd_x3_cluster: null operand in group %d", i);
-    grp.g[i] = LstmX3Params{(const float*)xproj[i], (const unsigned char*)w_hh[i], (const float*)w_inv[i],
-                            b_hh ? (const float*)b_hh[i] : nullptr, (float*)out[i]};
-  }
-  grp.B = B; grp.T = T; grp.ndir = ndir; grp.nsets = groups * ndir; grp.chunks = ceil_div(B, CL_ROWS);
-  grp.flags = (int*)workspace;
-  grp.hx = (unsigned char*)workspace + 1024;
-  MRN_CHECK_ARG(grp.nsets * grp.chunks * (int)sizeof(int) <= 1024, "mrn_lstm_layer_fwd_x3_cluster: too many counters");
-  (void)hipMemsetAsync(workspace, 0, 1024, (hipStream_t)stream);
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)lstm_cluster_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + NW * 2048); attr = true; }
-  const int blocks = 8 * ceil_div(grp.nsets, 8) * grp.chunks * CL_NS;
-  hipLaunchKernelGGL(lstm_cluster_x3_kernel, dim3(blocks), dim3(NTH), 65536 + NW * 2048, (hipStream_t)stream, grp);
-  MRN_LAUNCH_CHECK("lstm_cluster_x3");
   return MRN_OK;
 }
 

@@ -61,15 +61,7 @@ struct MixerParams {
   const float* g2;                // [G][C] LayerNorm2
   const float* b2;
   float* x_out;                   // [imgs][N][C]
-  unsigned char* y_hl;            // [imgs * N][C/32][128 B] (half-block form only)
-  // whole-block form: the Mlp half follows in the same kernel and x_out receives the block's result
-  const unsigned char* w1;        // [G][4C][C/32][128 B] fc1, INPUT channel permuted inside every 32-block
-  const unsigned char* w2;        // [G][C][4C/32][128 B] fc2, hidden index permuted inside every 32-block
-  const float* s1;                // [G][2]
-  const float* s2;
-  const float* bm1;               // [G][4C]
-  const float* bm2;               // [G][C]
-  const float* drop2;             // [imgs] or null
+  unsigned char* y_hl;            // [imgs * N][C/32][128 B]
   int imgs, imgs_per_group, N;
   float scale, eps1, eps2;
 };
@@ -81,10 +73,10 @@ __device__ __forceinline__ f32x16 mma(const u32x4 a, const u32x4 b, const f32x16
 // ATTN: attention only -- LayerNorm1 -> qkv -> attention, the context leaves as the HL32 operand of an unfused proj Linear (p.y_hl) and,
 // when a pending branch was folded in, t = x + drop_prev * pending as the residual stream (p.x_out).  For C = 256 (SVTR stage 3), where
 // the proj accumulators of the full form do not fit the register file next to the token fragments.
-template <int C, int NT, int IMG, int CHUNKS, int RING, bool MLP, bool ATTN = false>
+template <int C, int NT, int IMG, int CHUNKS, int RING, bool ATTN = false>
 __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerParams p) {
   static_assert(CHUNKS == 1 || (CHUNKS == 2 && IMG == 1), "key chunks: one image per workgroup");
-  static_assert(!ATTN || (CHUNKS == 1 && !MLP), "attention-only form: one key chunk");
+  static_assert(!ATTN || CHUNKS == 1, "attention-only form: one key chunk");
   constexpr int NW = NT * IMG, CB = C / 32, KB = C / 16, HEADS = C / 32, OC = C / 32;
   constexpr int STEPS = (ATTN ? 1 : 2) + 2 * CHUNKS; // weight slabs per head: (Wk, Wv) per key chunk, Wq, Wproj (not in the attention-only form)
   constexpr int SLAB = C * 128;                      // one weight slab: 32 rows x C channels, or C rows x 32 channels
@@ -544,7 +536,7 @@ __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerPa
 #pragma unroll
         for (int j = 0; j < 4; ++j) out[oc][4 * k + j] = (out[oc][4 * k + j] - mean) * rstd * gm[j] + bt[j];
       }
-    if constexpr (!MLP) {
+    {
       // ---- half-block form: LayerNorm2(x_out) leaves as the HL32 operand of the Mlp kernel, through the same LDS tile
 #pragma unroll
       for (int oc = 0; oc < OC; ++oc)
@@ -568,140 +560,29 @@ __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerPa
         const u32x4 v = *reinterpret_cast<const u32x4*>(stg + r * ROWB + cc);
         if (r < nvalid) *reinterpret_cast<u32x4*>(p.y_hl + (row0 + r) * (long)CB * 128 + cc) = v;
       }
-    } else {
-      // ---- whole-block form: the Mlp half (svtr_mlp.hip's chained MFMAs) on the registers.  Registers 8 s .. 8 s + 7 of block oc ARE
-      // the B-operand fragment of k-block 2 oc + s once fc1's input channel is permuted inside every 32-block the way the MFMA
-      // result layout presents it (position 16 s + 8 h + j <-> channel (j & 3) + 8 (2 s + (j >> 2)) + 4 h: a static repack of W1)
-      constexpr int HID = 4 * C, NH = HID / 32;
-      u32x4 yh[KB], yl[KB];
-#pragma unroll
-      for (int oc = 0; oc < OC; ++oc)
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          f16v8 vh, vl;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            _Float16 a, b;
-            split_f16(ok ? out[oc][8 * m + j] : 0.f, a, b);
-            vh[j] = a;
-            vl[j] = b;
-          }
-          yh[2 * oc + m] = __builtin_bit_cast(u32x4, vh);
-          yl[2 * oc + m] = __builtin_bit_cast(u32x4, vl);
-        }
-      // weight slab pairs (W1 rows of hidden block hs: [cb][32 rows]; W2' columns: [C rows], line hs) double-buffered in the ring's
-      // four slabs; the x_out tile above lived in the same LDS, so the first pair starts after every wave has stored its rows
-      float* bm1_lds = reinterpret_cast<float*>(slab0 + 4 * SLAB);
-      const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w1 + (long)g * HID * CB * 128), 0, HID * CB * 128, 0x00020000);
-      const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w2 + (long)g * C * NH * 128), 0, C * NH * 128, 0x00020000);
-      auto issue_pair = [&](int hs, unsigned char* buf) {
-#pragma unroll
-        for (int i = 0; i < DMA_ROUNDS; ++i) {
-          const int d = i * NW + wave;
-          if (d < NDMA) {
-            const int cb = d / 4, r = (d % 4) * 8 + (lane >> 3);
-            const int coff = ((lane & 7) ^ ((r >> 1) & 7)) << 4;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_ptr_t)(buf + d * 1024), 16, ((hs * 32 + r) * CB + cb) * 128 + coff, 0, 0, 0);
-            const int r_ = d * 8 + (lane >> 3);
-            const int coff_ = ((lane & 7) ^ ((r_ >> 1) & 7)) << 4;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r2, (lds_ptr_t)(buf + SLAB + d * 1024), 16, (r_ * NH + hs) * 128 + coff_, 0, 0, 0);
-          }
-        }
-      };
-      __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));            // (the x_out stores of this wave have left its LDS tile)
-      __syncthreads();
-      issue_pair(0, slab0);
-      for (int i = t; i < HID; i += NW * 64) bm1_lds[i] = p.bm1[(long)g * HID + i];
-      f32x16 out2[OC];
-#pragma unroll
-      for (int oc = 0; oc < OC; ++oc)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) out2[oc][e] = 0.f;
-      const float inv1 = p.s1 ? p.s1[g * 2 + 1] : 1.f, inv2 = p.s2 ? p.s2[g * 2 + 1] : 1.f;
-      for (int hs = 0; hs < NH; ++hs) {
-        __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));          // own DMAs of pair hs retired, then everyone's (svtr_mlp.hip)
-        __syncthreads();
-        const unsigned char* cur = slab0 + (hs & 1) * 2 * SLAB;
-        if (hs + 1 < NH) issue_pair(hs + 1, slab0 + ((hs + 1) & 1) * 2 * SLAB);
-        const f32x16 acc = w_times_y(cur, yh, yl);                 // fc1 for 32 hidden units
-        u32x4 hh[2], hl[2];
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          f16v8 vh, vl;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int e = 8 * m + j;
-            const int unit = (e & 3) + 8 * (e >> 2) + 4 * half;
-            const float v = gelu_fast(acc[e] * inv1 + bm1_lds[hs * 32 + unit]);
-            _Float16 a, b;
-            split_f16(v, a, b);
-            vh[j] = a;
-            vl[j] = b;
-          }
-          hh[m] = __builtin_bit_cast(u32x4, vh);
-          hl[m] = __builtin_bit_cast(u32x4, vl);
-        }
-        const unsigned char* w2b = cur + SLAB;                     // fc2 partial sums over these 32 hidden units
-#pragma unroll
-        for (int oc = 0; oc < OC; ++oc) {
-#pragma unroll
-          for (int m = 0; m < 2; ++m) {
-            const u32x4 wl = *reinterpret_cast<const u32x4*>(w2b + oc * 4096 + foff[1][m]);
-            const u32x4 wh = *reinterpret_cast<const u32x4*>(w2b + oc * 4096 + foff[0][m]);
-            out2[oc] = mma(wh, hl[m], out2[oc]);
-            out2[oc] = mma(wl, hh[m], out2[oc]);
-            out2[oc] = mma(wh, hh[m], out2[oc]);
-          }
-        }
-      }
-      // ---- result = x_out + drop2 * (Mlp + bias): x_out comes back from the rows this wave stored (L2), the sum leaves through the
-      // LDS tile again, over the same rows
-      __syncthreads();                                             // every wave is done with the last slab pair
-      const float d2 = p.drop2 ? p.drop2[img < p.imgs ? img : img0] : 1.f;
-      const float* xo = p.x_out + row * C;
-#pragma unroll
-      for (int oc = 0; oc < OC; ++oc)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int c = oc * 32 + 8 * k + 4 * half;
-          const f32x4 xv = *reinterpret_cast<const f32x4*>(xo + c);
-          const f32x4 b = *reinterpret_cast<const f32x4*>(p.bm2 + (long)g * C + c);
-          f32x4 v;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = fmaf(d2, out2[oc][4 * k + j] * inv2 + b[j], xv[j]);
-          *reinterpret_cast<f32x4*>(stg + l31 * ROWB + c * 4) = v;
-        }
-#pragma unroll
-      for (int i = 0; i < 32 / RPI; ++i) {
-        const int r = i * RPI + rr;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(stg + r * ROWB + cc);
-        if (r < nvalid) *reinterpret_cast<f32x4*>(reinterpret_cast<unsigned char*>(p.x_out + (row0 + r) * C) + cc) = v;
-      }
     }
   }
 }
 
-template <int C, int NT, int IMG, int CHUNKS, int RING, bool MLP, bool ATTN = false>
+template <int C, int NT, int IMG, int CHUNKS, int RING, bool ATTN = false>
 int launch_mixer(const MixerParams& p, hipStream_t st) {
-  static_assert(!MLP || RING == 4, "the Mlp half double-buffers its slab pairs in a four-slab ring");
   constexpr size_t ring = 2 * IMG * NT * 32 * 128 + RING * C * 128 + 4 * C * sizeof(float), stage = ATTN ? 0 : (size_t)NT * IMG * 32 * (C * 4 + 16);
   constexpr size_t ldsz = ring > stage ? ring : stage;
   static_assert(ldsz <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)svtr_mixer_kernel<C, NT, IMG, CHUNKS, RING, MLP, ATTN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);
+    (void)hipFuncSetAttribute((const void*)svtr_mixer_kernel<C, NT, IMG, CHUNKS, RING, ATTN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);
     attr_set = true;
   }
-  hipLaunchKernelGGL((svtr_mixer_kernel<C, NT, IMG, CHUNKS, RING, MLP, ATTN>), dim3((unsigned)((p.imgs + IMG - 1) / IMG * CHUNKS)), dim3(NT * IMG * 64), ldsz, st, p);
-  MRN_LAUNCH_CHECK(MLP ? "svtr_block_x3" : ATTN ? "svtr_attention_block_x3" : "svtr_mixer_x3");
+  hipLaunchKernelGGL((svtr_mixer_kernel<C, NT, IMG, CHUNKS, RING, ATTN>), dim3((unsigned)((p.imgs + IMG - 1) / IMG * CHUNKS)), dim3(NT * IMG * 64), ldsz, st, p);
+  MRN_LAUNCH_CHECK(ATTN ? "svtr_attention_block_x3" : "svtr_mixer_x3");
   return MRN_OK;
 }
 
-template <bool MLP>
 int dispatch_mixer(const MixerParams& p, int C, hipStream_t st) {
   const int N = p.N;
-  if (C == 64) return N <= 224 ? launch_mixer<64, 7, 1, 1, 4, MLP>(p, st) : N <= 256 ? launch_mixer<64, 8, 1, 1, 4, MLP>(p, st) : launch_mixer<64, 8, 1, 2, 4, MLP>(p, st);
-  return N <= 128 ? launch_mixer<128, 4, 2, 1, 4, MLP>(p, st) : launch_mixer<128, 8, 1, 1, 4, MLP>(p, st);
+  if (C == 64) return N <= 224 ? launch_mixer<64, 7, 1, 1, 4>(p, st) : N <= 256 ? launch_mixer<64, 8, 1, 1, 4>(p, st) : launch_mixer<64, 8, 1, 2, 4>(p, st);
+  return N <= 128 ? launch_mixer<128, 4, 2, 1, 4>(p, st) : launch_mixer<128, 8, 1, 1, 4>(p, st);
 }
 
 bool mixer_shape_ok(int C, int N, int imgs_per_group) {
@@ -742,44 +623,12 @@ MRN_EXPORT int mrn_svtr_mixer_x3_f32(const float* x, const float* pending, const
   p.bqkv = bqkv; p.mask_bits = (const unsigned*)mask_bits; p.wproj = (const unsigned char*)wproj_hl; p.sproj = sproj; p.bproj = bproj;
   p.drop1 = drop1; p.g2 = g2; p.b2 = b2; p.x_out = x_out; p.y_hl = (unsigned char*)y_hl;
   p.imgs = imgs; p.imgs_per_group = imgs_per_group; p.N = N; p.scale = scale; p.eps1 = eps1; p.eps2 = eps2;
-  p.w1 = p.w2 = nullptr; p.s1 = p.s2 = p.bm1 = p.bm2 = p.drop2 = nullptr;
-  return dispatch_mixer<false>(p, C, (hipStream_t)stream);
+  return dispatch_mixer(p, C, (hipStream_t)stream);
 }
 
-// A whole SVTR mixing block (modules/svtr.py:154-204 Block.forward: both residual branches) of G lock-step frozen experts in ONE kernel:
-// mrn_svtr_mixer_x3_f32 followed, on the same registers, by the Mlp half of mrn_svtr_mlp_x3_f32:
-//   t = x + drop_prev * pending;  u = t + drop1 * proj(attention(qkv(LayerNorm1(t))));  x_out = u + drop2 * fc2(GELU(fc1(LayerNorm2(u))))
-// Arguments as mrn_svtr_mixer_x3_f32 (no y_hl), plus
-//   w1_hl [G][4C][C/32][128 B]  fc1 weights packed from [4C][1][C] with the INPUT channel of every 32-block permuted (position 16 s + 8 h + j
-//                               holds channel (j & 3) + 8 (2 s + (j >> 2)) + 4 h); s1 [G][2]; bm1 [G][4C]
-//   w2_hl [G][C][4C/32][128 B]  fc2 weights, hidden index permuted the same way (as for mrn_svtr_mlp_x3_f32); s2 [G][2]; bm2 [G][C]
-//   drop2 [imgs] or NULL.
-// x_out must not alias x or pending (rows are re-read after their first store).  Same shapes as mrn_svtr_mixer_x3_f32.
-MRN_EXPORT int mrn_svtr_block_x3_f32(const float* x, const float* pending, const float* drop_prev, const float* g1, const float* b1,
-                                     float eps1, const void* wqkv_hl, const float* sqkv, const float* bqkv, const void* mask_bits,
-                                     float scale, const void* wproj_hl, const float* sproj, const float* bproj, const float* drop1,
-                                     const float* g2, const float* b2, float eps2, const void* w1_hl, const float* s1, const float* bm1,
-                                     const void* w2_hl, const float* s2, const float* bm2, const float* drop2, float* x_out, int imgs,
-                                     int imgs_per_group, int N, int C, void* stream) {
-  MRN_CHECK_ARG(x && g1 && b1 && wqkv_hl && wproj_hl && bproj && g2 && b2 && w1_hl && w2_hl && bm1 && bm2 && x_out && imgs >= 0 &&
-                    imgs_per_group >= 1 && x_out != x && x_out != pending,
-                "mrn_svtr_block_x3_f32: bad operands");
-  MRN_CHECK_ARG((uintptr_t)wqkv_hl % 128 == 0 && (uintptr_t)wproj_hl % 128 == 0 && (uintptr_t)w1_hl % 128 == 0 && (uintptr_t)w2_hl % 128 == 0 &&
-                    (uintptr_t)x % 16 == 0 && (uintptr_t)x_out % 16 == 0 && (!pending || (uintptr_t)pending % 16 == 0),
-                "mrn_svtr_block_x3_f32: operands must be 128-byte (HL32) / 16-byte (fp32) aligned");
-  if (!mixer_shape_ok(C, N, imgs_per_group)) {
-    mrn_set_error("mrn_svtr_block_x3_f32: unsupported shape C=%d N=%d imgs_per_group=%d", C, N, imgs_per_group);
-    return MRN_ERR_UNSUPPORTED;
-  }
-  if (imgs == 0) return MRN_OK;
-  MixerParams p;
-  p.x = x; p.pend = pending; p.drop_prev = drop_prev; p.g1 = g1; p.b1 = b1; p.wqkv = (const unsigned char*)wqkv_hl; p.sqkv = sqkv;
-  p.bqkv = bqkv; p.mask_bits = (const unsigned*)mask_bits; p.wproj = (const unsigned char*)wproj_hl; p.sproj = sproj; p.bproj = bproj;
-  p.drop1 = drop1; p.g2 = g2; p.b2 = b2; p.x_out = x_out; p.y_hl = nullptr;
-  p.w1 = (const unsigned char*)w1_hl; p.w2 = (const unsigned char*)w2_hl; p.s1 = s1; p.s2 = s2; p.bm1 = bm1; p.bm2 = bm2; p.drop2 = drop2;
-  p.imgs = imgs; p.imgs_per_group = imgs_per_group; p.N = N; p.scale = scale; p.eps1 = eps1; p.eps2 = eps2;
-  return dispatch_mixer<true>(p, C, (hipStream_t)stream);
-}
+// (The whole Block.forward in one launch -- this kernel followed by the Mlp half on the same registers -- was built, parity-tested and
+// measured slower than the two half-block kernels in round 3: C = 128, 256 tokens 1038 vs 965 us per block of 6 x 256 images; the Mlp
+// phase inherits the one-workgroup-per-CU occupancy of this kernel.  Removed in round 4.)
 
 // Attention-only form for the wide stage (C = 256, SVTR stage 3; reference modules/svtr.py:130-152 behind :200's norm1):
 //   t = x + drop_prev * pending  (written to t_out when pending is given);  ctx = attention(qkv(LayerNorm1(t)))
@@ -806,5 +655,5 @@ MRN_EXPORT int mrn_svtr_attention_block_x3_f32(const float* x, const float* pend
   p.bqkv = bqkv; p.mask_bits = (const unsigned*)mask_bits; p.x_out = t_out; p.y_hl = (unsigned char*)ctx_hl;
   p.imgs = imgs; p.imgs_per_group = imgs_per_group; p.N = N; p.scale = scale; p.eps1 = eps1; p.eps2 = eps1;
   const hipStream_t st = (hipStream_t)stream;
-  return N <= 64 ? launch_mixer<256, 2, 4, 1, 2, false, true>(p, st) : launch_mixer<256, 4, 2, 1, 2, false, true>(p, st);
+  return N <= 64 ? launch_mixer<256, 2, 4, 1, 2, true>(p, st) : launch_mixer<256, 4, 2, 1, 2, true>(p, st);
 }

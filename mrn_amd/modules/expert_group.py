@@ -66,7 +66,7 @@ def supported(experts):
     for mods in zip(*[_bn_modules(e) for e in experts]):
         if len({m.training for m in mods}) != 1:
             return False
-    return ops.CONV_PRECISION in ("auto", "fp16x3") and ops.AUTO_SPLIT_KIND == "fp16x3" and ops.AUTO_SPLIT_MIN_K == 0
+    return ops.CONV_PRECISION in ("auto", "fp16x3")
 
 
 class _GroupedLinear:
@@ -385,20 +385,6 @@ class BackboneGroup(_GroupedLinear):
             drop2 = self._drop_scales(blks, B, x.device)
             g2, b2 = self._ln_params(name + ".ln2", [b.norm2 for b in blks])
             Ch = blks[0].mlp.fc1.out_features
-            if ops.SVTR_FUSED_BLOCK and ops.SVTR_FUSED_MLP and Ch == 4 * C:
-                # ... and the Mlp half on the same registers: the whole Block.forward is one launch
-                fc1s, fc2s = [b.mlp.fc1 for b in blks], [b.mlp.fc2 for b in blks]
-
-                def build_block():
-                    pc, ph = ops.mlp_hidden_permutation(C, x.device), ops.mlp_hidden_permutation(Ch, x.device)
-                    w1, s1 = ops.pack_weights_hl32([m.weight.detach().index_select(1, pc).contiguous().view(Ch, 1, 1, C) for m in fc1s])
-                    w2, s2 = ops.pack_weights_hl32([m.weight.detach().index_select(1, ph).contiguous().view(C, 1, 1, Ch) for m in fc2s])
-                    return (w1, s1, torch.stack([m.bias.detach() for m in fc1s]).contiguous(), w2, s2,
-                            torch.stack([m.bias.detach() for m in fc2s]).contiguous())
-                w1, s1, b1_, w2, s2, b2_ = self._cached(name + ".block", [t_ for m in fc1s + fc2s for t_ in (m.weight, m.bias)], build_block)
-                x = ops.svtr_block_fused(x, br, dr, g1, b1, b0.norm1.eps, wq, sq, bq, mixer.mask, mixer.scale, wp, sp, bp, drop1,
-                                         g2, b2, b0.norm2.eps, w1, s1, b1_, w2, s2, b2_, drop2, B)
-                return x, None
             x, y_hl = ops.svtr_mixer_fused(x, br, dr, g1, b1, b0.norm1.eps, wq, sq, bq, mixer.mask, mixer.scale, wp, sp, bp, drop1,
                                            g2, b2, b0.norm2.eps, B)
         else:
@@ -555,7 +541,7 @@ class SequenceGroup(_GroupedLinear):
             return False
         if any(e.stages != e0.stages for e in extractors):
             return False
-        return ops.CONV_PRECISION in ("auto", "fp16x3") and ops.AUTO_SPLIT_KIND == "fp16x3"
+        return ops.CONV_PRECISION in ("auto", "fp16x3")
 
     def _bilstm(self, idx, x_hl, rows_shape, K, **dst):
         """BidirectionalLSTM number idx of every extractor: x [G, B*T, K] (HL32) -> [G,B,T,256] fp32 (or the strided `out`)"""
@@ -567,22 +553,14 @@ class SequenceGroup(_GroupedLinear):
         xproj = self._linear("ih%d" % idx, x_hl, B * T, K, [p[0] for p in packed], [p[2] for p in packed])
         w_hh = self._cached("hh%d" % idx, [p[1] for p in packed], lambda: torch.stack([p[1] for p in packed]).contiguous())
         b_hh = self._cached("bhh%d" % idx, [p[3] for p in packed], lambda: torch.stack([p[3] for p in packed]).contiguous())
-        if ops.RECURRENT_X3 and ops.LSTM_STEPS and H == 256:
-            # one kernel per time step over all CUs, replayed from a HIP graph (csrc/lstm_steps.hip): W_hh as HL32 stacks (cached)
-            def build_steps():
-                packs = [ops.pack_lstm_steps_weights([m.rnn.weight_hh_l0, m.rnn.weight_hh_l0_reverse]) for m in mods]
-                return torch.stack([p[0] for p in packs]).contiguous(), torch.stack([p[1] for p in packs]).contiguous()
-            w_s, w_sinv = self._cached("hhst_%d" % idx, [w for m in mods for w in (m.rnn.weight_hh_l0, m.rnn.weight_hh_l0_reverse)], build_steps)
-            rec = ops.lstm_layer_x3_steps(xproj.view(G, B, T, 2 * 4 * H), w_s, w_sinv, b_hh, H, 2)
-        elif ops.RECURRENT_X3:
+        if ops.RECURRENT_X3:
             # recurrent product on the f16 MFMA: W_hh pre-split into a fragment-major fp16 stream (cached), h split in LDS
             def build():
                 packs = [[ops.pack_fragment_major_h(w) for w in (m.rnn.weight_hh_l0, m.rnn.weight_hh_l0_reverse)] for m in mods]
                 return (torch.stack([torch.stack([d[0] for d in p]) for p in packs]).contiguous(),
                         torch.stack([torch.cat([d[1] for d in p]) for p in packs]).contiguous())
             w_h, w_inv = self._cached("hh16_%d" % idx, [w for m in mods for w in (m.rnn.weight_hh_l0, m.rnn.weight_hh_l0_reverse)], build)
-            lstm = ops.lstm_layer_x3_cluster if ops.lstm_cluster_supported(G, B, 2) else ops.lstm_layer_x3_grouped
-            rec = lstm(xproj.view(G, B, T, 2 * 4 * H), w_h, w_inv, b_hh, H, 2)
+            rec = ops.lstm_layer_x3_grouped(xproj.view(G, B, T, 2 * 4 * H), w_h, w_inv, b_hh, H, 2)
         else:
             rec = ops.lstm_layer_grouped(xproj.view(G, B, T, 2 * 4 * H), w_hh, b_hh, H, 2)
         y = self._linear("lin%d" % idx, ops.split_hl32(rec), B * T, 2 * H, [m.linear.weight for m in mods],

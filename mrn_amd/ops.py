@@ -74,31 +74,26 @@ SVTR_ATTENTION_X3 = os.environ.get("MRN_SVTR_ATTENTION_PRECISION", "fp16x3") == 
 RECURRENT_X3 = os.environ.get("MRN_RECURRENT", "fp16x3") == "fp16x3"   # frozen experts' LSTM recurrences on the f16 MFMA
 ROUTER_WGRAD_X3 = os.environ.get("MRN_WGRAD", "fp16x3") == "fp16x3"     # weight-gradient GEMMs too (A/B switch)
 
-# Arithmetic of the large implicit-GEMM convs (Cout > 64, K % 32 == 0):
-#   "f32"    exact fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere
-#   "auto"   (default) AUTO_SPLIT_KIND for reductions with K >= AUTO_SPLIT_MIN_K, exact fp32 below.  The default kind is
-#            "fp16x3" for every eligible conv: measured on the golden vectors (tools/precision_study.py, MI355X) the
-#            router weights / fused logits sit at the SAME distance from the reference as the exact fp32 kernel
-#            (TRBA 6.5e-5 / 6.4e-5 vs 5.7e-5 / 7.9e-5 -- that floor is the TPS grid's fp32 conditioning; CRNN 5.7e-7 vs
-#            3.6e-7), also with the TPS localisation network on it.
-#   "fp16x3" split-fp16 x3 on v_mfma_f32_32x32x16_f16 (22-bit products, power-of-two weight prescale) for every eligible conv
-#   "bf16x3" split-bf16 x3 (16-bit products): ~1e-4 on TRBA fused logits (edge of the band), 1e-5 on CRNN
-#   "bf16" / "fp16"  hi halves only, fp32 accumulate: ~2e-2 / ~2e-3 on features
+# Arithmetic of a frozen expert's convolutions OUTSIDE a lock-step group (a single network: validation() of a one-network learner,
+# LwF's previous network, ...; the lock-step groups of modules/expert_group.py always run the grouped split-fp16 x3 kernels):
+#   "auto" / "fp16x3"  (default) split-fp16 x3 on v_mfma_f32_32x32x16_f16 -- 22-bit products, power-of-two weight prescale -- on the
+#            grouped kernel with G = 1 for every conv with Cin % 32 == 0, exact fp32 otherwise.  Measured on the golden vectors the router
+#            weights / fused logits sit at the SAME distance from the reference as the exact fp32 kernel (TRBA 6.5e-5 / 6.4e-5 vs
+#            5.7e-5 / 7.9e-5 -- that floor is the TPS grid's fp32 conditioning; CRNN 5.7e-7 vs 3.6e-7), also with the TPS localisation
+#            network on it.
+#   "f32"    exact fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere, per expert
+# (Rounds 1-3 also carried split-bf16 x3 / plain bf16 / plain fp16 per-expert kernels -- 16-bit products sit at the edge of the 1e-4 band
+# on TRBA -- removed in round 4 together with their 128x128x32 kernel family.)
 CONV_PRECISION = "auto"
-AUTO_SPLIT_MIN_K = 0
 # Convs that are being TRAINED (loop A: forward and data gradients; weight gradients stay on the exact-fp32 kernel):
 #   "fp16x3s" (default) split-fp16 x3 on the grouped kernel with BOTH operands prescaled by a device-computed power of two,
 #             so gradient operands of 1e-6 keep 22-bit products; every parameter gradient of a CRNN / TRBA expert matches
 #             torch autograd on the oracle inside the bands of tests/test_model_gpu.py::test_loop_a_*
-#   "f32"     exact fp32 MFMA.  (Unscaled "fp16x3" fails the TRBA gradient test: small gradients fall into fp16
-#             subnormals; "bf16x3" amplifies 1e-5 forward differences through small-batch BatchNorm backward to ~3e-3.)
+#   "f32"     exact fp32 MFMA.  (Unscaled "fp16x3" fails the TRBA gradient test: small gradients fall into fp16 subnormals.)
 TRAIN_CONV_PRECISION = os.environ.get("MRN_TRAIN_PRECISION", "fp16x3s")
 TRAIN_WGRAD_X3 = os.environ.get("MRN_TRAIN_WGRAD", "fp16x3s") == "fp16x3s"   # weight gradients on the same path
 WGRAD_WINDOWS = os.environ.get("MRN_WGRAD_WINDOWS", "1") == "1"   # 3x3 / s1 / p1 weight gradients without an im2col (A/B switch)
 LOCNET_CONV_PRECISION = None   # TPS localisation network: None = follow CONV_PRECISION ("f32" to pin it exact)
-AUTO_SPLIT_KIND = "fp16x3"   # arithmetic "auto" picks for the deep reductions ("fp16x3" | "bf16x3")
-USE_DMA_CONV = True          # pre-split activation + direct-to-LDS staging for the split-16-bit convs
-DMA_MIN_CIN = 256            # below this the extra split pass costs more than the leaner main loop saves
 _ZERO_PAGES = {}
 
 
@@ -142,29 +137,22 @@ FP16_WEIGHT_PEAK = 16384.0   # fp16 weight planes are prescaled (power of two) s
 
 
 class PackedConvWeight:
-    """[O,kh,kw,I] fp32 weight plus its lazily built 16-bit hi/lo splits (bf16, or fp16 with a power-of-two prescale)."""
+    """[O,kh,kw,I] fp32 weight plus its lazily built split-fp16 operand stacks for the grouped x3 kernel (HL32 lines or the Winograd-domain
+    form, with their power-of-two prescale); modules/_nn.packed_weight rebuilds the object when the parameter's version changes."""
 
     def __init__(self, ohwi):
         self.ohwi = ohwi
         self.shape = ohwi.shape
-        self._split = {}
+        self._operand = {}
 
-    def split(self, half=False):
-        """-> (hi, lo, scale) ; scale is a device float[2] = {s, 1/s} for the fp16 planes, None for bf16."""
-        got = self._split.get(half)
+    def x3_operand(self, wino):
+        """-> (stack, scale) for conv_x3.hip with G = 1: pack_weights_wino (F(WINO_R,3)) or pack_weights_hl32"""
+        key = (bool(wino), WINO_R)
+        got = self._operand.get(key)
         if got is None:
-            n = self.ohwi.numel()
-            dev = self.ohwi.device
-            dt = torch.float16 if half else torch.bfloat16
-            hi = torch.empty(n, device=dev, dtype=dt)
-            lo = torch.empty(n, device=dev, dtype=dt)
-            scale = None
-            if half:
-                scale = torch.empty(2, device=dev, dtype=torch.float32)
-                call("mrn_pow2_scale_f32", _p(self.ohwi), n, FP16_WEIGHT_PEAK, _p(scale), _pow2_ws(), _stream())
-            call("mrn_split_weight_bf16", _p(self.ohwi), _p(hi), _p(lo), n, int(half), _p(scale), _stream())
-            got = (hi, lo, scale)
-            self._split[half] = got
+            w = self.ohwi.contiguous()
+            got = tuple(pack_weights_wino([w], WINO_R)) if wino else tuple(pack_weights_hl32([w]))
+            self._operand[key] = got
         return got
 
 
@@ -286,6 +274,10 @@ def conv2d_nhwc(x, w_ohwi, bias=None, stride=(1, 1), padding=(0, 0), act=ACT_NON
         if Cin % 32 == 0 and out is None and stats_out is None:
             return conv2d_x3_scaled(x, w_ohwi, bias, stride, padding, act, want_stats, sx=x_scale)
         precision = "f32"
+    if precision in ("auto", "fp16x3") and Cin % 32 == 0 and out is None and stats_out is None:
+        # a single (not lock-step) frozen expert, e.g. validation() of a one-network learner or LwF's previous network: the grouped
+        # split-fp16 x3 kernel with G = 1 -- plain HL32 operands, or the Winograd form where the lock-step path would use it
+        return conv2d_x3_frozen(x, packed if packed is not None else PackedConvWeight(w_ohwi), bias, stride, padding, act, want_stats)
     Ho, Wo = conv_out_hw(H, W, (kh, kw), stride, padding)
     y = out if out is not None else torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
     assert y.is_contiguous() and y.numel() == B * Ho * Wo * Cout
@@ -294,36 +286,12 @@ def conv2d_nhwc(x, w_ohwi, bias=None, stride=(1, 1), padding=(0, 0), act=ACT_NON
         n = call("mrn_conv2d_stats_floats", B, Ho, Wo, Cout)
         stats = stats_out if stats_out is not None else torch.empty(n, device=x.device, dtype=torch.float32)
         assert stats.is_contiguous() and stats.numel() == n
-    timed = CONV_TIMER is not None and Cout > 64          # the 128x128-tile kernels
+    timed = CONV_TIMER is not None and Cout > 64          # the 128x128-tile kernel
     Kred = kh * kw * Cin
     kind = "f32"
-    if precision == "auto":
-        precision = AUTO_SPLIT_KIND if Kred >= AUTO_SPLIT_MIN_K else "f32"
-    if precision != "f32" and Cout > 64 and Kred % 32 == 0:
-        if packed is None:
-            packed = PackedConvWeight(w_ohwi)
-        half = precision.startswith("fp16")
-        hi, lo, wscale = packed.split(half)
-        nsplit = 3 if precision.endswith("x3") else 1
-        if USE_DMA_CONV and Cin % 8 == 0 and Cin >= DMA_MIN_CIN:
-            # one HBM pass splits the activation into 16-bit hi/lo planes, then the GEMM loop stages both operands by DMA
-            n = x.numel()
-            xs = torch.empty(2, n, device=x.device, dtype=torch.bfloat16)
-            call("mrn_split_weight_bf16", _p(x), _p(xs[0]), _p(xs[1]), n, int(half), None, _stream())
-            kind = precision + "/dma"
-            t0 = CONV_TIMER.begin() if timed else None
-            call("mrn_conv2d_nhwc_bf16split_dma", _p(xs[0]), _p(xs[1]), _p(hi), _p(lo), _p(_zero_page(x.device)), _p(bias),
-                 _p(y), _p(stats), B, H, W, Cin, Cout, kh, kw, stride[0], stride[1], padding[0], padding[1], act, nsplit,
-                 int(half), _p(wscale), _stream())
-        else:
-            kind = precision + "/reg"
-            t0 = CONV_TIMER.begin() if timed else None
-            call("mrn_conv2d_nhwc_bf16split", _p(x), _p(hi), _p(lo), _p(bias), _p(y), _p(stats), B, H, W, Cin, Cout, kh, kw,
-                 stride[0], stride[1], padding[0], padding[1], act, nsplit, int(half), _p(wscale), _stream())
-    else:
-        t0 = CONV_TIMER.begin() if timed else None
-        call("mrn_conv2d_nhwc_f32", _p(x), _p(w_ohwi), _p(bias), _p(y), _p(stats), B, H, W, Cin, Cout, kh, kw,
-             stride[0], stride[1], padding[0], padding[1], act, _stream())
+    t0 = CONV_TIMER.begin() if timed else None
+    call("mrn_conv2d_nhwc_f32", _p(x), _p(w_ohwi), _p(bias), _p(y), _p(stats), B, H, W, Cin, Cout, kh, kw,
+         stride[0], stride[1], padding[0], padding[1], act, _stream())
     if timed:
         CONV_TIMER.end(t0, 2.0 * B * Ho * Wo * Cout * Kred, kind)
     return y, stats
@@ -822,6 +790,23 @@ def conv2d_x3_scaled(x, w_ohwi, bias, stride, padding, act=ACT_NONE, want_stats=
     return y[0], stats
 
 
+def conv2d_x3_frozen(x, packed, bias, stride, padding, act=ACT_NONE, want_stats=False):
+    """one convolution of a frozen expert outside a lock-step group on the grouped x3 kernel (G = 1): x fp32 [B,H,W,Cin] (Cin % 32 == 0)
+    split unscaled (post-BatchNorm activations), weights from the PackedConvWeight's cached operand -> (y [B,Ho,Wo,O], stats or None)"""
+    B, H, W, Cin = x.shape
+    Cout, kh, kw, _ = packed.shape
+    x = x.contiguous()
+    wino = WINO_R in (2, 4) and X3_PRODUCTS == 3 and wino_eligible((kh, kw), stride, padding, Cin, Cout)
+    w_hl, sw = packed.x3_operand(wino)
+    if wino:
+        _, _, v = bn_apply_wino_grouped(x.view(1, B, H, W, Cin), None, None, WINO_R, relu=False)
+        y, stats = conv2d_x3_wino(v, 1, False, B, H, W, Cin, w_hl, sw, Cout, WINO_R, bias=bias, act=act, want_stats=want_stats)
+        return y[0], stats
+    y, stats = conv2d_x3(split_hl32(x), 1, False, B, H, W, Cin, w_hl, sw, Cout, (kh, kw), stride, padding, bias=bias, act=act,
+                         want_stats=want_stats, products=X3_PRODUCTS)
+    return y[0], stats
+
+
 def conv3x3_c4_grouped(x, weights, bias=None, act=ACT_NONE, want_stats=False, out=None):
     """First conv of G frozen experts (3x3, stride 1, padding 1, Cin = 4, Cout 32 / 64) in one launch.  x: [B,H,W,4] (shared by
     all experts) or [G,B,H,W,4]; weights: [G,Cout,3,3,4] stack; bias [G,Cout] or None -> (y [G,B,H,W,Cout], stats or None)"""
@@ -1058,62 +1043,9 @@ def lstm_layer_x3_grouped(xproj, w_hh_h, w_inv, b_hh, hidden, ndir):
     return out
 
 
-LSTM_CLUSTER = os.environ.get("MRN_LSTM_CLUSTER", "0") == "1"    # opt-in: weight-stationary LSTM (measured slower than streaming, rnn.hip)
-LSTM_CLUSTER_MAX_WG = 128         # workgroups of one cluster launch (they spin on each other: two concurrent launches must fit)
-
-
-def lstm_cluster_supported(G, B, ndir):
-    return (LSTM_CLUSTER and B >= 64 and G * ndir <= 8
-            and call("mrn_lstm_cluster_workgroups", G, B, ndir) <= LSTM_CLUSTER_MAX_WG)
-
-
-def lstm_layer_x3_cluster(xproj, w_hh_h, w_inv, b_hh, hidden, ndir):
-    """lstm_layer_x3_grouped on the weight-stationary kernel (bit-identical results): W_hh slices stay in the LDS of 16 workgroups
-    per (expert, direction), h crosses the workgroups through a small exchange buffer every step"""
-    _chk(xproj, b_hh)
-    G, B, T, _ = xproj.shape
-    assert xproj.is_contiguous() and w_hh_h.is_contiguous() and w_inv.is_contiguous() and b_hh.is_contiguous()
-    out = torch.empty(G, B, T, ndir * hidden, device=xproj.device, dtype=torch.float32)
-    nbytes = call("mrn_lstm_cluster_workspace_bytes", G, B, ndir)
-    ws = torch.empty(nbytes, device=xproj.device, dtype=torch.uint8)
-    call("mrn_lstm_layer_fwd_x3_cluster", _ptr_array([xproj[g].data_ptr() for g in range(G)]),
-         _ptr_array([w_hh_h[g].data_ptr() for g in range(G)]), _ptr_array([w_inv[g].data_ptr() for g in range(G)]),
-         _ptr_array([b_hh[g].data_ptr() for g in range(G)]), _ptr_array([out[g].data_ptr() for g in range(G)]), G, B, T,
-         hidden, ndir, _p(ws), nbytes, _stream())
-    return out
-
-
-# frozen experts' LSTM layers as per-time-step kernels replayed from a HIP graph (csrc/lstm_steps.hip): built, parity-tested, measured
-# (tools/bench_lstm.py, B = 256, T = 65, us per step, persistent streaming kernel -> step kernels): G = 1 13.0 -> 16.6, G = 3 17.2 -> 18.3,
-# G = 6 22.3 -> 19.9.  A graph node costs 1.6 us, but a step is still a chain of dependent latencies (argument block, h / xproj loads,
-# eight slab barriers, pointwise, stores) of ~15 us, and the traffic-optimal tile leaves 16 workgroups per (expert, direction).  The
-# lock-step groups of the headline run G = 2 per stream, where the persistent kernel wins: opt-in (MRN_LSTM_STEPS=1).
-LSTM_STEPS = os.environ.get("MRN_LSTM_STEPS", "0") == "1"
-
-
-def pack_lstm_steps_weights(w_hh_dirs):
-    """list over directions of W_hh [4H, H] fp32 -> (HL32 stack [ndir][4H][H/32][128 B] bytes, inverse prescales [ndir])"""
-    H = w_hh_dirs[0].shape[1]
-    w_hl, sc = pack_weights_hl32([w.detach().contiguous().view(4 * H, 1, 1, H) for w in w_hh_dirs])
-    return w_hl, sc[:, 1].contiguous()
-
-
-def lstm_layer_x3_steps(xproj, w_hl, w_inv, b_hh, hidden, ndir):
-    """xproj [G,B,T,ndir*4H]; w_hl [G, bytes] HL32 stacks and w_inv [G,ndir] (pack_lstm_steps_weights per expert), b_hh [G,ndir*4H]
-    -> [G,B,T,ndir*H]: mrn_lstm_layer_fwd_x3_steps (one kernel per time step, replayed from a HIP graph)"""
-    _chk(xproj, b_hh)
-    G, B, T, _ = xproj.shape
-    assert xproj.is_contiguous() and w_hl.is_contiguous() and w_inv.is_contiguous() and b_hh.is_contiguous()
-    out = torch.empty(G, B, T, ndir * hidden, device=xproj.device, dtype=torch.float32)
-    for g0 in range(0, G, 8):
-        n = min(8, G - g0)
-        nbytes = call("mrn_lstm_steps_workspace_bytes", n, B, ndir)
-        ws = torch.empty(nbytes, device=xproj.device, dtype=torch.uint8)
-        rng = range(g0, g0 + n)
-        call("mrn_lstm_layer_fwd_x3_steps", _ptr_array([xproj[g].data_ptr() for g in rng]), _ptr_array([w_hl[g].data_ptr() for g in rng]),
-             _ptr_array([w_inv[g].data_ptr() for g in rng]), _ptr_array([b_hh[g].data_ptr() for g in rng]),
-             _ptr_array([out[g].data_ptr() for g in rng]), n, B, T, hidden, ndir, _p(ws), nbytes, _stream())
-    return out
+# Measured and removed in round 4 (DESIGN.md section 7 keeps the numbers): a weight-stationary LSTM (W_hh slices in the LDS of 16 workgroups per
+# (expert, direction), h exchanged every step: 22.3 vs 17.1 us / step at G = 3) and the layers as one small kernel per time step replayed from
+# a HIP graph (G = 1 13.0 -> 16.6, G = 3 17.2 -> 18.3, G = 6 22.3 -> 19.9 us / step).  The streaming kernels above are the product path.
 
 
 def lstm_layer_grouped(xproj, w_hh, b_hh, hidden, ndir):
@@ -1927,32 +1859,6 @@ def svtr_mixer_fused(x, pending, drop_prev, g1, b1, eps1, wqkv_hl, sqkv, bqkv, m
         rows = imgs * N
         CONV_TIMER.end(t0, 2.0 * rows * C * 4 * C + 4.0 * rows * N * C, "fp16x3/svtrmixer", 4.0 * rows * C * (4 if pending is not None else 3))
     return x_out, y_hl
-
-
-# ... and the Mlp half in the same kernel (whole Block.forward, mrn_svtr_block_x3_f32): built, parity-tested, and measured SLOWER than the two
-# half-block kernels (C = 128, 256 tokens: 1038 vs 965 us; C = 64, 512 tokens: 1162 vs 1072 us per block of 6 x 256 images) -- the
-# attention half runs one 8-wave workgroup per CU at 256 registers, and the Mlp phase inherits that occupancy, while the stand-alone Mlp
-# kernel (96 registers) runs two workgroups per CU; the 3 tensor passes it saves do not pay for that.  Opt-in: MRN_SVTR_BLOCK=fused.
-SVTR_FUSED_BLOCK = os.environ.get("MRN_SVTR_BLOCK", "half") == "fused"
-
-
-def svtr_block_fused(x, pending, drop_prev, g1, b1, eps1, wqkv_hl, sqkv, bqkv, mask, scale, wproj_hl, sproj, bproj, drop1, g2, b2, eps2,
-                     w1_hl, s1, bm1, w2_hl, s2, bm2, drop2, imgs_per_group):
-    """x [imgs, N, C] -> the residual stream after one whole mixing block (mrn_svtr_block_x3_f32); w1_hl packed from the input-permuted
-    fc1 weights, w2_hl from the hidden-permuted fc2 weights, wproj_hl from the input-permuted proj weights (mlp_hidden_permutation)"""
-    _chk(x, pending, drop_prev, g1, b1, bqkv, bproj, drop1, g2, b2, bm1, bm2, drop2)
-    imgs, N, C = x.shape
-    assert x.is_contiguous() and (pending is None or (pending.is_contiguous() and pending.numel() == x.numel()))
-    x_out = torch.empty_like(x)
-    bits = _mask_bits(mask) if mask is not None else None
-    t0 = CONV_TIMER.begin() if CONV_TIMER is not None else None
-    call("mrn_svtr_block_x3_f32", _p(x), _p(pending), _p(drop_prev), _p(g1), _p(b1), float(eps1), _p(wqkv_hl), _p(sqkv), _p(bqkv),
-         _p(bits), float(scale), _p(wproj_hl), _p(sproj), _p(bproj), _p(drop1), _p(g2), _p(b2), float(eps2), _p(w1_hl), _p(s1), _p(bm1),
-         _p(w2_hl), _p(s2), _p(bm2), _p(drop2), _p(x_out), imgs, imgs_per_group, N, C, _stream())
-    if t0 is not None:
-        rows = imgs * N
-        CONV_TIMER.end(t0, 2.0 * rows * C * 12 * C + 4.0 * rows * N * C, "fp16x3/svtrblock", 4.0 * rows * C * (3 if pending is not None else 2))
-    return x_out
 
 
 SVTR_ATTN_BLOCK = os.environ.get("MRN_SVTR_ATTN_BLOCK", "1") == "1"      # stage 3 (C = 256): LayerNorm1 -> qkv -> attention in one kernel

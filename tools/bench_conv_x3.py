@@ -68,7 +68,6 @@ def main():
                 print(f"conv G{G} B{B} {H}x{W} {Cin}->{Cout} k{k[0]}x{k[1]}: x3g {ms:8.3f} ms {flops / ms / 1e9:7.1f} TF", flush=True)
                 continue
             ops.CONV_PRECISION = "fp16x3"
-            ops.DMA_MIN_CIN = 0
             pw = [ops.PackedConvWeight(w) for w in ws]
 
             def old():
@@ -76,7 +75,7 @@ def main():
                     ops.conv2d_nhwc(xs[g], pw[g], None, s, p, want_stats=True)
             ms_old = timeit(old, reps)
             ms_split = timeit(lambda: ops.split_hl32(x), reps)
-            print(f"conv G{G} B{B} {H}x{W} {Cin}->{Cout} k{k[0]}x{k[1]}: x3g {ms:8.3f} ms {flops / ms / 1e9:7.1f} TF | old(dma+split) {ms_old:8.3f} ms "
+            print(f"conv G{G} B{B} {H}x{W} {Cin}->{Cout} k{k[0]}x{k[1]}: x3g {ms:8.3f} ms {flops / ms / 1e9:7.1f} TF | per-expert (G = 1 launches) {ms_old:8.3f} ms "
                   f"{flops / ms_old / 1e9:7.1f} TF | split_hl32 {ms_split:6.3f} ms | rel err {err:.2e} stats {serr:.2e}", flush=True)
 
 

@@ -64,20 +64,15 @@ def main():
         w2 = [torch.randn(C, Ch, device=dev) * Ch ** -0.5 for _ in range(G)]
         bm1, bm2 = torch.randn(G, Ch, device=dev) * 0.1, torch.randn(G, C, device=dev) * 0.1
         ph = ops.mlp_hidden_permutation(Ch, dev)
-        w1p, s1 = ops.pack_weights_hl32([w.index_select(1, perm).contiguous().view(Ch, 1, 1, C) for w in w1])
         w1n, s1n = ops.pack_weights_hl32([w.view(Ch, 1, 1, C).contiguous() for w in w1])
         w2p, s2 = ops.pack_weights_hl32([w.index_select(1, ph).contiguous().view(C, 1, 1, Ch) for w in w2])
-
-        def block():
-            return ops.svtr_block_fused(x, pend, dprev, g1, b1, 1e-6, wq, sq, bqkv, mask, 32 ** -0.5, wp, sp, bproj, d1, g1, b1, 1e-6,
-                                        w1p, s1, bm1, w2p, s2, bm2, d1, B)
 
         def halves():
             xo, yhl = fused()
             return ops.svtr_mlp_fused(yhl, G * rows, rows, G, C, w1n, s1n, bm1, w2p, s2, bm2)
 
-        ms_b, ms_h = timeit(block, reps), timeit(halves, reps)
-        print(f"C{C} N{N} ({H}x{W}) {'local ' if local else 'global'}: whole block {ms_b * 1e3:7.1f} us  mixer + Mlp kernels {ms_h * 1e3:7.1f} us", flush=True)
+        ms_h = timeit(halves, reps)
+        print(f"C{C} N{N} ({H}x{W}) {'local ' if local else 'global'}: mixer + Mlp kernels {ms_h * 1e3:7.1f} us", flush=True)
         ms_f = timeit(fused, reps)
         ms_c = float("nan") if only_fused else timeit(chain, reps)
         flops = 2.0 * G * rows * C * 4 * C + 4.0 * G * rows * N * C
