@@ -57,6 +57,11 @@ def build_library(force=False, verbose=True, jobs=4):
         for f in os.listdir(OBJ):
             os.remove(os.path.join(OBJ, f))
     srcs = sources()
+    for f in os.listdir(OBJ):                     # objects of sources that no longer exist (tools/build_probe.sh links the directory)
+        if f.endswith(".o") and f[:-2] not in srcs:
+            os.remove(os.path.join(OBJ, f))
+            if os.path.exists(os.path.join(OBJ, f + ".sha1")):
+                os.remove(os.path.join(OBJ, f + ".sha1"))
     with ThreadPoolExecutor(max_workers=jobs) as ex:
         results = list(ex.map(_compile, srcs))
     objs = [o for o, _ in results]

@@ -25,6 +25,7 @@
 // backbones in lock-step): weights / bias / scales / outputs / statistics are [G]-strided, the input is either
 // [G]-strided or shared (x_gstride = 0).  Tiles never straddle a group.
 #include "common.hpp"
+#include "conv_wino.hpp"
 #include <stdlib.h>
 
 namespace {
@@ -1337,8 +1338,20 @@ MRN_EXPORT int mrn_pack_weight_wino_hl32(const float* w_ohwi, void* out, int Cou
   return MRN_OK;
 }
 
+// row blocks of the BatchNorm partial statistics of one group: the x3 kernel writes one per 128 GEMM rows; the row-block kernel
+// (conv_wino.hip, H % 4 == 0) one per (64 positions, 4 output rows) and clears the rest
+static int wino_stats_blocks(int B, int H, int W, int Cout, int R) {
+  const int Wq = ceil_div(W, R);
+  int blocks = ceil_div((long)B * H * Wq, 128);
+  if (mrn_wino_rows_supported(H, R, Cout)) {
+    const int rows = ceil_div((long)B * Wq, 64) * (H / 4);
+    blocks = blocks > rows ? blocks : rows;
+  }
+  return blocks;
+}
+
 MRN_EXPORT int64_t mrn_conv2d_x3_wino_stats_floats(int G, int B, int H, int W, int Cout, int R) {
-  return (int64_t)G * ceil_div((long)B * H * ceil_div(W, R), 128) * 2 * Cout;
+  return (int64_t)G * wino_stats_blocks(B, H, W, Cout, R) * 2 * Cout;
 }
 
 // Grouped 3x3 / stride 1 / pad 1 convolution as 1-D Winograd F(R,3) along W on the x3 kernel (see conv_x3_kernel, WINO):
@@ -1356,6 +1369,18 @@ MRN_EXPORT int mrn_conv2d_x3_wino_hl32(const void* v_hl, const void* u_hl, const
   MRN_CHECK_ARG(H > 0 && W > 0 && B >= 0, "mrn_conv2d_x3_wino_hl32: empty output");
   MRN_CHECK_ARG((long)B * H * Wq * NC * Cin * 4 < (1L << 31) && (long)Cout * 3 * NC * Cin * 4 < (1L << 31),
                 "mrn_conv2d_x3_wino_hl32: one group's activation / weight must stay below 2 GiB (32-bit buffer offsets)");
+  if (mrn_wino_rows_supported(H, R, Cout)) {      // the row-block kernel (conv_wino.hip): 4-row maps and multiples
+    if ((long)B * H * Wq == 0) return MRN_OK;
+    WinoRowsParams q;
+    memset(&q, 0, sizeof(q));
+    q.v = (const unsigned char*)v_hl; q.u = (const unsigned char*)u_hl; q.bias = bias; q.out_scale = out_scale; q.x_scale = x_scale;
+    q.y = y; q.stats = stats;
+    q.v_gstride = v_group_stride_bytes; q.u_gstride = (long)Cout * 3 * NC * Cin * 4; q.y_gstride = (long)B * H * W * Cout;
+    q.v_bytes = (int)((long)B * H * Wq * NC * Cin * 4);
+    q.G = G; q.B = B; q.H = H; q.W = W; q.Wq = Wq; q.Cb = Cin / 32; q.N = Cout; q.act = act;
+    q.stats_blocks = wino_stats_blocks(B, H, W, Cout, R);
+    return mrn_launch_wino_rows(q, stream);
+  }
   ConvX3Params p;
   memset(&p, 0, sizeof(p));
   p.x = (const unsigned char*)v_hl; p.w = (const unsigned char*)u_hl; p.zero = (const unsigned char*)zero_page;

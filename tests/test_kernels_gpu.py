@@ -876,6 +876,8 @@ WINO_CONVS = [
     (6, 2, 4, 65, 512, 512, "none", True),       # the dominant TRBA shape
     (2, 64, 4, 64, 32, 128, "none", True),       # B * ceil(W/R) a multiple of the tile height: class-ordered tile schedule
     (3, 16, 3, 32, 64, 128, "hl32", True),       #   (R = 4: 16 * 8 = 128) one interior row
+    (2, 2, 16, 32, 32, 64, "none", True),        # four row blocks of the row-block kernel (conv_wino.hip): first / interior / last
+    (1, 3, 12, 20, 64, 96, "f32", False),        # three row blocks, signed inputs, Cout and positions not tile multiples
 ]
 
 
