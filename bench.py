@@ -290,6 +290,13 @@ def describe_kernel(kind):
     if kind.startswith("gemm_f32"):
         return ("gemm_f32_kernel (exact-fp32 MFMA GEMM, v_mfma_f32_32x32x2_f32)", FP32_MFMA_PEAK_TFLOPS, 1)
     arith, staging = kind.split("/")
+    if staging.startswith("winorows"):
+        R = int(staging[8])
+        return (f"wino_rows_kernel (grouped 3x3 conv of all experts as 1-D Winograd F({R},3) along W, row-block form: a workgroup owns 64 "
+                f"positions x 4 output rows x 64 channels, one wave per SIMD (453 registers), every input row staged once per (component, "
+                f"channel block) and used by up to three (kernel row, output row) products, {arith} on v_mfma_f32_32x32x16_f16, operands "
+                f"staged by buffer_load...lds through a 3-deep activation ring + 2-deep weight ring)",
+                BF16_MFMA_PEAK_TFLOPS, 3.0 * (R + 2) / (3 * R))
     if staging.startswith("wino"):
         R = int(staging[4])
         return (f"conv_x3_kernel<2, 4, 2, 1, false, 3, {R}> (grouped 3x3 conv of all experts as 1-D Winograd F({R},3) along W: "
@@ -770,6 +777,10 @@ def main():
         if world == 1 and args.model == "trba" and args.precision == "auto" and not args.no_reduced:
             # the reduced-precision mode BASELINE configs 2 ("bf16") and 5 ("fp16 MFMA") name, driver-timed in the default run: ONE fp16
             # product per term (fp16 keeps 11 significand bits where bf16 keeps 8; same MFMA rate), fp32 accumulate -- short lines
+            # BASELINE config 5 in the PARITY mode (split-fp16 x3 products everywhere): the DER step over six TRBA extractors, short line
+            reduced["der"] = {k: v for k, v in time_der_step(args, opt, rank, world, 3, 2).items()
+                              if k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "trainable_parameters")}
+            torch.cuda.empty_cache()
             saved = (ops.X3_PRODUCTS, ops.TRAIN_PRODUCTS)
             ops.X3_PRODUCTS = ops.TRAIN_PRODUCTS = 1
             try:

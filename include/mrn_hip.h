@@ -144,6 +144,10 @@ int mrn_maxpool_wino_grouped_f32(const float* x, const float* scale, const float
                                  void* out_wino, int G, int B, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw,
                                  int R, void* stream);
 int64_t mrn_conv2d_x3_wino_stats_floats(int G, int B, int H, int W, int Cout, int R);
+/* which kernel mrn_conv2d_x3_wino_hl32 runs: 1 = the row-block kernel (csrc/conv_wino.hip: R = 4, H % 4 == 0, Cout % 4 == 0 -- a workgroup
+ * owns 64 positions x 4 output rows x 64 channels and stages every input row once per (component, channel block)), 0 = the x3 kernel's
+ * Winograd form (one output row per tile).  Same operands and results either way (telemetry, statistics-buffer sizing). */
+int64_t mrn_conv2d_x3_wino_rows(int H, int R, int Cout);
 int mrn_conv2d_x3_wino_hl32(const void* v_hl, const void* u_hl, const void* zero_page, const float* bias, float* y, float* stats,
                             const float* out_scale, const float* x_scale, int G, int64_t v_group_stride_bytes, int B, int H, int W,
                             int Cin, int Cout, int R, int act, void* stream);

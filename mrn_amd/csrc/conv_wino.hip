@@ -196,8 +196,9 @@ __device__ __forceinline__ void wino_rows_tile(const WinoRowsParams& p, unsigned
         const int ks2 = (r + 1) / NR, slot2 = LO + (r + 1) % NR;
         if (ks2 != ks) read_B(b_st, ks2);
         read_A(a_st, slot2, ks2, par ^ 1);
-      } else if (s + 1 < nsteps) {
-        // step boundary: own fragment reads of this step are complete, own DMAs of the next step's operands have landed (the younger
+      } else {
+        // step boundary (also after the last step, where the reads below fetch a stale stage that nothing uses: a branch here makes the
+        // compiler wait for ALL of them before the MFMAs that follow -- its wait counts are merged over both paths): own fragment reads of this step are complete, own DMAs of the next step's operands have landed (the younger
         // ones -- activation lines of the step after it -- may still fly); after the barrier everyone's have, and this step's stages are free
         __builtin_amdgcn_s_waitcnt(WAIT_BOUNDARY);
 #ifndef MRN_WPROBE_NO_BARRIER

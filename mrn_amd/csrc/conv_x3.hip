@@ -1350,6 +1350,9 @@ static int wino_stats_blocks(int B, int H, int W, int Cout, int R) {
   return blocks;
 }
 
+// 1 when mrn_conv2d_x3_wino_hl32 runs this geometry on the row-block kernel (conv_wino.hip), 0 for the x3 kernel's Winograd form
+MRN_EXPORT int64_t mrn_conv2d_x3_wino_rows(int H, int R, int Cout) { return mrn_wino_rows_supported(H, R, Cout) ? 1 : 0; }
+
 MRN_EXPORT int64_t mrn_conv2d_x3_wino_stats_floats(int G, int B, int H, int W, int Cout, int R) {
   return (int64_t)G * wino_stats_blocks(B, H, W, Cout, R) * 2 * Cout;
 }

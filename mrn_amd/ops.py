@@ -656,7 +656,7 @@ def conv2d_x3_wino(v_hl, G, shared_input, B, H, W, Cin, u_hl, u_scale, Cout, R, 
     if timed:
         # algorithmic flops = the convolution's (2 * 9 * Cin per output element); the kernel executes (R+2)/(3R) of them as MFMA products
         nbytes = 4.0 * ((1 if shared_input else G) * B * H * Wq * (R + 2) * Cin + G * Cout * 3 * (R + 2) * Cin + G * B * H * W * Cout)
-        kind = "fp16x3/wino%dg128x128" % R
+        kind = ("fp16x3/winorows%d" if call("mrn_conv2d_x3_wino_rows", H, R, Cout) else "fp16x3/wino%dg128x128") % R
         if TIMER_SHAPES:
             kind += "|G%d B%d %dx%d %d->%d k3x3 s11" % (G, B, H, W, Cin, Cout)
         CONV_TIMER.end(t0, 2.0 * G * B * H * W * Cout * 9 * Cin, kind, nbytes)

@@ -28,6 +28,9 @@ def main():
         res = torch.rand(G, B, H, W, C, device="cuda")
         scale, shift = torch.rand(G, C, device="cuda"), torch.rand(G, C, device="cuda")
         n = y.numel() * 4
+        dst = torch.empty_like(y)
+        ms = timeit(lambda: dst.copy_(y))
+        print(f"torch copy {H}x{W}x{C} ({n / 1e6:.0f} MB in + out)   {ms:7.3f} ms  {2 * n / ms / 1e6:7.0f} GB/s")
         for name, kw, nb in [("hl only", dict(want_f32=False, want_hl=True), 2 * n),
                              ("res + f32 + hl", dict(residual=res, want_f32=True, want_hl=True), 4 * n),
                              ("res + hl", dict(residual=res, want_f32=False, want_hl=True), 3 * n)]:

@@ -11,5 +11,6 @@ cd $R
 python3 tools/rocprof_summary.py gpurun_out/$tag/prof/trace_results.db 3 > gpurun_out/$tag/summary.md 2>&1
 python3 tools/rocprof_timeline.py gpurun_out/$tag/prof/trace_results.db > gpurun_out/$tag/timeline.txt 2>&1
 python3 tools/rocprof_copies.py gpurun_out/$tag/prof/trace_results.db > gpurun_out/$tag/copies.txt 2>&1
+python3 tools/rocprof_step.py gpurun_out/$tag/prof/trace_results.db ${MARKER:-adam_kernel} ${STEP_LIST:+--list} > gpurun_out/$tag/step.md 2>&1
 rm -rf gpurun_out/$tag/prof
 tail -1 gpurun_out/$tag/prof.log | cut -c1-300
