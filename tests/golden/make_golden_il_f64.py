@@ -1,8 +1,8 @@
-"""The float64 yardstick of the TRBA learner flows: the REFERENCE learners of make_golden_il.py / make_golden_il2.py (LwF, EWC, DER,
+"""The float64 yardstick of the TRBA / CRNN learner flows: the REFERENCE learners of make_golden_il.py / make_golden_il2.py (LwF, EWC, DER,
 WA, Joint driven through incremental_train() over two tasks) run once more in float64 arithmetic -- same deterministic weights
 (fp32 values, widened), same deterministic batches -- and only the parameter movement of the task's optimiser steps is stored:
 
-    python tests/golden/make_golden_il_f64.py            # -> tests/golden/il_trba_f64.npz   (build container only)
+    python tests/golden/make_golden_il_f64.py            # -> tests/golden/il_{trba,crnn}_f64.npz   (build container only)
 
 Why: Adam normalises every element's update to ~lr, so after two steps the movement of elements whose gradient is near zero has an
 essentially arbitrary sign in ANY fp32 implementation.  tests/test_il_golden_gpu.py therefore judges the HIP movement against this
@@ -51,28 +51,29 @@ def main():
                     setattr(m, name, getattr(m, name).double())
         fill(learner, seed)
     G.det_fill = det_fill64
-    d = {}
-    tmp = tempfile.mkdtemp()
-    cwd = os.getcwd()
-    os.chdir(tmp)
-    os.makedirs("./saved_models/g", exist_ok=True)
-    try:
-        for which in ("lwf", "ewc", "der"):
-            for k, v in G.run_learner("trba", which).items():
-                if "/delta/" in k or k.endswith("param_keys") or k.endswith("/losses"):
-                    d[f"{which}/{k}"] = v
-            for f in os.listdir("./saved_models/g"):
-                os.remove(os.path.join("./saved_models/g", f))
-        for which, fn in (("wa", G2.run_wa), ("joint", G2.run_joint)):
-            for k, v in fn("trba").items():
-                if "/delta/" in k or k.endswith("param_keys") or k.endswith("/losses"):
-                    d[f"{which}/{k}"] = v
-            for f in os.listdir("./saved_models/g"):
-                os.remove(os.path.join("./saved_models/g", f))
-    finally:
-        os.chdir(cwd)
-    np.savez_compressed(os.path.join(OUT, "il_trba_f64.npz"), **d)
-    print("il_trba_f64.npz:", len(d), "arrays")
+    for kind in ("trba", "crnn"):
+        d = {}
+        tmp = tempfile.mkdtemp()
+        cwd = os.getcwd()
+        os.chdir(tmp)
+        os.makedirs("./saved_models/g", exist_ok=True)
+        try:
+            for which in ("lwf", "ewc", "der"):
+                for k, v in G.run_learner(kind, which).items():
+                    if "/delta/" in k or k.endswith("param_keys") or k.endswith("/losses"):
+                        d[f"{which}/{k}"] = v
+                for f in os.listdir("./saved_models/g"):
+                    os.remove(os.path.join("./saved_models/g", f))
+            for which, fn in (("wa", G2.run_wa), ("joint", G2.run_joint)):
+                for k, v in fn(kind).items():
+                    if "/delta/" in k or k.endswith("param_keys") or k.endswith("/losses"):
+                        d[f"{which}/{k}"] = v
+                for f in os.listdir("./saved_models/g"):
+                    os.remove(os.path.join("./saved_models/g", f))
+        finally:
+            os.chdir(cwd)
+        np.savez_compressed(os.path.join(OUT, f"il_{kind}_f64.npz"), **d)
+        print(f"il_{kind}_f64.npz:", len(d), "arrays")
 
 
 if __name__ == "__main__":
