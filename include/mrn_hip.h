@@ -148,6 +148,9 @@ int64_t mrn_conv2d_x3_wino_stats_floats(int G, int B, int H, int W, int Cout, in
  * owns 64 positions x 4 output rows x 64 channels and stages every input row once per (component, channel block)), 0 = the x3 kernel's
  * Winograd form (one output row per tile).  Same operands and results either way (telemetry, statistics-buffer sizing). */
 int64_t mrn_conv2d_x3_wino_rows(int H, int R, int Cout);
+/* process-wide A/B switch of that choice: -1 default (row-block kernel unless MRN_WINO_ROWS=0), 0 always the x3 kernel's form, 1 the
+ * row-block kernel wherever it applies; size statistics buffers after the call */
+int mrn_conv2d_x3_wino_select(int mode);
 int mrn_conv2d_x3_wino_hl32(const void* v_hl, const void* u_hl, const void* zero_page, const float* bias, float* y, float* stats,
                             const float* out_scale, const float* x_scale, int G, int64_t v_group_stride_bytes, int B, int H, int W,
                             int Cin, int Cout, int R, int act, void* stream);

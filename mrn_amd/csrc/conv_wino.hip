@@ -350,8 +350,12 @@ __global__ __launch_bounds__(256) void wino_rows_kernel(const WinoRowsParams p) 
 
 }  // namespace
 
+static int g_rows_mode = -1;      // -1: MRN_WINO_ROWS from the environment (default on); 0 / 1: set by mrn_conv2d_x3_wino_select (A/B runs, tests)
+void mrn_wino_rows_select(int mode) { g_rows_mode = mode; }
+
 bool mrn_wino_rows_supported(int H, int R, int Cout) {
-  static const bool off = getenv("MRN_WINO_ROWS") && atoi(getenv("MRN_WINO_ROWS")) == 0;      // A/B switch: 0 = the x3 kernel's Winograd form
+  static const bool env_off = getenv("MRN_WINO_ROWS") && atoi(getenv("MRN_WINO_ROWS")) == 0;   // A/B switch: 0 = the x3 kernel's Winograd form
+  const bool off = g_rows_mode >= 0 ? g_rows_mode == 0 : env_off;
   return !off && R == 4 && H % 4 == 0 && H >= 4 && Cout >= 32 && Cout % 4 == 0;
 }
 

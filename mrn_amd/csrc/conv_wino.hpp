@@ -18,4 +18,5 @@ struct WinoRowsParams {
 };
 
 bool mrn_wino_rows_supported(int H, int R, int Cout);
+void mrn_wino_rows_select(int mode);
 int mrn_launch_wino_rows(const WinoRowsParams& p, void* stream);

@@ -1351,6 +1351,13 @@ static int wino_stats_blocks(int B, int H, int W, int Cout, int R) {
 }
 
 // 1 when mrn_conv2d_x3_wino_hl32 runs this geometry on the row-block kernel (conv_wino.hip), 0 for the x3 kernel's Winograd form
+// A/B switch of the same choice for the whole process: -1 = default (row-block kernel unless MRN_WINO_ROWS=0), 0 = always the x3
+// kernel's Winograd form, 1 = the row-block kernel wherever it applies.  Statistics buffers must be sized AFTER the call.
+MRN_EXPORT int mrn_conv2d_x3_wino_select(int mode) {
+  mrn_wino_rows_select(mode);
+  return MRN_OK;
+}
+
 MRN_EXPORT int64_t mrn_conv2d_x3_wino_rows(int H, int R, int Cout) { return mrn_wino_rows_supported(H, R, Cout) ? 1 : 0; }
 
 MRN_EXPORT int64_t mrn_conv2d_x3_wino_stats_floats(int G, int B, int H, int W, int Cout, int R) {

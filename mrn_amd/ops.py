@@ -4,6 +4,7 @@ PyTorch is used here only for device memory (caching allocator), the current HIP
 arithmetic operation is a call into libmrn_hip.so.  All tensors must be fp32 CUDA tensors.
 """
 import os
+import sys
 import weakref
 
 import torch
@@ -589,6 +590,7 @@ def conv2d_x3(x_hl, G, shared_input, B, H, W, Cin, w_hl, w_scale, Cout, ksize, s
 # comes from a train-mode BatchNorm-apply pass (csrc/conv_x3.hip WINO, csrc/group_ops.hip): R = 4 halves the matrix work of
 # the dominant 512 -> 512 layers.  MRN_WINO=0 switches it off (A/B), MRN_WINO=2 selects F(2,3).
 WINO_R = int(os.environ.get("MRN_WINO", "4"))
+WINO_CHECK = os.environ.get("MRN_WINO_CHECK") == "1"      # debug: every row-block Winograd launch is re-run on the x3 kernel and compared
 WINO_MIN_CIN = int(os.environ.get("MRN_WINO_MIN_CIN", "128"))
 TRAIN_WINO = os.environ.get("MRN_TRAIN_WINO", "1") == "1"      # the trained convolutions of loop A too (forward + data gradient)
 # range target of the power-of-two scale of a TRAINED convolution's activation / gradient operand: the Winograd input transform B^T
@@ -653,6 +655,27 @@ def conv2d_x3_wino(v_hl, G, shared_input, B, H, W, Cin, u_hl, u_scale, Cout, R, 
     t0 = CONV_TIMER.begin() if timed else None
     call("mrn_conv2d_x3_wino_hl32", _p(v_hl), _p(u_hl), _p(_zero_page(dev)), _p(bias), _p(y), _p(stats), _p(u_scale), _p(x_scale), G, gstride,
          B, H, W, Cin, Cout, R, act, _stream())
+    if WINO_CHECK and call("mrn_conv2d_x3_wino_rows", H, R, Cout):
+        # debug (MRN_WINO_CHECK=1): the same call on the x3 kernel's Winograd form, compared element by element
+        call("mrn_conv2d_x3_wino_select", 0)
+        y2 = torch.empty_like(y)
+        st2 = torch.empty(call("mrn_conv2d_x3_wino_stats_floats", G, B, H, W, Cout, R), device=dev, dtype=torch.float32) if want_stats else None
+        call("mrn_conv2d_x3_wino_hl32", _p(v_hl), _p(u_hl), _p(_zero_page(dev)), _p(bias), _p(y2), _p(st2), _p(u_scale), _p(x_scale), G, gstride,
+             B, H, W, Cin, Cout, R, act, _stream())
+        call("mrn_conv2d_x3_wino_select", -1)
+        if want_stats:
+            a1, a2 = stats.view(G, -1, 2, Cout).sum(1), st2.view(G, -1, 2, Cout).sum(1)
+            print(f"[wino check] stats blocks {stats.numel() // (2 * Cout * G)} vs {st2.numel() // (2 * Cout * G)}: sum diff "
+                  f"{float((a1[:, 0] - a2[:, 0]).abs().max()):.3e} of {float(a2[:, 0].abs().max()):.3e}, sq diff "
+                  f"{float((a1[:, 1] - a2[:, 1]).abs().max()):.3e} of {float(a2[:, 1].abs().max()):.3e}", flush=True, file=sys.__stderr__)
+        d = float((y - y2).abs().max())
+        sc = float(y2.abs().max())
+        bad = int(((y - y2).abs() > 1e-4 * sc + 1e-30).sum())
+        print(f"[wino check] G{G} B{B} {H}x{W} {Cin}->{Cout} stats={want_stats} x_scale={x_scale is not None}: max diff {d:.3e} of {sc:.3e}, {bad} bad", flush=True, file=sys.__stderr__)
+        if bad:
+            idx = ((y - y2).abs() > 1e-4 * sc + 1e-30).nonzero()
+            print("   first bad indices [g,b,y,x,c]:", idx[:6].tolist(), "x range", int(idx[:, 3].min()), int(idx[:, 3].max()),
+                  "c range", int(idx[:, 4].min()), int(idx[:, 4].max()), "y set", sorted(set(idx[:, 2].tolist())), flush=True, file=sys.__stderr__)
     if timed:
         # algorithmic flops = the convolution's (2 * 9 * Cin per output element); the kernel executes (R+2)/(3R) of them as MFMA products
         nbytes = 4.0 * ((1 if shared_input else G) * B * H * Wq * (R + 2) * Cin + G * Cout * 3 * (R + 2) * Cin + G * B * H * W * Cout)
