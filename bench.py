@@ -31,15 +31,15 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0                         # MI355X_MICROARCH.md: de
 HBM_PEAK_GBS = 8000.0                                  # MI355X_MICROARCH.md: HBM3E peak (6.3 TB/s achievable on a float4 copy)
 
 
-PMC_SOURCE = ("static: profiles/r03_pmc.json -- separate rocprofv3 --pmc passes of this same command (tools/pmc_pass.sh), "
+PMC_SOURCE = ("static: profiles/r04_pmc.json -- separate rocprofv3 --pmc passes of this same command (tools/pmc_pass.sh), "
               "FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE; counters cannot be read from inside the timed run")
 
 
-def pmc_traffic(kernel_name):
+def pmc_traffic(kernel_name, section="kernels"):
     """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes (profiles/r01_pmc.json, produced by
     tools/pmc_pass.sh on this same command): FETCH_SIZE x 2 (the gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE,
     both KiB counters.  None when the kernel has no entry (counters cannot be read from inside the timed run)."""
-    for name in ("r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
+    for name in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             break
@@ -48,7 +48,9 @@ def pmc_traffic(kernel_name):
     with open(path) as f:
         pmc = json.load(f)
     key = kernel_name.split(" (")[0]
-    kernels = pmc.get("kernels", {})
+    kernels = pmc.get(section)
+    if kernels is None:          # (no pass of that workload in this file: no figure rather than another workload's)
+        return None
     ent = kernels.get(key)
     if ent is None:          # (template arguments the description leaves out: bn_apply_wino_grouped_kernel<4>)
         ent = next((v for k, v in kernels.items() if k.startswith(key + "<")), None)
@@ -320,8 +322,9 @@ def describe_kernel(kind):
     raise ValueError(f"unknown KernelTimer kind {kind!r}")
 
 
-def roofline_entries(kinds, steps, elapsed_s):
-    """KernelTimer.summary() -> (MFMA-bound entries sorted by share of the step, HBM-bound entries)"""
+def roofline_entries(kinds, steps, elapsed_s, pmc_section="kernels"):
+    """KernelTimer.summary() -> (MFMA-bound entries sorted by share of the step, HBM-bound entries); pmc_section: which workload's PMC
+    passes of the committed profile the `traffic` figures come from (loop A launches G = 1 kernels: its own passes)"""
     rl, hbm = [], []
     for kind, s_ in kinds.items():
         if kind.startswith("hbm/"):
@@ -331,7 +334,7 @@ def roofline_entries(kinds, steps, elapsed_s):
                     "bn_apply_wino_grouped": "BatchNorm-apply + residual + ReLU + Winograd input transform B^T over all experts, fp32 in, "
                                              "transformed HL32 operand (6 components per 4 columns) [+ plain HL32] out"}.get(kind[4:], kind[4:])
             hbm.append({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                        "traffic": pmc_traffic(kind[4:] + "_kernel"), "kernel": f"{kind[4:]}_kernel ({what})",
+                        "traffic": pmc_traffic(kind[4:] + "_kernel", pmc_section), "kernel": f"{kind[4:]}_kernel ({what})",
                         "algorithmic_bytes_per_launch": s_["total_bytes"] / s_["launches"],
                         "launches_per_step": s_["launches"] / steps, "avg_launch_ms": s_["union_ms"] / s_["launches"],
                         "avg_launch_ms_raw_event": s_["total_ms"] / s_["launches"],
@@ -345,7 +348,7 @@ def roofline_entries(kinds, steps, elapsed_s):
         ach = per_launch / (avg_ms * 1e-3) / 1e12
         kname, peak, per_flop = describe_kernel(kind)
         rl.append({"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                   "traffic": pmc_traffic(kname), "traffic_source": PMC_SOURCE,
+                   "traffic": pmc_traffic(kname, pmc_section), "traffic_source": PMC_SOURCE,
                    "algorithmic_bytes_per_launch": s_.get("total_bytes", 0.0) / s_["launches"],
                    "kernel": kname, "mfma_flops_per_algorithmic_flop": per_flop,
                    "mfma_issue_frac": ach * per_flop / peak,
@@ -392,7 +395,7 @@ def time_loop_a(args, opt, rank, world, steps, warmup, with_cpu_baseline=False):
            "warmup": warmup, "per_gpu_batch": args.batch, "trainable_parameters": n_params, "loss": float(loss.detach()),
            "dtype": train_dtype()}
     if timer is not None and timer.spans:
-        rl, hbm = roofline_entries(timer.summary(), steps, elapsed)
+        rl, hbm = roofline_entries(timer.summary(), steps, elapsed, pmc_section="kernels_loop_a" if args.model == "trba" else "none")
         if rl:
             res["roofline"] = rl[0]
             res["roofline"]["measured"] = ("timed region: HIP events per launch on the launch stream (forward, data-gradient and weight-gradient "
@@ -743,7 +746,8 @@ def main():
                                                  "rate); bench.py --precision fp16, and extra.fp16_loop_b / extra.fp16_der in this line"},
         }
         if timer is not None and timer.spans:
-            rl, hbm = roofline_entries(timer.summary(), args.steps, elapsed)
+            rl, hbm = roofline_entries(timer.summary(), args.steps, elapsed,
+                                       pmc_section="kernels" if (args.model, args.experts, args.batch) == ("trba", 6, 256) else "none")
             res["roofline"] = rl[0]
             if probe is not None:
                 res["roofline"]["power_probe"] = probe

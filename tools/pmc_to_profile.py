@@ -9,13 +9,9 @@ import json
 import sys
 
 
-def main():
-    d = json.load(open(sys.argv[1]))
-    cmd = sys.argv[2] if len(sys.argv) > 2 else "bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timer"
+def kernels_of(d):
     names = set(d.get("FETCH_SIZE", {})) | set(d.get("WRITE_SIZE", {}))
-    out = {"command": "rocprofv3 --pmc <group> --kernel-trace -- python3 " + cmd + "  (one run per counter group, tools/pmc_pass.sh)",
-           "units": "FETCH_SIZE / WRITE_SIZE in KiB; hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / launches",
-           "kernels": {}}
+    out = {"kernels": {}}
     for k in sorted(names):
         f, w = d.get("FETCH_SIZE", {}).get(k), d.get("WRITE_SIZE", {}).get(k)
         if f is None or w is None:
@@ -29,6 +25,18 @@ def main():
         if h and ms and h["sum"] + ms["sum"] > 0:
             ent["l2_hit_rate"] = h["sum"] / (h["sum"] + ms["sum"])
         out["kernels"][k.replace("void ", "").split("(")[0].replace(", false, 3, 0>", ">").replace(", false, 3>", ">").replace(", false>", ">")] = ent      # (HL_OUT = false, NPROD = 3, WINO = 0: the default variant)
+    return out["kernels"]
+
+
+def main():
+    """pmc_to_profile.py <loop-B pmc_summary.json> [<loop-A pmc_summary.json>]"""
+    out = {"command": "rocprofv3 --pmc <group> --kernel-trace -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timer --no-extra "
+                      "--no-power-probe [--loop a]  (one run per counter group, tools/pmc_pass.sh)",
+           "units": "FETCH_SIZE / WRITE_SIZE in KiB; hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / launches (the x2 is the gfx950 "
+                    "FETCH_SIZE correction of MI355X_MICROARCH.md); Infinity-Cache hits are counted",
+           "kernels": kernels_of(json.load(open(sys.argv[1])))}
+    if len(sys.argv) > 2:
+        out["kernels_loop_a"] = kernels_of(json.load(open(sys.argv[2])))
     json.dump(out, sys.stdout, indent=1)
 
 
