@@ -7,7 +7,7 @@ mkdir -p $R/gpurun_out/$tag
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$tag/prof -o trace -- python3 $R/tools/bench_loop_a.py $model 256 3 > $R/gpurun_out/$tag/prof.log 2>&1
 cd $R
-python3 tools/rocprof_summary.py gpurun_out/$tag/prof/trace_results.db 5 > gpurun_out/$tag/summary.md 2>&1
+python3 tools/rocprof_summary.py gpurun_out/$tag/prof/trace_results.db > gpurun_out/$tag/summary.md 2>&1
 python3 tools/rocprof_step.py gpurun_out/$tag/prof/trace_results.db ${MARKER:-adam_kernel} ${STEP_LIST:+--list} > gpurun_out/$tag/step.md 2>&1
 rm -rf gpurun_out/$tag/prof
 tail -1 gpurun_out/$tag/prof.log
