@@ -51,10 +51,34 @@ __device__ __forceinline__ f32x16 mma(const u32x4 a, const u32x4 b, const f32x16
 __constant__ float kWinoAT[6][4] = {{0.25f, 0.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f, -0.5f},
                                     {0.5f, 1.f, 2.f, 4.f}, {0.5f, -1.f, 2.f, -4.f}, {0.f, 0.f, 0.f, 1.f}};
 
+// scheduling pattern of one row-op (see the main loop): groups the scheduler fills in this order, empty ones are skipped
+#define WINO_SGB(mask) __builtin_amdgcn_sched_group_barrier(mask, 1, 0);
+#define WINO_INTERLEAVE_1 WINO_SGB(0x008) WINO_SGB(0x100) WINO_SGB(0x020)      // one MFMA, one DS read, one VMEM read (LDS-DMA piece)
+#define WINO_INTERLEAVE_3 WINO_INTERLEAVE_1 WINO_INTERLEAVE_1 WINO_INTERLEAVE_1
+
+#ifdef MRN_WPROBE_TIMING
+// what-if / timing probes (never in the product build): per-wave shader-clock totals of the main loop's phases, summed over all waves
+__device__ unsigned long long g_wino_dbg[8];
+extern "C" __attribute__((visibility("default"))) int mrn_wino_dbg_read(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wino_dbg), sizeof(g_wino_dbg)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wino_dbg), z, sizeof(z));
+  }
+  return 0;
+}
+#define WTICK(var) const long var = __builtin_readcyclecounter()
+#else
+#define WTICK(var)
+#endif
+
 // TOP / BOT: the row block has an input row above / below its four output rows inside the image (slot 0 / slot 5)
 template <int TOP, int BOT>
 __device__ __forceinline__ void wino_rows_tile(const WinoRowsParams& p, unsigned char* lds, int g, int pos0, int oy0, int n0, int tile_m) {
   constexpr int LO = 1 - TOP, HI = 4 + BOT, NR = HI - LO + 1;      // input-row slots present: slot = iy - oy0 + 1
+#ifdef MRN_WPROBE_TIMING
+  const long dbg_tile0 = __builtin_readcyclecounter();
+#endif
   // LDS: the activation lines run through a ring of ADEPTH stages (4-row maps: three -- the lines come from HBM, two steps of look-ahead),
   // the weight lines (L2 / Infinity Cache hits) through two
   constexpr int ADEPTH = NR == 4 ? 3 : 2;
@@ -178,6 +202,10 @@ __device__ __forceinline__ void wino_rows_tile(const WinoRowsParams& p, unsigned
   read_A(lds, LO, 0, 0);
   int cbi = 0, comp = 0;
   int a_cur = 0;                                                    // ring position of the current step's activation lines
+#ifdef MRN_WPROBE_TIMING
+  long dbg_wait = 0, dbg_bar = 0, dbg_fold = 0;
+  const long dbg_t0 = __builtin_readcyclecounter();
+#endif
   for (int s = 0; s < nsteps; ++s) {
     const unsigned char* a_st = lds + a_cur * A_STAGE;
     const unsigned char* b_st = lds + B_BASE + (s & 1) * B_STAGE;
@@ -200,17 +228,34 @@ __device__ __forceinline__ void wino_rows_tile(const WinoRowsParams& p, unsigned
         // step boundary (also after the last step, where the reads below fetch a stale stage that nothing uses: a branch here makes the
         // compiler wait for ALL of them before the MFMAs that follow -- its wait counts are merged over both paths): own fragment reads of this step are complete, own DMAs of the next step's operands have landed (the younger
         // ones -- activation lines of the step after it -- may still fly); after the barrier everyone's have, and this step's stages are free
+        WTICK(tk0);
         __builtin_amdgcn_s_waitcnt(WAIT_BOUNDARY);
+        WTICK(tk1);
 #ifndef MRN_WPROBE_NO_BARRIER
         __builtin_amdgcn_s_barrier();
+#endif
+        WTICK(tk2);
+#ifdef MRN_WPROBE_TIMING
+        dbg_wait += tk1 - tk0;
+        dbg_bar += tk2 - tk1;
 #endif
         read_B(b_dst, 0);
         read_A(lds + a_next * A_STAGE, LO, 0, par ^ 1);
       }
-      // (the scheduler otherwise sinks every fragment read to just in front of its first MFMA -- one register set, the LDS latency
-      // exposed once per input row; pin the software pipeline: DMA pieces and reads of row-op r + 1, then the MFMAs of row-op r)
+      // Software pipeline, pinned: left alone the scheduler sinks every fragment read to just in front of its first MFMA (one register
+      // set, the LDS latency exposed once per input row).  And a wave that is ALONE on its SIMD only hides what sits BETWEEN its
+      // MFMAs: the DMA pieces, fragment reads and address arithmetic of row-op r + 1 issued as one clump in front of the MFMA group of
+      // row-op r ran with the matrix pipe idle (in-kernel clocks: 2700 cycles per step against 1920 of MFMAs, barrier and counted
+      // waits 100).  So one row-op is one scheduling region whose order is given as [1 MFMA, 1 LDS read, 1 DMA piece] x 9.
+#ifdef MRN_WPROBE_CLUMPED
       __builtin_amdgcn_sched_barrier(0);
+#endif
       row_products(slot, ks, par);
+#ifndef MRN_WPROBE_CLUMPED
+      if (r + 1 < 2 * NR) {
+        WINO_INTERLEAVE_3 WINO_INTERLEAVE_3 WINO_INTERLEAVE_3
+      }
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
     a_cur = a_next;
@@ -220,6 +265,7 @@ __device__ __forceinline__ void wino_rows_tile(const WinoRowsParams& p, unsigned
     if (++cbi == Cb) {
 #endif
       // component `comp` is complete: Y_r += A^T[r][comp] * T, T = 0
+      WTICK(tf0);
       float cf[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) cf[r] = kWinoAT[comp][r];
@@ -238,9 +284,16 @@ __device__ __forceinline__ void wino_rows_tile(const WinoRowsParams& p, unsigned
         for (int e = 0; e < 16; ++e) acc[o][e] = 0.f;
       cbi = 0;
       ++comp;
+#ifdef MRN_WPROBE_TIMING
+      asm volatile("s_nop 0" ::: "memory");
+      dbg_fold += __builtin_readcyclecounter() - tf0;
+#endif
     }
   }
   __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));                 // vmcnt(0): the re-fetches of the tail are not left in flight
+#ifdef MRN_WPROBE_TIMING
+  const long dbg_t1 = __builtin_readcyclecounter();
+#endif
 
   // ---- epilogue: scale, bias, BatchNorm partial statistics, activation, store.  Lane = one position (b, column group q); register quad
   // j4 of an accumulator = channels c0 + 8 j4 .. + 3 with c0 = n0 + 32 wn + 4 (lane >> 5)
@@ -284,6 +337,18 @@ __device__ __forceinline__ void wino_rows_tile(const WinoRowsParams& p, unsigned
       }
     }
   }
+#ifdef MRN_WPROBE_TIMING
+  if (lane == 0) {
+    const long dbg_t2 = __builtin_readcyclecounter();
+    atomicAdd(&g_wino_dbg[0], (unsigned long long)(dbg_t1 - dbg_t0));      // main loop
+    atomicAdd(&g_wino_dbg[1], (unsigned long long)dbg_wait);               // s_waitcnt at the step boundary
+    atomicAdd(&g_wino_dbg[2], (unsigned long long)dbg_bar);                // s_barrier
+    atomicAdd(&g_wino_dbg[3], (unsigned long long)dbg_fold);               // component folds
+    atomicAdd(&g_wino_dbg[4], (unsigned long long)(dbg_t2 - dbg_t1));      // epilogue stores
+    atomicAdd(&g_wino_dbg[5], (unsigned long long)(dbg_t0 - dbg_tile0));   // prologue
+    atomicAdd(&g_wino_dbg[6], 1ull);
+  }
+#endif
   if (p.stats) {
     // per channel: sum over the 32 positions of each lane half, then over the two position waves through LDS
 #pragma unroll
