@@ -284,6 +284,46 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ i
   else out[(long)blockIdx.y * C + c] = s;
 }
 
+// the same sums with 16-byte loads: a thread owns 4 consecutive columns, a block is TX column quads x TY row lanes (TX * TY = 256,
+// TX = min(C / 4, 256) rounded up to a power of two), every row lane walks its rows with four loads in flight, the row lanes meet in
+// LDS.  Narrow matrices (SVTR's C = 64 ... 256 bias / LayerNorm gradients over 131 k rows: 262 launches, 18 % of a loop-A step with the
+// one-column-per-thread kernel above, a quarter of whose lanes were idle at C = 64) keep every lane busy.  C % 4 == 0, ld % 4 == 0, 16-byte
+// aligned base.
+template <int TX>
+__global__ __launch_bounds__(256) void colsum4_kernel(const float* __restrict__ in, long ld, float* __restrict__ out, long rows, int C,
+                                                      long rows_per_chunk, int accumulate, int direct) {
+  constexpr int TY = 256 / TX;
+  __shared__ f32x4 red[TY][TX];
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const int c = (blockIdx.x * TX + tx) * 4;
+  const long r0 = blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+  if (c < C) {
+    long r = r0 + ty;
+    for (; r + 3 * TY < r1; r += 4 * TY) {
+      s0 += *reinterpret_cast<const f32x4*>(in + r * ld + c);
+      s1 += *reinterpret_cast<const f32x4*>(in + (r + TY) * ld + c);
+      s2 += *reinterpret_cast<const f32x4*>(in + (r + 2 * TY) * ld + c);
+      s3 += *reinterpret_cast<const f32x4*>(in + (r + 3 * TY) * ld + c);
+    }
+    for (; r < r1; r += TY) s0 += *reinterpret_cast<const f32x4*>(in + r * ld + c);
+  }
+  f32x4 s = (s0 + s1) + (s2 + s3);
+  if constexpr (TY > 1) {
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0) {
+#pragma unroll
+      for (int j = 1; j < TY; ++j) s += red[j][tx];
+    }
+  }
+  if (ty == 0 && c < C) {
+    float* o = direct ? out + c : out + (long)blockIdx.y * C + c;
+    if (direct && accumulate) s += *reinterpret_cast<const f32x4*>(o);
+    *reinterpret_cast<f32x4*>(o) = s;
+  }
+}
+
 // out[i][j] = in[ridx[i]][cidx[j]] (index arrays may be null = identity); out row stride ld_out, padding cols zeroed
 __global__ void gather2d_kernel(const float* __restrict__ in, long ld_in, const int* __restrict__ ridx,
                                 const int* __restrict__ cidx, float* __restrict__ out, long ld_out, int R, int C, int Cpad) {
@@ -506,11 +546,39 @@ MRN_EXPORT int mrn_bn_stats_f32(const float* x, int64_t rows, int C, float* part
   return MRN_OK;
 }
 
+static int colsum4_tx(int C) {      // column quads per block of the vectorised kernel: C / 4 rounded up to a power of two, 4 ... 256
+  int tx = 4;
+  while (tx < 256 && tx * 4 < C) tx *= 2;
+  return tx;
+}
+
 MRN_EXPORT int64_t mrn_colsum_chunks(int64_t rows, int C) {
-  const int64_t colblocks = (C + 255) / 256;
-  int64_t chunks = 1024 / colblocks;
-  if (chunks > (rows + 63) / 64) chunks = (rows + 63) / 64;
+  // (sized for the vectorised kernel: column blocks of up to 1024 columns; the scalar fallback runs the same grid shape with more blocks)
+  const int64_t colblocks = (C + 1023) / 1024;
+  int64_t chunks = 2048 / colblocks;
+  const int ty = 256 / colsum4_tx(C);
+  const int64_t min_rows = 16L * ty;                 // at least 16 rows per row lane and chunk
+  if (chunks > (rows + min_rows - 1) / min_rows) chunks = (rows + min_rows - 1) / min_rows;
   return chunks < 1 ? 1 : chunks;
+}
+
+template <int TX>
+static void launch_colsum4(const float* in, long ld, float* out, long rows, int C, long rpc, long chunks, int accumulate, int direct,
+                           hipStream_t st) {
+  hipLaunchKernelGGL(colsum4_kernel<TX>, dim3((unsigned)ceil_div(C, TX * 4), (unsigned)chunks), dim3(256), 0, st, in, ld, out, rows, C, rpc,
+                     accumulate, direct);
+}
+
+static void colsum4(const float* in, long ld, float* out, long rows, int C, long rpc, long chunks, int accumulate, int direct, hipStream_t st) {
+  switch (colsum4_tx(C)) {
+    case 4: launch_colsum4<4>(in, ld, out, rows, C, rpc, chunks, accumulate, direct, st); break;
+    case 8: launch_colsum4<8>(in, ld, out, rows, C, rpc, chunks, accumulate, direct, st); break;
+    case 16: launch_colsum4<16>(in, ld, out, rows, C, rpc, chunks, accumulate, direct, st); break;
+    case 32: launch_colsum4<32>(in, ld, out, rows, C, rpc, chunks, accumulate, direct, st); break;
+    case 64: launch_colsum4<64>(in, ld, out, rows, C, rpc, chunks, accumulate, direct, st); break;
+    case 128: launch_colsum4<128>(in, ld, out, rows, C, rpc, chunks, accumulate, direct, st); break;
+    default: launch_colsum4<256>(in, ld, out, rows, C, rpc, chunks, accumulate, direct, st); break;
+  }
 }
 
 // out[c] (+)= sum over rows; workspace must hold mrn_colsum_chunks(rows, C) * C floats (unused when chunks == 1)
@@ -520,6 +588,19 @@ MRN_EXPORT int mrn_colsum_f32(const float* in, int64_t ld, float* out, float* wo
   if (C == 0) return MRN_OK;
   const long chunks = mrn_colsum_chunks(rows, C);
   const int cb = ceil_div(C, 256);
+  const hipStream_t st = (hipStream_t)stream;
+  if (C % 4 == 0 && ld % 4 == 0 && (uintptr_t)in % 16 == 0 && (uintptr_t)out % 16 == 0 && (chunks == 1 || (uintptr_t)workspace % 16 == 0)) {
+    if (chunks == 1) {
+      colsum4(in, (long)ld, out, (long)rows, C, (long)rows, 1, accumulate, 1, st);
+    } else {
+      MRN_CHECK_ARG(workspace, "mrn_colsum_f32: workspace required for %ld chunks", chunks);
+      const long rpc = (rows + chunks - 1) / chunks;
+      colsum4(in, (long)ld, workspace, (long)rows, C, rpc, chunks, 0, 0, st);
+      colsum4(workspace, (long)C, out, chunks, C, chunks, 1, accumulate, 1, st);
+    }
+    MRN_LAUNCH_CHECK("colsum");
+    return MRN_OK;
+  }
   if (chunks == 1) {
     hipLaunchKernelGGL(colsum_kernel, dim3(cb, 1), dim3(256), 0, (hipStream_t)stream, in, (long)ld, out, (long)rows, C,
                        (long)rows, accumulate, 1);

@@ -369,7 +369,8 @@ class ConvBlockFn(torch.autograd.Function):
         ctx.geom = (stride, padding, relu, precision, bn is not None, residual is not None)
         ctx.wpacked = w
         ctx.conv = conv
-        ops.note_param_uses((conv.weight,), any(ctx.needs_input_grad))
+        ctx.bn = bn
+        ops.note_param_uses((conv.weight, conv.bias) + ((bn.weight, bn.bias) if bn is not None else ()), any(ctx.needs_input_grad))
         if id(conv) not in ops.TRAINED_CONVS:
             ops.TRAINED_CONVS[id(conv)] = (weakref.ref(conv), stride, padding)
         # one max|x| pass serves the forward conv and the weight gradient (both split x with the same power-of-two scale)
@@ -449,6 +450,21 @@ class ConvBlockFn(torch.autograd.Function):
                 ops.direct_done((ctx.conv.weight,))
             else:
                 dw = ops.unpack_conv_weight(weight_gradient())
+        # the small per-channel gradients (conv bias, BatchNorm weight / bias) too: handed to autograd they cost two or three 5-us
+        # accumulation launches per block ON the backward chain (72 per TRBA step)
+        small = [(ctx.conv.bias, dbias), (ctx.bn.weight if ctx.bn is not None else None, dgamma),
+                 (ctx.bn.bias if ctx.bn is not None else None, dbeta)]
+        if (ops.WGRAD_SIDE_STREAM and ops.GRAD_DIRECT and not torch.is_grad_enabled()
+                and all(g is None or (p is not None and p.grad is not None and p.grad.dtype == torch.float32) for p, g in small)
+                and any(g is not None for _, g in small)):
+            side = ops.side_stream_begin()
+            with torch.cuda.stream(side):
+                for p, g in small:
+                    if g is not None:
+                        p.grad.add_(g.reshape(p.grad.shape))
+            ops.side_stream_keep([g for _, g in small])
+            ops.direct_done([p for p, g in small if g is not None])
+            dbias = dgamma = dbeta = None
         if ctx.needs_input_grad[0]:
             wt = ops.trained_dgrad_weight(w.ohwi)
             dx = ops.conv2d_dgrad(dy, wt, (x.shape[1], x.shape[2]), stride, padding, precision=precision, dy_scale=sd)

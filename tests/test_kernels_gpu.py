@@ -280,6 +280,17 @@ def test_rowops(ops):
     assert_close("mul", ops.ew_rows(ops.EW_MUL, cu(a)[:, :256], cu(bb)[:, 256:]), a[:, :256] * bb[:, 256:], atol=0)
     big = rnd(100000, 40, seed=60)
     assert_close("colsum", ops.colsum(cu(big)), big.sum(0), atol=2e-3, rtol=1e-5)
+    # the vectorised form (4 columns per thread, row lanes reduced through LDS) and its scalar fallback: narrow / wide / odd widths,
+    # strided views, one chunk and many, accumulation into an existing vector
+    for rows, C, ld in ((131072, 64, 64), (1000, 256, 256), (37, 12, 12), (5000, 1032, 1032), (3, 4, 4), (70000, 128, 384), (999, 30, 30),
+                        (257, 2048, 2048), (8, 16384, 16384)):
+        src = rnd(rows, ld, seed=63 + C)
+        view = cu(src)[:, :C]
+        ref_sum = src[:, :C].double().sum(0).float()
+        assert_close(f"colsum {rows}x{C} ld {ld}", ops.colsum(view), ref_sum, atol=2e-4 * rows ** 0.5, rtol=1e-5)
+        base = cu(rnd(C, seed=64))
+        got = ops.colsum(view, out=base.clone(), accumulate=True)
+        assert_close(f"colsum accumulate {rows}x{C}", got, ref_sum + base.cpu(), atol=2e-4 * rows ** 0.5, rtol=1e-5)
     m = rnd(30, 30, seed=61)
     perm = torch.randperm(30, generator=torch.Generator().manual_seed(1)).int()
     gat = ops.gather2d(cu(m), cu(perm), cu(perm), ld_out=32)
