@@ -889,6 +889,7 @@ WINO_CONVS = [
     (3, 16, 3, 32, 64, 128, "hl32", True),       #   (R = 4: 16 * 8 = 128) one interior row
     (2, 2, 16, 32, 32, 64, "none", True),        # four row blocks of the row-block kernel (conv_wino.hip): first / interior / last
     (1, 3, 12, 20, 64, 96, "f32", False),        # three row blocks, signed inputs, Cout and positions not tile multiples
+    (2, 5, 4, 9, 32, 32, "none", True),          # one channel block per component, half a channel tile, three column groups
 ]
 
 
