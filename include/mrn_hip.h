@@ -114,7 +114,9 @@ int mrn_transpose_oy3_hl32_f32(const float* x, void* out, int B, int H, int W, i
  * image-row-major group order), 18 K-windows (component x kernel row) of a quarter of the length on mrn_gemm_x3_windows_hl32, then
  * dW[ky][kx] = sum_m G[m][kx] dU_m[ky] over the split-K slabs (mrn_wino_wgrad_finish_f32): half the matrix work of the 9-window form */
 int mrn_transpose_oy_wino_hl32_f32(const float* t, void* out, int B, int H, int W, int C, int mode, const float* scale, void* stream);
-int mrn_wino_wgrad_finish_f32(const float* part, float* dw, int S, int Cout, int Cin, void* stream);
+int mrn_wino_wgrad_finish_f32(const float* part, float* dw, int S, int Cout, int Cin, int oihw_accumulate, void* stream);
+/* oihw_accumulate 0: dw [Cout][3][3][Cin] written; 1: ADDED into dw [Cout][Cin][3][3], the Conv2d parameter's own gradient layout
+ * (.grad accumulation of loss.backward() without a layout pass); out_scale / x_scale of the windows GEMM: ONE {s, 1/s} pair per operand */
 int mrn_gemm_x3_windows_hl32(const void* a_hl, int64_t a_bytes, int a_pitch_lines, const void* w_hl, int64_t w_bytes,
                              int w_pitch_lines, const void* windows, int G, int M, int N, const void* zero_page,
                              const float* out_scale, const float* x_scale, float* y, int tile_m, int tile_n, int products,
@@ -202,9 +204,14 @@ int mrn_dilate_nhwc_f32(const float* dy, float* out, int B, int Ho, int Wo, int 
 /* BatchNorm2d (training) backward with the ReLU mask fused: g = dz * (z > 0); partial per-channel sums of g and
  * g*xhat (reduce), then dy = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)) and dres = g (apply). */
 int64_t mrn_bn_bwd_blocks(int64_t rows);
-int mrn_bn_bwd_reduce_f32(const float* dz, const float* z, const float* y, const float* mean, const float* invstd,
+int mrn_bn_bwd_reduce_f32(const float* dz, const float* z, const void* zmask, const float* y, const float* mean, const float* invstd,
                           float* partials, int64_t rows, int C, int relu, void* stream);
-int mrn_bn_bwd_apply_f32(const float* dz, const float* z, const float* y, const float* mean, const float* invstd,
+/* zmask (optional, instead of z): the ReLU mask as 4 bits per 4 consecutive channels (one byte per 16-byte quad, bit j = element j > 0),
+ * written by mrn_scale_shift_act_f32(pos_mask) in the forward pass -- 1/32 of the bytes of reading z again in both passes.
+ * mrn_bn_bwd_finalize_f32: sums [2][C] = column sums of the partials; dgamma_acc / dbeta_acc (optional): the BatchNorm weight / bias
+ * gradients are ADDED there by the same launch (il_modules/mrn.py:260-261 loss.backward(): .grad accumulation). */
+int mrn_bn_bwd_finalize_f32(const float* partials, int64_t nblk, int C, float* sums, float* dgamma_acc, float* dbeta_acc, void* stream);
+int mrn_bn_bwd_apply_f32(const float* dz, const float* z, const void* zmask, const float* y, const float* mean, const float* invstd,
                          const float* gamma, const float* sums, float* dy, float* dres, int64_t rows, int C, int relu,
                          void* amax_ws, void* stream);   /* amax_ws (optional): max|dy| folded in */
 /* MaxPool2d backward: dx (zero-initialised) += dy at the first maximum of each window.  When mrn_maxpool_bwd_writes_all(...) is 1
@@ -234,7 +241,9 @@ int mrn_bn_eval_affine_f32(const float* gamma, const float* beta, const float* r
 /* y = act(x * scale[c] + shift[c] + residual): BatchNorm apply + residual add + activation in one pass
  * (BasicBlock tail, modules/feature_extraction.py:184-199; relu = 1 ReLU, 2 GELU for SVTR's PatchEmbed). In place allowed. */
 int mrn_scale_shift_act_f32(const float* x, const float* residual, float* y, const float* scale,
-                            const float* shift, int64_t rows, int C, int relu, void* amax_ws, void* stream);   /* amax_ws (optional): max|y| folded in, see mrn_pow2_finalize_f32 */
+                            const float* shift, int64_t rows, int C, int relu, void* amax_ws, void* pos_mask, void* stream);
+/* amax_ws (optional): max|y| folded in, see mrn_pow2_finalize_f32; pos_mask (optional, rows * C / 4 bytes): bit j of byte q = element 4q + j
+ * of y is > 0 -- the ReLU mask mrn_bn_bwd_* takes as zmask */
 /* NHWC max pooling (padding = -inf), optional fused (scale, shift, relu) on the input.
  * modules/feature_extraction.py:22,25,30,41,234,246,260; modules/transformation.py:71-79. */
 int mrn_maxpool_nhwc_f32(const float* x, float* y, const float* scale, const float* shift, int relu,

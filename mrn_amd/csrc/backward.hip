@@ -59,7 +59,8 @@ __global__ void dilate_nhwc_kernel(const float* __restrict__ dy, float* __restri
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dz, const float* __restrict__ z,
                                                             const float* __restrict__ y, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, float* __restrict__ part,
-                                                            long rows, int C, int relu, int rows_per_block) {
+                                                            long rows, int C, int relu, int rows_per_block,
+                                                            const unsigned char* __restrict__ zmask) {
   extern __shared__ __attribute__((aligned(16))) float red[];   // [lanes][2][C]
   const int C4 = C >> 2;
   const int cq = threadIdx.x % C4, rl = threadIdx.x / C4, lanes = 256 / C4;
@@ -71,10 +72,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     f32x4 g = reinterpret_cast<const f32x4*>(dz)[r * C4 + cq];
     const f32x4 yv = reinterpret_cast<const f32x4*>(y)[r * C4 + cq];
     if (relu) {
-      const f32x4 zv = reinterpret_cast<const f32x4*>(z)[r * C4 + cq];
+      if (zmask) {                       // 4 bits per quad from the forward pass (mrn_scale_shift_act_f32 pos_mask) instead of z itself
+        const unsigned m = zmask[r * C4 + cq];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (!(zv[j] > 0.f)) g[j] = 0.f;
+        for (int j = 0; j < 4; ++j)
+          if (!((m >> j) & 1u)) g[j] = 0.f;
+      } else {
+        const f32x4 zv = reinterpret_cast<const f32x4*>(z)[r * C4 + cq];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (!(zv[j] > 0.f)) g[j] = 0.f;
+      }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -99,7 +107,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ sums,  // [2][C]: sum g, sum g*xhat
                                                            float* __restrict__ dy, float* __restrict__ dres, long rows, int C,
-                                                           int relu, float inv_n, unsigned* __restrict__ amax_ws) {
+                                                           int relu, float inv_n, unsigned* __restrict__ amax_ws,
+                                                           const unsigned char* __restrict__ zmask) {
   const int C4 = C >> 2;
   const long n4 = rows * C4;
   float mx = 0.f;                                      // max |dy| of this lane (amax_ws: the range scale of the data / weight gradients)
@@ -108,10 +117,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     f32x4 g = reinterpret_cast<const f32x4*>(dz)[i];
     const f32x4 yv = reinterpret_cast<const f32x4*>(y)[i];
     if (relu) {
-      const f32x4 zv = reinterpret_cast<const f32x4*>(z)[i];
+      if (zmask) {
+        const unsigned m = zmask[i];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (!(zv[j] > 0.f)) g[j] = 0.f;
+        for (int j = 0; j < 4; ++j)
+          if (!((m >> j) & 1u)) g[j] = 0.f;
+      } else {
+        const f32x4 zv = reinterpret_cast<const f32x4*>(z)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (!(zv[j] > 0.f)) g[j] = 0.f;
+      }
     }
     const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[cq];
     const f32x4 is = reinterpret_cast<const f32x4*>(invstd)[cq];
@@ -404,28 +420,62 @@ MRN_EXPORT int64_t mrn_bn_bwd_blocks(int64_t rows) {
   return b < 1 ? 1 : b;
 }
 
-// partials: mrn_bn_bwd_blocks(rows) * 2 * C floats
-MRN_EXPORT int mrn_bn_bwd_reduce_f32(const float* dz, const float* z, const float* y, const float* mean, const float* invstd,
-                                     float* partials, int64_t rows, int C, int relu, void* stream) {
-  MRN_CHECK_ARG(dz && y && mean && invstd && partials && (!relu || z), "mrn_bn_bwd_reduce_f32: null operand");
+// partials: mrn_bn_bwd_blocks(rows) * 2 * C floats; the ReLU mask comes from z (z > 0) or from zmask (4 bits per 4 channels, bit j = element j > 0)
+MRN_EXPORT int mrn_bn_bwd_reduce_f32(const float* dz, const float* z, const void* zmask, const float* y, const float* mean,
+                                     const float* invstd, float* partials, int64_t rows, int C, int relu, void* stream) {
+  MRN_CHECK_ARG(dz && y && mean && invstd && partials && (!relu || z || zmask), "mrn_bn_bwd_reduce_f32: null operand");
   MRN_CHECK_ARG(C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0, "mrn_bn_bwd_reduce_f32: unsupported C=%d", C);
   if (rows == 0) return MRN_OK;
   const long nblk = mrn_bn_bwd_blocks(rows);
   const int rpb = (int)((rows + nblk - 1) / nblk);
   const int lanes = 256 / (C / 4);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)nblk), dim3(256), sizeof(float) * lanes * 2 * C, (hipStream_t)stream,
-                     dz, z, y, mean, invstd, partials, (long)rows, C, relu, rpb);
+                     dz, z, y, mean, invstd, partials, (long)rows, C, relu, rpb, (const unsigned char*)zmask);
   MRN_LAUNCH_CHECK("bn_bwd_reduce");
   return MRN_OK;
 }
 
-MRN_EXPORT int mrn_bn_bwd_apply_f32(const float* dz, const float* z, const float* y, const float* mean, const float* invstd,
-                                    const float* gamma, const float* sums, float* dy, float* dres, int64_t rows, int C,
-                                    int relu, void* amax_ws, void* stream) {
-  MRN_CHECK_ARG(dz && y && mean && invstd && gamma && sums && dy && (!relu || z) && C % 4 == 0, "mrn_bn_bwd_apply_f32: bad operands");
+// sums [2][C] = column sums of the partials [nblk][2][C] (sum g | sum g * xhat: what the apply pass needs); with dgamma_acc / dbeta_acc the
+// two parameter gradients are ADDED there in the same launch (dbeta += sum g, dgamma += sum g * xhat) -- the flat-gradient slices of the
+// BatchNorm weight / bias -- instead of two reduction launches and two accumulation launches
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ sums,
+                                                              float* __restrict__ dgamma_acc, float* __restrict__ dbeta_acc) {
+  __shared__ float red[8][33];
+  const int col = blockIdx.x * 32 + (threadIdx.x & 31), lane = threadIdx.x >> 5;
+  float s = 0.f;
+  if (col < 2 * C)
+    for (int r = lane; r < nblk; r += 8) s += part[(long)r * 2 * C + col];
+  red[lane][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (threadIdx.x < 32 && col < 2 * C) {
+    float t = 0.f;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) t += red[l][threadIdx.x];
+    sums[col] = t;
+    if (col < C) {
+      if (dbeta_acc) dbeta_acc[col] += t;
+    } else if (dgamma_acc) {
+      dgamma_acc[col - C] += t;
+    }
+  }
+}
+
+MRN_EXPORT int mrn_bn_bwd_finalize_f32(const float* partials, int64_t nblk, int C, float* sums, float* dgamma_acc, float* dbeta_acc,
+                                       void* stream) {
+  MRN_CHECK_ARG(partials && sums && nblk >= 1 && C >= 1, "mrn_bn_bwd_finalize_f32: bad operands");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)((2 * C + 31) / 32)), dim3(256), 0, (hipStream_t)stream, partials, (int)nblk, C,
+                     sums, dgamma_acc, dbeta_acc);
+  MRN_LAUNCH_CHECK("bn_bwd_finalize");
+  return MRN_OK;
+}
+
+MRN_EXPORT int mrn_bn_bwd_apply_f32(const float* dz, const float* z, const void* zmask, const float* y, const float* mean,
+                                    const float* invstd, const float* gamma, const float* sums, float* dy, float* dres, int64_t rows,
+                                    int C, int relu, void* amax_ws, void* stream) {
+  MRN_CHECK_ARG(dz && y && mean && invstd && gamma && sums && dy && (!relu || z || zmask) && C % 4 == 0, "mrn_bn_bwd_apply_f32: bad operands");
   if (rows == 0) return MRN_OK;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(rows * (C / 4), 1024)), dim3(256), 0, (hipStream_t)stream, dz, z, y, mean,
-                     invstd, gamma, sums, dy, dres, (long)rows, C, relu, 1.f / (float)rows, (unsigned*)amax_ws);
+                     invstd, gamma, sums, dy, dres, (long)rows, C, relu, 1.f / (float)rows, (unsigned*)amax_ws, (const unsigned char*)zmask);
   MRN_LAUNCH_CHECK("bn_bwd_apply");
   return MRN_OK;
 }

@@ -47,7 +47,8 @@ struct ConvX3Params {
   const unsigned char* w;     // HL32 weight
   const unsigned char* zero;  // >= 128 bytes of zeros
   const float* bias;          // [G][N] or null
-  const float* out_scale;     // [G][2] = {s, 1/s} (epilogue multiplies by [1]) or null
+  const float* out_scale;     // [G][os_stride] = {s, 1/s} (epilogue multiplies by [1]) or null; os_stride 2, or 0: one pair for all groups
+  int os_stride;
   const float* x_scale;       // [2] = {s, 1/s} of the activation operand (epilogue multiplies by [1]) or null
   const float* res;           // optional residual, same layout as y, added before the activation
   float* y;                   // [G][M][N], or null when only y_hl is wanted
@@ -529,7 +530,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
 
   // ---- epilogue: scale, bias, BatchNorm partial statistics, activation, store ------------------------------
   float* yg = p.y + (long)g * p.y_gstride;
-  const float osc = (p.out_scale ? p.out_scale[g * 2 + 1] : 1.f) * (p.x_scale ? p.x_scale[1] : 1.f);
+  const float osc = (p.out_scale ? p.out_scale[g * p.os_stride + 1] : 1.f) * (p.x_scale ? p.x_scale[1] : 1.f);
   const float* rg = p.res ? p.res + (long)g * p.y_gstride : nullptr;
   float csum[WN], csq[WN], bn[WN], cs[WN], sh[WN];
 #pragma unroll
@@ -936,6 +937,8 @@ __global__ __launch_bounds__(256) void transpose_oy_wino_hl32_kernel(const float
 
 // dW [Cout][3][3][Cin] = sum over split-K chunks s and components m of G[m][kx] * part[s][m * 3 + ky][co][ci]  (G of F(4,3), unfolded);
 // one lane = 4 consecutive input channels (Cin % 4 == 0): 18 S independent 16-byte streams per lane, split-K chunk outermost
+// OIHW_ACC: dW is ADDED into the parameter's own [Cout][Cin][3][3] gradient (the flat-gradient slice): a lane's 4 channels x 9 taps are 36 contiguous floats
+template <bool OIHW_ACC>
 __global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, long CC4, int Cin4) {
   const float G[6][3] = {{0.25f, 0.f, 0.f}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
                          {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
@@ -950,6 +953,7 @@ __global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __r
 #pragma unroll
       for (int k = 0; k < 18; ++k) u[k] += p4[((long)s_ * 18 + k) * CC4 + i];
     }
+    float o36[OIHW_ACC ? 36 : 1];
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -957,8 +961,23 @@ __global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __r
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int m = 0; m < 6; ++m) v += G[m][kx] * u[m * 3 + ky];
-        reinterpret_cast<f32x4*>(dw)[((co * 3 + ky) * 3 + kx) * Cin4 + c4] = v;
+        if constexpr (OIHW_ACC) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o36[j * 9 + ky * 3 + kx] = v[j];
+        } else {
+          reinterpret_cast<f32x4*>(dw)[((co * 3 + ky) * 3 + kx) * Cin4 + c4] = v;
+        }
       }
+    if constexpr (OIHW_ACC) {
+      f32x4* d = reinterpret_cast<f32x4*>(dw + (co * Cin4 + c4) * 36);          // (co * Cin + 4 c4) * 9 floats: 144-byte aligned
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        f32x4 t = d[q];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] += o36[q * 4 + j];
+        d[q] = t;
+      }
+    }
   }
 }
 
@@ -1062,7 +1081,7 @@ MRN_EXPORT int mrn_conv2d_x3_hl32(const void* x_hl, const void* w_hl, const void
   ConvX3Params p;
   memset(&p, 0, sizeof(p));
   p.x = (const unsigned char*)x_hl; p.w = (const unsigned char*)w_hl; p.zero = (const unsigned char*)zero_page;
-  p.bias = bias; p.out_scale = out_scale; p.x_scale = x_scale; p.res = residual; p.y = y; p.y_hl = (unsigned char*)y_hl32; p.stats = stats;
+  p.bias = bias; p.out_scale = out_scale; p.os_stride = 2; p.x_scale = x_scale; p.res = residual; p.y = y; p.y_hl = (unsigned char*)y_hl32; p.stats = stats;
   p.ch_scale = ch_scale; p.ch_shift = ch_shift; p.res_hl = (const unsigned char*)residual_hl32;
   p.Cb = Cin / 32; p.taps = kh * kw; p.nk = p.Cb * p.taps;
   p.x_gstride = x_group_stride_bytes; p.w_gstride = (long)Cout * p.nk * 128;
@@ -1216,12 +1235,17 @@ MRN_EXPORT int mrn_transpose_oy_wino_hl32_f32(const float* t, void* out, int B, 
 }
 
 // part [S][18][Cout][Cin] (group (m, ky) = m * 3 + ky of split-K chunk s, from mrn_gemm_x3_windows_hl32) -> dW [Cout][3][3][Cin]
-MRN_EXPORT int mrn_wino_wgrad_finish_f32(const float* part, float* dw, int S, int Cout, int Cin, void* stream) {
+// (oihw_accumulate 0), or ADDED into dW [Cout][Cin][3][3], the parameter's own layout (oihw_accumulate 1; 16-byte aligned)
+MRN_EXPORT int mrn_wino_wgrad_finish_f32(const float* part, float* dw, int S, int Cout, int Cin, int oihw_accumulate, void* stream) {
   MRN_CHECK_ARG(part && dw && S >= 1 && Cout >= 1 && Cin >= 4 && Cin % 4 == 0, "mrn_wino_wgrad_finish_f32: bad operands (Cin %% 4 == 0)");
+  MRN_CHECK_ARG(!oihw_accumulate || (uintptr_t)dw % 16 == 0, "mrn_wino_wgrad_finish_f32: the accumulated gradient must be 16-byte aligned");
   const long CC4 = (long)Cout * Cin / 4;
   long grid = (CC4 + 255) / 256;
   if (grid > 16384) grid = 16384;
-  hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, part, dw, S, CC4, Cin / 4);
+  if (oihw_accumulate)
+    hipLaunchKernelGGL(wino_wgrad_finish_kernel<true>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, part, dw, S, CC4, Cin / 4);
+  else
+    hipLaunchKernelGGL(wino_wgrad_finish_kernel<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, part, dw, S, CC4, Cin / 4);
   MRN_LAUNCH_CHECK("wino_wgrad_finish");
   return MRN_OK;
 }
@@ -1230,7 +1254,8 @@ MRN_EXPORT int mrn_wino_wgrad_finish_f32(const float* part, float* dw, int S, in
 //   y[g][m][n] = out_scale * sum over the window's K of A[m][a_off_g + k] * Wm[n][w_off_g + k]
 // a_hl: [M][a_pitch lines][128 B], w_hl: [N][w_pitch lines][128 B] (a_bytes / w_bytes their sizes); windows: DEVICE array of G
 // records {int64 a_off_bytes, int64 w_off_bytes, int32 n_lines, int32 pad}: where the window starts inside a row of each matrix
-// and how many 128-byte lines (32 K each) it spans (>= 1).  y [G][M][N] fp32.  out_scale / x_scale: {s, 1/s} of the two operands.
+// and how many 128-byte lines (32 K each) it spans (>= 1).  y [G][M][N] fp32.  out_scale / x_scale: ONE {s, 1/s} pair per operand
+// (w_hl's and a_hl's), shared by all groups.
 // Used by the convolution weight gradient: A = dy^T, Wm = one of three x-shifted copies of x^T, one group per (split-K chunk, tap).
 MRN_EXPORT int mrn_gemm_x3_windows_hl32(const void* a_hl, int64_t a_bytes, int a_pitch_lines, const void* w_hl, int64_t w_bytes,
                                         int w_pitch_lines, const void* windows, int G, int M, int N, const void* zero_page,
@@ -1255,9 +1280,8 @@ MRN_EXPORT int mrn_gemm_x3_windows_hl32(const void* a_hl, int64_t a_bytes, int a
   magic_div(1u, p.wo_magic, p.wo_shift);
   magic_div((unsigned)p.BWo, p.bw_magic, p.bw_shift);
   magic_div(1u, p.kw_magic, p.kw_shift);
-  // both operands carry their own power-of-two prescale: the epilogue multiplies by out_scale[g*2+1] * x_scale[1]; here ONE pair
-  // serves every group, so it is passed as a G-strided view of the same two floats by the caller when needed
-  p.out_scale = out_scale;
+  // both operands carry their own power-of-two prescale: the epilogue multiplies by out_scale[1] * x_scale[1]; ONE pair serves every group
+  p.out_scale = out_scale; p.os_stride = 0;
   hipStream_t st = (hipStream_t)stream;
   if (products == 1) {
     if (tile_n == 256) return launch_x3<4, 4, 2, 2, false, 1>(p, st);
@@ -1394,7 +1418,7 @@ MRN_EXPORT int mrn_conv2d_x3_wino_hl32(const void* v_hl, const void* u_hl, const
   ConvX3Params p;
   memset(&p, 0, sizeof(p));
   p.x = (const unsigned char*)v_hl; p.w = (const unsigned char*)u_hl; p.zero = (const unsigned char*)zero_page;
-  p.bias = bias; p.out_scale = out_scale; p.x_scale = x_scale; p.y = y; p.stats = stats;
+  p.bias = bias; p.out_scale = out_scale; p.os_stride = 2; p.x_scale = x_scale; p.y = y; p.stats = stats;
   p.Cb = NC * (Cin / 32); p.taps = 3; p.nk = p.Cb * 3;
   p.x_gstride = v_group_stride_bytes; p.w_gstride = (long)Cout * p.nk * 128;
   p.x_group_div = 1;

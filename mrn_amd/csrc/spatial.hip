@@ -97,7 +97,7 @@ __global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const flo
 __global__ __launch_bounds__(256) void scale_shift_act_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                               float* __restrict__ y, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, long n4, int C4, int relu,
-                                                              unsigned* __restrict__ amax_ws) {
+                                                              unsigned* __restrict__ amax_ws, unsigned char* __restrict__ pos_mask) {
   float mx = 0.f;                  // max |y| of this lane (amax_ws: the range scale of the NEXT trained convolution's operand)
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
     const int c4 = (int)(i % C4);
@@ -120,6 +120,8 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const float* __res
       for (int j = 0; j < 4; ++j) o[j] = 0.5f * o[j] * (1.f + erff(o[j] * 0.70710678118654752440f));
     }
     reinterpret_cast<f32x4*>(y)[i] = o;
+    // the ReLU mask of the backward pass (mrn_bn_bwd_*: g = dz * (y > 0)), 4 bits per lane: 1/32 of the bytes of re-reading y there
+    if (pos_mask) pos_mask[i] = (unsigned char)((o[0] > 0.f) | ((o[1] > 0.f) << 1) | ((o[2] > 0.f) << 2) | ((o[3] > 0.f) << 3));
     mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
   }
   if (amax_ws) {                       // one atomic per BLOCK, spread over 64 slots (thousands of same-address atomics would serialise)
@@ -242,12 +244,12 @@ MRN_EXPORT int mrn_bn_eval_affine_f32(const float* gamma, const float* beta, con
 }
 
 MRN_EXPORT int mrn_scale_shift_act_f32(const float* x, const float* residual, float* y, const float* scale,
-                                       const float* shift, int64_t rows, int C, int relu, void* amax_ws, void* stream) {
+                                       const float* shift, int64_t rows, int C, int relu, void* amax_ws, void* pos_mask, void* stream) {
   MRN_CHECK_ARG(x && y && scale && shift && C % 4 == 0, "mrn_scale_shift_act_f32: bad args (C=%d)", C);
   const long n4 = rows * (C / 4);
   if (n4 == 0) return MRN_OK;
   hipLaunchKernelGGL(scale_shift_act_kernel, dim3(ew_grid(n4, 256 * 4)), dim3(256), 0, (hipStream_t)stream, x, residual,
-                     y, scale, shift, n4, C / 4, relu, (unsigned*)amax_ws);
+                     y, scale, shift, n4, C / 4, relu, (unsigned*)amax_ws, (unsigned char*)pos_mask);
   MRN_LAUNCH_CHECK("scale_shift_act");
   return MRN_OK;
 }

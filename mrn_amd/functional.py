@@ -86,9 +86,10 @@ def _pick_split(R, tiles, target=1024, min_rows=128):
     return 1
 
 
-def x3_wgrad(dy2, x2, sd=None, sx=None):
+def x3_wgrad(dy2, x2, sd=None, sx=None, out=None):
     """dW = dy2^T @ x2 on the split-fp16 x3 path: both operands transposed-split (reduction axis = rows) with device
-    prescales; split-K chunks are the grouped conv's groups, partial slabs reduced by a column-sum pass."""
+    prescales; split-K chunks are the grouped conv's groups, partial slabs reduced by a column-sum pass (which ADDS into `out`
+    [N,K] when one is given and returns it)."""
     R, N = dy2.shape
     K = x2.shape[1]
     blocks = R // 32
@@ -102,17 +103,21 @@ def x3_wgrad(dy2, x2, sd=None, sx=None):
     w_hl = ops.split_hl32_t(x2, S, sx)                       # [S][K][rps/32][128]: "weight" rows = k
     part, _ = ops.conv2d_x3(a_hl, S, False, N, 1, 1, rps, w_hl, sx.view(1, 2).expand(S, 2).contiguous(), K, (1, 1), x_scale=sd)
     part = part.view(S, N * K)
+    if S > 1 and out is not None:
+        ops.colsum(part, out=out.view(-1), accumulate=True)
+        return out
     return (ops.colsum(part) if S > 1 else part[0]).view(N, K)
 
 
-def linear_wgrad(dy, x, sd=None, sx=None):
-    """dW[n][k] = sum_r dy[r][n] * x[r][k] with split-K over r (partials reduced by a column-sum pass)."""
+def linear_wgrad(dy, x, sd=None, sx=None, out=None):
+    """dW[n][k] = sum_r dy[r][n] * x[r][k] with split-K over r (partials reduced by a column-sum pass; with `out` [N,K] -- a
+    parameter's gradient buffer -- that pass ADDS into it and `out` is returned: no separate accumulation launch)."""
     dy2, x2 = ops.rows2d(dy), ops.rows2d(x)
     R, N = dy2.shape
     K = x2.shape[1]
     if (ops.ROUTER_GEMM_PRECISION == "fp16x3" and ops.ROUTER_WGRAD_X3 and R % 32 == 0 and R >= 4096 and K >= 64 and N >= 64 and N % 4 == 0 and K % 4 == 0
             and dy2.is_contiguous() and x2.is_contiguous()):
-        return x3_wgrad(dy2, x2, sd, sx)
+        return x3_wgrad(dy2, x2, sd, sx, out)
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     S = _pick_split(R, tiles)
     Rc = R // S
@@ -121,23 +126,29 @@ def linear_wgrad(dy, x, sd=None, sx=None):
                  (N * K, K, 1))
     if S == 1:
         return part[0]
+    if out is not None:
+        ops.colsum(part.view(S, N * K), out=out.view(-1), accumulate=True)
+        return out
     return ops.colsum(part.view(S, N * K)).view(N, K)
 
 
-def side_param_grads(params, compute, used):
+def side_param_grads(params, compute, used, into=False):
     """params: the Parameters a backward function owes gradients (None entries allowed); compute() -> their gradients in the same
     order.  Inside `with ops.direct_gradients()` (loss.backward() into the flat gradient, N = 1) the gradients are computed on the side
     stream and ADDED into each parameter's .grad there -- off the backward chain, filling the idle CUs next to the recurrent kernels
     (ops.side_stream_begin; the backward pass's final callback joins the streams) -- and None is returned for every parameter.
-    `used`: the tensors compute() reads (kept alive for the side stream).  Otherwise: just compute()."""
+    `used`: the tensors compute() reads (kept alive for the side stream).  Otherwise: just compute().
+    into=True: compute(outs) is handed the parameters' gradient buffers (None outside direct mode) and may ADD a gradient there itself
+    (its last reduction pass accumulating), returning that same buffer in the gradient's place."""
     ok = (ops.WGRAD_SIDE_STREAM and ops.GRAD_DIRECT and not torch.is_grad_enabled() and
           all(p is None or (p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32) for p in params))
     if not ok:
-        return list(compute())
+        return list(compute([None] * len(params)) if into else compute())
     side = ops.side_stream_begin()
     with torch.cuda.stream(side):
-        for p, g in zip(params, compute()):
-            if p is not None and g is not None:
+        outs = [p.grad if p is not None else None for p in params]
+        for p, g, o in zip(params, compute(outs) if into else compute(), outs):
+            if p is not None and g is not None and g is not o:
                 p.grad.add_(g.reshape(p.grad.shape))
     ops.side_stream_keep(used)
     ops.direct_done(params)
@@ -162,7 +173,8 @@ class LinearFn(torch.autograd.Function):
         dx = linear_dgrad(dy, weight).view(x.shape) if ctx.needs_input_grad[0] else None
         need_w, need_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         dw, db = side_param_grads([ctx.params[0] if need_w else None, ctx.params[1] if need_b else None],
-                                  lambda: (linear_wgrad(dy, x) if need_w else None, ops.colsum(dy) if need_b else None), (dy, x))
+                                  lambda o: (linear_wgrad(dy, x, out=o[0]) if need_w else None,
+                                             ops.colsum(dy, out=o[1], accumulate=True) if need_b else None), (dy, x), into=True)
         return dx, dw, db
 
 
@@ -394,13 +406,14 @@ class ConvBlockFn(torch.autograd.Function):
         mom = 0.1 if bn.momentum is None else bn.momentum
         scale, shift, mean, invstd = ops.bn_finalize(stats, bn.num_features, count, gamma, beta, bn.running_mean,
                                                      bn.running_var, mom, bn.eps, save=True)
-        if bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
+        ops.count_batch(bn)
         z = torch.empty_like(y)
+        # the backward pass needs only the SIGN of z (ReLU mask): 4 bits per 4 channels written by this pass, read there instead of z
+        zmask = torch.empty(z.numel() // 4, device=z.device, dtype=torch.uint8) if relu else None
         # z is (almost always) the operand of the next trained convolution: its range scale comes out of this pass
-        ops.scale_shift_act(y, scale, shift, relu=relu, residual=residual, out=z,
+        ops.scale_shift_act(y, scale, shift, relu=relu, residual=residual, out=z, pos_mask=zmask,
                             range_target=ops.TRAIN_OPERAND_PEAK if (precision == "fp16x3s" and z.shape[-1] % 32 == 0) else None)
-        ctx.save_for_backward(x, z if relu else None, y, mean, invstd, gamma)
+        ctx.save_for_backward(x, zmask, y, mean, invstd, gamma)
         return z
 
     @staticmethod
@@ -411,12 +424,22 @@ class ConvBlockFn(torch.autograd.Function):
         dz = dz.contiguous()
         dgamma = dbeta = dres = dbias = None
         sd = None
+        direct = ops.WGRAD_SIDE_STREAM and ops.GRAD_DIRECT and not torch.is_grad_enabled()
         if has_bn:
+            # (z is the bit mask here.)  In direct mode the BatchNorm weight / bias gradients are added to the flat gradient by the
+            # finalize launch of the statistics (main stream): no reduction launches, no accumulation launches
+            bw, bb = ctx.bn.weight, ctx.bn.bias
+            acc = None
+            if (direct and ctx.needs_input_grad[3] and ctx.needs_input_grad[4]
+                    and all(p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous() for p in (bw, bb))):
+                acc = (bw.grad, bb.grad)
             if precision == "fp16x3s":      # max|dy| folded into the apply pass: the range scale shared by the data and weight gradients
-                dy, dgamma, dbeta, dres, sd = ops.bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres=has_res,
-                                                         range_target=ops.TRAIN_OPERAND_PEAK)
+                dy, dgamma, dbeta, dres, sd = ops.bn_bwd(dz, None, y, mean, invstd, gamma, relu, want_dres=has_res,
+                                                         range_target=ops.TRAIN_OPERAND_PEAK, zmask=z, grad_acc=acc)
             else:
-                dy, dgamma, dbeta, dres = ops.bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres=has_res)
+                dy, dgamma, dbeta, dres = ops.bn_bwd(dz, None, y, mean, invstd, gamma, relu, want_dres=has_res, zmask=z, grad_acc=acc)
+            if acc is not None:
+                ops.direct_done((bw, bb))
             if ctx.needs_input_grad[2]:       # a conv bias in front of train-mode BatchNorm (SVTR PatchEmbed) cancels in the
                 dbias = torch.zeros(dy.shape[-1], device=dy.device, dtype=torch.float32)     # mean: its gradient is exactly 0
         else:
@@ -428,11 +451,11 @@ class ConvBlockFn(torch.autograd.Function):
         if sd is None and precision == "fp16x3s":
             sd = ops.pow2_scale(dy, ops.TRAIN_OPERAND_PEAK)                                   # shared by the data and weight gradients
 
-        def weight_gradient():                                                               # -> [O,kh,kw,I]
+        def weight_gradient(acc=None):                  # -> [O,kh,kw,I], or None when it was ADDED into acc ([O,I,kh,kw], 16-byte aligned)
             kh, kw = w.shape[1], w.shape[2]
             if precision == "fp16x3s" and x.shape[-1] % 4 == 0 and ops.TRAIN_WGRAD_X3:
                 if ops.wgrad_wino_supported(dy, x, (kh, kw), stride, padding):
-                    return ops.conv2d_wgrad_x3_wino(dy, x, dy_scale=sd, x_scale=ctx.x_scale)
+                    return ops.conv2d_wgrad_x3_wino(dy, x, dy_scale=sd, x_scale=ctx.x_scale, acc_oihw=acc)
                 if ops.WGRAD_WINDOWS and ops.wgrad_windows_supported(dy, x, (kh, kw), stride, padding):
                     return ops.conv2d_wgrad_x3_windows(dy, x, dy_scale=sd, x_scale=ctx.x_scale)
                 return ops.conv2d_wgrad_x3(dy, x, (kh, kw), stride, padding, dy_scale=sd, x_scale=ctx.x_scale)
@@ -445,7 +468,9 @@ class ConvBlockFn(torch.autograd.Function):
                 # off the critical path: second stream, accumulated straight into the parameter's gradient (ops.side_stream_begin)
                 side = ops.side_stream_begin()
                 with torch.cuda.stream(side):
-                    ops.unpack_conv_weight(weight_gradient(), out=wgrad, accumulate=True)
+                    g = weight_gradient(wgrad if wgrad.data_ptr() % 16 == 0 else None)
+                    if g is not None:
+                        ops.unpack_conv_weight(g, out=wgrad, accumulate=True)
                 ops.side_stream_keep((dy, x, sd, ctx.x_scale))
                 ops.direct_done((ctx.conv.weight,))
             else:
@@ -484,8 +509,7 @@ class BatchNorm2dFn(torch.autograd.Function):
         mom = 0.1 if bn.momentum is None else bn.momentum
         scale, shift, mean, invstd = ops.bn_finalize(ops.bn_stats(x), C, count, gamma, beta, bn.running_mean, bn.running_var,
                                                      mom, bn.eps, save=True)
-        if bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
+        ops.count_batch(bn)
         y = torch.empty_like(x)
         ops.scale_shift_act(x, scale, shift, relu=relu, out=y)
         ctx.save_for_backward(x, y, mean, invstd, gamma)
@@ -508,8 +532,7 @@ def batch_norm_nhwc(x, bn, relu=False):
         mom = 0.1 if bn.momentum is None else bn.momentum
         scale, shift, _, _ = ops.bn_finalize(ops.bn_stats(x.contiguous()), C, x.numel() // C, bn.weight, bn.bias, bn.running_mean,
                                              bn.running_var, mom, bn.eps)
-        if bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
+        ops.count_batch(bn)
     else:
         if needs_grad(bn, x):
             raise NotImplementedError("backward through eval-mode BatchNorm is not implemented (experts train in train mode)")
@@ -825,8 +848,8 @@ class TrainLinearFn(torch.autograd.Function):
         dx = linear_dgrad(dy2, weight, sd=sd, sw=sw).view(x.shape) if ctx.needs_input_grad[0] else None
         need_w, need_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         dw, db = side_param_grads([ctx.params[0] if need_w else None, ctx.params[1] if need_b else None],
-                                  lambda: (linear_wgrad(dy2, x.view(-1, x.shape[-1]), sd, sx) if need_w else None,
-                                           ops.colsum(dy2) if need_b else None), (dy2, x, sd, sx))
+                                  lambda o: (linear_wgrad(dy2, x.view(-1, x.shape[-1]), sd, sx, out=o[0]) if need_w else None,
+                                             ops.colsum(dy2, out=o[1], accumulate=True) if need_b else None), (dy2, x, sd, sx), into=True)
         return dx, dw, db
 
 
@@ -836,12 +859,24 @@ class LayerNormFn(torch.autograd.Function):
         x = x.contiguous()
         y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, eps)
         ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.params = (gamma, beta)
+        ops.note_param_uses(ctx.params, any(ctx.needs_input_grad))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, gamma, mean, rstd = ctx.saved_tensors
-        dx, dgamma, dbeta = ops.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd)
+        gw, gb = (p.grad for p in ctx.params)
+        C = gamma.numel()
+        acc = None
+        # direct mode: weight.grad and bias.grad are neighbours in the flat gradient -- the reduction of the partials adds into both at once
+        if (ops.GRAD_DIRECT and not torch.is_grad_enabled() and ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and gw is not None
+                and gb is not None and gw.dtype == torch.float32 and gw.is_contiguous() and gb.is_contiguous()
+                and gb.data_ptr() == gw.data_ptr() + 4 * C and gw.untyped_storage().data_ptr() == gb.untyped_storage().data_ptr()):
+            acc = torch.as_strided(gw, (2 * C,), (1,))
+        dx, dgamma, dbeta = ops.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, grad_acc=acc)
+        if acc is not None:
+            ops.direct_done(ctx.params)
         return dx, dgamma, dbeta, None
 
 

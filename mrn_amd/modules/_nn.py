@@ -63,8 +63,7 @@ def bn_scale_shift(bn, stats, count):
         mom = 0.1 if bn.momentum is None else bn.momentum
         scale, shift, _, _ = ops.bn_finalize(stats, bn.num_features, count, bn.weight, bn.bias, bn.running_mean,
                                              bn.running_var, mom, bn.eps)
-        if bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
+        ops.count_batch(bn)
         return scale, shift
     return ops.bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
 

@@ -62,9 +62,10 @@ class Model_Extractor(nn.Module):
 
     def visual(self, image):
         """Transformation + FeatureExtraction (+ the reference's permute / AdaptiveAvgPool / squeeze): [B,C,H,W] -> [B,T,C']"""
-        if not self.stages["Trans"] == "None":
-            image = self.Transformation(image)
-        fmap = self.FeatureExtraction(image)                 # logical [B,C,H,W], NHWC memory
+        with ops.batch_counters():                           # (the train-mode BatchNorm layers' num_batches_tracked: one launch)
+            if not self.stages["Trans"] == "None":
+                image = self.Transformation(image)
+            fmap = self.FeatureExtraction(image)             # logical [B,C,H,W], NHWC memory
         B, C, H, W = fmap.shape
         if H != 1:
             raise NotImplementedError("HIP path expects a height-1 feature map (32x256 inputs); got H=%d" % H)

@@ -449,7 +449,7 @@ def conv2d_wgrad_x3_windows(dy, x, dy_scale=None, x_scale=None):
     timed = CONV_TIMER is not None
     t0 = CONV_TIMER.begin() if timed else None
     call("mrn_gemm_x3_windows_hl32", _p(a_hl), Cout * lines * 128, lines, _p(w_hl), 3 * per, lines, _p(tab), G, Cout, Cin,
-         _p(_zero_page(dev)), _p(sx.view(1, 2).expand(G, 2).contiguous()), _p(sd), _p(part), tile_m, tile_n, int(TRAIN_PRODUCTS), _stream())
+         _p(_zero_page(dev)), _p(sx), _p(sd), _p(part), tile_m, tile_n, int(TRAIN_PRODUCTS), _stream())
     if timed:
         CONV_TIMER.end(t0, 2.0 * 9 * Cout * Cin * P, "fp16x3/x3g%dx%d" % (tile_m, tile_n), 4.0 * (4 * P * Cin + P * Cout + G * Cout * Cin))
     dw = colsum(part.view(S, 9 * Cout * Cin)).view(9, Cout, Cin) if S > 1 else part[0]
@@ -468,10 +468,11 @@ def wgrad_wino_supported(dy, x, ksize, stride, padding):
             and H >= 2 and (B * ((W + 3) // 4)) % 32 == 0 and Cout % 4 == 0 and tuple(x.shape[:3]) == (B, H, W))
 
 
-def conv2d_wgrad_x3_wino(dy, x, dy_scale=None, x_scale=None):
+def conv2d_wgrad_x3_wino(dy, x, dy_scale=None, x_scale=None, acc_oihw=None):
     """dW [Cout,3,3,Cin] of a 3x3 / stride 1 / pad 1 conv in the Winograd domain (F(4,3) along W): dU_m[ky] = sum over column groups of
     (A dy)_m (x) (B^T x)_m shifted by ky - 1 image rows -- 18 K-windows of a quarter of the pixel count on the grouped x3 GEMM -- then
-    dW[ky][kx] = sum_m G[m][kx] dU_m[ky].  Half the matrix work of conv2d_wgrad_x3_windows and 3x instead of 4x the operand bytes."""
+    dW[ky][kx] = sum_m G[m][kx] dU_m[ky].  Half the matrix work of conv2d_wgrad_x3_windows and 3x instead of 4x the operand bytes.
+    acc_oihw: the parameter's [Cout,Cin,3,3] gradient -- dW is ADDED there by the finish launch and None is returned"""
     B, H, W, Cout = dy.shape
     Cin = x.shape[-1]
     Wq = (W + 3) // 4
@@ -509,11 +510,15 @@ def conv2d_wgrad_x3_wino(dy, x, dy_scale=None, x_scale=None):
     timed = CONV_TIMER is not None
     t0 = CONV_TIMER.begin() if timed else None
     call("mrn_gemm_x3_windows_hl32", _p(a_hl), a_bytes, lines, _p(w_hl), w_bytes, lines, _p(tab), G, Cout, Cin,
-         _p(_zero_page(dev)), _p(sx.view(1, 2).expand(G, 2).contiguous()), _p(sd), _p(part), tile_m, tile_n, int(TRAIN_PRODUCTS), _stream())
+         _p(_zero_page(dev)), _p(sx), _p(sd), _p(part), tile_m, tile_n, int(TRAIN_PRODUCTS), _stream())
     if timed:
         CONV_TIMER.end(t0, 2.0 * 9 * Cout * Cin * B * H * W, "fp16x3/x3g%dx%d" % (tile_m, tile_n), 4.0 * (6 * Pq * (Cin + Cout) + G * Cout * Cin))
+    if acc_oihw is not None:
+        assert acc_oihw.is_contiguous() and tuple(acc_oihw.shape) == (Cout, Cin, 3, 3) and acc_oihw.data_ptr() % 16 == 0
+        call("mrn_wino_wgrad_finish_f32", _p(part), _p(acc_oihw), S, Cout, Cin, 1, _stream())
+        return None
     dw = torch.empty(Cout, 3, 3, Cin, device=dev, dtype=torch.float32)
-    call("mrn_wino_wgrad_finish_f32", _p(part), _p(dw), S, Cout, Cin, _stream())
+    call("mrn_wino_wgrad_finish_f32", _p(part), _p(dw), S, Cout, Cin, 0, _stream())
     return dw
 
 
@@ -942,15 +947,16 @@ def clear_scale_cache():
     _SCALE_CACHE.clear()
 
 
-def scale_shift_act(x, scale, shift, relu=True, residual=None, out=None, range_target=None):
+def scale_shift_act(x, scale, shift, relu=True, residual=None, out=None, range_target=None, pos_mask=None):
     """range_target: also fold max|out| into the pass and keep the power-of-two range scale {s, 1/s} (s * max|out| <= range_target)
-    for the consumer (cached_scale): saves the extra read of the tensor mrn_pow2_scale_f32 would make"""
+    for the consumer (cached_scale): saves the extra read of the tensor mrn_pow2_scale_f32 would make.
+    pos_mask: uint8 [numel / 4] receiving the ReLU mask of the backward pass (bn_bwd zmask)"""
     C = x.shape[-1]
     rows = x.numel() // C
     if out is None:
         out = x
     ws = _amax_ws() if (range_target is not None and FUSED_AMAX) else None
-    call("mrn_scale_shift_act_f32", _p(x), _p(residual), _p(out), _p(scale), _p(shift), rows, C, int(relu), ws, _stream())
+    call("mrn_scale_shift_act_f32", _p(x), _p(residual), _p(out), _p(scale), _p(shift), rows, C, int(relu), ws, _p(pos_mask), _stream())
     if ws is not None:
         sc = torch.empty(2, device=x.device, dtype=torch.float32)
         call("mrn_pow2_finalize_f32", float(range_target), _p(sc), ws, _stream())
@@ -1202,8 +1208,9 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, out=None):
     return out, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dx=None, accumulate=False):
-    """-> (dx, dgamma, dbeta)"""
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx=None, accumulate=False, grad_acc=None):
+    """-> (dx, dgamma, dbeta); grad_acc: [2C] buffer ([weight.grad | bias.grad], adjacent in the flat gradient) the reduction of the
+    partials ADDS into -- (dx, None, None) is returned"""
     dy2, x2 = rows2d(dy), rows2d(x)
     rows, C = x2.shape
     if dx is None:
@@ -1214,6 +1221,9 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx=None, accumulate=False):
     part = torch.empty(nblk, 2 * C, device=x.device, dtype=torch.float32)
     call("mrn_layernorm_bwd_f32", _p(dy2), dy2.stride(0), _p(x2), x2.stride(0), _p(gamma), _p(mean), _p(rstd), _p(dx2),
          dx2.stride(0), int(accumulate), _p(part), rows, C, _stream())
+    if grad_acc is not None:
+        colsum(part, out=grad_acc, accumulate=True)
+        return dx, None, None
     dgb = colsum(part)
     return dx, dgb[:C], dgb[C:]
 
@@ -1622,27 +1632,65 @@ def side_stream_begin():
     return st
 
 
-def bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres=False, range_target=None):
+# BatchNorm2d.num_batches_tracked += 1 of every train-mode layer: inside `with batch_counters():` (one expert's backbone forward,
+# modules/model.py visual()) the increments are collected and issued as ONE multi-tensor launch at the end (36 launches -> 1 on TRBA)
+_NBT_PENDING, _NBT_DEPTH = [], [0]
+
+
+def count_batch(bn):
+    if bn.num_batches_tracked is None:
+        return
+    if _NBT_DEPTH[0] > 0:
+        _NBT_PENDING.append(bn.num_batches_tracked)
+    else:
+        bn.num_batches_tracked.add_(1)
+
+
+class batch_counters:
+    def __enter__(self):
+        _NBT_DEPTH[0] += 1
+
+    def __exit__(self, *exc):
+        _NBT_DEPTH[0] -= 1
+        if _NBT_DEPTH[0] == 0 and _NBT_PENDING:
+            pending = list(_NBT_PENDING)
+            _NBT_PENDING.clear()
+            while pending:                           # a layer called twice is listed twice: one round per multiplicity (no in-launch races)
+                seen, first, rest = set(), [], []
+                for t in pending:
+                    (rest if id(t) in seen else first).append(t)
+                    seen.add(id(t))
+                torch._foreach_add_(first, 1)
+                pending = rest
+        return False
+
+
+def bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres=False, range_target=None, zmask=None, grad_acc=None):
     """BatchNorm2d(train) backward with fused ReLU mask -> (dy, dgamma, dbeta, dres or None[, range scale of dy]); range_target: max|dy|
-    is folded into the apply pass and the power-of-two scale {s, 1/s} with s * max|dy| <= range_target is returned as a fifth value"""
+    is folded into the apply pass and the power-of-two scale {s, 1/s} with s * max|dy| <= range_target is returned as a fifth value.
+    zmask: the forward pass's ReLU bit mask (scale_shift_act pos_mask) in place of z.  grad_acc = (weight.grad, bias.grad): dgamma / dbeta
+    are ADDED there by the finalize launch and returned as None"""
     C = y.shape[-1]
     rows = y.numel() // C
     nblk = call("mrn_bn_bwd_blocks", rows)
     part = torch.empty(nblk, 2 * C, device=y.device, dtype=torch.float32)
-    call("mrn_bn_bwd_reduce_f32", _p(dz), _p(z), _p(y), _p(mean), _p(invstd), _p(part), rows, C, int(relu), _stream())
-    sums = colsum(part)                     # [2C]: sum g, sum g*xhat
+    call("mrn_bn_bwd_reduce_f32", _p(dz), _p(z), _p(zmask), _p(y), _p(mean), _p(invstd), _p(part), rows, C, int(relu), _stream())
+    sums = torch.empty(2 * C, device=y.device, dtype=torch.float32)          # sum g | sum g * xhat
+    gw, gb = grad_acc if grad_acc is not None else (None, None)
+    call("mrn_bn_bwd_finalize_f32", _p(part), nblk, C, _p(sums), _p(gw), _p(gb), _stream())
+    dgamma, dbeta = (None, None) if grad_acc is not None else (sums[C:], sums[:C])
     dy = torch.empty_like(y)
     dres = torch.empty_like(y) if want_dres else None
     ws = _amax_ws() if (range_target is not None and FUSED_AMAX) else None
-    call("mrn_bn_bwd_apply_f32", _p(dz), _p(z), _p(y), _p(mean), _p(invstd), _p(gamma), _p(sums), _p(dy), _p(dres), rows, C,
+    call("mrn_bn_bwd_apply_f32", _p(dz), _p(z), _p(zmask), _p(y), _p(mean), _p(invstd), _p(gamma), _p(sums), _p(dy), _p(dres), rows, C,
          int(relu), ws, _stream())
     if range_target is None:
-        return dy, sums[C:], sums[:C], dres
+        return dy, dgamma, dbeta, dres
     if ws is None:
-        return dy, sums[C:], sums[:C], dres, pow2_scale(dy, range_target)
+        return dy, dgamma, dbeta, dres, pow2_scale(dy, range_target)
     sc = torch.empty(2, device=y.device, dtype=torch.float32)
     call("mrn_pow2_finalize_f32", float(range_target), _p(sc), ws, _stream())
-    return dy, sums[C:], sums[:C], dres, sc
+    return dy, dgamma, dbeta, dres, sc
 
 
 def maxpool_bwd(dy, x, kernel, stride, padding):

@@ -41,8 +41,10 @@ def main():
     for _ in range(steps):
         image, labels = data.get_batch()
         loss = learner.train_step(image, labels)
+    host = (time.perf_counter() - t0) / steps       # launch-side time: equal to dt when the host is the bottleneck
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    print(f"host launch time {host * 1e3:.1f} ms/step")
     print(f"loop A {model} B={batch} train precision {ops.TRAIN_CONV_PRECISION}: {dt * 1e3:.1f} ms/step, {batch / dt:.0f} images/s, loss {float(loss):.4f}")
 
 
