@@ -86,7 +86,9 @@ int mrn_conv2d_x3_hl32(const void* x_hl, const void* w_hl, const void* zero_page
                        const float* residual, float* y, float* stats, const float* out_scale, const float* x_scale, int G, int64_t x_group_stride_bytes, int B, int H, int W,
                        int Cin, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int act, int tile_m, int tile_n,
                        int64_t y_row_stride, int64_t y_group_stride, int x_group_div, void* y_hl32, int products, const float* ch_scale,
-                       const float* ch_shift, const void* residual_hl32, void* stream);
+                       const float* ch_shift, const void* residual_hl32, void* amax_ws, void* stream);
+/* amax_ws (optional): max|y| of the stored result folded into 64 words (mrn_pow2_finalize_f32 turns them into {s, 1/s}): the range of the
+ * NEXT trained layer's operand without a pass over y (qkv -> attention -> proj, fc1 -> GELU -> fc2 in loop A) */
 int64_t mrn_conv2d_x3_stats_floats(int G, int B, int Ho, int Wo, int Cout, int tile_m);
 int mrn_split_hl32_f32(const float* x, void* out, int64_t rows, int C, const float* scale, void* stream);
 /* transposed split for weight-gradient GEMMs (dW = dy^T x reduces over rows): x[rows][C] -> [splits][C][rows/splits/32][128 B],
@@ -369,6 +371,17 @@ int mrn_embed_gather_f32(const int64_t* idx, int64_t idx_stride, const float* ta
  * mean / rstd [rows] are saved for the backward. C % 4 == 0, C <= 1024. */
 int mrn_layernorm_fwd_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy,
                           float* mean, float* rstd, int64_t rows, int C, float eps, void* stream);
+/* ... and, for the Linear layer the norm feeds in an expert being TRAINED (svtr.py:200-204: norm1 -> qkv, norm2 -> fc1), the result a
+ * second time as that GEMM's range-scaled HL32 operand: y_hl [rows][C/32][128 B] = split(s * y), scale_out = {s, 1/s} with s the largest
+ * power of two such that s * (sqrt(C) max|gamma| + max|beta|) <= target -- a bound from the parameters: no max|y| pass, no split pass */
+int mrn_layernorm_fwd_hl32_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy, float* mean,
+                               float* rstd, int64_t rows, int C, float eps, void* y_hl, float* scale_out, float target, void* stream);
+/* elementwise producers of a trained Linear layer's operand over contiguous [rows][C]: y = op(a, b) (op 0 gelu(a), 1 b * gelu'(a), 3 a + b,
+ * 8 a + b * d[row / rows_per_d]: svtr.py:46-67 Mlp activation and its gradient, :17-22,202-203 the DropPath residual add) with, in the same
+ * pass, y_hl = split(scale[0] * y) (HL32, C % 32 == 0) for a scale the caller has (a bound of max|y|) and / or max|y| folded into amax_ws
+ * (64 words, mrn_pow2_finalize_f32) */
+int mrn_ew_operand_f32(const float* a, const float* b, const float* d, int64_t rows_per_d, float* y, void* y_hl, const float* scale,
+                       void* amax_ws, int64_t rows, int C, int op, void* stream);
 int64_t mrn_layernorm_bwd_blocks(int64_t rows);
 /* dx (+)= LayerNorm backward; partials [blocks][2][C] receive per-block sums of (dgamma, dbeta) */
 int mrn_layernorm_bwd_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
@@ -436,7 +449,9 @@ int mrn_svtr_attention_block_x3_f32(const float* x, const float* pending, const 
  * mask_bits: instead of `mask`, the visibility bits [N][ceil(N/32)] of a mask whose entries are 0 or -inf (SVTR's local window
  * mask, svtr.py:117-128): bit k of word t of row q set = key 32t + k is visible to query q. */
 int mrn_svtr_attention_f32(const float* qkv, const float* mask, const void* mask_bits, float* out, void* out_hl32, float* lse,
-                           int B, int N, int C, int heads, float scale, int x3, void* stream);
+                           int B, int N, int C, int heads, float scale, int x3, const float* hl_scale, void* stream);
+/* hl_scale (optional, x3 = 0): {s, 1/s}, out_hl32 = split(s * out): the range-scaled operand of the proj Linear of an expert being trained;
+ * rows of out are convex combinations of rows of v, so the scale of max|qkv| (the qkv GEMM's amax_ws) is a valid one */
 /* Backward of the above for an expert being trained (autograd of svtr.py:140-149 under loss.backward(), il_modules/mrn.py:260):
  * the forward call also stores lse [B][heads][N] (base-2 log-sum-exp of the scaled, masked scores; pass NULL when frozen);
  * dqkv [B][N][3*C] is recomputed tile by tile from qkv, out, dout and lse -- no [N][N] tensor is kept.  dsum: [B][heads][N]

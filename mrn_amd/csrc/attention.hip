@@ -31,6 +31,7 @@ struct AttnParams {
   float* out;          // [B][N][C] fp32, or null
   unsigned char* out_hl;   // the same tensor as HL32 lines [B*N][heads][hi 32 | lo 32] (a head is one 32-channel block), or null
   float* lse;          // [B][heads][N] base-2 log-sum-exp of the scaled, masked scores (kept for the backward pass), or null
+  const float* hl_scale;   // {s, 1/s}: out_hl = split(s * out) -- the range scale of the proj Linear's operand in an expert being trained -- or null
   int B, N, C, heads;
   float scale;
 };
@@ -174,6 +175,7 @@ __global__ __launch_bounds__(AW * 64) void svtr_attention_kernel(const AttnParam
   if (qok) {
     const float inv = 1.f / l_run;
     const long row = (long)b * p.N + q;
+    const float hs = p.hl_scale ? p.hl_scale[0] : 1.f;
     if (p.lse && half == 0) p.lse[(long)bh * p.N + q] = m_run + __builtin_amdgcn_logf(l_run);     // (v_log_f32 is log2)
 #pragma unroll
     for (int e = 0; e < 16; e += 4) {
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(AW * 64) void svtr_attention_kernel(const AttnParam
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           _Float16 hh, ll;
-          split_f16(v[j], hh, ll);
+          split_f16_sat(v[j] * hs, hh, ll);
           hi[j] = hh;
           lo[j] = ll;
         }
@@ -690,15 +692,19 @@ __global__ __launch_bounds__(AW * 64) void svtr_attention_dkv_kernel(const AttnB
 // x3 != 0: both products as split-fp16 x3 (frozen experts; lse must be NULL), else exact fp32 products.
 // mask_bits (optional, instead of mask): [N][ceil(N/32)] visibility bits of a 0 / -inf mask (bit k of word t of row q = key
 // 32t + k is visible to query q): one word per (query, key tile) instead of 16 floats per lane.
+// hl_scale (optional, fp32 kernel only): {s, 1/s} -- out_hl32 = split(s * out), the range-scaled operand of the proj Linear of an expert
+// being trained; any s with s * max|v| <= the fp16 headroom serves (a row of out is a convex combination of rows of v), e.g. the scale
+// of max|qkv| from the qkv GEMM's epilogue (mrn_conv2d_x3_hl32 amax_ws)
 MRN_EXPORT int mrn_svtr_attention_f32(const float* qkv, const float* mask, const void* mask_bits, float* out, void* out_hl32,
-                                      float* lse, int B, int N, int C, int heads, float scale, int x3, void* stream) {
+                                      float* lse, int B, int N, int C, int heads, float scale, int x3, const float* hl_scale, void* stream) {
   MRN_CHECK_ARG(!(mask && mask_bits), "mrn_svtr_attention_f32: pass the additive mask or its bit form, not both");
+  MRN_CHECK_ARG(!(x3 && hl_scale), "mrn_svtr_attention_f32: the x3 variant (frozen experts) writes the unscaled operand");
   MRN_CHECK_ARG(!(x3 && lse), "mrn_svtr_attention_f32: the x3 variant keeps no log-sum-exp (training uses the fp32 kernel)");
   MRN_CHECK_ARG(qkv && (out || out_hl32) && heads >= 1 && C == heads * HD, "mrn_svtr_attention_f32: head dimension must be %d (C=%d heads=%d)", HD, C, heads);
   MRN_CHECK_ARG(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)out % 16 == 0), "mrn_svtr_attention_f32: operands must be 16-byte aligned");
   if (B == 0 || N == 0) return MRN_OK;
   AttnParams p;
-  p.qkv = qkv; p.mask = mask; p.mask_bits = (const unsigned*)mask_bits; p.out = out; p.out_hl = (unsigned char*)out_hl32; p.lse = lse; p.B = B; p.N = N; p.C = C; p.heads = heads; p.scale = scale;
+  p.qkv = qkv; p.mask = mask; p.mask_bits = (const unsigned*)mask_bits; p.out = out; p.out_hl = (unsigned char*)out_hl32; p.lse = lse; p.hl_scale = hl_scale; p.B = B; p.N = N; p.C = C; p.heads = heads; p.scale = scale;
   const long groups = (long)B * heads * ((N + 32 * AW - 1) / (32 * AW));
   if (x3) hipLaunchKernelGGL(svtr_attention_x3_kernel, dim3((unsigned)groups), dim3(AW * 64), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(svtr_attention_kernel, dim3((unsigned)groups), dim3(AW * 64), 0, (hipStream_t)stream, p);

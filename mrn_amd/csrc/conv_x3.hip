@@ -49,6 +49,7 @@ struct ConvX3Params {
   const float* bias;          // [G][N] or null
   const float* out_scale;     // [G][os_stride] = {s, 1/s} (epilogue multiplies by [1]) or null; os_stride 2, or 0: one pair for all groups
   int os_stride;
+  unsigned* amax_ws;          // optional: max|y| of the stored result folded into 64 words (slot = block % 64), see mrn_pow2_finalize_f32
   const float* x_scale;       // [2] = {s, 1/s} of the activation operand (epilogue multiplies by [1]) or null
   const float* res;           // optional residual, same layout as y, added before the activation
   float* y;                   // [G][M][N], or null when only y_hl is wanted
@@ -533,6 +534,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
   const float osc = (p.out_scale ? p.out_scale[g * p.os_stride + 1] : 1.f) * (p.x_scale ? p.x_scale[1] : 1.f);
   const float* rg = p.res ? p.res + (long)g * p.y_gstride : nullptr;
   float csum[WN], csq[WN], bn[WN], cs[WN], sh[WN];
+  float amx = 0.f;
 #pragma unroll
   for (int j = 0; j < WN; ++j) {
     csum[j] = csq[j] = 0.f;
@@ -571,6 +573,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
           csq[j] += v * v;
           if (p.act == 1) v = fmaxf(v, 0.f);
           else if (p.act == 2) v = gelu_fast(v);                                             // GELU (erf), SVTR Mlp
+          amx = fmaxf(amx, fabsf(v));
           if (!HL_OUT || p.y) yg[pix * p.y_ld + n] = v;
           if (HL_OUT && p.y_hl) {       // operand of the next GEMM: 32 lanes fill the hi half and the lo half of one 128-byte line
             _Float16 h, l;               // (pairing neighbouring lanes' halves into 4-byte stores measured no better: SVTR x 6 -2 %)
@@ -583,6 +586,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
       }
       }
     }
+  }
+  if (p.amax_ws) {        // the range of the result for whoever turns it into the next operand (one atomic per wave, spread over 64 words)
+    amx = wave_max(amx);
+    if (lane == 0 && !(amx <= 0.f)) atomicMax(p.amax_ws + ((blockIdx.x * (WAVES_M * WAVES_N) + wave) & 63), __float_as_uint(amx));
   }
   if (p.stats) {
     __syncthreads();      // (every main-loop variant has drained its DMAs with an explicit vmcnt(0) before the epilogue)
@@ -1062,7 +1069,7 @@ MRN_EXPORT int mrn_conv2d_x3_hl32(const void* x_hl, const void* w_hl, const void
                                   int W, int Cin, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int act,
                                   int tile_m, int tile_n, int64_t y_row_stride, int64_t y_group_stride, int x_group_div,
                                   void* y_hl32, int products, const float* ch_scale, const float* ch_shift,
-                                  const void* residual_hl32, void* stream) {
+                                  const void* residual_hl32, void* amax_ws, void* stream) {
   MRN_CHECK_ARG(x_hl && w_hl && zero_page && (y || y_hl32) && G >= 1, "mrn_conv2d_x3_hl32: bad operands");
   MRN_CHECK_ARG(!y_hl32 || (Cout % 32 == 0 && y_row_stride <= 0 && y_group_stride <= 0 && (uintptr_t)y_hl32 % 128 == 0),
                 "mrn_conv2d_x3_hl32: the HL32 result needs Cout %% 32 == 0 and dense rows");
@@ -1081,6 +1088,7 @@ MRN_EXPORT int mrn_conv2d_x3_hl32(const void* x_hl, const void* w_hl, const void
   ConvX3Params p;
   memset(&p, 0, sizeof(p));
   p.x = (const unsigned char*)x_hl; p.w = (const unsigned char*)w_hl; p.zero = (const unsigned char*)zero_page;
+  p.amax_ws = (unsigned*)amax_ws;
   p.bias = bias; p.out_scale = out_scale; p.os_stride = 2; p.x_scale = x_scale; p.res = residual; p.y = y; p.y_hl = (unsigned char*)y_hl32; p.stats = stats;
   p.ch_scale = ch_scale; p.ch_shift = ch_shift; p.res_hl = (const unsigned char*)residual_hl32;
   p.Cb = Cin / 32; p.taps = kh * kw; p.nk = p.Cb * p.taps;

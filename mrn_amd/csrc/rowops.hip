@@ -13,14 +13,36 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 constexpr int LN_MAXV = 4;  // float4 per lane -> C <= 64*4*4 = 1024
 
+// HL: the result also as the range-scaled HL32 operand of the Linear layer that follows (y_hl [rows][C/32][hi 32 | lo 32], C % 32 == 0),
+// with a scale that needs no pass over the data: |xhat| < sqrt(C), so |y| <= sqrt(C) max|gamma| + max|beta| -- every wave derives
+// the same power of two s (s * bound <= target) from the parameters it reads anyway; scale_out = {s, 1/s} for the GEMM's epilogue
+template <bool HL>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, long ldx,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ y, long ldy, float* __restrict__ mean_out,
-                                                            float* __restrict__ rstd_out, long rows, int C, float eps) {
+                                                            float* __restrict__ rstd_out, long rows, int C, float eps,
+                                                            unsigned char* __restrict__ y_hl, float* __restrict__ scale_out, float target) {
   const int lane = threadIdx.x & 63;
   const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int C4 = C >> 2;
+  float sc = 1.f;
+  if constexpr (HL) {
+    float mg = 0.f, mb = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c4 = lane + i * 64;
+      if (c4 < C4) {
+        const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[c4];
+        const f32x4 b = reinterpret_cast<const f32x4*>(beta)[c4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { mg = fmaxf(mg, fabsf(g[j])); mb = fmaxf(mb, fabsf(b[j])); }
+      }
+    }
+    const float bound = sqrtf((float)C) * wave_max(mg) + wave_max(mb);
+    if (bound > 0.f && isfinite(bound)) sc = exp2f(floorf(log2f(target / bound)));
+    if (row == 0 && lane == 0) { scale_out[0] = sc; scale_out[1] = 1.f / sc; }
+  }
   f32x4 v[LN_MAXV];
   float s = 0.f;
 #pragma unroll
@@ -55,6 +77,19 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
       reinterpret_cast<f32x4*>(y + row * ldy)[c4] = o;
+      if constexpr (HL) {
+        typedef _Float16 f16v4 __attribute__((ext_vector_type(4)));
+        f16v4 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          _Float16 hh, ll;
+          split_f16_sat(o[j] * sc, hh, ll);
+          hi[j] = hh; lo[j] = ll;
+        }
+        unsigned char* line = y_hl + (row * (C >> 5) + (c4 >> 3)) * 128 + (c4 & 7) * 8;
+        *reinterpret_cast<f16v4*>(line) = hi;
+        *reinterpret_cast<f16v4*>(line + 64) = lo;
+      }
     }
   }
 }
@@ -241,6 +276,63 @@ __global__ __launch_bounds__(256) void ew_rows_kernel(const float* __restrict__ 
       else o[j] = fmaxf(av[j] + bv[j], 0.f);
     }
     reinterpret_cast<f32x4*>(y + r * ldy)[c4] = o;
+  }
+}
+
+// Elementwise producer of a TRAINED Linear layer's operand (SVTR blocks in loop A, contiguous rows): y = op(a, b) in fp32 and, in the same pass,
+//   y_hl   the range-scaled HL32 operand split(scale[0] * y) ([rows][C/32][hi 32 | lo 32], C % 32 == 0), for a scale the caller already has
+//          (a bound: |gelu(f)| <= |f|, so max|f| from the fc1 GEMM's epilogue serves gelu(f));
+//   amax_ws  max|y| folded into 64 words (mrn_pow2_finalize_f32) for a consumer that needs the exact range (gradients).
+// op 0: gelu(a)   1: b * gelu'(a)   3: a + b   8: a + b * d[row / rows_per_d] (residual add with the per-sample DropPath multiplier)
+__global__ __launch_bounds__(256) void ew_operand_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ d,
+                                                         long rows_per_d, float* __restrict__ y, unsigned char* __restrict__ y_hl,
+                                                         const float* __restrict__ scale, unsigned* __restrict__ amax_ws, long n4, int C4, int op) {
+  typedef _Float16 f16v4 __attribute__((ext_vector_type(4)));
+  const float sc = (y_hl && scale) ? scale[0] : 1.f;
+  float mx = 0.f;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const f32x4 av = reinterpret_cast<const f32x4*>(a)[i];
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (b) bv = reinterpret_cast<const f32x4*>(b)[i];
+    f32x4 o;
+    if (op == 8) {
+      const float dv = d[(i / C4) / rows_per_d];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = fmaf(dv, bv[j], av[j]);      // (as mrn_residual_scale_rows_f32)
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (op == 0) o[j] = gelu_f(av[j]);
+        else if (op == 1) o[j] = bv[j] * gelu_grad_f(av[j]);
+        else o[j] = av[j] + bv[j];
+      }
+    }
+    if (y) reinterpret_cast<f32x4*>(y)[i] = o;
+    if (y_hl) {
+      f16v4 hi, lo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        _Float16 hh, ll;
+        split_f16_sat(o[j] * sc, hh, ll);
+        hi[j] = hh; lo[j] = ll;
+      }
+      const long r = i / C4;
+      const int c4 = (int)(i - r * C4);
+      unsigned char* line = y_hl + (r * (C4 >> 3) + (c4 >> 3)) * 128 + (c4 & 7) * 8;
+      *reinterpret_cast<f16v4*>(line) = hi;
+      *reinterpret_cast<f16v4*>(line + 64) = lo;
+    }
+    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+  }
+  if (amax_ws) {
+    __shared__ float wmax[4];
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      mx = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+      if (!(mx <= 0.f)) atomicMax(amax_ws + (blockIdx.x & 63), __float_as_uint(mx));
+    }
   }
 }
 
@@ -476,9 +568,24 @@ MRN_EXPORT int mrn_layernorm_fwd_f32(const float* x, int64_t ldx, const float* g
   MRN_CHECK_ARG(x && gamma && beta && y, "mrn_layernorm_fwd_f32: null operand");
   MRN_CHECK_ARG(C % 4 == 0 && C <= 1024 && ldx % 4 == 0 && ldy % 4 == 0, "mrn_layernorm_fwd_f32: C=%d must be a multiple of 4, <= 1024", C);
   if (rows == 0) return MRN_OK;
-  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, (long)ldx,
-                     gamma, beta, y, (long)ldy, mean, rstd, (long)rows, C, eps);
+  hipLaunchKernelGGL(layernorm_fwd_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, (long)ldx,
+                     gamma, beta, y, (long)ldy, mean, rstd, (long)rows, C, eps, (unsigned char*)nullptr, (float*)nullptr, 1.f);
   MRN_LAUNCH_CHECK("layernorm_fwd");
+  return MRN_OK;
+}
+
+// the same, and the result a second time as the range-scaled split-fp16 operand of the Linear layer it feeds in an expert being TRAINED
+// (svtr.py:200-204 norm1 -> qkv, norm2 -> fc1): y_hl [rows][C/32][128 B] = split(s * y), scale_out = {s, 1/s}, s the largest power of two
+// with s * (sqrt(C) max|gamma| + max|beta|) <= target -- a bound from the parameters, so no max|y| pass and no separate split pass
+MRN_EXPORT int mrn_layernorm_fwd_hl32_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy,
+                                          float* mean, float* rstd, int64_t rows, int C, float eps, void* y_hl, float* scale_out,
+                                          float target, void* stream) {
+  MRN_CHECK_ARG(x && gamma && beta && y && y_hl && scale_out && target > 0.f, "mrn_layernorm_fwd_hl32_f32: null operand");
+  MRN_CHECK_ARG(C % 32 == 0 && C <= 1024 && ldx % 4 == 0 && ldy % 4 == 0, "mrn_layernorm_fwd_hl32_f32: C=%d must be a multiple of 32, <= 1024", C);
+  if (rows == 0) return MRN_OK;
+  hipLaunchKernelGGL(layernorm_fwd_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, (long)ldx,
+                     gamma, beta, y, (long)ldy, mean, rstd, (long)rows, C, eps, (unsigned char*)y_hl, scale_out, target);
+  MRN_LAUNCH_CHECK("layernorm_fwd_hl32");
   return MRN_OK;
 }
 
@@ -531,6 +638,19 @@ MRN_EXPORT int mrn_ew_rows_f32(const float* a, int64_t lda, const float* b, int6
   hipLaunchKernelGGL(ew_rows_kernel, dim3(ew_grid(rows * (C / 4), 1024)), dim3(256), 0, (hipStream_t)stream, a, (long)lda, b,
                      (long)ldb, y, (long)ldy, (long)rows, C / 4, op);
   MRN_LAUNCH_CHECK("ew_rows");
+  return MRN_OK;
+}
+
+// see ew_operand_kernel: a, b, y contiguous [rows][C]; d [rows / rows_per_d] (op 8); y and / or y_hl (needs C % 32 == 0) and / or amax_ws
+MRN_EXPORT int mrn_ew_operand_f32(const float* a, const float* b, const float* d, int64_t rows_per_d, float* y, void* y_hl,
+                                  const float* scale, void* amax_ws, int64_t rows, int C, int op, void* stream) {
+  MRN_CHECK_ARG(a && (y || y_hl) && (op == 0 || op == 1 || op == 3 || op == 8) && (op == 0 || b) && (op != 8 || (d && rows_per_d >= 1)),
+                "mrn_ew_operand_f32: bad operands for op %d", op);
+  MRN_CHECK_ARG(C % 4 == 0 && (!y_hl || (C % 32 == 0 && (uintptr_t)y_hl % 16 == 0)), "mrn_ew_operand_f32: C %% 4 == 0 (C %% 32 == 0 with an HL32 result), got %d", C);
+  if (rows == 0) return MRN_OK;
+  hipLaunchKernelGGL(ew_operand_kernel, dim3(ew_grid(rows * (C / 4), 1024)), dim3(256), 0, (hipStream_t)stream, a, b, d, (long)rows_per_d, y,
+                     (unsigned char*)y_hl, scale, (unsigned*)amax_ws, (long)(rows * (C / 4)), C / 4, op);
+  MRN_LAUNCH_CHECK("ew_operand");
   return MRN_OK;
 }
 

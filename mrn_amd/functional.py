@@ -21,16 +21,18 @@ def x3_eligible(x2, N, K):
             and x2.shape[0] * max(N, K) * 4 < 2 ** 31)
 
 
-def x3_linear(x2, weight, bias=None, residual=None, act=ops.ACT_NONE, sx=None, sw=None, want_sw=False):
+def x3_linear(x2, weight, bias=None, residual=None, act=ops.ACT_NONE, sx=None, sw=None, want_sw=False, x_hl=None, w_pack=None,
+              amax_ws=None):
     """y = act(x2 @ weight^T + bias (+ residual)) on the split-fp16 x3 MFMA path, both operands prescaled on the device
-    (x2 [R,K] contiguous, weight [N,K]); 22-bit products, fp32 accumulation."""
+    (x2 [R,K] contiguous, weight [N,K]); 22-bit products, fp32 accumulation.  x_hl (with sx): the operand as its producer already
+    split it; w_pack = (w_hl, sw): the weight operand packed ahead of use; amax_ws: max|y| folded into the epilogue"""
     R, K = x2.shape
     N = weight.shape[0]
     if sx is None:
         sx = ops.pow2_scale(x2)
-    w_hl, sw = ops.pack_weights_hl32([weight.detach().contiguous().view(N, 1, 1, K)], scale=sw)
-    y, _ = ops.conv2d_x3(ops.split_hl32(x2, sx), 1, False, R, 1, 1, K, w_hl, sw, N, (1, 1), bias=bias, act=act,
-                         residual=residual, x_scale=sx)
+    w_hl, sw = w_pack if w_pack is not None else ops.pack_weights_hl32([weight.detach().contiguous().view(N, 1, 1, K)], scale=sw)
+    y, _ = ops.conv2d_x3(x_hl if x_hl is not None else ops.split_hl32(x2, sx), 1, False, R, 1, 1, K, w_hl, sw, N, (1, 1), bias=bias,
+                         act=act, residual=residual, x_scale=sx, amax_ws=amax_ws)
     return (y.view(R, N), sw) if want_sw else y.view(R, N)
 
 
@@ -61,12 +63,15 @@ def linear_fwd(x2, weight, bias=None, residual=None, act=ops.ACT_NONE):
     return ops.linear(x2, weight, bias, act=act, residual=residual)
 
 
-def linear_dgrad(dy, weight, out=None, accumulate=False, sd=None, sw=None):
-    """dx = dy @ weight ; dy rows [R, N], weight [N, K] -> [R, K]; sd / sw: pow2 scales of dy / weight when already known"""
+def linear_dgrad(dy, weight, out=None, accumulate=False, sd=None, sw=None, wt_pack=None):
+    """dx = dy @ weight ; dy rows [R, N], weight [N, K] -> [R, K]; sd / sw: pow2 scales of dy / weight when already known; wt_pack:
+    the transposed weight operand (HL32 stack, scale) packed ahead of use"""
     dy2 = ops.rows2d(dy)
     R, N = dy2.shape
     K = weight.shape[1]
     if out is None and x3_eligible(dy2, K, N):
+        if wt_pack is not None:
+            return x3_linear(dy2, weight.detach().t(), sx=sd, w_pack=wt_pack)
         return x3_linear(dy2, weight.detach().t().contiguous(), sx=sd, sw=sw)
     if out is None:
         out = torch.empty(R, K, device=dy.device, dtype=torch.float32)
@@ -821,43 +826,82 @@ def kd_loss(pred, soft, c0, c1, T=2.0):
 
 # ---------------------------------------------------------------------------------------------------------
 # SVTR mixing blocks in expert training (loop A): autograd of modules/svtr.py Block / Attention / Mlp / SubSample
+def _pack_linear(w):
+    """(HL32 stack, scale) of a trained Linear weight [N,K] as the x3 GEMM's weight operand"""
+    N, K = w.shape
+    return ops.pack_weights_hl32([w.detach().contiguous().view(N, 1, 1, K)])
+
+
+def _pack_linear_t(w):
+    """... of its transpose (the data gradient dx = dy W multiplies by W^T as the [K,N] weight operand)"""
+    N, K = w.shape
+    return ops.pack_weights_hl32([w.detach().t().contiguous().view(K, 1, 1, N)])
+
+
 class TrainLinearFn(torch.autograd.Function):
     """y = x W^T + b over contiguous rows, Linear layers of an expert being trained: forward, data gradient and weight
     gradient on the range-safe split-fp16 x3 GEMM when the shape is eligible (exact fp32 otherwise)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, want_range=False):
+        """want_range: max|y| is folded into the GEMM's epilogue and its power-of-two scale left for the pass that derives the next
+        trained operand from y under a bound (|attention(qkv)| <= max|qkv|, |gelu(f)| <= |f|): ops.cached_operand(y)"""
+        xin = x
         x = x.contiguous()
         ctx.has_bias = bias is not None
         K, N = x.shape[-1], weight.shape[0]
         x2 = x.view(-1, K)
-        # one max|x| pass serves the forward product and the weight gradient; one max|dy| pass both gradients
+        # one max|x| pass serves the forward product and the weight gradient; one max|dy| pass both gradients -- and neither pass runs
+        # when the producer of x / dy left the operand's range scale (and the split operand itself) behind
         ctx.x3 = x3_eligible(x2, N, K)
-        sx = ops.pow2_scale(x2) if ctx.x3 else None
-        y, sw = x3_linear(x2, weight, bias, sx=sx, want_sw=True) if ctx.x3 else (ops.linear(x2, weight, bias), None)
+        if not ctx.x3:
+            y, sx, sw = ops.linear(x2, weight, bias), None, None
+        else:
+            got = ops.cached_operand(xin)
+            x_hl, sx = got if (got is not None and got[0] is not None) else (None, ops.pow2_scale(x2))
+            w_pack = ops.train_pack("lin_fwd_x3", (weight,), _pack_linear) if isinstance(weight, torch.nn.Parameter) else None
+            ws = ops._amax_ws() if want_range else None
+            y, sw = x3_linear(x2, weight, bias, sx=sx, want_sw=True, x_hl=x_hl, w_pack=w_pack, amax_ws=ws)
         ctx.save_for_backward(x, weight, sx, sw)          # (sw: max|W| is the same for W^T in the data gradient)
         ctx.params = (weight, bias)
         ops.note_param_uses(ctx.params, any(ctx.needs_input_grad))
-        return y.view(*x.shape[:-1], N)
+        y = y.view(*x.shape[:-1], N)
+        if ctx.x3 and want_range:
+            ops.stash_operand(y, None, ops.pow2_finalize(ops.FP16_WEIGHT_PEAK))
+        return y
 
     @staticmethod
     def backward(ctx, dy):
         x, weight, sx, sw = ctx.saved_tensors
+        got = ops.cached_operand(dy)
         dy2 = dy.contiguous().view(-1, dy.shape[-1])
-        sd = ops.pow2_scale(dy2) if (ctx.x3 or x3_eligible(dy2, x.shape[-1], dy2.shape[1])) else None
-        dx = linear_dgrad(dy2, weight, sd=sd, sw=sw).view(x.shape) if ctx.needs_input_grad[0] else None
+        sd = None
+        if ctx.x3 or x3_eligible(dy2, x.shape[-1], dy2.shape[1]):
+            sd = got[1] if (got is not None and dy2.data_ptr() == dy.data_ptr()) else ops.pow2_scale(dy2)
+        wt_pack = None
+        if ctx.needs_input_grad[0] and sd is not None and isinstance(ctx.params[0], torch.nn.Parameter) and x3_eligible(dy2, x.shape[-1], dy2.shape[1]):
+            wt_pack = ops.train_pack("lin_bwd_x3", (ctx.params[0],), _pack_linear_t)
+        dx = linear_dgrad(dy2, weight, sd=sd, sw=sw, wt_pack=wt_pack).view(x.shape) if ctx.needs_input_grad[0] else None
         need_w, need_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         dw, db = side_param_grads([ctx.params[0] if need_w else None, ctx.params[1] if need_b else None],
                                   lambda o: (linear_wgrad(dy2, x.view(-1, x.shape[-1]), sd, sx, out=o[0]) if need_w else None,
                                              ops.colsum(dy2, out=o[1], accumulate=True) if need_b else None), (dy2, x, sd, sx), into=True)
-        return dx, dw, db
+        return dx, dw, db, None
 
 
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, operand=False):
+        """operand: the result feeds a trained Linear layer -- the pass also writes that GEMM's range-scaled HL32 operand (the scale is
+        a bound from gamma / beta: no max|y| pass, no split pass) and leaves it for TrainLinearFn (ops.cached_operand)"""
         x = x.contiguous()
-        y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, eps)
+        hl = sc = None
+        if operand and x.shape[-1] % 32 == 0 and ops.ROUTER_GEMM_PRECISION == "fp16x3" and ops.TRAIN_OPERAND_FUSION:
+            y, mean, rstd, hl, sc = ops.layernorm_fwd_operand(x, gamma, beta, eps)
+        else:
+            y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, eps)
+        if hl is not None:
+            ops.stash_operand(y, hl, sc)
         ctx.save_for_backward(x, gamma, mean, rstd)
         ctx.params = (gamma, beta)
         ops.note_param_uses(ctx.params, any(ctx.needs_input_grad))
@@ -877,19 +921,31 @@ class LayerNormFn(torch.autograd.Function):
         dx, dgamma, dbeta = ops.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, grad_acc=acc)
         if acc is not None:
             ops.direct_done(ctx.params)
-        return dx, dgamma, dbeta, None
+        return dx, dgamma, dbeta, None, None
 
 
 class GeluFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
+        got = ops.cached_operand(x) if ops.TRAIN_OPERAND_FUSION else None
         x = x.contiguous()
         ctx.save_for_backward(x)
+        if got is not None and x.shape[-1] % 32 == 0:
+            # x came out of a trained Linear that left the scale of max|x| (TrainLinearFn want_range): |gelu(x)| <= |x|, so the same scale
+            # serves the result -- written here as the next Linear's split operand too
+            y, hl, _ = ops.ew_operand(ops.EW_GELU, x, scale=got[1], want_hl=True)
+            ops.stash_operand(y, hl, got[1])
+            return y
         return ops.ew_rows(ops.EW_GELU, x)
 
     @staticmethod
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
+        if ops.TRAIN_OPERAND_FUSION and ops.ROUTER_GEMM_PRECISION == "fp16x3":
+            # the gradient is a trained Linear's dy: its exact range comes out of this pass
+            dx, _, sc = ops.ew_operand(ops.EW_GELU_BWD, x, dy.contiguous(), want_amax=ops.FP16_WEIGHT_PEAK)
+            ops.stash_operand(dx, None, sc, grad=True)
+            return dx
         return ops.ew_rows(ops.EW_GELU_BWD, x, dy.contiguous())
 
 
@@ -926,6 +982,11 @@ class ResidualScaleFn(torch.autograd.Function):
         dy = dy.contiguous()
         if ctx.drop is None:
             return dy, dy, None, None
+        if ops.TRAIN_OPERAND_FUSION and ops.ROUTER_GEMM_PRECISION == "fp16x3":
+            # drop * dy is the dy of the branch's last trained Linear (proj / fc2): its range comes out of this pass
+            db, _, sc = ops.ew_operand(ops.EW_RESIDUAL_SCALE, dy, dy, drop=ctx.drop - 1.0, rows_per_drop=ctx.rps, want_amax=ops.FP16_WEIGHT_PEAK)
+            ops.stash_operand(db, None, sc, grad=True)
+            return dy, db, None, None
         return dy, ops.residual_scale_rows(dy, dy, ctx.drop - 1.0, ctx.rps), None, None       # dy + (drop - 1) dy = drop * dy
 
 
@@ -936,13 +997,21 @@ class SvtrAttentionFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, qkv, mask, heads, scale):
+        qkv_in = qkv
         qkv = qkv.contiguous()
         B, N, C3 = qkv.shape
         C, h = C3 // 3, heads
         d = C // h
         ctx.fused = d == 32 and ops.SVTR_FUSED_ATTENTION
         if ctx.fused:      # flash-style: the fused forward kernel keeps only the log-sum-exp, backward recomputes the tiles
-            out, lse = ops.svtr_attention(qkv, h, scale, mask, want_lse=True)
+            got = ops.cached_operand(qkv_in) if ops.TRAIN_OPERAND_FUSION else None
+            if got is not None:
+                # qkv came out of a trained Linear that left the scale of max|qkv|: rows of the result are convex combinations of rows of
+                # v, so that scale serves it -- written here as the proj Linear's split operand too
+                out, lse, hl = ops.svtr_attention(qkv, h, scale, mask, want_lse=True, want_hl=True, hl_scale=got[1])
+                ops.stash_operand(out, hl, got[1])
+            else:
+                out, lse = ops.svtr_attention(qkv, h, scale, mask, want_lse=True)
             ctx.save_for_backward(qkv, out, lse, mask)
             ctx.cfg = (h, scale)
             return out

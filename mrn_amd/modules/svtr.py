@@ -92,7 +92,7 @@ class Attention(nn.Module):
 
     def forward_train(self, x):
         """autograd path of an expert being trained: x [B,N,C] -> proj(softmax(q k^T * scale + mask) v)"""
-        qkv = TrainLinearFn.apply(x, self.qkv.weight, self.qkv.bias)
+        qkv = TrainLinearFn.apply(x, self.qkv.weight, self.qkv.bias, True)      # (leaves the range of qkv for the attention pass)
         ctx = SvtrAttentionFn.apply(qkv, self._mask_on(x.device), self.num_heads, self.scale)
         return TrainLinearFn.apply(ctx, self.proj.weight, self.proj.bias)
 
@@ -146,11 +146,11 @@ class Block(nn.Module):
         """Block.forward (svtr.py:200-204) under autograd, same DropPath draw order as the inference path"""
         B, N, C = x.shape
         sc = self.drop_path.scale(B, x.device) if isinstance(self.drop_path, DropPath) else None
-        y = LayerNormFn.apply(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        y = LayerNormFn.apply(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, True)
         x = ResidualScaleFn.apply(x, self.mixer.forward_train(y), sc, N)
         sc = self.drop_path.scale(B, x.device) if isinstance(self.drop_path, DropPath) else None
-        y = LayerNormFn.apply(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        hdn = GeluFn.apply(TrainLinearFn.apply(y, self.mlp.fc1.weight, self.mlp.fc1.bias))
+        y = LayerNormFn.apply(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, True)
+        hdn = GeluFn.apply(TrainLinearFn.apply(y, self.mlp.fc1.weight, self.mlp.fc1.bias, True))
         return ResidualScaleFn.apply(x, TrainLinearFn.apply(hdn, self.mlp.fc2.weight, self.mlp.fc2.bias), sc, N)
 
     def forward(self, x):

@@ -126,6 +126,14 @@ def _amax_ws():
     return ws.data_ptr()
 
 
+def pow2_finalize(target):
+    """{s, 1/s} from the maxima a producer just folded into this stream's 64 words (_amax_ws), which are put back to zero"""
+    st = torch.cuda.current_stream()
+    sc = torch.empty(2, device=torch.device("cuda", st.device_index), dtype=torch.float32)
+    call("mrn_pow2_finalize_f32", float(target), _p(sc), _amax_ws(), _stream())
+    return sc
+
+
 def _zero_page(device):
     z = _ZERO_PAGES.get(device)
     if z is None:
@@ -553,7 +561,7 @@ def pack_weights_hl32(ws, scale=None):
 
 def conv2d_x3(x_hl, G, shared_input, B, H, W, Cin, w_hl, w_scale, Cout, ksize, stride=(1, 1), padding=(0, 0), bias=None,
               act=ACT_NONE, want_stats=False, out=None, out_row_stride=0, out_group_stride=0, residual=None, x_scale=None,
-              x_group_div=1, hl_only=False, products=3, ch_scale=None, ch_shift=None, residual_hl=None, also_hl=False):
+              x_group_div=1, hl_only=False, products=3, ch_scale=None, ch_shift=None, residual_hl=None, also_hl=False, amax_ws=None):
     """Grouped conv on HL32 operands -> (y [G,B,Ho,Wo,Cout] fp32, stats or None).  With `out` and the two strides (floats)
     the rows of group g land at out.data_ptr + g * out_group_stride + row * out_row_stride.
     hl_only: the result is written ONLY as the HL32 operand of the next GEMM (returned in place of y); also_hl: fp32 AND HL32
@@ -580,7 +588,7 @@ def conv2d_x3(x_hl, G, shared_input, B, H, W, Cin, w_hl, w_scale, Cout, ksize, s
     call("mrn_conv2d_x3_hl32", _p(x_hl), _p(w_hl), _p(_zero_page(dev)), _p(bias), _p(residual), _p(y), _p(stats), _p(w_scale),
          _p(x_scale), G, gstride,
          B, H, W, Cin, Cout, kh, kw, stride[0], stride[1], padding[0], padding[1], act, tile_m, tile_n, out_row_stride, out_group_stride,
-         x_group_div, _p(y_hl), int(products), _p(ch_scale), _p(ch_shift), _p(residual_hl), _stream())
+         x_group_div, _p(y_hl), int(products), _p(ch_scale), _p(ch_shift), _p(residual_hl), amax_ws, _stream())
     if timed:
         # algorithmic bytes: every operand element once (HL32 = 4 B / element, like fp32) + the fp32 result
         nbytes = 4.0 * ((1 if shared_input else G) * B * H * W * Cin + G * Cout * kh * kw * Cin + G * B * Ho * Wo * Cout)
@@ -698,6 +706,9 @@ def conv2d_x3_wino(v_hl, G, shared_input, B, H, W, Cin, u_hl, u_scale, Cout, R, 
 # layers registered by ConvBlockFn, one event per layer; the consumers below find the operands by (source tensor, version) and wait
 # on the event.  A miss (first step, a layer that changed since) just packs in place, as before.
 TRAIN_PREPACK = os.environ.get("MRN_TRAIN_PREPACK", "1") == "1"
+# trained SVTR blocks (loop A): the pass that produces a Linear layer's input also writes its split operand / leaves its range scale
+# (LayerNorm -> qkv / fc1, attention -> proj, GELU -> fc2; GELU' and the DropPath residual for the gradients); MRN_TRAIN_OPERAND_FUSION=0: A/B
+TRAIN_OPERAND_FUSION = os.environ.get("MRN_TRAIN_OPERAND_FUSION", "1") == "1"
 _PREPACKED = {}                     # key -> (value, event, source tensor kept alive)
 TRAINED_CONVS = {}                  # id(conv) -> (weakref to the module, stride, padding), filled by functional.ConvBlockFn.forward
 
@@ -1208,6 +1219,74 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, out=None):
     return out, mean, rstd
 
 
+def layernorm_fwd_operand(x, gamma, beta, eps=1e-5, target=None):
+    """LayerNorm of contiguous rows, with the result also as the range-scaled HL32 operand of the trained Linear layer it feeds
+    -> (y, mean, rstd, y_hl bytes, scale {s, 1/s}); the scale comes from the parameters (sqrt(C) max|gamma| + max|beta| bounds |y|)"""
+    assert x.is_contiguous()
+    C = x.shape[-1]
+    rows = x.numel() // C
+    out = torch.empty_like(x)
+    mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+    rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+    hl = torch.empty(x.numel() * 4, device=x.device, dtype=torch.uint8)
+    sc = torch.empty(2, device=x.device, dtype=torch.float32)
+    call("mrn_layernorm_fwd_hl32_f32", _p(x), C, _p(gamma), _p(beta), _p(out), C, _p(mean), _p(rstd), rows, C, float(eps), _p(hl), _p(sc),
+         float(FP16_WEIGHT_PEAK if target is None else target), _stream())
+    return out, mean, rstd, hl, sc
+
+
+def ew_operand(op, a, b=None, drop=None, rows_per_drop=1, scale=None, want_hl=False, want_amax=None, want_f32=True):
+    """y = op(a, b) over contiguous [..., C] (EW_GELU, EW_GELU_BWD, EW_ADD, EW_RESIDUAL_SCALE: a + b * drop[row // rows_per_drop]) with the
+    trained consumer's needs folded in: want_hl -> the HL32 operand split(scale[0] * y); want_amax = range target -> max|y| folded and the
+    exact power-of-two scale {s, 1/s} returned.  -> (y or None, y_hl or None, scale or None)"""
+    C = a.shape[-1]
+    rows = a.numel() // C
+    assert a.is_contiguous() and (b is None or (b.is_contiguous() and b.numel() == a.numel()))
+    y = torch.empty_like(a) if want_f32 else None
+    hl = torch.empty(a.numel() * 4, device=a.device, dtype=torch.uint8) if want_hl else None
+    ws = _amax_ws() if want_amax is not None else None
+    call("mrn_ew_operand_f32", _p(a), _p(b), _p(drop), int(rows_per_drop), _p(y), _p(hl), _p(scale), ws, rows, C, int(op), _stream())
+    sc = None
+    if ws is not None:
+        sc = torch.empty(2, device=a.device, dtype=torch.float32)
+        call("mrn_pow2_finalize_f32", float(want_amax), _p(sc), ws, _stream())
+    return y, hl, sc
+
+
+EW_RESIDUAL_SCALE = 8
+
+
+# trained Linear layers find their operand -- already split, with its range scale -- where the producing pass left it (SVTR blocks of
+# loop A: LayerNorm -> qkv / fc1, attention -> proj, GELU -> fc2), or the range scale alone (a bound of max|.| for a producer that
+# derives the next operand from this tensor: qkv -> attention, fc1 -> GELU); keyed by the tensor object, dropped with it
+_OPERANDS = {}
+_GRAD_OPERANDS = {}                 # the same for gradients inside a backward pass: strong references (a gradient's Python object lives only
+                                    # while autograd hands it on), dropped when the pass ends (join_side_stream) or the table grows
+
+
+def stash_operand(t, hl, scale, grad=False):
+    if grad:
+        if len(_GRAD_OPERANDS) > 512:
+            _GRAD_OPERANDS.clear()
+        _GRAD_OPERANDS[id(t)] = (t, hl, scale)
+        return
+    if len(_OPERANDS) > 256:
+        for k in [k for k, v in _OPERANDS.items() if v[0]() is None]:
+            del _OPERANDS[k]
+    _OPERANDS[id(t)] = (weakref.ref(t), hl, scale)
+
+
+def cached_operand(t):
+    """-> (hl or None, scale) left by the producer of t, or None"""
+    got = _GRAD_OPERANDS.get(id(t))
+    if got is not None and got[0] is t:
+        return got[1], got[2]
+    got = _OPERANDS.get(id(t))
+    if got is None or got[0]() is not t:
+        return None
+    return got[1], got[2]
+
+
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx=None, accumulate=False, grad_acc=None):
     """-> (dx, dgamma, dbeta); grad_acc: [2C] buffer ([weight.grad | bias.grad], adjacent in the flat gradient) the reduction of the
     partials ADDS into -- (dx, None, None) is returned"""
@@ -1609,6 +1688,7 @@ def join_side_stream():
         _SIDE_PENDING[0] = False
         torch.cuda.current_stream().wait_stream(side_stream())
     _SIDE_KEEP.clear()
+    _GRAD_OPERANDS.clear()
 
 
 def side_stream_keep(tensors):
@@ -1822,7 +1902,7 @@ def _mask_bits(mask):
     return got[1]
 
 
-def svtr_attention(qkv, heads, scale, mask=None, want_f32=True, want_hl=False, want_lse=False, x3=False):
+def svtr_attention(qkv, heads, scale, mask=None, want_f32=True, want_hl=False, want_lse=False, x3=False, hl_scale=None):
     """qkv [B,N,3C] (q | k | v, head dim 32), mask [N,N] additive symmetric or None -> [B,N,C]: fused q k^T / softmax / attn v.
     want_hl: also (or only) the HL32 operand of the proj Linear; returns the fp32 tensor, the HL32 bytes, or (fp32, hl).
     want_lse: returns (fp32, lse [B,heads,N]) -- what svtr_attention_bwd needs.  x3: split-fp16 x3 products (frozen experts)"""
@@ -1835,9 +1915,9 @@ def svtr_attention(qkv, heads, scale, mask=None, want_f32=True, want_hl=False, w
     lse = torch.empty(B, heads, N, device=qkv.device, dtype=torch.float32) if want_lse else None
     bits = _mask_bits(mask) if (mask is not None and not want_lse) else None     # (the backward kernels read the additive mask)
     call("mrn_svtr_attention_f32", _p(qkv), None if bits is not None else _p(mask), _p(bits), _p(out), _p(hl), _p(lse), B, N, C,
-         heads, float(scale), int(bool(x3) and not want_lse), _stream())
+         heads, float(scale), int(bool(x3) and not want_lse), _p(hl_scale), _stream())
     if want_lse:
-        return out, lse
+        return (out, lse, hl) if want_hl else (out, lse)
     return (out, hl) if (want_f32 and want_hl) else (hl if want_hl else out)
 
 

@@ -1195,3 +1195,68 @@ def test_wgrad_in_the_winograd_domain(B, H, W, Cin, Cout, magnitude):
     if ops.wgrad_windows_supported(dyd, xd, (3, 3), (1, 1), (1, 1)):
         assert (dw - ops.conv2d_wgrad_x3_windows(dyd, xd)).abs().max().item() <= 8e-6 * scale
     assert not ops.wgrad_wino_supported(dyd[:5], xd[:5], (3, 3), (1, 1), (1, 1))                  # 5 * ceil(W/4) groups: not whole lines
+
+
+# ---------------------------------------------------------------------------------------------------------
+# producers of a trained Linear layer's operand (SVTR blocks in loop A): the split operand / its range scale out of the producing pass
+# ---------------------------------------------------------------------------------------------------------
+def _hl_value(hl, rows, C):
+    hv = hl.view(torch.float16).view(rows, C // 32, 2, 32).float()
+    return (hv[:, :, 0] + hv[:, :, 1]).reshape(rows, C)
+
+
+@pytest.mark.parametrize("rows,C,mag", [(517, 64, 1.0), (96, 256, 1e-4), (33, 128, 300.0)])
+def test_layernorm_operand_bound_scale(ops, rows, C, mag):
+    """mrn_layernorm_fwd_hl32_f32: same y / mean / rstd as the plain kernel (bit for bit), the HL32 operand = s * y to 22 bits, and s the
+    largest power of two with s * (sqrt(C) max|gamma| + max|beta|) <= 2^14 -- which bounds max|y|"""
+    x = cu(rnd(rows, C, seed=900) * 3 + 0.5)
+    gamma, beta = cu((rnd(C, seed=901) + 1.5) * mag), cu(rnd(C, seed=902) * 0.3 * mag)
+    y0, m0, r0 = ops.layernorm_fwd(x, gamma, beta, 1e-6)
+    y, mean, rstd, hl, sc = ops.layernorm_fwd_operand(x, gamma, beta, 1e-6)
+    assert torch.equal(y, y0) and torch.equal(mean, m0) and torch.equal(rstd, r0)
+    bound = float(C ** 0.5 * gamma.abs().max() + beta.abs().max())
+    s = float(sc[0])
+    assert s == 2.0 ** np.floor(np.log2(ops.FP16_WEIGHT_PEAK / bound)) and float(sc[1]) == 1.0 / s
+    assert float(y.abs().max()) * s <= ops.FP16_WEIGHT_PEAK
+    assert_close("HL32 operand", _hl_value(hl, rows, C) / s, y, atol=float(y.abs().max()) * 3e-7, rtol=3e-7)
+
+
+def test_elementwise_operand_producers(ops):
+    """mrn_ew_operand_f32: gelu / gelu' / DropPath residual against the plain kernels (bit for bit), the HL32 form under a given scale, and
+    the folded max|y| -> exact power-of-two scale"""
+    B, N, C = 6, 40, 96
+    a, b = cu(rnd(B, N, C, seed=910) * 2), cu(rnd(B, N, C, seed=911) * 1e-3)
+    drop = cu(torch.tensor([0.0, 1.25, 1.25, 0.0, 1.25, 1.25]))
+    sc_in = cu(torch.tensor([2048.0, 1 / 2048.0]))
+    y, hl, _ = ops.ew_operand(ops.EW_GELU, a, scale=sc_in, want_hl=True)
+    assert torch.equal(y, ops.ew_rows(ops.EW_GELU, a))
+    assert_close("gelu HL32 operand", _hl_value(hl, B * N, C) / 2048.0, y.view(-1, C), atol=1e-6, rtol=3e-7)
+    g, _, sc = ops.ew_operand(ops.EW_GELU_BWD, a, b, want_amax=ops.FP16_WEIGHT_PEAK)
+    assert torch.equal(g, ops.ew_rows(ops.EW_GELU_BWD, a, b))
+    assert torch.equal(sc, ops.pow2_scale(g))
+    r, _, sc = ops.ew_operand(ops.EW_RESIDUAL_SCALE, a, b, drop=drop, rows_per_drop=N, want_amax=ops.FP16_WEIGHT_PEAK)
+    assert torch.equal(r, ops.residual_scale_rows(a, b, drop, N))
+    assert torch.equal(sc, ops.pow2_scale(r))
+    # a second producer on the same stream starts from cleared words
+    _, _, sc2 = ops.ew_operand(ops.EW_GELU_BWD, a, b * 1e-3, want_amax=ops.FP16_WEIGHT_PEAK)
+    assert torch.equal(sc2, ops.pow2_scale(ops.ew_rows(ops.EW_GELU_BWD, a, b * 1e-3)))
+
+
+def test_gemm_epilogue_range_and_attention_operand(ops):
+    """mrn_conv2d_x3_hl32 amax_ws: the folded max|y| equals the maximum of the stored result (bias and activation included);
+    mrn_svtr_attention_f32 hl_scale: the HL32 form of the result under the scale of max|qkv| (a bound of max|out|)"""
+    from mrn_amd import functional as Fn
+    R, K, N = 700, 64, 192
+    x, w, bias = cu(rnd(R, K, seed=920)), cu(rnd(N, K, seed=921) * 0.2), cu(rnd(N, seed=922))
+    y = Fn.x3_linear(x, w, bias, amax_ws=ops._amax_ws())
+    sc = ops.pow2_finalize(ops.FP16_WEIGHT_PEAK)
+    assert torch.equal(sc, ops.pow2_scale(y))
+    assert torch.equal(Fn.x3_linear(x, w, bias), y)
+    B, Nt, heads = 3, 72, 2
+    qkv = cu(rnd(B, Nt, 3 * 32 * heads, seed=930) * 1.7)
+    sq = ops.pow2_scale(qkv)
+    out0, lse0 = ops.svtr_attention(qkv, heads, 32 ** -0.5, None, want_lse=True)
+    out, lse, hl = ops.svtr_attention(qkv, heads, 32 ** -0.5, None, want_lse=True, want_hl=True, hl_scale=sq)
+    assert torch.equal(out, out0) and torch.equal(lse, lse0)
+    assert float(out.abs().max()) <= float(qkv.abs().max())
+    assert_close("attention HL32 operand", _hl_value(hl, B * Nt, 32 * heads) / float(sq[0]), out.view(-1, 32 * heads), atol=1e-6, rtol=3e-7)
