@@ -457,7 +457,8 @@ int mrn_svtr_attention_f32(const float* qkv, const float* mask, const void* mask
  * dqkv [B][N][3*C] is recomputed tile by tile from qkv, out, dout and lse -- no [N][N] tensor is kept.  dsum: [B][heads][N]
  * floats of workspace (rowsum(dout o out)). */
 int mrn_svtr_attention_bwd_f32(const float* qkv, const float* mask, const float* out, const float* dout, const float* lse,
-                               float* dsum, float* dqkv, int B, int N, int C, int heads, float scale, void* stream);
+                               float* dsum, float* dqkv, int B, int N, int C, int heads, float scale, void* amax_ws, void* stream);
+/* amax_ws (optional): max|dqkv| folded into 64 words by both kernels (mrn_pow2_finalize_f32): the range of the qkv Linear's gradient operand */
 /* y = x + scale[row / rows_per_group] * branch : residual add with the per-sample DropPath scale (svtr.py:7-22,202-203) */
 int mrn_residual_scale_rows_f32(const float* x, const float* branch, const float* scale, float* y, int64_t rows, int C,
                                 int64_t rows_per_group, void* stream);

@@ -430,9 +430,16 @@ struct AttnBwdParams {
   const float* lse;    // [B][heads][N] from the forward pass (base 2)
   float* dsum;         // [B][heads][N] workspace: D = rowsum(dO o O), written by the dq kernel, read by the dk/dv kernel
   float* dqkv;         // [B][N][3*C]
+  unsigned* amax_ws;   // optional: max|dqkv| folded into 64 words (the range of the qkv Linear's gradient operand), see mrn_pow2_finalize_f32
   int B, N, C, heads;
   float scale;
 };
+
+// one atomic per wave into slot (wave id % 64)
+__device__ __forceinline__ void fold_amax(unsigned* ws, float m, int lane, int slot) {
+  m = wave_max(m);
+  if (lane == 0 && !(m <= 0.f)) atomicMax(ws + (slot & 63), __float_as_uint(m));
+}
 
 constexpr int RS = 40;          // LDS row stride of tiles that are read both by rows (b128) and by columns
 constexpr int kKeyOf(int e) { return (e & 3) + 8 * (e >> 2); }
@@ -548,14 +555,17 @@ __global__ __launch_bounds__(AW * 64) void svtr_attention_dq_kernel(const AttnBw
     if (more) stash(cur ^ 1);
     __syncthreads();
   }
+  float amx = 0.f;
   if (qok) {
     float* drow = p.dqkv + ((long)b * p.N + q) * rs + h * HD;
 #pragma unroll
     for (int e = 0; e < 16; e += 4) {
       const f32x4 v = {dq[e] * p.scale, dq[e + 1] * p.scale, dq[e + 2] * p.scale, dq[e + 3] * p.scale};
       *reinterpret_cast<f32x4*>(drow + 8 * (e >> 2) + 4 * half) = v;
+      amx = fmaxf(fmaxf(amx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
     }
   }
+  if (p.amax_ws) fold_amax(p.amax_ws, amx, lane, blockIdx.x * AW + wave);
 }
 
 __global__ __launch_bounds__(AW * 64) void svtr_attention_dkv_kernel(const AttnBwdParams p) {
@@ -670,6 +680,7 @@ __global__ __launch_bounds__(AW * 64) void svtr_attention_dkv_kernel(const AttnB
     if (more) stash(cur ^ 1);
     __syncthreads();
   }
+  float amx = 0.f;
   if (kok) {
     float* krow = p.dqkv + ((long)b * p.N + key) * rs + p.C + h * HD;
     float* vrow = krow + p.C;
@@ -679,8 +690,11 @@ __global__ __launch_bounds__(AW * 64) void svtr_attention_dkv_kernel(const AttnB
       const f32x4 c = {dv[e], dv[e + 1], dv[e + 2], dv[e + 3]};
       *reinterpret_cast<f32x4*>(krow + 8 * (e >> 2) + 4 * half) = a;
       *reinterpret_cast<f32x4*>(vrow + 8 * (e >> 2) + 4 * half) = c;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) amx = fmaxf(amx, fmaxf(fabsf(a[j]), fabsf(c[j])));
     }
   }
+  if (p.amax_ws) fold_amax(p.amax_ws, amx, lane, blockIdx.x * AW + wave);
 }
 
 }  // namespace
@@ -716,14 +730,14 @@ MRN_EXPORT int mrn_svtr_attention_f32(const float* qkv, const float* mask, const
 // forward pass's log-sum-exp `lse` [B][heads][N]; dsum: [B][heads][N] floats of workspace.  No N x N tensor is stored or read.
 MRN_EXPORT int mrn_svtr_attention_bwd_f32(const float* qkv, const float* mask, const float* out, const float* dout,
                                           const float* lse, float* dsum, float* dqkv, int B, int N, int C, int heads,
-                                          float scale, void* stream) {
+                                          float scale, void* amax_ws, void* stream) {
   MRN_CHECK_ARG(qkv && out && dout && lse && dsum && dqkv && heads >= 1 && C == heads * HD,
                 "mrn_svtr_attention_bwd_f32: bad operands (C=%d heads=%d)", C, heads);
   MRN_CHECK_ARG(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)dout % 16 == 0) && ((uintptr_t)dqkv % 16 == 0),
                 "mrn_svtr_attention_bwd_f32: operands must be 16-byte aligned");
   if (B == 0 || N == 0) return MRN_OK;
   AttnBwdParams p;
-  p.qkv = qkv; p.mask = mask; p.out = out; p.dout = dout; p.lse = lse; p.dsum = dsum; p.dqkv = dqkv;
+  p.qkv = qkv; p.mask = mask; p.out = out; p.dout = dout; p.lse = lse; p.dsum = dsum; p.dqkv = dqkv; p.amax_ws = (unsigned*)amax_ws;
   p.B = B; p.N = N; p.C = C; p.heads = heads; p.scale = scale;
   const long groups = (long)B * heads * ((N + 32 * AW - 1) / (32 * AW));
   hipLaunchKernelGGL(svtr_attention_dq_kernel, dim3((unsigned)groups), dim3(AW * 64), 0, (hipStream_t)stream, p);

@@ -63,7 +63,7 @@ def linear_fwd(x2, weight, bias=None, residual=None, act=ops.ACT_NONE):
     return ops.linear(x2, weight, bias, act=act, residual=residual)
 
 
-def linear_dgrad(dy, weight, out=None, accumulate=False, sd=None, sw=None, wt_pack=None):
+def linear_dgrad(dy, weight, out=None, accumulate=False, sd=None, sw=None, wt_pack=None, amax_ws=None, dy_hl=None):
     """dx = dy @ weight ; dy rows [R, N], weight [N, K] -> [R, K]; sd / sw: pow2 scales of dy / weight when already known; wt_pack:
     the transposed weight operand (HL32 stack, scale) packed ahead of use"""
     dy2 = ops.rows2d(dy)
@@ -71,7 +71,7 @@ def linear_dgrad(dy, weight, out=None, accumulate=False, sd=None, sw=None, wt_pa
     K = weight.shape[1]
     if out is None and x3_eligible(dy2, K, N):
         if wt_pack is not None:
-            return x3_linear(dy2, weight.detach().t(), sx=sd, w_pack=wt_pack)
+            return x3_linear(dy2, weight.detach().t(), sx=sd, w_pack=wt_pack, amax_ws=amax_ws, x_hl=dy_hl)
         return x3_linear(dy2, weight.detach().t().contiguous(), sx=sd, sw=sw)
     if out is None:
         out = torch.empty(R, K, device=dy.device, dtype=torch.float32)
@@ -843,10 +843,12 @@ class TrainLinearFn(torch.autograd.Function):
     gradient on the range-safe split-fp16 x3 GEMM when the shape is eligible (exact fp32 otherwise)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, want_range=False):
+    def forward(ctx, x, weight, bias, want_range=False, dx_range=False):
         """want_range: max|y| is folded into the GEMM's epilogue and its power-of-two scale left for the pass that derives the next
-        trained operand from y under a bound (|attention(qkv)| <= max|qkv|, |gelu(f)| <= |f|): ops.cached_operand(y)"""
+        trained operand from y under a bound (|attention(qkv)| <= max|qkv|, |gelu(f)| <= |f|): ops.cached_operand(y).
+        dx_range: the same for dx in the backward pass, for a GELU in front of this layer (|dx gelu'(.)| <= 1.13 |dx|)"""
         xin = x
+        ctx.dx_range = dx_range
         x = x.contiguous()
         ctx.has_bias = bias is not None
         K, N = x.shape[-1], weight.shape[0]
@@ -875,18 +877,26 @@ class TrainLinearFn(torch.autograd.Function):
         x, weight, sx, sw = ctx.saved_tensors
         got = ops.cached_operand(dy)
         dy2 = dy.contiguous().view(-1, dy.shape[-1])
-        sd = None
+        sd = dy_hl = None
         if ctx.x3 or x3_eligible(dy2, x.shape[-1], dy2.shape[1]):
-            sd = got[1] if (got is not None and dy2.data_ptr() == dy.data_ptr()) else ops.pow2_scale(dy2)
+            if got is not None and dy2.data_ptr() == dy.data_ptr():
+                dy_hl, sd = got
+            else:
+                sd = ops.pow2_scale(dy2)
         wt_pack = None
         if ctx.needs_input_grad[0] and sd is not None and isinstance(ctx.params[0], torch.nn.Parameter) and x3_eligible(dy2, x.shape[-1], dy2.shape[1]):
             wt_pack = ops.train_pack("lin_bwd_x3", (ctx.params[0],), _pack_linear_t)
-        dx = linear_dgrad(dy2, weight, sd=sd, sw=sw, wt_pack=wt_pack).view(x.shape) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            fold = ctx.dx_range and wt_pack is not None and ops.TRAIN_OPERAND_FUSION
+            dx = linear_dgrad(dy2, weight, sd=sd, sw=sw, wt_pack=wt_pack, amax_ws=ops._amax_ws() if fold else None, dy_hl=dy_hl).view(x.shape)
+            if fold:        # half the range target: the consumer multiplies by gelu'(.) <= 1.13
+                ops.stash_operand(dx, None, ops.pow2_finalize(ops.FP16_WEIGHT_PEAK / 2), grad=True)
         need_w, need_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         dw, db = side_param_grads([ctx.params[0] if need_w else None, ctx.params[1] if need_b else None],
                                   lambda o: (linear_wgrad(dy2, x.view(-1, x.shape[-1]), sd, sx, out=o[0]) if need_w else None,
                                              ops.colsum(dy2, out=o[1], accumulate=True) if need_b else None), (dy2, x, sd, sx), into=True)
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 class LayerNormFn(torch.autograd.Function):
@@ -942,8 +952,16 @@ class GeluFn(torch.autograd.Function):
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
         if ops.TRAIN_OPERAND_FUSION and ops.ROUTER_GEMM_PRECISION == "fp16x3":
-            # the gradient is a trained Linear's dy: its exact range comes out of this pass
-            dx, _, sc = ops.ew_operand(ops.EW_GELU_BWD, x, dy.contiguous(), want_amax=ops.FP16_WEIGHT_PEAK)
+            # the gradient is a trained Linear's dy.  With the range of the incoming gradient at hand (the Linear behind this GELU folded
+            # max|dy| into its data-gradient GEMM, at half the target: gelu' <= 1.13) this pass writes the split operand itself;
+            # otherwise the result's exact range comes out of it
+            got = ops.cached_operand(dy)
+            dy = dy.contiguous()
+            if got is not None and x.shape[-1] % 32 == 0:
+                dx, hl, _ = ops.ew_operand(ops.EW_GELU_BWD, x, dy, scale=got[1], want_hl=True)
+                ops.stash_operand(dx, hl, got[1], grad=True)
+                return dx
+            dx, _, sc = ops.ew_operand(ops.EW_GELU_BWD, x, dy, want_amax=ops.FP16_WEIGHT_PEAK)
             ops.stash_operand(dx, None, sc, grad=True)
             return dx
         return ops.ew_rows(ops.EW_GELU_BWD, x, dy.contiguous())
@@ -1035,6 +1053,10 @@ class SvtrAttentionFn(torch.autograd.Function):
         dout = dout.contiguous()
         if ctx.fused:
             qkv, out, lse, mask = ctx.saved_tensors
+            if ops.TRAIN_OPERAND_FUSION and ops.ROUTER_GEMM_PRECISION == "fp16x3":      # dqkv is the qkv Linear's dy: its range comes out of the two kernels
+                dqkv, sc = ops.svtr_attention_bwd(qkv, mask, out, dout, lse, h, scale, want_range=ops.FP16_WEIGHT_PEAK)
+                ops.stash_operand(dqkv, None, sc, grad=True)
+                return dqkv, None, None, None
             return ops.svtr_attention_bwd(qkv, mask, out, dout, lse, h, scale), None, None, None
         qkv, attn = ctx.saved_tensors
         B, N, C3 = qkv.shape

@@ -151,7 +151,7 @@ class Block(nn.Module):
         sc = self.drop_path.scale(B, x.device) if isinstance(self.drop_path, DropPath) else None
         y = LayerNormFn.apply(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, True)
         hdn = GeluFn.apply(TrainLinearFn.apply(y, self.mlp.fc1.weight, self.mlp.fc1.bias, True))
-        return ResidualScaleFn.apply(x, TrainLinearFn.apply(hdn, self.mlp.fc2.weight, self.mlp.fc2.bias), sc, N)
+        return ResidualScaleFn.apply(x, TrainLinearFn.apply(hdn, self.mlp.fc2.weight, self.mlp.fc2.bias, False, True), sc, N)
 
     def forward(self, x):
         if needs_grad(self, x):

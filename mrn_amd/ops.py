@@ -1921,15 +1921,18 @@ def svtr_attention(qkv, heads, scale, mask=None, want_f32=True, want_hl=False, w
     return (out, hl) if (want_f32 and want_hl) else (hl if want_hl else out)
 
 
-def svtr_attention_bwd(qkv, mask, out, dout, lse, heads, scale):
-    """-> dqkv [B,N,3C]; recomputes the probabilities from lse (nothing of size N x N is stored)"""
+def svtr_attention_bwd(qkv, mask, out, dout, lse, heads, scale, want_range=None):
+    """-> dqkv [B,N,3C]; recomputes the probabilities from lse (nothing of size N x N is stored).  want_range = range target: max|dqkv|
+    is folded into both kernels and (dqkv, {s, 1/s}) is returned"""
     _chk(qkv, mask, out, dout, lse)
     B, N, C3 = qkv.shape
     assert qkv.is_contiguous() and out.is_contiguous() and dout.is_contiguous() and lse.is_contiguous()
     dqkv = torch.empty_like(qkv)
     dsum = torch.empty_like(lse)
     call("mrn_svtr_attention_bwd_f32", _p(qkv), _p(mask), _p(out), _p(dout), _p(lse), _p(dsum), _p(dqkv), B, N, C3 // 3, heads,
-         float(scale), _stream())
+         float(scale), _amax_ws() if want_range is not None else None, _stream())
+    if want_range is not None:
+        return dqkv, pow2_finalize(want_range)
     return dqkv
 
 

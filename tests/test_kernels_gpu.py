@@ -1260,3 +1260,7 @@ def test_gemm_epilogue_range_and_attention_operand(ops):
     assert torch.equal(out, out0) and torch.equal(lse, lse0)
     assert float(out.abs().max()) <= float(qkv.abs().max())
     assert_close("attention HL32 operand", _hl_value(hl, B * Nt, 32 * heads) / float(sq[0]), out.view(-1, 32 * heads), atol=1e-6, rtol=3e-7)
+    dout = cu(rnd(B, Nt, 32 * heads, seed=931) * 1e-4)
+    d0 = ops.svtr_attention_bwd(qkv, None, out, dout, lse, heads, 32 ** -0.5)
+    d1, sc = ops.svtr_attention_bwd(qkv, None, out, dout, lse, heads, 32 ** -0.5, want_range=ops.FP16_WEIGHT_PEAK)
+    assert torch.equal(d0, d1) and torch.equal(sc, ops.pow2_scale(d0))
