@@ -17,6 +17,8 @@ def main():
     torch.cuda.set_device(0)
     opt = bench.make_opt("trba", 256)
     learner = bench.build_learner(opt, 6)
+    if os.environ.get("SERIAL") == "1":          # one lock-step group of all experts on one stream: every launch has the GPU to itself
+        learner.model.module.expert_halves = 0
     data = SyntheticTextLines(opt, seed=111)
     data.set_characters(learner.character)
 

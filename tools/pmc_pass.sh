@@ -22,7 +22,7 @@ for f in glob.glob("gpurun_out/$tag/p*/**/*counter_collection.csv", recursive=Tr
         a = agg[row["Counter_Name"]][row["Kernel_Name"].replace("(anonymous namespace)::", "")[:90]]
         a[0] += 1
         a[1] += float(row["Counter_Value"])
-out = {c: {k: {"n": v[0], "sum": v[1]} for k, v in sorted(d.items(), key=lambda kv: -kv[1][1])[:12]} for c, d in agg.items()}
+out = {c: {k: {"n": v[0], "sum": v[1]} for k, v in sorted(d.items(), key=lambda kv: -kv[1][1])[:28]} for c, d in agg.items()}
 json.dump(out, open("gpurun_out/$tag/pmc_summary.json", "w"), indent=1)
 for c, d in out.items():
     k, v = next(iter(d.items()))
