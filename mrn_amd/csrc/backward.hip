@@ -438,19 +438,27 @@ MRN_EXPORT int mrn_bn_bwd_reduce_f32(const float* dz, const float* z, const void
 // sums [2][C] = column sums of the partials [nblk][2][C] (sum g | sum g * xhat: what the apply pass needs); with dgamma_acc / dbeta_acc the
 // two parameter gradients are ADDED there in the same launch (dbeta += sum g, dgamma += sum g * xhat) -- the flat-gradient slices of the
 // BatchNorm weight / bias -- instead of two reduction launches and two accumulation launches
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ sums,
-                                                              float* __restrict__ dgamma_acc, float* __restrict__ dbeta_acc) {
-  __shared__ float red[8][33];
+// (a block = 32 columns x 32 row lanes, two independent loads in flight per lane: the partials are few -- up to 2048 rows -- and the pass is
+// latency-bound; it sits on the backward chain between the reduce and the apply pass)
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ sums,
+                                                               float* __restrict__ dgamma_acc, float* __restrict__ dbeta_acc) {
+  __shared__ float red[32][33];
   const int col = blockIdx.x * 32 + (threadIdx.x & 31), lane = threadIdx.x >> 5;
-  float s = 0.f;
-  if (col < 2 * C)
-    for (int r = lane; r < nblk; r += 8) s += part[(long)r * 2 * C + col];
-  red[lane][threadIdx.x & 31] = s;
+  float s0 = 0.f, s1 = 0.f;
+  if (col < 2 * C) {
+    int r = lane;
+    for (; r + 32 < nblk; r += 64) {
+      s0 += part[(long)r * 2 * C + col];
+      s1 += part[(long)(r + 32) * 2 * C + col];
+    }
+    if (r < nblk) s0 += part[(long)r * 2 * C + col];
+  }
+  red[lane][threadIdx.x & 31] = s0 + s1;
   __syncthreads();
   if (threadIdx.x < 32 && col < 2 * C) {
     float t = 0.f;
 #pragma unroll
-    for (int l = 0; l < 8; ++l) t += red[l][threadIdx.x];
+    for (int l = 0; l < 32; ++l) t += red[l][threadIdx.x];
     sums[col] = t;
     if (col < C) {
       if (dbeta_acc) dbeta_acc[col] += t;
@@ -463,7 +471,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 MRN_EXPORT int mrn_bn_bwd_finalize_f32(const float* partials, int64_t nblk, int C, float* sums, float* dgamma_acc, float* dbeta_acc,
                                        void* stream) {
   MRN_CHECK_ARG(partials && sums && nblk >= 1 && C >= 1, "mrn_bn_bwd_finalize_f32: bad operands");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)((2 * C + 31) / 32)), dim3(256), 0, (hipStream_t)stream, partials, (int)nblk, C,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)((2 * C + 31) / 32)), dim3(1024), 0, (hipStream_t)stream, partials, (int)nblk, C,
                      sums, dgamma_acc, dbeta_acc);
   MRN_LAUNCH_CHECK("bn_bwd_finalize");
   return MRN_OK;

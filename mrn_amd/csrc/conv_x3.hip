@@ -943,46 +943,45 @@ __global__ __launch_bounds__(256) void transpose_oy_wino_hl32_kernel(const float
 }
 
 // dW [Cout][3][3][Cin] = sum over split-K chunks s and components m of G[m][kx] * part[s][m * 3 + ky][co][ci]  (G of F(4,3), unfolded);
-// one lane = 4 consecutive input channels (Cin % 4 == 0): 18 S independent 16-byte streams per lane, split-K chunk outermost
-// OIHW_ACC: dW is ADDED into the parameter's own [Cout][Cin][3][3] gradient (the flat-gradient slice): a lane's 4 channels x 9 taps are 36 contiguous floats
+// one lane = 4 consecutive input channels (Cin % 4 == 0) of ONE kernel row (blockIdx.y = ky: the three rows are independent, and a
+// 512 x 512 layer has only 65536 channel quads -- one wave per SIMD without the split): 6 accumulators, two split-K slabs in flight
+// OIHW_ACC: dW is ADDED into the parameter's own [Cout][Cin][3][3] gradient (the flat-gradient slice)
 template <bool OIHW_ACC>
 __global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, long CC4, int Cin4) {
   const float G[6][3] = {{0.25f, 0.f, 0.f}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
                          {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
   const f32x4* p4 = reinterpret_cast<const f32x4*>(part);
+  const int ky = blockIdx.y;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < CC4; i += (long)gridDim.x * 256) {      // i = (co * Cin + ci) / 4
     const long co = i / Cin4;
     const int c4 = (int)(i - co * Cin4);
-    f32x4 u[18];
+    f32x4 u[6], w[6];
 #pragma unroll
-    for (int k = 0; k < 18; ++k) u[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int s_ = 0; s_ < S; ++s_) {
+    for (int m = 0; m < 6; ++m) u[m] = w[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int s_ = 0;
+    for (; s_ + 1 < S; s_ += 2) {
 #pragma unroll
-      for (int k = 0; k < 18; ++k) u[k] += p4[((long)s_ * 18 + k) * CC4 + i];
-    }
-    float o36[OIHW_ACC ? 36 : 1];
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int m = 0; m < 6; ++m) v += G[m][kx] * u[m * 3 + ky];
-        if constexpr (OIHW_ACC) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) o36[j * 9 + ky * 3 + kx] = v[j];
-        } else {
-          reinterpret_cast<f32x4*>(dw)[((co * 3 + ky) * 3 + kx) * Cin4 + c4] = v;
-        }
+      for (int m = 0; m < 6; ++m) {
+        u[m] += p4[((long)s_ * 18 + m * 3 + ky) * CC4 + i];
+        w[m] += p4[((long)(s_ + 1) * 18 + m * 3 + ky) * CC4 + i];
       }
-    if constexpr (OIHW_ACC) {
-      f32x4* d = reinterpret_cast<f32x4*>(dw + (co * Cin4 + c4) * 36);          // (co * Cin + 4 c4) * 9 floats: 144-byte aligned
+    }
+    if (s_ < S) {
 #pragma unroll
-      for (int q = 0; q < 9; ++q) {
-        f32x4 t = d[q];
+      for (int m = 0; m < 6; ++m) u[m] += p4[((long)s_ * 18 + m * 3 + ky) * CC4 + i];
+    }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) t[j] += o36[q * 4 + j];
-        d[q] = t;
+    for (int m = 0; m < 6; ++m) u[m] += w[m];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int m = 0; m < 6; ++m) v += G[m][kx] * u[m];
+      if constexpr (OIHW_ACC) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dw[((co * Cin4 + c4) * 4 + j) * 9 + ky * 3 + kx] += v[j];
+      } else {
+        reinterpret_cast<f32x4*>(dw)[((co * 3 + ky) * 3 + kx) * Cin4 + c4] = v;
       }
     }
   }
@@ -1243,17 +1242,16 @@ MRN_EXPORT int mrn_transpose_oy_wino_hl32_f32(const float* t, void* out, int B, 
 }
 
 // part [S][18][Cout][Cin] (group (m, ky) = m * 3 + ky of split-K chunk s, from mrn_gemm_x3_windows_hl32) -> dW [Cout][3][3][Cin]
-// (oihw_accumulate 0), or ADDED into dW [Cout][Cin][3][3], the parameter's own layout (oihw_accumulate 1; 16-byte aligned)
+// (oihw_accumulate 0), or ADDED into dW [Cout][Cin][3][3], the parameter's own layout (oihw_accumulate 1)
 MRN_EXPORT int mrn_wino_wgrad_finish_f32(const float* part, float* dw, int S, int Cout, int Cin, int oihw_accumulate, void* stream) {
   MRN_CHECK_ARG(part && dw && S >= 1 && Cout >= 1 && Cin >= 4 && Cin % 4 == 0, "mrn_wino_wgrad_finish_f32: bad operands (Cin %% 4 == 0)");
-  MRN_CHECK_ARG(!oihw_accumulate || (uintptr_t)dw % 16 == 0, "mrn_wino_wgrad_finish_f32: the accumulated gradient must be 16-byte aligned");
   const long CC4 = (long)Cout * Cin / 4;
   long grid = (CC4 + 255) / 256;
   if (grid > 16384) grid = 16384;
   if (oihw_accumulate)
-    hipLaunchKernelGGL(wino_wgrad_finish_kernel<true>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, part, dw, S, CC4, Cin / 4);
+    hipLaunchKernelGGL(wino_wgrad_finish_kernel<true>, dim3((unsigned)grid, 3), dim3(256), 0, (hipStream_t)stream, part, dw, S, CC4, Cin / 4);
   else
-    hipLaunchKernelGGL(wino_wgrad_finish_kernel<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, part, dw, S, CC4, Cin / 4);
+    hipLaunchKernelGGL(wino_wgrad_finish_kernel<false>, dim3((unsigned)grid, 3), dim3(256), 0, (hipStream_t)stream, part, dw, S, CC4, Cin / 4);
   MRN_LAUNCH_CHECK("wino_wgrad_finish");
   return MRN_OK;
 }

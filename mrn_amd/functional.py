@@ -456,7 +456,7 @@ class ConvBlockFn(torch.autograd.Function):
         if sd is None and precision == "fp16x3s":
             sd = ops.pow2_scale(dy, ops.TRAIN_OPERAND_PEAK)                                   # shared by the data and weight gradients
 
-        def weight_gradient(acc=None):                  # -> [O,kh,kw,I], or None when it was ADDED into acc ([O,I,kh,kw], 16-byte aligned)
+        def weight_gradient(acc=None):                  # -> [O,kh,kw,I], or None when it was ADDED into acc ([O,I,kh,kw])
             kh, kw = w.shape[1], w.shape[2]
             if precision == "fp16x3s" and x.shape[-1] % 4 == 0 and ops.TRAIN_WGRAD_X3:
                 if ops.wgrad_wino_supported(dy, x, (kh, kw), stride, padding):
@@ -473,7 +473,7 @@ class ConvBlockFn(torch.autograd.Function):
                 # off the critical path: second stream, accumulated straight into the parameter's gradient (ops.side_stream_begin)
                 side = ops.side_stream_begin()
                 with torch.cuda.stream(side):
-                    g = weight_gradient(wgrad if wgrad.data_ptr() % 16 == 0 else None)
+                    g = weight_gradient(wgrad)
                     if g is not None:
                         ops.unpack_conv_weight(g, out=wgrad, accumulate=True)
                 ops.side_stream_keep((dy, x, sd, ctx.x_scale))

@@ -522,7 +522,7 @@ def conv2d_wgrad_x3_wino(dy, x, dy_scale=None, x_scale=None, acc_oihw=None):
     if timed:
         CONV_TIMER.end(t0, 2.0 * 9 * Cout * Cin * B * H * W, "fp16x3/x3g%dx%d" % (tile_m, tile_n), 4.0 * (6 * Pq * (Cin + Cout) + G * Cout * Cin))
     if acc_oihw is not None:
-        assert acc_oihw.is_contiguous() and tuple(acc_oihw.shape) == (Cout, Cin, 3, 3) and acc_oihw.data_ptr() % 16 == 0
+        assert acc_oihw.is_contiguous() and tuple(acc_oihw.shape) == (Cout, Cin, 3, 3)
         call("mrn_wino_wgrad_finish_f32", _p(part), _p(acc_oihw), S, Cout, Cin, 1, _stream())
         return None
     dw = torch.empty(Cout, 3, 3, Cin, device=dev, dtype=torch.float32)
