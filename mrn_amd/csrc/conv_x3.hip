@@ -627,6 +627,8 @@ template __global__ void conv_x3_kernel<4, 2, 2, 2>(const ConvX3Params);
 template __global__ void conv_x3_kernel<4, 2, 1, 2>(const ConvX3Params);
 template __global__ void conv_x3_kernel<8, 1, 1, 2>(const ConvX3Params);
 template __global__ void conv_x3_kernel<4, 4, 2, 2>(const ConvX3Params);
+template __global__ void conv_x3_kernel<2, 2, 1, 1>(const ConvX3Params);     // 64 x 64: weight-gradient GEMMs of the first layers (Cout, Cin <= 64)
+template __global__ void conv_x3_kernel<4, 1, 1, 2>(const ConvX3Params);     // 128 x 64: ... of the Cout = 128, Cin <= 64 layers
 template __global__ void conv_x3_kernel<4, 2, 2, 2, true>(const ConvX3Params);
 template __global__ void conv_x3_kernel<4, 2, 1, 2, true>(const ConvX3Params);
 template __global__ void conv_x3_kernel<8, 1, 1, 2, true>(const ConvX3Params);
@@ -1271,8 +1273,9 @@ MRN_EXPORT int mrn_gemm_x3_windows_hl32(const void* a_hl, int64_t a_bytes, int a
   MRN_CHECK_ARG(products == 3 || products == 1, "mrn_gemm_x3_windows_hl32: products must be 3 (split-fp16 x3) or 1 (hi x hi), got %d", products);
   MRN_CHECK_ARG(a_bytes < (1L << 31) && w_bytes < (1L << 31) && (uintptr_t)a_hl % 128 == 0 && (uintptr_t)w_hl % 128 == 0,
                 "mrn_gemm_x3_windows_hl32: operand matrices must be 128-byte aligned and below 2 GiB");
-  MRN_CHECK_ARG((tile_m == 256 && (tile_n == 256 || tile_n == 128 || tile_n == 64)) || (tile_m == 128 && tile_n == 128),
-                "mrn_gemm_x3_windows_hl32: tile must be 256x256, 256x128, 256x64 or 128x128");
+  MRN_CHECK_ARG((tile_m == 256 && (tile_n == 256 || tile_n == 128 || tile_n == 64)) || (tile_m == 128 && tile_n == 128) ||
+                    ((tile_m == 64 || tile_m == 128) && tile_n == 64 && products == 3),
+                "mrn_gemm_x3_windows_hl32: tile must be 256x256, 256x128, 256x64, 128x128 or (x3 products) 128x64 / 64x64");
   ConvX3Params p;
   memset(&p, 0, sizeof(p));
   p.x = (const unsigned char*)a_hl; p.w = (const unsigned char*)w_hl; p.zero = (const unsigned char*)zero_page;
@@ -1295,6 +1298,8 @@ MRN_EXPORT int mrn_gemm_x3_windows_hl32(const void* a_hl, int64_t a_bytes, int a
     if (tile_m == 256) return launch_x3<4, 2, 2, 2, false, 1>(p, st);
     return launch_x3<4, 2, 1, 2, false, 1>(p, st);
   }
+  if (tile_m == 64) return launch_x3<2, 2, 1, 1>(p, st);
+  if (tile_m == 128 && tile_n == 64) return launch_x3<4, 1, 1, 2>(p, st);
   if (tile_n == 256) return launch_x3<4, 4, 2, 2>(p, st);
   if (tile_m == 256 && tile_n == 64) return launch_x3<8, 1, 1, 2>(p, st);
   if (tile_m == 256) return launch_x3<4, 2, 2, 2>(p, st);

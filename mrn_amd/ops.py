@@ -435,7 +435,9 @@ def conv2d_wgrad_x3_windows(dy, x, dy_scale=None, x_scale=None):
     w_hl = torch.empty(3 * per, device=dev, dtype=torch.uint8)
     call("mrn_transpose_oy3_hl32_f32", _p(x), _p(w_hl), B, H, W, Cin, _p(sx), _stream())       # shifts -1, 0, +1 from one read
     tiles = ((Cout + 255) // 256) * ((Cin + 255) // 256) * 9
-    S = max(1, min(512 // tiles if tiles < 512 else 1, max((lines - bwl) // 8, 1)))
+    small = Cout <= 128 and Cin <= 64 and TRAIN_PRODUCTS == 3 and WGRAD_SMALL_TILE
+    # (64 x 64 tiles: 32 KiB of LDS, several workgroups per CU -- four times the split-K chunks fill them)
+    S = max(1, min((2048 if small else 512) // tiles if tiles < 512 else 1, max((lines - bwl) // 8, 1)))
     key = (lines, bwl, Cin, S, dev)
     tab = _WINDOW_TABLES.get(key)
     if tab is None:
@@ -454,6 +456,8 @@ def conv2d_wgrad_x3_windows(dy, x, dy_scale=None, x_scale=None):
     G = S * 9
     part = torch.empty(S, 9, Cout, Cin, device=dev, dtype=torch.float32)
     tile_m, tile_n = x3_tile(Cin, 32 * ((lines + S - 1) // S), M=Cout, G=G)
+    if small:
+        tile_m, tile_n = (64 if Cout <= 64 else 128), 64      # the first layers: a 256-row tile would stage (and multiply) mostly padding
     timed = CONV_TIMER is not None
     t0 = CONV_TIMER.begin() if timed else None
     call("mrn_gemm_x3_windows_hl32", _p(a_hl), Cout * lines * 128, lines, _p(w_hl), 3 * per, lines, _p(tab), G, Cout, Cin,
@@ -705,6 +709,7 @@ def conv2d_x3_wino(v_hl, G, shared_input, B, H, W, Cin, u_hl, u_scale, Cout, R, 
 # needs it.  prepack_trained() (called by the learners right after the optimiser step) runs all of them on the side stream for the
 # layers registered by ConvBlockFn, one event per layer; the consumers below find the operands by (source tensor, version) and wait
 # on the event.  A miss (first step, a layer that changed since) just packs in place, as before.
+WGRAD_SMALL_TILE = os.environ.get("MRN_WGRAD_SMALL_TILE", "1") == "1"      # A/B: 64 x 64 tiles for the weight gradients of Cout, Cin <= 64 layers
 TRAIN_PREPACK = os.environ.get("MRN_TRAIN_PREPACK", "1") == "1"
 # trained SVTR blocks (loop A): the pass that produces a Linear layer's input also writes its split operand / leaves its range scale
 # (LayerNorm -> qkv / fc1, attention -> proj, GELU -> fc2; GELU' and the DropPath residual for the gradients); MRN_TRAIN_OPERAND_FUSION=0: A/B

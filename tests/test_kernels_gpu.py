@@ -855,7 +855,7 @@ def test_softargmax1d_matches_torch():
     assert_close("softargmax1d grad", mine_in.grad, ref_in.grad, atol=1e-6, rtol=1e-4)
 
 
-@pytest.mark.parametrize("B,H,W,Cin,Cout", [(32, 4, 65, 64, 128), (64, 2, 16, 32, 64), (32, 8, 64, 128, 96)])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(32, 4, 65, 64, 128), (64, 2, 16, 32, 64), (32, 8, 64, 128, 96), (16, 8, 32, 64, 48), (8, 16, 128, 32, 100)])
 def test_wgrad_without_im2col_matches_exact_fp32(B, H, W, Cin, Cout):
     """mrn_transpose_oy_hl32_f32 + mrn_gemm_x3_windows_hl32 (3x3 / s1 / p1 weight gradient over K-windows of dy^T and three
     x-shifted copies of x^T) against torch's conv weight gradient and against the im2col-based x3 path; gradient-sized dy"""
