@@ -307,7 +307,7 @@ def describe_kernel(kind):
                 BF16_MFMA_PEAK_TFLOPS, 3.0 * (R + 2) / (3 * R))
     if staging.startswith("x3g"):
         tile = staging[3:]
-        targs = {"256x256": "4, 4, 2, 2", "256x128": "4, 2, 2, 2", "128x128": "4, 2, 1, 2", "256x64": "8, 1, 1, 2"}[tile]
+        targs = {"256x256": "4, 4, 2, 2", "256x128": "4, 2, 2, 2", "128x128": "4, 2, 1, 2", "256x64": "8, 1, 1, 2", "128x64": "4, 1, 1, 2", "64x64": "2, 2, 1, 1"}[tile]
         nprod = 3 if arith == "fp16x3" else 1
         return (f"conv_x3_kernel<{targs}{', false, 1' if nprod == 1 else ''}> (grouped {tile}x32 implicit-GEMM conv / Linear over "
                 f"all experts, {arith} on v_mfma_f32_32x32x16_f16, HL32 operands staged by buffer_load...lds)",
@@ -692,7 +692,7 @@ def main():
     ops.CONV_TIMER = None
     # Isolated pass (outside the timed region): the same workload with ONE lock-step group on ONE stream and no
     # look-ahead, so every launch of the dominant kernel has the GPU to itself -- its own rate, next to the in-situ
-    # rate of the timed region where two half-groups and the router phase share the chip.
+    # rate of the timed region where the experts' stream(s) and the router phase share the chip.
     isolated = None
     if timer is not None and not args.no_isolated_pass:     # (every rank: routing_step holds the gradient all-reduce)
         net = learner.model.module
@@ -751,9 +751,12 @@ def main():
             res["roofline"] = rl[0]
             if probe is not None:
                 res["roofline"]["power_probe"] = probe
-            res["roofline"]["measured"] = ("timed region: HIP events per launch on the launch streams; the lock-step sub-groups (three of two experts) "
-                                           "and the router phase of the previous batch share the GPU, so the rate is taken over "
-                                           "the union of this kernel's launch intervals")
+            net = learner.model.module
+            groups = net._half_groups(True) if hasattr(net, "_half_groups") else None
+            res["roofline"]["measured"] = ("timed region: HIP events per launch on the launch streams; %s and the router phase of the previous "
+                                           "batch share the GPU, so the rate is taken over the union of this kernel's launch intervals"
+                                           % ("one lock-step group of all experts (one side stream)" if groups is not None and len(groups) == 1 else
+                                              "%d lock-step sub-groups of the experts (one stream each)" % (len(groups) if groups else 1)))
             if isolated:
                 k = max((k for k in isolated if not k.startswith("hbm/")), key=lambda k: isolated[k]["total_ms"])
                 i_ = isolated[k]

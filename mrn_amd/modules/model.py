@@ -386,7 +386,11 @@ class MRNNet(nn.Module):
         I = len(self.model)
         k = self.expert_halves
         if k < 0:
-            k = 3 if I >= 6 else 2
+            # default: ONE lock-step group of all experts on one side stream.  Sub-groups on separate streams (MRN_EXPERT_HALVES=2 / 3) were
+            # the default while the convolution kernels left CU resources to share; the row-block Winograd kernel owns its CU (144 KiB of
+            # LDS, 453 registers), so sub-groups only add tile-quantisation tails: same box 90.7 -> 89.7 ms for six TRBA experts, and every
+            # launch has the GPU to itself (in-situ rate of the dominant kernel 0.25 -> 0.325 of peak)
+            k = I
         if k < 2 or I < 2:
             return None
         if I < 2 * k:

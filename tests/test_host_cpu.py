@@ -294,7 +294,10 @@ def test_lockstep_grouping_policy():
     assert ops.x3_tile(128, 576) == (128, 128) and ops.x3_tile(128, 2304) == (256, 128)
     # one expert's 4x65 layer (loop A): 520 tiles of 256x256 = 2.03 rounds on 256 CUs -> smaller tiles; six experts: 12.2 rounds
     assert ops.x3_tile(512, 4608, M=66560, G=1) == (128, 128) and ops.x3_tile(512, 4608, M=66560, G=6) == (256, 256)
-    # five experts -> two half-groups (2 + 3) on two streams, never for fewer than four
+    # default: ONE lock-step group of all experts on one side stream; MRN_EXPERT_HALVES / expert_halves = 2: five experts -> two
+    # sub-groups (2 + 3) on two streams, never for fewer than four
+    assert [(lo, hi) for lo, hi, _, _ in net._half_groups(True)] == [(0, 5)]
+    net.expert_halves = 2
     parts = net._half_groups(True)
     assert [(lo, hi) for lo, hi, _, _ in parts] == [(0, 2), (2, 5)]
     net.expert_halves = 0

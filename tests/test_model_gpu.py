@@ -285,7 +285,7 @@ def test_full_size_trba6_loop_b_properties():
         net = build()
         with torch.no_grad():
             handle = net.experts_prefetch(image, text[:, :-1], True)
-            assert handle is not None and len(handle["parts"]) == 3          # six experts: three lock-step sub-groups
+            assert handle is not None and len(handle["parts"]) == 1          # six experts: ONE lock-step group on one side stream (the default)
             fast = net(image, True, text[:, :-1], True, experts=handle)
         torch.cuda.synchronize()
         bn_fast = {k: v.clone() for k, v in net.state_dict().items() if "running_" in k}
@@ -401,7 +401,7 @@ def _trba6_b32_case(net, sd, crops, classes, B, I):
     handle = None
     with torch.no_grad():
         handle = net.experts_prefetch(image.cuda(), text[:, :-1].cuda(), True)
-    assert handle is not None and len(handle["parts"]) == 3
+    assert handle is not None and len(handle["parts"]) == 1
     out = net(image.cuda(), True, text[:, :-1].cuda(), True, experts=handle)
     loss = 15 * Fn.cross_entropy(out["logits"], text[:, 1:].cuda(), 1) + Fn.cross_entropy(out["index"], domain.cuda(), -100)
     loss.backward()
