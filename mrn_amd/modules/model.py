@@ -355,8 +355,8 @@ class MRNNet(nn.Module):
         self._group = None
         self._heads = None
         self._halves = None
-        # concurrent lock-step sub-groups: -1 = by expert count (three groups of >= 2 from six experts on -- +1.1 % over two groups
-        # on TRBA x 6 -- two from four on, else one), 0 = off, k >= 2 = exactly k
+        # concurrent lock-step sub-groups: -1 = by backbone family (convolutional experts: ONE group; SVTR: three groups of >= 2 from six
+        # experts on, two from four on), 0 = off (one group on the caller's stream), k >= 2 = exactly k
         self.expert_halves = int(os.environ.get("MRN_EXPERT_HALVES", "-1"))
         #   (measured on TRBA x 6, MI355X: 1 group 1.00, 2 halves on two streams 1.044, 3 thirds 1.015, staggered halves 1.035,
         #    halves with one high-priority stream 0.96; with the final conv kernel and the loop-B pipeline: one group on a
@@ -389,8 +389,10 @@ class MRNNet(nn.Module):
             # default: ONE lock-step group of all experts on one side stream.  Sub-groups on separate streams (MRN_EXPERT_HALVES=2 / 3) were
             # the default while the convolution kernels left CU resources to share; the row-block Winograd kernel owns its CU (144 KiB of
             # LDS, 453 registers), so sub-groups only add tile-quantisation tails: same box 90.7 -> 89.7 ms for six TRBA experts, and every
-            # launch has the GPU to itself (in-situ rate of the dominant kernel 0.25 -> 0.325 of peak)
-            k = I
+            # launch has the GPU to itself (in-situ rate of the dominant kernel 0.25 -> 0.325 of peak).  SVTR's kernels share a CU, and its
+            # experts keep their sub-groups (same box, six experts: one group 23.5-23.6 ms, three 22.4-22.6)
+            svtr = I > 0 and self.model[0].model.stages.get("Feat") == "SVTR"
+            k = (3 if I >= 6 else 2) if svtr else I
         if k < 2 or I < 2:
             return None
         if I < 2 * k:

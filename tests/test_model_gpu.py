@@ -341,7 +341,7 @@ def test_full_size_trba6_loop_b_properties():
 
 def test_trba6_batch32_full_class_counts_vs_oracle():
     """The headline configuration against the CPU ORACLE (not against another HIP schedule): TRBA x 6 experts with the bench's
-    class counts 2091 ... 5374, 32 crops, the production schedule (three lock-step sub-groups on three streams, Winograd F(4,3) +
+    class counts 2091 ... 5374, 32 crops, the production schedule (one lock-step group of the six experts on a side stream, Winograd F(4,3) +
     split-fp16 x3 convolutions).  Smooth crops: routing weights and fused logits within 1e-4 of the fp32 oracle -- or, where the
     fp32 oracle itself is further than that from float64 arithmetic (the TPS grid's conditioning), within 3x that band -- routing
     argmax and eval routing / greedy indices bit-exact, the gradients of all router tensors of one loop-B step within 2e-3.
