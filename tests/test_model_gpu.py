@@ -558,6 +558,43 @@ def test_loop_a_svtr_gradients_vs_oracle():
             assert_close(k, net.state_dict()[k], sd[k], atol=1e-5)
 
 
+def test_svtr_operand_fusion_matches_separate_passes():
+    """loop A on an SVTR expert with the trained Linear layers' operands written by the producing pass (LayerNorm with its parameter bound,
+    attention / GELU under the upstream GEMM's epilogue maximum, gradients' ranges folded into GELU', the DropPath residual and the attention
+    backward kernels) against the separate max / split passes (ops.TRAIN_OPERAND_FUSION off): only the power-of-two range scales differ
+    (a bound instead of the exact maximum), so logits, loss and every gradient agree to fp32 round-off -- measured 1e-6 of the logits'
+    range, 3e-5 of a gradient tensor's (both paths are deterministic run to run)"""
+    from mrn_amd import functional as Fn
+    from mrn_amd import ops
+    kind, classes, B, seed = "svtr", (40,), 8, 9
+    g = load_golden("svtr_mrn3")
+    image, words, chars, _ = det_inputs(kind, classes, B, seed)
+    conv, labels_index, labels_length = labels_for(kind, words, chars)
+    outs = []
+    saved = ops.TRAIN_OPERAND_FUSION
+    try:
+        for fused in (True, False):
+            ops.TRAIN_OPERAND_FUSION = fused
+            opt, net = build_net(kind, (40, 70, 97), g, 3)
+            net.train()
+            for n, p in net.named_parameters():
+                p.requires_grad = n.startswith("model.0.")
+            set_drop_masks(net, kind, B, seed, "fusion", [0])
+            preds = net.model[0](image.cuda(), None, True)["predict"]
+            loss = Fn.ctc_loss(preds, labels_index.cuda(), labels_length.cuda())
+            loss.backward()
+            outs.append((preds.detach().clone(), float(loss), {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}))
+    finally:
+        ops.TRAIN_OPERAND_FUSION = saved
+    (p1, l1, g1), (p0, l0, g0) = outs
+    assert_close("logits", p1, p0, atol=5e-6 * float(p0.abs().max()), rtol=0)
+    assert abs(l1 - l0) <= 5e-6 * max(1.0, abs(l0))
+    assert set(g1) == set(g0) and len(g0) > 130
+    for n in g0:
+        scale = float(g0[n].abs().max())
+        assert float((g1[n] - g0[n]).abs().max()) <= 2e-4 * scale + 1e-12, (n, float((g1[n] - g0[n]).abs().max()), scale)
+
+
 def _oracle_trba_grads(g, image, labels_index, dtype):
     """loss and parameter gradients of a TRBA expert's loop A on the CPU oracle in the given precision"""
     from oracle import mrn_oracle as O
