@@ -1275,6 +1275,8 @@ def stash_operand(t, hl, scale, grad=False):
             _GRAD_OPERANDS.clear()
         _GRAD_OPERANDS[id(t)] = (t, hl, scale)
         return
+    if _GRAD_OPERANDS:
+        _GRAD_OPERANDS.clear()          # a forward pass is running: whatever the last backward pass left (one without a side-stream join) is dead
     if len(_OPERANDS) > 256:
         for k in [k for k, v in _OPERANDS.items() if v[0]() is None]:
             del _OPERANDS[k]
