@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256) void tps_sample_bwd_kernel(const float* __rest
 // samples per workgroup of the decoder backward: the smallest of {4, 8, 16} that keeps the grid within 128 workgroups
 static int attn_bwd_vb(int B) {
   static const int forced = getenv("MRN_ATTN_BWD_VB") ? atoi(getenv("MRN_ATTN_BWD_VB")) : 0;     // (A/B switch, read once)
-  if (forced == 4 || forced == 8 || forced == 16) return forced;
+  if (forced == 1 || forced == 2 || forced == 4 || forced == 8 || forced == 16) return forced;
   return ceil_div(B, 4) <= 128 ? 4 : ceil_div(B, 8) <= 128 ? 8 : 16;
 }
 

@@ -692,7 +692,7 @@ static int attn_launch(AttnDecGroup& grp, int groups, int D, int T, hipStream_t 
   const int B = grp.g[0].B;
   grp.vb = (groups * ceil_div(B, 4) <= 128 && B > 4) ? 4 : (groups * ceil_div(B, BT) <= 128 && B > 8) ? 8 : BT;
   static const int forced_vb = getenv("MRN_ATTN_VB") ? atoi(getenv("MRN_ATTN_VB")) : 0;     // (A/B switch, read once)
-  if (forced_vb == 4 || forced_vb == 8 || forced_vb == 16) grp.vb = forced_vb;
+  if (forced_vb == 1 || forced_vb == 2 || forced_vb == 4 || forced_vb == 8 || forced_vb == 16) grp.vb = forced_vb;
   grp.tiles = ceil_div(B, grp.vb);
   grp.pinned = groups > 1 && grp.tiles * ceil_div(groups, 8) <= 32;
   const bool x3 = grp.g[0].w_inv != nullptr;
