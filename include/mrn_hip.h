@@ -178,7 +178,11 @@ int mrn_conv3x3_c4_grouped_f32(const float* x, const float* w_ohwi, const float*
  * mrn_maxpool_grouped_f32: the same with MaxPool2d (padding = -inf) applied after the affine + ReLU.
  * modules/feature_extraction.py:171-199,222-294; modules/transformation.py:69-81. */
 int mrn_bn_finalize_grouped_f32(const float* partials, int G, int nblk, int C, int64_t count, const void* const* ptrs,
-                                float momentum, float eps, float* scale, float* shift, void* stream);
+                                float momentum, float eps, float* scale, float* shift, void* chunk_ws, void* tickets, void* stream);
+/* the partial rows are reduced in mrn_bn_finalize_grouped_chunks(nblk) chunks by as many workgroups per (expert, 32 channels); with more
+ * than one chunk: chunk_ws = G * ceil(C / 32) * chunks * 64 doubles of scratch, tickets = G * ceil(C / 32) 32-bit words zeroed ONCE by the
+ * caller (the last workgroup to arrive adds the chunk sums in chunk order -- deterministic -- and puts its ticket back to zero) */
+int64_t mrn_bn_finalize_grouped_chunks(int nblk);
 /* eval-mode BatchNorm2d (modules/feature_extraction.py:171-197 under model.eval()) of G modules folded to per-channel affines
  * scale / shift [G][C] from the modules' CURRENT running statistics, through the same [4][G] pointer table */
 int mrn_bn_eval_affine_grouped_f32(const void* const* ptrs, int G, int C, float eps, float* scale, float* shift, void* stream);

@@ -43,26 +43,62 @@ __device__ __forceinline__ void store_hl(unsigned char* out, long row, int C, in
   *reinterpret_cast<f16v8*>(o + 64) = l;
 }
 
-// one wave per (group, channel): same arithmetic as bn_finalize_kernel (spatial.hip), parameters through pointer tables
-__global__ __launch_bounds__(256) void bn_finalize_grouped_kernel(const float* __restrict__ part, int nblk, int C, long count,
-                                                                  const float* const* __restrict__ ptrs, int G, float momentum,
-                                                                  float eps, float* __restrict__ scale, float* __restrict__ shift) {
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int g = blockIdx.y;
-  const int lane = threadIdx.x & 63;
-  if (c >= C) return;
+// a block = 32 channels x 32 row lanes of one group over ONE CHUNK of the partial rows (coalesced 128-byte reads, sums in double as
+// bn_finalize_kernel, spatial.hip: same arithmetic), parameters through pointer tables.  gridDim.z chunks: the first layers come with up
+// to 16384 partial rows per expert (128-pixel blocks of the 32 x 256 maps) for 32 / 64 channels -- one wave per channel walked them in
+// 256 dependent steps (300 us per launch, five such launches per loop-B step).  Chunk sums go to `ws` [G][cblocks][Z][2][32] doubles; the
+// last block to arrive (ticket per (group, channel block), self-resetting) adds them IN CHUNK ORDER -- deterministic -- and finalises.
+__global__ __launch_bounds__(1024) void bn_finalize_grouped_kernel(const float* __restrict__ part, int nblk, int C, long count,
+                                                                   const float* const* __restrict__ ptrs, int G, float momentum,
+                                                                   float eps, float* __restrict__ scale, float* __restrict__ shift,
+                                                                   double* __restrict__ ws, unsigned* __restrict__ tickets) {
+  __shared__ double red[2][32][33];
+  __shared__ unsigned last;
+  const int cl = threadIdx.x & 31, lane = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  const int g = blockIdx.y, Z = gridDim.z, z = blockIdx.z;
+  const int chunk = (nblk + Z - 1) / Z, b0 = z * chunk, b1 = min(nblk, b0 + chunk);
   const float* pg = part + (long)g * nblk * 2 * C;
   double s = 0.0, q = 0.0;
-  for (int b = lane; b < nblk; b += 64) {
-    s += (double)pg[((long)b * 2 + 0) * C + c];
-    q += (double)pg[((long)b * 2 + 1) * C + c];
-  }
+  if (c < C)
+    for (int b = b0 + lane; b < b1; b += 32) {
+      s += (double)pg[((long)b * 2 + 0) * C + c];
+      q += (double)pg[((long)b * 2 + 1) * C + c];
+    }
+  red[0][lane][cl] = s;
+  red[1][lane][cl] = q;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    s = q = 0.0;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    s += __shfl_xor(s, o);
-    q += __shfl_xor(q, o);
+    for (int l = 0; l < 32; ++l) {
+      s += red[0][l][cl];
+      q += red[1][l][cl];
+    }
   }
-  if (lane == 0) {
+  if (Z > 1) {
+    const long slot = (long)g * gridDim.x + blockIdx.x;
+    double* w = ws + slot * Z * 64;
+    if (threadIdx.x < 32) {
+      w[z * 64 + cl] = s;
+      w[z * 64 + 32 + cl] = q;
+      __threadfence();
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(tickets + slot, 1u) == (unsigned)(Z - 1);
+    __syncthreads();
+    if (!last) return;
+    if (threadIdx.x == 0) tickets[slot] = 0u;
+    __threadfence();
+    if (threadIdx.x < 32) {
+      s = q = 0.0;
+      for (int k = 0; k < Z; ++k) {
+        s += __builtin_nontemporal_load(w + k * 64 + cl);
+        q += __builtin_nontemporal_load(w + k * 64 + 32 + cl);
+      }
+    }
+  }
+  if (threadIdx.x < 32 && c < C) {
     const float* gamma = ptrs[0 * G + g];
     const float* beta = ptrs[1 * G + g];
     float* run_mean = const_cast<float*>(ptrs[2 * G + g]);
@@ -501,12 +537,22 @@ __global__ __launch_bounds__(256) void add_layernorm_grouped_kernel(const float*
 // Train-mode BatchNorm2d statistics for G BatchNorm modules of C channels at once.  partials: [G][nblk][2][C] from the
 // grouped conv epilogue; ptrs: device table [4][G] of device pointers {gamma, beta, running_mean, running_var} (entries
 // may be NULL); scale / shift: [G][C].  Same arithmetic as mrn_bn_finalize_f32.
+// row chunks of mrn_bn_finalize_grouped_f32 (1: no workspace needed); workspace = G * ceil(C / 32) * chunks * 64 doubles + G * ceil(C / 32)
+// 32-bit tickets that the caller zeroed ONCE (the kernel puts them back to zero)
+MRN_EXPORT int64_t mrn_bn_finalize_grouped_chunks(int nblk) {
+  int64_t z = (nblk + 511) / 512;
+  return z < 1 ? 1 : (z > 32 ? 32 : z);
+}
+
 MRN_EXPORT int mrn_bn_finalize_grouped_f32(const float* partials, int G, int nblk, int C, int64_t count,
                                            const void* const* ptrs, float momentum, float eps, float* scale, float* shift,
-                                           void* stream) {
+                                           void* chunk_ws, void* tickets, void* stream) {
   MRN_CHECK_ARG(partials && ptrs && scale && shift && G >= 1 && C >= 1 && count >= 1, "mrn_bn_finalize_grouped_f32: bad operands");
-  hipLaunchKernelGGL(bn_finalize_grouped_kernel, dim3((C + 3) / 4, G), dim3(256), 0, (hipStream_t)stream, partials, nblk, C,
-                     (long)count, (const float* const*)ptrs, G, momentum, eps, scale, shift);
+  const int Z = (int)mrn_bn_finalize_grouped_chunks(nblk);
+  MRN_CHECK_ARG(Z == 1 || (chunk_ws && tickets && (uintptr_t)chunk_ws % 8 == 0),
+                "mrn_bn_finalize_grouped_f32: %d partial rows need the chunk workspace and the zeroed tickets", nblk);
+  hipLaunchKernelGGL(bn_finalize_grouped_kernel, dim3((C + 31) / 32, G, Z), dim3(1024), 0, (hipStream_t)stream, partials, nblk, C,
+                     (long)count, (const float* const*)ptrs, G, momentum, eps, scale, shift, (double*)chunk_ws, (unsigned*)tickets);
   MRN_LAUNCH_CHECK("bn_finalize_grouped");
   return MRN_OK;
 }

@@ -43,26 +43,32 @@ __global__ void pack_oihw_ohwi_kernel(const float* __restrict__ w, float* __rest
 // Reduce the conv epilogue's per-row-block partials to batch mean / biased variance, fold them with the
 // affine parameters into (scale, shift), and update the running statistics exactly like
 // torch.nn.BatchNorm2d in training mode (momentum form, unbiased running variance).
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nblk, int C, long count,
-                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          float* __restrict__ run_mean, float* __restrict__ run_var,
-                                                          float momentum, float eps, float* __restrict__ scale,
-                                                          float* __restrict__ shift, float* __restrict__ save_mean,
-                                                          float* __restrict__ save_invstd) {
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (c >= C) return;
+// (a block = 32 channels x 32 row lanes: coalesced 128-byte reads of the partial rows, the sums in double)
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int nblk, int C, long count,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                           float momentum, float eps, float* __restrict__ scale,
+                                                           float* __restrict__ shift, float* __restrict__ save_mean,
+                                                           float* __restrict__ save_invstd) {
+  __shared__ double red[2][32][33];
+  const int cl = threadIdx.x & 31, lane = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   double s = 0.0, q = 0.0;
-  for (int b = lane; b < nblk; b += 64) {
-    s += (double)part[((long)b * 2 + 0) * C + c];
-    q += (double)part[((long)b * 2 + 1) * C + c];
-  }
+  if (c < C)
+    for (int b = lane; b < nblk; b += 32) {
+      s += (double)part[((long)b * 2 + 0) * C + c];
+      q += (double)part[((long)b * 2 + 1) * C + c];
+    }
+  red[0][lane][cl] = s;
+  red[1][lane][cl] = q;
+  __syncthreads();
+  if (threadIdx.x < 32 && c < C) {
+    s = q = 0.0;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    s += __shfl_xor(s, o);
-    q += __shfl_xor(q, o);
-  }
-  if (lane == 0) {
+    for (int l = 0; l < 32; ++l) {
+      s += red[0][l][cl];
+      q += red[1][l][cl];
+    }
     const double mean = s / (double)count;
     double var = q / (double)count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -226,7 +232,7 @@ MRN_EXPORT int mrn_bn_finalize_f32(const float* partials, int nblk, int C, int64
                                    float eps, float* scale, float* shift, float* save_mean, float* save_invstd,
                                    void* stream) {
   MRN_CHECK_ARG(partials && scale && shift && C > 0 && count > 0, "mrn_bn_finalize_f32: bad args");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, (hipStream_t)stream, partials, nblk, C,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 32)), dim3(1024), 0, (hipStream_t)stream, partials, nblk, C,
                      (long)count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, save_mean,
                      save_invstd);
   MRN_LAUNCH_CHECK("bn_finalize");

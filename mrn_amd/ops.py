@@ -869,13 +869,33 @@ def conv3x3_c4_grouped(x, weights, bias=None, act=ACT_NONE, want_stats=False, ou
     return y, stats
 
 
+_FINALIZE_TICKETS = {}
+
+
+def _finalize_tickets(device, slots):
+    """zeroed 32-bit tickets per (device, stream) for the chunked BatchNorm finalize (the kernel's last workgroup resets its ticket)"""
+    st = torch.cuda.current_stream()
+    key = (st.device_index, st.cuda_stream)
+    t = _FINALIZE_TICKETS.get(key)
+    if t is None or t.numel() < slots:
+        t = torch.zeros(max(slots, 1024), device=device, dtype=torch.int32)
+        _FINALIZE_TICKETS[key] = t
+    return t
+
+
 def bn_finalize_grouped(stats, G, C, count, ptr_table, momentum, eps):
     """stats [G][nblk][2][C]; ptr_table: int64 device tensor [4,G] of {gamma, beta, running_mean, running_var} addresses"""
     scale = torch.empty(G, C, device=stats.device, dtype=torch.float32)
     shift = torch.empty(G, C, device=stats.device, dtype=torch.float32)
     nblk = stats.numel() // (2 * C * G)
+    Z = call("mrn_bn_finalize_grouped_chunks", nblk)
+    ws = tk = None
+    if Z > 1:       # (the first layers: thousands of partial rows per expert -- reduced in Z chunks, combined by the last workgroup to arrive)
+        slots = G * ((C + 31) // 32)
+        ws = torch.empty(slots * Z * 64, device=stats.device, dtype=torch.float64)
+        tk = _finalize_tickets(stats.device, slots)
     call("mrn_bn_finalize_grouped_f32", _p(stats), G, nblk, C, count, _p(ptr_table), float(momentum), float(eps), _p(scale),
-         _p(shift), _stream())
+         _p(shift), _p(ws), _p(tk), _stream())
     return scale, shift
 
 

@@ -1264,3 +1264,35 @@ def test_gemm_epilogue_range_and_attention_operand(ops):
     d0 = ops.svtr_attention_bwd(qkv, None, out, dout, lse, heads, 32 ** -0.5)
     d1, sc = ops.svtr_attention_bwd(qkv, None, out, dout, lse, heads, 32 ** -0.5, want_range=ops.FP16_WEIGHT_PEAK)
     assert torch.equal(d0, d1) and torch.equal(sc, ops.pow2_scale(d0))
+
+
+@pytest.mark.parametrize("G,nblk,C", [(3, 7, 64), (2, 5000, 32), (6, 16384, 64), (2, 1100, 96)])
+def test_bn_finalize_grouped_chunked(ops, G, nblk, C):
+    """mrn_bn_finalize_grouped_f32 over few and over thousands of partial rows (the first layers: 128-pixel blocks of 32 x 256 maps; reduced
+    in chunks by several workgroups, the last to arrive combines them in chunk order): scale / shift / running statistics against the
+    float64 formula, and twice the same result bit for bit (no atomics in the sums)"""
+    torch.manual_seed(nblk)
+    count = nblk * 128
+    part = torch.rand(G, nblk, 2, C, device="cuda") * 4
+    part[:, :, 1] += 40.0                                    # sums of squares dominate: var > 0
+    gammas = [torch.rand(C, device="cuda") + 0.5 for _ in range(G)]
+    betas = [torch.randn(C, device="cuda") for _ in range(G)]
+    outs = []
+    for _ in range(2):
+        rm = [torch.zeros(C, device="cuda") for _ in range(G)]
+        rv = [torch.ones(C, device="cuda") for _ in range(G)]
+        table = torch.tensor([[t.data_ptr() for t in ts] for ts in (gammas, betas, rm, rv)], dtype=torch.int64).cuda()
+        scale, shift = ops.bn_finalize_grouped(part, G, C, count, table, 0.1, 1e-5)
+        torch.cuda.synchronize()
+        outs.append((scale.clone(), shift.clone(), torch.stack(rm), torch.stack(rv)))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    s = part[:, :, 0].double().sum(1)
+    q = part[:, :, 1].double().sum(1)
+    mean = s / count
+    var = (q / count - mean * mean).clamp_min(0)
+    sc = torch.stack(gammas).double() / torch.sqrt(var + 1e-5)
+    assert_close("scale", outs[0][0], sc.float(), atol=1e-6, rtol=2e-6)
+    assert_close("shift", outs[0][1], (torch.stack(betas).double() - mean * sc).float(), atol=2e-6, rtol=2e-6)
+    assert_close("running_mean", outs[0][2], (0.1 * mean).float(), atol=1e-6, rtol=2e-6)
+    assert_close("running_var", outs[0][3], (0.9 + 0.1 * var * count / (count - 1)).float(), atol=1e-6, rtol=2e-6)
