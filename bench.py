@@ -322,6 +322,11 @@ def describe_kernel(kind):
     raise ValueError(f"unknown KernelTimer kind {kind!r}")
 
 
+def rl_allow_hbm(kind):
+    """the dominant Winograd kernels always stay MFMA entries (their intensity is far above the ridge anyway)"""
+    return "wino" not in kind
+
+
 def roofline_entries(kinds, steps, elapsed_s, pmc_section="kernels"):
     """KernelTimer.summary() -> (MFMA-bound entries sorted by share of the step, HBM-bound entries); pmc_section: which workload's PMC
     passes of the committed profile the `traffic` figures come from (loop A launches G = 1 kernels: its own passes)"""
@@ -347,6 +352,19 @@ def roofline_entries(kinds, steps, elapsed_s, pmc_section="kernels"):
         avg_ms = s_["union_ms"] / s_["launches"]
         ach = per_launch / (avg_ms * 1e-3) / 1e12
         kname, peak, per_flop = describe_kernel(kind)
+        nbytes = s_.get("total_bytes", 0.0)
+        # a launch family whose MFMA work per algorithmic byte lies under the ridge (peak flop/s over peak B/s) is priced against HBM:
+        # the small-K / narrow x3 launches (1 x 1 shortcuts, the first-stage convolutions, heads) are output-write-bound, not MFMA-bound
+        if nbytes > 0 and s_["total_flops"] * per_flop / nbytes < peak * 1e12 / (HBM_PEAK_GBS * 1e9) and rl_allow_hbm(kind):
+            gbs = nbytes / (s_["union_ms"] * 1e-3) / 1e9
+            hbm.append({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                        "traffic": pmc_traffic(kname, pmc_section), "kernel": kname,
+                        "algorithmic_bytes_per_launch": nbytes / s_["launches"], "algorithmic_gflop_per_launch": per_launch / 1e9,
+                        "mfma_flop_per_algorithmic_byte": s_["total_flops"] * per_flop / nbytes,
+                        "mfma_issue_frac": ach * per_flop / peak,
+                        "launches_per_step": s_["launches"] / steps, "avg_launch_ms": avg_ms, "avg_launch_ms_raw_event": raw_ms,
+                        "kernel_share_of_step": s_["union_ms"] / (elapsed_s * 1e3)})
+            continue
         rl.append({"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                    "traffic": pmc_traffic(kname, pmc_section), "traffic_source": PMC_SOURCE,
                    "algorithmic_bytes_per_launch": s_.get("total_bytes", 0.0) / s_["launches"],
@@ -748,6 +766,9 @@ def main():
         if timer is not None and timer.spans:
             rl, hbm = roofline_entries(timer.summary(), args.steps, elapsed,
                                        pmc_section="kernels" if (args.model, args.experts, args.batch) == ("trba", 6, 256) else "none")
+            if not rl:                      # (every timed family under the ridge: the largest HBM-bound one leads)
+                hbm.sort(key=lambda r: -r["kernel_share_of_step"])
+                rl, hbm = hbm[:1], hbm[1:]
             res["roofline"] = rl[0]
             if probe is not None:
                 res["roofline"]["power_probe"] = probe
