@@ -1297,7 +1297,7 @@ def stash_operand(t, hl, scale, grad=False):
         return
     if _GRAD_OPERANDS:
         _GRAD_OPERANDS.clear()          # a forward pass is running: whatever the last backward pass left (one without a side-stream join) is dead
-    if len(_OPERANDS) > 256:
+    if len(_OPERANDS) > 48:         # (entries own the HL32 buffers: dead owners' entries go before they pile up -- a block leaves four per step)
         for k in [k for k, v in _OPERANDS.items() if v[0]() is None]:
             del _OPERANDS[k]
     _OPERANDS[id(t)] = (weakref.ref(t), hl, scale)
