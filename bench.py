@@ -696,7 +696,8 @@ def main():
     if reducer is not None:
         reducer.record, reducer.exposed = True, []
     if not args.no_kernel_timer:
-        ops.CONV_TIMER = ops.KernelTimer()
+        only = os.environ.get("MRN_TIMER_ONLY")
+        ops.CONV_TIMER = ops.KernelTimer(set(only.split(",")) if only else None)
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

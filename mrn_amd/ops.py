@@ -18,15 +18,20 @@ class KernelTimer:
     """Optional HIP-event bracket around the dominant kernel (the 128x128 implicit-GEMM conv) so bench.py can report
     achieved FLOP/s per launch, measured on the stream the kernel runs on."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.spans = []          # (start_event, end_event, flops)
+        self.only = only         # None: every timed call site; else a set of site tags ("wino": the row-block / Winograd convolutions)
 
-    def begin(self):
+    def begin(self, site="other"):
+        if self.only is not None and site not in self.only:
+            return None
         e = torch.cuda.Event(enable_timing=True)
         e.record()
         return e
 
     def end(self, start, flops, kind="f32", nbytes=0.0):
+        if start is None:
+            return
         e = torch.cuda.Event(enable_timing=True)
         e.record()
         self.spans.append((start, e, flops, kind, nbytes))
@@ -649,7 +654,7 @@ def bn_apply_wino_grouped(y, scale, shift, R, relu=True, residual=None, residual
     out = torch.empty_like(y) if want_f32 else None
     out_hl = torch.empty(y.numel() * 4, device=y.device, dtype=torch.uint8) if want_hl else None
     v = torch.empty(G * B * H * Wq * (R + 2) * C * 4, device=y.device, dtype=torch.uint8)
-    t0 = CONV_TIMER.begin() if CONV_TIMER is not None else None
+    t0 = CONV_TIMER.begin("bnw") if CONV_TIMER is not None else None
     call("mrn_bn_apply_wino_grouped_f32", _p(y), _p(residual), _p(residual_hl), _p(scale), _p(shift), _p(out), _p(out_hl), _p(v),
          G, B, H, W, C, R, int(bool(relu)), _p(prescale), _stream())
     if t0 is not None:       # algorithmic bytes: every input / output element once; the transformed operand is (R+2)/R elements per element
@@ -669,7 +674,7 @@ def conv2d_x3_wino(v_hl, G, shared_input, B, H, W, Cin, u_hl, u_scale, Cout, R, 
     Wq = (W + R - 1) // R
     gstride = 0 if shared_input else B * H * Wq * (R + 2) * Cin * 4
     timed = CONV_TIMER is not None
-    t0 = CONV_TIMER.begin() if timed else None
+    t0 = CONV_TIMER.begin("wino") if timed else None
     call("mrn_conv2d_x3_wino_hl32", _p(v_hl), _p(u_hl), _p(_zero_page(dev)), _p(bias), _p(y), _p(stats), _p(u_scale), _p(x_scale), G, gstride,
          B, H, W, Cin, Cout, R, act, _stream())
     if WINO_CHECK and call("mrn_conv2d_x3_wino_rows", H, R, Cout):
