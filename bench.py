@@ -745,6 +745,7 @@ def main():
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "host_issue_ms_per_step": host_elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "skipped_optimizer_steps": learner.optimizer.skipped_steps(),      # non-finite gradient norms (csrc/optim.hip): 0 or the line is suspect
             "dtype": "fp16 (one fp16 MFMA product per term, fp32 accumulate and fp32 storage: reduced-precision mode, NOT the headline)"
             if ops.X3_PRODUCTS == 1 else
             {"auto": "f32 (convs with Cout>64 as split-fp16 x3 MFMA products, 22-bit significand, fp32 accumulate)",

@@ -538,7 +538,9 @@ int mrn_weight_align_f32(float* w, int64_t ld, int64_t rows, int64_t n_old, int 
 /* ---- optimiser (il_modules/base.py:85,255-262) ------------------------------------------------------------------ */
 
 int64_t mrn_grad_norm_workspace_floats(int64_t n);
-/* norm_coef[0] = ||g||_2, norm_coef[1] = min(1, max_norm/(norm+1e-6))  (clip_grad_norm_) */
+/* norm_coef: THREE floats.  [0] = ||g||_2, [1] = min(1, max_norm/(norm+1e-6))  (clip_grad_norm_); [2] += 1 when the norm is not
+   finite -- the update kernels below skip such a step (parameters and optimiser state untouched) -- a counter the caller
+   zero-initialises once and keeps across steps */
 int mrn_grad_norm_clip_f32(const float* g, int64_t n, float max_norm, float* workspace, float* norm_coef, void* stream);
 /* g *= coef (in place), then torch.optim.Adam's update; step_size = lr/(1-beta1^t), bc2_sqrt = sqrt(1-beta2^t) */
 int mrn_adam_step_f32(float* p, float* g, float* m, float* v, int64_t n, const float* norm_coef, float step_size,

@@ -23,9 +23,12 @@ __global__ __launch_bounds__(256) void sqsum_partial_kernel(const float* __restr
   if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
 
-// out[0] = total L2 norm, out[1] = clip coefficient min(1, max_norm / (norm + 1e-6)).  A non-finite norm (an overflowed
-// gradient) makes the update kernels skip the step: torch's clip_grad_norm_ + Adam would write NaN into every parameter
-// from which no later step recovers; parameters, moments and the step count's bias correction stay as they were.
+// out[0] = total L2 norm, out[1] = clip coefficient min(1, max_norm / (norm + 1e-6)), out[2] += 1 when the norm is not finite.
+// A non-finite norm (an overflowed gradient) makes the update kernels skip the step: torch's clip_grad_norm_ + Adam would write NaN
+// into every parameter, from which no later step recovers; parameters and moments stay as they were.  The host's step count -- Adam's
+// bias correction, the learning-rate schedule -- advances all the same (the host never waits for the norm), which is why the skip is
+// COUNTED: out[2] is the caller's persistent counter (FlatOptimizer.skipped_steps(), the learners' log lines, bench.py's JSON), so a
+// persistent overflow shows up as a number instead of as training that quietly stops learning.
 __global__ __launch_bounds__(256) void norm_finalize_kernel(const float* __restrict__ part, int nblk, float max_norm,
                                                             float* __restrict__ out) {
   __shared__ float scratch[4];
@@ -37,6 +40,7 @@ __global__ __launch_bounds__(256) void norm_finalize_kernel(const float* __restr
     out[0] = norm;
     const float c = max_norm / (norm + 1e-6f);
     out[1] = c < 1.f ? c : 1.f;
+    if (!(norm <= 3.0e38f)) out[2] += 1.f;
   }
 }
 
@@ -222,7 +226,8 @@ MRN_EXPORT int64_t mrn_grad_norm_workspace_floats(int64_t n) {
   return b < 1 ? 1 : b;
 }
 
-// norm_coef[0] = ||g||_2, norm_coef[1] = clip coefficient; workspace holds mrn_grad_norm_workspace_floats(n) floats
+// norm_coef[0] = ||g||_2, norm_coef[1] = clip coefficient, norm_coef[2] += 1 when the norm is not finite (three floats; the caller
+// zero-initialises the counter and keeps the buffer across steps); workspace holds mrn_grad_norm_workspace_floats(n) floats
 MRN_EXPORT int mrn_grad_norm_clip_f32(const float* g, int64_t n, float max_norm, float* workspace, float* norm_coef,
                                       void* stream) {
   MRN_CHECK_ARG(g && workspace && norm_coef && ((uintptr_t)g % 16 == 0), "mrn_grad_norm_clip_f32: bad operands");

@@ -137,14 +137,15 @@ def linear_wgrad(dy, x, sd=None, sx=None, out=None):
     return ops.colsum(part.view(S, N * K)).view(N, K)
 
 
-def side_param_grads(params, compute, used, into=False):
+def side_param_grads(params, compute, used, into=False, gen=None):
     """params: the Parameters a backward function owes gradients (None entries allowed); compute() -> their gradients in the same
     order.  Inside `with ops.direct_gradients()` (loss.backward() into the flat gradient, N = 1) the gradients are computed on the side
     stream and ADDED into each parameter's .grad there -- off the backward chain, filling the idle CUs next to the recurrent kernels
     (ops.side_stream_begin; the backward pass's final callback joins the streams) -- and None is returned for every parameter.
     `used`: the tensors compute() reads (kept alive for the side stream).  Otherwise: just compute().
     into=True: compute(outs) is handed the parameters' gradient buffers (None outside direct mode) and may ADD a gradient there itself
-    (its last reduction pass accumulating), returning that same buffer in the gradient's place."""
+    (its last reduction pass accumulating), returning that same buffer in the gradient's place.
+    gen: the forward generation ops.note_param_uses returned for this function's forward (ctx.use_gen)."""
     ok = (ops.WGRAD_SIDE_STREAM and ops.GRAD_DIRECT and not torch.is_grad_enabled() and
           all(p is None or (p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32) for p in params))
     if not ok:
@@ -156,7 +157,7 @@ def side_param_grads(params, compute, used, into=False):
             if p is not None and g is not None and g is not o:
                 p.grad.add_(g.reshape(p.grad.shape))
     ops.side_stream_keep(used)
-    ops.direct_done(params)
+    ops.direct_done(params, gen)
     return [None] * len(params)
 
 
@@ -168,7 +169,7 @@ class LinearFn(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         ctx.params = (weight, bias)
-        ops.note_param_uses(ctx.params, any(ctx.needs_input_grad))
+        ctx.use_gen = ops.note_param_uses(ctx.params, any(ctx.needs_input_grad))
         return ops.linear(x, weight, bias)
 
     @staticmethod
@@ -179,7 +180,7 @@ class LinearFn(torch.autograd.Function):
         need_w, need_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         dw, db = side_param_grads([ctx.params[0] if need_w else None, ctx.params[1] if need_b else None],
                                   lambda o: (linear_wgrad(dy, x, out=o[0]) if need_w else None,
-                                             ops.colsum(dy, out=o[1], accumulate=True) if need_b else None), (dy, x), into=True)
+                                             ops.colsum(dy, out=o[1], accumulate=True) if need_b else None), (dy, x), into=True, gen=ctx.use_gen)
         return dx, dw, db
 
 
@@ -387,7 +388,7 @@ class ConvBlockFn(torch.autograd.Function):
         ctx.wpacked = w
         ctx.conv = conv
         ctx.bn = bn
-        ops.note_param_uses((conv.weight, conv.bias) + ((bn.weight, bn.bias) if bn is not None else ()), any(ctx.needs_input_grad))
+        ctx.use_gen = ops.note_param_uses((conv.weight, conv.bias) + ((bn.weight, bn.bias) if bn is not None else ()), any(ctx.needs_input_grad))
         if id(conv) not in ops.TRAINED_CONVS:
             ops.TRAINED_CONVS[id(conv)] = (weakref.ref(conv), stride, padding)
         # one max|x| pass serves the forward conv and the weight gradient (both split x with the same power-of-two scale)
@@ -444,7 +445,7 @@ class ConvBlockFn(torch.autograd.Function):
             else:
                 dy, dgamma, dbeta, dres = ops.bn_bwd(dz, None, y, mean, invstd, gamma, relu, want_dres=has_res, zmask=z, grad_acc=acc)
             if acc is not None:
-                ops.direct_done((bw, bb))
+                ops.direct_done((bw, bb), ctx.use_gen)
             if ctx.needs_input_grad[2]:       # a conv bias in front of train-mode BatchNorm (SVTR PatchEmbed) cancels in the
                 dbias = torch.zeros(dy.shape[-1], device=dy.device, dtype=torch.float32)     # mean: its gradient is exactly 0
         else:
@@ -477,7 +478,7 @@ class ConvBlockFn(torch.autograd.Function):
                     if g is not None:
                         ops.unpack_conv_weight(g, out=wgrad, accumulate=True)
                 ops.side_stream_keep((dy, x, sd, ctx.x_scale))
-                ops.direct_done((ctx.conv.weight,))
+                ops.direct_done((ctx.conv.weight,), ctx.use_gen)
             else:
                 dw = ops.unpack_conv_weight(weight_gradient())
         # the small per-channel gradients (conv bias, BatchNorm weight / bias) too: handed to autograd they cost two or three 5-us
@@ -493,7 +494,7 @@ class ConvBlockFn(torch.autograd.Function):
                     if g is not None:
                         p.grad.add_(g.reshape(p.grad.shape))
             ops.side_stream_keep([g for _, g in small])
-            ops.direct_done([p for p, g in small if g is not None])
+            ops.direct_done([p for p, g in small if g is not None], ctx.use_gen)
             dbias = dgamma = dbeta = None
         if ctx.needs_input_grad[0]:
             wt = ops.trained_dgrad_weight(w.ohwi)
@@ -648,7 +649,7 @@ class BiLSTMFn(torch.autograd.Function):
         ctx.save_for_backward(x, w_ih, w_hh_f, w_hh_r, out, gates, cseq)
         ctx.H = H
         ctx.params = (w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r)
-        ops.note_param_uses(ctx.params, any(ctx.needs_input_grad))
+        ctx.use_gen = ops.note_param_uses(ctx.params, any(ctx.needs_input_grad))
         return out
 
     @staticmethod
@@ -676,7 +677,7 @@ class BiLSTMFn(torch.autograd.Function):
             dw_hh_r = linear_wgrad(dg[:, :, 1, :], hprev[:, :, 1, :])
             return (dw_ih[:4 * H], dw_hh_f, db[:4 * H], db[:4 * H], dw_ih[4 * H:], dw_hh_r, db[4 * H:], db[4 * H:])
         # (the parameter gradients hang off the chain: with direct gradients they overlap the next recurrent kernel's idle CUs)
-        return (dx, *side_param_grads(list(ctx.params), param_grads, (dg, x, out)))
+        return (dx, *side_param_grads(list(ctx.params), param_grads, (dg, x, out), gen=ctx.use_gen))
 
 
 class LinearReluFn(torch.autograd.Function):
@@ -687,7 +688,7 @@ class LinearReluFn(torch.autograd.Function):
         y = ops.linear(x, weight, bias, act=ops.ACT_RELU)
         ctx.save_for_backward(x, weight, y)
         ctx.params = (weight, bias)
-        ops.note_param_uses(ctx.params, any(ctx.needs_input_grad))
+        ctx.use_gen = ops.note_param_uses(ctx.params, any(ctx.needs_input_grad))
         return y
 
     @staticmethod
@@ -695,7 +696,7 @@ class LinearReluFn(torch.autograd.Function):
         x, weight, y = ctx.saved_tensors
         g = ops.ew_rows(ops.EW_RELU_BWD, y, dy.contiguous())
         dx = linear_dgrad(g, weight).view(x.shape) if ctx.needs_input_grad[0] else None
-        dw, db = side_param_grads(list(ctx.params), lambda: (linear_wgrad(g, x), ops.colsum(g)), (g, x))
+        dw, db = side_param_grads(list(ctx.params), lambda: (linear_wgrad(g, x), ops.colsum(g)), (g, x), gen=ctx.use_gen)
         return dx, dw, db
 
 
@@ -771,7 +772,7 @@ class AttnDecoderFn(torch.autograd.Function):
         ctx.save_for_backward(batch_H, Hproj, emb, hid, i2h_w, h2h_w, score_w, w_ih, w_hh, gen_w, tok, *saves)
         ctx.dims = (Hd, D, num_class, S)
         ctx.params = (i2h_w, h2h_w, h2h_b, score_w, w_ih, w_hh, b_ih, b_hh, emb_w, gen_w, gen_b)
-        ops.note_param_uses(ctx.params, any(ctx.needs_input_grad))
+        ctx.use_gen = ops.note_param_uses(ctx.params, any(ctx.needs_input_grad))
         return probs
 
     @staticmethod
@@ -804,7 +805,7 @@ class AttnDecoderFn(torch.autograd.Function):
             demb_w = ops.embed_scatter_add(tok, demb.view(B, S, -1), num_class)
             di2h_w = linear_wgrad(dHproj, batch_H)
             return (di2h_w, dh2h_w, dh2h_b, dws.view_as(score_w), dw_ih, dw_hh, db, db, demb_w, dgen_w, dgen_b)
-        grads = side_param_grads(list(ctx.params), param_grads, (dprobs, hid, dgates, cx, emb, dhp, dHproj, batch_H, dws, w_ih, tok))
+        grads = side_param_grads(list(ctx.params), param_grads, (dprobs, hid, dgates, cx, emb, dhp, dHproj, batch_H, dws, w_ih, tok), gen=ctx.use_gen)
         dH = None
         if ctx.needs_input_grad[0]:
             dH = linear_dgrad(dHproj, i2h_w, out=dHb.view(B * T, D), accumulate=True).view(B, T, D)
@@ -873,7 +874,7 @@ class TrainLinearFn(torch.autograd.Function):
             y, sw = x3_linear(x2, weight, bias, sx=sx, want_sw=True, x_hl=x_hl, w_pack=w_pack, amax_ws=ws)
         ctx.save_for_backward(x, weight, sx, sw)          # (sw: max|W| is the same for W^T in the data gradient)
         ctx.params = (weight, bias)
-        ops.note_param_uses(ctx.params, any(ctx.needs_input_grad))
+        ctx.use_gen = ops.note_param_uses(ctx.params, any(ctx.needs_input_grad))
         y = y.view(*x.shape[:-1], N)
         if ctx.x3 and want_range:
             ops.stash_operand(y, None, ops.pow2_finalize(ops.FP16_WEIGHT_PEAK))
@@ -902,7 +903,7 @@ class TrainLinearFn(torch.autograd.Function):
         need_w, need_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         dw, db = side_param_grads([ctx.params[0] if need_w else None, ctx.params[1] if need_b else None],
                                   lambda o: (linear_wgrad(dy2, x.view(-1, x.shape[-1]), sd, sx, out=o[0]) if need_w else None,
-                                             ops.colsum(dy2, out=o[1], accumulate=True) if need_b else None), (dy2, x, sd, sx), into=True)
+                                             ops.colsum(dy2, out=o[1], accumulate=True) if need_b else None), (dy2, x, sd, sx), into=True, gen=ctx.use_gen)
         return dx, dw, db, None, None
 
 
@@ -921,7 +922,7 @@ class LayerNormFn(torch.autograd.Function):
             ops.stash_operand(y, hl, sc)
         ctx.save_for_backward(x, gamma, mean, rstd)
         ctx.params = (gamma, beta)
-        ops.note_param_uses(ctx.params, any(ctx.needs_input_grad))
+        ctx.use_gen = ops.note_param_uses(ctx.params, any(ctx.needs_input_grad))
         return y
 
     @staticmethod
@@ -937,7 +938,7 @@ class LayerNormFn(torch.autograd.Function):
             acc = torch.as_strided(gw, (2 * C,), (1,))
         dx, dgamma, dbeta = ops.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, grad_acc=acc)
         if acc is not None:
-            ops.direct_done(ctx.params)
+            ops.direct_done(ctx.params, ctx.use_gen)
         return dx, dgamma, dbeta, None, None
 
 

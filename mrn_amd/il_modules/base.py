@@ -292,6 +292,9 @@ class BaseLearner(object):
                f'{"":9s}Infer_time: {infer_time:0.2f},     Elapsed_time: {time.time() - start_time:0.2f}\n')
         if train_taski_loss_avg is not None:
             log += f'{"":9s}Train_taski_loss: {float(train_taski_loss_avg.val()):0.5f}\n'
+        skipped = self.optimizer.skipped_steps() if hasattr(self.optimizer, "skipped_steps") else 0
+        if skipped:     # (the reference would have gone NaN and been noticed; here an overflowed gradient skips its step, csrc/optim.hip)
+            log += f'{"":9s}Optimiser steps SKIPPED for a non-finite gradient norm so far: {skipped}\n'
         dashed = "-" * 80
         log += f'{dashed}\n{"Ground Truth":25s} | {"Prediction":25s} | Confidence Score & T/F\n{dashed}\n'
         for gt, pred, confidence in zip(labels[:5], preds[:5], confidence_score[:5]):

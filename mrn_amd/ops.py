@@ -1294,28 +1294,42 @@ _GRAD_OPERANDS = {}                 # the same for gradients inside a backward p
                                     # while autograd hands it on), dropped when the pass ends (join_side_stream) or the table grows
 
 
+OPERAND_STATS = {"hits": 0, "stale": 0}       # cached_operand: operands served / entries refused because the tensor changed in place
+
+
 def stash_operand(t, hl, scale, grad=False):
+    """the producer of t leaves t's split operand (hl) and / or its range scale for the Linear that consumes t; the entry is valid for
+    this tensor OBJECT at its current version counter (an in-place op on t between producer and consumer invalidates it)"""
     if grad:
         if len(_GRAD_OPERANDS) > 512:
             _GRAD_OPERANDS.clear()
-        _GRAD_OPERANDS[id(t)] = (t, hl, scale)
+        _GRAD_OPERANDS[id(t)] = (t, hl, scale, t._version)
         return
     if _GRAD_OPERANDS:
         _GRAD_OPERANDS.clear()          # a forward pass is running: whatever the last backward pass left (one without a side-stream join) is dead
     if len(_OPERANDS) > 48:         # (entries own the HL32 buffers: dead owners' entries go before they pile up -- a block leaves four per step)
         for k in [k for k, v in _OPERANDS.items() if v[0]() is None]:
             del _OPERANDS[k]
-    _OPERANDS[id(t)] = (weakref.ref(t), hl, scale)
+    _OPERANDS[id(t)] = (weakref.ref(t), hl, scale, t._version)
 
 
 def cached_operand(t):
-    """-> (hl or None, scale) left by the producer of t, or None"""
+    """-> (hl or None, scale) left by the producer of t, or None (no entry, another tensor at the same address, or t modified in place
+    since the entry was made)"""
     got = _GRAD_OPERANDS.get(id(t))
     if got is not None and got[0] is t:
+        if got[3] != t._version:
+            OPERAND_STATS["stale"] += 1
+            return None
+        OPERAND_STATS["hits"] += 1
         return got[1], got[2]
     got = _OPERANDS.get(id(t))
     if got is None or got[0]() is not t:
         return None
+    if got[3] != t._version:
+        OPERAND_STATS["stale"] += 1
+        return None
+    OPERAND_STATS["hits"] += 1
     return got[1], got[2]
 
 
@@ -1543,11 +1557,12 @@ def ctc_loss_bwd(ctx, upstream):
 # ---------------------------------------------------------------------------------------------------------
 # optimiser
 # ---------------------------------------------------------------------------------------------------------
-def grad_norm_clip(gflat, max_norm):
-    """-> device tensor [norm, clip_coef]"""
+def grad_norm_clip(gflat, max_norm, out=None):
+    """-> device tensor [norm, clip_coef, skipped steps]; `out`: the caller's persistent three-float buffer (zero-initialised once), whose
+    third element counts the steps the update kernels skipped because the gradient norm was not finite"""
     n = gflat.numel()
     ws = torch.empty(call("mrn_grad_norm_workspace_floats", n), device=gflat.device, dtype=torch.float32)
-    nc = torch.empty(2, device=gflat.device, dtype=torch.float32)
+    nc = out if out is not None else torch.zeros(3, device=gflat.device, dtype=torch.float32)
     call("mrn_grad_norm_clip_f32", _p(gflat), n, float(max_norm), _p(ws), _p(nc), _stream())
     return nc
 
@@ -1644,7 +1659,15 @@ def unpack_conv_weight(g_ohwi, out=None, accumulate=False):
 WGRAD_SIDE_STREAM = os.environ.get("MRN_WGRAD_STREAM", "1") == "1"
 GRAD_DIRECT = False                 # set by direct_gradients(): only a caller that runs loss.backward() INTO .grad may skip autograd's accumulation
 _GRAD_NOTIFY = [None]               # direct_gradients(notify=...): called with a Parameter once ALL its side-stream accumulations are issued
-_PARAM_USES = {}                    # id(Parameter) -> forward uses (by functions that may accumulate directly) not yet matched by a backward
+# Forward uses (by functions that may accumulate directly) not yet matched by a backward, PER FORWARD GENERATION: a function's forward
+# stores the generation it was counted under on its ctx (ctx.use_gen) and its backward ticks the counts of THAT generation, so graphs
+# whose backward runs elsewhere (torch.autograd.grad: Fisher passes; grad-enabled validation) or interleaved graphs (fwd A, fwd B,
+# bwd A, bwd B) never touch each other's counts.  A generation ends when a backward under direct_gradients exits or a data-parallel
+# wrapper starts a forward (new_use_generation); the table keeps the last few.  A parameter that is MISSING from its generation's
+# table is never reported complete by direct_done -- the bucketed all-reduce's finish() picks it up after the join.
+_PARAM_USES = {0: {}}               # generation -> {id(Parameter): uses}
+_USE_GEN = [0]
+_USE_GEN_KEEP = 8
 _SIDE_STREAMS = {}
 _SIDE_PENDING = [False]
 _SIDE_KEEP = []                     # tensors the side stream still reads, held until the join (see side_stream_keep)
@@ -1671,34 +1694,54 @@ class direct_gradients:
         global GRAD_DIRECT
         GRAD_DIRECT = self.prev
         _GRAD_NOTIFY[0] = self.prev_notify
-        _PARAM_USES.clear()
+        new_use_generation()
         join_side_stream()           # (normally done by the backward pass's final callback; an exception inside backward skips that)
         return False
+
+
+def new_use_generation():
+    """later forwards count their parameter uses in a fresh table (called when a backward under direct_gradients has run and by the
+    data-parallel wrapper at the start of every grad-enabled forward)"""
+    _USE_GEN[0] += 1
+    _PARAM_USES[_USE_GEN[0]] = {}
+    for old in [g for g in _PARAM_USES if g <= _USE_GEN[0] - _USE_GEN_KEEP]:
+        del _PARAM_USES[old]
+    return _USE_GEN[0]
 
 
 def note_param_uses(params, recording=True):
     """forward of a function whose backward may accumulate these parameters' gradients on the side stream: one more use to wait for
     before the parameter counts as complete (a recurrent conv layer applies one weight several times).  `recording`: the call is
-    being recorded by autograd (any(ctx.needs_input_grad); grad mode itself is off inside a Function's forward)"""
+    being recorded by autograd (any(ctx.needs_input_grad); grad mode itself is off inside a Function's forward).
+    -> the generation the uses were counted under: the caller keeps it on its ctx and hands it to direct_done."""
+    gen = _USE_GEN[0]
     if recording:
+        table = _PARAM_USES[gen]
         for p in params:
             if p is not None and p.requires_grad:
-                _PARAM_USES[id(p)] = _PARAM_USES.get(id(p), 0) + 1
+                table[id(p)] = table.get(id(p), 0) + 1
+    return gen
 
 
-DIRECT_STATS = {"parameters": 0}    # side-stream accumulations issued (tests / bench telemetry)
+DIRECT_STATS = {"parameters": 0, "notified": 0}    # side-stream accumulations issued / parameters reported complete (tests, bench telemetry)
 
 
-def direct_done(params):
-    """the side-stream accumulation of one use of each of `params` has been issued"""
+def direct_done(params, gen=None):
+    """the side-stream accumulation of one use of each of `params` has been issued; gen: what note_param_uses returned in the
+    forward of the calling function.  A parameter is reported to direct_gradients(notify=...) when the count of ITS generation
+    reaches zero; one without a count (generation dropped, forward not recorded) is left to the reducer's finish()."""
     notify = _GRAD_NOTIFY[0]
+    table = _PARAM_USES.get(gen)
     for p in params:
         if p is None:
             continue
         DIRECT_STATS["parameters"] += 1
-        n = _PARAM_USES.get(id(p), 1) - 1
-        _PARAM_USES[id(p)] = n
+        if table is None or id(p) not in table:
+            continue
+        n = table[id(p)] - 1
+        table[id(p)] = n
         if n == 0 and notify is not None:
+            DIRECT_STATS["notified"] += 1
             notify(p)
 
 

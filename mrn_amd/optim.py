@@ -85,9 +85,16 @@ class FlatOptimizer:
         self.step_count = 0
         self.param_groups = [{"lr": lr}]      # what the learners' logging and adjust_learning_rate() touch
         self.last_norm = None
+        self.norm_state = torch.zeros(3, device=dev, dtype=torch.float32)      # [norm, clip coefficient, skipped steps] (ops.grad_norm_clip)
 
     def zero_grad(self):
         self.grad.zero_()
+
+    def skipped_steps(self):
+        """steps the update kernels skipped because the clipped gradient's norm was not finite (device counter: this call synchronises;
+        the learners read it when they log, bench.py after its timed region).  The host's step_count -- bias correction, schedule --
+        advances on such a step too."""
+        return int(self.norm_state[2].item())
 
     def view_of(self, flat_like, i):
         """the slice of a flat-buffer-shaped tensor that belongs to parameter i, shaped like it"""
@@ -102,7 +109,7 @@ class FlatOptimizer:
         self.lr = lr
         self.param_groups[0]["lr"] = lr
         self.step_count += 1
-        nc = ops.grad_norm_clip(self.grad, max_norm) if max_norm is not None else None
+        nc = ops.grad_norm_clip(self.grad, max_norm, out=self.norm_state) if max_norm is not None else None
         self.last_norm = nc
         self._update(nc, lr, momentum)
         # the kernels wrote the parameters through raw pointers: tell torch, so that every repacked-weight cache keyed on

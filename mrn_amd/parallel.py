@@ -8,6 +8,7 @@ per-step traffic at all; BatchNorm statistics stay per replica exactly as under 
 broadcast from rank 0 once, when a learner builds or grows its model.
 """
 import os
+import sys
 
 import torch
 import torch.distributed as dist
@@ -22,6 +23,11 @@ class ReplicaDataParallel(nn.Module):
         self.module = module
 
     def forward(self, *args, **kwargs):
+        ops = sys.modules.get(__package__ + ".ops")       # (not imported by the CPU-only users of this module: nothing to count then)
+        if ops is not None and torch.is_grad_enabled():
+            # parameter uses of this forward are counted in a table of their own (ops.note_param_uses): graphs whose backward never
+            # runs under ops.direct_gradients (Fisher passes, grad-enabled validation) leave nothing behind in a later step's counts
+            ops.new_use_generation()
         return self.module(*args, **kwargs)
 
 

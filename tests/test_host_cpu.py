@@ -185,15 +185,21 @@ class DirectLinear(torch.autograd.Function):
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
         ctx.params = (w, b)
-        ops.note_param_uses(ctx.params, any(ctx.needs_input_grad))
+        ctx.use_gen = ops.note_param_uses(ctx.params, any(ctx.needs_input_grad))
         return x @ w.t() + b
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         assert ops.GRAD_DIRECT
         ctx.params[0].grad.add_(dy.t() @ x)
-        ops.direct_done((ctx.params[0],))
+        accumulated[id(ctx.params[0])] = accumulated.get(id(ctx.params[0]), 0) + 1
+        ops.direct_done((ctx.params[0],), ctx.use_gen)
         return dy @ w, None, dy.sum(0)                 # (the bias goes through autograd: hooks and notifications mix inside a bucket)
+accumulated = {}
+def notify_checked(p):
+    # a parameter is reported complete only after ALL its uses of this graph have been accumulated (the last Linear: two)
+    assert accumulated.get(id(p), 0) == (2 if p is net[3].weight else 1), "parameter reported complete before its last accumulation"
+    red.param_ready(p)
 def forward(x):
     h = torch.relu(net[1](DirectLinear.apply(x, net[0].weight, net[0].bias)))
     h = torch.relu(DirectLinear.apply(h, net[3].weight, net[3].bias))
@@ -203,10 +209,17 @@ for step in range(2):
     torch.manual_seed(70 + 10 * step + rank)
     x, y = torch.randn(16, 40), torch.randn(16, 7)
     opt.zero_grad()
+    if step == 1:
+        # a recorded forward whose backward never runs under direct_gradients (a Fisher pass through torch.autograd.grad, a
+        # grad-enabled validation) must not inflate the counts of the step that follows it; the data-parallel wrapper starts a new
+        # generation at every grad-enabled forward
+        dropped = forward(torch.randn(16, 40))
+        ops.new_use_generation()
     red.begin()
-    with ops.direct_gradients(notify=red.param_ready):
+    accumulated.clear()
+    with ops.direct_gradients(notify=notify_checked):
         ((forward(x) - y) ** 2).mean().backward()
-    assert not ops._PARAM_USES and ops._GRAD_NOTIFY[0] is None
+    assert ops._GRAD_NOTIFY[0] is None
     # every bucket but the one holding the never-used parameter completed DURING backward
     assert red.next >= len(red.buckets) - 1, (red.next, len(red.buckets))
     red.finish()
@@ -219,6 +232,40 @@ for step in range(2):
     both = [torch.zeros_like(mine) for _ in range(2)]
     torch.distributed.all_gather(both, mine)
     assert torch.allclose(g, (both[0] + both[1]) / 2, atol=1e-7), (g - (both[0] + both[1]) / 2).abs().max()
+# interleaved graphs -- forward A, forward B, backward A, backward B -- with the twice-used weight: every backward ticks the counts of ITS
+# OWN forward generation (ADVICE r4: the exit after backward A used to clear B's counts, and the weight was then reported complete after
+# the first of its two accumulations)
+torch.manual_seed(300 + rank)
+xa, ya, xb, yb = torch.randn(16, 40), torch.randn(16, 7), torch.randn(16, 40), torch.randn(16, 7)
+loss_a = ((forward(xa) - ya) ** 2).mean()
+ops.new_use_generation()
+loss_b = ((forward(xb) - yb) ** 2).mean()
+for loss, (xx, yy) in ((loss_a, (xa, ya)), (loss_b, (xb, yb))):
+    opt.zero_grad()
+    red.begin()
+    accumulated.clear()
+    with ops.direct_gradients(notify=notify_checked):
+        loss.backward()
+    assert red.next >= len(red.buckets) - 1, (red.next, len(red.buckets))
+    red.finish()
+    g = opt.grad.clone()
+    opt.zero_grad()
+    with ops.direct_gradients():
+        ((forward(xx) - yy) ** 2).mean().backward()
+    mine = opt.grad.clone()
+    both = [torch.zeros_like(mine) for _ in range(2)]
+    torch.distributed.all_gather(both, mine)
+    assert torch.allclose(g, (both[0] + both[1]) / 2, atol=1e-7), (g - (both[0] + both[1]) / 2).abs().max()
+# a backward whose forward generation has been dropped (or was never counted) reports nothing: finish() launches what is left
+loss_c = ((forward(xa) - ya) ** 2).mean()
+for _ in range(ops._USE_GEN_KEEP + 1):
+    ops.new_use_generation()
+opt.zero_grad()
+red.begin()
+with ops.direct_gradients(notify=notify_checked):
+    loss_c.backward()
+red.finish()
+assert red.launched_log == list(range(len(red.buckets))), red.launched_log
 parallel.barrier()
 open(os.path.join(os.environ["MRN_OUT"], f"bok_{rank}"), "w").write("ok")
 """

@@ -60,9 +60,18 @@ def record(learner, name, out):
 
 
 _F64 = {}
-_ALT = {}                        # name -> movement of the same flow on the alternate convolution kernel (conditioning run)
+_ALT = {}                        # name -> (movement of the same flow on the alternate convolution kernel, its distance from float64)
 _MOVE_MODE = ["assert"]
-MOVEMENT_FACTOR, MOVEMENT_FLOOR, MOVEMENT_COND = 3.0, 1e-2, 2.0
+MOVEMENT_FACTOR, MOVEMENT_FLOOR = 3.0, 1e-2
+COND_FACTOR, COND_FLOOR = 3.0, 1e-2
+# Tensors whose two-kernel spread is allowed above COND_FACTOR x the reference's own fp32-vs-float64 distance, pinned BY NAME with the
+# cap they get (calibrated on MI355X with MRN_MOVEMENT_LOG; DESIGN section 2: LwF task 0 on CRNN has ONE knife-edge ReLU at the last
+# convolution -- a pre-activation within 1e-6 of zero under one of the largest upstream gradients -- that flips with the accumulation
+# order of either kernel and moves 14 % of the two-step Adam movement of the tensors upstream of it, while the reference's fp32 and
+# float64 runs agree to 3e-5 there).  Every other tensor of every flow has to stay inside the reference's own conditioning.
+KNIFE_EDGE_CAPS = {("crnn", "lwf/t0/delta/model.FeatureExtraction.ConvNet.14.weight/sub"): 0.2}      # measured 0.139 (r05 calibration: the
+# row-block kernel's run flips the ReLU, the x3 kernel's run sits at 3.7e-5 of the float64 movement; 182 other tensors need no entry:
+# their spread is <= 1.6 x the reference's own fp32-vs-float64 distance or under the 1e-2 floor)
 MOVEMENT_LOG = []
 
 
@@ -71,29 +80,38 @@ def _assert_movement(kind, name, k, mine, ref32):
     tests/golden/il_{trba,crnn}_f64.npz hold the SAME reference flows run in float64 arithmetic (make_golden_il_f64.py).  Adam turns the
     fp32 round-off of near-zero gradients into +-lr steps, so the reference's own fp32 run is 12-35 % (relative L2) away from its float64
     run on TRBA's ResNet / TPS tensors and up to 9 % on CRNN's first convolution, while it sits at 5e-5 ... 5e-3 on the recurrent / head
-    tensors.  The HIP movement must be as close to the float64 run as the largest of
-      * MOVEMENT_FACTOR x the reference's own fp32 run,
-      * MOVEMENT_FLOOR (the split-fp16 x3 products' distance on well-conditioned tensors: <= 3.4e-3 measured),
-      * MOVEMENT_COND x the HIP path's OWN sensitivity to a re-ordering of its fp32 accumulation: every flow runs twice, once with the
-        Winograd convolutions on the x3 kernel's form and once on the row-block kernel (mrn_conv2d_x3_wino_select; the two agree to
-        1e-6 launch by launch).  One knife-edge ReLU -- a pre-activation within 1e-6 of zero under a large upstream gradient: LwF task 0
-        on CRNN has one at the last convolution -- flips with the accumulation order and moves 0.2 % of a weight gradient's signs, i.e.
-        14 % of the Adam movement; a result that changes by X under such a re-ordering cannot be pinned tighter than X."""
-    if _MOVE_MODE[0] == "collect":
-        _ALT[name] = np.array(mine, copy=True)
-        return
+    tensors.  Every flow runs twice: on the x3 kernel's Winograd form (the alternate kernel, first) and on the row-block kernel (the
+    default); the two agree to 1e-6 launch by launch, so their movements differ only through the conditioning of the flow itself.
+    Three assertions per tensor, none of which can be satisfied by the quantity it bounds:
+      1. band = max(MOVEMENT_FACTOR x the reference's own fp32 run, MOVEMENT_FLOOR): the CLOSER of the two HIP runs must be inside it
+         (MOVEMENT_FLOOR: the split-fp16 x3 products' distance on well-conditioned tensors, <= 3.4e-3 measured);
+      2. the two HIP runs may differ from each other by no more than max(COND_FACTOR x the reference's fp32-vs-float64 distance,
+         COND_FLOOR) -- a bug that only one of the two kernels has shows up HERE, however close the other run is to the yardstick --
+         except for the tensors pinned by name in KNIFE_EDGE_CAPS, which get the absolute cap written there;
+      3. hence (triangle inequality) BOTH runs are within band + that spread of the float64 run; asserted explicitly for the log."""
     if kind not in _F64:
         _F64[kind] = dict(load_golden(f"il_{kind}_f64"))
     r64 = _F64[kind][name].astype(np.float64)
     n64 = max(np.linalg.norm(r64), 1e-30)
     e_ref = np.linalg.norm(ref32 - r64) / n64
     e_hip = np.linalg.norm(mine - r64) / n64
-    e_cond = np.linalg.norm(mine - _ALT[name]) / n64 if name in _ALT else 0.0
-    MOVEMENT_LOG.append(f"movement {kind} {name}: HIP vs f64 {e_hip:.3e}, reference fp32 vs f64 {e_ref:.3e}, HIP kernel A vs B {e_cond:.3e}")
+    if _MOVE_MODE[0] == "collect":
+        _ALT[name] = (np.array(mine, copy=True), e_hip)
+        return
+    alt, e_alt = _ALT[name]
+    e_cond = np.linalg.norm(mine - alt) / n64
+    band = max(MOVEMENT_FACTOR * e_ref, MOVEMENT_FLOOR)
+    spread = KNIFE_EDGE_CAPS.get((kind, name), max(COND_FACTOR * e_ref, COND_FLOOR))
+    MOVEMENT_LOG.append(f"movement {kind} {name}: HIP vs f64 {e_hip:.3e} (alternate kernel {e_alt:.3e}), reference fp32 vs f64 {e_ref:.3e}, "
+                        f"HIP kernel A vs B {e_cond:.3e}; band {band:.3e}, allowed spread {spread:.3e}")
     if os.environ.get("MRN_MOVEMENT_LOG"):          # (stdout is captured by the flows' own redirect: calibration runs log to a file)
         with open(os.environ["MRN_MOVEMENT_LOG"], "a") as f:
             f.write(MOVEMENT_LOG[-1] + "\n")
-    assert e_hip <= max(MOVEMENT_FACTOR * e_ref, MOVEMENT_FLOOR, MOVEMENT_COND * e_cond), MOVEMENT_LOG[-1]
+    if os.environ.get("MRN_MOVEMENT_CALIBRATE"):    # log every tensor of every flow without stopping at the first one out of band
+        return
+    assert min(e_hip, e_alt) <= band, MOVEMENT_LOG[-1]
+    assert e_cond <= spread, MOVEMENT_LOG[-1]
+    assert max(e_hip, e_alt) <= band + spread, MOVEMENT_LOG[-1]
 
 
 def _twice(tmp_path, body):

@@ -811,6 +811,36 @@ def test_sgd_and_adadelta_steps_vs_torch():
                 assert_close(f"{kind} step {it}", q.detach(), p.detach(), atol=1e-6, rtol=1e-5)
 
 
+def test_non_finite_gradient_norm_skips_the_step_and_is_counted():
+    """an inf / NaN in the gradient (an overflowed split-fp16 product chain): clip + update leave parameters and optimiser state as they
+    were for all three optimisers, and the skip is COUNTED on the device (FlatOptimizer.skipped_steps(); the learners' log and bench.py's
+    JSON show it) -- torch's clip_grad_norm_ + step would have written NaN into every parameter.  The next finite step applies."""
+    from mrn_amd.optim import FlatAdadelta, FlatAdam, FlatSGD
+    g = torch.Generator().manual_seed(6)
+    shapes = [(37, 5), (130,), (4, 3, 3, 3)]
+    for make in (lambda ps: FlatAdam(ps, lr=1e-3), lambda ps: FlatSGD(ps, 0.05, momentum=0.9, weight_decay=1e-3),
+                 lambda ps: FlatAdadelta(ps, 1.0, rho=0.95, eps=1e-8)):
+        ps = [torch.nn.Parameter(torch.randn(*s, generator=g).cuda()) for s in shapes]
+        opt = make(ps)
+        for q in ps:
+            q.grad.copy_(torch.randn(*q.shape, generator=g))
+        opt.step(lr=opt.lr, max_norm=5.0)
+        assert opt.skipped_steps() == 0
+        before = (opt.flat.clone(), [t.clone() for t in opt.state])
+        for bad in (float("inf"), float("nan")):
+            for q in ps:
+                q.grad.copy_(torch.randn(*q.shape, generator=g))
+            ps[1].grad[17] = bad
+            nc = opt.step(lr=opt.lr, max_norm=5.0)
+            assert not torch.isfinite(nc[0])
+            assert torch.equal(opt.flat, before[0]) and all(torch.equal(a, b) for a, b in zip(opt.state, before[1]))
+        assert opt.skipped_steps() == 2
+        for q in ps:
+            q.grad.copy_(torch.randn(*q.shape, generator=g))
+        opt.step(lr=opt.lr, max_norm=5.0)
+        assert opt.skipped_steps() == 2 and not torch.equal(opt.flat, before[0]) and bool(torch.isfinite(opt.flat).all())
+
+
 def test_native_rccl_entry_points_single_rank():
     """include/mrn_hip.h: mrn_comm_unique_id / mrn_comm_init / mrn_allreduce_f32 / mrn_broadcast_f32 / mrn_comm_destroy (RCCL bound
     with dlopen at init time) on a one-rank communicator, through the stream plumbing the learners use with MRN_COMM=native.

@@ -573,8 +573,10 @@ def test_svtr_operand_fusion_matches_separate_passes():
     outs = []
     saved = ops.TRAIN_OPERAND_FUSION
     try:
+        hits = {}
         for fused in (True, False):
             ops.TRAIN_OPERAND_FUSION = fused
+            h0 = ops.OPERAND_STATS["hits"]
             opt, net = build_net(kind, (40, 70, 97), g, 3)
             net.train()
             for n, p in net.named_parameters():
@@ -583,9 +585,20 @@ def test_svtr_operand_fusion_matches_separate_passes():
             preds = net.model[0](image.cuda(), None, True)["predict"]
             loss = Fn.ctc_loss(preds, labels_index.cuda(), labels_length.cuda())
             loss.backward()
-            outs.append((preds.detach().clone(), float(loss), {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}))
+            outs.append((preds.detach().clone(), float(loss.detach()), {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}))
+            hits[fused] = ops.OPERAND_STATS["hits"] - h0
     finally:
         ops.TRAIN_OPERAND_FUSION = saved
+    # the fused path really was taken (a miss silently falls back to the separate passes: the A/B above could not tell): every trained
+    # Linear of the twelve mixing blocks finds its operand or range in the forward pass and again in the backward pass
+    assert hits[True] >= 60 and hits[False] == 0, hits
+    # an entry is valid for the tensor at the version it was stashed under: an in-place change between producer and consumer is refused
+    t = torch.ones(4, 32, device="cuda")
+    ops.stash_operand(t, None, torch.ones(2, device="cuda"))
+    assert ops.cached_operand(t) is not None
+    stale0 = ops.OPERAND_STATS["stale"]
+    t.add_(1.0)
+    assert ops.cached_operand(t) is None and ops.OPERAND_STATS["stale"] == stale0 + 1
     (p1, l1, g1), (p0, l0, g0) = outs
     assert_close("logits", p1, p0, atol=5e-6 * float(p0.abs().max()), rtol=0)
     assert abs(l1 - l0) <= 5e-6 * max(1.0, abs(l0))
