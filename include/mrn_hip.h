@@ -168,6 +168,22 @@ int64_t mrn_conv3x3_c4_stats_blocks(int B, int H, int W);
 int mrn_conv3x3_c4_grouped_f32(const float* x, const float* w_ohwi, const float* bias, float* y, float* stats, int G,
                                int64_t x_group_stride, int B, int H, int W, int Cout, int act, void* stream);
 
+/* Patch-resident, weight-stationary 3x3 / stride 1 / pad 1 convolution of the narrow early layers of G lock-step experts
+ * ((Cin, Cout) = (32, 64): ResNet conv0_2, feature_extraction.py:216-218; (64, 128): layer1[0].conv1 :171-199 and conv 2 of the TPS
+ * localisation network, transformation.py:63-66) as split-fp16 x3 products: x_hl HL32 lines [Gx][B][H][W][Cin/32][128 B]
+ * (x_group_stride_bytes 0: one shared input), w_hl / w_scale as for mrn_conv2d_x3_hl32, bias [G][Cout] or NULL, y
+ * [G][B][H][W][Cout], stats [G][mrn_conv3x3_patch_stats_blocks][2][Cout] or NULL, act 0 / 1 (ReLU).
+ * pool = 1 (even H, W): the 2x2 / stride-2 max-pool that follows BatchNorm + ReLU (feature_extraction.py:219, transformation.py:62-66)
+ * is taken in the epilogue: y is [G][B][H/2][W/2][Cout] and holds, per window and channel, the MAXIMUM of the raw convolution output
+ * where the BatchNorm weight is >= 0 and the MINIMUM where it is negative (bn_gamma_ptrs: device table of G device addresses of the
+ * weights; NULL: every channel keeps its maximum) -- BatchNorm is monotone per channel, so applying scale / shift / ReLU to this map
+ * (mrn_bn_apply[_wino]_grouped_f32) equals max-pooling the applied full map bit for bit; the statistics cover the full map. */
+int mrn_conv3x3_patch_supported(int Cin, int Cout);
+int64_t mrn_conv3x3_patch_stats_blocks(int G, int B, int H, int W, int Cin);
+int mrn_conv3x3_patch_x3_hl32(const void* x_hl, const void* w_hl, const float* w_scale, const float* bias, const void* bn_gamma_ptrs,
+                              float* y, float* stats, int G, int64_t x_group_stride_bytes, int B, int H, int W, int Cin, int Cout,
+                              int act, int pool, void* stream);
+
 /* Elementwise passes between grouped convolutions (G frozen experts in lock-step).
  * mrn_bn_finalize_grouped_f32: train-mode BatchNorm2d statistics for G modules at once; partials [G][nblk][2][C] from
  *   the conv epilogue; ptrs = device table [4][G] of device pointers {gamma, beta, running_mean, running_var} (NULL

@@ -874,6 +874,39 @@ def conv3x3_c4_grouped(x, weights, bias=None, act=ACT_NONE, want_stats=False, ou
     return y, stats
 
 
+PATCH_CONV = os.environ.get("MRN_PATCH_CONV", "1") == "1"       # A/B switch: the narrow early 3x3 layers on the patch-resident kernel
+
+
+def patch_conv_supported(ksize, stride, padding, Cin, Cout):
+    return (PATCH_CONV and X3_PRODUCTS == 3 and tuple(ksize) == (3, 3) and tuple(stride) == (1, 1) and tuple(padding) == (1, 1)
+            and bool(call("mrn_conv3x3_patch_supported", Cin, Cout)))
+
+
+def conv3x3_patch_x3(x_hl, G, shared_input, B, H, W, Cin, w_hl, w_scale, Cout, bias=None, act=ACT_NONE, want_stats=False, pool=False,
+                     gamma_ptrs=None, out=None):
+    """3x3 / stride 1 / pad 1 convolution of G lock-step experts on the patch-resident weight-stationary kernel (csrc/conv_patch.hip;
+    (Cin, Cout) = (32, 64) / (64, 128)) -> (y, stats or None).  pool: y is the [G,B,H/2,W/2,Cout] map of per-window extremes -- maxima
+    where the BatchNorm weight that follows is >= 0 (gamma_ptrs: int64 device tensor [G] of the weights' addresses; None: all maxima),
+    minima elsewhere -- on which BatchNorm-apply + ReLU equals apply + ReLU + 2x2 max-pool of the full map."""
+    dev = x_hl.device
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    y = out if out is not None else torch.empty(G, B, Ho, Wo, Cout, device=dev, dtype=torch.float32)
+    stats = None
+    if want_stats:
+        stats = torch.empty(G, call("mrn_conv3x3_patch_stats_blocks", G, B, H, W, Cin), 2, Cout, device=dev, dtype=torch.float32)
+    timed = CONV_TIMER is not None
+    t0 = CONV_TIMER.begin() if timed else None
+    call("mrn_conv3x3_patch_x3_hl32", _p(x_hl), _p(w_hl), _p(w_scale), _p(bias), _p(gamma_ptrs), _p(y), _p(stats), G,
+         0 if shared_input else B * H * W * Cin * 4, B, H, W, Cin, Cout, act, int(bool(pool)), _stream())
+    if timed:
+        nbytes = 4.0 * ((1 if shared_input else G) * B * H * W * Cin + G * Cout * 9 * Cin + G * B * Ho * Wo * Cout)
+        kind = "fp16x3/patch" + ("pool" if pool else "")
+        if TIMER_SHAPES:
+            kind += "|G%d B%d %dx%d %d->%d k3x3 s11" % (G, B, H, W, Cin, Cout)
+        CONV_TIMER.end(t0, 2.0 * G * B * H * W * Cout * 9 * Cin, kind, nbytes)
+    return y, stats
+
+
 _FINALIZE_TICKETS = {}
 
 

@@ -778,6 +778,54 @@ def test_first_conv_c4_grouped(ops, G, B, H, W, Cout, shared, act):
         assert_close("sum of squares", tot[1].float(), (pre.double() ** 2).sum((0, 2, 3)).float(), atol=2e-2, rtol=1e-4)
 
 
+@pytest.mark.parametrize("G,B,H,W,Cin,Cout,shared", [(3, 3, 32, 256, 32, 64, False), (2, 2, 16, 128, 64, 128, False), (2, 5, 16, 64, 32, 64, True),
+                                                     (1, 2, 12, 70, 64, 128, False), (2, 37, 8, 32, 32, 64, False)])
+def test_patch_resident_conv(ops, G, B, H, W, Cin, Cout, shared):
+    """mrn_conv3x3_patch_x3_hl32 (the narrow early 3x3 layers: weights in registers, activation patch in LDS) against torch conv2d in
+    float64 on the split operands' values: outputs at the x3 products' 2^-22 level, BatchNorm partial statistics, the ReLU epilogue,
+    ragged tiles (12 x 70: partial tiles in both directions), more tiles than workgroups (persistent loop), and the POOLED epilogue:
+    with mixed-sign BatchNorm weights, BatchNorm-apply + ReLU on the pooled-extremes map equals -- bit for bit -- the 2 x 2 max-pool of
+    BatchNorm-apply + ReLU on the full map (mrn_maxpool_grouped_f32 on the unpooled result of the same kernel)"""
+    x = rnd(*((B, H, W, Cin) if shared else (G, B, H, W, Cin)), seed=330, scale=2.0)
+    x = torch.relu(x) if Cin == 64 else x
+    w = [rnd(Cout, 3, 3, Cin, seed=331 + g, scale=0.1) for g in range(G)]
+    bias = rnd(G, Cout, seed=339)
+    x_hl = ops.split_hl32(cu(x))
+    w_hl, w_scale = ops.pack_weights_hl32([cu(t) for t in w])
+    y, stats = ops.conv3x3_patch_x3(x_hl, G, shared, B, H, W, Cin, w_hl, w_scale, Cout, bias=cu(bias), want_stats=True)
+    yr, _ = ops.conv3x3_patch_x3(x_hl, G, shared, B, H, W, Cin, w_hl, w_scale, Cout, bias=cu(bias), act=ops.ACT_RELU)
+    for g in range(G):
+        xg = (x if shared else x[g]).permute(0, 3, 1, 2).double()
+        pre = torch.nn.functional.conv2d(xg, w[g].permute(0, 3, 1, 2).double(), bias[g].double(), 1, 1)
+        scale = float(pre.abs().max())
+        assert_close(f"patch conv, expert {g}", y[g].permute(0, 3, 1, 2), pre.float(), atol=3e-6 * scale, rtol=0)
+        assert torch.equal(yr[g], torch.relu(y[g]))
+        tot = stats[g].double().sum(0).cpu()
+        n = B * H * W
+        assert_close("sum", tot[0].float(), pre.sum((0, 2, 3)).float(), atol=1e-5 * scale * n, rtol=0)
+        assert_close("sum of squares", tot[1].float(), (pre ** 2).sum((0, 2, 3)).float(), atol=1e-5 * scale * scale * n, rtol=0)
+    # same launch twice: deterministic partial statistics (one row per persistent workgroup, fixed tile order)
+    y2, stats2 = ops.conv3x3_patch_x3(x_hl, G, shared, B, H, W, Cin, w_hl, w_scale, Cout, bias=cu(bias), want_stats=True)
+    assert torch.equal(y, y2) and torch.equal(stats, stats2)
+    if H % 2 or W % 2:
+        return
+    # pooled epilogue with mixed-sign BatchNorm weights (incl. an exact zero)
+    gammas = [cu(rnd(Cout, seed=340 + g)) for g in range(G)]
+    gammas[0][3] = 0.0
+    ptrs = torch.tensor([t.data_ptr() for t in gammas], dtype=torch.int64, device="cuda")
+    bn_scale = torch.stack([t * (0.5 + 0.1 * g) for g, t in enumerate(gammas)]).contiguous()       # sign(scale) = sign(gamma)
+    bn_shift = cu(rnd(G, Cout, seed=349, scale=0.3))
+    yp, sp = ops.conv3x3_patch_x3(x_hl, G, shared, B, H, W, Cin, w_hl, w_scale, Cout, bias=cu(bias), want_stats=True, pool=True, gamma_ptrs=ptrs)
+    assert torch.equal(sp, stats)                                  # the statistics cover the unpooled map
+    got, got_hl = ops.bn_apply_grouped(yp.clone(), bn_scale, bn_shift, relu=True, want_f32=True, want_hl=True)
+    ref, ref_hl, _ = ops.maxpool_grouped(y, (2, 2), (2, 2), (0, 0), bn_scale, bn_shift, relu=True, want_f32=True, want_hl=True)
+    assert torch.equal(got, ref) and torch.equal(got_hl, ref_hl)
+    # no BatchNorm behind the pool (VGG): all maxima, ReLU in the epilogue
+    ypr, _ = ops.conv3x3_patch_x3(x_hl, G, shared, B, H, W, Cin, w_hl, w_scale, Cout, bias=cu(bias), act=ops.ACT_RELU, pool=True)
+    refr, _, _ = ops.maxpool_grouped(yr, (2, 2), (2, 2), (0, 0), None, None, relu=False, want_f32=True, want_hl=False)
+    assert torch.equal(ypr, refr)
+
+
 def test_sgd_and_adadelta_steps_vs_torch():
     """FlatSGD / FlatAdadelta (mrn_sgd_step_f32 / mrn_adadelta_step_f32) against torch.optim.SGD(momentum, weight_decay) and
     torch.optim.Adadelta(rho, eps) with clip_grad_norm_ in front -- the other two optimisers of il_modules/base.py:72-85"""
