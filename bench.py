@@ -312,6 +312,11 @@ def describe_kernel(kind):
         return (f"conv_x3_kernel<{targs}{', false, 1' if nprod == 1 else ''}> (grouped {tile}x32 implicit-GEMM conv / Linear over "
                 f"all experts, {arith} on v_mfma_f32_32x32x16_f16, HL32 operands staged by buffer_load...lds)",
                 BF16_MFMA_PEAK_TFLOPS, nprod)
+    if staging.startswith("patch"):
+        return ("conv_patch_x3_kernel (narrow early 3x3 layers of all experts, patch-resident and weight-stationary: weights in registers, "
+                "activation patch staged once by buffer_load...lds, nine shifted ds_read_b128 views"
+                + (", 2x2 max-pool taken in the epilogue by BatchNorm-weight sign" if staging.endswith("pool") else "")
+                + f", {arith} on v_mfma_f32_32x32x16_f16)", BF16_MFMA_PEAK_TFLOPS, 3)
     svtr = {"svtrmlp": "svtr_mlp_kernel (fc1 -> GELU -> fc2 of an SVTR mixing block over all experts, hidden activation in registers)",
             "svtrmixer": "svtr_mixer_kernel (LayerNorm1 -> qkv -> local / global attention -> proj -> residual -> LayerNorm2 of an SVTR mixing "
                          "block over all experts, chained MFMAs, K / V through LDS)",

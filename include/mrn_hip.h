@@ -178,7 +178,7 @@ int mrn_conv3x3_c4_grouped_f32(const float* x, const float* w_ohwi, const float*
  * where the BatchNorm weight is >= 0 and the MINIMUM where it is negative (bn_gamma_ptrs: device table of G device addresses of the
  * weights; NULL: every channel keeps its maximum) -- BatchNorm is monotone per channel, so applying scale / shift / ReLU to this map
  * (mrn_bn_apply[_wino]_grouped_f32) equals max-pooling the applied full map bit for bit; the statistics cover the full map. */
-int mrn_conv3x3_patch_supported(int Cin, int Cout);
+int64_t mrn_conv3x3_patch_supported(int Cin, int Cout);
 int64_t mrn_conv3x3_patch_stats_blocks(int G, int B, int H, int W, int Cin);
 int mrn_conv3x3_patch_x3_hl32(const void* x_hl, const void* w_hl, const float* w_scale, const float* bias, const void* bn_gamma_ptrs,
                               float* y, float* stats, int G, int64_t x_group_stride_bytes, int B, int H, int W, int Cin, int Cout,

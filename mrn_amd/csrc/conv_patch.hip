@@ -36,11 +36,12 @@ struct ConvPatchParams {
   const float* bias;           // [G][Cout] or null
   const long long* gamma;      // [G] device addresses of the BatchNorm weights that follow (pooled form: which extreme to keep), or null
   float* y;                    // [G][B][H][W][Cout], pooled form [G][B][H/2][W/2][Cout]
-  float* stats;                // [G][gridDim.x][2][Cout] or null
+  float* stats;                // [G][rows * RG][2][Cout] or null (RG = wave row groups: 2 for Cin 32, 1 for Cin 64)
   long x_gstride;              // bytes between the experts' inputs (0: shared)
   int x_bytes;                 // bytes of one expert's input
   int B, H, W, act, pool;
   int tiles_x, tiles_y, tiles; // per expert
+  int rows;                    // statistics rows per expert: tile t belongs to row t % rows, whatever workgroup computes it
 };
 
 template <int CB, int NCO, int NST>
@@ -297,7 +298,34 @@ __global__ __launch_bounds__(256) void conv_patch_x3_kernel(const ConvPatchParam
     return e;
   };
 
-  int tile = blockIdx.x, stage = 0;
+  // ---- tile order.  The partial BatchNorm statistics must not depend on how many workgroups the launch has (the experts run as one
+  // lock-step group of six or as sub-groups of two or three: bit-identical results either way), so tiles are summed per ROW -- tile t
+  // belongs to row t % rows, rows = min(tiles, 1008) whatever the grid -- and a workgroup walks whole rows: row = blockIdx.x,
+  // blockIdx.x + gridDim.x, ...; inside a row tiles row, row + rows, ...  A row's sums leave (flush_stats) when its last epilogue has run.
+  auto flush_stats = [&](int row) {
+    f32x4 v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      v[c] = LEAN ? *reinterpret_cast<const f32x4*>(st_base + c * 1024) : (c < 4 ? st_s[LEAN ? 0 : c] : st_q[LEAN ? 0 : c - 4]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float sum = v[c][i];
+#pragma unroll
+        for (int ofs = 16; ofs > 0; ofs >>= 1) sum += __shfl_xor(sum, ofs);      // over the 32 pixel columns of a kh half
+        v[c][i] = sum;
+      }
+      if (LEAN) *reinterpret_cast<f32x4*>(st_base + c * 1024) = f32x4{0.f, 0.f, 0.f, 0.f};
+      else if (c < 4) st_s[LEAN ? 0 : c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      else st_q[LEAN ? 0 : c - 4] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (n == 0 && p.stats) {                      // lanes 0 and 32: channels co0 + 8 q + 4 kh .. + 3 of the wave's row group
+      float* dst = p.stats + (((long)g * p.rows + row) * C::RG + rg) * 2 * Cout + co0 + 4 * kh;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) *reinterpret_cast<f32x4*>(dst + (c >> 2) * Cout + 8 * (c & 3)) = v[c];
+    }
+  };
+  int row = blockIdx.x, tile = row, stage = 0;
+  int flush_row = -1;                             // row whose sums are complete once the pending epilogue has run
   TileAt cur = locate(tile < p.tiles ? tile : 0);
   if (tile < p.tiles) {
 #pragma unroll
@@ -307,7 +335,7 @@ __global__ __launch_bounds__(256) void conv_patch_x3_kernel(const ConvPatchParam
 #ifdef MRN_PPROBE_TIMING
   long dbg_acc[6] = {0, 0, 0, 0, 0, 0};
 #endif
-  for (; tile < p.tiles; tile += gridDim.x) {
+  while (tile < p.tiles) {
     PTICK(tk0);
     // NST = 2: everyone's pieces of this tile's patch have landed (each wave waited for its own at the end of its last tile / above)
     // and everyone has left the other stage (tile - gridDim.x)
@@ -316,9 +344,13 @@ __global__ __launch_bounds__(256) void conv_patch_x3_kernel(const ConvPatchParam
     asm volatile("" ::: "memory");
     PTICK(tk1);
     PADD(0, tk0, tk1);                                              // loop-top barrier (+ the single-stage form's patch fetch)
-    const int nxt = tile + gridDim.x;
+    int nxt = tile + p.rows, nrow = row;
+    if (nxt >= p.tiles) {                         // the row is done: on to the workgroup's next row
+      nrow = row + gridDim.x;
+      nxt = nrow < p.rows ? nrow : p.tiles;
+    }
     const bool more = nxt < p.tiles;
-    const TileAt nx = locate(nxt < p.tiles ? nxt : tile);
+    const TileAt nx = locate(more ? nxt : tile);
 
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
@@ -366,6 +398,10 @@ __global__ __launch_bounds__(256) void conv_patch_x3_kernel(const ConvPatchParam
         PATCH_INTERLEAVE PATCH_INTERLEAVE PATCH_INTERLEAVE PATCH_INTERLEAVE PATCH_INTERLEAVE PATCH_INTERLEAVE
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (ps == 0 && flush_row >= 0) {            // (the pending epilogue of the previous row's last tile ran under this pass)
+        flush_stats(flush_row);
+        flush_row = -1;
+      }
       pend = make_pending(cur, ps);
       if (!PIPE) {                                 // (LEAN: no second accumulator set -- the epilogue runs behind its pass)
 #pragma unroll
@@ -385,7 +421,10 @@ __global__ __launch_bounds__(256) void conv_patch_x3_kernel(const ConvPatchParam
 #ifdef MRN_PPROBE_TIMING
     dbg_acc[5] += 1;
 #endif
+    if (nrow != row) flush_row = row;
     cur = nx;
+    tile = nxt;
+    row = nrow;
     stage ^= 1;
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx)
@@ -404,38 +443,7 @@ __global__ __launch_bounds__(256) void conv_patch_x3_kernel(const ConvPatchParam
   if (lane == 0)
     for (int i = 0; i < 6; ++i) atomicAdd(&g_patch_dbg[i], (unsigned long long)dbg_acc[i]);
 #endif
-  // ---- the workgroup's row of partial statistics: sum the lanes of a wave (32 pixel columns per kh half), then the row groups
-  if (p.stats) {
-    f32x4 v[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      v[c] = LEAN ? *reinterpret_cast<const f32x4*>(st_base + c * 1024) : (c < 4 ? st_s[LEAN ? 0 : c] : st_q[LEAN ? 0 : c - 4]);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float s = v[c][i];
-#pragma unroll
-        for (int ofs = 16; ofs > 0; ofs >>= 1) s += __shfl_xor(s, ofs);
-        v[c][i] = s;
-      }
-    }
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(lds);                    // [4 waves][2][32]
-    if (n == 0) {
-#pragma unroll
-      for (int c = 0; c < 8; ++c)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) red[(wave * 2 + (c >> 2)) * 32 + 8 * (c & 3) + 4 * kh + i] = v[c][i];
-    }
-    __syncthreads();
-    if (t < 2 * Cout) {
-      const int which = t / Cout, co = t - which * Cout;
-      const int cb_ = co >> 5, ci = co & 31;
-      float s = 0.f;
-#pragma unroll
-      for (int r = 0; r < C::RG; ++r) s += red[((r * NCO + cb_) * 2 + which) * 32 + ci];
-      p.stats[(((long)g * gridDim.x + blockIdx.x) * 2 + which) * Cout + co] = s;
-    }
-  }
+  if (flush_row >= 0) flush_stats(flush_row);
 }
 
 int patch_wgs(int G, long tiles, int per_cu) {
@@ -457,12 +465,16 @@ int patch_wgs(int G, long tiles, int per_cu) {
 }  // namespace
 
 // does the patch-resident kernel take this layer?  (3 x 3, stride 1, padding 1 is implied by the entry point)
-MRN_EXPORT int mrn_conv3x3_patch_supported(int Cin, int Cout) { return (Cin == 32 && Cout == 64) || (Cin == 64 && Cout == 128); }
+MRN_EXPORT int64_t mrn_conv3x3_patch_supported(int Cin, int Cout) { return (Cin == 32 && Cout == 64) || (Cin == 64 && Cout == 128); }
 
-// rows of partial statistics per expert that mrn_conv3x3_patch_x3_hl32 writes (= its persistent workgroups per expert)
+static int patch_rows(long tiles) { return (int)(tiles < 1008 ? tiles : 1008); }      // (1008 = 42 x 24: no imbalance for six experts on 256 CUs, <= 1.6 % for 1 / 2 / 3)
+
+// rows of partial statistics per expert that mrn_conv3x3_patch_x3_hl32 writes: a function of the layer only, NOT of G or the device --
+// tile t is summed into row t % rows whatever workgroup computes it, so every grouping of the experts yields the same bits
 MRN_EXPORT int64_t mrn_conv3x3_patch_stats_blocks(int G, int B, int H, int W, int Cin) {
-  const int TH = Cin == 32 ? 8 : 4;
-  return patch_wgs(G, (long)B * ((H + TH - 1) / TH) * ((W + 31) / 32), 1);
+  (void)G;
+  const int TH = Cin == 32 ? 8 : 4, RG = Cin == 32 ? 2 : 1;
+  return (int64_t)patch_rows((long)B * ((H + TH - 1) / TH) * ((W + 31) / 32)) * RG;
 }
 
 // y[g] = act(conv3x3(x[g or shared], w[g]) / w_scale[g] + bias[g]) for G experts, stride 1, padding 1, (Cin, Cout) = (32, 64) or (64, 128).
@@ -489,7 +501,9 @@ MRN_EXPORT int mrn_conv3x3_patch_x3_hl32(const void* x_hl, const void* w_hl, con
   p.B = B; p.H = H; p.W = W; p.act = act; p.pool = pool;
   const int TH = Cin == 32 ? 8 : 4;
   p.tiles_x = (W + 31) / 32; p.tiles_y = (H + TH - 1) / TH; p.tiles = B * p.tiles_x * p.tiles_y;
-  const int wgs = patch_wgs(G, p.tiles, 1);
+  p.rows = patch_rows(p.tiles);
+  int wgs = patch_wgs(G, p.tiles, 1);
+  if (wgs > p.rows) wgs = p.rows;
 #define PATCH_LAUNCH(CB_, NCO_, POOL_)                                                                                                   \
   do {                                                                                                                                   \
     using C = Cfg<CB_, NCO_, 2>;                                                                                                          \

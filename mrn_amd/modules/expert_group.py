@@ -198,8 +198,22 @@ class BackboneGroup(_GroupedLinear):
             if want_hl and want_f32:
                 return Act((G, B, Ho, Wo, Cout), got[0], got[1])
             return Act((G, B, Ho, Wo, Cout), None, got) if want_hl else Act((G, B, Ho, Wo, Cout), got, None)
-        y = torch.empty(G, B, Ho, Wo, Cout, device=dev, dtype=torch.float32)
-        if use_wino:
+        # the narrow early 3x3 layers (32 -> 64, 64 -> 128): patch-resident weight-stationary kernel (csrc/conv_patch.hip); a 2x2 / 2
+        # max-pool behind it is taken in ITS epilogue -- per window and channel the maximum where the BatchNorm weight is >= 0, the
+        # minimum where it is negative (BatchNorm is monotone per channel) -- so the pass below runs on a quarter of the pixels
+        use_patch = not use_wino and (x.hl is not None or x.f32 is not None) and ops.patch_conv_supported(ksize, stride, padding, Cin, Cout)
+        pooled = use_patch and pool == ((2, 2), (2, 2), (0, 0)) and Ho % 2 == 0 and Wo % 2 == 0
+        y = torch.empty(G, B, Ho // 2 if pooled else Ho, Wo // 2 if pooled else Wo, Cout, device=dev, dtype=torch.float32)
+        if use_patch:
+            if x.hl is None:
+                x.hl = ops.split_hl32(x.f32)
+            w_hl, w_scale = self._weights_hl(convs)
+            _, stats = ops.conv3x3_patch_x3(x.hl, G, x.shared, B, H, W, Cin, w_hl, w_scale, Cout, bias=self._bias_stack(convs), act=act,
+                                            want_stats=training, pool=pooled, gamma_ptrs=self._bn_table(bns)[0] if bns is not None else None,
+                                            out=y)
+            if pooled:
+                pool = None                      # (done: what follows is the plain BatchNorm-apply pass on the pooled map)
+        elif use_wino:
             u_hl, u_scale = self._weights_wino(convs, x.wino_R)
             _, stats = ops.conv2d_x3_wino(x.wino, G, x.shared, B, H, W, Cin, u_hl, u_scale, Cout, x.wino_R,
                                           bias=self._bias_stack(convs), act=act, want_stats=training, out=y)
@@ -242,6 +256,7 @@ class BackboneGroup(_GroupedLinear):
             f32, hl, (Hp, Wp) = ops.maxpool_grouped(y, pool[0], pool[1], pool[2], scale, shift, relu=post_relu,
                                                     want_f32=want_f32, want_hl=want_hl)
             return Act((G, B, Hp, Wp, Cout), f32, hl)
+        Ho, Wo = y.shape[2], y.shape[3]              # (a pooled patch convolution left the pooled map)
         if scale is None and res is None and res_hl is None and not post_relu and not want_hl and not want_wino:
             return Act((G, B, Ho, Wo, Cout), y, None)
         if want_wino:

@@ -807,6 +807,12 @@ def test_patch_resident_conv(ops, G, B, H, W, Cin, Cout, shared):
     # same launch twice: deterministic partial statistics (one row per persistent workgroup, fixed tile order)
     y2, stats2 = ops.conv3x3_patch_x3(x_hl, G, shared, B, H, W, Cin, w_hl, w_scale, Cout, bias=cu(bias), want_stats=True)
     assert torch.equal(y, y2) and torch.equal(stats, stats2)
+    # ... and independent of the grouping: expert 0 launched alone (four to six times the workgroups per expert) gives the same bits --
+    # tiles are summed into rows by tile index, not by the workgroup that happens to compute them
+    if not shared:
+        per_x, per_w = x_hl.numel() // G, w_hl.numel() // G
+        y1, stats1 = ops.conv3x3_patch_x3(x_hl[:per_x], 1, False, B, H, W, Cin, w_hl[:per_w], w_scale[:1], Cout, bias=cu(bias)[:1], want_stats=True)
+        assert torch.equal(y1[0], y[0]) and torch.equal(stats1[0], stats[0])
     if H % 2 or W % 2:
         return
     # pooled epilogue with mixed-sign BatchNorm weights (incl. an exact zero)
