@@ -158,15 +158,26 @@ int mrn_conv2d_x3_wino_select(int mode);
 int mrn_conv2d_x3_wino_hl32(const void* v_hl, const void* u_hl, const void* zero_page, const float* bias, float* y, float* stats,
                             const float* out_scale, const float* x_scale, int G, int64_t v_group_stride_bytes, int B, int H, int W,
                             int Cin, int Cout, int R, int act, void* stream);
+/* the same convolution with the 2x2 / stride-2 max-pool that follows BatchNorm + ReLU (feature_extraction.py:229,242; transformation.py:
+ * 70-75) taken in the epilogue of the row-block kernel (needs mrn_conv2d_x3_wino_rows(H, R, Cout) != 0 and even H, W; otherwise
+ * MRN_ERR_UNSUPPORTED): y [G][B][H/2][W/2][Cout] = per window and channel the maximum of the raw output where the BatchNorm weight
+ * (bn_gamma_ptrs: device table of G device addresses, NULL: all maxima) is >= 0, the minimum elsewhere; statistics over the full map */
+int mrn_conv2d_x3_wino_pool_hl32(const void* v_hl, const void* u_hl, const void* zero_page, const float* bias, float* y, float* stats,
+                                 const float* out_scale, const float* x_scale, int G, int64_t v_group_stride_bytes, int B, int H, int W,
+                                 int Cin, int Cout, int R, int act, const void* bn_gamma_ptrs, void* stream);
 
 /* First convolution of the frozen experts' stacks (3x3, stride 1, padding 1, Cin = 4, Cout = 32 or 64: VGG conv 0
  * feature_extraction.py:19, ResNet conv0_1 :214, TPS localisation conv 1 transformation.py:60), G experts in one launch on the
  * exact-fp32 MFMA; x [Gx][B][H][W][4] with x_group_stride floats between groups (0: all experts read the same crops), w
  * [G][Cout][3][3][4], bias [G][Cout] or NULL, y [G][B][H][W][Cout], stats [G][mrn_conv3x3_c4_stats_blocks][2][Cout] (BatchNorm
- * partial sums / sums of squares of the pre-activation result) or NULL; act 0 / 1 (ReLU). */
+ * partial sums / sums of squares of the pre-activation result) or NULL; act 0 / 1 (ReLU).  pool = 1 (even H, W): the 2x2 / stride-2
+ * max-pool behind BatchNorm + ReLU (feature_extraction.py:20, transformation.py:61-62) is taken in the epilogue as in
+ * mrn_conv3x3_patch_x3_hl32 below: y is [G][B][H/2][W/2][Cout], per window and channel the maximum where the BatchNorm weight
+ * (bn_gamma_ptrs: device table of G device addresses, NULL: all maxima) is >= 0, the minimum elsewhere. */
 int64_t mrn_conv3x3_c4_stats_blocks(int B, int H, int W);
 int mrn_conv3x3_c4_grouped_f32(const float* x, const float* w_ohwi, const float* bias, float* y, float* stats, int G,
-                               int64_t x_group_stride, int B, int H, int W, int Cout, int act, void* stream);
+                               int64_t x_group_stride, int B, int H, int W, int Cout, int act, int pool, const void* bn_gamma_ptrs,
+                               void* stream);
 
 /* Patch-resident, weight-stationary 3x3 / stride 1 / pad 1 convolution of the narrow early layers of G lock-step experts
  * ((Cin, Cout) = (32, 64): ResNet conv0_2, feature_extraction.py:216-218; (64, 128): layer1[0].conv1 :171-199 and conv 2 of the TPS

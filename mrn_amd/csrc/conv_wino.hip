@@ -312,7 +312,7 @@ __device__ __forceinline__ void wino_rows_tile(const WinoRowsParams& p, unsigned
   f32x4 csum[4], csq[4];
 #pragma unroll
   for (int j4 = 0; j4 < 4; ++j4) csum[j4] = csq[j4] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (pos_ok) {
+  if (pos_ok && !p.pool) {
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
       const long pix0 = ((long)b * p.H + oy0 + o) * p.W + 4 * q;
@@ -333,6 +333,53 @@ __device__ __forceinline__ void wino_rows_tile(const WinoRowsParams& p, unsigned
             for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
           }
           *reinterpret_cast<f32x4*>(dst + 8 * j4) = v;
+        }
+      }
+    }
+  } else if (pos_ok) {
+    // POOLED form (p.pool: the 2x2 / stride-2 max-pool behind BatchNorm + ReLU taken here, see conv_patch.hip): a lane holds the 4 x 4
+    // pixels of its position -- four whole windows per channel.  Per window and channel the maximum of the raw output where the
+    // BatchNorm weight is >= 0, the minimum (= -max(-v), exact) where it is negative; the statistics cover every unpooled value.
+    const int Ho = p.H >> 1, Wo = p.W >> 1;
+    float* ypg = p.y + (long)g * p.B * Ho * Wo * p.N;
+    const float* gm = p.gamma ? reinterpret_cast<const float*>(p.gamma[g]) : nullptr;
+    const float relu_floor = p.act == 1 ? 0.f : -INFINITY;
+#pragma unroll
+    for (int j4 = 0; j4 < 4; ++j4) {
+      if (c0 + 8 * j4 >= p.N) continue;
+      f32x4 sg = {1.f, 1.f, 1.f, 1.f};
+      if (gm) {
+        const f32x4 gq = *reinterpret_cast<const f32x4*>(gm + c0 + 8 * j4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sg[i] = gq[i] < 0.f ? -1.f : 1.f;
+      }
+#pragma unroll
+      for (int po = 0; po < 2; ++po) {
+        f32x4 mx[2];                             // the two windows of this row pair (the statistics see the values in the unpooled form's order: same bits)
+#pragma unroll
+        for (int oo = 0; oo < 2; ++oo)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int o = 2 * po + oo;
+            f32x4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = Y[r][o][4 * j4 + i] * osc + bias4[j4][i];
+            if (4 * q + r < p.W) {                // (columns beyond the row exist only in the padded last group: W even => whole windows)
+              csum[j4] += v;
+              csq[j4] += v * v;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mx[r >> 1][i] = (oo | (r & 1)) ? fmaxf(mx[r >> 1][i], v[i] * sg[i]) : v[i] * sg[i];
+          }
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          const int ox = 2 * q + pr;
+          if (ox < Wo) {
+            f32x4 out;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) out[i] = fmaxf(mx[pr][i] * sg[i], relu_floor);
+            *reinterpret_cast<f32x4*>(ypg + (((long)b * Ho + (oy0 >> 1) + po) * Wo + ox) * p.N + c0 + 8 * j4) = out;
+          }
         }
       }
     }

@@ -1404,10 +1404,14 @@ MRN_EXPORT int64_t mrn_conv2d_x3_wino_stats_floats(int G, int B, int H, int W, i
 //   u_hl  [G][Cout][R+2][Cin/32][3][128 B]            transformed weight (mrn_pack_weight_wino_hl32), out_scale [G][2] its {s, 1/s}
 //   y     [G][B][H][W][Cout] fp32 = conv + bias (act 0 / 1), stats [G][mrn_conv2d_x3_wino_stats_floats / G] BatchNorm partials or NULL
 //   x_scale {s, 1/s} of an activation operand that was transformed as s * B^T(x) (trained layers), or NULL
-MRN_EXPORT int mrn_conv2d_x3_wino_hl32(const void* v_hl, const void* u_hl, const void* zero_page, const float* bias, float* y,
-                                       float* stats, const float* out_scale, const float* x_scale, int G, int64_t v_group_stride_bytes,
-                                       int B, int H, int W, int Cin, int Cout, int R, int act, void* stream) {
+static int wino_conv_launch(const void* v_hl, const void* u_hl, const void* zero_page, const float* bias, float* y, float* stats,
+                            const float* out_scale, const float* x_scale, int G, int64_t v_group_stride_bytes, int B, int H, int W, int Cin,
+                            int Cout, int R, int act, int pool, const void* bn_gamma_ptrs, void* stream) {
   MRN_CHECK_ARG(v_hl && u_hl && zero_page && y && G >= 1 && (R == 2 || R == 4), "mrn_conv2d_x3_wino_hl32: bad operands");
+  if (pool && !(mrn_wino_rows_supported(H, R, Cout) && H % 2 == 0 && W % 2 == 0)) {
+    mrn_set_error("mrn_conv2d_x3_wino_pool_hl32: the pooled form needs the row-block kernel (mrn_conv2d_x3_wino_rows) and even H, W (%d x %d)", H, W);
+    return MRN_ERR_UNSUPPORTED;
+  }
   MRN_CHECK_ARG(Cin % 32 == 0 && ((uintptr_t)v_hl % 128 == 0) && ((uintptr_t)u_hl % 128 == 0) && v_group_stride_bytes % 128 == 0,
                 "mrn_conv2d_x3_wino_hl32: HL32 operands must be 128-byte aligned, Cin %% 32 == 0 (Cin=%d)", Cin);
   const int NC = R + 2, Wq = ceil_div(W, R);
@@ -1424,6 +1428,7 @@ MRN_EXPORT int mrn_conv2d_x3_wino_hl32(const void* v_hl, const void* u_hl, const
     q.v_bytes = (int)((long)B * H * Wq * NC * Cin * 4);
     q.G = G; q.B = B; q.H = H; q.W = W; q.Wq = Wq; q.Cb = Cin / 32; q.N = Cout; q.act = act;
     q.stats_blocks = wino_stats_blocks(B, H, W, Cout, R);
+    q.pool = pool; q.gamma = (const long long*)bn_gamma_ptrs;
     return mrn_launch_wino_rows(q, stream);
   }
   ConvX3Params p;
@@ -1448,4 +1453,23 @@ MRN_EXPORT int mrn_conv2d_x3_wino_hl32(const void* v_hl, const void* u_hl, const
   magic_div(1u, p.kw_magic, p.kw_shift);
   if (R == 4) return launch_x3<2, 4, 2, 1, false, 3, 4>(p, (hipStream_t)stream);
   return launch_x3<2, 4, 2, 1, false, 3, 2>(p, (hipStream_t)stream);
+}
+
+MRN_EXPORT int mrn_conv2d_x3_wino_hl32(const void* v_hl, const void* u_hl, const void* zero_page, const float* bias, float* y,
+                                       float* stats, const float* out_scale, const float* x_scale, int G, int64_t v_group_stride_bytes,
+                                       int B, int H, int W, int Cin, int Cout, int R, int act, void* stream) {
+  return wino_conv_launch(v_hl, u_hl, zero_page, bias, y, stats, out_scale, x_scale, G, v_group_stride_bytes, B, H, W, Cin, Cout, R, act, 0,
+                          nullptr, stream);
+}
+
+// mrn_conv2d_x3_wino_hl32 with the 2x2 / stride-2 max-pool that follows BatchNorm + ReLU taken in the epilogue (row-block kernel only:
+// mrn_conv2d_x3_wino_rows(H, R, Cout) != 0, H and W even): y is [G][B][H/2][W/2][Cout] and holds, per window and channel, the maximum
+// of the raw output where the BatchNorm weight (bn_gamma_ptrs: device table of G device addresses; NULL: all maxima) is >= 0 and the
+// minimum where it is negative; the statistics cover the full map (see mrn_conv3x3_patch_x3_hl32).
+MRN_EXPORT int mrn_conv2d_x3_wino_pool_hl32(const void* v_hl, const void* u_hl, const void* zero_page, const float* bias, float* y,
+                                            float* stats, const float* out_scale, const float* x_scale, int G,
+                                            int64_t v_group_stride_bytes, int B, int H, int W, int Cin, int Cout, int R, int act,
+                                            const void* bn_gamma_ptrs, void* stream) {
+  return wino_conv_launch(v_hl, u_hl, zero_page, bias, y, stats, out_scale, x_scale, G, v_group_stride_bytes, B, H, W, Cin, Cout, R, act, 1,
+                          bn_gamma_ptrs, stream);
 }

@@ -202,7 +202,10 @@ class BackboneGroup(_GroupedLinear):
         # max-pool behind it is taken in ITS epilogue -- per window and channel the maximum where the BatchNorm weight is >= 0, the
         # minimum where it is negative (BatchNorm is monotone per channel) -- so the pass below runs on a quarter of the pixels
         use_patch = not use_wino and (x.hl is not None or x.f32 is not None) and ops.patch_conv_supported(ksize, stride, padding, Cin, Cout)
-        pooled = use_patch and pool == ((2, 2), (2, 2), (0, 0)) and Ho % 2 == 0 and Wo % 2 == 0
+        use_c4 = (not use_patch and not use_wino and Cin == 4 and ksize == (3, 3) and stride == (1, 1) and padding == (1, 1)
+                  and Cout in (32, 64) and x.f32 is not None)       # first conv of the stacks (csrc/conv_first.hip): pools the same way
+        pooled = ((use_patch or (use_c4 and ops.PATCH_CONV) or (use_wino and ops.wino_pool_supported(H, W, x.wino_R, Cout)))
+                  and pool == ((2, 2), (2, 2), (0, 0)) and Ho % 2 == 0 and Wo % 2 == 0)
         y = torch.empty(G, B, Ho // 2 if pooled else Ho, Wo // 2 if pooled else Wo, Cout, device=dev, dtype=torch.float32)
         if use_patch:
             if x.hl is None:
@@ -216,7 +219,10 @@ class BackboneGroup(_GroupedLinear):
         elif use_wino:
             u_hl, u_scale = self._weights_wino(convs, x.wino_R)
             _, stats = ops.conv2d_x3_wino(x.wino, G, x.shared, B, H, W, Cin, u_hl, u_scale, Cout, x.wino_R,
-                                          bias=self._bias_stack(convs), act=act, want_stats=training, out=y)
+                                          bias=self._bias_stack(convs), act=act, want_stats=training, out=y, pool=pooled,
+                                          gamma_ptrs=self._bn_table(bns)[0] if (pooled and bns is not None) else None)
+            if pooled:
+                pool = None
         elif Cin % 32 == 0 and Cout >= 64:
             if x.hl is None:
                 assert x.f32 is not None
@@ -224,11 +230,14 @@ class BackboneGroup(_GroupedLinear):
             w_hl, w_scale = self._weights_hl(convs)
             _, stats = ops.conv2d_x3(x.hl, G, x.shared, B, H, W, Cin, w_hl, w_scale, Cout, ksize, stride, padding,
                                      bias=self._bias_stack(convs), act=act, want_stats=training, out=y, products=ops.X3_PRODUCTS)
-        elif Cin == 4 and ksize == (3, 3) and stride == (1, 1) and padding == (1, 1) and Cout in (32, 64) and x.f32 is not None:
+        elif use_c4:
             # first conv of the stacks: one launch for all experts on the dedicated Cin = 4 kernel (csrc/conv_first.hip)
             w = self._cached("c4w%d" % id(c0), [c.weight for c in convs],
                              lambda: torch.stack([packed_weight(c).ohwi for c in convs]).contiguous())
-            _, stats = ops.conv3x3_c4_grouped(x.f32, w, self._bias_stack(convs), act=act, want_stats=training, out=y)
+            _, stats = ops.conv3x3_c4_grouped(x.f32, w, self._bias_stack(convs), act=act, want_stats=training, out=y, pool=pooled,
+                                              gamma_ptrs=self._bn_table(bns)[0] if bns is not None else None)
+            if pooled:
+                pool = None
         else:   # other small-Cin layers: exact-fp32 kernel per expert, written into the stack
             assert x.f32 is not None
             n = ops.call("mrn_conv2d_stats_floats", B, Ho, Wo, Cout) if training else 0

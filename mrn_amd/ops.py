@@ -663,11 +663,18 @@ def bn_apply_wino_grouped(y, scale, shift, R, relu=True, residual=None, residual
     return out, out_hl, v
 
 
+def wino_pool_supported(H, W, R, Cout):
+    """can the 2x2 / 2 max-pool behind this Winograd convolution be taken in its epilogue (row-block kernel, even map)"""
+    return PATCH_CONV and H % 2 == 0 and W % 2 == 0 and bool(call("mrn_conv2d_x3_wino_rows", H, R, Cout))
+
+
 def conv2d_x3_wino(v_hl, G, shared_input, B, H, W, Cin, u_hl, u_scale, Cout, R, bias=None, act=ACT_NONE, want_stats=False, out=None,
-                   x_scale=None):
-    """3x3 / stride 1 / pad 1 grouped conv on Winograd-domain operands -> (y [G,B,H,W,Cout] fp32, stats or None)"""
+                   x_scale=None, pool=False, gamma_ptrs=None):
+    """3x3 / stride 1 / pad 1 grouped conv on Winograd-domain operands -> (y [G,B,H,W,Cout] fp32, stats or None).
+    pool (wino_pool_supported): y is the [G,B,H/2,W/2,Cout] map of per-window extremes (maxima where the BatchNorm weight that follows is
+    >= 0 -- gamma_ptrs: int64 device tensor [G] of the weights' addresses, None: all maxima -- minima elsewhere), see conv3x3_patch_x3"""
     dev = v_hl.device
-    y = out if out is not None else torch.empty(G, B, H, W, Cout, device=dev, dtype=torch.float32)
+    y = out if out is not None else torch.empty(G, B, H // 2 if pool else H, W // 2 if pool else W, Cout, device=dev, dtype=torch.float32)
     stats = None
     if want_stats:
         stats = torch.empty(call("mrn_conv2d_x3_wino_stats_floats", G, B, H, W, Cout, R), device=dev, dtype=torch.float32)
@@ -675,9 +682,13 @@ def conv2d_x3_wino(v_hl, G, shared_input, B, H, W, Cin, u_hl, u_scale, Cout, R, 
     gstride = 0 if shared_input else B * H * Wq * (R + 2) * Cin * 4
     timed = CONV_TIMER is not None
     t0 = CONV_TIMER.begin("wino") if timed else None
-    call("mrn_conv2d_x3_wino_hl32", _p(v_hl), _p(u_hl), _p(_zero_page(dev)), _p(bias), _p(y), _p(stats), _p(u_scale), _p(x_scale), G, gstride,
-         B, H, W, Cin, Cout, R, act, _stream())
-    if WINO_CHECK and call("mrn_conv2d_x3_wino_rows", H, R, Cout):
+    if pool:
+        call("mrn_conv2d_x3_wino_pool_hl32", _p(v_hl), _p(u_hl), _p(_zero_page(dev)), _p(bias), _p(y), _p(stats), _p(u_scale), _p(x_scale), G,
+             gstride, B, H, W, Cin, Cout, R, act, _p(gamma_ptrs), _stream())
+    else:
+        call("mrn_conv2d_x3_wino_hl32", _p(v_hl), _p(u_hl), _p(_zero_page(dev)), _p(bias), _p(y), _p(stats), _p(u_scale), _p(x_scale), G,
+             gstride, B, H, W, Cin, Cout, R, act, _stream())
+    if WINO_CHECK and not pool and call("mrn_conv2d_x3_wino_rows", H, R, Cout):
         # debug (MRN_WINO_CHECK=1): the same call on the x3 kernel's Winograd form, compared element by element
         call("mrn_conv2d_x3_wino_select", 0)
         y2 = torch.empty_like(y)
@@ -856,21 +867,28 @@ def conv2d_x3_frozen(x, packed, bias, stride, padding, act=ACT_NONE, want_stats=
     return y[0], stats
 
 
-def conv3x3_c4_grouped(x, weights, bias=None, act=ACT_NONE, want_stats=False, out=None):
+def conv3x3_c4_grouped(x, weights, bias=None, act=ACT_NONE, want_stats=False, out=None, pool=False, gamma_ptrs=None):
     """First conv of G frozen experts (3x3, stride 1, padding 1, Cin = 4, Cout 32 / 64) in one launch.  x: [B,H,W,4] (shared by
-    all experts) or [G,B,H,W,4]; weights: [G,Cout,3,3,4] stack; bias [G,Cout] or None -> (y [G,B,H,W,Cout], stats or None)"""
+    all experts) or [G,B,H,W,4]; weights: [G,Cout,3,3,4] stack; bias [G,Cout] or None -> (y [G,B,H,W,Cout], stats or None).
+    pool: y is the [G,B,H/2,W/2,Cout] map of per-window extremes (maxima where the BatchNorm weight that follows is >= 0 -- gamma_ptrs:
+    int64 device tensor [G] of the weights' addresses, None: all maxima -- minima elsewhere), see conv3x3_patch_x3"""
     _chk(x, weights, bias)
     G, Cout = weights.shape[0], weights.shape[1]
     shared = x.dim() == 4
     B, H, W, C = x.shape[-4:]
     assert C == 4 and x.is_contiguous() and weights.is_contiguous() and tuple(weights.shape[2:]) == (3, 3, 4)
-    y = out if out is not None else torch.empty(G, B, H, W, Cout, device=x.device, dtype=torch.float32)
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    y = out if out is not None else torch.empty(G, B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
     stats = None
     if want_stats:
         nblk = call("mrn_conv3x3_c4_stats_blocks", B, H, W)
         stats = torch.empty(G, nblk, 2, Cout, device=x.device, dtype=torch.float32)
+    t0 = CONV_TIMER.begin() if CONV_TIMER is not None else None
     call("mrn_conv3x3_c4_grouped_f32", _p(x), _p(weights), _p(bias), _p(y), _p(stats), G, 0 if shared else B * H * W * 4, B, H, W,
-         Cout, act, _stream())
+         Cout, act, int(bool(pool)), _p(gamma_ptrs), _stream())
+    if t0 is not None:
+        CONV_TIMER.end(t0, 2.0 * G * B * H * W * Cout * 36, "hbm/conv_first" + ("_pool" if pool else ""),
+                       4.0 * ((1 if shared else G) * B * H * W * 4 + G * B * Ho * Wo * Cout))
     return y, stats
 
 

@@ -760,7 +760,7 @@ def test_svtr_attention_backward(ops, B, N, heads, H):
 
 
 @pytest.mark.parametrize("G,B,H,W,Cout,shared,act", [(3, 5, 32, 256, 32, False, 0), (2, 3, 32, 256, 64, True, 1), (1, 2, 7, 100, 64, True, 0),
-                                                     (2, 2, 5, 130, 32, False, 1)])
+                                                     (2, 2, 5, 130, 32, False, 1), (2, 2, 6, 130, 64, False, 0)])
 def test_first_conv_c4_grouped(ops, G, B, H, W, Cout, shared, act):
     """mrn_conv3x3_c4_grouped_f32 (first conv of the experts' stacks, Cin = 4) against torch conv2d: outputs, and the
     BatchNorm partial statistics summed over blocks against the pre-activation result; ragged widths included"""
@@ -776,6 +776,23 @@ def test_first_conv_c4_grouped(ops, G, B, H, W, Cout, shared, act):
         tot = stats[g].double().sum(0).cpu()
         assert_close("sum", tot[0].float(), pre.double().sum((0, 2, 3)).float(), atol=2e-2, rtol=1e-4)
         assert_close("sum of squares", tot[1].float(), (pre.double() ** 2).sum((0, 2, 3)).float(), atol=2e-2, rtol=1e-4)
+    if H % 2 or W % 2:
+        return
+    # pooled epilogue: BatchNorm-apply + ReLU on the map of per-window extremes (mixed-sign BatchNorm weights) equals, bit for bit, the
+    # 2 x 2 max-pool of BatchNorm-apply + ReLU on the full map; the statistics still cover the full map
+    y0, _ = ops.conv3x3_c4_grouped(cu(x), cu(w), cu(bias), act=0, want_stats=False)
+    gammas = [cu(rnd(Cout, seed=323 + g)) for g in range(G)]
+    ptrs = torch.tensor([t.data_ptr() for t in gammas], dtype=torch.int64, device="cuda")
+    bn_scale = torch.stack([t * (0.5 + 0.1 * g) for g, t in enumerate(gammas)]).contiguous()
+    bn_shift = cu(rnd(G, Cout, seed=329, scale=0.3))
+    yp, sp = ops.conv3x3_c4_grouped(cu(x), cu(w), cu(bias), act=0, want_stats=True, pool=True, gamma_ptrs=ptrs)
+    assert torch.equal(sp, stats)
+    got, _ = ops.bn_apply_grouped(yp.clone(), bn_scale, bn_shift, relu=True, want_f32=True, want_hl=False)
+    ref, _, _ = ops.maxpool_grouped(y0, (2, 2), (2, 2), (0, 0), bn_scale, bn_shift, relu=True, want_f32=True, want_hl=False)
+    assert torch.equal(got, ref)
+    ypr, _ = ops.conv3x3_c4_grouped(cu(x), cu(w), cu(bias), act=1, pool=True)            # (VGG: no BatchNorm behind the pool)
+    refr, _, _ = ops.maxpool_grouped(torch.relu(y0), (2, 2), (2, 2), (0, 0), None, None, relu=False, want_f32=True, want_hl=False)
+    assert torch.equal(ypr, refr)
 
 
 @pytest.mark.parametrize("G,B,H,W,Cin,Cout,shared", [(3, 3, 32, 256, 32, 64, False), (2, 2, 16, 128, 64, 128, False), (2, 5, 16, 64, 32, 64, True),
@@ -1013,6 +1030,18 @@ def test_winograd_conv_matches_direct(ops, cfg, R):
     # ReLU in the epilogue, no statistics
     y1, _ = ops.conv2d_x3_wino(v, G, False, B, H, W, Cin, u_hl, u_scale, Cout, R, bias=cu(bias), act=1)
     assert torch.equal(y1, y.clamp_min(0))
+    # the 2x2 / 2 max-pool behind BatchNorm + ReLU taken in the row-block kernel's epilogue (mrn_conv2d_x3_wino_pool_hl32): BatchNorm-apply +
+    # ReLU on the map of per-window extremes (mixed-sign BatchNorm weights) == max-pool of the applied full map, bit for bit; same statistics
+    if ops.wino_pool_supported(H, W, R, Cout):
+        gammas = [cu(rnd(Cout, seed=330 + g)) for g in range(G)]
+        ptrs = torch.tensor([t.data_ptr() for t in gammas], dtype=torch.int64, device="cuda")
+        bn_scale = torch.stack([t * (0.5 + 0.1 * g) for g, t in enumerate(gammas)]).contiguous()
+        bn_shift = cu(rnd(G, Cout, seed=339, scale=0.3))
+        yp, sp = ops.conv2d_x3_wino(v, G, False, B, H, W, Cin, u_hl, u_scale, Cout, R, bias=cu(bias), want_stats=True, pool=True, gamma_ptrs=ptrs)
+        assert torch.equal(sp, stats)
+        got, _ = ops.bn_apply_grouped(yp.clone(), bn_scale, bn_shift, relu=True, want_f32=True, want_hl=False)
+        ref, _, _ = ops.maxpool_grouped(y, (2, 2), (2, 2), (0, 0), bn_scale, bn_shift, relu=True, want_f32=True, want_hl=False)
+        assert torch.equal(got, ref)
 
 
 def test_winograd_full_size_dominant_shape_properties(ops):
