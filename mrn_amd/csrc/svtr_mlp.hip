@@ -17,7 +17,9 @@
 // tokens) share the weight slabs of a hidden block (W1: 32 rows x C, W2': C rows x 32) through a double-buffered LDS ring filled by
 // direct-to-LDS DMA; the weights of one expert (8 C^2 x 4 bytes: 128 KiB at C = 64, 512 KiB at C = 128) are re-read per 256 tokens from L2.
 // HBM traffic: the HL32 input once (4 B / element), the fp32 branch output once -- against 10 x that for fc1 and fc2 as two GEMMs.
-// C = 64 and 128 (SVTR stages 1 and 2): at C = 256 the token fragments (128 registers) and the output accumulators (128) do not fit.
+// C = 64 and 128 (SVTR stages 1 and 2): eight waves of 32 tokens, two per SIMD.  C = 256 (stage 3): the token fragments (128 registers)
+// and the output accumulators (128) need the 512-register form -- four waves, one per SIMD, 128 tokens per workgroup, 2 x 64 KiB of
+// slab ring (the round-4 pricing: fc1 + fc2 as two GEMMs 0.89 ms per block against ~0.5 here).
 #include "common.hpp"
 
 namespace {
@@ -44,8 +46,8 @@ __device__ __forceinline__ f32x16 mma(const u32x4 a, const u32x4 b, const f32x16
 }
 
 template <int C>
-__global__ __launch_bounds__(512) void svtr_mlp_kernel(const MlpParams p) {
-  constexpr int NW = 8, CB = C / 32, KB = C / 16, HID = 4 * C, NH = HID / 32, OC = C / 32;
+__global__ __launch_bounds__(C == 256 ? 256 : 512) void svtr_mlp_kernel(const MlpParams p) {
+  constexpr int NW = C == 256 ? 4 : 8, CB = C / 32, KB = C / 16, HID = 4 * C, NH = HID / 32, OC = C / 32;
   constexpr int W1_SLAB = CB * 32 * 128;            // 32 hidden rows x C channels, [channel block][row][128 B]
   constexpr int W2_SLAB = C * 128;                  // C output rows x one 32-hidden line
   constexpr int SLAB = W1_SLAB + W2_SLAB;
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(512) void svtr_mlp_kernel(const MlpParams p) {
   const int g = blockIdx.x / p.tiles_per_group, tile = blockIdx.x % p.tiles_per_group;
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int half = lane >> 5, tok_l = lane & 31;
-  const long row0 = (long)g * p.rows_per_group + (long)tile * 256 + wave * 32;
+  const long row0 = (long)g * p.rows_per_group + (long)tile * (NW * 32) + wave * 32;
   const long row_end = min((long)(g + 1) * p.rows_per_group, p.rows);
   const long row = row0 + tok_l;
   const bool ok = row < row_end;
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(512) void svtr_mlp_kernel(const MlpParams p) {
       xl[kb] = ok ? *reinterpret_cast<const u32x4*>(xr + off + 64) : u32x4{0u, 0u, 0u, 0u};
     }
   }
-  for (int i = t; i < HID; i += 512) b1_lds[i] = p.b1[(long)g * HID + i];
+  for (int i = t; i < HID; i += NW * 64) b1_lds[i] = p.b1[(long)g * HID + i];
 
   // ---- weight slabs through LDS: DMA instruction d (0 .. N1+N2-1) moves 8 rows x 128 B; lane -> row 8 d' + lane / 8, chunk lane & 7,
   // source chunk XOR-swizzled with (row >> 1) & 7 as in conv_x3.hip (conflict-free ds_read_b128 fragment reads)
@@ -192,7 +194,7 @@ int launch_mlp(const MlpParams& p, int G, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)svtr_mlp_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);
     attr_set = true;
   }
-  hipLaunchKernelGGL((svtr_mlp_kernel<C>), dim3((unsigned)(G * p.tiles_per_group)), dim3(512), ldsz, st, p);
+  hipLaunchKernelGGL((svtr_mlp_kernel<C>), dim3((unsigned)(G * p.tiles_per_group)), dim3(C == 256 ? 256 : 512), ldsz, st, p);
   MRN_LAUNCH_CHECK("svtr_mlp_x3");
   return MRN_OK;
 }
@@ -205,13 +207,13 @@ int launch_mlp(const MlpParams& p, int G, hipStream_t st) {
 //   w2_hl [G][C][4C/32][128 B]           fc2 weights packed from [C][1][4C] with the hidden index of every 32-block permuted:
 //                                        position p = 16 s + 8 h + j holds unit (j & 3) + 8 (2 s + (j >> 2)) + 4 h; s2, b2 [G][C]
 //   y     [rows][C] fp32
-// C = 64 or 128.
+// C = 64, 128 or 256.
 MRN_EXPORT int mrn_svtr_mlp_x3_f32(const void* x_hl, const void* w1_hl, const float* s1, const float* b1, const void* w2_hl,
                                    const float* s2, const float* b2, float* y, int64_t rows, int64_t rows_per_group, int G, int C,
                                    void* stream) {
   MRN_CHECK_ARG(x_hl && w1_hl && w2_hl && b1 && b2 && y && G >= 1 && rows_per_group >= 1 && rows <= (int64_t)G * rows_per_group,
                 "mrn_svtr_mlp_x3_f32: bad operands");
-  MRN_CHECK_ARG(C == 64 || C == 128, "mrn_svtr_mlp_x3_f32: C must be 64 or 128 (got %d)", C);
+  MRN_CHECK_ARG(C == 64 || C == 128 || C == 256, "mrn_svtr_mlp_x3_f32: C must be 64, 128 or 256 (got %d)", C);
   MRN_CHECK_ARG((uintptr_t)x_hl % 128 == 0 && (uintptr_t)w1_hl % 128 == 0 && (uintptr_t)w2_hl % 128 == 0 && (uintptr_t)y % 16 == 0,
                 "mrn_svtr_mlp_x3_f32: operands must be 128-byte (HL32) / 16-byte (y) aligned");
   if (rows == 0) return MRN_OK;
@@ -219,6 +221,8 @@ MRN_EXPORT int mrn_svtr_mlp_x3_f32(const void* x_hl, const void* w1_hl, const fl
   p.x_hl = (const unsigned char*)x_hl; p.w1 = (const unsigned char*)w1_hl; p.w2 = (const unsigned char*)w2_hl;
   p.b1 = b1; p.b2 = b2; p.s1 = s1; p.s2 = s2; p.y = y;
   p.rows = rows; p.rows_per_group = rows_per_group;
-  p.tiles_per_group = (int)((rows_per_group + 255) / 256);
+  const int tile_rows = C == 256 ? 128 : 256;
+  p.tiles_per_group = (int)((rows_per_group + tile_rows - 1) / tile_rows);
+  if (C == 256) return launch_mlp<256>(p, G, (hipStream_t)stream);
   return C == 64 ? launch_mlp<64>(p, G, (hipStream_t)stream) : launch_mlp<128>(p, G, (hipStream_t)stream);
 }

@@ -433,7 +433,7 @@ class BackboneGroup(_GroupedLinear):
             g2, b2 = self._ln_params(name + ".ln2", [b.norm2 for b in blks])
             x, _, y_hl = ops.add_layernorm_grouped(x, br.view(G * B, N, C), drop1, N, g2, b2, rows, b0.norm2.eps, want_sum=True)
         Ch = blks[0].mlp.fc1.out_features
-        if ops.SVTR_FUSED_MLP and C in (64, 128) and Ch == 4 * C and ops.X3_PRODUCTS == 3:
+        if ops.SVTR_FUSED_MLP and (C in (64, 128) or (C == 256 and ops.SVTR_FUSED_MLP256)) and Ch == 4 * C and ops.X3_PRODUCTS == 3:
             # fc1 -> GELU -> fc2 in one kernel: the 4C-wide hidden tensor stays in registers (csrc/svtr_mlp.hip)
             fc1s, fc2s = [b.mlp.fc1 for b in blks], [b.mlp.fc2 for b in blks]
 

@@ -2109,6 +2109,7 @@ def svtr_mlp_fused(x_hl, rows, rows_per_group, G, C, w1_hl, s1, b1, w2_hl, s2, b
     return y
 
 
+SVTR_FUSED_MLP256 = os.environ.get("MRN_SVTR_MLP256", "1") == "1"       # stage 3 (C = 256) on the fused Mlp kernel too (512-register form; A/B switch)
 SVTR_FUSED_MIXER = os.environ.get("MRN_SVTR_MIXER", "fused") == "fused"   # LN1 -> qkv -> attention -> proj -> +residual -> LN2 in one kernel
 
 

@@ -1094,7 +1094,7 @@ def test_maxpool_winograd_producer(ops, G, B, H, W, C, pool):
     assert torch.equal(f32, pf) and torch.equal(hl, ph) and torch.equal(v, v_ref)
 
 
-@pytest.mark.parametrize("C,G,rows_pg", [(64, 3, 700), (128, 2, 515), (64, 1, 256), (128, 6, 31)])
+@pytest.mark.parametrize("C,G,rows_pg", [(64, 3, 700), (128, 2, 515), (64, 1, 256), (128, 6, 31), (256, 2, 515), (256, 3, 128)])
 def test_svtr_fused_mlp_matches_two_gemms(ops, C, G, rows_pg):
     """mrn_svtr_mlp_x3_f32 (fc1 -> GELU -> fc2 of G experts in one kernel, hidden activation in registers, chained MFMAs on the
     transposed problem with the hidden-permuted fc2 weights) against torch float64 and against the two grouped x3 GEMMs it replaces"""
