@@ -448,6 +448,16 @@ int mrn_add_layernorm_grouped_f32(const float* x, const float* branch, const flo
  * [G][C][4C/32][128 B] (mrn_pack_weight_hl32), s1 / s2 [G][2] their prescales, b1 [G][4C], b2 [G][C]; y [rows][C] fp32.  C = 64 | 128. */
 int mrn_svtr_mlp_x3_f32(const void* x_hl, const void* w1_hl, const float* s1, const float* b1, const void* w2_hl, const float* s2,
                         const float* b2, float* y, int64_t rows, int64_t rows_per_group, int G, int C, void* stream);
+
+/* The second half of an SVTR stage-3 mixing block (C = 256; modules/svtr.py:196-204 from the attention context on) for the rows of G
+ * lock-step experts in one launch: x_res[r] += drop[r / rows_per_drop] * (ctx[r] Wproj^T + bproj) (drop NULL: 1, in place);
+ * branch[r] = fc2(GELU(fc1(LayerNorm(x_res[r]; gamma[g], beta[g], eps)))).  ctx_hl [rows][8][128 B] from
+ * mrn_svtr_attention_block_x3_f32; wproj_hl / sproj / bproj: proj packed by mrn_pack_weight_hl32; w1_hl as for mrn_svtr_mlp_x3_f32 but
+ * with fc1's INPUT channels permuted inside every 32-block like fc2's hidden units there; the rest as there. */
+int mrn_svtr_tail_x3_f32(const void* ctx_hl, float* x_res, const void* wproj_hl, const float* sproj, const float* bproj, const float* drop,
+                         int64_t rows_per_drop, const float* gamma, const float* beta, float eps, const void* w1_hl, const float* s1,
+                         const float* b1, const void* w2_hl, const float* s2, const float* b2, float* branch, int64_t rows,
+                         int64_t rows_per_group, int G, int C, void* stream);
 /* The attention half of an SVTR mixing block (modules/svtr.py:196-201 `x = x + drop_path(mixer(norm1(x)))`, Attention :90-152) of G
  * lock-step frozen experts in ONE kernel (group = image / imgs_per_group):
  *   t = x + drop_prev[img] * pending;  x_out = t + drop1[img] * proj(attention(qkv(LayerNorm1(t))));  y_hl = HL32(LayerNorm2(x_out))

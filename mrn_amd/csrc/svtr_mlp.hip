@@ -39,14 +39,31 @@ struct MlpParams {
   float* y;                       // [rows][C]
   long rows, rows_per_group;
   int tiles_per_group;
+  // TAIL form (C = 256): x_hl is the attention context; proj -> DropPath-scaled residual add -> LayerNorm2 run in front of fc1
+  const unsigned char* wp;        // [G][C][C/32][128 B] proj weights
+  const float* sp;                // [G][2]
+  const float* bp;                // [G][C]
+  const float* drop;              // [rows / rows_per_drop] DropPath multipliers of the attention branch, or null
+  const float* gamma;             // [G][C] LayerNorm2
+  const float* beta;              // [G][C]
+  float* x_res;                   // [rows][C] residual stream, updated in place: x += drop * proj(ctx)
+  long rows_per_drop;
+  float eps;
 };
 
 __device__ __forceinline__ f32x16 mma(const u32x4 a, const u32x4 b, const f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16v8*>(&a), *reinterpret_cast<const f16v8*>(&b), c, 0, 0, 0);
 }
 
-template <int C>
+// TAIL (C = 256 only): the second half of a stage-3 mixing block in one launch -- modules/svtr.py:196-204 from the attention context on:
+//   x <- x + drop * (ctx Wproj^T + bproj);  y = LayerNorm2(x);  branch = fc2(GELU(fc1(y)))
+// The proj product is one more link of the chain: A = Wproj rows from the slab ring, B = the context's token fragments; its result
+// lands as lane = token, register = channel, so the residual add and LayerNorm2 (sum over a lane's 128 registers + one cross-half
+// shuffle) happen in registers, and registers 8 s .. 8 s + 7 of a 32-channel block are again a valid B operand once fc1's INPUT
+// channels are permuted inside every 32-block the way fc2's hidden units are (a static repack of W1).
+template <int C, bool TAIL>
 __global__ __launch_bounds__(C == 256 ? 256 : 512) void svtr_mlp_kernel(const MlpParams p) {
+  static_assert(!TAIL || C == 256, "the tail form is the 512-register form");
   constexpr int NW = C == 256 ? 4 : 8, CB = C / 32, KB = C / 16, HID = 4 * C, NH = HID / 32, OC = C / 32;
   constexpr int W1_SLAB = CB * 32 * 128;            // 32 hidden rows x C channels, [channel block][row][128 B]
   constexpr int W2_SLAB = C * 128;                  // C output rows x one 32-hidden line
@@ -56,8 +73,12 @@ __global__ __launch_bounds__(C == 256 ? 256 : 512) void svtr_mlp_kernel(const Ml
   constexpr int NDMA = (N1 + N2) / NW;
   extern __shared__ __attribute__((aligned(128))) unsigned char lds[];
   float* b1_lds = reinterpret_cast<float*>(lds + 2 * SLAB);     // [HID]
+  float* ln_lds = b1_lds + HID;                                  // TAIL: [3][C] = LayerNorm2 gamma, beta, proj bias
 
-  const int g = blockIdx.x / p.tiles_per_group, tile = blockIdx.x % p.tiles_per_group;
+  // (block b runs on XCD b % 8: consecutive LOGICAL tiles share an XCD, so an XCD's L2 holds the 0.5 - 2 MB weights of one or two experts
+  // instead of all six -- the slabs are re-read from L2 by every workgroup)
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int g = lid / p.tiles_per_group, tile = lid % p.tiles_per_group;
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int half = lane >> 5, tok_l = lane & 31;
   const long row0 = (long)g * p.rows_per_group + (long)tile * (NW * 32) + wave * 32;
@@ -78,6 +99,13 @@ __global__ __launch_bounds__(C == 256 ? 256 : 512) void svtr_mlp_kernel(const Ml
     }
   }
   for (int i = t; i < HID; i += NW * 64) b1_lds[i] = p.b1[(long)g * HID + i];
+  if (TAIL) {
+    for (int i = t; i < C; i += NW * 64) {
+      ln_lds[i] = p.gamma[(long)g * C + i];
+      ln_lds[C + i] = p.beta[(long)g * C + i];
+      ln_lds[2 * C + i] = p.bp[(long)g * C + i];
+    }
+  }
 
   // ---- weight slabs through LDS: DMA instruction d (0 .. N1+N2-1) moves 8 rows x 128 B; lane -> row 8 d' + lane / 8, chunk lane & 7,
   // source chunk XOR-swizzled with (row >> 1) & 7 as in conv_x3.hip (conflict-free ds_read_b128 fragment reads)
@@ -115,7 +143,102 @@ __global__ __launch_bounds__(C == 256 ? 256 : 512) void svtr_mlp_kernel(const Ml
     for (int e = 0; e < 16; ++e) out[o][e] = 0.f;
   const float inv1 = p.s1 ? p.s1[g * 2 + 1] : 1.f, inv2 = p.s2 ? p.s2[g * 2 + 1] : 1.f;
 
-  issue(0, lds);
+  if (TAIL) {
+    // ---- proj: eight slabs of 32 output channels x C input channels through the W1 half of the ring (slab o -> buffer o & 1; the
+    // Mlp's first slab follows into buffer 0), then residual + LayerNorm2 in registers
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)(p.wp + (long)g * C * CB * 128), 0, C * CB * 128, 0x00020000);
+    auto issue_proj = [&](int o, unsigned char* buf) {
+#pragma unroll
+      for (int i = 0; i < N1 / NW; ++i) {
+        const int d = i * NW + wave;
+        const int cb = d / 4, r = (d % 4) * 8 + (lane >> 3);
+        const int coff = ((lane & 7) ^ ((r >> 1) & 7)) << 4;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (lds_ptr_t)(buf + d * 1024), 16, ((o * 32 + r) * CB + cb) * 128 + coff, 0, 0, 0);
+      }
+    };
+    static_assert(N1 % NW == 0, "proj slab DMA instructions divide over the waves");
+    const float invp = p.sp ? p.sp[g * 2 + 1] : 1.f;
+    issue_proj(0, lds);
+#pragma unroll
+    for (int o = 0; o < OC; ++o) {
+      __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));            // vmcnt(0)
+      __syncthreads();
+      const unsigned char* cur = lds + (o & 1) * SLAB;
+      if (o + 1 < OC) issue_proj(o + 1, lds + ((o + 1) & 1) * SLAB);
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        const unsigned char* blk = cur + (kb >> 1) * 4096;
+        const u32x4 wl = *reinterpret_cast<const u32x4*>(blk + foff[1][kb & 1]);
+        const u32x4 wh = *reinterpret_cast<const u32x4*>(blk + foff[0][kb & 1]);
+        acc = mma(wh, xl[kb], acc);
+        acc = mma(wl, xh[kb], acc);
+        acc = mma(wh, xh[kb], acc);
+      }
+      out[o] = acc;
+    }
+    // the Mlp's slab 0 into buffer 0 (OC even), flying under the residual add and LayerNorm2 below.  Behind a barrier of its own:
+    // issued under the last proj slab's reads (no barrier between) the last 32 channels came out wrong on the GPU, with every wait
+    // and barrier that orders the two buffers in place -- the arrangement that is correct by measurement is kept
+    __syncthreads();
+    issue(0, lds);
+    // x <- x + drop * (proj + bias): registers 4 k .. 4 k + 3 of block o are channels 32 o + 8 k + 4 half + 0 .. 3 of token lane & 31
+    const float ds = p.drop ? p.drop[(ok ? row : row0) / p.rows_per_drop] : 1.f;
+    float* xr_ = p.x_res + row * C;
+    float sum = 0.f;
+#pragma unroll
+    for (int o = 0; o < OC; ++o)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = o * 32 + 8 * k + 4 * half;
+        const f32x4 xv = ok ? *reinterpret_cast<const f32x4*>(xr_ + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 bpv = *reinterpret_cast<const f32x4*>(ln_lds + 2 * C + c);
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] = fmaf(ds, fmaf(out[o][4 * k + j], invp, bpv[j]), xv[j]);
+          out[o][4 * k + j] = v[j];
+          sum += v[j];
+        }
+        if (ok) *reinterpret_cast<f32x4*>(xr_ + c) = v;
+      }
+    // LayerNorm2 (the arithmetic of add_layernorm_grouped_kernel: mean, then the centred sum of squares)
+    sum += __shfl_xor(sum, 32);
+    const float mean = sum / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int o = 0; o < OC; ++o)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { const float d = out[o][e] - mean; q += d * d; }
+    q += __shfl_xor(q, 32);
+    const float rstd = 1.f / sqrtf(q / (float)C + p.eps);
+    // y -> fc1's B operand: k-block kb = 2 o + s holds registers 8 s .. 8 s + 7 of block o (fc1's input channels are packed in that order)
+#pragma unroll
+    for (int o = 0; o < OC; ++o)
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) {
+        f16v8 vh, vl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int e = s_ * 8 + j, c = o * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+          const float v = (out[o][e] - mean) * rstd * ln_lds[c] + ln_lds[C + c];
+          _Float16 a, b;
+          split_f16(v, a, b);
+          vh[j] = a;
+          vl[j] = b;
+        }
+        xh[2 * o + s_] = __builtin_bit_cast(u32x4, vh);
+        xl[2 * o + s_] = __builtin_bit_cast(u32x4, vl);
+      }
+#pragma unroll
+    for (int o = 0; o < OC; ++o)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) out[o][e] = 0.f;
+  } else {
+    issue(0, lds);
+  }
   for (int hs = 0; hs < NH; ++hs) {
     // own DMAs of slab hs retired -- spelled out: hipcc drops the vmcnt wait of __syncthreads() here (LDS-DMA is not a load it
     // orders behind the barrier; seen as stale slabs in 1 of ~10^4 workgroups at two workgroups per CU) -- then everyone's have, and
@@ -186,15 +309,15 @@ __global__ __launch_bounds__(C == 256 ? 256 : 512) void svtr_mlp_kernel(const Ml
   }
 }
 
-template <int C>
+template <int C, bool TAIL>
 int launch_mlp(const MlpParams& p, int G, hipStream_t st) {
-  constexpr size_t ldsz = 2 * ((C / 32) * 32 * 128 + C * 128) + 4 * C * sizeof(float);
+  constexpr size_t ldsz = 2 * ((C / 32) * 32 * 128 + C * 128) + 4 * C * sizeof(float) + (TAIL ? 3 * C * sizeof(float) : 0);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)svtr_mlp_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);
+    (void)hipFuncSetAttribute((const void*)svtr_mlp_kernel<C, TAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);
     attr_set = true;
   }
-  hipLaunchKernelGGL((svtr_mlp_kernel<C>), dim3((unsigned)(G * p.tiles_per_group)), dim3(C == 256 ? 256 : 512), ldsz, st, p);
+  hipLaunchKernelGGL((svtr_mlp_kernel<C, TAIL>), dim3((unsigned)(G * p.tiles_per_group)), dim3(C == 256 ? 256 : 512), ldsz, st, p);
   MRN_LAUNCH_CHECK("svtr_mlp_x3");
   return MRN_OK;
 }
@@ -223,6 +346,36 @@ MRN_EXPORT int mrn_svtr_mlp_x3_f32(const void* x_hl, const void* w1_hl, const fl
   p.rows = rows; p.rows_per_group = rows_per_group;
   const int tile_rows = C == 256 ? 128 : 256;
   p.tiles_per_group = (int)((rows_per_group + tile_rows - 1) / tile_rows);
-  if (C == 256) return launch_mlp<256>(p, G, (hipStream_t)stream);
-  return C == 64 ? launch_mlp<64>(p, G, (hipStream_t)stream) : launch_mlp<128>(p, G, (hipStream_t)stream);
+  p.wp = nullptr; p.sp = p.bp = p.drop = p.gamma = p.beta = nullptr; p.x_res = nullptr; p.rows_per_drop = 1; p.eps = 0.f;
+  if (C == 256) return launch_mlp<256, false>(p, G, (hipStream_t)stream);
+  return C == 64 ? launch_mlp<64, false>(p, G, (hipStream_t)stream) : launch_mlp<128, false>(p, G, (hipStream_t)stream);
+}
+
+// The second half of an SVTR stage-3 mixing block (C = 256) for the rows of G lock-step experts, one launch (modules/svtr.py:196-204):
+//   x_res[r] += drop[r / rows_per_drop] * (ctx[r] Wproj^T + bproj)        (drop NULL: 1)
+//   branch[r] = fc2(GELU(fc1(LayerNorm(x_res[r]; gamma, beta, eps))))
+// ctx_hl [rows][8][128 B]: the attention context (mrn_svtr_attention_block_x3_f32); wproj_hl [G][256][8][128 B] from mrn_pack_weight_hl32,
+// sproj / bproj its scale pair and bias; gamma, beta [G][256]; w1_hl as for mrn_svtr_mlp_x3_f32 but with fc1's INPUT channels permuted
+// inside every 32-block by the same permutation as fc2's hidden units (position p = 16 s + 8 h + j holds channel
+// (j & 3) + 8 (2 s + (j >> 2)) + 4 h); w2_hl, s1, b1, s2, b2 as there; branch [rows][256] fp32.
+MRN_EXPORT int mrn_svtr_tail_x3_f32(const void* ctx_hl, float* x_res, const void* wproj_hl, const float* sproj, const float* bproj,
+                                    const float* drop, int64_t rows_per_drop, const float* gamma, const float* beta, float eps,
+                                    const void* w1_hl, const float* s1, const float* b1, const void* w2_hl, const float* s2, const float* b2,
+                                    float* branch, int64_t rows, int64_t rows_per_group, int G, int C, void* stream) {
+  MRN_CHECK_ARG(ctx_hl && x_res && wproj_hl && bproj && gamma && beta && w1_hl && w2_hl && b1 && b2 && branch && G >= 1 &&
+                    rows_per_group >= 1 && rows <= (int64_t)G * rows_per_group && rows_per_drop >= 1,
+                "mrn_svtr_tail_x3_f32: bad operands");
+  MRN_CHECK_ARG(C == 256, "mrn_svtr_tail_x3_f32: C must be 256 (got %d)", C);
+  MRN_CHECK_ARG((uintptr_t)ctx_hl % 128 == 0 && (uintptr_t)wproj_hl % 128 == 0 && (uintptr_t)w1_hl % 128 == 0 && (uintptr_t)w2_hl % 128 == 0 &&
+                    (uintptr_t)branch % 16 == 0 && (uintptr_t)x_res % 16 == 0,
+                "mrn_svtr_tail_x3_f32: operands must be 128-byte (HL32) / 16-byte (fp32) aligned");
+  if (rows == 0) return MRN_OK;
+  MlpParams p;
+  p.x_hl = (const unsigned char*)ctx_hl; p.w1 = (const unsigned char*)w1_hl; p.w2 = (const unsigned char*)w2_hl;
+  p.b1 = b1; p.b2 = b2; p.s1 = s1; p.s2 = s2; p.y = branch;
+  p.rows = rows; p.rows_per_group = rows_per_group;
+  p.tiles_per_group = (int)((rows_per_group + 127) / 128);
+  p.wp = (const unsigned char*)wproj_hl; p.sp = sproj; p.bp = bproj; p.drop = drop; p.gamma = gamma; p.beta = beta; p.x_res = x_res;
+  p.rows_per_drop = rows_per_drop; p.eps = eps;
+  return launch_mlp<256, true>(p, G, (hipStream_t)stream);
 }

@@ -421,6 +421,26 @@ class BackboneGroup(_GroupedLinear):
                     return wq, sq, torch.stack([m.bias.detach() for m in qkvs]).contiguous() if qkvs[0].bias is not None else None
                 wq, sq, bq = self._cached(name + ".attnblk", [t_ for m in qkvs for t_ in (m.weight, m.bias) if t_ is not None], build_qkv)
                 x, ctx_hl = ops.svtr_attention_block_fused(x, br, dr, g1, b1, b0.norm1.eps, wq, sq, bq, mixer.mask, mixer.scale, B)
+                Ch = blks[0].mlp.fc1.out_features
+                if ops.SVTR_FUSED_TAIL and ops.SVTR_FUSED_MLP and C == 256 and Ch == 4 * C and ops.X3_PRODUCTS == 3:
+                    # ... and the rest of the block as ONE more launch: proj -> + residual -> LayerNorm2 -> fc1 -> GELU -> fc2 (csrc/svtr_mlp.hip TAIL)
+                    projs, fc1s, fc2s = [b.mixer.proj for b in blks], [b.mlp.fc1 for b in blks], [b.mlp.fc2 for b in blks]
+
+                    def build_tail():
+                        wp, sp = ops.pack_weights_hl32([m.weight.detach().contiguous().view(C, 1, 1, C) for m in projs])
+                        pin = ops.mlp_hidden_permutation(C, x.device)
+                        w1, s1 = ops.pack_weights_hl32([m.weight.detach().index_select(1, pin).contiguous().view(Ch, 1, 1, C) for m in fc1s])
+                        ph = ops.mlp_hidden_permutation(Ch, x.device)
+                        w2, s2 = ops.pack_weights_hl32([m.weight.detach().index_select(1, ph).contiguous().view(C, 1, 1, Ch) for m in fc2s])
+                        return (wp, sp, torch.stack([m.bias.detach() for m in projs]).contiguous(), w1, s1,
+                                torch.stack([m.bias.detach() for m in fc1s]).contiguous(), w2, s2,
+                                torch.stack([m.bias.detach() for m in fc2s]).contiguous())
+                    wp, sp, bp, w1, s1, b1_, w2, s2, b2_ = self._cached(name + ".tail", [t_ for m in projs + fc1s + fc2s for t_ in (m.weight, m.bias)],
+                                                                        build_tail)
+                    drop2 = self._drop_scales(blks, B, x.device)
+                    g2, b2 = self._ln_params(name + ".ln2", [b.norm2 for b in blks])
+                    br = ops.svtr_tail_fused(ctx_hl, x, G * rows, rows, G, C, wp, sp, bp, drop1, N, g2, b2, b0.norm2.eps, w1, s1, b1_, w2, s2, b2_)
+                    return x, (br.view(G * B, N, C), drop2)
             else:
                 t, _, y_hl = ops.add_layernorm_grouped(x, br, dr, N, g1, b1, rows, b0.norm1.eps, want_sum=br is not None)
                 x = t if t is not None else x

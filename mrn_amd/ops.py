@@ -2109,6 +2109,20 @@ def svtr_mlp_fused(x_hl, rows, rows_per_group, G, C, w1_hl, s1, b1, w2_hl, s2, b
     return y
 
 
+def svtr_tail_fused(ctx_hl, x_res, rows, rows_per_group, G, C, wp_hl, sp, bp, drop, rows_per_drop, g2, b2, eps2, w1_hl, s1, b1, w2_hl, s2, b2m):
+    """the second half of an SVTR stage-3 block in one launch (mrn_svtr_tail_x3_f32): x_res += drop * proj(ctx) IN PLACE, -> branch
+    [rows, C] = fc2(GELU(fc1(LayerNorm2(x_res)))); w1_hl packed from fc1's weights with the input channels permuted by
+    mlp_hidden_permutation(C), w2_hl from the hidden-permuted fc2 weights"""
+    br = torch.empty(rows, C, device=x_res.device, dtype=torch.float32)
+    t0 = CONV_TIMER.begin() if CONV_TIMER is not None else None
+    call("mrn_svtr_tail_x3_f32", _p(ctx_hl), _p(x_res), _p(wp_hl), _p(sp), _p(bp), _p(drop), rows_per_drop, _p(g2), _p(b2), float(eps2),
+         _p(w1_hl), _p(s1), _p(b1), _p(w2_hl), _p(s2), _p(b2m), _p(br), rows, rows_per_group, G, C, _stream())
+    if t0 is not None:
+        CONV_TIMER.end(t0, 2.0 * rows * C * C + 2.0 * 2 * rows * C * 4 * C, "fp16x3/svtrblock3", 4.0 * (4 * rows * C + G * 9 * C * C))
+    return br
+
+
+SVTR_FUSED_TAIL = os.environ.get("MRN_SVTR_TAIL", "1") == "1"           # stage 3: proj -> residual -> LayerNorm2 -> Mlp in one launch (A/B switch)
 SVTR_FUSED_MLP256 = os.environ.get("MRN_SVTR_MLP256", "1") == "1"       # stage 3 (C = 256) on the fused Mlp kernel too (512-register form; A/B switch)
 SVTR_FUSED_MIXER = os.environ.get("MRN_SVTR_MIXER", "fused") == "fused"   # LN1 -> qkv -> attention -> proj -> +residual -> LN2 in one kernel
 

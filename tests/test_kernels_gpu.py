@@ -1118,6 +1118,42 @@ def test_svtr_fused_mlp_matches_two_gemms(ops, C, G, rows_pg):
     assert_close("fused vs two GEMMs", y.view(G, rows_pg, C), y2.view(G, rows_pg, C), atol=2e-6, rtol=2e-6)
 
 
+@pytest.mark.parametrize("G,imgs_pg,N,with_drop", [(2, 3, 128, True), (3, 1, 100, False), (1, 5, 128, True)])
+def test_svtr_fused_tail_c256(ops, G, imgs_pg, N, with_drop):
+    """mrn_svtr_tail_x3_f32 (stage 3: proj -> DropPath-scaled residual add -> LayerNorm2 -> fc1 -> GELU -> fc2 of G experts in one launch;
+    the LayerNorm output becomes fc1's operand in registers through the input-channel permutation of W1) against torch float64: the
+    updated residual stream and the Mlp branch; ragged row counts (100 tokens per image: partial 128-token tiles)"""
+    C, Ch = 256, 1024
+    rows_pg = imgs_pg * N
+    rows = G * rows_pg
+    ctx = rnd(rows, C, seed=640) * 1.5
+    x = rnd(rows, C, seed=641) * 2
+    wp = [rnd(C, C, seed=642 + g, scale=(1.0 / C) ** 0.5) for g in range(G)]
+    w1 = [rnd(Ch, C, seed=650 + g, scale=(1.0 / C) ** 0.5) for g in range(G)]
+    w2 = [rnd(C, Ch, seed=660 + g, scale=(1.0 / Ch) ** 0.5) for g in range(G)]
+    bp, b1, b2 = rnd(G, C, seed=670) * 0.2, rnd(G, Ch, seed=671) * 0.2, rnd(G, C, seed=672) * 0.2
+    gam, bet = rnd(G, C, seed=673) * 0.3 + 1.0, rnd(G, C, seed=674) * 0.2
+    drop = (torch.tensor([0.0, 1.25] * ((G * imgs_pg + 1) // 2))[:G * imgs_pg]) if with_drop else None
+    eps = 1e-6
+    xd, cd = x.double().view(G, rows_pg, C), ctx.double().view(G, rows_pg, C)
+    xo, br = [], []
+    for g in range(G):
+        d = drop.double().view(G, imgs_pg)[g].repeat_interleave(N)[:, None] if with_drop else 1.0
+        t = xd[g] + d * (cd[g] @ wp[g].double().t() + bp[g].double())
+        y = F.layer_norm(t, (C,), gam[g].double(), bet[g].double(), eps)
+        xo.append(t)
+        br.append(F.gelu(y @ w1[g].double().t() + b1[g].double()) @ w2[g].double().t() + b2[g].double())
+    dev = torch.device("cuda")
+    wp_hl, sp = ops.pack_weights_hl32([cu(w).view(C, 1, 1, C).contiguous() for w in wp])
+    w1_hl, s1 = ops.pack_weights_hl32([cu(w).index_select(1, ops.mlp_hidden_permutation(C, dev)).contiguous().view(Ch, 1, 1, C) for w in w1])
+    w2_hl, s2 = ops.pack_weights_hl32([cu(w).index_select(1, ops.mlp_hidden_permutation(Ch, dev)).contiguous().view(C, 1, 1, Ch) for w in w2])
+    x_res = cu(x).clone()
+    got = ops.svtr_tail_fused(ops.split_hl32(cu(ctx)), x_res, rows, rows_pg, G, C, wp_hl, sp, cu(bp), cu(drop) if with_drop else None, N,
+                              cu(gam), cu(bet), eps, w1_hl, s1, cu(b1), w2_hl, s2, cu(b2))
+    assert_close("residual stream after proj", x_res.view(G, rows_pg, C), torch.stack(xo).float(), atol=2e-5, rtol=1e-5)
+    assert_close("Mlp branch of the fused tail", got.view(G, rows_pg, C), torch.stack(br).float(), atol=4e-5, rtol=2e-5)
+
+
 def test_svtr_fused_mlp_full_size_no_stale_slabs(ops):
     """mrn_svtr_mlp_x3_f32 at SVTR stage-1 size (two experts x 131072 tokens, C = 64: two workgroups per CU, 1024 of them), several
     launches against the two-GEMM path: every row must agree.  Pins the LDS-DMA ordering inside the kernel's slab ring -- hipcc drops
