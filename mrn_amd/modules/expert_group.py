@@ -172,8 +172,12 @@ class BackboneGroup(_GroupedLinear):
         res = residual.f32 if residual is not None else None
         res_hl = residual.hl if residual is not None and res is None else None
         use_wino = x.wino is not None and x.wino_R == self.wino_for(c0, bns)
+        # (an eval-mode layer with a 2x2 / 2 pool behind it that the patch-resident kernel takes runs there too: the pool in the conv
+        #  epilogue and the running-statistics affine on the pooled map beat the one-launch fold + a pooling pass over the full map)
+        patch_pool = (pool == ((2, 2), (2, 2), (0, 0)) and Ho % 2 == 0 and Wo % 2 == 0
+                      and ops.patch_conv_supported(ksize, stride, padding, Cin, Cout))
         if (EVAL_BN_FOLD and bns is not None and not training and Cin % 32 == 0 and Cout >= 64 and Cout % 32 == 0
-                and (want_hl or res_hl is None) and not use_wino and not want_wino):
+                and (want_hl or res_hl is None) and not use_wino and not want_wino and not patch_pool):
             # frozen experts in EVAL mode (DERNet's old extractors, LwF's previous network, validation): the BatchNorm is a fixed
             # per-channel affine, so conv -> BN -> (+ identity) -> ReLU -> operand split is ONE launch: the affine, the shortcut
             # and the activation run in the conv epilogue, which writes the HL32 operand of the next layer directly
