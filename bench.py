@@ -31,7 +31,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0                         # MI355X_MICROARCH.md: de
 HBM_PEAK_GBS = 8000.0                                  # MI355X_MICROARCH.md: HBM3E peak (6.3 TB/s achievable on a float4 copy)
 
 
-PMC_SOURCE = ("static: profiles/r04_pmc.json -- separate rocprofv3 --pmc passes of this same command (tools/pmc_pass.sh), "
+PMC_SOURCE = ("static: profiles/r05_pmc.json -- separate rocprofv3 --pmc passes of this same command (tools/pmc_pass.sh), "
               "FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE; counters cannot be read from inside the timed run")
 
 
@@ -39,7 +39,7 @@ def pmc_traffic(kernel_name, section="kernels"):
     """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes (profiles/r01_pmc.json, produced by
     tools/pmc_pass.sh on this same command): FETCH_SIZE x 2 (the gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE,
     both KiB counters.  None when the kernel has no entry (counters cannot be read from inside the timed run)."""
-    for name in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
+    for name in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             break
@@ -342,7 +342,10 @@ def roofline_entries(kinds, steps, elapsed_s, pmc_section="kernels"):
             gbs = s_["total_bytes"] / (s_["union_ms"] * 1e-3) / 1e9
             what = {"bn_apply_grouped": "BatchNorm-apply + residual + ReLU over all experts, fp32 in, HL32 split-fp16 operand out",
                     "bn_apply_wino_grouped": "BatchNorm-apply + residual + ReLU + Winograd input transform B^T over all experts, fp32 in, "
-                                             "transformed HL32 operand (6 components per 4 columns) [+ plain HL32] out"}.get(kind[4:], kind[4:])
+                                             "transformed HL32 operand (6 components per 4 columns) [+ plain HL32] out",
+                    "conv_first": "first 3x3 convolution of the stacks on the Cin = 4 crops, all experts, exact-fp32 MFMA, full map out",
+                    "conv_first_pool": "first 3x3 convolution of the stacks on the Cin = 4 crops, all experts, exact-fp32 MFMA, the 2x2 "
+                                       "max-pool taken in the epilogue by BatchNorm-weight sign: a quarter of the map out"}.get(kind[4:], kind[4:])
             hbm.append({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                         "traffic": pmc_traffic(kind[4:] + "_kernel", pmc_section), "kernel": f"{kind[4:]}_kernel ({what})",
                         "algorithmic_bytes_per_launch": s_["total_bytes"] / s_["launches"],

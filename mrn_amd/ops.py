@@ -79,6 +79,7 @@ SVTR_ATTENTION_X3 = os.environ.get("MRN_SVTR_ATTENTION_PRECISION", "fp16x3") == 
 # section 4 quote the runs.
 RECURRENT_X3 = os.environ.get("MRN_RECURRENT", "fp16x3") == "fp16x3"   # frozen experts' LSTM recurrences on the f16 MFMA
 ROUTER_WGRAD_X3 = os.environ.get("MRN_WGRAD", "fp16x3") == "fp16x3"     # weight-gradient GEMMs too (A/B switch)
+ROUTER_TOKEN_WGRAD_X3 = os.environ.get("MRN_TOKEN_WGRAD", "fp16x3") == "fp16x3"     # the token-mixing weight gradient of the DM-Router too (A/B switch)
 
 # Arithmetic of a frozen expert's convolutions OUTSIDE a lock-step group (a single network: validation() of a one-network learner,
 # LwF's previous network, ...; the lock-step groups of modules/expert_group.py always run the grouped split-fp16 x3 kernels):
