@@ -61,8 +61,30 @@ __device__ __forceinline__ f32x16 mma(const u32x4 a, const u32x4 b, const f32x16
 // lands as lane = token, register = channel, so the residual add and LayerNorm2 (sum over a lane's 128 registers + one cross-half
 // shuffle) happen in registers, and registers 8 s .. 8 s + 7 of a 32-channel block are again a valid B operand once fc1's INPUT
 // channels are permuted inside every 32-block the way fc2's hidden units are (a static repack of W1).
+#ifdef MRN_MPROBE_TIMING
+// timing probe (never in the product build; bash tools/build_probe.sh MRN_MPROBE_TIMING svtr_mlp.hip): per-wave shader-clock totals
+__device__ unsigned long long g_mlp_dbg[8];
+extern "C" __attribute__((visibility("default"))) int mrn_mlp_dbg_read(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mlp_dbg), sizeof(g_mlp_dbg)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mlp_dbg), z, sizeof(z));
+  }
+  return 0;
+}
+#define MTICK(var) const long var = __builtin_readcyclecounter()
+#define MADD(slot, a, b) dbg_acc[slot] += (b) - (a)
+#else
+#define MTICK(var)
+#define MADD(slot, a, b)
+#endif
+
 template <int C, bool TAIL>
 __global__ __launch_bounds__(C == 256 ? 256 : 512) void svtr_mlp_kernel(const MlpParams p) {
+#ifdef MRN_MPROBE_TIMING
+  long dbg_acc[6] = {0, 0, 0, 0, 0, 0};
+  const long dbg_t0 = __builtin_readcyclecounter();
+#endif
   static_assert(!TAIL || C == 256, "the tail form is the 512-register form");
   constexpr int NW = C == 256 ? 4 : 8, CB = C / 32, KB = C / 16, HID = 4 * C, NH = HID / 32, OC = C / 32;
   constexpr int W1_SLAB = CB * 32 * 128;            // 32 hidden rows x C channels, [channel block][row][128 B]
@@ -71,6 +93,7 @@ __global__ __launch_bounds__(C == 256 ? 256 : 512) void svtr_mlp_kernel(const Ml
   constexpr int N1 = W1_SLAB / 1024, N2 = W2_SLAB / 1024;        // 1-KiB DMA instructions per slab part
   static_assert((N1 + N2) % NW == 0, "slab DMA instructions divide over the waves");
   constexpr int NDMA = (N1 + N2) / NW;
+  constexpr bool SKEW = C == 256;                   // (the one-wave-per-SIMD form: see the main loop)
   extern __shared__ __attribute__((aligned(128))) unsigned char lds[];
   float* b1_lds = reinterpret_cast<float*>(lds + 2 * SLAB);     // [HID]
   float* ln_lds = b1_lds + HID;                                  // TAIL: [3][C] = LayerNorm2 gamma, beta, proj bias
@@ -111,23 +134,28 @@ __global__ __launch_bounds__(C == 256 ? 256 : 512) void svtr_mlp_kernel(const Ml
   // source chunk XOR-swizzled with (row >> 1) & 7 as in conv_x3.hip (conflict-free ds_read_b128 fragment reads)
   const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w1 + (long)g * HID * CB * 128), 0, HID * CB * 128, 0x00020000);
   const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w2 + (long)g * C * NH * 128), 0, C * NH * 128, 0x00020000);
-  auto issue = [&](int hs, unsigned char* buf) {
+  // W1 rows of hidden block h1 -> the W1 region of ring buffer h1 & 1, W2' columns of hidden block h2 -> the W2 region of buffer h2 & 1
+  // (either may be -1: nothing); the plain schedule moves both parts of one block, the skewed one (C = 256) W1 one block ahead of W2'
+  auto issue2 = [&](int h1, int h2) {
 #pragma unroll
     for (int i = 0; i < NDMA; ++i) {
       const int d = i * NW + wave;
-      if (d < N1) {                                 // W1: LDS [cb][32 rows]; source row = hs * 32 + r, line cb
+      if (d < N1) {                                 // W1: LDS [cb][32 rows]; source row = h1 * 32 + r, line cb
+        if (h1 < 0) continue;
         const int cb = d / 4, r = (d % 4) * 8 + (lane >> 3);
         const int coff = ((lane & 7) ^ ((r >> 1) & 7)) << 4;
-        const int voff = ((hs * 32 + r) * CB + cb) * 128 + coff;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_ptr_t)(buf + d * 1024), 16, voff, 0, 0, 0);
-      } else {                                      // W2': LDS [C rows]; source row r, line hs
+        const int voff = ((h1 * 32 + r) * CB + cb) * 128 + coff;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_ptr_t)(lds + (h1 & 1) * SLAB + d * 1024), 16, voff, 0, 0, 0);
+      } else {                                      // W2': LDS [C rows]; source row r, line h2
+        if (h2 < 0) continue;
         const int d2 = d - N1, r = d2 * 8 + (lane >> 3);
         const int coff = ((lane & 7) ^ ((r >> 1) & 7)) << 4;
-        const int voff = (r * NH + hs) * 128 + coff;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(r2, (lds_ptr_t)(buf + W1_SLAB + d2 * 1024), 16, voff, 0, 0, 0);
+        const int voff = (r * NH + h2) * 128 + coff;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r2, (lds_ptr_t)(lds + (h2 & 1) * SLAB + W1_SLAB + d2 * 1024), 16, voff, 0, 0, 0);
       }
     }
   };
+  auto issue = [&](int hs, unsigned char*) { issue2(hs, hs); };
   // fragment read offsets inside a 32-row block: row = lane & 31, logical chunk = plane * 4 + ks * 2 + half, swizzled
   const int key = (lane >> 1) & 7;
   int foff[2][2];
@@ -165,25 +193,31 @@ __global__ __launch_bounds__(C == 256 ? 256 : 512) void svtr_mlp_kernel(const Ml
       __syncthreads();
       const unsigned char* cur = lds + (o & 1) * SLAB;
       if (o + 1 < OC) issue_proj(o + 1, lds + ((o + 1) & 1) * SLAB);
-      f32x16 acc;
+      f32x16 acc, acc1;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+      for (int e = 0; e < 16; ++e) acc[e] = acc1[e] = 0.f;
 #pragma unroll
-      for (int kb = 0; kb < KB; ++kb) {
+      for (int kb = 0; kb < KB; kb += 2) {
         const unsigned char* blk = cur + (kb >> 1) * 4096;
-        const u32x4 wl = *reinterpret_cast<const u32x4*>(blk + foff[1][kb & 1]);
-        const u32x4 wh = *reinterpret_cast<const u32x4*>(blk + foff[0][kb & 1]);
-        acc = mma(wh, xl[kb], acc);
-        acc = mma(wl, xh[kb], acc);
-        acc = mma(wh, xh[kb], acc);
+        const u32x4 wl0 = *reinterpret_cast<const u32x4*>(blk + foff[1][0]), wh0 = *reinterpret_cast<const u32x4*>(blk + foff[0][0]);
+        const u32x4 wl1 = *reinterpret_cast<const u32x4*>(blk + foff[1][1]), wh1 = *reinterpret_cast<const u32x4*>(blk + foff[0][1]);
+        acc = mma(wh0, xl[kb], acc);
+        acc1 = mma(wh1, xl[kb + 1], acc1);
+        acc = mma(wl0, xh[kb], acc);
+        acc1 = mma(wl1, xh[kb + 1], acc1);
+        acc = mma(wh0, xh[kb], acc);
+        acc1 = mma(wh1, xh[kb + 1], acc1);
       }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] += acc1[e];
       out[o] = acc;
     }
     // the Mlp's slab 0 into buffer 0 (OC even), flying under the residual add and LayerNorm2 below.  Behind a barrier of its own:
     // issued under the last proj slab's reads (no barrier between) the last 32 channels came out wrong on the GPU, with every wait
     // and barrier that orders the two buffers in place -- the arrangement that is correct by measurement is kept
     __syncthreads();
-    issue(0, lds);
+    if (SKEW) issue2(0, -1);
+    else issue(0, lds);
     // x <- x + drop * (proj + bias): registers 4 k .. 4 k + 3 of block o are channels 32 o + 8 k + 4 half + 0 .. 3 of token lane & 31
     const float ds = p.drop ? p.drop[(ok ? row : row0) / p.rows_per_drop] : 1.f;
     float* xr_ = p.x_res + row * C;
@@ -237,31 +271,34 @@ __global__ __launch_bounds__(C == 256 ? 256 : 512) void svtr_mlp_kernel(const Ml
 #pragma unroll
       for (int e = 0; e < 16; ++e) out[o][e] = 0.f;
   } else {
-    issue(0, lds);
+    if (SKEW) issue2(0, -1);
+    else issue(0, lds);
   }
-  for (int hs = 0; hs < NH; ++hs) {
-    // own DMAs of slab hs retired -- spelled out: hipcc drops the vmcnt wait of __syncthreads() here (LDS-DMA is not a load it
-    // orders behind the barrier; seen as stale slabs in 1 of ~10^4 workgroups at two workgroups per CU) -- then everyone's have, and
-    // everyone is done with the other buffer
-    __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));              // vmcnt(0)
-    __syncthreads();
+  // fc1 of hidden block hs from its W1 slab; GELU + split of an fc1 result into fc2's B operand; fc2 of a hidden block from its W2' slab
+  // (a 32x32x16 MFMA that accumulates into the result of the one issued right before it waits for that result: ~64 cycles per MFMA
+  //  instead of 32 -- in-kernel clocks, 3249 cycles for the 48 chained MFMAs of fc1 at C = 256.  Two accumulators, alternating.)
+  auto fc1 = [&](int hs) {
     const unsigned char* cur = lds + (hs & 1) * SLAB;
-    if (hs + 1 < NH) issue(hs + 1, lds + ((hs + 1) & 1) * SLAB);
-    // ---- fc1 for 32 hidden units
-    f32x16 acc;
+    f32x16 acc0, acc1;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int e = 0; e < 16; ++e) acc0[e] = acc1[e] = 0.f;
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      const unsigned char* blk = cur + (kb >> 1) * 4096;
-      const u32x4 wl = *reinterpret_cast<const u32x4*>(blk + foff[1][kb & 1]);
-      const u32x4 wh = *reinterpret_cast<const u32x4*>(blk + foff[0][kb & 1]);
-      acc = mma(wh, xl[kb], acc);                   // (x_lo * w_hi, x_hi * w_lo, x_hi * w_hi: the order of conv_x3.hip)
-      acc = mma(wl, xh[kb], acc);
-      acc = mma(wh, xh[kb], acc);
+    for (int kb = 0; kb < KB; kb += 2) {
+      const unsigned char* blk = cur + (kb >> 1) * 4096;      // (kb and kb + 1: the two 16-channel halves of one channel block)
+      const u32x4 wl0 = *reinterpret_cast<const u32x4*>(blk + foff[1][0]), wh0 = *reinterpret_cast<const u32x4*>(blk + foff[0][0]);
+      const u32x4 wl1 = *reinterpret_cast<const u32x4*>(blk + foff[1][1]), wh1 = *reinterpret_cast<const u32x4*>(blk + foff[0][1]);
+      acc0 = mma(wh0, xl[kb], acc0);                // (x_lo * w_hi, x_hi * w_lo, x_hi * w_hi: the order of conv_x3.hip)
+      acc1 = mma(wh1, xl[kb + 1], acc1);
+      acc0 = mma(wl0, xh[kb], acc0);
+      acc1 = mma(wl1, xh[kb + 1], acc1);
+      acc0 = mma(wh0, xh[kb], acc0);
+      acc1 = mma(wh1, xh[kb + 1], acc1);
     }
-    // ---- bias, GELU, split: registers 8 s .. 8 s + 7 become the B operand of k half s of the second product
-    u32x4 hh[2], hl[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc0[e] += acc1[e];
+    return acc0;
+  };
+  auto gelu_split = [&](const f32x16& acc, int hs, u32x4 (&hh)[2], u32x4 (&hl)[2]) {
 #pragma unroll
     for (int s_ = 0; s_ < 2; ++s_) {
       f16v8 vh, vl;
@@ -278,20 +315,89 @@ __global__ __launch_bounds__(C == 256 ? 256 : 512) void svtr_mlp_kernel(const Ml
       hh[s_] = __builtin_bit_cast(u32x4, vh);
       hl[s_] = __builtin_bit_cast(u32x4, vl);
     }
-    // ---- fc2 partial sums over these 32 hidden units
-    const unsigned char* w2b = cur + W1_SLAB;
+  };
+  auto fc2 = [&](int hs, const u32x4 (&hh)[2], const u32x4 (&hl)[2]) {
+    const unsigned char* w2b = lds + (hs & 1) * SLAB + W1_SLAB;
 #pragma unroll
-    for (int o = 0; o < OC; ++o) {
+    for (int o = 0; o < OC; o += 2) {              // two output blocks at a time: consecutive MFMAs hit different accumulators
 #pragma unroll
       for (int s_ = 0; s_ < 2; ++s_) {
-        const u32x4 wl = *reinterpret_cast<const u32x4*>(w2b + o * 4096 + foff[1][s_]);
-        const u32x4 wh = *reinterpret_cast<const u32x4*>(w2b + o * 4096 + foff[0][s_]);
-        out[o] = mma(wh, hl[s_], out[o]);
-        out[o] = mma(wl, hh[s_], out[o]);
-        out[o] = mma(wh, hh[s_], out[o]);
+        const u32x4 wla = *reinterpret_cast<const u32x4*>(w2b + o * 4096 + foff[1][s_]);
+        const u32x4 wha = *reinterpret_cast<const u32x4*>(w2b + o * 4096 + foff[0][s_]);
+        const u32x4 wlb = *reinterpret_cast<const u32x4*>(w2b + (o + 1) * 4096 + foff[1][s_]);
+        const u32x4 whb = *reinterpret_cast<const u32x4*>(w2b + (o + 1) * 4096 + foff[0][s_]);
+        out[o] = mma(wha, hl[s_], out[o]);
+        out[o + 1] = mma(whb, hl[s_], out[o + 1]);
+        out[o] = mma(wla, hh[s_], out[o]);
+        out[o + 1] = mma(wlb, hh[s_], out[o + 1]);
+        out[o] = mma(wha, hh[s_], out[o]);
+        out[o + 1] = mma(whb, hh[s_], out[o + 1]);
       }
     }
+  };
+  if (SKEW) {
+    // One wave per SIMD (C = 256): the bias + GELU + split of a hidden block (~500 VALU operations) ran with the matrix pipe idle -- as
+    // long as fc1 or fc2 (in-kernel clocks).  Skewed schedule: iteration hs computes fc1(hs), then GELU(hs) INTERLEAVED with fc2(hs - 1),
+    // which needs W2' one block later than W1: the two halves of the ring are refilled one block apart (W1(hs + 1) and W2'(hs) at the
+    // top of iteration hs), same LDS.
+    u32x4 hh[2], hl[2], nh[2], nl[2];
+    __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));              // vmcnt(0): W1(0) has landed
+    __syncthreads();
+    issue2(1, 0);
+    gelu_split(fc1(0), 0, hh, hl);
+    for (int hs = 1; hs < NH; ++hs) {
+      __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));            // vmcnt(0): W1(hs) and W2'(hs - 1) have landed
+      __syncthreads();
+      issue2(hs + 1 < NH ? hs + 1 : -1, hs);
+      const f32x16 acc = fc1(hs);
+      __builtin_amdgcn_sched_barrier(0);
+      fc2(hs - 1, hh, hl);
+      gelu_split(acc, hs, nh, nl);
+#pragma unroll
+      for (int i = 0; i < 48; ++i) {               // one region: [1 MFMA of fc2(hs - 1), a dozen VALU operations of GELU(hs), a fragment read]
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      hh[0] = nh[0]; hh[1] = nh[1]; hl[0] = nl[0]; hl[1] = nl[1];
+    }
+    __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));
+    __syncthreads();
+    fc2(NH - 1, hh, hl);
+  } else
+  for (int hs = 0; hs < NH; ++hs) {
+    MTICK(tk0);
+    // own DMAs of slab hs retired -- spelled out: hipcc drops the vmcnt wait of __syncthreads() here (LDS-DMA is not a load it
+    // orders behind the barrier; seen as stale slabs in 1 of ~10^4 workgroups at two workgroups per CU) -- then everyone's have, and
+    // everyone is done with the other buffer
+    __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));              // vmcnt(0)
+    __syncthreads();
+    const unsigned char* cur = lds + (hs & 1) * SLAB;
+    MTICK(tk1);
+    MADD(0, tk0, tk1);                               // slab wait + barrier
+    if (hs + 1 < NH) issue(hs + 1, lds + ((hs + 1) & 1) * SLAB);
+    // ---- fc1 for 32 hidden units
+    const f32x16 acc = fc1(hs);
+    MTICK(tk2);
+    MADD(1, tk1, tk2);                               // slab issue + fc1
+    // ---- bias, GELU, split: registers 8 s .. 8 s + 7 become the B operand of k half s of the second product
+    u32x4 hh[2], hl[2];
+    gelu_split(acc, hs, hh, hl);
+    MTICK(tk3);
+    MADD(2, tk2, tk3);                               // bias + GELU + split
+    // ---- fc2 partial sums over these 32 hidden units
+    fc2(hs, hh, hl);
+    MTICK(tk4);
+    MADD(3, tk3, tk4);                               // fc2
   }
+#ifdef MRN_MPROBE_TIMING
+  if (lane == 0) {
+    dbg_acc[4] = __builtin_readcyclecounter() - dbg_t0;
+    for (int i = 0; i < 5; ++i) atomicAdd(&g_mlp_dbg[i], (unsigned long long)dbg_acc[i]);
+    atomicAdd(&g_mlp_dbg[5], 1ull);
+  }
+#endif
   // ---- epilogue: registers 4 k .. 4 k + 3 of an output block are channels 32 o + 8 k + 4 half + 0 .. 3 of token lane & 31
   if (ok) {
     float* yr = p.y + row * C;
