@@ -292,6 +292,9 @@ def describe_kernel(kind):
     if kind.startswith("gemm_f32"):
         return ("gemm_f32_kernel (exact-fp32 MFMA GEMM, v_mfma_f32_32x32x2_f32)", FP32_MFMA_PEAK_TFLOPS, 1)
     arith, staging = kind.split("/")
+    if arith == "f32mfma":
+        return (staging + " (first 3x3 convolution of the stacks on the Cin = 4 crops, all experts, v_mfma_f32_32x32x2_f32, the 2x2 max-pool taken "
+                          "in the epilogue by BatchNorm-weight sign: a quarter of the map out)", FP32_MFMA_PEAK_TFLOPS, 1)
     if staging.startswith("winorows"):
         R = int(staging[8])
         return (f"wino_rows_kernel (grouped 3x3 conv of all experts as 1-D Winograd F({R},3) along W, row-block form: a workgroup owns 64 "
@@ -313,9 +316,12 @@ def describe_kernel(kind):
                 f"all experts, {arith} on v_mfma_f32_32x32x16_f16, HL32 operands staged by buffer_load...lds)",
                 BF16_MFMA_PEAK_TFLOPS, nprod)
     if staging.startswith("patch"):
-        return ("conv_patch_x3_kernel (narrow early 3x3 layers of all experts, patch-resident and weight-stationary: weights in registers, "
+        cin = int(staging[5:7])
+        pooled = staging.endswith("pool")
+        return (f"conv_patch_x3_kernel<{cin // 32}, {cin // 16}, 2{', true' if pooled else ''}> ({cin} -> {2 * cin} channels: narrow early 3x3 layers of all "
+                "experts, patch-resident and weight-stationary: weights in registers, "
                 "activation patch staged once by buffer_load...lds, nine shifted ds_read_b128 views"
-                + (", 2x2 max-pool taken in the epilogue by BatchNorm-weight sign" if staging.endswith("pool") else "")
+                + (", 2x2 max-pool taken in the epilogue by BatchNorm-weight sign" if pooled else "")
                 + f", {arith} on v_mfma_f32_32x32x16_f16)", BF16_MFMA_PEAK_TFLOPS, 3)
     svtr = {"svtrmlp": "svtr_mlp_kernel (fc1 -> GELU -> fc2 of an SVTR mixing block over all experts, hidden activation in registers)",
             "svtrmixer": "svtr_mixer_kernel (LayerNorm1 -> qkv -> local / global attention -> proj -> residual -> LayerNorm2 of an SVTR mixing "
@@ -343,11 +349,12 @@ def roofline_entries(kinds, steps, elapsed_s, pmc_section="kernels"):
             what = {"bn_apply_grouped": "BatchNorm-apply + residual + ReLU over all experts, fp32 in, HL32 split-fp16 operand out",
                     "bn_apply_wino_grouped": "BatchNorm-apply + residual + ReLU + Winograd input transform B^T over all experts, fp32 in, "
                                              "transformed HL32 operand (6 components per 4 columns) [+ plain HL32] out",
-                    "conv_first": "first 3x3 convolution of the stacks on the Cin = 4 crops, all experts, exact-fp32 MFMA, full map out",
-                    "conv_first_pool": "first 3x3 convolution of the stacks on the Cin = 4 crops, all experts, exact-fp32 MFMA, the 2x2 "
-                                       "max-pool taken in the epilogue by BatchNorm-weight sign: a quarter of the map out"}.get(kind[4:], kind[4:])
+                    "conv_first_kernel": "first 3x3 convolution of the stacks on the Cin = 4 crops, all experts, exact-fp32 MFMA; <NT, true>: "
+                                         "the 2x2 max-pool taken in the epilogue by BatchNorm-weight sign, a quarter of the map out"
+                    }.get(kind[4:].split("<")[0], kind[4:])
+            kfull = kind[4:] if "_kernel" in kind else kind[4:] + "_kernel"
             hbm.append({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                        "traffic": pmc_traffic(kind[4:] + "_kernel", pmc_section), "kernel": f"{kind[4:]}_kernel ({what})",
+                        "traffic": pmc_traffic(kfull, pmc_section), "kernel": f"{kfull} ({what})",
                         "algorithmic_bytes_per_launch": s_["total_bytes"] / s_["launches"],
                         "launches_per_step": s_["launches"] / steps, "avg_launch_ms": s_["union_ms"] / s_["launches"],
                         "avg_launch_ms_raw_event": s_["total_ms"] / s_["launches"],

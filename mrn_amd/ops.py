@@ -888,7 +888,8 @@ def conv3x3_c4_grouped(x, weights, bias=None, act=ACT_NONE, want_stats=False, ou
     call("mrn_conv3x3_c4_grouped_f32", _p(x), _p(weights), _p(bias), _p(y), _p(stats), G, 0 if shared else B * H * W * 4, B, H, W,
          Cout, act, int(bool(pool)), _p(gamma_ptrs), _stream())
     if t0 is not None:
-        CONV_TIMER.end(t0, 2.0 * G * B * H * W * Cout * 36, "hbm/conv_first" + ("_pool" if pool else ""),
+        # (the full-map form is bound by its output write; the pooled form writes a quarter and is bound by the exact-fp32 MFMA)
+        CONV_TIMER.end(t0, 2.0 * G * B * H * W * Cout * 36, ("f32mfma/" if pool else "hbm/") + "conv_first_kernel<%d%s>" % (Cout // 32, ", true" if pool else ""),
                        4.0 * ((1 if shared else G) * B * H * W * 4 + G * B * Ho * Wo * Cout))
     return y, stats
 
@@ -919,7 +920,7 @@ def conv3x3_patch_x3(x_hl, G, shared_input, B, H, W, Cin, w_hl, w_scale, Cout, b
          0 if shared_input else B * H * W * Cin * 4, B, H, W, Cin, Cout, act, int(bool(pool)), _stream())
     if timed:
         nbytes = 4.0 * ((1 if shared_input else G) * B * H * W * Cin + G * Cout * 9 * Cin + G * B * Ho * Wo * Cout)
-        kind = "fp16x3/patch" + ("pool" if pool else "")
+        kind = "fp16x3/patch%d" % Cin + ("pool" if pool else "")
         if TIMER_SHAPES:
             kind += "|G%d B%d %dx%d %d->%d k3x3 s11" % (G, B, H, W, Cin, Cout)
         CONV_TIMER.end(t0, 2.0 * G * B * H * W * Cout * 9 * Cin, kind, nbytes)
