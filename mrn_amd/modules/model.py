@@ -25,6 +25,13 @@ from .sequence_modeling import BidirectionalLSTM
 from .transformation import TPS_SpatialTransformerNetwork
 
 
+
+# Loop B: the heads of the frozen experts (BiLSTM x 2 + attention decoder / CTC Linear: latency-bound launches of 64-192 workgroups,
+# 8 ms of a TRBA x 6 step) run on a stream of their own behind their backbones, so that the NEXT batch's backbones -- issued one step
+# ahead by experts_prefetch -- start as soon as this batch's backbones are done instead of queueing behind its recurrences.
+# MRN_HEADS_STREAM=0/1 is the A/B switch.
+HEADS_STREAM = os.environ.get("MRN_HEADS_STREAM", "1") == "1"
+
 class Model_Extractor(nn.Module):
     def __init__(self, opt):
         super().__init__()
@@ -452,21 +459,39 @@ class MRNNet(nn.Module):
             main = torch.cuda.current_stream()
             ready = torch.cuda.Event()
             ready.record(main)
-            streams = self._streams(len(halves), dev)
+            # the heads on a stream of their own (see HEADS_STREAM) when the experts run as ONE lock-step group (convolutional experts;
+            # measured, same box: CRNN x 3 11.23 -> 10.80 ms, TRBA x 6 unchanged -- the row-block kernel is power-bound and the
+            # recurrences take their CUs from it; SVTR's three sub-groups already interleave: 21.4 -> 21.9 with six streams, not split)
+            split = HEADS_STREAM and len(halves) == 1
+            streams = self._streams(len(halves) * (2 if split else 1), dev)
             # the router's [B,P,I,C] feature tensor is allocated ONCE (issuing stream's pool) and every sub-group writes its experts'
             # slice of it: no concatenation launch when the router phase adopts the outputs
             feats = torch.empty(B, self.patch, I, self.out_dim, device=dev, dtype=torch.float32)
             parts = []
-            for (lo, hi, bg, hg), st in zip(halves, streams):
+            for k, (lo, hi, bg, hg) in enumerate(halves):
+                st = streams[k]
+                sh = streams[len(halves) + k] if split else st
                 st.wait_event(ready)
                 with torch.cuda.stream(st):
+                    visual = bg.visual_all(img, as_act=True)
+                    if split:
+                        grown = torch.cuda.Event()
+                        grown.record(st)
+                if split:
+                    sh.wait_event(grown)
+                    for t in (visual.f32, visual.hl):
+                        if t is not None:
+                            t.record_stream(sh)          # (allocated in the backbone stream's pool, read by the heads' stream)
+                with torch.cuda.stream(sh):
                     lg = [ops.padded_rows(B, T_pred, e.fc.out_features, dev) for e in list(self.model)[lo:hi]]
-                    hg.run(bg.visual_all(img, as_act=True), text, feats[:, :, lo:hi, :], lg)
+                    hg.run(visual, text, feats[:, :, lo:hi, :], lg)
                     done = torch.cuda.Event()
-                    done.record(st)
+                    done.record(sh)
                 for t in (img, image, text, feats):
                     if t is not None:
                         t.record_stream(st)
+                        if split:
+                            t.record_stream(sh)
                 parts.append((lg, done))
             return {"parts": parts, "batch": B, "feats": feats}
 
