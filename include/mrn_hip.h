@@ -102,6 +102,12 @@ int mrn_split_hl32_t_f32(const float* x, void* out, int64_t rows, int64_t rows_p
 int mrn_im2col_t_hl32_f32(const float* x, void* out, int B, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw,
                           int64_t rows_padded, int splits, const float* scale, void* stream);
 int mrn_pack_weight_hl32(const float* w_ohwi, void* out, int Cout, int taps, int Cin, const float* scale, void* stream);
+/* The weight operands of ALL trained Linear layers for the coming step in one call (what `optimizer.step()` invalidates every iteration,
+ * il_modules/mrn.py:262; nn.Linear products of modules/svtr.py:46-152): desc = n x 8 int64 on the device {W fp32 [N][K], out, scale
+ * float[2], N, K, transposed, first_tile, tiles_i}; out = HL32 [O][I/32][128 B] of s * W (O = N, I = K) or s * W^T (O = K, I = N), s the
+ * power-of-two prescale of mrn_pow2_scale_f32 for `target`, written to scale; tiles = sum of ceil(O/32) * (I/32), first_tile its running
+ * sum; amax: n words of scratch.  N % 4 == 0, K % 4 == 0, I % 32 == 0. */
+int mrn_multi_pack_linear_hl32(const void* desc, int n, int64_t tiles, void* amax, float target, void* stream);
 /* Convolution weight gradient of a 3x3 / stride 1 / pad 1 conv WITHOUT an im2col (loss.backward() through Conv2d, il_modules/mrn.py:260-261):
  * mrn_transpose_oy_hl32_f32 writes x^T (or dy^T) as an HL32 matrix [C][ceil(B*H*W/32)][128 B] in image-row-major pixel order
  * k = (y*B + b)*W + xx, shifted by shift_x along x with zero fill -- in that order a kernel-row offset is a whole number of lines

@@ -1163,6 +1163,95 @@ MRN_EXPORT int mrn_pack_weight_hl32(const float* w_ohwi, void* out, int Cout, in
   return MRN_OK;
 }
 
+// Every trained Linear weight's operands for the coming step in ONE call (3 stream operations): the per-weight sequence max|W| ->
+// power-of-two prescale -> HL32 pack [-> the same for W^T, the data gradient's operand] was 6 launches per layer, ~310 per SVTR loop-A
+// step, issued by the host while the forward pass waited (a host-bound step: 1287 dispatches in 27 ms of host time).
+// desc: n x 8 int64 on the device {W (fp32 [N][K]), out, scale (float[2]), N, K, transposed, first_tile, tiles_i}: the operand is
+// L = W (O = N, I = K) or L = W^T (O = K, I = N), out [O][I/32][128 B] = HL32 of s * L, s = 2^floor(log2(target / max|W|)) exactly as
+// mrn_pow2_scale_f32 + mrn_pack_weight_hl32 produce it.  amax: n zeroed-by-this-call words.  One block = one 32 x 32 tile of L.
+namespace {
+struct MultiPackDesc { const float* w; unsigned char* out; float* scale; long N, K, transposed, first_tile, tiles_i; };
+
+__device__ __forceinline__ int multi_pack_find(const MultiPackDesc* __restrict__ d, int n, long tile) {
+  int lo = 0, hi = n - 1;                       // last descriptor with first_tile <= tile
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (d[mid].first_tile <= tile) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void multi_pack_amax_kernel(const MultiPackDesc* __restrict__ desc, int n, unsigned* __restrict__ amax) {
+  __shared__ float scratch[4];
+  const int di = multi_pack_find(desc, n, blockIdx.x);
+  const MultiPackDesc d = desc[di];
+  const long tl = blockIdx.x - d.first_tile;
+  const long to = tl / d.tiles_i, ti = tl - to * d.tiles_i;
+  // the tile of L as a 32 x 32 region of the SOURCE matrix [N][K]: rows = o (plain) or i (transposed), columns the other index
+  const long r0 = (d.transposed ? ti : to) * 32, c0 = (d.transposed ? to : ti) * 32;
+  const int r = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
+  float m = 0.f;
+  if (r0 + r < d.N && c0 + c4 < d.K) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(d.w + (r0 + r) * d.K + c0 + c4);
+    m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+  m = block_max<256>(m, scratch);
+  if (threadIdx.x == 0 && !(m <= 0.f)) atomicMax(amax + di, __float_as_uint(m));      // NaN / inf pass through
+}
+
+__global__ __launch_bounds__(256) void multi_pack_kernel(const MultiPackDesc* __restrict__ desc, int n, const unsigned* __restrict__ amax,
+                                                         float target) {
+  __shared__ float tile[32][33];
+  const int di = multi_pack_find(desc, n, blockIdx.x);
+  const MultiPackDesc d = desc[di];
+  const long tl = blockIdx.x - d.first_tile;
+  const long to = tl / d.tiles_i, ti = tl - to * d.tiles_i;
+  const float mm = __uint_as_float(amax[di]);
+  float sc = 1.f;
+  if (mm > 0.f && isfinite(mm)) sc = exp2f(floorf(log2f(target / mm)));
+  if (tl == 0 && threadIdx.x == 0) {
+    d.scale[0] = sc;
+    d.scale[1] = 1.f / sc;
+  }
+  const long O = d.transposed ? d.K : d.N, Cb = (d.transposed ? d.N : d.K) >> 5;
+  const int r = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (!d.transposed) {
+    if (to * 32 + r < O) v = *reinterpret_cast<const f32x4*>(d.w + (to * 32 + r) * d.K + ti * 32 + c4);
+    tile[r][c4 + 0] = v[0] * sc; tile[r][c4 + 1] = v[1] * sc; tile[r][c4 + 2] = v[2] * sc; tile[r][c4 + 3] = v[3] * sc;
+  } else {        // source row = i, source columns = o: lands transposed
+    if (to * 32 + c4 < O) v = *reinterpret_cast<const f32x4*>(d.w + (ti * 32 + r) * d.K + to * 32 + c4);
+    tile[c4 + 0][r] = v[0] * sc; tile[c4 + 1][r] = v[1] * sc; tile[c4 + 2][r] = v[2] * sc; tile[c4 + 3][r] = v[3] * sc;
+  }
+  __syncthreads();
+  const int o = threadIdx.x >> 3, seg = threadIdx.x & 7;          // row o of the tile, elements seg*4 .. +3 of its 32-channel line
+  if (to * 32 + o < O) {
+    typedef _Float16 f16v4 __attribute__((ext_vector_type(4)));
+    f16v4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      _Float16 hh, ll;
+      split_h(tile[o][seg * 4 + e], hh, ll);
+      h[e] = hh; l[e] = ll;
+    }
+    unsigned char* dst = d.out + ((to * 32 + o) * Cb + ti) * 128 + seg * 8;
+    *reinterpret_cast<f16v4*>(dst) = h;
+    *reinterpret_cast<f16v4*>(dst + 64) = l;
+  }
+}
+}  // namespace
+
+MRN_EXPORT int mrn_multi_pack_linear_hl32(const void* desc, int n, int64_t tiles, void* amax, float target, void* stream) {
+  MRN_CHECK_ARG(desc && amax && n > 0 && tiles > 0 && tiles < (1L << 31) && target > 0.f, "mrn_multi_pack_linear_hl32: bad operands (n=%d)", n);
+  const hipStream_t st = (hipStream_t)stream;
+  const hipError_t e = hipMemsetAsync(amax, 0, sizeof(unsigned) * (size_t)n, st);
+  MRN_CHECK_ARG(e == hipSuccess, "mrn_multi_pack_linear_hl32: memset failed (%s)", hipGetErrorString(e));
+  hipLaunchKernelGGL(multi_pack_amax_kernel, dim3((unsigned)tiles), dim3(256), 0, st, (const MultiPackDesc*)desc, n, (unsigned*)amax);
+  hipLaunchKernelGGL(multi_pack_kernel, dim3((unsigned)tiles), dim3(256), 0, st, (const MultiPackDesc*)desc, n, (const unsigned*)amax, target);
+  MRN_LAUNCH_CHECK("multi_pack_linear_hl32");
+  return MRN_OK;
+}
+
 // fp32 x[rows][C] (C % 4 == 0) -> `splits` transposed HL32 matrices [splits][C][rows_padded/splits/32][128 B] of scale[0] * x
 // (rows_padded % (32 * splits) == 0, rows beyond `rows` are zero): the operand layout of a weight-gradient GEMM that
 // reduces over rows, split-K = groups.

@@ -109,11 +109,10 @@ _POW2_WS = {}
 
 def _pow2_ws():
     """two zeroed words per (device, stream): the self-resetting workspace of mrn_pow2_scale_f32 (stream-ordered reuse)"""
-    st = torch.cuda.current_stream()
-    key = (st.device_index, st.cuda_stream)
+    key = _dev_stream()
     ws = _POW2_WS.get(key)
     if ws is None:
-        ws = torch.zeros(2, device=torch.device("cuda", st.device_index), dtype=torch.int32)
+        ws = torch.zeros(2, device=torch.device("cuda", key[0]), dtype=torch.int32)
         _POW2_WS[key] = ws
     return ws.data_ptr()
 
@@ -123,20 +122,19 @@ _AMAX_WS = {}
 
 def _amax_ws():
     """64 zeroed words per (device, stream): the slots producers fold per-block maxima into (mrn_pow2_finalize_f32 clears them)"""
-    st = torch.cuda.current_stream()
-    key = (st.device_index, st.cuda_stream)
+    key = _dev_stream()
     ws = _AMAX_WS.get(key)
     if ws is None:
-        ws = torch.zeros(64, device=torch.device("cuda", st.device_index), dtype=torch.int32)
+        ws = torch.zeros(64, device=torch.device("cuda", key[0]), dtype=torch.int32)
         _AMAX_WS[key] = ws
     return ws.data_ptr()
 
 
 def pow2_finalize(target):
     """{s, 1/s} from the maxima a producer just folded into this stream's 64 words (_amax_ws), which are put back to zero"""
-    st = torch.cuda.current_stream()
-    sc = torch.empty(2, device=torch.device("cuda", st.device_index), dtype=torch.float32)
-    call("mrn_pow2_finalize_f32", float(target), _p(sc), _amax_ws(), _stream())
+    dev, st = _dev_stream()
+    sc = torch.empty(2, device=torch.device("cuda", dev), dtype=torch.float32)
+    call("mrn_pow2_finalize_f32", float(target), _p(sc), _amax_ws(), st)
     return sc
 
 
@@ -171,8 +169,15 @@ class PackedConvWeight:
         return got
 
 
+def _dev_stream():
+    """(device index, raw handle of the current stream): two C calls -- torch.cuda.current_stream() builds a Stream object through five
+    Python frames, 4-8 us a call, ~1300 calls in a launch-bound SVTR loop-A step"""
+    dev = torch._C._cuda_getDevice()
+    return dev, torch._C._cuda_getCurrentRawStream(dev)
+
+
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def _p(t):
@@ -817,16 +822,73 @@ def prepack_trained():
             ev.record(side)
             for k, (val, src) in new.items():
                 _PREPACKED[k] = (val, ev, src)
+        batched = []                                            # Linear weights: all of them in one call (multi_pack_linear)
         for rk, (refs, build) in list(_PACK_REGISTRY.items()):
             ps = [r() for r in refs]
             if any(p_ is None or not p_.requires_grad for p_ in ps):
                 del _PACK_REGISTRY[rk]
+                continue
+            if MULTI_PACK and rk[0] in _MULTI_PACK_KINDS and multi_pack_eligible(ps[0], rk[0]):
+                batched.append((rk[0], ps[0]))
                 continue
             with torch.no_grad():
                 val = build(*ps)
             ev = torch.cuda.Event()
             ev.record(side)
             _PREPACKED[(rk[0],) + tuple((p_.data_ptr(), p_._version) for p_ in ps)] = (val, ev, ps)
+        if batched:
+            vals = multi_pack_linear(batched)
+            ev = torch.cuda.Event()
+            ev.record(side)
+            for (kind, p_), val in zip(batched, vals):
+                _PREPACKED[(kind, (p_.data_ptr(), p_._version))] = (val, ev, [p_])
+
+
+MULTI_PACK = os.environ.get("MRN_MULTI_PACK", "1") == "1"      # A/B switch: 0 = one max / pack launch sequence per Linear weight
+_MULTI_PACK_KINDS = {"lin_fwd_x3": 0, "lin_bwd_x3": 1}        # -> transposed flag (functional._pack_linear / _pack_linear_t)
+_MULTI_PACK_STATE = {}
+MULTI_PACK_STATS = {"calls": 0, "rebuilds": 0, "weights": 0}
+
+
+def multi_pack_eligible(p, kind):
+    if p.dim() != 2 or p.dtype != torch.float32 or not p.is_contiguous() or p.data_ptr() % 16:
+        return False
+    N, K = p.shape
+    return N % 4 == 0 and K % 4 == 0 and (N if _MULTI_PACK_KINDS[kind] else K) % 32 == 0
+
+
+def multi_pack_linear(entries):
+    """entries [(kind, weight [N,K])] -> [(HL32 operand bytes, scale [1,2])] exactly as pack_weights_hl32 builds them one by one
+    (kind lin_fwd_x3: of W; lin_bwd_x3: of W^T), in ONE library call on the current stream.  The operands live in one persistent
+    buffer per device that every call rewrites in stream order (the table of weights is rebuilt when the set of layers changes)."""
+    dev = entries[0][1].device
+    sig = tuple((kind, p.data_ptr(), tuple(p.shape)) for kind, p in entries)
+    st = _MULTI_PACK_STATE.get(dev)
+    if st is None or st["sig"] != sig:
+        n = len(entries)
+        offs, tiles, rows, total = [], 0, [], 0
+        for kind, p in entries:
+            N, K = p.shape
+            tr = _MULTI_PACK_KINDS[kind]
+            O, I = (K, N) if tr else (N, K)
+            offs.append(total)
+            rows.append([p.data_ptr(), 0, 0, N, K, tr, tiles, I // 32])
+            tiles += ((O + 31) // 32) * (I // 32)
+            total += (N * K * 4 + 255) // 256 * 256
+        out = torch.empty(total, device=dev, dtype=torch.uint8)
+        scale = torch.empty(n, 2, device=dev, dtype=torch.float32)
+        for i, row in enumerate(rows):
+            row[1], row[2] = out.data_ptr() + offs[i], scale.data_ptr() + 8 * i
+        desc = torch.tensor(rows, dtype=torch.int64).to(dev)
+        views = [(out[offs[i]:offs[i] + p.numel() * 4], scale[i:i + 1]) for i, (_, p) in enumerate(entries)]
+        st = {"sig": sig, "desc": desc, "out": out, "scale": scale, "amax": torch.zeros(n, device=dev, dtype=torch.int32),
+              "tiles": tiles, "views": views}
+        _MULTI_PACK_STATE[dev] = st
+        MULTI_PACK_STATS["rebuilds"] += 1
+    call("mrn_multi_pack_linear_hl32", st["desc"].data_ptr(), len(entries), st["tiles"], st["amax"].data_ptr(), FP16_WEIGHT_PEAK, _stream())
+    MULTI_PACK_STATS["calls"] += 1
+    MULTI_PACK_STATS["weights"] += len(entries)
+    return st["views"]
 
 
 def conv2d_x3_scaled(x, w_ohwi, bias, stride, padding, act=ACT_NONE, want_stats=False, sx=None):
@@ -932,8 +994,7 @@ _FINALIZE_TICKETS = {}
 
 def _finalize_tickets(device, slots):
     """zeroed 32-bit tickets per (device, stream) for the chunked BatchNorm finalize (the kernel's last workgroup resets its ticket)"""
-    st = torch.cuda.current_stream()
-    key = (st.device_index, st.cuda_stream)
+    key = _dev_stream()
     t = _FINALIZE_TICKETS.get(key)
     if t is None or t.numel() < slots:
         t = torch.zeros(max(slots, 1024), device=device, dtype=torch.int32)

@@ -1445,3 +1445,41 @@ def test_bn_finalize_grouped_chunked(ops, G, nblk, C):
     assert_close("shift", outs[0][1], (torch.stack(betas).double() - mean * sc).float(), atol=2e-6, rtol=2e-6)
     assert_close("running_mean", outs[0][2], (0.1 * mean).float(), atol=1e-6, rtol=2e-6)
     assert_close("running_var", outs[0][3], (0.9 + 0.1 * var * count / (count - 1)).float(), atol=1e-6, rtol=2e-6)
+
+
+def test_multi_pack_linear_matches_one_by_one(ops):
+    """every trained Linear weight's operand (and its transpose's) from ONE call == the per-weight max / scale / pack sequence, byte for
+    byte: ragged row counts, tiny and huge magnitudes, an all-zero weight (scale 1), a non-finite one (scale 1), a changed set of layers"""
+    shapes = [(192, 64), (64, 64), (256, 64), (100, 96), (68, 128), (1024, 256), (256, 1024), (512, 32), (36, 160)]
+    ws = []
+    for i, (N, K) in enumerate(shapes):
+        w = cu(rnd(N, K, seed=40 + i, scale=(1e-6, 1.0, 300.0)[i % 3]))
+        ws.append(w)
+    ws[3].zero_()
+    ws[4][5, 7] = float("inf")
+    entries = []
+    for w in ws:
+        N, K = w.shape
+        if K % 32 == 0:
+            entries.append(("lin_fwd_x3", w))
+        if N % 32 == 0:
+            entries.append(("lin_bwd_x3", w))
+    assert all(ops.multi_pack_eligible(w, kind) for kind, w in entries)
+    assert not ops.multi_pack_eligible(ws[3], "lin_bwd_x3") and not ops.multi_pack_eligible(ws[0][:, :32], "lin_fwd_x3")
+
+    def check(entries):
+        got = ops.multi_pack_linear(entries)
+        for (kind, w), (hl, sc) in zip(entries, got):
+            N, K = w.shape
+            src = w.t().contiguous().view(K, 1, 1, N) if kind == "lin_bwd_x3" else w.view(N, 1, 1, K)
+            ref_hl, ref_sc = ops.pack_weights_hl32([src])
+            assert torch.equal(sc, ref_sc), (kind, tuple(w.shape), sc, ref_sc)
+            assert torch.equal(hl, ref_hl), (kind, tuple(w.shape))
+    check(entries)
+    before = dict(ops.MULTI_PACK_STATS)
+    for w in ws[:3]:                           # new values, same table: no rebuild, results follow the weights
+        w.mul_(-3.7)
+    check(entries)
+    assert ops.MULTI_PACK_STATS["rebuilds"] == before["rebuilds"]
+    check(entries[3:])                         # another set of layers: the table is rebuilt
+    assert ops.MULTI_PACK_STATS["rebuilds"] == before["rebuilds"] + 1
