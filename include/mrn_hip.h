@@ -95,6 +95,13 @@ int mrn_split_hl32_f32(const float* x, void* out, int64_t rows, int C, const flo
  * i.e. `splits` HL32 matrices whose reduction axis is a row chunk (split-K = the conv's group dimension) */
 int mrn_split_hl32_t_f32(const float* x, void* out, int64_t rows, int64_t rows_padded, int C, int splits, const float* scale,
                          void* stream);
+/* mrn_split_hl32_t_f32 of dy that also leaves the bias gradient colsum[c] (+)= sum_r dy[r][c] of the Linear layer whose weight gradient the
+ * transposed operand feeds (loss.backward() through nn.Linear, il_modules/mrn.py:260-261; modules/svtr.py:46-152): partial =
+ * mrn_split_hl32_t_colsum_chunks(rows_padded, C) * C floats of scratch (<= 256 chunk rows, finished by one column-sum pass in a fixed
+ * order: deterministic). */
+int64_t mrn_split_hl32_t_colsum_chunks(int64_t rows_padded, int C);
+int mrn_split_hl32_t_colsum_f32(const float* x, void* out, int64_t rows, int64_t rows_padded, int C, int splits, const float* scale,
+                                float* colsum, int accumulate, float* partial, void* stream);
 /* transposed im2col for the convolution weight gradient (loss.backward() through Conv2d, il_modules/mrn.py:260-261):
  * out[s][tap][ci][rows_padded/splits/32][128 B], element (tap, ci, p) = scale * x[pixel(p) shifted by tap][ci] (0 in the
  * padding).  With mrn_split_hl32_t_f32(dy) as the other operand, dW = mrn_conv2d_x3_hl32 with groups = splits * taps and

@@ -711,6 +711,74 @@ __global__ __launch_bounds__(256) void split_hl32_t_kernel(const float* __restri
   }
 }
 
+// The same transposed split WITH the column sums of x (the bias gradient of a Linear layer is the column sum of the very dy this pass
+// transposes for the weight gradient: two more passes over dy, 100 launches and 2.5 ms of an SVTR loop-A step's weight-gradient stream).
+// grid (column tiles, chunks): a block keeps ONE 32-column tile and walks the 32-row blocks of its chunk four at a time (four 16-byte
+// loads in flight per lane); its column sums (of the scaled values: the scale is a power of two, so 1/s * sum(s x) == sum(x) in the
+// same order) go to partial[chunk][C] (one chunk: straight into colsum); a column-sum pass over those <= 256 rows finishes.  [Measured:
+// the finish inside this kernel -- last block to arrive per column tile, __threadfence() + ticket -- made it 8-15 x slower, 39 -> 324 us
+// at 131072 x 256: every block's agent-scope release writes back an L2 that 2048 blocks keep dirtying with 134 MB of operand lines.]
+__global__ __launch_bounds__(256) void split_hl32_t_colsum_kernel(const float* __restrict__ x, unsigned char* __restrict__ out, int C,
+                                                                  long rows, long rps32, long rblocks, long rb_per_chunk,
+                                                                  const float* __restrict__ scale, float* __restrict__ partial,
+                                                                  float* __restrict__ colsum, int accumulate) {
+  __shared__ float tile[4][32][33];
+  const float sc = scale ? scale[0] : 1.f, inv = scale ? scale[1] : 1.f;
+  const int t = threadIdx.x;
+  const int c0 = blockIdx.x * 32, chunk = blockIdx.y, nchunks = gridDim.y;
+  const long rb0 = chunk * rb_per_chunk, rb1 = min(rblocks, rb0 + rb_per_chunk);
+  const int r = t >> 3, c4 = (t & 7) * 4;          // load role: row r of a row block, columns c4 .. +3
+  const int c = t >> 3, seg = t & 7;               // store role: column c, rows seg*4 .. +3
+  float acc = 0.f;
+  for (long rb = rb0; rb < rb1; rb += 4) {
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const long row = (rb + u) * 32 + r;
+      if (rb + u < rb1 && c0 + c4 < C && row < rows) v[u] = *reinterpret_cast<const f32x4*>(x + row * C + c0 + c4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      tile[u][r][c4 + 0] = v[u][0] * sc; tile[u][r][c4 + 1] = v[u][1] * sc;
+      tile[u][r][c4 + 2] = v[u][2] * sc; tile[u][r][c4 + 3] = v[u][3] * sc;
+    }
+    __syncthreads();
+    if (c0 + c < C) {
+      typedef _Float16 f16v4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (rb + u >= rb1) break;
+        const long s_ = (rb + u) / rps32, rl = (rb + u) - s_ * rps32;
+        unsigned char* o = out + ((s_ * C + c0 + c) * rps32 + rl) * 128 + seg * 8;
+        f16v4 h, l;
+        float a = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float f = tile[u][seg * 4 + e][c];
+          _Float16 hh, ll;
+          split_h(f, hh, ll);
+          h[e] = hh; l[e] = ll;
+          a += f;
+        }
+        acc += a;
+        *reinterpret_cast<f16v4*>(o) = h;
+        *reinterpret_cast<f16v4*>(o + 64) = l;
+      }
+    }
+    __syncthreads();
+  }
+  acc += __shfl_xor(acc, 1);
+  acc += __shfl_xor(acc, 2);
+  acc += __shfl_xor(acc, 4);
+  acc *= inv;
+  if (nchunks == 1) {
+    if (seg == 0 && c0 + c < C) colsum[c0 + c] = accumulate ? colsum[c0 + c] + acc : acc;
+    return;
+  }
+  if (seg == 0 && c0 + c < C) partial[(long)chunk * C + c0 + c] = acc;
+}
+
 struct Im2colT {
   const float* x; unsigned char* out; const float* scale;
   int B, H, W, C, Ho, Wo, kw, taps, sh, sw, ph, pw;
@@ -1265,6 +1333,37 @@ MRN_EXPORT int mrn_split_hl32_t_f32(const float* x, void* out, int64_t rows, int
   hipLaunchKernelGGL(split_hl32_t_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, (unsigned char*)out, C,
                      (long)rows, (long)(rows_padded / splits / 32), tiles_c, ntiles, scale);
   MRN_LAUNCH_CHECK("split_hl32_t");
+  return MRN_OK;
+}
+
+// mrn_split_hl32_t_f32 that also leaves colsum[c] (+)= sum over rows of x[r][c].  partial: mrn_split_hl32_t_colsum_chunks(rows_padded, C) * C
+// floats of scratch (unused with one chunk).
+extern "C" int mrn_colsum_f32(const float* in, int64_t ld, float* out, float* workspace, int64_t rows, int C, int accumulate, void* stream);
+
+MRN_EXPORT int64_t mrn_split_hl32_t_colsum_chunks(int64_t rows_padded, int C) {
+  const long rblocks = rows_padded / 32, tiles_c = (C + 31) / 32;
+  long want = 4096 / (tiles_c < 1 ? 1 : tiles_c);
+  want = want < 1 ? 1 : (want > 256 ? 256 : want);
+  long per = (rblocks + want - 1) / want;
+  per = (per + 3) / 4 * 4;                             // (four row blocks per iteration)
+  const long chunks = per > 0 ? (rblocks + per - 1) / per : 1;
+  return chunks < 1 ? 1 : chunks;
+}
+
+MRN_EXPORT int mrn_split_hl32_t_colsum_f32(const float* x, void* out, int64_t rows, int64_t rows_padded, int C, int splits,
+                                           const float* scale, float* colsum, int accumulate, float* partial, void* stream) {
+  MRN_CHECK_ARG(x && out && colsum && splits >= 1 && C % 4 == 0 && rows_padded >= rows && rows_padded % (32L * splits) == 0,
+                "mrn_split_hl32_t_colsum_f32: bad operands (rows=%ld padded=%ld C=%d splits=%d)", (long)rows, (long)rows_padded, C, splits);
+  if (rows_padded == 0 || C == 0) return MRN_OK;
+  const long rblocks = rows_padded / 32, tiles_c = (C + 31) / 32;
+  const long chunks = mrn_split_hl32_t_colsum_chunks(rows_padded, C);
+  const long per = (((rblocks + chunks - 1) / chunks) + 3) / 4 * 4;
+  MRN_CHECK_ARG(chunks == 1 || partial, "mrn_split_hl32_t_colsum_f32: %ld chunks need the scratch rows", chunks);
+  MRN_CHECK_ARG(per * chunks >= rblocks && chunks <= 512, "mrn_split_hl32_t_colsum_f32: bad chunking (%ld x %ld < %ld)", per, chunks, rblocks);
+  hipLaunchKernelGGL(split_hl32_t_colsum_kernel, dim3((unsigned)tiles_c, (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, x,
+                     (unsigned char*)out, C, (long)rows, (long)(rows_padded / splits / 32), rblocks, per, scale, partial, colsum, accumulate);
+  MRN_LAUNCH_CHECK("split_hl32_t_colsum");
+  if (chunks > 1) return mrn_colsum_f32(partial, C, colsum, nullptr, chunks, C, accumulate, stream);     // (<= 512 rows: one pass)
   return MRN_OK;
 }
 

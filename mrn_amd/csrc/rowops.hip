@@ -672,14 +672,39 @@ static int colsum4_tx(int C) {      // column quads per block of the vectorised 
   return tx;
 }
 
-MRN_EXPORT int64_t mrn_colsum_chunks(int64_t rows, int C) {
-  // (sized for the vectorised kernel: column blocks of up to 1024 columns; the scalar fallback runs the same grid shape with more blocks)
-  const int64_t colblocks = (C + 1023) / 1024;
-  int64_t chunks = 2048 / colblocks;
-  const int ty = 256 / colsum4_tx(C);
-  const int64_t min_rows = 16L * ty;                 // at least 16 rows per row lane and chunk
+// column quads per block for a pass over `rows` rows that ends in ONE row of sums: as many row lanes (TY = 256 / TX, up to 64) as keep
+// 16 rows each -- a [2048][1024] second pass on one 256-quad block walked 2048 dependent rows per lane (190 us for a 134 MB bias gradient)
+static int colsum4_tx_final(long rows, int C) {
+  int ty = 1;
+  while (ty < 64 && ty * 16L < rows) ty *= 2;
+  const int tx = 256 / ty, need = colsum4_tx(C);
+  return tx < need ? tx : need;
+}
+
+// (chunks, TX of the first pass): few rows -> one pass; otherwise blocks of at most 256 columns with >= 4 row lanes, up to 256 chunks and
+// about 4096 blocks, and a second pass planned by colsum4_tx_final
+static void colsum_plan(long rows, int C, long& chunks, int& tx1) {
+  if (rows <= 512) {
+    chunks = 1;
+    tx1 = colsum4_tx_final(rows, C);
+    return;
+  }
+  tx1 = colsum4_tx(C);
+  if (tx1 > 64) tx1 = 64;
+  const int ty1 = 256 / tx1;
+  const long colblocks = ceil_div(C, tx1 * 4);
+  chunks = 4096 / colblocks;
+  chunks = chunks < 1 ? 1 : (chunks > 256 ? 256 : chunks);
+  const long min_rows = 16L * ty1;                    // at least 16 rows per row lane and chunk
   if (chunks > (rows + min_rows - 1) / min_rows) chunks = (rows + min_rows - 1) / min_rows;
-  return chunks < 1 ? 1 : chunks;
+  if (chunks < 1) chunks = 1;
+}
+
+MRN_EXPORT int64_t mrn_colsum_chunks(int64_t rows, int C) {
+  long chunks;
+  int tx1;
+  colsum_plan((long)rows, C, chunks, tx1);
+  return chunks;
 }
 
 template <int TX>
@@ -689,8 +714,9 @@ static void launch_colsum4(const float* in, long ld, float* out, long rows, int 
                      accumulate, direct);
 }
 
-static void colsum4(const float* in, long ld, float* out, long rows, int C, long rpc, long chunks, int accumulate, int direct, hipStream_t st) {
-  switch (colsum4_tx(C)) {
+static void colsum4(int tx, const float* in, long ld, float* out, long rows, int C, long rpc, long chunks, int accumulate, int direct,
+                    hipStream_t st) {
+  switch (tx) {
     case 4: launch_colsum4<4>(in, ld, out, rows, C, rpc, chunks, accumulate, direct, st); break;
     case 8: launch_colsum4<8>(in, ld, out, rows, C, rpc, chunks, accumulate, direct, st); break;
     case 16: launch_colsum4<16>(in, ld, out, rows, C, rpc, chunks, accumulate, direct, st); break;
@@ -706,17 +732,19 @@ MRN_EXPORT int mrn_colsum_f32(const float* in, int64_t ld, float* out, float* wo
                               int accumulate, void* stream) {
   MRN_CHECK_ARG(in && out, "mrn_colsum_f32: null operand");
   if (C == 0) return MRN_OK;
-  const long chunks = mrn_colsum_chunks(rows, C);
+  long chunks;
+  int tx1;
+  colsum_plan((long)rows, C, chunks, tx1);
   const int cb = ceil_div(C, 256);
   const hipStream_t st = (hipStream_t)stream;
   if (C % 4 == 0 && ld % 4 == 0 && (uintptr_t)in % 16 == 0 && (uintptr_t)out % 16 == 0 && (chunks == 1 || (uintptr_t)workspace % 16 == 0)) {
     if (chunks == 1) {
-      colsum4(in, (long)ld, out, (long)rows, C, (long)rows, 1, accumulate, 1, st);
+      colsum4(tx1, in, (long)ld, out, (long)rows, C, (long)rows, 1, accumulate, 1, st);
     } else {
       MRN_CHECK_ARG(workspace, "mrn_colsum_f32: workspace required for %ld chunks", chunks);
       const long rpc = (rows + chunks - 1) / chunks;
-      colsum4(in, (long)ld, workspace, (long)rows, C, rpc, chunks, 0, 0, st);
-      colsum4(workspace, (long)C, out, chunks, C, chunks, 1, accumulate, 1, st);
+      colsum4(tx1, in, (long)ld, workspace, (long)rows, C, rpc, chunks, 0, 0, st);
+      colsum4(colsum4_tx_final(chunks, C), workspace, (long)C, out, chunks, C, chunks, 1, accumulate, 1, st);
     }
     MRN_LAUNCH_CHECK("colsum");
     return MRN_OK;

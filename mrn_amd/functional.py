@@ -91,10 +91,11 @@ def _pick_split(R, tiles, target=1024, min_rows=128):
     return 1
 
 
-def x3_wgrad(dy2, x2, sd=None, sx=None, out=None):
+def x3_wgrad(dy2, x2, sd=None, sx=None, out=None, bias_out=None, bias_accumulate=False):
     """dW = dy2^T @ x2 on the split-fp16 x3 path: both operands transposed-split (reduction axis = rows) with device
     prescales; split-K chunks are the grouped conv's groups, partial slabs reduced by a column-sum pass (which ADDS into `out`
-    [N,K] when one is given and returns it)."""
+    [N,K] when one is given and returns it).  bias_out [N]: the pass that transposes dy also leaves its column sums (the bias
+    gradient) there, added when bias_accumulate."""
     R, N = dy2.shape
     K = x2.shape[1]
     blocks = R // 32
@@ -104,7 +105,7 @@ def x3_wgrad(dy2, x2, sd=None, sx=None, out=None):
     rps = R // S
     sd = ops.pow2_scale(dy2) if sd is None else sd
     sx = ops.pow2_scale(x2) if sx is None else sx
-    a_hl = ops.split_hl32_t(dy2, S, sd)                      # [S][N][rps/32][128]: "activation" rows = n
+    a_hl = ops.split_hl32_t(dy2, S, sd, colsum_out=bias_out, accumulate=bias_accumulate)     # [S][N][rps/32][128]: "activation" rows = n
     w_hl = ops.split_hl32_t(x2, S, sx)                       # [S][K][rps/32][128]: "weight" rows = k
     part, _ = ops.conv2d_x3(a_hl, S, False, N, 1, 1, rps, w_hl, sx.view(1, 2).expand(S, 2).contiguous(), K, (1, 1), x_scale=sd)
     part = part.view(S, N * K)
@@ -114,15 +115,22 @@ def x3_wgrad(dy2, x2, sd=None, sx=None, out=None):
     return (ops.colsum(part) if S > 1 else part[0]).view(N, K)
 
 
-def linear_wgrad(dy, x, sd=None, sx=None, out=None):
+def linear_wgrad(dy, x, sd=None, sx=None, out=None, bias_out=None, bias_accumulate=False):
     """dW[n][k] = sum_r dy[r][n] * x[r][k] with split-K over r (partials reduced by a column-sum pass; with `out` [N,K] -- a
-    parameter's gradient buffer -- that pass ADDS into it and `out` is returned: no separate accumulation launch)."""
+    parameter's gradient buffer -- that pass ADDS into it and `out` is returned: no separate accumulation launch).
+    bias_out [N]: also the bias gradient sum_r dy[r][n] (+= when bias_accumulate) -- out of the transposing pass over dy on the x3
+    path, a column-sum pass otherwise."""
     dy2, x2 = ops.rows2d(dy), ops.rows2d(x)
     R, N = dy2.shape
     K = x2.shape[1]
     if (ops.ROUTER_GEMM_PRECISION == "fp16x3" and ops.ROUTER_WGRAD_X3 and R % 32 == 0 and R >= 4096 and K >= 64 and N >= 64 and N % 4 == 0 and K % 4 == 0
             and dy2.is_contiguous() and x2.is_contiguous()):
-        return x3_wgrad(dy2, x2, sd, sx, out)
+        if bias_out is not None and not ops.SPLIT_T_COLSUM:
+            ops.colsum(dy2, out=bias_out, accumulate=bias_accumulate)
+            bias_out = None
+        return x3_wgrad(dy2, x2, sd, sx, out, bias_out, bias_accumulate)
+    if bias_out is not None:
+        ops.colsum(dy2, out=bias_out, accumulate=bias_accumulate)
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     S = _pick_split(R, tiles)
     Rc = R // S
@@ -910,9 +918,15 @@ class TrainLinearFn(torch.autograd.Function):
             if fold:        # half the range target: the consumer multiplies by gelu'(.) <= 1.13
                 ops.stash_operand(dx, None, ops.pow2_finalize(ops.FP16_WEIGHT_PEAK / 2), grad=True)
         need_w, need_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
-        dw, db = side_param_grads([ctx.params[0] if need_w else None, ctx.params[1] if need_b else None],
-                                  lambda o: (linear_wgrad(dy2, x.view(-1, x.shape[-1]), sd, sx, out=o[0]) if need_w else None,
-                                             ops.colsum(dy2, out=o[1], accumulate=True) if need_b else None), (dy2, x, sd, sx), into=True, gen=ctx.use_gen)
+        def grads(o):
+            if not need_w:
+                return None, (ops.colsum(dy2, out=o[1], accumulate=True) if need_b else None)
+            db = None
+            if need_b:         # the bias gradient rides on the weight gradient's pass over dy
+                db = o[1] if o[1] is not None else torch.empty(dy2.shape[1], device=dy2.device, dtype=torch.float32)
+            return linear_wgrad(dy2, x.view(-1, x.shape[-1]), sd, sx, out=o[0], bias_out=db, bias_accumulate=o[1] is not None), db
+        dw, db = side_param_grads([ctx.params[0] if need_w else None, ctx.params[1] if need_b else None], grads, (dy2, x, sd, sx), into=True,
+                                  gen=ctx.use_gen)
         return dx, dw, db, None, None
 
 

@@ -366,15 +366,26 @@ def split_hl32(x, scale=None):
     return out
 
 
-def split_hl32_t(x2, splits, scale=None, rows_padded=None):
+SPLIT_T_COLSUM = os.environ.get("MRN_SPLIT_T_COLSUM", "1") == "1"      # A/B switch: 0 = the bias gradient as its own column-sum passes
+
+
+def split_hl32_t(x2, splits, scale=None, rows_padded=None, colsum_out=None, accumulate=False):
     """fp32 [rows, C] -> `splits` transposed HL32 matrices [splits][C][rows_padded/splits/32][128 B] of scale[0] * x
-    (rows beyond x2's are zero)"""
+    (rows beyond x2's are zero).  colsum_out [C]: the same pass leaves the column sums of x there (added when `accumulate`): the bias
+    gradient of the Linear layer whose weight gradient this operand feeds"""
     _chk(x2)
     rows, C = x2.shape
     rows_padded = rows if rows_padded is None else rows_padded
     assert x2.is_contiguous() and rows_padded % (32 * splits) == 0
     out = torch.empty(rows_padded * C * 4, device=x2.device, dtype=torch.uint8)
-    call("mrn_split_hl32_t_f32", _p(x2), _p(out), rows, rows_padded, C, splits, _p(scale), _stream())
+    if colsum_out is None:
+        call("mrn_split_hl32_t_f32", _p(x2), _p(out), rows, rows_padded, C, splits, _p(scale), _stream())
+        return out
+    assert colsum_out.is_contiguous() and colsum_out.numel() == C and colsum_out.dtype == torch.float32
+    chunks = call("mrn_split_hl32_t_colsum_chunks", rows_padded, C)
+    part = torch.empty(chunks * C, device=x2.device, dtype=torch.float32) if chunks > 1 else None
+    call("mrn_split_hl32_t_colsum_f32", _p(x2), _p(out), rows, rows_padded, C, splits, _p(scale), _p(colsum_out), int(accumulate), _p(part),
+         _stream())
     return out
 
 

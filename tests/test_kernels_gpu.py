@@ -1483,3 +1483,28 @@ def test_multi_pack_linear_matches_one_by_one(ops):
     assert ops.MULTI_PACK_STATS["rebuilds"] == before["rebuilds"]
     check(entries[3:])                         # another set of layers: the table is rebuilt
     assert ops.MULTI_PACK_STATS["rebuilds"] == before["rebuilds"] + 1
+
+
+@pytest.mark.parametrize("rows,padded,C,S,mag", [(4096, 4096, 64, 8, 1.0), (8192, 8192, 384, 4, 1e-5), (1000, 1024, 100, 1, 300.0),
+                                                  (32, 32, 8, 1, 1.0), (65536, 65536, 64, 64, 1.0), (16384, 16384, 1024, 2, 1e-3)])
+def test_transposed_split_with_column_sums(ops, rows, padded, C, S, mag):
+    """the weight gradient's transposed operand of dy and the bias gradient from ONE pass: same bytes as the plain pass, column sums equal
+    to the fp64 sums to fp32 rounding, bit-identical across runs, `accumulate` adds"""
+    x = cu(rnd(rows, C, seed=5, scale=mag))
+    sc = ops.pow2_scale(x)
+    ref = ops.split_hl32_t(x, S, sc, rows_padded=padded)
+    out = torch.full((C,), 7.0, device="cuda")
+    got = ops.split_hl32_t(x, S, sc, rows_padded=padded, colsum_out=out)
+    assert torch.equal(got, ref)
+    want = x.double().sum(0)
+    err = (out.double() - want).abs().max().item()
+    assert err <= 2e-6 * mag * rows ** 0.5 + 1e-30, (err, mag)
+    out2 = out.clone()
+    again = ops.split_hl32_t(x, S, sc, rows_padded=padded, colsum_out=out2, accumulate=True)
+    assert torch.equal(again, ref) and torch.equal(out2, out + out)
+    out3 = torch.empty_like(out)
+    ops.split_hl32_t(x, S, sc, rows_padded=padded, colsum_out=out3)
+    assert torch.equal(out3, out)
+    unscaled = torch.empty_like(out)                       # no prescale: plain sums
+    assert torch.equal(ops.split_hl32_t(x, S, None, rows_padded=padded, colsum_out=unscaled), ops.split_hl32_t(x, S, None, rows_padded=padded))
+    assert (unscaled.double() - want).abs().max().item() <= 2e-6 * mag * rows ** 0.5 + 1e-30
