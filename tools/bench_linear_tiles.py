@@ -4,7 +4,7 @@ import torch
 sys.path.insert(0, ".")
 from mrn_amd import ops
 dev = torch.device("cuda:0")
-G = 3
+G = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 orig = ops.x3_tile
 for name, rows, K, N, act, hl in (("qkv s1", 131072, 64, 192, 0, False), ("proj s1", 131072, 64, 64, 0, False), ("fc1 s1", 131072, 64, 256, 2, True),
                                   ("fc2 s1", 131072, 256, 64, 0, False), ("qkv s2", 65536, 128, 384, 0, False), ("proj s2", 65536, 128, 128, 0, False),
