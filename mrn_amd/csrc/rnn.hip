@@ -224,7 +224,24 @@ struct LstmX3Group {
 __global__ __launch_bounds__(NTH) void lstm_layer_x3_kernel(const LstmX3Group grp) {
   __shared__ __attribute__((aligned(16))) _Float16 h_hi[2][BT * LDH];
   __shared__ __attribute__((aligned(16))) _Float16 h_lo[2][BT * LDH];
-  const int set = grp.pinned ? (int)(blockIdx.x % 8) + 8 * (int)((blockIdx.x / 8) / grp.tiles) : (int)blockIdx.x / grp.tiles;
+  // pinned: all tiles of a (expert, direction) set run on XCD (set % 8), whose L2 then holds that set's 1 MiB of W_hh.  pinned == 2: the
+  // nsets % 8 sets of the last, partly filled round are spread over ALL eight XCDs (12 sets: XCD x = set x + half of set 8 + x / 2, 24
+  // workgroups each, instead of 32 on XCDs 0-3 and 16 on 4-7 -- the step time follows the busiest L2)
+  int set, tile;
+  if (grp.pinned == 2) {
+    const int full = (grp.nsets / 8) * 8, r = grp.nsets - full, head = full * grp.tiles;
+    if ((int)blockIdx.x < head) {
+      set = (int)(blockIdx.x % 8) + 8 * (int)((blockIdx.x / 8) / grp.tiles);
+      tile = (int)((blockIdx.x / 8) % grp.tiles);
+    } else {
+      const int b2 = (int)blockIdx.x - head, xcd = b2 % 8, k = b2 / 8, share = 8 / r, per = grp.tiles / share;
+      set = full + xcd / share;
+      tile = (xcd % share) * per + k;
+    }
+  } else {
+    set = grp.pinned ? (int)(blockIdx.x % 8) + 8 * (int)((blockIdx.x / 8) / grp.tiles) : (int)blockIdx.x / grp.tiles;
+    tile = grp.pinned ? (int)((blockIdx.x / 8) % grp.tiles) : (int)blockIdx.x % grp.tiles;
+  }
   if (set >= grp.nsets) return;
   const int gi = set / grp.ndir;
   const float* __restrict__ xproj = grp.g[gi].xproj;
@@ -234,7 +251,7 @@ __global__ __launch_bounds__(NTH) void lstm_layer_x3_kernel(const LstmX3Group gr
   float* __restrict__ c_out = grp.g[gi].c_out;
   const int B = grp.B, T = grp.T, ndir = grp.ndir;
   const int dir = set - gi * grp.ndir;
-  const int b0 = (grp.pinned ? (int)((blockIdx.x / 8) % grp.tiles) : (int)blockIdx.x % grp.tiles) * BT;
+  const int b0 = tile * BT;
   const int t_ = threadIdx.x, lane = t_ & 63, wave = t_ >> 6;
   const unsigned char* W = grp.g[gi].w_hh + (long)dir * 4 * HID * HID * 4;     // hi + lo fp16 = 4 bytes per weight
   const float inv = grp.g[gi].w_inv[dir];
@@ -647,7 +664,13 @@ MRN_EXPORT int mrn_lstm_layer_fwd_x3_grouped(const void* const* xproj, const voi
     grp.tiles = ceil_div(B, BT); grp.B = B; grp.T = T; grp.ndir = ndir;
     grp.nsets = n * ndir;
     grp.pinned = grp.nsets > 2 && grp.tiles * ceil_div(grp.nsets, 8) <= 32;
-    const int blocks = grp.pinned ? 8 * ceil_div(grp.nsets, 8) * grp.tiles : grp.nsets * grp.tiles;
+    int blocks = grp.pinned ? 8 * ceil_div(grp.nsets, 8) * grp.tiles : grp.nsets * grp.tiles;
+    static const bool balance = !(getenv("MRN_LSTM_BALANCE") && atoi(getenv("MRN_LSTM_BALANCE")) == 0);     // (A/B switch, read once)
+    const int r = grp.nsets % 8;
+    if (grp.pinned && balance && grp.nsets > 8 && r > 0 && 8 % r == 0 && grp.tiles % (8 / r) == 0) {
+      grp.pinned = 2;
+      blocks = grp.nsets * grp.tiles;
+    }
     hipLaunchKernelGGL(lstm_layer_x3_kernel, dim3(blocks), dim3(NTH), 0, (hipStream_t)stream, grp);
     MRN_LAUNCH_CHECK("lstm_layer_x3");
   }

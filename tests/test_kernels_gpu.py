@@ -1508,3 +1508,22 @@ def test_transposed_split_with_column_sums(ops, rows, padded, C, S, mag):
     unscaled = torch.empty_like(out)                       # no prescale: plain sums
     assert torch.equal(ops.split_hl32_t(x, S, None, rows_padded=padded, colsum_out=unscaled), ops.split_hl32_t(x, S, None, rows_padded=padded))
     assert (unscaled.double() - want).abs().max().item() <= 2e-6 * mag * rows ** 0.5 + 1e-30
+
+
+def test_lstm_grouped_tail_sets_spread_over_all_xcds(ops):
+    """twelve (expert, direction) sets of 16 tiles (six experts, B = 256): the four sets of the partly filled second round are spread over
+    all eight XCDs (rnn.hip: pinned == 2) -- every (set, tile) is computed exactly once: the grouped launch equals the per-expert launches
+    bit for bit; also a shape the spread does not apply to (G = 5: ten sets, 8 % 2 == 0 but ...) and one it does (G = 5 -> r = 2)"""
+    Hd, T = 256, 7
+    for G, B in ((6, 256), (5, 256), (6, 250), (9, 64)):
+        xproj = cu(rnd(G, B, T, 8 * Hd, seed=300 + G, scale=0.7))
+        ws = [[cu(rnd(4 * Hd, Hd, seed=301 + 2 * g + d, scale=1 / 16.0)) for d in range(2)] for g in range(G)]
+        b_hh = cu(rnd(G, 8 * Hd, seed=350, scale=1 / 16.0))
+        packs = [[ops.pack_fragment_major_h(w) for w in p] for p in ws]
+        w_h = torch.stack([torch.stack([d[0] for d in p]) for p in packs]).contiguous()
+        w_inv = torch.stack([torch.cat([d[1] for d in p]) for p in packs]).contiguous()
+        out = ops.lstm_layer_x3_grouped(xproj, w_h, w_inv, b_hh, Hd, 2)
+        for g in range(G):
+            one = ops.lstm_layer_x3_grouped(xproj[g:g + 1].contiguous(), w_h[g:g + 1].contiguous(), w_inv[g:g + 1].contiguous(),
+                                            b_hh[g:g + 1].contiguous(), Hd, 2)
+            assert torch.equal(out[g], one[0]), (G, B, g)
