@@ -224,20 +224,16 @@ struct LstmX3Group {
 __global__ __launch_bounds__(NTH) void lstm_layer_x3_kernel(const LstmX3Group grp) {
   __shared__ __attribute__((aligned(16))) _Float16 h_hi[2][BT * LDH];
   __shared__ __attribute__((aligned(16))) _Float16 h_lo[2][BT * LDH];
-  // pinned: all tiles of a (expert, direction) set run on XCD (set % 8), whose L2 then holds that set's 1 MiB of W_hh.  pinned == 2: the
-  // nsets % 8 sets of the last, partly filled round are spread over ALL eight XCDs (12 sets: XCD x = set x + half of set 8 + x / 2, 24
-  // workgroups each, instead of 32 on XCDs 0-3 and 16 on 4-7 -- the step time follows the busiest L2)
+  // pinned == 1: all tiles of a (expert, direction) set run on XCD (set % 8), whose L2 then holds that set's 1 MiB of W_hh.
+  // pinned == 2: the (set, tile) pairs in set-major order are cut into eight equal runs, one per XCD (workgroup b runs on XCD b % 8): every
+  // L2 serves the same number of workgroups and at most two or three sets' weights.  The step time follows the number of workgroups
+  // streaming through one L2 (13.1 us at 4, 17.4 at 16, 21.9 at 32): 12 sets = 24 per XCD instead of 32 / 16, 6 sets = 12 instead of 16 / 0.
   int set, tile;
   if (grp.pinned == 2) {
-    const int full = (grp.nsets / 8) * 8, r = grp.nsets - full, head = full * grp.tiles;
-    if ((int)blockIdx.x < head) {
-      set = (int)(blockIdx.x % 8) + 8 * (int)((blockIdx.x / 8) / grp.tiles);
-      tile = (int)((blockIdx.x / 8) % grp.tiles);
-    } else {
-      const int b2 = (int)blockIdx.x - head, xcd = b2 % 8, k = b2 / 8, share = 8 / r, per = grp.tiles / share;
-      set = full + xcd / share;
-      tile = (xcd % share) * per + k;
-    }
+    const int per = grp.nsets * grp.tiles / 8;
+    const int pair = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);
+    set = pair / grp.tiles;
+    tile = pair - set * grp.tiles;
   } else {
     set = grp.pinned ? (int)(blockIdx.x % 8) + 8 * (int)((blockIdx.x / 8) / grp.tiles) : (int)blockIdx.x / grp.tiles;
     tile = grp.pinned ? (int)((blockIdx.x / 8) % grp.tiles) : (int)blockIdx.x % grp.tiles;
@@ -666,8 +662,7 @@ MRN_EXPORT int mrn_lstm_layer_fwd_x3_grouped(const void* const* xproj, const voi
     grp.pinned = grp.nsets > 2 && grp.tiles * ceil_div(grp.nsets, 8) <= 32;
     int blocks = grp.pinned ? 8 * ceil_div(grp.nsets, 8) * grp.tiles : grp.nsets * grp.tiles;
     static const bool balance = !(getenv("MRN_LSTM_BALANCE") && atoi(getenv("MRN_LSTM_BALANCE")) == 0);     // (A/B switch, read once)
-    const int r = grp.nsets % 8;
-    if (grp.pinned && balance && grp.nsets > 8 && r > 0 && 8 % r == 0 && grp.tiles % (8 / r) == 0) {
+    if (balance && grp.nsets > 2 && (grp.nsets * grp.tiles) % 8 == 0 && grp.nsets * grp.tiles <= 256) {
       grp.pinned = 2;
       blocks = grp.nsets * grp.tiles;
     }

@@ -1511,9 +1511,9 @@ def test_transposed_split_with_column_sums(ops, rows, padded, C, S, mag):
 
 
 def test_lstm_grouped_tail_sets_spread_over_all_xcds(ops):
-    """twelve (expert, direction) sets of 16 tiles (six experts, B = 256): the four sets of the partly filled second round are spread over
-    all eight XCDs (rnn.hip: pinned == 2) -- every (set, tile) is computed exactly once: the grouped launch equals the per-expert launches
-    bit for bit; also a shape the spread does not apply to (G = 5: ten sets, 8 % 2 == 0 but ...) and one it does (G = 5 -> r = 2)"""
+    """the (expert, direction, tile) workgroups of a grouped layer are dealt to the eight XCDs in equal set-major runs (rnn.hip: pinned == 2;
+    twelve sets of 16 tiles = 24 per XCD) -- every (set, tile) is computed exactly once: the grouped launch equals the per-expert launches
+    bit for bit, also with a ragged last tile (B = 250), ten sets, and eighteen sets of four tiles"""
     Hd, T = 256, 7
     for G, B in ((6, 256), (5, 256), (6, 250), (9, 64)):
         xproj = cu(rnd(G, B, T, 8 * Hd, seed=300 + G, scale=0.7))
