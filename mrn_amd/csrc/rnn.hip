@@ -349,8 +349,18 @@ struct AttnDecGroup {
 template <bool X3>
 __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecGroup grp) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  // one expert's recurrent weights (2.3 MiB) stay in one XCD's L2: all tiles of a group run on XCD (group % 8)
-  const int gi = grp.pinned ? (int)(blockIdx.x % 8) + 8 * (int)((blockIdx.x / 8) / grp.tiles) : (int)blockIdx.x / grp.tiles;
+  // pinned == 1: one expert's recurrent weights (2.3 MiB) stay in one XCD's L2, all tiles of a group run on XCD (group % 8); pinned == 2
+  // (six experts: 24 workgroups on every XCD instead of 32 on six of them; two experts' weights per L2 at most)
+  int gi, tile_;
+  if (grp.pinned == 2) {          // equal group-major runs of (group, tile) pairs per XCD: see lstm_layer_x3_kernel
+    const int per = grp.groups * grp.tiles / 8;
+    const int pair = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);
+    gi = pair / grp.tiles;
+    tile_ = pair - gi * grp.tiles;
+  } else {
+    gi = grp.pinned ? (int)(blockIdx.x % 8) + 8 * (int)((blockIdx.x / 8) / grp.tiles) : (int)blockIdx.x / grp.tiles;
+    tile_ = grp.pinned ? (int)((blockIdx.x / 8) % grp.tiles) : (int)blockIdx.x % grp.tiles;
+  }
   if (gi >= grp.groups) return;
   const AttnDecParams p = grp.g[gi];
   const int D = p.D, T = p.T;
@@ -371,7 +381,7 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecGroup gr
   // re-reads the workgroup's Hproj / Hb slices (66 KB per sample each), so more, smaller workgroups shorten the step);
   // rows >= vb of the 16-row MFMA tile are treated like rows beyond the batch
   const int vb = grp.vb;
-  const int b0 = (grp.pinned ? (int)((blockIdx.x / 8) % grp.tiles) : (int)blockIdx.x % grp.tiles) * vb;
+  const int b0 = tile_ * vb;
   const int Bend = min(p.B, b0 + vb);
   const int t_ = threadIdx.x, lane = t_ & 63, wave = t_ >> 6;
   const int col = lane & 15, rbase = (lane >> 4) * 4;
@@ -713,11 +723,13 @@ static int attn_launch(AttnDecGroup& grp, int groups, int D, int T, hipStream_t 
   if (forced_vb == 1 || forced_vb == 2 || forced_vb == 4 || forced_vb == 8 || forced_vb == 16) grp.vb = forced_vb;
   grp.tiles = ceil_div(B, grp.vb);
   grp.pinned = groups > 1 && grp.tiles * ceil_div(groups, 8) <= 32;
+  static const bool balance = !(getenv("MRN_ATTN_BALANCE") && atoi(getenv("MRN_ATTN_BALANCE")) == 0);     // (A/B switch, read once)
+  if (balance && groups > 1 && (groups * grp.tiles) % 8 == 0 && groups * grp.tiles <= 256) grp.pinned = 2;
   const bool x3 = grp.g[0].w_inv != nullptr;
   const size_t lds = sizeof(float) * (2 * BT * HLD + BT * (D + 4) + BT * T + HID) + (x3 ? 1024 : 0);
   MRN_CHECK_ARG(lds <= 160 * 1024, "mrn_attn_decoder_fwd: LDS budget exceeded (D=%d T=%d)", D, T);
   MRN_CHECK_ARG(!x3 || D % 32 == 0, "mrn_attn_decoder_fwd (x3): D=%d must be a multiple of 32", D);
-  const dim3 grid(grp.pinned ? 8 * ceil_div(groups, 8) * grp.tiles : groups * grp.tiles);
+  const dim3 grid(grp.pinned == 1 ? 8 * ceil_div(groups, 8) * grp.tiles : groups * grp.tiles);
   if (x3) {
     if (lds > 64 * 1024) hipFuncSetAttribute((const void*)attn_decoder_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(attn_decoder_kernel<true>, grid, dim3(NTH), lds, st, grp);
