@@ -355,3 +355,40 @@ def test_lockstep_grouping_policy():
     net.model = torch.nn.ModuleList(list(saved_models)[:3])
     assert [(lo, hi) for lo, hi, _, _ in net._half_groups(True)] == [(0, 3)]
     net.model = saved_models
+
+
+def test_converter_encode_array_fill_equals_the_per_word_loop():
+    """CTCLabelConverter / AttnLabelConverter.encode build the index batch with one array fill; the reference fills a padded tensor word by
+    word (tools/utils.py:35-58,102-131).  Same tensors on random batches (empty words, unknown characters, full-length words, an empty
+    batch), and a word that does not fit raises as the reference's slice assignment does"""
+    from mrn_amd.tools.utils import AttnLabelConverter, CTCLabelConverter
+    chars = "abcdefghij 0123"
+    with contextlib.redirect_stdout(io.StringIO()):
+        c, a = CTCLabelConverter(chars), AttnLabelConverter(chars)
+    rng = np.random.default_rng(3)
+    alphabet = list(chars) + ["?", "Z"]                 # two characters outside the dictionary -> [UNK]
+    for trial in range(20):
+        n = int(rng.integers(0, 9))
+        words = ["".join(alphabet[i] for i in rng.integers(0, len(alphabet), size=int(rng.integers(0, 26)))) for _ in range(n)]
+        if trial == 0:
+            words = []
+        idx, ln = c.encode(words, 25)
+        ref = torch.full((len(words), 25), c.dict["[PAD]"], dtype=torch.long)
+        for i, w in enumerate(words):
+            ids = [c.dict[ch] if ch in c.dict else c.dict["[UNK]"] for ch in w]
+            ref[i][:len(ids)] = torch.LongTensor(ids)
+        assert idx.dtype == torch.long and tuple(idx.shape) == (len(words), 25) and torch.equal(idx.cpu(), ref)
+        assert ln.dtype == torch.int32 and ln.tolist() == [len(w) for w in words]
+        idx, ln = a.encode(words, 25)
+        ref = torch.full((len(words), 27), a.dict["[PAD]"], dtype=torch.long)
+        if len(words):
+            ref[:, 0] = a.dict["[SOS]"]
+        for i, w in enumerate(words):
+            ids = [a.dict[ch] if ch in a.dict else a.dict["[UNK]"] for ch in list(w) + ["[EOS]"]]
+            ref[i][1:1 + len(ids)] = torch.LongTensor(ids)
+        assert idx.dtype == torch.long and tuple(idx.shape) == (len(words), 27) and torch.equal(idx.cpu(), ref)
+        assert ln.tolist() == [len(w) + 1 for w in words]
+    with pytest.raises(RuntimeError):
+        c.encode(["a" * 26], 25)
+    with pytest.raises(RuntimeError):
+        a.encode(["a" * 26], 25)

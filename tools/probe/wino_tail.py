@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 from mrn_amd import ops
 
 
-def timeit(fn, reps=10):
+def timeit(fn, reps=40):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
@@ -22,7 +22,8 @@ def timeit(fn, reps=10):
 H, W, Cin, Cout, G = 4, 65, 512, 512, 1
 ws = [(torch.rand(Cout, 3, 3, Cin, device="cuda") * 2 - 1) * 0.05 for _ in range(G)]
 u_hl, u_scale = ops.pack_weights_wino(ws, 4)
-for B in (120, 240, 256, 360, 376, 480):
+order = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else (120, 240, 256, 360, 376, 480)
+for B in order:
     ypre = torch.randn(G, B, H, W, Cin, device="cuda")
     sc, sh = torch.ones(G, Cin, device="cuda"), torch.zeros(G, Cin, device="cuda")
     _, _, v = ops.bn_apply_wino_grouped(ypre, sc, sh, 4, relu=True)
