@@ -39,7 +39,7 @@ def pmc_traffic(kernel_name, section="kernels"):
     """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes (profiles/r01_pmc.json, produced by
     tools/pmc_pass.sh on this same command): FETCH_SIZE x 2 (the gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE,
     both KiB counters.  None when the kernel has no entry (counters cannot be read from inside the timed run)."""
-    for name in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
+    for name in ("r06_pmc.json", "r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             break
@@ -47,12 +47,13 @@ def pmc_traffic(kernel_name, section="kernels"):
         return None
     with open(path) as f:
         pmc = json.load(f)
-    key = kernel_name.split(" (")[0]
+    key = kernel_name.split(" ")[0]          # ("wino_rows_kernel F(4,3)" -> wino_rows_kernel; template arguments carry no spaces here)
     kernels = pmc.get(section)
     if kernels is None:          # (no pass of that workload in this file: no figure rather than another workload's)
         return None
+    kernels = {k.replace(" ", ""): v for k, v in kernels.items()}
     ent = kernels.get(key)
-    if ent is None:          # (template arguments the description leaves out: bn_apply_wino_grouped_kernel<4>)
+    if ent is None:          # (template arguments the name leaves out: bn_apply_wino_grouped_kernel<4>)
         ent = next((v for k, v in kernels.items() if k.startswith(key + "<")), None)
     return None if ent is None else ent["hbm_bytes_per_launch"]
 
@@ -138,6 +139,8 @@ def cpu_baseline(learner, opt, n_experts, batch=32, iters=3, max_threads=32, bud
                      for _ in range(n_experts)]
         out = O.mrn_forward(sd, cfg, n_experts, image, True, text, True, training=True, masks=masks)
         loss, _, _ = O.mrn_step_loss(out, li, ll, domain, opt.Prediction)
+        if it == 0:          # the oracle as the checker: index agreement of the HIP path on this bench's own input distribution
+            agreement = index_agreement(learner, image, text, masks, out)
         grads = torch.autograd.grad(loss, params)
         with torch.no_grad():
             O.clip_and_adam(params, grads, state, 2.5e-5, it + 1)
@@ -152,8 +155,30 @@ def cpu_baseline(learner, opt, n_experts, batch=32, iters=3, max_threads=32, bud
             break
     sec = sum(times) / len(times)
     return {"value": batch / sec, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "cpu": cpu_model_string(),
-            "sample": f"{len(times)} timed iteration(s) (+1 warm-up) of the same loop B at batch {batch}, fp32, torch-CPU oracle"}
+            "cpu": cpu_model_string(), "sample": f"{len(times)} iters of loop B at batch {batch}, fp32 torch-CPU oracle",
+            "index_agreement": agreement}
+
+
+def index_agreement(learner, image, text, masks, ref):
+    """the HIP path's train-mode loop-B forward on the batch the CPU oracle just ran (same weights, same DropPath draws): how many
+    greedy indices of the fused logits and how many routing decisions (argmax of the gate weights) are equal, and the largest
+    differences -- measured on U(-1,1) noise crops, the distribution the headline is timed on"""
+    dev = learner.device
+    net = learner.model.module
+    if masks is not None:
+        from mrn_amd.modules.svtr import DropPath
+        for e, ms in enumerate(masks):
+            for j, m in enumerate(mod for mod in net.model[e].modules() if isinstance(mod, DropPath)):
+                m.forced_masks = [ms[2 * j].clone(), ms[2 * j + 1].clone()]
+    with torch.no_grad():
+        got = learner.model(image.to(dev), True, None if text is None else text.to(dev), True)
+    gl, gw = got["logits"].float().cpu(), got["index"].float().cpu()
+    rl, rw = ref["logits"].detach(), ref["index"].detach()
+    return {"samples": int(rl.shape[0]), "positions": int(rl.shape[0] * rl.shape[1]),
+            "greedy_index_agreement": (gl.argmax(2) == rl.argmax(2)).float().mean().item(),
+            "routing_argmax_agreement": (gw.argmax(1) == rw.argmax(1)).float().mean().item(),
+            "max_abs_logit_diff": (gl - rl).abs().max().item(), "max_abs_logit": rl.abs().max().item(),
+            "max_abs_gate_weight_diff": (gw - rw).abs().max().item()}
 
 
 def power_probe(ops, R, launches=3):
@@ -259,8 +284,7 @@ def cpu_baseline_loop_a(learner, opt, batch=32, max_threads=32, budget_s=45.0):
             break
     sec = sum(times) / len(times)
     return {"value": batch / sec, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port", "cpu": cpu_model_string(),
-            "sample": f"{len(times)} timed iteration(s) of the same loop A (one {opt.FeatureExtraction} expert: fwd + bwd + clip + Adam) at batch {batch}, "
-                      f"fp32, torch-CPU oracle"}
+            "sample": f"{len(times)} iters of loop A (one {opt.FeatureExtraction} expert) at batch {batch}, fp32 torch-CPU oracle"}
 
 
 def build_loop_a_learner(opt, quiet=True):
@@ -278,58 +302,39 @@ def build_loop_a_learner(opt, quiet=True):
 
 
 def train_dtype():
+    """f32: every product is a 22-bit split-fp16 x3 MFMA term or exact fp32, fp32 accumulate and storage; fp16: ONE fp16 product per term
+    (--precision fp16, the reduced mode of BASELINE configs 2 / 5)"""
     from mrn_amd import ops
-    if ops.TRAIN_PRODUCTS == 1:
-        return ("fp16 (reduced-precision mode: ONE fp16 MFMA product per term in the trained and frozen convolutions, range-scaled operands, "
-                "fp32 accumulate and fp32 storage; router / head Linear layers on split-fp16 x3)")
-    return "f32 (trained and frozen convolutions as range-safe split-fp16 x3 products, fp32 accumulate)"
+    return "fp16" if ops.TRAIN_PRODUCTS == 1 else "f32"
 
 
 def describe_kernel(kind):
-    """KernelTimer kind -> (kernel description, peak TFLOP/s of its MFMA dtype, MFMA flops executed per algorithmic flop)"""
+    """KernelTimer kind -> (kernel name, peak TFLOP/s of its MFMA dtype, MFMA flops executed per algorithmic flop).
+    What each kernel does is DESIGN.md's kernel table, not the bench line's business."""
     if kind == "f32":
-        return ("gemm_f32_kernel<2,2,2,2,16,true> (128x128x16 implicit-GEMM conv, v_mfma_f32_32x32x2_f32)", FP32_MFMA_PEAK_TFLOPS, 1)
+        return ("gemm_f32_kernel<2,2,2,2,16,true>", FP32_MFMA_PEAK_TFLOPS, 1)
     if kind.startswith("gemm_f32"):
-        return ("gemm_f32_kernel (exact-fp32 MFMA GEMM, v_mfma_f32_32x32x2_f32)", FP32_MFMA_PEAK_TFLOPS, 1)
+        return ("gemm_f32_kernel", FP32_MFMA_PEAK_TFLOPS, 1)
     arith, staging = kind.split("/")
     if arith == "f32mfma":
-        return (staging + " (first 3x3 convolution of the stacks on the Cin = 4 crops, all experts, v_mfma_f32_32x32x2_f32, the 2x2 max-pool taken "
-                          "in the epilogue by BatchNorm-weight sign: a quarter of the map out)", FP32_MFMA_PEAK_TFLOPS, 1)
+        return (staging, FP32_MFMA_PEAK_TFLOPS, 1)
+    nprod = 3 if arith == "fp16x3" else 1
     if staging.startswith("winorows"):
         R = int(staging[8])
-        return (f"wino_rows_kernel (grouped 3x3 conv of all experts as 1-D Winograd F({R},3) along W, row-block form: a workgroup owns 64 "
-                f"positions x 4 output rows x 64 channels, one wave per SIMD (453 registers), every input row staged once per (component, "
-                f"channel block) and used by up to three (kernel row, output row) products, {arith} on v_mfma_f32_32x32x16_f16, operands "
-                f"staged by buffer_load...lds through a 3-deep activation ring + 2-deep weight ring)",
-                BF16_MFMA_PEAK_TFLOPS, 3.0 * (R + 2) / (3 * R))
+        return (f"wino_rows_kernel F({R},3)", BF16_MFMA_PEAK_TFLOPS, 3.0 * (R + 2) / (3 * R))
     if staging.startswith("wino"):
         R = int(staging[4])
-        return (f"conv_x3_kernel<2, 4, 2, 1, false, 3, {R}> (grouped 3x3 conv of all experts as 1-D Winograd F({R},3) along W: "
-                f"128 column-groups x 128 channels x 32 tiles, {R + 2} component reductions folded into {R} output accumulators in "
-                f"registers, {arith} on v_mfma_f32_32x32x16_f16, transformed HL32 operands staged by buffer_load...lds through a 3-stage ring)",
-                BF16_MFMA_PEAK_TFLOPS, 3.0 * (R + 2) / (3 * R))
+        return (f"conv_x3_kernel<2,4,2,1,false,3,{R}>", BF16_MFMA_PEAK_TFLOPS, 3.0 * (R + 2) / (3 * R))
     if staging.startswith("x3g"):
         tile = staging[3:]
-        targs = {"256x256": "4, 4, 2, 2", "256x128": "4, 2, 2, 2", "128x128": "4, 2, 1, 2", "256x64": "8, 1, 1, 2", "128x64": "4, 1, 1, 2", "64x64": "2, 2, 1, 1"}[tile]
-        nprod = 3 if arith == "fp16x3" else 1
-        return (f"conv_x3_kernel<{targs}{', false, 1' if nprod == 1 else ''}> (grouped {tile}x32 implicit-GEMM conv / Linear over "
-                f"all experts, {arith} on v_mfma_f32_32x32x16_f16, HL32 operands staged by buffer_load...lds)",
-                BF16_MFMA_PEAK_TFLOPS, nprod)
+        targs = {"256x256": "4,4,2,2", "256x128": "4,2,2,2", "128x128": "4,2,1,2", "256x64": "8,1,1,2", "128x64": "4,1,1,2", "64x64": "2,2,1,1"}[tile]
+        return (f"conv_x3_kernel<{targs}{',false,1' if nprod == 1 else ''}>", BF16_MFMA_PEAK_TFLOPS, nprod)
     if staging.startswith("patch"):
         cin = int(staging[5:7])
-        pooled = staging.endswith("pool")
-        return (f"conv_patch_x3_kernel<{cin // 32}, {cin // 16}, 2{', true' if pooled else ''}> ({cin} -> {2 * cin} channels: narrow early 3x3 layers of all "
-                "experts, patch-resident and weight-stationary: weights in registers, "
-                "activation patch staged once by buffer_load...lds, nine shifted ds_read_b128 views"
-                + (", 2x2 max-pool taken in the epilogue by BatchNorm-weight sign" if pooled else "")
-                + f", {arith} on v_mfma_f32_32x32x16_f16)", BF16_MFMA_PEAK_TFLOPS, 3)
-    svtr = {"svtrmlp": "svtr_mlp_kernel (fc1 -> GELU -> fc2 of an SVTR mixing block over all experts, hidden activation in registers)",
-            "svtrmixer": "svtr_mixer_kernel (LayerNorm1 -> qkv -> local / global attention -> proj -> residual -> LayerNorm2 of an SVTR mixing "
-                         "block over all experts, chained MFMAs, K / V through LDS)",
-            "svtrattn": "svtr_mixer_kernel<256, ..., ATTN> (stage 3: LayerNorm1 -> qkv -> attention, context out as the proj operand)",
-            "svtrblock3": "svtr_tail_kernel<256> (stage 3: proj -> residual -> LayerNorm2 -> fc1 -> GELU -> fc2 -> residual)"}
+        return (f"conv_patch_x3_kernel<{cin // 32},{cin // 16},2{',true' if staging.endswith('pool') else ''}>", BF16_MFMA_PEAK_TFLOPS, 3)
+    svtr = {"svtrmlp": "svtr_mlp_kernel", "svtrmixer": "svtr_mixer_kernel", "svtrattn": "svtr_mixer_kernel<256,ATTN>", "svtrblock3": "svtr_tail_kernel<256>"}
     if staging in svtr:
-        return (svtr[staging] + f", {arith} on v_mfma_f32_32x32x16_f16", BF16_MFMA_PEAK_TFLOPS, 3)
+        return (svtr[staging], BF16_MFMA_PEAK_TFLOPS, 3)
     raise ValueError(f"unknown KernelTimer kind {kind!r}")
 
 
@@ -593,7 +598,72 @@ def time_loop_b_short(args, opt, steps, warmup):
     del learner
     return {"metric": "text-line images/sec (fwd+bwd) at 32x256, TRBA+MRN 6 experts, REDUCED precision (not the headline)",
             "value": args.batch * steps / elapsed, "unit": "images/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": warmup,
-            "dtype": "fp16 (one fp16 MFMA product per term, fp32 accumulate and storage)" if ops.X3_PRODUCTS == 1 else "f32 x3"}
+            "dtype": "fp16" if ops.X3_PRODUCTS == 1 else "f32"}
+
+
+RL_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "algorithmic_gflop_per_launch",
+           "launches_per_step", "avg_launch_ms", "kernel_share_of_step", "mfma_flops_per_algorithmic_flop")
+CPU_KEYS = ("value", "unit", "cores", "kind", "cpu", "sample", "index_agreement")
+COMM_KEYS = ("backend", "ranks_seen", "rccl_version", "allreduce_bytes_per_step", "buckets", "allreduce_ms_per_step", "exposed_ms_per_step",
+             "overlap_frac")
+HEAD_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+LINE_LIMIT = 4096            # the driver keeps an 8 KB tail of stdout: the line must fit with room to spare
+
+
+def _sig(x, digits=5):
+    """numbers of the compact line at 5 significant digits (the detail file keeps them in full)"""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+def compact_line(res, detail_path=None):
+    """the ONE stdout line: headline fields, the dominant kernel's roofline (numbers + kernel name), cpu_baseline, comm (N > 1) and
+    {value, ms_per_step} per extra workload -- no prose.  Everything else stays in the detail file."""
+    out = {k: res[k] for k in HEAD_KEYS if k in res}
+    cfg = res.get("config", {})
+    out["config"] = {k: cfg[k] for k in ("workload", "per_gpu_batch", "global_batch", "parallelism", "classes") if k in cfg}
+    if "roofline" in res:
+        out["roofline"] = {k: res["roofline"][k] for k in RL_KEYS if k in res["roofline"]}
+        iso = res["roofline"].get("isolated")
+        if iso:
+            out["roofline"]["isolated"] = {k: iso[k] for k in ("achieved", "frac", "avg_launch_ms") if k in iso}
+    if "cpu_baseline" in res:
+        out["cpu_baseline"] = {k: res["cpu_baseline"][k] for k in CPU_KEYS if k in res["cpu_baseline"]}
+    if "comm" in res:
+        out["comm"] = {k: res["comm"][k] for k in COMM_KEYS if k in res["comm"]}
+    if "extra" in res:
+        out["extra"] = {name: {k: line[k] for k in ("value", "ms_per_step") if k in line} for name, line in res["extra"].items()}
+    if detail_path:
+        out["detail"] = detail_path
+    line = json.dumps(_sig(out), separators=(",", ":"))
+    if len(line) >= LINE_LIMIT:          # never let the line outgrow the driver again: drop the optional objects, loudest last
+        for k in ("extra", "comm"):
+            out.pop(k, None)
+            line = json.dumps(_sig(out), separators=(",", ":"))
+            if len(line) < LINE_LIMIT:
+                break
+    assert len(line) < LINE_LIMIT and "\n" not in line, len(line)
+    return line
+
+
+def emit(res):
+    """rank 0: write the full record to bench_detail.json (repo root, and gpurun_out/ so it travels back from a gpurun call), then
+    print the compact line as the LAST line of stdout"""
+    rel = "bench_detail.json"
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        try:
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, rel), "w") as f:
+                json.dump(res, f, indent=1)
+        except OSError:
+            rel = None if d == ROOT else rel
+    sys.stdout.flush()
+    print(compact_line(res, rel), flush=True)
 
 
 def self_launch(n):
@@ -677,7 +747,7 @@ def main():
             res.update({"n_gpus": world, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
                         "config": {"workload": f"{what} on 32x256x4 crops, random-init weights",
                                    "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}"}})
-            print(json.dumps(res))
+            emit(res)
         parallel.barrier()
         return
     learner = build_learner(opt, args.experts, quiet=not args.verbose)
@@ -761,24 +831,16 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "host_issue_ms_per_step": host_elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "skipped_optimizer_steps": learner.optimizer.skipped_steps(),      # non-finite gradient norms (csrc/optim.hip): 0 or the line is suspect
-            "dtype": "fp16 (one fp16 MFMA product per term, fp32 accumulate and fp32 storage: reduced-precision mode, NOT the headline)"
-            if ops.X3_PRODUCTS == 1 else
-            {"auto": "f32 (convs with Cout>64 as split-fp16 x3 MFMA products, 22-bit significand, fp32 accumulate)",
-             "f32": "f32", "fp16x3": "fp16x3 (split-fp16 MFMA, fp32 accumulate)"}[ops.CONV_PRECISION],
+            "dtype": "fp16" if ops.X3_PRODUCTS == 1 else "f32",
+            "arithmetic": "one fp16 MFMA product per term, fp32 accumulate (reduced mode, not the headline)" if ops.X3_PRODUCTS == 1 else
+            {"auto": "split-fp16 x3 MFMA products (22-bit), fp32 accumulate", "f32": "exact fp32 MFMA",
+             "fp16x3": "split-fp16 x3 MFMA products (22-bit), fp32 accumulate"}[ops.CONV_PRECISION],
             "data": "synthetic",
-            "config": {"workload": f"MRN loop B (router phase): {args.model.upper()} x {args.experts} frozen experts "
-                                   f"(train-mode BN) + DM-Router fwd/bwd + clip + Adam, 32x256x4 crops, random-init weights",
+            "config": {"workload": f"MRN loop B: {args.model.upper()}x{args.experts} frozen experts fwd + DM-Router fwd/bwd + clip + Adam, 32x256x4 crops",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "classes": [sum(CLASSES_MLT19[:i + 1]) + (5 if args.model == "trba" else 4) for i in range(args.experts)],
                        "loss_clf": loss_clf.detach().item(), "loss_taski": loss_t.detach().item(),
-                       "parity_band": ("1e-4 smooth / 3x f64-band noise: logits and losses within 1e-4 of the reference on smooth crops; on "
-                                       "U(-1,1) noise crops (this bench's inputs) TRBA is held to 3x the reference's own fp32-vs-float64 band "
-                                       "(TPS grid conditioning, several 1e-3; tests/test_model_gpu.py::test_trba_noise_inside_reference_band); "
-                                       "argmax / routing / CTC indices bit-exact") if args.model == "trba" else
-                                      "1e-4 on logits and losses (smooth and U(-1,1) noise crops); argmax / routing / CTC indices bit-exact",
-                       "reduced_precision_note": "BASELINE configs 2 (\"bf16\") and 5 (\"fp16 MFMA\") are served by ONE reduced mode: one fp16 "
-                                                 "product per term, fp32 accumulate (fp16 keeps 11 significand bits where bf16 keeps 8, same MFMA "
-                                                 "rate); bench.py --precision fp16, and extra.fp16_loop_b / extra.fp16_der in this line"},
+                       "parity": "tests/test_model_gpu.py (bands and index-agreement rates: DESIGN.md section 2)"},
         }
         if timer is not None and timer.spans:
             rl, hbm = roofline_entries(timer.summary(), args.steps, elapsed,
@@ -849,7 +911,7 @@ def main():
         if extra is not None:
             res["extra"] = {"loop_a": extra}
             res["extra"].update(reduced)
-        print(json.dumps(res))
+        emit(res)
     parallel.barrier()
 
 

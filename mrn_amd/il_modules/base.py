@@ -160,7 +160,7 @@ class BaseLearner(object):
         # step runs the same schedule as the single-GPU one
         if self.reducer is not None:
             self.reducer.begin()
-            with ops.direct_gradients(notify=self.reducer.param_ready):
+            with ops.direct_gradients(notify=self.reducer.param_ready, roots=(loss,)):
                 loss.backward()
             self.reducer.finish()
         else:

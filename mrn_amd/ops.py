@@ -870,36 +870,41 @@ def multi_pack_eligible(p, kind):
 
 def multi_pack_linear(entries):
     """entries [(kind, weight [N,K])] -> [(HL32 operand bytes, scale [1,2])] exactly as pack_weights_hl32 builds them one by one
-    (kind lin_fwd_x3: of W; lin_bwd_x3: of W^T), in ONE library call on the current stream.  The operands live in one persistent
-    buffer per device that every call rewrites in stream order (the table of weights is rebuilt when the set of layers changes)."""
+    (kind lin_fwd_x3: of W; lin_bwd_x3: of W^T), in ONE library call on the current stream.
+    ALIASING CONTRACT: the returned operands are views into persistent per-device buffers, not fresh tensors.  Two buffers alternate
+    call by call, so a view stays valid through the NEXT call (one optimiser step: prepack_trained() rewrites the other buffer) and is
+    overwritten in stream order by the call after that; nothing may hold a pack across two optimiser steps (the _PREPACKED / _memo
+    keys -- data pointer + version -- only guard the lookup, not a reference somebody kept)."""
     dev = entries[0][1].device
     sig = tuple((kind, p.data_ptr(), tuple(p.shape)) for kind, p in entries)
     st = _MULTI_PACK_STATE.get(dev)
     if st is None or st["sig"] != sig:
         n = len(entries)
-        offs, tiles, rows, total = [], 0, [], 0
+        offs, tiles, total = [], 0, 0
         for kind, p in entries:
             N, K = p.shape
             tr = _MULTI_PACK_KINDS[kind]
             O, I = (K, N) if tr else (N, K)
-            offs.append(total)
-            rows.append([p.data_ptr(), 0, 0, N, K, tr, tiles, I // 32])
+            offs.append((total, tiles, I // 32, tr))
             tiles += ((O + 31) // 32) * (I // 32)
             total += (N * K * 4 + 255) // 256 * 256
-        out = torch.empty(total, device=dev, dtype=torch.uint8)
-        scale = torch.empty(n, 2, device=dev, dtype=torch.float32)
-        for i, row in enumerate(rows):
-            row[1], row[2] = out.data_ptr() + offs[i], scale.data_ptr() + 8 * i
-        desc = torch.tensor(rows, dtype=torch.int64).to(dev)
-        views = [(out[offs[i]:offs[i] + p.numel() * 4], scale[i:i + 1]) for i, (_, p) in enumerate(entries)]
-        st = {"sig": sig, "desc": desc, "out": out, "scale": scale, "amax": torch.zeros(n, device=dev, dtype=torch.int32),
-              "tiles": tiles, "views": views}
+        halves = []
+        for _ in range(2):
+            out = torch.empty(total, device=dev, dtype=torch.uint8)
+            scale = torch.empty(n, 2, device=dev, dtype=torch.float32)
+            rows = [[p.data_ptr(), out.data_ptr() + off, scale.data_ptr() + 8 * i, p.shape[0], p.shape[1], tr, t0, ib]
+                    for i, ((_, p), (off, t0, ib, tr)) in enumerate(zip(entries, offs))]
+            views = [(out[offs[i][0]:offs[i][0] + p.numel() * 4], scale[i:i + 1]) for i, (_, p) in enumerate(entries)]
+            halves.append({"desc": torch.tensor(rows, dtype=torch.int64).to(dev), "out": out, "scale": scale, "views": views})
+        st = {"sig": sig, "halves": halves, "flip": 0, "amax": torch.zeros(n, device=dev, dtype=torch.int32), "tiles": tiles}
         _MULTI_PACK_STATE[dev] = st
         MULTI_PACK_STATS["rebuilds"] += 1
-    call("mrn_multi_pack_linear_hl32", st["desc"].data_ptr(), len(entries), st["tiles"], st["amax"].data_ptr(), FP16_WEIGHT_PEAK, _stream())
+    half = st["halves"][st["flip"]]
+    st["flip"] ^= 1
+    call("mrn_multi_pack_linear_hl32", half["desc"].data_ptr(), len(entries), st["tiles"], st["amax"].data_ptr(), FP16_WEIGHT_PEAK, _stream())
     MULTI_PACK_STATS["calls"] += 1
     MULTI_PACK_STATS["weights"] += len(entries)
-    return st["views"]
+    return half["views"]
 
 
 def conv2d_x3_scaled(x, w_ohwi, bias, stride, padding, act=ACT_NONE, want_stats=False, sx=None):
@@ -1783,6 +1788,7 @@ def unpack_conv_weight(g_ohwi, out=None, accumulate=False):
 # N > 1 ranks the bucketed all-reduce is told about every completed parameter through direct_gradients(notify=...)).
 WGRAD_SIDE_STREAM = os.environ.get("MRN_WGRAD_STREAM", "1") == "1"
 GRAD_DIRECT = False                 # set by direct_gradients(): only a caller that runs loss.backward() INTO .grad may skip autograd's accumulation
+_GRAD_GENS = [()]                   # direct_gradients(notify=..., roots=...): forward generations of the graph being run backward
 _GRAD_NOTIFY = [None]               # direct_gradients(notify=...): called with a Parameter once ALL its side-stream accumulations are issued
 # Forward uses (by functions that may accumulate directly) not yet matched by a backward, PER FORWARD GENERATION: a function's forward
 # stores the generation it was counted under on its ctx (ctx.use_gen) and its backward ticks the counts of THAT generation, so graphs
@@ -1806,22 +1812,42 @@ class direct_gradients:
     has had its accumulation issued on the side stream (note_param_uses counts the uses).  On exit -- also when backward raised -- the
     streams are joined and the references the side stream held are dropped."""
 
-    def __init__(self, notify=None):
+    def __init__(self, notify=None, roots=()):
         self.notify = notify
+        self.roots = roots           # the tensors backward() is about to be called on: with notify, their graph is walked for the
+        #                              forward generations it holds (a loss fed by two wrapper forwards spans two)
 
     def __enter__(self):
         global GRAD_DIRECT
         self.prev, GRAD_DIRECT = GRAD_DIRECT, True
         self.prev_notify, _GRAD_NOTIFY[0] = _GRAD_NOTIFY[0], self.notify
+        self.prev_gens, _GRAD_GENS[0] = _GRAD_GENS[0], (graph_generations(self.roots) if self.notify is not None else ())
         return self
 
     def __exit__(self, *exc):
         global GRAD_DIRECT
         GRAD_DIRECT = self.prev
         _GRAD_NOTIFY[0] = self.prev_notify
+        _GRAD_GENS[0] = self.prev_gens
         new_use_generation()
         join_side_stream()           # (normally done by the backward pass's final callback; an exception inside backward skips that)
         return False
+
+
+def graph_generations(roots):
+    """the forward generations (ctx.use_gen of our autograd Functions) found in the graphs behind `roots`"""
+    gens, seen = set(), set()
+    stack = [t.grad_fn for t in roots if t is not None and t.grad_fn is not None]
+    while stack:
+        node = stack.pop()
+        if node in seen:
+            continue
+        seen.add(node)
+        g = getattr(node, "use_gen", None)
+        if g is not None:
+            gens.add(g)
+        stack.extend(fn for fn, _ in node.next_functions if fn is not None)
+    return tuple(gens)
 
 
 def new_use_generation():
@@ -1854,7 +1880,8 @@ DIRECT_STATS = {"parameters": 0, "notified": 0}    # side-stream accumulations i
 def direct_done(params, gen=None):
     """the side-stream accumulation of one use of each of `params` has been issued; gen: what note_param_uses returned in the
     forward of the calling function.  A parameter is reported to direct_gradients(notify=...) when the count of ITS generation
-    reaches zero; one without a count (generation dropped, forward not recorded) is left to the reducer's finish()."""
+    reaches zero AND no other generation of the running backward's graph still holds uses of it; one without a count (generation
+    dropped, forward not recorded) is left to the reducer's finish()."""
     notify = _GRAD_NOTIFY[0]
     table = _PARAM_USES.get(gen)
     for p in params:
@@ -1865,7 +1892,9 @@ def direct_done(params, gen=None):
             continue
         n = table[id(p)] - 1
         table[id(p)] = n
-        if n == 0 and notify is not None:
+        # two grad-enabled wrapper forwards that feed ONE backward count the same parameter in two tables: complete only when every
+        # generation this backward's graph holds (direct_gradients(roots=...)) has run dry, not just the calling function's own
+        if n == 0 and notify is not None and not any(_PARAM_USES.get(g, {}).get(id(p), 0) > 0 for g in _GRAD_GENS[0] if g != gen):
             DIRECT_STATS["notified"] += 1
             notify(p)
 

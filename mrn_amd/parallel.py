@@ -249,22 +249,26 @@ class BucketedAllReduce:
 
     def _make_hook(self, i):
         def hook(_param):
-            if self.active:
-                b = self.bucket_of[i]
-                self.pending[b] -= 1
-                self._launch_ready()
+            self._report(i)
         return hook
+
+    def _report(self, i):
+        """count parameter i's bucket down ONCE per step, whoever reports it (autograd's hook, the side stream's notify, or both)"""
+        if self.active and i not in self.reported:
+            self.reported.add(i)
+            self.pending[self.bucket_of[i]] -= 1
+            self._launch_ready()
 
     def param_ready(self, param):
         """ops.direct_gradients(notify=...): a parameter whose gradient never passes autograd's accumulation -- it is ADDED into the
         flat gradient on the side stream (functional.side_param_grads, ConvBlockFn.backward) -- has had its last accumulation issued"""
         i = self.index_of.get(id(param))
-        if self.active and i is not None:
-            self.pending[self.bucket_of[i]] -= 1
-            self._launch_ready()
+        if i is not None:
+            self._report(i)
 
     def begin(self):
         self.pending = list(self.sizes)
+        self.reported = set()
         self.next = 0
         self.handles = []
         self.launched_log = []

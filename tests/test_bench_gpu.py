@@ -22,10 +22,20 @@ def _fresh_process_only():
         pytest.skip("run tests/test_bench_gpu.py in a fresh process")
 
 
-def _last_json(out):
-    lines = [l for l in out.splitlines() if l.startswith("{")]
-    assert lines, out[-2000:]
-    return json.loads(lines[-1])
+def _the_line(out):
+    """stdout holds exactly ONE JSON line, it is the last line, it is compact (the driver keeps an 8 KB tail) and it round-trips"""
+    lines = out.splitlines()
+    js = [l for l in lines if l.startswith("{")]
+    assert len(js) == 1 and lines[-1] == js[0], out[-2000:]
+    assert len(js[0]) < 4096, len(js[0])
+    d = json.loads(js[0])
+    assert json.loads(json.dumps(d)) == d
+    return d
+
+
+def _detail(d):
+    with open(os.path.join(ROOT, d["detail"])) as f:
+        return json.load(f)
 
 
 def test_bench_single_process_line():
@@ -33,12 +43,39 @@ def test_bench_single_process_line():
     r = subprocess.run([sys.executable, "bench.py", "--model", "crnn", "--experts", "3", "--batch", "32", "--steps", "2",
                         "--warmup", "1", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    d = _last_json(r.stdout)
+    d = _the_line(r.stdout)
     for k in FIELDS:
         assert k in d, k
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["scaling"] == "weak" and d["data"] == "synthetic"
     rl = d["roofline"]
     assert rl["bound"] in ("mfma", "hbm") and 0 < rl["frac"] < 1 and rl["peak"] > 0 and "isolated" in rl
+    assert len(rl["kernel"]) < 64                      # a kernel name, not a paragraph
+    full = _detail(d)                                  # everything else: the side file
+    assert full["value"] == pytest.approx(d["value"], rel=1e-4) and "measured" in full["roofline"]
+
+
+def test_bench_default_command_line_is_compact_and_complete():
+    """the driver's command (default workload: TRBA x 6, batch 256, every extra line, the CPU baseline leg), shortened only in
+    --steps / --warmup: ONE parseable line under 4 KB carrying roofline.frac and cpu_baseline.value (the 20 KB line
+    of round 5 did not parse and voided the round's measurement)"""
+    _fresh_process_only()
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1"], cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _the_line(r.stdout)
+    for k in FIELDS + ("cpu_baseline", "extra", "detail"):
+        assert k in d, k
+    assert d["metric"] == "text-line images/sec (fwd+bwd) at 32x256, TRBA+MRN 6 experts" and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert d["config"]["per_gpu_batch"] == 256 and len(d["config"]["classes"]) == 6 and len(d["config"]["workload"]) <= 120
+    rl, cb = d["roofline"], d["cpu_baseline"]
+    assert rl["bound"] == "mfma" and 0 < rl["frac"] < 1 and rl["achieved"] / rl["peak"] == pytest.approx(rl["frac"], rel=1e-3)
+    assert rl["kernel"].startswith("wino_rows_kernel") and rl["avg_launch_ms"] > 0 and rl["launches_per_step"] > 0
+    assert cb["value"] > 0 and cb["kind"] == "port" and cb["cores"] >= 1 and cb["unit"] == "images/s"
+    ia = cb["index_agreement"]                         # measured on this run's noise crops against the oracle
+    assert ia["routing_argmax_agreement"] >= 0.9 and ia["greedy_index_agreement"] >= 0.99
+    for name in ("loop_a", "der", "fp16_loop_b", "fp16_der", "crnn3_loop_b", "svtr6_loop_b"):
+        assert d["extra"][name]["value"] > 0 and d["extra"][name]["ms_per_step"] > 0
+    full = _detail(d)
+    assert "roofline_other_kernels" in full and "roofline" in full["extra"]["loop_a"]
 
 
 def test_bench_two_ranks_control_flow():
@@ -49,18 +86,20 @@ def test_bench_two_ranks_control_flow():
     cmd = [sys.executable, "bench.py", "--gpus", "2", "--model", "crnn", "--experts", "3", "--batch", "16", "--steps", "2", "--warmup", "1"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)     # (a timeout FAILS the test)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
-    d = _last_json(r.stdout)
+    d = _the_line(r.stdout)                 # rank 0 prints exactly one line
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 32 and d["config"]["parallelism"] == "dp2"
     assert "cpu_baseline" not in d          # reported at N = 1 only
-    # comm telemetry of the N > 1 line: did the backend see both ranks, what one step's gradient exchange moves and costs
-    for line in (d, d["extra"]["loop_a"]):
+    assert d["comm"]["ranks_seen"] == [0, 1] and d["comm"]["backend"] == "gloo"
+    # comm telemetry of the N > 1 record: did the backend see both ranks, what one step's gradient exchange moves and costs
+    full = _detail(d)
+    for line in (full, full["extra"]["loop_a"]):
         c = line["comm"]
         assert c["backend"] == "gloo" and c["ranks_seen"] == [0, 1] and "rccl_version" in c
         assert c["allreduce_bytes_per_step"] > 0 and c["buckets"] >= 1 and c["allreduce_ms_per_step"] > 0
         assert c["exposed_ms_per_step"] >= 0 and 0.0 <= c["overlap_frac"] <= 1.0
-    assert d["comm"]["allreduce_bytes_per_step"] < d["extra"]["loop_a"]["comm"]["allreduce_bytes_per_step"]     # router only vs a whole expert
+    assert full["comm"]["allreduce_bytes_per_step"] < full["extra"]["loop_a"]["comm"]["allreduce_bytes_per_step"]     # router only vs a whole expert
     # N > 1 runs the single-GPU schedule: parameter gradients on the side stream, the buckets told through direct_gradients(notify=)
-    assert d["extra"]["loop_a"]["comm"]["side_stream_parameters_per_step"] > 0
+    assert full["extra"]["loop_a"]["comm"]["side_stream_parameters_per_step"] > 0
 
 
 def test_bench_refuses_a_mismatched_world():

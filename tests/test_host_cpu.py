@@ -256,6 +256,38 @@ for loss, (xx, yy) in ((loss_a, (xa, ya)), (loss_b, (xb, yb))):
     both = [torch.zeros_like(mine) for _ in range(2)]
     torch.distributed.all_gather(both, mine)
     assert torch.allclose(g, (both[0] + both[1]) / 2, atol=1e-7), (g - (both[0] + both[1]) / 2).abs().max()
+# forward A, forward B (the data-parallel wrapper starts a generation for each), ONE backward of the summed loss: a parameter counts
+# in two tables and is reported once, after the last accumulation of BOTH (ADVICE r05: it used to be reported twice, the first time
+# after half of its accumulations -- the bucket then travelled before its gradient was complete)
+ops.new_use_generation()
+out_a = forward(xa)
+ops.new_use_generation()
+out_b = forward(xb)
+loss_ab = ((out_a - ya) ** 2).mean() + ((out_b - yb) ** 2).mean()
+assert len(ops.graph_generations((loss_ab,))) == 2
+opt.zero_grad()
+red.begin()
+accumulated.clear()
+reported = []
+def notify_both(p):
+    assert accumulated.get(id(p), 0) == (4 if p is net[3].weight else 2), "reported before the last accumulation of both forwards"
+    reported.append(id(p))
+    red.param_ready(p)
+    red.param_ready(p)                                   # idempotent per step
+with ops.direct_gradients(notify=notify_both, roots=(loss_ab,)):
+    loss_ab.backward()
+assert len(reported) == len(set(reported)) == 3, reported
+assert red.next >= len(red.buckets) - 1, (red.next, len(red.buckets))
+red.finish()
+assert red.launched_log == list(range(len(red.buckets))), red.launched_log
+g = opt.grad.clone()
+opt.zero_grad()
+with ops.direct_gradients():
+    (((forward(xa) - ya) ** 2).mean() + ((forward(xb) - yb) ** 2).mean()).backward()
+mine = opt.grad.clone()
+both = [torch.zeros_like(mine) for _ in range(2)]
+torch.distributed.all_gather(both, mine)
+assert torch.allclose(g, (both[0] + both[1]) / 2, atol=1e-7), (g - (both[0] + both[1]) / 2).abs().max()
 # a backward whose forward generation has been dropped (or was never counted) reports nothing: finish() launches what is left
 loss_c = ((forward(xa) - ya) ** 2).mean()
 for _ in range(ops._USE_GEN_KEEP + 1):
