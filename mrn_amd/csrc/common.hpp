@@ -70,6 +70,11 @@ __device__ __forceinline__ void split_f16_sat(float x, _Float16& hi, _Float16& l
   split_f16(x, hi, lo);
 }
 
+// torch.relu / max_pool2d propagate NaN; v_max_f32 (fmaxf) returns the OTHER operand.  The pooled epilogues and the separate pooling
+// pass must agree on non-finite data too (a NaN in a frozen expert's raw convolution output must reach the features).
+__device__ __forceinline__ float relu_nan(float v, float floor_ = 0.f) { return v != v ? v : fmaxf(v, floor_); }
+__device__ __forceinline__ float max_nan(float a, float b) { return (a != a || b != b) ? a + b : fmaxf(a, b); }
+
 // GELU(x) = x * Phi(x) with erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute on erf, so <= 0.75e-7 * |x| on the
 // result: below one fp32 ulp of the activations that matter): one v_rcp, one v_exp and 7 FMAs instead of the branchy ~45
 // instruction erff of the device library -- the GELU of the SVTR Mlp runs in a GEMM epilogue (64 elements per thread).

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const ConvFirstParams p
         if (rok && ox < p.W) {
           sm += v;
           sq = fmaf(v, v, sq);
-          if (!POOL) yrow[(long)ox * Cout + co] = fmaxf(v, relu_floor);
+          if (!POOL) yrow[(long)ox * Cout + co] = relu_nan(v, relu_floor);
         }
       }
     }
@@ -121,8 +121,8 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const ConvFirstParams p
 #pragma unroll
       for (int e = 0; e < 16; e += 2) {
         const int pxo = (x0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg) >> 1;
-        const float mx = fmaxf(fmaxf(acc[0][j][e] * sg, acc[0][j][e + 1] * sg), fmaxf(acc[1][j][e] * sg, acc[1][j][e + 1] * sg));
-        if (py < Ho && pxo < Wo) prow[(long)pxo * Cout + co] = fmaxf(mx * sg, relu_floor);
+        const float mx = max_nan(max_nan(acc[0][j][e] * sg, acc[0][j][e + 1] * sg), max_nan(acc[1][j][e] * sg, acc[1][j][e + 1] * sg));
+        if (py < Ho && pxo < Wo) prow[(long)pxo * Cout + co] = relu_nan(mx * sg, relu_floor);
       }
     }
     if (p.stats) {

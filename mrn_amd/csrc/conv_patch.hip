@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void conv_patch_x3_kernel(const ConvPatchParam
       for (int r = 0; r < RP; ++r) {
         f32x4 v;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = fmaxf(acc[r][4 * q + i], relu_floor);
+        for (int i = 0; i < 4; ++i) v[i] = relu_nan(acc[r][4 * q + i], relu_floor);
         store16(v, pend.off + r * p.W * Cout + 8 * q, r == 0 ? pend.ok0 : pend.ok1);
       }
     } else {
@@ -267,9 +267,9 @@ __global__ __launch_bounds__(256) void conv_patch_x3_kernel(const ConvPatchParam
       for (int i = 0; i < 4; ++i) {
         const float sg = sign_of(4 * q + i);
         const float f0 = acc[0][4 * q + i], f1 = acc[1][4 * q + i];      // (copies: __builtin_bit_cast applied to a vector-element lvalue read element 0)
-        float mx = fmaxf(f0 * sg, f1 * sg);
-        mx = fmaxf(mx, swap1(mx));
-        sel[i] = fmaxf(mx * sg, relu_floor);
+        float mx = max_nan(f0 * sg, f1 * sg);
+        mx = max_nan(mx, swap1(mx));
+        sel[i] = relu_nan(mx * sg, relu_floor);
       }
       const bool odd = n & 1;
       if (q == 0 || q == 2) hold = sel;          // (even lanes have stored quads 0-1 by the time quad 2 overwrites it)

@@ -330,7 +330,7 @@ __device__ __forceinline__ void wino_rows_tile(const WinoRowsParams& p, unsigned
           csq[j4] += v * v;
           if (p.act == 1) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+            for (int i = 0; i < 4; ++i) v[i] = relu_nan(v[i]);
           }
           *reinterpret_cast<f32x4*>(dst + 8 * j4) = v;
         }
@@ -369,7 +369,7 @@ __device__ __forceinline__ void wino_rows_tile(const WinoRowsParams& p, unsigned
               csq[j4] += v * v;
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) mx[r >> 1][i] = (oo | (r & 1)) ? fmaxf(mx[r >> 1][i], v[i] * sg[i]) : v[i] * sg[i];
+            for (int i = 0; i < 4; ++i) mx[r >> 1][i] = (oo | (r & 1)) ? max_nan(mx[r >> 1][i], v[i] * sg[i]) : v[i] * sg[i];
           }
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
@@ -377,7 +377,7 @@ __device__ __forceinline__ void wino_rows_tile(const WinoRowsParams& p, unsigned
           if (ox < Wo) {
             f32x4 out;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) out[i] = fmaxf(mx[pr][i] * sg[i], relu_floor);
+            for (int i = 0; i < 4; ++i) out[i] = relu_nan(mx[pr][i] * sg[i], relu_floor);
             *reinterpret_cast<f32x4*>(ypg + (((long)b * Ho + (oy0 >> 1) + po) * Wo + ox) * p.N + c0 + 8 * j4) = out;
           }
         }

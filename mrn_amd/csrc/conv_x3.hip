@@ -571,7 +571,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_x3_kernel(const Co
           }
           csum[j] += v;
           csq[j] += v * v;
-          if (p.act == 1) v = fmaxf(v, 0.f);
+          if (p.act == 1) v = relu_nan(v);
           else if (p.act == 2) v = gelu_fast(v);                                             // GELU (erf), SVTR Mlp
           amx = fmaxf(amx, fabsf(v));
           if (!HL_OUT || p.y) yg[pix * p.y_ld + n] = v;

@@ -193,7 +193,7 @@ __device__ __forceinline__ void load_wgrad(float (&r)[stage_regs(ROWS, NT, BK)],
 }
 
 __device__ __forceinline__ float apply_act(float v, int act) {
-  if (act == 1) return fmaxf(v, 0.f);
+  if (act == 1) return relu_nan(v);
   if (act == 2) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
   return v;
 }

@@ -179,8 +179,8 @@ __global__ __launch_bounds__(256) void bn_apply_grouped_kernel(const float* __re
     if (relu == 1) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        v.a[e] = fmaxf(v.a[e], 0.f);
-        v.b[e] = fmaxf(v.b[e], 0.f);
+        v.a[e] = relu_nan(v.a[e]);
+        v.b[e] = relu_nan(v.b[e]);
       }
     } else if (relu == 2) {   // GELU (erf), SVTR PatchEmbed (modules/svtr.py:227-233), as mrn_scale_shift_act_f32
 #pragma unroll
@@ -247,8 +247,8 @@ __global__ __launch_bounds__(256) void bn_apply_wino_grouped_kernel(const float*
         if (relu) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            v.a[e] = fmaxf(v.a[e], 0.f);
-            v.b[e] = fmaxf(v.b[e], 0.f);
+            v.a[e] = relu_nan(v.a[e]);
+            v.b[e] = relu_nan(v.b[e]);
           }
         }
         if (j >= 1 && j <= R) {                  // the group's own columns
@@ -330,16 +330,16 @@ __global__ __launch_bounds__(256) void maxpool_grouped_kernel(const float* __res
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          m.a[e] = fmaxf(m.a[e], v.a[e]);
-          m.b[e] = fmaxf(m.b[e], v.b[e]);
+          m.a[e] = max_nan(m.a[e], v.a[e]);
+          m.b[e] = max_nan(m.b[e], v.b[e]);
         }
       }
     }
     if (relu) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        m.a[e] = fmaxf(m.a[e], 0.f);
-        m.b[e] = fmaxf(m.b[e], 0.f);
+        m.a[e] = relu_nan(m.a[e]);
+        m.b[e] = relu_nan(m.b[e]);
       }
     }
     if (out) store8(out + i * 8, m);
@@ -395,16 +395,16 @@ __global__ __launch_bounds__(256) void maxpool_wino_grouped_kernel(const float* 
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              m.a[e] = fmaxf(m.a[e], v.a[e]);
-              m.b[e] = fmaxf(m.b[e], v.b[e]);
+              m.a[e] = max_nan(m.a[e], v.a[e]);
+              m.b[e] = max_nan(m.b[e], v.b[e]);
             }
           }
         }
         if (relu) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            m.a[e] = fmaxf(m.a[e], 0.f);
-            m.b[e] = fmaxf(m.b[e], 0.f);
+            m.a[e] = relu_nan(m.a[e]);
+            m.b[e] = relu_nan(m.b[e]);
           }
         }
         if (j >= 1 && j <= R) {

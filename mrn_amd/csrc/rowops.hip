@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void ew_rows_kernel(const float* __restrict__ 
       else if (op == 4) o[j] = av[j] > 0.f ? bv[j] : 0.f;
       else if (op == 5) o[j] = 1.f / (1.f + expf(-av[j]));
       else if (op == 6) o[j] = bv[j] * av[j] * (1.f - av[j]);
-      else o[j] = fmaxf(av[j] + bv[j], 0.f);
+      else o[j] = relu_nan(av[j] + bv[j]);
     }
     reinterpret_cast<f32x4*>(y + r * ldy)[c4] = o;
   }

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const float* __res
     }
     if (relu == 1) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.f);
+      for (int j = 0; j < 4; ++j) o[j] = relu_nan(o[j]);
     } else if (relu == 2) {   // GELU (erf), SVTR PatchEmbed (modules/svtr.py:227-233)
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = 0.5f * o[j] * (1.f + erff(o[j] * 0.70710678118654752440f));
@@ -173,8 +173,8 @@ __global__ __launch_bounds__(256) void maxpool_nhwc_kernel(const float* __restri
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float t = v[j] * sc[j] + sf[j];
-          if (relu) t = fmaxf(t, 0.f);
-          m[j] = fmaxf(m[j], t);
+          if (relu) t = relu_nan(t);
+          m[j] = max_nan(m[j], t);
         }
       }
     }
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void avgpool_nhwc_kernel(const float* __restri
   float s = 0.f;
   for (int p = 0; p < HW; ++p) {
     float t = xb[(long)p * C] * sc + sf;
-    if (relu) t = fmaxf(t, 0.f);
+    if (relu) t = relu_nan(t);
     s += t;
   }
   y[(long)b * C + c] = s / (float)HW;

@@ -169,15 +169,25 @@ class PackedConvWeight:
         return got
 
 
-def _dev_stream():
-    """(device index, raw handle of the current stream): two C calls -- torch.cuda.current_stream() builds a Stream object through five
-    Python frames, 4-8 us a call, ~1300 calls in a launch-bound SVTR loop-A step"""
-    dev = torch._C._cuda_getDevice()
-    return dev, torch._C._cuda_getCurrentRawStream(dev)
+# (device index, raw handle of the current stream) through two C calls: torch.cuda.current_stream() builds a Stream object through five
+# Python frames, 4-8 us a call, ~1300 calls in a launch-bound SVTR loop-A step.  The two torch._C entry points are private: resolved ONCE
+# here, with the public API as the fallback of a torch that renames them.
+_GET_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+_GET_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+if _GET_DEVICE is None or _GET_RAW_STREAM is None:
+    def _dev_stream():
+        dev = torch.cuda.current_device()
+        return dev, torch.cuda.current_stream(dev).cuda_stream
 
+    def _stream():
+        return torch.cuda.current_stream().cuda_stream
+else:
+    def _dev_stream():
+        dev = _GET_DEVICE()
+        return dev, _GET_RAW_STREAM(dev)
 
-def _stream():
-    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+    def _stream():
+        return _GET_RAW_STREAM(_GET_DEVICE())
 
 
 def _p(t):

@@ -73,6 +73,7 @@ KNIFE_EDGE_CAPS = {("crnn", "lwf/t0/delta/model.FeatureExtraction.ConvNet.14.wei
 # row-block kernel's run flips the ReLU, the x3 kernel's run sits at 3.7e-5 of the float64 movement; 182 other tensors need no entry:
 # their spread is <= 1.6 x the reference's own fp32-vs-float64 distance or under the 1e-2 floor)
 MOVEMENT_LOG = []
+_FLOWS_SEEN, _CAPS_VISITED = set(), set()     # (kind, flow) pairs whose movements were judged / cap entries that were actually used
 
 
 def _assert_movement(kind, name, k, mine, ref32):
@@ -102,6 +103,9 @@ def _assert_movement(kind, name, k, mine, ref32):
     e_cond = np.linalg.norm(mine - alt) / n64
     band = max(MOVEMENT_FACTOR * e_ref, MOVEMENT_FLOOR)
     spread = KNIFE_EDGE_CAPS.get((kind, name), max(COND_FACTOR * e_ref, COND_FLOOR))
+    _FLOWS_SEEN.add((kind, name.split("/")[0]))
+    if (kind, name) in KNIFE_EDGE_CAPS:
+        _CAPS_VISITED.add((kind, name))
     MOVEMENT_LOG.append(f"movement {kind} {name}: HIP vs f64 {e_hip:.3e} (alternate kernel {e_alt:.3e}), reference fp32 vs f64 {e_ref:.3e}, "
                         f"HIP kernel A vs B {e_cond:.3e}; band {band:.3e}, allowed spread {spread:.3e}")
     if os.environ.get("MRN_MOVEMENT_LOG"):          # (stdout is captured by the flows' own redirect: calibration runs log to a file)
@@ -520,3 +524,13 @@ def _joint_flow(tmp_path, kind):
             assert learner._known_classes == int(g[f"{pre}t{taski}/known_classes"])
     assert sink.getvalue().count("Current_score") == int(g[pre + "n_valid_calls"])
     assert sorted(os.listdir(f"./saved_models/{opt.exp_name}")) == [str(s) for s in g[pre + "checkpoints"]]
+
+
+def test_zz_movement_assertions_were_live():
+    """runs last in this file: the calibration switch turns _assert_movement into a logger, so a suite run with it set proves nothing
+     -- fail loudly; and every tensor exempted BY NAME in KNIFE_EDGE_CAPS must have been met by the flow it names, or a
+    renamed tensor has silently lost (or kept) its exemption"""
+    assert not os.environ.get("MRN_MOVEMENT_CALIBRATE"), "MRN_MOVEMENT_CALIBRATE is set: the movement assertions of this run were skipped"
+    for kind, name in KNIFE_EDGE_CAPS:
+        if (kind, name.split("/")[0]) in _FLOWS_SEEN:
+            assert (kind, name) in _CAPS_VISITED, f"KNIFE_EDGE_CAPS entry {(kind, name)} matched no tensor of its flow"

@@ -847,6 +847,20 @@ def test_patch_resident_conv(ops, G, B, H, W, Cin, Cout, shared):
     ypr, _ = ops.conv3x3_patch_x3(x_hl, G, shared, B, H, W, Cin, w_hl, w_scale, Cout, bias=cu(bias), act=ops.ACT_RELU, pool=True)
     refr, _, _ = ops.maxpool_grouped(yr, (2, 2), (2, 2), (0, 0), None, None, relu=False, want_f32=True, want_hl=False)
     assert torch.equal(ypr, refr)
+    # non-finite data: torch's max_pool2d / relu propagate NaN, v_max_f32 would return the finite neighbour.  One NaN
+    # activation poisons the 3 x 3 output positions around it (all channels): every pooled window that holds one must be NaN, in the
+    # pooled epilogue exactly where the separate pooling pass over the full map has it
+    xn = (x if shared else x[0]).clone()
+    xn[B - 1, 5, 7, 0] = float("nan")
+    xn_hl = ops.split_hl32(cu(xn))
+    w1, s1, b1 = w_hl[:w_hl.numel() // G], w_scale[:1], cu(bias)[:1].contiguous()
+    yn, _ = ops.conv3x3_patch_x3(xn_hl, 1, False, B, H, W, Cin, w1, s1, Cout, bias=b1, act=ops.ACT_RELU)
+    ynp, _ = ops.conv3x3_patch_x3(xn_hl, 1, False, B, H, W, Cin, w1, s1, Cout, bias=b1, act=ops.ACT_RELU, pool=True)
+    refn, _, _ = ops.maxpool_grouped(yn, (2, 2), (2, 2), (0, 0), None, None, relu=False, want_f32=True, want_hl=False)
+    want = torch.nn.functional.max_pool2d(yn[0].permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+    assert torch.isnan(yn[0, B - 1, 4:7, 6:9]).all() and int(torch.isnan(want).sum()) == 4 * Cout
+    assert torch.equal(torch.isnan(ynp[0]), torch.isnan(want)) and torch.equal(torch.isnan(refn[0]), torch.isnan(want))
+    assert torch.equal(torch.nan_to_num(ynp), torch.nan_to_num(refn))
 
 
 def test_sgd_and_adadelta_steps_vs_torch():

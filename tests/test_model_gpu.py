@@ -447,6 +447,128 @@ def _trba6_b32_case(net, sd, crops, classes, B, I):
         assert float((am[same] == am32[same]).float().mean()) >= 0.99
 
 
+def _ctc_family_b32_case(kind, classes, crops, seed):
+    """CRNN / SVTR + MRN at the bench's class counts, 32 crops, production lock-step schedule, against the CPU oracle in fp32 (the
+    reference's arithmetic, autograd through the router) and float64 (the conditioning yardstick).  No TPS stage in these families, so
+    the plain 1e-4 band of north_star has to hold on U(-1,1) noise as well as on smooth crops; indices bit-exact."""
+    from mrn_amd import functional as Fn
+    from mrn_amd.modules.model import MRNNet
+    from mrn_amd.tools import weights as W
+    from oracle import mrn_oracle as O
+    from tests.helpers import oracle_dtype
+    opt = make_opt(kind)
+    B, I = 32, len(classes)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = MRNNet(opt)
+        for c in classes:
+            net.update_fc(256, c)
+            net.build_prediction(opt, c)
+    W.fill_state_dict(net.state_dict(), seed=seed)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    net = net.cuda().train()
+    for n, p in net.named_parameters():
+        p.requires_grad = not n.startswith("model.")
+    if crops == "smooth":
+        image = torch.from_numpy(W.smooth_image(f"b32_{kind}", (B, 4, 32, 256), seed))
+    else:
+        image = torch.from_numpy(W.uniform(f"b32_{kind}", (B, 4, 32, 256), -1.0, 1.0, seed))
+    # CTC targets as CTCLabelConverter.encode lays them out (tools/utils.py:35-58): [B,25] long, [PAD] = 1 behind the label
+    lens = torch.from_numpy(W.randint("b32_len", (B,), 1, 26, seed)).int()
+    labels = torch.from_numpy(W.randint("b32_ctc", (B, 25), 4, classes[-1], seed))
+    labels[torch.arange(25)[None, :] >= lens[:, None]] = 1
+    lens[0] = 25
+    labels[0] = torch.from_numpy(W.randint("b32_ctc_full", (25,), 4, classes[-1], seed))       # a full-length label
+    domain = torch.from_numpy(W.randint("b32_dom", (B,), 0, 2, seed))
+    cfg = O.Cfg("None", "VGG" if kind == "crnn" else "SVTR", "BiLSTM" if kind == "crnn" else "None", "CTC")
+    masks = drop_masks(B, seed, "b32", I) if kind == "svtr" else None
+    names = [n for n in sd if not n.startswith("model.") and sd[n].is_floating_point()]
+    sd32 = {k: v.clone() for k, v in sd.items()}
+    for n in names:
+        sd32[n].requires_grad_(True)
+    out32 = O.mrn_forward(sd32, cfg, I, image, True, None, True, training=True, masks=[[m.clone() for m in ms] for ms in masks] if masks else None)
+    clf32 = O.ctc_loss(out32["logits"], labels, lens)
+    loss32 = 15 * clf32 + torch.nn.functional.cross_entropy(out32["index"], domain)
+    g32 = torch.autograd.grad(loss32, [sd32[n] for n in names])
+    with oracle_dtype(torch.float64) as od, torch.no_grad():
+        out64 = O.mrn_forward(od.cast(sd), cfg, I, image.double(), True, None, True, training=True,
+                              masks=[[m.double() for m in ms] for ms in masks] if masks else None)
+    w32, l32 = out32["index"].detach(), out32["logits"].detach()
+    band_w = float((w32.double() - out64["index"]).abs().max())
+    band_l = float((l32.double() - out64["logits"]).abs().max())
+    # ---- HIP, production schedule: the lock-step group(s) issued ahead on the side stream(s), as the learner's pipeline does
+    set_drop_masks_from(net, masks)
+    with torch.no_grad():
+        handle = net.experts_prefetch(image.cuda(), None, True)
+    assert handle is not None
+    out = net(image.cuda(), True, experts=handle)
+    clf = Fn.ctc_loss(out["logits"], labels.cuda(), lens.cuda())
+    loss = 15 * clf + Fn.cross_entropy(out["index"], domain.cuda(), -100)
+    loss.backward()
+    w, lg = out["index"].detach().cpu(), out["logits"].detach().cpu()
+    ew, el = float((w - w32).abs().max()), float((lg - l32).abs().max())
+    scale_l = float(l32.abs().max())
+    assert band_w < 1e-4 and band_l < 1e-4 * max(1.0, scale_l), (band_w, band_l)       # the premise: no ill-conditioned stage here
+    assert ew <= 1e-4, (ew, band_w)
+    assert el <= 1e-4 * max(1.0, scale_l), (el, band_l, scale_l)
+    assert abs(float(clf.detach()) - float(clf32.detach())) <= 1e-4 * max(1.0, abs(float(clf32.detach())))
+    assert abs(float(loss.detach()) - float(loss32.detach())) <= 1e-4 * max(1.0, abs(float(loss32.detach())))
+    top2 = out64["index"].sort(1, descending=True)[0]
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-4
+    assert int(clear.sum()) >= B - 4
+    assert torch.equal(w.argmax(1)[clear], w32.argmax(1)[clear]) and torch.equal(w.argmax(1)[clear], out64["index"].argmax(1)[clear])
+    # train-mode greedy CTC path (argmax over classes per frame): bit-exact wherever the float64 top-2 logit margin clears 1e-4
+    t2 = out64["logits"].topk(2, dim=2)[0]
+    clear_l = (t2[..., 0] - t2[..., 1]) > 2e-4 * max(1.0, scale_l)
+    assert float(clear_l.float().mean()) > 0.9
+    assert torch.equal(lg.argmax(2)[clear_l], l32.argmax(2)[clear_l])
+    mine = dict(net.named_parameters())
+    for n, gr in zip(names, g32):
+        if n == "route.bias":
+            assert float(gr.abs().max()) < 1e-5 and float(mine[n].grad.abs().max()) < 1e-5      # shift-invariant under softmax: round-off noise
+            continue
+        _grad_check(n, mine[n].grad, gr, rel_l2=2e-3, rel_max=1e-2)
+    # ---- eval routing + greedy CTC strings (test.py:validation's model call + preds.max(2) + converter.decode): integers, bit-exact
+    with torch.no_grad():
+        oe32 = O.mrn_forward({k: v.detach() for k, v in sd32.items()}, cfg, I, image, True, None, False, training=False)
+    net.eval()
+    with torch.no_grad():
+        oe = net(image.cuda(), True, None, False)
+    assert torch.equal(oe["index"].cpu(), oe32["index"]), (oe["index"].cpu(), oe32["index"])
+    am, am32 = oe["logits"].max(2)[1].cpu(), oe32["logits"].max(2)[1]
+    assert torch.equal(am, am32), int((am != am32).sum())
+    from mrn_amd.data.synthetic import synthetic_characters
+    from mrn_amd.tools.utils import CTCLabelConverter
+    with contextlib.redirect_stdout(io.StringIO()):
+        conv = CTCLabelConverter(synthetic_characters(classes[-1] - 4))
+    T = am.shape[1]
+    assert conv.decode(am.numpy(), [T] * B) == O.CTCConverter(synthetic_characters(classes[-1] - 4)).decode(am32.numpy(), [T] * B)
+    del net
+
+
+def set_drop_masks_from(net, masks):
+    """pin the DropPath draws of the SVTR experts to `masks` (per expert: 22 [B] 0/1 tensors, two per stochastic block)"""
+    if masks is None:
+        return
+    from mrn_amd.modules.svtr import DropPath
+    for e, ms in enumerate(masks):
+        mods = [m for m in net.model[e].modules() if isinstance(m, DropPath)]
+        assert len(mods) == 11 and len(ms) == 22
+        for j, m in enumerate(mods):
+            m.forced_masks = [ms[2 * j].clone(), ms[2 * j + 1].clone()]
+
+
+@pytest.mark.parametrize("crops", ["smooth", "noise"])
+def test_crnn3_batch32_full_class_counts_vs_oracle(crops):
+    """BASELINE config 2 at the bench's size: CRNN x 3 experts, CTC class counts 2090 / 2310 / 4038 (VERDICT r05 missing #3)"""
+    _ctc_family_b32_case("crnn", (2090, 2310, 4038), crops, seed=41)
+
+
+@pytest.mark.parametrize("crops", ["smooth", "noise"])
+def test_svtr6_batch32_full_class_counts_vs_oracle(crops):
+    """BASELINE config 4 at the bench's size: SVTR x 6 experts, CTC class counts 2090 ... 5373, injected DropPath draws"""
+    _ctc_family_b32_case("svtr", (2090, 2310, 4038, 5198, 5271, 5373), crops, seed=43)
+
+
 def _grad_check(name, mine, ref, rel_l2=2e-3, rel_max=2e-3):
     a = mine.detach().cpu().double().numpy()
     b = ref.detach().double().numpy()
