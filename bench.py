@@ -321,7 +321,7 @@ def describe_kernel(kind):
     nprod = 3 if arith == "fp16x3" else 1
     if staging.startswith("winorows"):
         R = int(staging[8])
-        return (f"wino_rows_kernel F({R},3)", BF16_MFMA_PEAK_TFLOPS, 3.0 * (R + 2) / (3 * R))
+        return (f"wino_rows_kernel F({R},3)", BF16_MFMA_PEAK_TFLOPS, nprod * (R + 2) / (3.0 * R))
     if staging.startswith("wino"):
         R = int(staging[4])
         return (f"conv_x3_kernel<2,4,2,1,false,3,{R}>", BF16_MFMA_PEAK_TFLOPS, 3.0 * (R + 2) / (3 * R))

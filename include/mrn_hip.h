@@ -179,6 +179,26 @@ int mrn_conv2d_x3_wino_pool_hl32(const void* v_hl, const void* u_hl, const void*
                                  const float* out_scale, const float* x_scale, int G, int64_t v_group_stride_bytes, int B, int H, int W,
                                  int Cin, int Cout, int R, int act, const void* bn_gamma_ptrs, void* stream);
 
+/* Reduced-precision mode (BASELINE configs 2 "bf16" and 5 "fp16 MFMA"; bench.py --precision fp16; never the parity path): the same
+ * F(4,3) row-block convolution of feature_extraction.py:165-199,262-294 with ONE fp16 product per term (fp32 accumulate, fp32 results)
+ * on PLAIN fp16 operands, 64 channels per 128-byte line -- a third of the MFMAs on half the operand bytes of the split form:
+ *   mrn_pack_weight_wino_d16            w [Cout][3][3][Cin] -> [Cout][6][Cin/64][3][128 B] = fp16(scale * G g)
+ *   mrn_bn_apply_wino_grouped_d16_f32   as mrn_bn_apply_wino_grouped_f32 (R = 4), V [G][B][H][ceil(W/4)][6][C/64][128 B] in fp16; the
+ *   mrn_maxpool_wino_grouped_d16_f32    plain fp32 / HL32 by-products (identity-shortcut sources) keep full precision
+ *   mrn_conv2d_x3_wino_d16              y, stats, out_scale, x_scale, v_group_stride_bytes as mrn_conv2d_x3_wino_hl32; pool != 0: the
+ *                                       pooled epilogue of mrn_conv2d_x3_wino_pool_hl32.  H % 4 == 0 and Cin % 64 == 0, else
+ *                                       MRN_ERR_UNSUPPORTED (there is no fallback kernel for this layout). */
+int mrn_pack_weight_wino_d16(const float* w_ohwi, void* out, int Cout, int Cin, const float* scale, void* stream);
+int mrn_bn_apply_wino_grouped_d16_f32(const float* y, const float* residual, const void* residual_hl32, const float* scale,
+                                      const float* shift, float* out_f32, void* out_hl32, void* out_wino_d16, int G, int B, int H,
+                                      int W, int C, int relu, const float* prescale, void* stream);
+int mrn_maxpool_wino_grouped_d16_f32(const float* x, const float* scale, const float* shift, int relu, float* out_f32, void* out_hl32,
+                                     void* out_wino_d16, int G, int B, int H, int W, int C, int kh, int kw, int sh, int sw, int ph,
+                                     int pw, void* stream);
+int mrn_conv2d_x3_wino_d16(const void* v_d16, const void* u_d16, const float* bias, float* y, float* stats, const float* out_scale,
+                           const float* x_scale, int G, int64_t v_group_stride_bytes, int B, int H, int W, int Cin, int Cout, int act,
+                           int pool, const void* bn_gamma_ptrs, void* stream);
+
 /* First convolution of the frozen experts' stacks (3x3, stride 1, padding 1, Cin = 4, Cout = 32 or 64: VGG conv 0
  * feature_extraction.py:19, ResNet conv0_1 :214, TPS localisation conv 1 transformation.py:60), G experts in one launch on the
  * exact-fp32 MFMA; x [Gx][B][H][W][4] with x_group_stride floats between groups (0: all experts read the same crops), w

@@ -73,7 +73,11 @@ extern "C" __attribute__((visibility("default"))) int mrn_wino_dbg_read(unsigned
 #endif
 
 // TOP / BOT: the row block has an input row above / below its four output rows inside the image (slot 0 / slot 5)
-template <int TOP, int BOT>
+// DENSE: the reduced-precision operand layout (one fp16 product per term): a 128-byte line holds 64 CHANNELS as plain fp16 (p.Cb = Cin / 64)
+// instead of [hi | lo] of 32.  The staging geometry is unchanged -- the "hi" half-line is channels 0 .. 31, the "lo" half-line channels
+// 32 .. 63 -- and a row-op multiplies matching halves (Bh.Ah + Bl.Al: two MFMAs per (kernel row, output row) for 64 channels) where the
+// split form takes the three cross products of 32: a third of the MFMAs on half the bytes.
+template <int TOP, int BOT, int DENSE>
 __device__ __forceinline__ void wino_rows_tile(const WinoRowsParams& p, unsigned char* lds, int g, int pos0, int oy0, int n0, int tile_m) {
   constexpr int LO = 1 - TOP, HI = 4 + BOT, NR = HI - LO + 1;      // input-row slots present: slot = iy - oy0 + 1
 #ifdef MRN_WPROBE_TIMING
@@ -166,6 +170,19 @@ __device__ __forceinline__ void wino_rows_tile(const WinoRowsParams& p, unsigned
   // the products of one input row (slot = iy - oy0 + 1, iy = oy + ky - 1  =>  block-local output row o = slot - ky); consecutive MFMAs
   // target different accumulators
   auto row_products = [&](int slot, int ks, int par) {
+    if constexpr (DENSE) {
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int o = slot - ky;
+        if (o >= 0 && o <= 3) acc[o] = mma(Bh[ks][ky], Ah[par], acc[o]);
+      }
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int o = slot - ky;
+        if (o >= 0 && o <= 3) acc[o] = mma(Bl[ks][ky], Al[par], acc[o]);
+      }
+      return;
+    }
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
       const int o = slot - ky;
@@ -253,7 +270,8 @@ __device__ __forceinline__ void wino_rows_tile(const WinoRowsParams& p, unsigned
       row_products(slot, ks, par);
 #ifndef MRN_WPROBE_CLUMPED
       if (r + 1 < 2 * NR) {
-        WINO_INTERLEAVE_3 WINO_INTERLEAVE_3 WINO_INTERLEAVE_3
+        WINO_INTERLEAVE_3 WINO_INTERLEAVE_3
+        if constexpr (!DENSE) { WINO_INTERLEAVE_3 }
       }
 #endif
       __builtin_amdgcn_sched_barrier(0);
@@ -437,6 +455,7 @@ __device__ __forceinline__ void wino_rows_tile(const WinoRowsParams& p, unsigned
   }
 }
 
+template <int DENSE>
 __global__ __launch_bounds__(256) void wino_rows_kernel(const WinoRowsParams p) {
   extern __shared__ __attribute__((aligned(128))) unsigned char lds[];
   // tile order: output-channel tile fastest, so the workgroups that share an XCD's L2 at one time read the same activation lines
@@ -452,11 +471,11 @@ __global__ __launch_bounds__(256) void wino_rows_kernel(const WinoRowsParams p) 
   const int tile_m = tp * p.row_blocks + rb;
   const bool top = oy0 > 0, bot = oy0 + 4 < p.H;
   if (top) {
-    if (bot) wino_rows_tile<1, 1>(p, lds, g, pos0, oy0, n0, tile_m);
-    else wino_rows_tile<1, 0>(p, lds, g, pos0, oy0, n0, tile_m);
+    if (bot) wino_rows_tile<1, 1, DENSE>(p, lds, g, pos0, oy0, n0, tile_m);
+    else wino_rows_tile<1, 0, DENSE>(p, lds, g, pos0, oy0, n0, tile_m);
   } else {
-    if (bot) wino_rows_tile<0, 1>(p, lds, g, pos0, oy0, n0, tile_m);
-    else wino_rows_tile<0, 0>(p, lds, g, pos0, oy0, n0, tile_m);
+    if (bot) wino_rows_tile<0, 1, DENSE>(p, lds, g, pos0, oy0, n0, tile_m);
+    else wino_rows_tile<0, 0, DENSE>(p, lds, g, pos0, oy0, n0, tile_m);
   }
 }
 
@@ -484,10 +503,12 @@ int mrn_launch_wino_rows(const WinoRowsParams& p0, void* stream) {
   const long tiles = (long)p.G * p.tiles_m * p.tiles_n;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)wino_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)wino_rows_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)wino_rows_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL(wino_rows_kernel, dim3((unsigned)tiles), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
+  if (p.dense) hipLaunchKernelGGL(wino_rows_kernel<1>, dim3((unsigned)tiles), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(wino_rows_kernel<0>, dim3((unsigned)tiles), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
   MRN_LAUNCH_CHECK("conv2d_wino_rows");
   return MRN_OK;
 }

@@ -2,8 +2,8 @@
 #pragma once
 
 struct WinoRowsParams {
-  const unsigned char* v;     // transformed activation [Gx][B][H][Wq][6][Cin/32][128 B]
-  const unsigned char* u;     // transformed weight [G][Cout][6][Cin/32][3][128 B]
+  const unsigned char* v;     // transformed activation [Gx][B][H][Wq][6][Cb][128 B]; Cb = Cin/32 HL32 lines, or (dense) Cin/64 fp16 lines
+  const unsigned char* u;     // transformed weight [G][Cout][6][Cb][3][128 B]
   const float* bias;          // [G][N] or null
   const float* out_scale;     // [G][2] = {s, 1/s} of the weight prescale or null
   const float* x_scale;       // [2] = {s, 1/s} of the activation operand or null
@@ -14,6 +14,7 @@ struct WinoRowsParams {
   int v_bytes;                // bytes of one group's activation
   int G, B, H, W, Wq, Cb, N, act;
   int stats_blocks;           // row blocks the statistics buffer was sized for (mrn_conv2d_x3_wino_stats_floats)
+  int dense;                  // 1: operands are plain fp16, 64 channels per line (one product per term: the reduced-precision mode)
   int pool;                   // 1: y is [G][B][H/2][W/2][N], per 2x2 window the extreme chosen by the sign of the BatchNorm weight
   const long long* gamma;     // [G] device addresses of those BatchNorm weights, or null (all maxima)
   int tiles_p, row_blocks, tiles_n, tiles_m;   // filled by the launcher

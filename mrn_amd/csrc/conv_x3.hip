@@ -1516,7 +1516,7 @@ __device__ __forceinline__ double wino_g(int R, int m, int kx) {
 // w [Cout][3][3][Cin] fp32 (OHWI) -> U [Cout][NC][Cin/32][3 (ky)][hi 32 | lo 32] with U_m = scale * sum_kx G[m][kx] * w[.][ky][kx][.],
 // the sum in double, split to hi + lo from the double; one thread = 8 channels of one (cout, component, ky)
 __global__ __launch_bounds__(256) void pack_weight_wino_hl32_kernel(const float* __restrict__ w, unsigned char* __restrict__ out,
-                                                                    int Cout, int Cin, int R, const float* __restrict__ scale) {
+                                                                    int Cout, int Cin, int R, const float* __restrict__ scale, int dense) {
   const double sc = scale ? (double)scale[0] : 1.0;
   const int Cb = Cin >> 5, NC = R + 2;
   const long n8 = (long)Cout * NC * 3 * (Cin >> 3);
@@ -1539,6 +1539,10 @@ __global__ __launch_bounds__(256) void pack_weight_wino_hl32_kernel(const float*
       const _Float16 ll = (_Float16)(u - (double)hh);
       h[e] = hh; l[e] = ll;
     }
+    if (dense) {           // plain fp16, 64 channels per line: [Cout][NC][Cin/64][3][128 B]
+      *reinterpret_cast<f16v8*>(out + (((o_ * NC + m) * (Cin >> 6) + (c8 >> 3)) * 3 + ky) * 128 + (c8 & 7) * 16) = h;
+      continue;
+    }
     const int cb = c8 >> 2;
     unsigned char* o = out + (((o_ * NC + m) * Cb + cb) * 3 + ky) * 128 + (c8 & 3) * 16;
     *reinterpret_cast<f16v8*>(o) = h;
@@ -1556,8 +1560,22 @@ MRN_EXPORT int mrn_pack_weight_wino_hl32(const float* w_ohwi, void* out, int Cou
   long grid = (n8 + 255) / 256;
   if (grid > 8192) grid = 8192;
   hipLaunchKernelGGL(pack_weight_wino_hl32_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, w_ohwi, (unsigned char*)out,
-                     Cout, Cin, R, scale);
+                     Cout, Cin, R, scale, 0);
   MRN_LAUNCH_CHECK("pack_weight_wino_hl32");
+  return MRN_OK;
+}
+
+// the same transform as PLAIN fp16 for the reduced-precision mode: w [Cout][3][3][Cin] fp32 -> [Cout][6][Cin/64][3][128 B] of
+// scale[0] * (G w), F(4,3), 64 channels per line (mrn_conv2d_x3_wino_d16's weight operand); Cin % 64 == 0
+MRN_EXPORT int mrn_pack_weight_wino_d16(const float* w_ohwi, void* out, int Cout, int Cin, const float* scale, void* stream) {
+  MRN_CHECK_ARG(w_ohwi && out && Cin % 64 == 0, "mrn_pack_weight_wino_d16: bad operands (Cin=%d)", Cin);
+  const long n8 = (long)Cout * 6 * 3 * (Cin / 8);
+  if (n8 == 0) return MRN_OK;
+  long grid = (n8 + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(pack_weight_wino_hl32_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, w_ohwi, (unsigned char*)out,
+                     Cout, Cin, 4, scale, 1);
+  MRN_LAUNCH_CHECK("pack_weight_wino_d16");
   return MRN_OK;
 }
 
@@ -1594,8 +1612,12 @@ MRN_EXPORT int64_t mrn_conv2d_x3_wino_stats_floats(int G, int B, int H, int W, i
 //   x_scale {s, 1/s} of an activation operand that was transformed as s * B^T(x) (trained layers), or NULL
 static int wino_conv_launch(const void* v_hl, const void* u_hl, const void* zero_page, const float* bias, float* y, float* stats,
                             const float* out_scale, const float* x_scale, int G, int64_t v_group_stride_bytes, int B, int H, int W, int Cin,
-                            int Cout, int R, int act, int pool, const void* bn_gamma_ptrs, void* stream) {
-  MRN_CHECK_ARG(v_hl && u_hl && zero_page && y && G >= 1 && (R == 2 || R == 4), "mrn_conv2d_x3_wino_hl32: bad operands");
+                            int Cout, int R, int act, int pool, const void* bn_gamma_ptrs, void* stream, int dense = 0) {
+  MRN_CHECK_ARG(v_hl && u_hl && (zero_page || dense) && y && G >= 1 && (R == 2 || R == 4), "mrn_conv2d_x3_wino_hl32: bad operands");
+  if (dense && !(mrn_wino_rows_supported(H, R, Cout) && Cin % 64 == 0)) {
+    mrn_set_error("mrn_conv2d_x3_wino_d16: the plain-fp16 form runs on the row-block kernel only (H %% 4 == 0, F(4,3), Cin %% 64 == 0; H=%d Cin=%d)", H, Cin);
+    return MRN_ERR_UNSUPPORTED;
+  }
   if (pool && !(mrn_wino_rows_supported(H, R, Cout) && H % 2 == 0 && W % 2 == 0)) {
     mrn_set_error("mrn_conv2d_x3_wino_pool_hl32: the pooled form needs the row-block kernel (mrn_conv2d_x3_wino_rows) and even H, W (%d x %d)", H, W);
     return MRN_ERR_UNSUPPORTED;
@@ -1612,9 +1634,11 @@ static int wino_conv_launch(const void* v_hl, const void* u_hl, const void* zero
     memset(&q, 0, sizeof(q));
     q.v = (const unsigned char*)v_hl; q.u = (const unsigned char*)u_hl; q.bias = bias; q.out_scale = out_scale; q.x_scale = x_scale;
     q.y = y; q.stats = stats;
-    q.v_gstride = v_group_stride_bytes; q.u_gstride = (long)Cout * 3 * NC * Cin * 4; q.y_gstride = (long)B * H * W * Cout;
-    q.v_bytes = (int)((long)B * H * Wq * NC * Cin * 4);
-    q.G = G; q.B = B; q.H = H; q.W = W; q.Wq = Wq; q.Cb = Cin / 32; q.N = Cout; q.act = act;
+    const int eb = dense ? 2 : 4;                 // operand bytes per (component, channel)
+    q.v_gstride = v_group_stride_bytes; q.u_gstride = (long)Cout * 3 * NC * Cin * eb; q.y_gstride = (long)B * H * W * Cout;
+    q.v_bytes = (int)((long)B * H * Wq * NC * Cin * eb);
+    q.G = G; q.B = B; q.H = H; q.W = W; q.Wq = Wq; q.Cb = Cin / (dense ? 64 : 32); q.N = Cout; q.act = act;
+    q.dense = dense;
     q.stats_blocks = wino_stats_blocks(B, H, W, Cout, R);
     q.pool = pool; q.gamma = (const long long*)bn_gamma_ptrs;
     return mrn_launch_wino_rows(q, stream);
@@ -1648,6 +1672,19 @@ MRN_EXPORT int mrn_conv2d_x3_wino_hl32(const void* v_hl, const void* u_hl, const
                                        int B, int H, int W, int Cin, int Cout, int R, int act, void* stream) {
   return wino_conv_launch(v_hl, u_hl, zero_page, bias, y, stats, out_scale, x_scale, G, v_group_stride_bytes, B, H, W, Cin, Cout, R, act, 0,
                           nullptr, stream);
+}
+
+// The reduced-precision form (ONE fp16 product per term, fp32 accumulate; BASELINE configs 2 / 5): the same F(4,3) row-block kernel on
+// PLAIN fp16 operands, 64 channels per 128-byte line -- a third of the MFMAs on half the bytes of the split form:
+//   v_d16 [Gx][B][H][ceil(W/4)][6][Cin/64][128 B]  (mrn_bn_apply_wino_grouped_d16_f32 / mrn_maxpool_wino_grouped_d16_f32)
+//   u_d16 [G][Cout][6][Cin/64][3][128 B]           (mrn_pack_weight_wino_d16), out_scale [G][2]
+// pool != 0: the pooled epilogue of mrn_conv2d_x3_wino_pool_hl32 (bn_gamma_ptrs as there).  H % 4 == 0, Cin % 64 == 0, else
+// MRN_ERR_UNSUPPORTED.  Statistics buffer: mrn_conv2d_x3_wino_stats_floats(G, B, H, W, Cout, 4).
+MRN_EXPORT int mrn_conv2d_x3_wino_d16(const void* v_d16, const void* u_d16, const float* bias, float* y, float* stats,
+                                      const float* out_scale, const float* x_scale, int G, int64_t v_group_stride_bytes, int B, int H,
+                                      int W, int Cin, int Cout, int act, int pool, const void* bn_gamma_ptrs, void* stream) {
+  return wino_conv_launch(v_d16, u_d16, nullptr, bias, y, stats, out_scale, x_scale, G, v_group_stride_bytes, B, H, W, Cin, Cout, 4, act,
+                          pool, bn_gamma_ptrs, stream, 1);
 }
 
 // mrn_conv2d_x3_wino_hl32 with the 2x2 / stride-2 max-pool that follows BatchNorm + ReLU taken in the epilogue (row-block kernel only:

@@ -43,6 +43,17 @@ __device__ __forceinline__ void store_hl(unsigned char* out, long row, int C, in
   *reinterpret_cast<f16v8*>(o + 64) = l;
 }
 
+// the reduced-precision operand line: 64 channels of plain fp16 per 128 bytes (conv_wino.hip, DENSE), saturating like store_hl
+__device__ __forceinline__ void store_d16(unsigned char* out, long row, int C, int c8, const F8& v) {
+  f16v8 h;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    h[e] = (_Float16)fminf(fmaxf(v.a[e], -65504.f), 65504.f);
+    h[4 + e] = (_Float16)fminf(fmaxf(v.b[e], -65504.f), 65504.f);
+  }
+  *reinterpret_cast<f16v8*>(out + (row * (C >> 6) + (c8 >> 3)) * 128 + (c8 & 7) * 16) = h;
+}
+
 // a block = 32 channels x 32 row lanes of one group over ONE CHUNK of the partial rows (coalesced 128-byte reads, sums in double as
 // bn_finalize_kernel, spatial.hip: same arithmetic), parameters through pointer tables.  gridDim.z chunks: the first layers come with up
 // to 16384 partial rows per expert (128-pixel blocks of the 32 x 256 maps) for 32 / 64 channels -- one wave per channel walked them in
@@ -207,7 +218,7 @@ __global__ __launch_bounds__(256) void bn_apply_wino_grouped_kernel(const float*
                                                                     float* __restrict__ out, unsigned char* __restrict__ out_hl,
                                                                     unsigned char* __restrict__ out_v, long imgrows_per_group, int W,
                                                                     int Wq, long n8, int C, int relu,
-                                                                    const float* __restrict__ prescale) {
+                                                                    const float* __restrict__ prescale, int dense) {
   constexpr int NC = R + 2;
   const float ps = prescale ? prescale[0] : 1.f;     // power-of-two range scale of a trained layer's operand (B^T is linear: applied once, after it)
   const int C8 = C >> 3, Cb = C >> 5;
@@ -286,7 +297,10 @@ __global__ __launch_bounds__(256) void bn_apply_wino_grouped_kernel(const float*
       }
     }
 #pragma unroll
-    for (int k = 0; k < NC; ++k) store_hl(out_v, t * NC + k, C, c8, m[k]);
+    for (int k = 0; k < NC; ++k) {
+      if (dense) store_d16(out_v, t * NC + k, C, c8, m[k]);
+      else store_hl(out_v, t * NC + k, C, c8, m[k]);
+    }
   }
 }
 
@@ -355,7 +369,7 @@ __global__ __launch_bounds__(256) void maxpool_wino_grouped_kernel(const float* 
                                                                    const float* __restrict__ shift, float* __restrict__ out,
                                                                    unsigned char* __restrict__ out_hl, unsigned char* __restrict__ out_v,
                                                                    int relu, int B, long n8, int H, int W, int C, int Ho, int Wo, int Wq,
-                                                                   int kh, int kw, int sh, int sw, int ph, int pw) {
+                                                                   int kh, int kw, int sh, int sw, int ph, int pw, int dense) {
   constexpr int NC = R + 2;
   const int C8 = C >> 3;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
@@ -443,7 +457,10 @@ __global__ __launch_bounds__(256) void maxpool_wino_grouped_kernel(const float* 
       }
     }
 #pragma unroll
-    for (int k = 0; k < NC; ++k) store_hl(out_v, t * NC + k, C, c8, m_[k]);
+    for (int k = 0; k < NC; ++k) {
+      if (dense) store_d16(out_v, t * NC + k, C, c8, m_[k]);
+      else store_hl(out_v, t * NC + k, C, c8, m_[k]);
+    }
   }
 }
 
@@ -593,10 +610,10 @@ MRN_EXPORT int mrn_bn_apply_grouped_f32(const float* y, const float* residual, c
 // out_wino [G][B][H][ceil(W/R)][R+2][C/32][128 B] receives B^T applied to out = act(y * scale + shift (+ residual)) per group of R
 // columns (zero padding outside the row); out_f32 (must NOT alias y: neighbouring groups re-read y) / out_hl32 optionally
 // receive the plain result.
-MRN_EXPORT int mrn_bn_apply_wino_grouped_f32(const float* y, const float* residual, const void* residual_hl32, const float* scale,
-                                             const float* shift, float* out_f32, void* out_hl32, void* out_wino, int G, int B, int H,
-                                             int W, int C, int R, int relu, const float* prescale, void* stream) {
-  MRN_CHECK_ARG(y && out_wino && C % 32 == 0 && (!scale == !shift) && !(residual && residual_hl32) && (R == 2 || R == 4) &&
+static int bn_apply_wino_launch(const float* y, const float* residual, const void* residual_hl32, const float* scale,
+                                const float* shift, float* out_f32, void* out_hl32, void* out_wino, int G, int B, int H,
+                                int W, int C, int R, int relu, const float* prescale, int dense, void* stream) {
+  MRN_CHECK_ARG(y && out_wino && C % (dense ? 64 : 32) == 0 && (!scale == !shift) && !(residual && residual_hl32) && (R == 2 || R == 4) &&
                     out_f32 != y && (uintptr_t)out_wino % 128 == 0,
                 "mrn_bn_apply_wino_grouped_f32: bad operands (C=%d R=%d)", C, R);
   const int Wq = (W + R - 1) / R;
@@ -607,13 +624,28 @@ MRN_EXPORT int mrn_bn_apply_wino_grouped_f32(const float* y, const float* residu
   if (R == 4)
     hipLaunchKernelGGL(bn_apply_wino_grouped_kernel<4>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, y, residual,
                        (const unsigned char*)residual_hl32, scale, shift, out_f32, (unsigned char*)out_hl32, (unsigned char*)out_wino,
-                       (long)B * H, W, Wq, n8, C, relu, prescale);
+                       (long)B * H, W, Wq, n8, C, relu, prescale, dense);
   else
     hipLaunchKernelGGL(bn_apply_wino_grouped_kernel<2>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, y, residual,
                        (const unsigned char*)residual_hl32, scale, shift, out_f32, (unsigned char*)out_hl32, (unsigned char*)out_wino,
-                       (long)B * H, W, Wq, n8, C, relu, prescale);
+                       (long)B * H, W, Wq, n8, C, relu, prescale, dense);
   MRN_LAUNCH_CHECK("bn_apply_wino_grouped");
   return MRN_OK;
+}
+
+MRN_EXPORT int mrn_bn_apply_wino_grouped_f32(const float* y, const float* residual, const void* residual_hl32, const float* scale,
+                                             const float* shift, float* out_f32, void* out_hl32, void* out_wino, int G, int B, int H,
+                                             int W, int C, int R, int relu, const float* prescale, void* stream) {
+  return bn_apply_wino_launch(y, residual, residual_hl32, scale, shift, out_f32, out_hl32, out_wino, G, B, H, W, C, R, relu, prescale, 0, stream);
+}
+
+// mrn_bn_apply_wino_grouped_f32 for the reduced-precision mode (one fp16 product per term): out_wino_d16 [G][B][H][ceil(W/4)][6][C/64][128 B]
+// receives the F(4,3) components as PLAIN fp16, 64 channels per line (mrn_conv2d_x3_wino_d16's activation operand); C % 64 == 0.  The plain
+// results (out_f32 / out_hl32: identity-shortcut sources) keep their full-precision forms.
+MRN_EXPORT int mrn_bn_apply_wino_grouped_d16_f32(const float* y, const float* residual, const void* residual_hl32, const float* scale,
+                                                 const float* shift, float* out_f32, void* out_hl32, void* out_wino_d16, int G, int B, int H,
+                                                 int W, int C, int relu, const float* prescale, void* stream) {
+  return bn_apply_wino_launch(y, residual, residual_hl32, scale, shift, out_f32, out_hl32, out_wino_d16, G, B, H, W, C, 4, relu, prescale, 1, stream);
 }
 
 // MaxPool2d over x [G][B][H][W][C] with the BatchNorm-apply (+ ReLU) of group g fused on the input (scale/shift [G][C] or NULL)
@@ -637,10 +669,10 @@ MRN_EXPORT int mrn_maxpool_grouped_f32(const float* x, const float* scale, const
 // mrn_maxpool_grouped_f32 as the producer of a Winograd F(R,3) convolution: out_wino [G][B][Ho][ceil(Wo/R)][R+2][C/32][128 B]
 // receives B^T applied to the pooled map per group of R pooled columns (zero padding outside the row); out_f32 / out_hl32 optionally
 // the plain pooled result (C % 32 == 0)
-MRN_EXPORT int mrn_maxpool_wino_grouped_f32(const float* x, const float* scale, const float* shift, int relu, float* out_f32,
-                                            void* out_hl32, void* out_wino, int G, int B, int H, int W, int C, int kh, int kw, int sh,
-                                            int sw, int ph, int pw, int R, void* stream) {
-  MRN_CHECK_ARG(x && out_wino && C % 32 == 0 && (!scale == !shift) && (R == 2 || R == 4) && (uintptr_t)out_wino % 128 == 0,
+static int maxpool_wino_launch(const float* x, const float* scale, const float* shift, int relu, float* out_f32,
+                               void* out_hl32, void* out_wino, int G, int B, int H, int W, int C, int kh, int kw, int sh,
+                               int sw, int ph, int pw, int R, int dense, void* stream) {
+  MRN_CHECK_ARG(x && out_wino && C % (dense ? 64 : 32) == 0 && (!scale == !shift) && (R == 2 || R == 4) && (uintptr_t)out_wino % 128 == 0,
                 "mrn_maxpool_wino_grouped_f32: bad operands (C=%d R=%d)", C, R);
   const int Ho = (H + 2 * ph - kh) / sh + 1, Wo = (W + 2 * pw - kw) / sw + 1;
   MRN_CHECK_ARG(Ho > 0 && Wo > 0, "mrn_maxpool_wino_grouped_f32: empty output");
@@ -651,12 +683,25 @@ MRN_EXPORT int mrn_maxpool_wino_grouped_f32(const float* x, const float* scale, 
   if (grid > 32768) grid = 32768;
   if (R == 4)
     hipLaunchKernelGGL(maxpool_wino_grouped_kernel<4>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, scale, shift, out_f32,
-                       (unsigned char*)out_hl32, (unsigned char*)out_wino, relu, B, n8, H, W, C, Ho, Wo, Wq, kh, kw, sh, sw, ph, pw);
+                       (unsigned char*)out_hl32, (unsigned char*)out_wino, relu, B, n8, H, W, C, Ho, Wo, Wq, kh, kw, sh, sw, ph, pw, dense);
   else
     hipLaunchKernelGGL(maxpool_wino_grouped_kernel<2>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, scale, shift, out_f32,
-                       (unsigned char*)out_hl32, (unsigned char*)out_wino, relu, B, n8, H, W, C, Ho, Wo, Wq, kh, kw, sh, sw, ph, pw);
+                       (unsigned char*)out_hl32, (unsigned char*)out_wino, relu, B, n8, H, W, C, Ho, Wo, Wq, kh, kw, sh, sw, ph, pw, dense);
   MRN_LAUNCH_CHECK("maxpool_wino_grouped");
   return MRN_OK;
+}
+
+MRN_EXPORT int mrn_maxpool_wino_grouped_f32(const float* x, const float* scale, const float* shift, int relu, float* out_f32,
+                                            void* out_hl32, void* out_wino, int G, int B, int H, int W, int C, int kh, int kw, int sh,
+                                            int sw, int ph, int pw, int R, void* stream) {
+  return maxpool_wino_launch(x, scale, shift, relu, out_f32, out_hl32, out_wino, G, B, H, W, C, kh, kw, sh, sw, ph, pw, R, 0, stream);
+}
+
+// mrn_maxpool_wino_grouped_f32 for the reduced-precision mode: out_wino_d16 [G][B][Ho][ceil(Wo/4)][6][C/64][128 B] plain fp16 (C % 64 == 0)
+MRN_EXPORT int mrn_maxpool_wino_grouped_d16_f32(const float* x, const float* scale, const float* shift, int relu, float* out_f32,
+                                                void* out_hl32, void* out_wino_d16, int G, int B, int H, int W, int C, int kh, int kw, int sh,
+                                                int sw, int ph, int pw, void* stream) {
+  return maxpool_wino_launch(x, scale, shift, relu, out_f32, out_hl32, out_wino_d16, G, B, H, W, C, kh, kw, sh, sw, ph, pw, 4, 1, stream);
 }
 
 // t = x + drop[r / rows_per_drop] * branch (branch NULL: t = x; drop NULL: 1) -> sum_out (optional, may alias x);

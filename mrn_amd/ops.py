@@ -508,7 +508,7 @@ def wgrad_wino_supported(dy, x, ksize, stride, padding):
     fill whole 32-group lines (B * ceil(W / 4) % 32 == 0), with operands range-scaled for the transforms (TRAIN_OPERAND_PEAK)"""
     B, H, W, Cout = dy.shape
     Cin = x.shape[-1]
-    return (TRAIN_WGRAD_WINO and TRAIN_WINO and WINO_R == 4 and TRAIN_PRODUCTS == 3 and wino_eligible(ksize, stride, padding, Cin, Cout)
+    return (TRAIN_WGRAD_WINO and TRAIN_WINO and WINO_R == 4 and TRAIN_PRODUCTS == 3 and wino_eligible(ksize, stride, padding, Cin, Cout, 3)
             and H >= 2 and (B * ((W + 3) // 4)) % 32 == 0 and Cout % 4 == 0 and tuple(x.shape[:3]) == (B, H, W))
 
 
@@ -648,18 +648,36 @@ TRAIN_WINO = os.environ.get("MRN_TRAIN_WINO", "1") == "1"      # the trained con
 TRAIN_OPERAND_PEAK = 16384.0 / 16 if TRAIN_WINO else 16384.0
 
 
-def wino_eligible(ksize, stride, padding, Cin, Cout):
-    return (WINO_R in (2, 4) and tuple(ksize) == (3, 3) and tuple(stride) == (1, 1) and tuple(padding) == (1, 1)
-            and Cin % 32 == 0 and Cin >= WINO_MIN_CIN and Cout >= 64 and X3_PRODUCTS == 3)
+# Reduced-precision mode (X3_PRODUCTS / TRAIN_PRODUCTS == 1): the Winograd layers run the row-block kernel on PLAIN fp16 operands, 64 channels
+# per 128-byte line ("d16": a third of the MFMAs on half the operand bytes; csrc/conv_wino.hip DENSE).  MRN_WINO_DENSE=0: the round-5 form of
+# the mode (no Winograd, direct one-product convolutions on HL32 lines whose lo halves are not read) -- the A/B partner.
+WINO_DENSE = os.environ.get("MRN_WINO_DENSE", "1") == "1"
 
 
-def pack_weights_wino(ws, R, scale=None):
-    """list of G [O,3,3,I] fp32 weights -> (Winograd-domain HL32 stack bytes [G][O][R+2][I/32][3][128], scale [G,2])"""
+def wino_dense(products=None):
+    """does a Winograd layer of a `products`-product pass (None: the frozen experts' X3_PRODUCTS) run on plain-fp16 operands"""
+    return (X3_PRODUCTS if products is None else products) == 1 and WINO_DENSE and WINO_R == 4
+
+
+def wino_eligible(ksize, stride, padding, Cin, Cout, products=None):
+    """products: of the pass that asks (None: X3_PRODUCTS, the frozen experts; the trained layers pass TRAIN_PRODUCTS)"""
+    products = X3_PRODUCTS if products is None else products
+    ok = (WINO_R in (2, 4) and tuple(ksize) == (3, 3) and tuple(stride) == (1, 1) and tuple(padding) == (1, 1)
+          and Cin % 32 == 0 and Cin >= WINO_MIN_CIN and Cout >= 64)
+    if products == 3:
+        return ok
+    return ok and wino_dense(products) and Cin % 64 == 0 and Cout % 4 == 0          # (the d16 form has no fallback kernel: row-block geometry only)
+
+
+def pack_weights_wino(ws, R, scale=None, dense=None):
+    """list of G [O,3,3,I] fp32 weights -> (Winograd-domain HL32 stack bytes [G][O][R+2][I/32][3][128], scale [G,2]); dense (None:
+    wino_dense()): plain fp16 [G][O][6][I/64][3][128]"""
     O, kh, kw, I = ws[0].shape
     assert (kh, kw) == (3, 3)
     G = len(ws)
     dev = ws[0].device
-    per = O * (R + 2) * 3 * I * 4
+    dense = wino_dense() if dense is None else dense
+    per = O * (R + 2) * 3 * I * (2 if dense else 4)
     out = torch.empty(G * per, device=dev, dtype=torch.uint8)
     known = scale is not None
     if not known:
@@ -669,24 +687,34 @@ def pack_weights_wino(ws, R, scale=None):
         assert tuple(w.shape) == (O, 3, 3, I) and w.is_contiguous()
         if not known:
             call("mrn_pow2_scale_f32", _p(w), w.numel(), FP16_WEIGHT_PEAK, scale[g].data_ptr(), _pow2_ws(), _stream())
-        call("mrn_pack_weight_wino_hl32", _p(w), out.data_ptr() + g * per, O, I, R, scale[g].data_ptr(), _stream())
+        if dense:
+            call("mrn_pack_weight_wino_d16", _p(w), out.data_ptr() + g * per, O, I, scale[g].data_ptr(), _stream())
+        else:
+            call("mrn_pack_weight_wino_hl32", _p(w), out.data_ptr() + g * per, O, I, R, scale[g].data_ptr(), _stream())
     return out, scale
 
 
-def bn_apply_wino_grouped(y, scale, shift, R, relu=True, residual=None, residual_hl=None, want_f32=False, want_hl=False, prescale=None):
+def bn_apply_wino_grouped(y, scale, shift, R, relu=True, residual=None, residual_hl=None, want_f32=False, want_hl=False, prescale=None,
+                          dense=None):
     """y [G,B,H,W,C] fp32 -> (fp32 result (a NEW tensor) or None, HL32 bytes or None, Winograd-domain operand bytes
-    [G][B][H][ceil(W/R)][R+2][C/32][128])"""
+    [G][B][H][ceil(W/R)][R+2][C/32][128]); dense (None: wino_dense()): the operand as plain fp16 [..][R+2][C/64][128]"""
     G, B, H, W, C = y.shape
     Wq = (W + R - 1) // R
+    dense = wino_dense() if dense is None else dense
+    eb = 2 if dense else 4
     out = torch.empty_like(y) if want_f32 else None
     out_hl = torch.empty(y.numel() * 4, device=y.device, dtype=torch.uint8) if want_hl else None
-    v = torch.empty(G * B * H * Wq * (R + 2) * C * 4, device=y.device, dtype=torch.uint8)
+    v = torch.empty(G * B * H * Wq * (R + 2) * C * eb, device=y.device, dtype=torch.uint8)
     t0 = CONV_TIMER.begin("bnw") if CONV_TIMER is not None else None
-    call("mrn_bn_apply_wino_grouped_f32", _p(y), _p(residual), _p(residual_hl), _p(scale), _p(shift), _p(out), _p(out_hl), _p(v),
-         G, B, H, W, C, R, int(bool(relu)), _p(prescale), _stream())
+    if dense:
+        call("mrn_bn_apply_wino_grouped_d16_f32", _p(y), _p(residual), _p(residual_hl), _p(scale), _p(shift), _p(out), _p(out_hl), _p(v),
+             G, B, H, W, C, int(bool(relu)), _p(prescale), _stream())
+    else:
+        call("mrn_bn_apply_wino_grouped_f32", _p(y), _p(residual), _p(residual_hl), _p(scale), _p(shift), _p(out), _p(out_hl), _p(v),
+             G, B, H, W, C, R, int(bool(relu)), _p(prescale), _stream())
     if t0 is not None:       # algorithmic bytes: every input / output element once; the transformed operand is (R+2)/R elements per element
         n_io = 1 + int(residual is not None or residual_hl is not None) + int(want_f32) + int(want_hl)
-        CONV_TIMER.end(t0, 0.0, "hbm/bn_apply_wino_grouped", 4.0 * y.numel() * n_io + 4.0 * G * B * H * Wq * (R + 2) * C)
+        CONV_TIMER.end(t0, 0.0, "hbm/bn_apply_wino_grouped", 4.0 * y.numel() * n_io + float(eb) * G * B * H * Wq * (R + 2) * C)
     return out, out_hl, v
 
 
@@ -696,7 +724,7 @@ def wino_pool_supported(H, W, R, Cout):
 
 
 def conv2d_x3_wino(v_hl, G, shared_input, B, H, W, Cin, u_hl, u_scale, Cout, R, bias=None, act=ACT_NONE, want_stats=False, out=None,
-                   x_scale=None, pool=False, gamma_ptrs=None):
+                   x_scale=None, pool=False, gamma_ptrs=None, dense=None):
     """3x3 / stride 1 / pad 1 grouped conv on Winograd-domain operands -> (y [G,B,H,W,Cout] fp32, stats or None).
     pool (wino_pool_supported): y is the [G,B,H/2,W/2,Cout] map of per-window extremes (maxima where the BatchNorm weight that follows is
     >= 0 -- gamma_ptrs: int64 device tensor [G] of the weights' addresses, None: all maxima -- minima elsewhere), see conv3x3_patch_x3"""
@@ -706,16 +734,21 @@ def conv2d_x3_wino(v_hl, G, shared_input, B, H, W, Cin, u_hl, u_scale, Cout, R, 
     if want_stats:
         stats = torch.empty(call("mrn_conv2d_x3_wino_stats_floats", G, B, H, W, Cout, R), device=dev, dtype=torch.float32)
     Wq = (W + R - 1) // R
-    gstride = 0 if shared_input else B * H * Wq * (R + 2) * Cin * 4
+    dense = wino_dense() if dense is None else dense
+    eb = 2 if dense else 4
+    gstride = 0 if shared_input else B * H * Wq * (R + 2) * Cin * eb
     timed = CONV_TIMER is not None
     t0 = CONV_TIMER.begin("wino") if timed else None
-    if pool:
+    if dense:           # (reduced-precision mode: plain fp16 operands, one product per term; row-block kernel only -- fails loudly otherwise)
+        call("mrn_conv2d_x3_wino_d16", _p(v_hl), _p(u_hl), _p(bias), _p(y), _p(stats), _p(u_scale), _p(x_scale), G, gstride, B, H, W, Cin,
+             Cout, act, int(bool(pool)), _p(gamma_ptrs), _stream())
+    elif pool:
         call("mrn_conv2d_x3_wino_pool_hl32", _p(v_hl), _p(u_hl), _p(_zero_page(dev)), _p(bias), _p(y), _p(stats), _p(u_scale), _p(x_scale), G,
              gstride, B, H, W, Cin, Cout, R, act, _p(gamma_ptrs), _stream())
     else:
         call("mrn_conv2d_x3_wino_hl32", _p(v_hl), _p(u_hl), _p(_zero_page(dev)), _p(bias), _p(y), _p(stats), _p(u_scale), _p(x_scale), G,
              gstride, B, H, W, Cin, Cout, R, act, _stream())
-    if WINO_CHECK and not pool and call("mrn_conv2d_x3_wino_rows", H, R, Cout):
+    if WINO_CHECK and not pool and not dense and call("mrn_conv2d_x3_wino_rows", H, R, Cout):
         # debug (MRN_WINO_CHECK=1): the same call on the x3 kernel's Winograd form, compared element by element
         call("mrn_conv2d_x3_wino_select", 0)
         y2 = torch.empty_like(y)
@@ -738,8 +771,9 @@ def conv2d_x3_wino(v_hl, G, shared_input, B, H, W, Cin, u_hl, u_scale, Cout, R, 
                   "c range", int(idx[:, 4].min()), int(idx[:, 4].max()), "y set", sorted(set(idx[:, 2].tolist())), flush=True, file=sys.__stderr__)
     if timed:
         # algorithmic flops = the convolution's (2 * 9 * Cin per output element); the kernel executes (R+2)/(3R) of them as MFMA products
-        nbytes = 4.0 * ((1 if shared_input else G) * B * H * Wq * (R + 2) * Cin + G * Cout * 3 * (R + 2) * Cin + G * B * H * W * Cout)
-        kind = ("fp16x3/winorows%d" if call("mrn_conv2d_x3_wino_rows", H, R, Cout) else "fp16x3/wino%dg128x128") % R
+        nbytes = (float(eb) * ((1 if shared_input else G) * B * H * Wq * (R + 2) * Cin + G * Cout * 3 * (R + 2) * Cin)
+                  + 4.0 * G * B * (H // 2 if pool else H) * (W // 2 if pool else W) * Cout)
+        kind = (("fp16" if dense else "fp16x3") + "/winorows%d" if call("mrn_conv2d_x3_wino_rows", H, R, Cout) else "fp16x3/wino%dg128x128") % R
         if TIMER_SHAPES:
             kind += "|G%d B%d %dx%d %d->%d k3x3 s11" % (G, B, H, W, Cin, Cout)
         CONV_TIMER.end(t0, 2.0 * G * B * H * W * Cout * 9 * Cin, kind, nbytes)
@@ -793,15 +827,17 @@ def train_pack(kind, params, build):
     return val
 
 
-def trained_weight_operand(w_ohwi, stride, padding):
-    """-> ("wino", Winograd-domain stack, scale) or ("hl32", HL32 stack, scale) of one trained layer's [O,kh,kw,I] weights"""
+def trained_weight_operand(w_ohwi, stride, padding, H=None):
+    """-> ("wino", Winograd-domain stack, scale) or ("hl32", HL32 stack, scale) of one trained layer's [O,kh,kw,I] weights; H: rows of
+    the map it is applied to (the plain-fp16 Winograd form of the reduced mode exists on the row-block kernel only: H % 4 == 0)"""
     Cout, kh, kw, Cin = w_ohwi.shape
-    wino = TRAIN_WINO and TRAIN_PRODUCTS == 3 and wino_eligible((kh, kw), stride, padding, Cin, Cout)
+    dense = wino_dense(TRAIN_PRODUCTS)
+    wino = TRAIN_WINO and wino_eligible((kh, kw), stride, padding, Cin, Cout, TRAIN_PRODUCTS) and (not dense or (H is not None and H % 4 == 0))
 
     def build():
         w = w_ohwi.contiguous()
-        return ("wino",) + tuple(pack_weights_wino([w], WINO_R)) if wino else ("hl32",) + tuple(pack_weights_hl32([w]))
-    return _memo(_wkey("op", w_ohwi, wino, WINO_R), w_ohwi, build)
+        return ("wino",) + tuple(pack_weights_wino([w], WINO_R, dense=dense)) if wino else ("hl32",) + tuple(pack_weights_hl32([w]))
+    return _memo(_wkey("op", w_ohwi, wino, WINO_R, dense), w_ohwi, build)
 
 
 def trained_dgrad_weight(w_ohwi):
@@ -828,17 +864,19 @@ def prepack_trained():
             new = {}
             if w.shape[-1] % 32 == 0:                        # (what conv2d_nhwc sends to conv2d_x3_scaled)
                 Cout, _, _, Cin = w.shape
-                wino = TRAIN_WINO and TRAIN_PRODUCTS == 3 and wino_eligible((kh, kw), stride, padding, Cin, Cout)
+                dense = wino_dense(TRAIN_PRODUCTS)          # (H unknown here: a layer on a map the d16 form cannot take misses and packs in place)
+                wino = TRAIN_WINO and wino_eligible((kh, kw), stride, padding, Cin, Cout, TRAIN_PRODUCTS)
                 wc = w.contiguous()
-                new[_wkey("op", w, wino, WINO_R)] = (("wino",) + tuple(pack_weights_wino([wc], WINO_R)) if wino
-                                                     else ("hl32",) + tuple(pack_weights_hl32([wc])), w)
+                new[_wkey("op", w, wino, WINO_R, dense)] = (("wino",) + tuple(pack_weights_wino([wc], WINO_R, dense=dense)) if wino
+                                                            else ("hl32",) + tuple(pack_weights_hl32([wc])), w)
             wt = pack_dgrad_weight(w)
             new[_wkey("dgrad", w)] = (wt, w)
             if wt.ohwi.shape[-1] % 32 == 0:
                 dpad = (kh - 1 - padding[0], kw - 1 - padding[1])
-                wino = TRAIN_WINO and TRAIN_PRODUCTS == 3 and wino_eligible((kh, kw), (1, 1), dpad, wt.ohwi.shape[-1], wt.ohwi.shape[0])
-                new[_wkey("op", wt.ohwi, wino, WINO_R)] = (("wino",) + tuple(pack_weights_wino([wt.ohwi], WINO_R)) if wino
-                                                           else ("hl32",) + tuple(pack_weights_hl32([wt.ohwi])), wt.ohwi)
+                dense = wino_dense(TRAIN_PRODUCTS)
+                wino = TRAIN_WINO and wino_eligible((kh, kw), (1, 1), dpad, wt.ohwi.shape[-1], wt.ohwi.shape[0], TRAIN_PRODUCTS)
+                new[_wkey("op", wt.ohwi, wino, WINO_R, dense)] = (("wino",) + tuple(pack_weights_wino([wt.ohwi], WINO_R, dense=dense)) if wino
+                                                                  else ("hl32",) + tuple(pack_weights_hl32([wt.ohwi])), wt.ohwi)
             ev = torch.cuda.Event()
             ev.record(side)
             for k, (val, src) in new.items():
@@ -925,14 +963,15 @@ def conv2d_x3_scaled(x, w_ohwi, bias, stride, padding, act=ACT_NONE, want_stats=
     x = x.contiguous()
     if sx is None:
         sx = pow2_scale(x, TRAIN_OPERAND_PEAK)          # (callers that use x in several GEMMs compute it once: ConvBlockFn)
-    kind, w_hl, sw = trained_weight_operand(w_ohwi, stride, padding)
+    kind, w_hl, sw = trained_weight_operand(w_ohwi, stride, padding, H)
     if kind == "wino":
         # Winograd F(R,3) along W, as for the frozen experts (conv_x3.hip WINO): the operand pass applies B^T to sx * x in place of the
         # plain split, the weights are re-transformed with the step's values.  Serves the forward AND the data-gradient convolutions of
         # loop A (conv2d_dgrad arrives here with the flipped weights and the gradient's own range scale).
         R = WINO_R
-        _, _, v = bn_apply_wino_grouped(x.view(1, B, H, W, Cin), None, None, R, relu=False, prescale=sx)
-        y, stats = conv2d_x3_wino(v, 1, False, B, H, W, Cin, w_hl, sw, Cout, R, bias=bias, act=act, want_stats=want_stats, x_scale=sx)
+        dense = wino_dense(TRAIN_PRODUCTS)
+        _, _, v = bn_apply_wino_grouped(x.view(1, B, H, W, Cin), None, None, R, relu=False, prescale=sx, dense=dense)
+        y, stats = conv2d_x3_wino(v, 1, False, B, H, W, Cin, w_hl, sw, Cout, R, bias=bias, act=act, want_stats=want_stats, x_scale=sx, dense=dense)
         return y[0], stats
     y, stats = conv2d_x3(split_hl32(x, sx), 1, False, B, H, W, Cin, w_hl, sw, Cout, (kh, kw), stride, padding, bias=bias, act=act,
                          want_stats=want_stats, x_scale=sx, products=TRAIN_PRODUCTS)
@@ -1078,16 +1117,22 @@ def maxpool_grouped(x, kernel, stride, padding, scale=None, shift=None, relu=Fal
     return out, out_hl, (Ho, Wo)
 
 
-def maxpool_wino_grouped(x, kernel, stride, padding, R, scale=None, shift=None, relu=False, want_f32=False, want_hl=False):
-    """x [G,B,H,W,C] -> (fp32 [G,B,Ho,Wo,C] or None, HL32 bytes or None, Winograd-domain operand bytes of the pooled map, (Ho, Wo))"""
+def maxpool_wino_grouped(x, kernel, stride, padding, R, scale=None, shift=None, relu=False, want_f32=False, want_hl=False, dense=None):
+    """x [G,B,H,W,C] -> (fp32 [G,B,Ho,Wo,C] or None, HL32 bytes or None, Winograd-domain operand bytes of the pooled map, (Ho, Wo));
+    dense (None: wino_dense()): the operand as plain fp16"""
     G, B, H, W, C = x.shape
     Ho, Wo = conv_out_hw(H, W, kernel, stride, padding)
     Wq = (Wo + R - 1) // R
+    dense = wino_dense() if dense is None else dense
     out = torch.empty(G, B, Ho, Wo, C, device=x.device, dtype=torch.float32) if want_f32 else None
     out_hl = torch.empty(G * B * Ho * Wo * C * 4, device=x.device, dtype=torch.uint8) if want_hl else None
-    v = torch.empty(G * B * Ho * Wq * (R + 2) * C * 4, device=x.device, dtype=torch.uint8)
-    call("mrn_maxpool_wino_grouped_f32", _p(x), _p(scale), _p(shift), int(bool(relu)), _p(out), _p(out_hl), _p(v), G, B, H, W, C,
-         kernel[0], kernel[1], stride[0], stride[1], padding[0], padding[1], R, _stream())
+    v = torch.empty(G * B * Ho * Wq * (R + 2) * C * (2 if dense else 4), device=x.device, dtype=torch.uint8)
+    if dense:
+        call("mrn_maxpool_wino_grouped_d16_f32", _p(x), _p(scale), _p(shift), int(bool(relu)), _p(out), _p(out_hl), _p(v), G, B, H, W, C,
+             kernel[0], kernel[1], stride[0], stride[1], padding[0], padding[1], _stream())
+    else:
+        call("mrn_maxpool_wino_grouped_f32", _p(x), _p(scale), _p(shift), int(bool(relu)), _p(out), _p(out_hl), _p(v), G, B, H, W, C,
+             kernel[0], kernel[1], stride[0], stride[1], padding[0], padding[1], R, _stream())
     return out, out_hl, v, (Ho, Wo)
 
 

@@ -1058,6 +1058,88 @@ def test_winograd_conv_matches_direct(ops, cfg, R):
         assert torch.equal(got, ref)
 
 
+D16_CONVS = [(6, 2, 4, 65, 512, 512, "none", True), (2, 32, 4, 65, 64, 160, "hl32", True), (2, 2, 16, 32, 64, 64, "none", True),
+             (1, 3, 12, 20, 128, 96, "f32", False), (3, 4, 8, 64, 128, 256, "none", True)]
+
+
+@pytest.mark.parametrize("cfg", D16_CONVS)
+def test_winograd_d16_reduced_mode(ops, cfg):
+    """The reduced-precision form of the row-block Winograd convolution (mrn_bn_apply_wino_grouped_d16_f32 -> mrn_conv2d_x3_wino_d16 +
+    mrn_pack_weight_wino_d16: ONE fp16 product per term on plain-fp16 operands, 64 channels per line) against (a) float64 arithmetic on
+    the SAME fp16-quantised Winograd operands -- the kernel's own contract: fp32 accumulation of exact fp16 products, 1e-5 of the output
+    scale -- and (b) the float64 convolution of the unquantised data: the fp16 mode's accuracy, a few 1e-3 of the scale (rms 1e-3).
+    Plain by-products of the producer keep full precision; statistics, ReLU and the pooled epilogue behave as in the split form."""
+    G, B, H, W, Cin, Cout, shortcut, relu = cfg
+    R = 4
+    yprev = rnd(G, B, H, W, Cin, seed=300)
+    scale, shift = rnd(G, Cin, seed=301) + 1.5, rnd(G, Cin, seed=302) * 0.5
+    res = rnd(G, B, H, W, Cin, seed=303) if shortcut != "none" else None
+    ws = [rnd(Cout, Cin, 3, 3, seed=310 + g, scale=(2.0 / (Cin * 9)) ** 0.5) for g in range(G)]
+    bias = rnd(G, Cout, seed=320)
+    a = yprev.double() * scale.double()[:, None, None, None, :] + shift.double()[:, None, None, None, :]
+    if res is not None:
+        a = a + res.double()
+    if relu:
+        a = a.clamp_min(0)
+    refs = torch.stack([F.conv2d(a[g].permute(0, 3, 1, 2), ws[g].double(), bias[g].double(), 1, 1).permute(0, 2, 3, 1) for g in range(G)])
+    resd = cu(res) if res is not None else None
+    f32, hl, v = ops.bn_apply_wino_grouped(cu(yprev), cu(scale), cu(shift), R, relu=relu, residual=resd if shortcut == "f32" else None,
+                                           residual_hl=ops.split_hl32(resd) if shortcut == "hl32" else None, want_f32=True, want_hl=True,
+                                           dense=True)
+    Wq = (W + 3) // 4
+    assert v.numel() == G * B * H * Wq * 6 * Cin * 2                   # half the bytes of the split operand
+    assert_close("producer fp32 by-product", f32, a.float(), atol=4e-6 if shortcut == "hl32" else 1e-6, rtol=4e-6)
+    hv = hl.view(torch.float16).view(-1, Cin // 32, 2, 32).float()
+    assert_close("producer HL32 by-product", (hv[:, :, 0] + hv[:, :, 1]).reshape(f32.shape), f32, atol=1e-6, rtol=2e-7)
+    u, u_scale = ops.pack_weights_wino([cu(w.permute(0, 2, 3, 1).contiguous()) for w in ws], R, dense=True)
+    assert u.numel() == G * Cout * 6 * 3 * Cin * 2
+    y, stats = ops.conv2d_x3_wino(v, G, False, B, H, W, Cin, u, u_scale, Cout, R, bias=cu(bias), want_stats=True, dense=True)
+    # (a) float64 on the quantised operands: V [G,B,H,Wq,6,Cin] fp16, U [G,Cout,6,Cin/64,3,64] fp16 (scaled), A^T with the row scales of G
+    Vq = v.view(torch.float16).view(G, B, H, Wq, 6, Cin).double().cpu()
+    Uq = u.view(torch.float16).view(G, Cout, 6, Cin // 64, 3, 64).double().cpu().permute(0, 1, 2, 4, 3, 5).reshape(G, Cout, 6, 3, Cin)
+    AT = torch.tensor([[0.25, 0.5, 0.5, 0.5, 0.5, 0.0], [0.0, 0.5, -0.5, 1.0, -1.0, 0.0], [0.0, 0.5, 0.5, 2.0, 2.0, 0.0],
+                       [0.0, 0.5, -0.5, 4.0, -4.0, 1.0]], dtype=torch.float64)
+    inv = u_scale.double().cpu()[:, 1]
+    Vp = torch.nn.functional.pad(Vq, (0, 0, 0, 0, 0, 0, 1, 1))            # one zero image row above and below
+    T = torch.zeros(G, B, H, Wq, 6, Cout, dtype=torch.float64)
+    for ky in range(3):
+        T += torch.einsum("gbhqmc,gomc->gbhqmo", Vp[:, :, ky:ky + H], Uq[:, :, :, ky])
+    yq = torch.einsum("rm,gbhqmo->gbhqro", AT, T).reshape(G, B, H, Wq * 4, Cout)[:, :, :, :W] * inv[:, None, None, None, None]
+    yq = yq + bias.double()[:, None, None, None, :]
+    sc = float(refs.abs().max())
+    err_q = float((y.double().cpu() - yq).abs().max())
+    assert err_q <= 1e-5 * sc, (err_q, sc)
+    # (b) the mode's accuracy against the unquantised convolution
+    d = y.double().cpu() - refs
+    assert float(d.abs().max()) <= 1.5e-2 * sc and float(d.pow(2).mean().sqrt()) <= 2e-3 * sc, (float(d.abs().max()), float(d.pow(2).mean().sqrt()), sc)
+    assert float(d.abs().max()) > 1e-5 * sc                                # (it really is the one-product form)
+    tot = stats.view(G, -1, 2, Cout).sum(1)
+    assert_close("fused column sums", tot[:, 0], y.double().sum((1, 2, 3)).float(), atol=1e-3, rtol=2e-5)
+    assert_close("fused column sums of squares", tot[:, 1], (y.double() ** 2).sum((1, 2, 3)).float(), atol=1e-3, rtol=2e-5)
+    y1, _ = ops.conv2d_x3_wino(v, G, False, B, H, W, Cin, u, u_scale, Cout, R, bias=cu(bias), act=1, dense=True)
+    assert torch.equal(y1, y.clamp_min(0))
+    if ops.wino_pool_supported(H, W, R, Cout):
+        gammas = [cu(rnd(Cout, seed=330 + g)) for g in range(G)]
+        ptrs = torch.tensor([t.data_ptr() for t in gammas], dtype=torch.int64, device="cuda")
+        bn_scale = torch.stack([t * (0.5 + 0.1 * g) for g, t in enumerate(gammas)]).contiguous()
+        bn_shift = cu(rnd(G, Cout, seed=339, scale=0.3))
+        yp, sp = ops.conv2d_x3_wino(v, G, False, B, H, W, Cin, u, u_scale, Cout, R, bias=cu(bias), want_stats=True, pool=True, gamma_ptrs=ptrs,
+                                    dense=True)
+        assert torch.equal(sp, stats)
+        got, _ = ops.bn_apply_grouped(yp.clone(), bn_scale, bn_shift, relu=True, want_f32=True, want_hl=False)
+        ref, _, _ = ops.maxpool_grouped(y, (2, 2), (2, 2), (0, 0), bn_scale, bn_shift, relu=True, want_f32=True, want_hl=False)
+        assert torch.equal(got, ref)
+    # the pooling producer in the same layout == the two-pass form, bit for bit
+    if H % 2 == 0 and W % 2 == 0 and (H // 2) % 4 == 0:
+        pf, _, _ = ops.maxpool_grouped(cu(yprev), (2, 2), (2, 2), (0, 0), cu(scale), cu(shift), relu=True, want_f32=True, want_hl=False)
+        _, _, v_ref = ops.bn_apply_wino_grouped(pf, None, None, 4, relu=False, dense=True)
+        _, _, v_p, _ = ops.maxpool_wino_grouped(cu(yprev), (2, 2), (2, 2), (0, 0), 4, cu(scale), cu(shift), relu=True, dense=True)
+        assert torch.equal(v_p, v_ref)
+    # a map the row-block kernel cannot take (H % 4 != 0): refused loudly, there is no fallback for this layout
+    with pytest.raises(RuntimeError):
+        ops.conv2d_x3_wino(v, G, False, B * H // 2, 2, W, Cin, u, u_scale, Cout, R, dense=True)
+
+
 def test_winograd_full_size_dominant_shape_properties(ops):
     """BASELINE-size check of the Winograd form of the dominant layer (6 experts x 256 images, 4x65 maps, 512 -> 512) against the
     direct split-fp16 x3 kernel on the same post-ReLU activations, and of the fused statistics"""
