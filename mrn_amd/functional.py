@@ -56,11 +56,20 @@ def frozen_linear(x, weight, bias=None, act=ops.ACT_NONE, residual=None):
     return y.view(*x.shape[:-1], N)
 
 
-def linear_fwd(x2, weight, bias=None, residual=None, act=ops.ACT_NONE):
-    """router Linear: split-fp16 x3 when eligible, exact fp32 otherwise"""
+def linear_fwd(x2, weight, bias=None, residual=None, act=ops.ACT_NONE, sx=None):
+    """router Linear: split-fp16 x3 when eligible, exact fp32 otherwise; sx: the operand's range scale when the caller already has it"""
     if x3_eligible(x2, weight.shape[0], weight.shape[1]) and (residual is None or residual.is_contiguous()):
-        return x3_linear(x2, weight, bias, residual, act)
+        return x3_linear(x2, weight, bias, residual, act, sx=sx)
     return ops.linear(x2, weight, bias, act=act, residual=residual)
+
+
+def operand_scale(x2):
+    """the power-of-two range scale of a router GEMM operand, computed ONCE per tensor: the forward Linear, the weight gradient that
+    reads the same activation in backward, and the two backward GEMMs that read one gradient (data + weight gradient) all used to run
+    their own max|.| pass over it (26 such passes per loop-B step, 8 of them repeats); None off the split-fp16 path"""
+    if ops.ROUTER_GEMM_PRECISION != "fp16x3" or not x2.is_contiguous():
+        return None
+    return ops.pow2_scale(x2)
 
 
 def linear_dgrad(dy, weight, out=None, accumulate=False, sd=None, sw=None, wt_pack=None, amax_ws=None, dy_hl=None):
@@ -214,7 +223,8 @@ class DMRouterFn(torch.autograd.Function):
         x = x.contiguous()
         X = x.view(R, C)
         xn, mu1, rs1 = ops.layernorm_fwd(X, n_w, n_b)
-        hpre = linear_fwd(xn, w1, b1)
+        s_xn = operand_scale(xn)
+        hpre = linear_fwd(xn, w1, b1, sx=s_xn)
         h = ops.ew_rows(ops.EW_GELU, hpre)
         u, v = h[:, :C], h[:, C:]
         vn, mu2, rs2 = ops.layernorm_fwd(v, sn_w, sn_b)
@@ -226,12 +236,16 @@ class DMRouterFn(torch.autograd.Function):
         # vp[b] = Wsp' . vn[b] + bsp'[:, None]
         ops.gemm_raw(wsp_p, vn, vp, N, C, N, B, (0, ldw, 1), (N * C, 1, C), (N * C, C, 1), bias=bsp_p, bias_axis=1)
         g = ops.ew_rows(ops.EW_MUL, u, vp)
-        y = linear_fwd(g, w2, b2, residual=X)
+        s_g = operand_scale(g)
+        y = linear_fwd(g, w2, b2, residual=X, sx=s_g)
         y3 = y.view(B, P, I * C)
         zn, mu3, rs3 = ops.colnorm_fwd(y3, cn_w, cn_b)
-        zp = linear_fwd(zn.view(B * P, I * C), wch, bch).view(R, C)
+        s_zn = operand_scale(zn.view(B * P, I * C))
+        zp = linear_fwd(zn.view(B * P, I * C), wch, bch, sx=s_zn).view(R, C)
         z2 = ops.ew_rows(ops.EW_MUL, y, zp)
-        out = linear_fwd(z2, w3, b3, residual=X)
+        s_z2 = operand_scale(z2)
+        out = linear_fwd(z2, w3, b3, residual=X, sx=s_z2)
+        ctx.scales = (s_xn, s_g, s_zn, s_z2)
         ctx.save_for_backward(X, n_w, w1, sn_w, w2, cn_w, wch, w3, mu1, rs1, xn, hpre, h, mu2, rs2, vn, wsp_p, vp, g, y,
                               mu3, rs3, zn, zp, z2, inv)
         ctx.dims = (B, P, I, C, ldw)
@@ -247,21 +261,25 @@ class DMRouterFn(torch.autograd.Function):
         dout = dout.contiguous().view(R, C)
         dev = dout.device
         # out = z2 W3^T + b3 + X
-        dw3, db3 = linear_wgrad(dout, z2), ops.colsum(dout)
-        dz2 = linear_dgrad(dout, w3)
+        s_xn, s_g, s_zn, s_z2 = ctx.scales
+        s_do = operand_scale(dout)
+        dw3, db3 = linear_wgrad(dout, z2, sd=s_do, sx=s_z2), ops.colsum(dout)
+        dz2 = linear_dgrad(dout, w3, sd=s_do)
         # z2 = y * zp
         dy = ops.ew_rows(ops.EW_MUL, dz2, zp)
         dzp = ops.ew_rows(ops.EW_MUL, dz2, y)
         # zp = zn Wch^T + bch over rows [B*P, I*C]
         dzp2, zn2 = dzp.view(B * P, I * C), zn.view(B * P, I * C)
-        dwch, dbch = linear_wgrad(dzp2, zn2), ops.colsum(dzp2)
-        dzn = linear_dgrad(dzp2, wch)
+        s_dzp = operand_scale(dzp2)
+        dwch, dbch = linear_wgrad(dzp2, zn2, sd=s_dzp, sx=s_zn), ops.colsum(dzp2)
+        dzn = linear_dgrad(dzp2, wch, sd=s_dzp)
         # zn = LayerNorm_P(y)
         _, dcn_w, dcn_b = ops.colnorm_bwd(dzn.view(B, P, I * C), y.view(B, P, I * C), cn_w, mu3, rs3,
                                           dx=dy.view(B, P, I * C), accumulate=True)
         # y = g W2^T + b2 + X
-        dw2, db2 = linear_wgrad(dy, g), ops.colsum(dy)
-        dg = linear_dgrad(dy, w2)
+        s_dy = operand_scale(dy)
+        dw2, db2 = linear_wgrad(dy, g, sd=s_dy, sx=s_g), ops.colsum(dy)
+        dg = linear_dgrad(dy, w2, sd=s_dy)
         # g = u * vp
         u, v = h[:, :C], h[:, C:]
         dh = torch.empty(R, 2 * C, device=dev, dtype=torch.float32)
@@ -292,8 +310,9 @@ class DMRouterFn(torch.autograd.Function):
         _, dsn_w, dsn_b = ops.layernorm_bwd(dvn, v, sn_w, mu2, rs2, dx=dh[:, C:])
         # h = gelu(hpre)
         dhpre = ops.ew_rows(ops.EW_GELU_BWD, hpre, dh)
-        dw1, db1 = linear_wgrad(dhpre, xn), ops.colsum(dhpre)
-        dxn = linear_dgrad(dhpre, w1)
+        s_dh = operand_scale(dhpre)
+        dw1, db1 = linear_wgrad(dhpre, xn, sd=s_dh, sx=s_xn), ops.colsum(dhpre)
+        dxn = linear_dgrad(dhpre, w1, sd=s_dh)
         # xn = LayerNorm(X)
         dx_ln, dn_w, dn_b = ops.layernorm_bwd(dxn, X, n_w, mu1, rs1)
         dx = None

@@ -376,9 +376,34 @@ class BackboneGroup(_GroupedLinear):
             return None
         if any(b.drop_path.forced_masks for b in blks):       # parity tests pin the draws per expert
             return torch.cat([b.drop_path.scale(B, dev) for b in blks])
+        bank = getattr(self, "_drop_bank", None)
+        if bank is not None and bank[1] < bank[0].shape[0] and bank[2][bank[1]] == dp.drop_prob:
+            bank[1] += 1                      # (the next row of the forward's one-launch draw, see _svtr)
+            return bank[0][bank[1] - 1]
         keep = 1 - dp.drop_prob
         m = torch.empty(self.G * B, device=dev).bernoulli_(keep)
         return m / keep if (keep > 0.0 and dp.scale_by_keep) else m
+
+    def _draw_drop_bank(self, nets, B, dev):
+        """every DropPath multiplier of one grouped SVTR forward in TWO launches (one Bernoulli draw over [draws, G*B] with a per-row
+        keep probability, one scaling) instead of two per residual branch -- 44 short launches per sub-group and forward.  Rows in
+        Block.forward's draw order (mixer branch, then MLP branch, block by block); _drop_scales hands them out.  Pinned draws
+        (forced_masks: the parity tests) and eval mode bypass the bank."""
+        self._drop_bank = None
+        probs = []
+        for si in range(3):
+            stages = [list(getattr(n, "blocks%d" % (si + 1))) for n in nets]
+            for i, blk in enumerate(stages[0]):
+                dp = blk.drop_path
+                if hasattr(dp, "drop_prob") and dp.drop_prob != 0. and dp.training:
+                    if any(st[i].drop_path.forced_masks for st in stages) or not dp.scale_by_keep:
+                        return
+                    probs += [dp.drop_prob, dp.drop_prob]
+        if not probs or max(probs) >= 1.0:
+            return
+        keep = self._cached("dropkeep%d" % len(probs), [], lambda: torch.tensor([1.0 - p_ for p_ in probs], device=dev, dtype=torch.float32).view(-1, 1))
+        m = torch.bernoulli(keep.expand(len(probs), self.G * B))
+        self._drop_bank = [m.div_(keep), 0, probs]
 
     def _ln_params(self, name, norms):
         return self._cached(name, [n.weight for n in norms] + [n.bias for n in norms],
@@ -500,6 +525,7 @@ class BackboneGroup(_GroupedLinear):
                 # PatchEmbed (Cin = 4 and 32: exact-fp32 convs + BatchNorm + GELU, as on the per-expert path) + position embedding
                 tok = n.patch_embed(logical)
                 ops.ew_rows(ops.EW_ADD, tok.view(B, N * C), n.pos_embed.view(1, N * C).expand(B, N * C), out=x[g * B:(g + 1) * B].view(B, N * C))
+        self._draw_drop_bank(nets, B, image.device)
         for si in range(3):
             blocks = [list(getattr(n, "blocks%d" % (si + 1))) for n in nets]
             pending = None
