@@ -500,12 +500,16 @@ int mrn_svtr_tail_x3_f32(const void* ctx_hl, float* x_res, const void* wproj_hl,
  * permuted to the MFMA result layout (position 16 s + 8 h + j holds channel (j & 3) + 8 (2 s + (j >> 2)) + 4 h), sproj [G][2], bproj
  * [G][C]; y_hl [imgs * N][C/32][128 B] is the operand of mrn_svtr_mlp_x3_f32.  Split-fp16 x3 products throughout; q | k | v, the
  * probabilities and the context never leave registers / LDS.  Supported: C = 64 with N <= 512, C = 128 with N <= 256 (N <= 128:
- * imgs_per_group even); otherwise MRN_ERR_UNSUPPORTED (the caller runs the unfused chain). */
+ * imgs_per_group even); otherwise MRN_ERR_UNSUPPORTED (the caller runs the unfused chain).
+ * token_h, token_w: 0, 0 = tokens walked in memory order.  For a LOCAL mixer on a token_h x token_w map (token_h * token_w == N, the 7 x 11
+ * window of svtr.py:110-128 sees every row but only 11 columns) pass the map's shape and mask_bits in COLUMN-major position order
+ * (position p = col * token_h + row <-> token row * token_w + col, rows and bits permuted alike): a 32-position key tile is then a block of
+ * whole columns and 5 of 8 (stage 2) / 11 of 16 (stage 1) tiles are fully masked and skipped.  Same result per token. */
 int mrn_svtr_mixer_x3_f32(const float* x, const float* pending, const float* drop_prev, const float* g1, const float* b1, float eps1,
                           const void* wqkv_hl, const float* sqkv, const float* bqkv, const void* mask_bits, float scale,
                           const void* wproj_hl, const float* sproj, const float* bproj, const float* drop1, const float* g2,
                           const float* b2, float eps2, float* x_out, void* y_hl, int imgs, int imgs_per_group, int N, int C,
-                          void* stream);
+                          int token_h, int token_w, void* stream);
 /* Attention-only form for the wide stage (C = 256, SVTR stage 3: the proj accumulators of mrn_svtr_mixer_x3_f32 do not fit next to the token
  * fragments): t = x + drop_prev * pending (written to t_out when pending is given); ctx_hl = HL32(attention(qkv(LayerNorm1(t)))), the
  * operand of the (unfused) proj Linear -- the residual add and LayerNorm2 follow as mrn_add_layernorm_grouped_f32.  Saves the LayerNorm

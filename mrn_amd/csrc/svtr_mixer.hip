@@ -63,6 +63,10 @@ struct MixerParams {
   float* x_out;                   // [imgs][N][C]
   unsigned char* y_hl;            // [imgs * N][C/32][128 B]
   int imgs, imgs_per_group, N;
+  int perm_h, perm_w;             // > 0: the kernel walks the tokens of an image COLUMN-major (position p = col * perm_h + row is token
+                                  // row * perm_w + col; N == perm_h * perm_w) and mask_bits is indexed by positions: a key tile of 32
+                                  // positions is then a block of 32 / perm_h whole columns, and the local mixer's window (all rows, 11
+                                  // columns) touches 3 tiles of 8 (stage 2) / 5 of 16 (stage 1) instead of every row's half-rows
   float scale, eps1, eps2;
 };
 
@@ -98,9 +102,15 @@ __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerPa
   const int img0 = (blockIdx.x / CHUNKS) * IMG;
   const int g = img0 / p.imgs_per_group;
   const int img = img0 + wi;
-  const int tok = (qc * NT + ti) * 32 + l31;
+  // position -> token: everything per token (LayerNorm, projections, residual) is order-free; only the row addresses and the mask see it
+  auto token_of = [&](int pos) -> int {
+    if (p.perm_h <= 0) return pos;
+    const int col = pos / p.perm_h;
+    return (pos - col * p.perm_h) * p.perm_w + col;
+  };
+  const int tok = (qc * NT + ti) * 32 + l31;                  // POSITION of this lane's query
   const bool ok = tok < p.N && img < p.imgs;
-  const long row = (long)(img < p.imgs ? img : img0) * p.N + (tok < p.N ? tok : 0);
+  const long row = (long)(img < p.imgs ? img : img0) * p.N + (tok < p.N ? token_of(tok) : 0);
 
   for (int i = t; i < 3 * C; i += NW * 64) bias_lds[i] = p.bqkv ? p.bqkv[(long)g * 3 * C + i] : 0.f;
 
@@ -413,7 +423,7 @@ __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerPa
       // inside kv_tiles is the point where every wave is done with the own chunk's tiles
       const int tok2 = ((1 - qc) * NT + ti) * 32 + l31;
       u32x4 th[KB], tl[KB];
-      load_ln1((long)(img < p.imgs ? img : img0) * p.N + (tok2 < p.N ? tok2 : 0), tok2 < p.N && img < p.imgs, th, tl);
+      load_ln1((long)(img < p.imgs ? img : img0) * p.N + (tok2 < p.N ? token_of(tok2) : 0), tok2 < p.N && img < p.imgs, th, tl);
       kv_tiles(step0 + 3, h, th, tl);
     }
     if constexpr (ATTN) {
@@ -482,7 +492,7 @@ __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerPa
     unsigned char* stg = lds + wave * (32 * ROWB);
     const int tbase = (qc * NT + ti) * 32;
     const int nvalid = img < p.imgs ? min(32, max(0, p.N - tbase)) : 0;
-    const long row0 = (long)(img < p.imgs ? img : img0) * p.N + tbase;
+    const long img_row0 = (long)(img < p.imgs ? img : img0) * p.N;
     const int rr = lane / LPR, cc = (lane % LPR) * 16;
     const float* xr = p.x + row * C;
     const float* pr = p.pend ? p.pend + row * C : nullptr;
@@ -514,7 +524,7 @@ __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerPa
       for (int i = 0; i < 32 / RPI; ++i) {
         const int r = i * RPI + rr;
         const f32x4 v = *reinterpret_cast<const f32x4*>(stg + r * ROWB + cc);
-        if (r < nvalid) *reinterpret_cast<f32x4*>(reinterpret_cast<unsigned char*>(p.x_out + (row0 + r) * C) + cc) = v;
+        if (r < nvalid) *reinterpret_cast<f32x4*>(reinterpret_cast<unsigned char*>(p.x_out + (img_row0 + token_of(tbase + r)) * C) + cc) = v;
       }
     }
     s += __shfl_xor(s, 32);
@@ -558,7 +568,7 @@ __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerPa
       for (int i = 0; i < 32 / RPI; ++i) {
         const int r = i * RPI + rr;
         const u32x4 v = *reinterpret_cast<const u32x4*>(stg + r * ROWB + cc);
-        if (r < nvalid) *reinterpret_cast<u32x4*>(p.y_hl + (row0 + r) * (long)CB * 128 + cc) = v;
+        if (r < nvalid) *reinterpret_cast<u32x4*>(p.y_hl + (img_row0 + token_of(tbase + r)) * (long)CB * 128 + cc) = v;
       }
     }
   }
@@ -601,13 +611,17 @@ bool mixer_shape_ok(int C, int N, int imgs_per_group) {
 //   wproj_hl           [G][C][C/32][128 B] proj weight packed from [C][1][C] with the input channel of every 32-block (= head) permuted:
 //                      position 16 s + 8 h + j holds channel (j & 3) + 8 (2 s + (j >> 2)) + 4 h; sproj [G][2]; bproj [G][C]
 //   y_hl               [imgs * N][C/32][128 B]
+//   token_h, token_w   0, 0: tokens are walked in memory order.  token_h x token_w == N (local mixers on a token_h x token_w map): the kernel
+//                      walks them COLUMN-major -- position p = col * token_h + row is token row * token_w + col -- and mask_bits must be
+//                      given in POSITION order (rows and bits permuted alike); the result is the same function of x, token by token, but
+//                      a 32-position key tile is a block of whole columns, so the local window leaves most tiles fully masked (skipped)
 // Heads have 32 channels.  Supported: C = 64 with N <= 512, C = 128 with N <= 256 (N <= 128: imgs_per_group even); anything else
 // returns MRN_ERR_UNSUPPORTED and the caller runs the unfused chain.
 MRN_EXPORT int mrn_svtr_mixer_x3_f32(const float* x, const float* pending, const float* drop_prev, const float* g1, const float* b1,
                                      float eps1, const void* wqkv_hl, const float* sqkv, const float* bqkv, const void* mask_bits,
                                      float scale, const void* wproj_hl, const float* sproj, const float* bproj, const float* drop1,
                                      const float* g2, const float* b2, float eps2, float* x_out, void* y_hl, int imgs,
-                                     int imgs_per_group, int N, int C, void* stream) {
+                                     int imgs_per_group, int N, int C, int token_h, int token_w, void* stream) {
   MRN_CHECK_ARG(x && g1 && b1 && wqkv_hl && wproj_hl && bproj && g2 && b2 && x_out && y_hl && imgs >= 0 && imgs_per_group >= 1,
                 "mrn_svtr_mixer_x3_f32: bad operands");
   MRN_CHECK_ARG((uintptr_t)wqkv_hl % 128 == 0 && (uintptr_t)wproj_hl % 128 == 0 && (uintptr_t)y_hl % 128 == 0 &&
@@ -618,7 +632,10 @@ MRN_EXPORT int mrn_svtr_mixer_x3_f32(const float* x, const float* pending, const
     return MRN_ERR_UNSUPPORTED;
   }
   if (imgs == 0) return MRN_OK;
+  MRN_CHECK_ARG(token_h == 0 || (token_h > 0 && token_w > 0 && token_h * token_w == N && mask_bits),
+                "mrn_svtr_mixer_x3_f32: column-major token walk needs token_h * token_w == N (%d x %d vs %d) and a mask in that order", token_h, token_w, N);
   MixerParams p;
+  p.perm_h = token_h; p.perm_w = token_w;
   p.x = x; p.pend = pending; p.drop_prev = drop_prev; p.g1 = g1; p.b1 = b1; p.wqkv = (const unsigned char*)wqkv_hl; p.sqkv = sqkv;
   p.bqkv = bqkv; p.mask_bits = (const unsigned*)mask_bits; p.wproj = (const unsigned char*)wproj_hl; p.sproj = sproj; p.bproj = bproj;
   p.drop1 = drop1; p.g2 = g2; p.b2 = b2; p.x_out = x_out; p.y_hl = (unsigned char*)y_hl;

@@ -439,7 +439,7 @@ class BackboneGroup(_GroupedLinear):
             g2, b2 = self._ln_params(name + ".ln2", [b.norm2 for b in blks])
             Ch = blks[0].mlp.fc1.out_features
             x, y_hl = ops.svtr_mixer_fused(x, br, dr, g1, b1, b0.norm1.eps, wq, sq, bq, mixer.mask, mixer.scale, wp, sp, bp, drop1,
-                                           g2, b2, b0.norm2.eps, B)
+                                           g2, b2, b0.norm2.eps, B, hw=mixer.HW if mixer.mask is not None else None)
         else:
             if mixer.num_heads * 32 == C and ops.svtr_attention_block_supported(N, C, B, mixer.mask):
                 # stage 3 (C = 256): LayerNorm1 -> qkv -> attention in one kernel, proj and the rest unfused (csrc/svtr_mixer.hip ATTN form)

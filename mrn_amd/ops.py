@@ -2294,20 +2294,44 @@ def svtr_mixer_supported(N, C, imgs_per_group, mask):
     return mask is None or _mask_bits(mask) is not None
 
 
+SVTR_LOCAL_COLUMNS = os.environ.get("MRN_SVTR_LOCAL_COLUMNS", "1") == "1"     # A/B: 0 = local mixers walk their tokens in memory (row-major) order
+
+
+def _mask_bits_columns(mask, H, W):
+    """_mask_bits of the same mask with queries and keys in COLUMN-major position order (position p = col * H + row <-> token row * W + col)"""
+    got = getattr(mask, "_mrn_bits_cols", None)
+    if got is None or got[0] != (mask._version, H, W):
+        pos = torch.arange(H * W, device=mask.device)
+        tok = (pos % H) * W + pos // H
+        pm = mask.index_select(0, tok).index_select(1, tok).contiguous()
+        got = ((mask._version, H, W), _mask_bits(pm))
+        mask._mrn_bits_cols = got
+    return got[1]
+
+
 def svtr_mixer_fused(x, pending, drop_prev, g1, b1, eps1, wqkv_hl, sqkv, bqkv, mask, scale, wproj_hl, sproj, bproj, drop1, g2, b2, eps2,
-                     imgs_per_group):
+                     imgs_per_group, hw=None):
     """x [imgs, N, C] -> (x_out [imgs, N, C], y_hl HL32 bytes of LayerNorm2(x_out)): the attention half of a mixing block
-    (mrn_svtr_mixer_x3_f32); wproj_hl packed from the input-permuted proj weights (mlp_hidden_permutation(C))"""
+    (mrn_svtr_mixer_x3_f32); wproj_hl packed from the input-permuted proj weights (mlp_hidden_permutation(C)).  hw = (H, W) of the token
+    map of a LOCAL mixer: the kernel walks the tokens column-major, so that whole key tiles fall outside the 7 x 11 window (svtr.py:110-128)
+    and are skipped -- same result per token"""
     _chk(x, pending, drop_prev, g1, b1, bqkv, bproj, drop1, g2, b2)
     imgs, N, C = x.shape
     assert x.is_contiguous() and (pending is None or (pending.is_contiguous() and pending.numel() == x.numel()))
     x_out = torch.empty_like(x)
     y_hl = torch.empty(x.numel() * 4, device=x.device, dtype=torch.uint8)
-    bits = _mask_bits(mask) if mask is not None else None
+    th = tw = 0
+    bits = None
+    if mask is not None:
+        if SVTR_LOCAL_COLUMNS and hw is not None and hw[0] * hw[1] == N and N % 32 == 0 and 32 % hw[0] == 0:
+            th, tw = int(hw[0]), int(hw[1])
+            bits = _mask_bits_columns(mask, th, tw)
+        else:
+            bits = _mask_bits(mask)
     t0 = CONV_TIMER.begin() if CONV_TIMER is not None else None
     call("mrn_svtr_mixer_x3_f32", _p(x), _p(pending), _p(drop_prev), _p(g1), _p(b1), float(eps1), _p(wqkv_hl), _p(sqkv), _p(bqkv),
          _p(bits), float(scale), _p(wproj_hl), _p(sproj), _p(bproj), _p(drop1), _p(g2), _p(b2), float(eps2), _p(x_out), _p(y_hl),
-         imgs, imgs_per_group, N, C, _stream())
+         imgs, imgs_per_group, N, C, th, tw, _stream())
     if t0 is not None:
         rows = imgs * N
         CONV_TIMER.end(t0, 2.0 * rows * C * 4 * C + 4.0 * rows * N * C, "fp16x3/svtrmixer", 4.0 * rows * C * (4 if pending is not None else 3))

@@ -1316,14 +1316,44 @@ def _mixer_reference(t, C, N, G, B, heads):
     return torch.cat(outs), torch.cat(ys)
 
 
-def _mixer_run(ops, t, C, N, G, B):
+def _mixer_run(ops, t, C, N, G, B, hw=None):
     dev = torch.device("cuda")
     wq, sq = ops.pack_weights_hl32([cu(w).view(3 * C, 1, 1, C).contiguous() for w in t["wqkv"]])
     perm = ops.mlp_hidden_permutation(C, dev)
     wp, sp = ops.pack_weights_hl32([cu(w).index_select(1, perm).contiguous().view(C, 1, 1, C) for w in t["wproj"]])
     o = lambda v: cu(v) if v is not None else None
     return ops.svtr_mixer_fused(cu(t["x"]), o(t["pend"]), o(t["dprev"]), cu(t["g1"]), cu(t["b1"]), 1e-6, wq, sq, o(t["bqkv"]), o(t["mask"]),
-                                32 ** -0.5, wp, sp, cu(t["bproj"]), cu(t["d1"]), cu(t["g2"]), cu(t["b2"]), 1e-6, B)
+                                32 ** -0.5, wp, sp, cu(t["bproj"]), cu(t["d1"]), cu(t["g2"]), cu(t["b2"]), 1e-6, B, hw=hw)
+
+
+@pytest.mark.parametrize("C,N,H,G,B", [(64, 512, 8, 2, 3), (128, 256, 4, 2, 3), (128, 160, 4, 1, 3), (64, 256, 8, 1, 2), (64, 512, 8, 6, 40)])
+def test_svtr_fused_mixer_column_major_walk(ops, C, N, H, G, B):
+    """LOCAL mixers walk their tokens column-major (mrn_svtr_mixer_x3_f32 token_h / token_w + position-ordered mask bits): the 7 x 11 window
+    (modules/svtr.py:110-128) then leaves whole 32-position key tiles masked, and they are skipped.  Per token the same function: equal to
+    float64 torch inside the usual band and to the memory-order walk to 4e-6 (another summation order over the key tiles); the mask bits in
+    position order are the permuted mask's; a map the walk does not fit (N % 32 != 0) silently keeps the memory order."""
+    t, heads = _mixer_case(C, N, G, B, True, True, True)
+    W = N // H
+    x_ref, y_ref = _mixer_reference(t, C, N, G, B, heads)
+    x_col, y_col = _mixer_run(ops, t, C, N, G, B, hw=(H, W))
+    saved = ops.SVTR_LOCAL_COLUMNS
+    try:
+        ops.SVTR_LOCAL_COLUMNS = False
+        x_row, y_row = _mixer_run(ops, t, C, N, G, B, hw=(H, W))
+    finally:
+        ops.SVTR_LOCAL_COLUMNS = saved
+    assert_close("column walk: residual stream vs float64", x_col, x_ref.float(), atol=2e-5, rtol=1e-5)
+    assert_close("column walk: LayerNorm2 operand vs float64", _hl32_to_f32(y_col, G * B * N, C).view(G * B, N, C), y_ref.float(), atol=4e-5, rtol=1e-5)
+    assert_close("column walk vs memory-order walk", x_col, x_row, atol=4e-6, rtol=2e-6)
+    assert not torch.equal(x_col, x_row) or N <= 32          # (it really took the other order)
+    m = cu(t["mask"])
+    pos = torch.arange(N, device="cuda")
+    tok = (pos % H) * W + pos // H
+    assert torch.equal(ops._mask_bits_columns(m, H, W), ops._mask_bits(m[tok][:, tok].contiguous()))
+    # fully masked tiles per wave of 32 queries (what the walk buys): count the (query tile, key tile) pairs with any visible key
+    vis = (m[tok][:, tok] == 0).view(N // 32, 32, N // 32, 32).any(3).any(1).float().mean().item()
+    vis_row = (m == 0).view(N // 32, 32, N // 32, 32).any(3).any(1).float().mean().item()
+    assert vis < vis_row and (N < 512 or vis < 0.5 * vis_row), (vis, vis_row)
 
 
 @pytest.mark.parametrize("C,N,G,B,masked,bias,with_pending", [(64, 200, 2, 3, True, True, True), (64, 200, 1, 5, False, False, False),

@@ -50,7 +50,8 @@ def main():
         rows = B * N
 
         def fused():
-            return ops.svtr_mixer_fused(x, pend, dprev, g1, b1, 1e-6, wq, sq, bqkv, mask, 32 ** -0.5, wp, sp, bproj, d1, g1, b1, 1e-6, B)
+            return ops.svtr_mixer_fused(x, pend, dprev, g1, b1, 1e-6, wq, sq, bqkv, mask, 32 ** -0.5, wp, sp, bproj, d1, g1, b1, 1e-6, B,
+                                        hw=(H, W) if local else None)      # (MRN_SVTR_LOCAL_COLUMNS=0: the memory-order walk, A/B)
 
         def chain():
             t, _, hl = ops.add_layernorm_grouped(x, pend, dprev, N, g1, b1, rows, 1e-6, want_sum=True)

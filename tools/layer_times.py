@@ -15,8 +15,9 @@ from mrn_amd.data.synthetic import SyntheticTextLines  # noqa: E402
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     torch.cuda.set_device(0)
-    opt = bench.make_opt("trba", 256)
-    learner = bench.build_learner(opt, 6)
+    model = os.environ.get("MODEL", "trba")
+    opt = bench.make_opt(model, 256)
+    learner = bench.build_learner(opt, int(os.environ.get("EXPERTS", "6")))
     if os.environ.get("SERIAL") == "1":          # one lock-step group of all experts on one stream: every launch has the GPU to itself
         learner.model.module.expert_halves = 0
     data = SyntheticTextLines(opt, seed=111)
