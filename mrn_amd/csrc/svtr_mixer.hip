@@ -329,13 +329,45 @@ __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerPa
             kh[m] = *reinterpret_cast<const u32x4*>(kt_ + foff[0][m]);
             kl[m] = *reinterpret_cast<const u32x4*>(kt_ + foff[1][m]);
           }
+#ifdef MRN_XPROBE_NO_ATTN_MFMA
+          // what-if probe: the softmax VALU work without the twelve attention MFMAs of a key tile (scores = a fragment's bits)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) s[e] = __builtin_bit_cast(float, (kh[e >> 3][e & 3] ^ qh[0][e & 3]) & 0x3fffffffu);
+#else
 #pragma unroll
           for (int m = 0; m < 2; ++m) s = mma(kl[m], qh[m], s);
 #pragma unroll
           for (int m = 0; m < 2; ++m) s = mma(kh[m], ql[m], s);
 #pragma unroll
           for (int m = 0; m < 2; ++m) s = mma(kh[m], qh[m], s);
+#endif
         }
+#ifdef MRN_XPROBE_NO_SOFTMAX
+        // what-if probe (never in the product build; bash tools/build_probe.sh MRN_XPROBE_NO_SOFTMAX svtr_mixer.hip): the score registers go
+        // straight into the P operand -- no mask, maximum, exponential, split or rescale: what the key-tile loop costs WITHOUT its VALU work
+        {
+          u32x4 ph_[2], pl_[2];
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            ph_[m] = u32x4{__builtin_bit_cast(unsigned, s[8 * m]), __builtin_bit_cast(unsigned, s[8 * m + 1]), __builtin_bit_cast(unsigned, s[8 * m + 2]), __builtin_bit_cast(unsigned, s[8 * m + 3])};
+            pl_[m] = u32x4{__builtin_bit_cast(unsigned, s[8 * m + 4]), __builtin_bit_cast(unsigned, s[8 * m + 5]), __builtin_bit_cast(unsigned, s[8 * m + 6]), __builtin_bit_cast(unsigned, s[8 * m + 7])};
+          }
+          l_run = 1.f;
+          u32x4 vh[2], vl[2];
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            vh[m] = *reinterpret_cast<const u32x4*>(vt_ + foff[0][m]);
+            vl[m] = *reinterpret_cast<const u32x4*>(vt_ + foff[1][m]);
+          }
+#pragma unroll
+          for (int m = 0; m < 2; ++m) o = mma(vl[m], ph_[m], o);
+#pragma unroll
+          for (int m = 0; m < 2; ++m) o = mma(vh[m], pl_[m], o);
+#pragma unroll
+          for (int m = 0; m < 2; ++m) o = mma(vh[m], ph_[m], o);
+          continue;
+        }
+#endif
         if (brow) {
 #pragma unroll
           for (int e = 0; e < 16; ++e)
@@ -383,12 +415,17 @@ __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerPa
             vh[m] = *reinterpret_cast<const u32x4*>(vt_ + foff[0][m]);
             vl[m] = *reinterpret_cast<const u32x4*>(vt_ + foff[1][m]);
           }
+#ifdef MRN_XPROBE_NO_ATTN_MFMA
+#pragma unroll
+          for (int e = 0; e < 16; ++e) o[e] += __builtin_bit_cast(float, (vh[e >> 3][e & 3] ^ ph[e >> 3][e & 3] ^ pl[0][e & 3] ^ vl[1][e & 3]) & 0x3fffffffu);
+#else
 #pragma unroll
           for (int m = 0; m < 2; ++m) o = mma(vl[m], ph[m], o);
 #pragma unroll
           for (int m = 0; m < 2; ++m) o = mma(vh[m], pl[m], o);
 #pragma unroll
           for (int m = 0; m < 2; ++m) o = mma(vh[m], ph[m], o);
+#endif
         }
       }
     };
