@@ -74,6 +74,26 @@ __device__ __forceinline__ f32x16 mma(const u32x4 a, const u32x4 b, const f32x16
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16v8*>(&a), *reinterpret_cast<const f16v8*>(&b), c, 0, 0, 0);
 }
 
+#ifdef MRN_XPROBE_TIMING
+// timing probe (never in the product build; bash tools/build_probe.sh MRN_XPROBE_TIMING svtr_mixer.hip; tools/probe/xtiming.py): shader-clock
+// totals of a wave's phases, summed over all waves: [0] prologue (x + pending, LayerNorm1), [1] K / V projections, [2] Q projection,
+// [3] key-tile loop, [4] proj, [5] epilogue, [6] waves, [7] whole kernel
+__device__ unsigned long long g_mixer_dbg[8];
+extern "C" __attribute__((visibility("default"))) int mrn_mixer_dbg_read(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mixer_dbg), sizeof(g_mixer_dbg)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mixer_dbg), z, sizeof(z));
+  }
+  return 0;
+}
+#define XTICK(var) const long var = __builtin_readcyclecounter()
+#define XADD(slot, a, b) xdbg[slot] += (b) - (a)
+#else
+#define XTICK(var)
+#define XADD(slot, a, b)
+#endif
+
 // ATTN: attention only -- LayerNorm1 -> qkv -> attention, the context leaves as the HL32 operand of an unfused proj Linear (p.y_hl) and,
 // when a pending branch was folded in, t = x + drop_prev * pending as the residual stream (p.x_out).  For C = 256 (SVTR stage 3), where
 // the proj accumulators of the full form do not fit the register file next to the token fragments.
@@ -93,8 +113,16 @@ __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerPa
   unsigned char* lds_k = lds;                        // [IMG * NT] tiles, line = key
   unsigned char* lds_v = lds + IMG * NT * TILE;      // [IMG * NT] tiles, line = d, slots = the tile's keys in score-register order
   unsigned char* slab0 = lds + 2 * IMG * NT * TILE;  // RING slabs
-  float* bias_lds = reinterpret_cast<float*>(slab0 + RING * SLAB);   // [3C]
+  // the parameter block sits behind BOTH the K / V tiles + slab ring and the epilogue's row-staging tiles (which reuse the LDS from offset 0)
+  constexpr int RING_END = 2 * IMG * NT * TILE + RING * SLAB, STAGE_END = ATTN ? 0 : NT * IMG * 32 * (C * 4 + 16);
+  constexpr int PARAM_OFF = RING_END > STAGE_END ? RING_END : STAGE_END;
+  float* bias_lds = reinterpret_cast<float*>(lds + PARAM_OFF);        // [3C] qkv bias, then [C] each: LayerNorm1 gamma, beta, LayerNorm2 gamma, beta, proj bias
+  float* ln_lds = bias_lds + 3 * C;                                  // (per-channel vectors read by every lane: from LDS, not 16 dependent global round trips)
 
+#ifdef MRN_XPROBE_TIMING
+  long xdbg[6] = {0, 0, 0, 0, 0, 0};
+#endif
+  XTICK(x_t0);
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int half = lane >> 5, l31 = lane & 31;
   const int wi = wave / NT, ti = wave % NT;
@@ -113,6 +141,16 @@ __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerPa
   const long row = (long)(img < p.imgs ? img : img0) * p.N + (tok < p.N ? token_of(tok) : 0);
 
   for (int i = t; i < 3 * C; i += NW * 64) bias_lds[i] = p.bqkv ? p.bqkv[(long)g * 3 * C + i] : 0.f;
+  for (int i = t; i < C; i += NW * 64) {
+    ln_lds[i] = p.g1[(long)g * C + i];
+    ln_lds[C + i] = p.b1[(long)g * C + i];
+    if (!ATTN) {
+      ln_lds[2 * C + i] = p.g2[(long)g * C + i];
+      ln_lds[3 * C + i] = p.b2[(long)g * C + i];
+      ln_lds[4 * C + i] = p.bproj[(long)g * C + i];
+    }
+  }
+  bool params_ready = false;          // (the first reader of the parameter block waits for it: load_ln1 below)
 
   // ---- weight slabs, STEPS per head in the order Wk, Wv (own key chunk), Wq, [Wk, Wv (other chunk),] Wproj.  DMA instruction d moves 8
   // lines of 128 B: lane -> line 8 d + lane / 8, chunk lane & 7, source chunk XOR-swizzled with (line >> 1) & 7 (conflict-free
@@ -152,18 +190,49 @@ __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerPa
     float v[KB][8];
     const float* xr = p.x + r * C;
     const float* pr = p.pend ? p.pend + r * C : nullptr;
+    // every piece of the token's row in flight at once (2 KB loads of 16 B, then the pending branch's): issued four at a time behind a
+    // full s_waitcnt each -- what the compiler made of the interleaved form -- the prologue was 16 serialized memory round trips, a
+    // quarter of the kernel's time with ONE workgroup per CU and nothing to overlap them with (in-kernel clocks, tools/probe/xtiming.py)
+    {
+      f32x4 xa[KB], xb[KB];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        const int c = 16 * kb + 8 * half;
+        xa[kb] = *reinterpret_cast<const f32x4*>(xr + c);
+        xb[kb] = *reinterpret_cast<const f32x4*>(xr + c + 4);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[kb][j] = xa[kb][j]; v[kb][4 + j] = xb[kb][j]; }
+    }
+    if (pr) {
+      constexpr int PB = KB > 8 ? 8 : KB;          // (C = 256: two batches of 64 registers -- one of 128 next to the row itself spills)
+#pragma unroll
+      for (int k0 = 0; k0 < KB; k0 += PB) {
+        f32x4 pa[PB], pb[PB];
+#pragma unroll
+        for (int kb = 0; kb < PB; ++kb) {
+          const int c = 16 * (k0 + kb) + 8 * half;
+          pa[kb] = *reinterpret_cast<const f32x4*>(pr + c);
+          pb[kb] = *reinterpret_cast<const f32x4*>(pr + c + 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kb = 0; kb < PB; ++kb)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[k0 + kb][j] = fmaf(ds, pa[kb][j], v[k0 + kb][j]);
+            v[k0 + kb][4 + j] = fmaf(ds, pb[kb][j], v[k0 + kb][4 + j]);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
     float s = 0.f;
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
       const int c = 16 * kb + 8 * half;
-      const f32x4 a = *reinterpret_cast<const f32x4*>(xr + c), b = *reinterpret_cast<const f32x4*>(xr + c + 4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { v[kb][j] = a[j]; v[kb][4 + j] = b[j]; }
-      if (pr) {
-        const f32x4 pa = *reinterpret_cast<const f32x4*>(pr + c), pb = *reinterpret_cast<const f32x4*>(pr + c + 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { v[kb][j] = fmaf(ds, pa[j], v[kb][j]); v[kb][4 + j] = fmaf(ds, pb[j], v[kb][4 + j]); }
-      }
       if (store_t && valid) {                      // attention-only form: the folded residual stream t = x + drop_prev * pending
         *reinterpret_cast<f32x4*>(p.x_out + r * C + c) = f32x4{v[kb][0], v[kb][1], v[kb][2], v[kb][3]};
         *reinterpret_cast<f32x4*>(p.x_out + r * C + c + 4) = f32x4{v[kb][4], v[kb][5], v[kb][6], v[kb][7]};
@@ -180,11 +249,15 @@ __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerPa
       for (int j = 0; j < 8; ++j) { const float d = v[kb][j] - mean; q += d * d; }
     q += __shfl_xor(q, 32);
     const float rstd = 1.f / sqrtf(q / (float)C + p.eps1);
+    if (!params_ready) {                           // (first call: the parameter block was written by other lanes)
+      __syncthreads();
+      params_ready = true;
+    }
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
       const int c = 16 * kb + 8 * half;
-      const f32x4 ga = *reinterpret_cast<const f32x4*>(p.g1 + (long)g * C + c), gb = *reinterpret_cast<const f32x4*>(p.g1 + (long)g * C + c + 4);
-      const f32x4 ba = *reinterpret_cast<const f32x4*>(p.b1 + (long)g * C + c), bb = *reinterpret_cast<const f32x4*>(p.b1 + (long)g * C + c + 4);
+      const f32x4 ga = *reinterpret_cast<const f32x4*>(ln_lds + c), gb = *reinterpret_cast<const f32x4*>(ln_lds + c + 4);
+      const f32x4 ba = *reinterpret_cast<const f32x4*>(ln_lds + C + c), bb = *reinterpret_cast<const f32x4*>(ln_lds + C + c + 4);
       f16v8 vh, vl;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -200,6 +273,11 @@ __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerPa
   };
   u32x4 xh[KB], xl[KB];
   load_ln1(row, ok, xh, xl, ATTN && p.pend != nullptr && p.x_out != nullptr);
+#ifdef MRN_XPROBE_TIMING
+  asm volatile("" :: "v"(xh[KB - 1][3]), "v"(xl[KB - 1][3]));
+#endif
+  XTICK(x_t1);
+  XADD(0, x_t0, x_t1);
 
   // fragment offsets inside a 32-line tile / slab block: line = lane & 31, logical chunk = plane * 4 + ks * 2 + half, swizzled
   const int key = (l31 >> 1) & 7;
@@ -431,7 +509,10 @@ __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerPa
     };
 
     const int step0 = h * STEPS;
+    XTICK(x_h0);
     kv_tiles(step0, h, xh, xl);                                  // own chunk's K / V from this wave's own tokens
+    XTICK(x_h1);
+    XADD(1, x_h0, x_h1);
     {
       // ---- Q^T of this wave's tokens (registers); the slab's barrier also publishes every wave's K and V lines
       const unsigned char* cur = next_slab(step0 + 2);
@@ -453,7 +534,14 @@ __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerPa
         qh[m] = __builtin_bit_cast(u32x4, vh);
         ql[m] = __builtin_bit_cast(u32x4, vl);
       }
+      XTICK(x_h2);
+      XADD(2, x_h1, x_h2);
       attend(qc);
+#ifdef MRN_XPROBE_TIMING
+      asm volatile("" :: "v"(o[15]));
+#endif
+      XTICK(x_h3);
+      XADD(3, x_h2, x_h3);
     }
     if constexpr (CHUNKS == 2) {
       // ---- the other chunk: its tokens' LayerNorm1 fragments again (x from L2), K / V into the same tiles -- the first slab barrier
@@ -486,6 +574,7 @@ __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerPa
     } else
     // ---- branch^T += Wproj[:, head h] . O^T: the context registers (normalised, split in place) are the B operand
     {
+      XTICK(x_p0);
       const unsigned char* cur = next_slab(step0 + STEPS - 1);  // (its barrier publishes the other chunk's tiles / frees the own chunk's)
       if constexpr (CHUNKS == 2) attend(1 - qc);
       const float inv = l_run > 0.f ? 1.f / (l_run * OPSCALE) : 0.f;
@@ -514,8 +603,14 @@ __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerPa
           out[oc] = mma(wh, oh[m], out[oc]);
         }
       }
+#ifdef MRN_XPROBE_TIMING
+      asm volatile("" :: "v"(out[OC - 1][15]));
+      XTICK(x_p1);
+      XADD(4, x_p0, x_p1);
+#endif
     }
   }
+  XTICK(x_e0);
 
   // ---- epilogue: registers 4 k .. 4 k + 3 of block oc are channels 32 oc + 8 k + 4 half + 0 .. 3 of token lane & 31:
   // x_out = t + drop1 * (branch + bias), LayerNorm2 on the registers, HL32 lines for the Mlp kernel.  A lane holds 16-byte pieces of
@@ -535,22 +630,32 @@ __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerPa
     const float* pr = p.pend ? p.pend + row * C : nullptr;
     const float d1 = p.drop1 ? p.drop1[img < p.imgs ? img : img0] : 1.f;
     float s = 0.f;
+    // the token's row again (L2 / Infinity Cache): all pieces in flight at once, as in the prologue -- interleaved with their uses they
+    // were 16 more serialized round trips (40 % of the kernel's time by the in-kernel clocks)
+    f32x4 tv[OC * 4];
+#pragma unroll
+    for (int i = 0; i < OC * 4; ++i) tv[i] = *reinterpret_cast<const f32x4*>(xr + (i >> 2) * 32 + 8 * (i & 3) + 4 * half);
+    __builtin_amdgcn_sched_barrier(0);
+    if (pr) {
+      f32x4 pv[OC * 4];
+#pragma unroll
+      for (int i = 0; i < OC * 4; ++i) pv[i] = *reinterpret_cast<const f32x4*>(pr + (i >> 2) * 32 + 8 * (i & 3) + 4 * half);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < OC * 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tv[i][j] = fmaf(ds, pv[i][j], tv[i][j]);
+    }
 #pragma unroll
     for (int oc = 0; oc < OC; ++oc)
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int c = oc * 32 + 8 * k + 4 * half;
-        f32x4 tv = *reinterpret_cast<const f32x4*>(xr + c);
-        if (pr) {
-          const f32x4 pv = *reinterpret_cast<const f32x4*>(pr + c);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) tv[j] = fmaf(ds, pv[j], tv[j]);
-        }
-        const f32x4 b = *reinterpret_cast<const f32x4*>(p.bproj + (long)g * C + c);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(ln_lds + 4 * C + c);
         f32x4 v;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          v[j] = fmaf(d1, out[oc][4 * k + j] * invp + b[j], tv[j]);
+          v[j] = fmaf(d1, out[oc][4 * k + j] * invp + b[j], tv[oc * 4 + k][j]);
           out[oc][4 * k + j] = v[j];
           s += v[j];
         }
@@ -578,8 +683,8 @@ __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerPa
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int c = oc * 32 + 8 * k + 4 * half;
-        const f32x4 gm = *reinterpret_cast<const f32x4*>(p.g2 + (long)g * C + c);
-        const f32x4 bt = *reinterpret_cast<const f32x4*>(p.b2 + (long)g * C + c);
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(ln_lds + 2 * C + c);
+        const f32x4 bt = *reinterpret_cast<const f32x4*>(ln_lds + 3 * C + c);
 #pragma unroll
         for (int j = 0; j < 4; ++j) out[oc][4 * k + j] = (out[oc][4 * k + j] - mean) * rstd * gm[j] + bt[j];
       }
@@ -609,12 +714,22 @@ __global__ __launch_bounds__(NT * IMG * 64) void svtr_mixer_kernel(const MixerPa
       }
     }
   }
+#ifdef MRN_XPROBE_TIMING
+  __builtin_amdgcn_s_waitcnt(0);
+  if (lane == 0) {
+    const long x_e1 = __builtin_readcyclecounter();
+    xdbg[5] += x_e1 - x_e0;
+    for (int i = 0; i < 6; ++i) atomicAdd(&g_mixer_dbg[i], (unsigned long long)xdbg[i]);
+    atomicAdd(&g_mixer_dbg[6], 1ull);
+    atomicAdd(&g_mixer_dbg[7], (unsigned long long)(x_e1 - x_t0));
+  }
+#endif
 }
 
 template <int C, int NT, int IMG, int CHUNKS, int RING, bool ATTN = false>
 int launch_mixer(const MixerParams& p, hipStream_t st) {
-  constexpr size_t ring = 2 * IMG * NT * 32 * 128 + RING * C * 128 + 4 * C * sizeof(float), stage = ATTN ? 0 : (size_t)NT * IMG * 32 * (C * 4 + 16);
-  constexpr size_t ldsz = ring > stage ? ring : stage;
+  constexpr size_t ring = 2 * IMG * NT * 32 * 128 + RING * C * 128, stage = ATTN ? 0 : (size_t)NT * IMG * 32 * (C * 4 + 16);
+  constexpr size_t ldsz = (ring > stage ? ring : stage) + 8 * C * sizeof(float);      // + the parameter block (PARAM_OFF in the kernel)
   static_assert(ldsz <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {

@@ -97,6 +97,7 @@ __global__ __launch_bounds__(C == 256 ? 256 : 512) void svtr_mlp_kernel(const Ml
   extern __shared__ __attribute__((aligned(128))) unsigned char lds[];
   float* b1_lds = reinterpret_cast<float*>(lds + 2 * SLAB);     // [HID]
   float* ln_lds = b1_lds + HID;                                  // TAIL: [3][C] = LayerNorm2 gamma, beta, proj bias
+  float* b2_lds = ln_lds + (TAIL ? 3 * C : 0);                   // [C] fc2 bias: read in the epilogue between the stores (see there)
 
   // (block b runs on XCD b % 8: consecutive LOGICAL tiles share an XCD, so an XCD's L2 holds the 0.5 - 2 MB weights of one or two experts
   // instead of all six -- the slabs are re-read from L2 by every workgroup)
@@ -122,6 +123,7 @@ __global__ __launch_bounds__(C == 256 ? 256 : 512) void svtr_mlp_kernel(const Ml
     }
   }
   for (int i = t; i < HID; i += NW * 64) b1_lds[i] = p.b1[(long)g * HID + i];
+  for (int i = t; i < C; i += NW * 64) b2_lds[i] = p.b2[(long)g * C + i];
   if (TAIL) {
     for (int i = t; i < C; i += NW * 64) {
       ln_lds[i] = p.gamma[(long)g * C + i];
@@ -222,22 +224,29 @@ __global__ __launch_bounds__(C == 256 ? 256 : 512) void svtr_mlp_kernel(const Ml
     const float ds = p.drop ? p.drop[(ok ? row : row0) / p.rows_per_drop] : 1.f;
     float* xr_ = p.x_res + row * C;
     float sum = 0.f;
+    // the residual row in batches of eight 16-byte pieces in flight (one load -> wait -> add -> store per piece was 32 serialized round trips)
 #pragma unroll
-    for (int o = 0; o < OC; ++o)
+    for (int o0 = 0; o0 < OC; o0 += 2) {
+      f32x4 xv[8];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int i = 0; i < 8; ++i)
+        xv[i] = ok ? *reinterpret_cast<const f32x4*>(xr_ + (o0 + (i >> 2)) * 32 + 8 * (i & 3) + 4 * half) : f32x4{0.f, 0.f, 0.f, 0.f};
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int o = o0 + (i >> 2), k = i & 3;
         const int c = o * 32 + 8 * k + 4 * half;
-        const f32x4 xv = ok ? *reinterpret_cast<const f32x4*>(xr_ + c) : f32x4{0.f, 0.f, 0.f, 0.f};
         const f32x4 bpv = *reinterpret_cast<const f32x4*>(ln_lds + 2 * C + c);
         f32x4 v;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          v[j] = fmaf(ds, fmaf(out[o][4 * k + j], invp, bpv[j]), xv[j]);
+          v[j] = fmaf(ds, fmaf(out[o][4 * k + j], invp, bpv[j]), xv[i][j]);
           out[o][4 * k + j] = v[j];
           sum += v[j];
         }
         if (ok) *reinterpret_cast<f32x4*>(xr_ + c) = v;
       }
+    }
     // LayerNorm2 (the arithmetic of add_layernorm_grouped_kernel: mean, then the centred sum of squares)
     sum += __shfl_xor(sum, 32);
     const float mean = sum / (float)C;
@@ -406,7 +415,9 @@ __global__ __launch_bounds__(C == 256 ? 256 : 512) void svtr_mlp_kernel(const Ml
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int c = o * 32 + 8 * k + 4 * half;
-        const f32x4 b = *reinterpret_cast<const f32x4*>(p.b2 + (long)g * C + c);
+        // (the bias from LDS: as a global load per store it cost `load, s_waitcnt vmcnt(0), store` sixteen to thirty-two times in a
+        //  row -- and vmcnt(0) also waits for the PREVIOUS store: the epilogue was a chain of serialized memory round trips)
+        const f32x4 b = *reinterpret_cast<const f32x4*>(b2_lds + c);
         f32x4 v;
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = out[o][4 * k + j] * inv2 + b[j];
@@ -417,7 +428,7 @@ __global__ __launch_bounds__(C == 256 ? 256 : 512) void svtr_mlp_kernel(const Ml
 
 template <int C, bool TAIL>
 int launch_mlp(const MlpParams& p, int G, hipStream_t st) {
-  constexpr size_t ldsz = 2 * ((C / 32) * 32 * 128 + C * 128) + 4 * C * sizeof(float) + (TAIL ? 3 * C * sizeof(float) : 0);
+  constexpr size_t ldsz = 2 * ((C / 32) * 32 * 128 + C * 128) + 4 * C * sizeof(float) + (TAIL ? 3 * C * sizeof(float) : 0) + C * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)svtr_mlp_kernel<C, TAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);
