@@ -79,14 +79,17 @@ extern "C" __attribute__((visibility("default"))) int mrn_mlp_dbg_read(unsigned 
 #define MADD(slot, a, b)
 #endif
 
+#ifndef MRN_MLP_WAVES
+#define MRN_MLP_WAVES 8       // waves per workgroup at C = 64 / 128 (what-if: 4 = two independent 128-token workgroups per CU)
+#endif
 template <int C, bool TAIL>
-__global__ __launch_bounds__(C == 256 ? 256 : 512) void svtr_mlp_kernel(const MlpParams p) {
+__global__ __launch_bounds__(C == 256 ? 256 : MRN_MLP_WAVES * 64, C == 256 ? 1 : 2) void svtr_mlp_kernel(const MlpParams p) {
 #ifdef MRN_MPROBE_TIMING
   long dbg_acc[6] = {0, 0, 0, 0, 0, 0};
   const long dbg_t0 = __builtin_readcyclecounter();
 #endif
   static_assert(!TAIL || C == 256, "the tail form is the 512-register form");
-  constexpr int NW = C == 256 ? 4 : 8, CB = C / 32, KB = C / 16, HID = 4 * C, NH = HID / 32, OC = C / 32;
+  constexpr int NW = C == 256 ? 4 : MRN_MLP_WAVES, CB = C / 32, KB = C / 16, HID = 4 * C, NH = HID / 32, OC = C / 32;
   constexpr int W1_SLAB = CB * 32 * 128;            // 32 hidden rows x C channels, [channel block][row][128 B]
   constexpr int W2_SLAB = C * 128;                  // C output rows x one 32-hidden line
   constexpr int SLAB = W1_SLAB + W2_SLAB;
@@ -434,7 +437,7 @@ int launch_mlp(const MlpParams& p, int G, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)svtr_mlp_kernel<C, TAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);
     attr_set = true;
   }
-  hipLaunchKernelGGL((svtr_mlp_kernel<C, TAIL>), dim3((unsigned)(G * p.tiles_per_group)), dim3(C == 256 ? 256 : 512), ldsz, st, p);
+  hipLaunchKernelGGL((svtr_mlp_kernel<C, TAIL>), dim3((unsigned)(G * p.tiles_per_group)), dim3(C == 256 ? 256 : MRN_MLP_WAVES * 64), ldsz, st, p);
   MRN_LAUNCH_CHECK("svtr_mlp_x3");
   return MRN_OK;
 }
@@ -461,7 +464,7 @@ MRN_EXPORT int mrn_svtr_mlp_x3_f32(const void* x_hl, const void* w1_hl, const fl
   p.x_hl = (const unsigned char*)x_hl; p.w1 = (const unsigned char*)w1_hl; p.w2 = (const unsigned char*)w2_hl;
   p.b1 = b1; p.b2 = b2; p.s1 = s1; p.s2 = s2; p.y = y;
   p.rows = rows; p.rows_per_group = rows_per_group;
-  const int tile_rows = C == 256 ? 128 : 256;
+  const int tile_rows = C == 256 ? 128 : MRN_MLP_WAVES * 32;
   p.tiles_per_group = (int)((rows_per_group + tile_rows - 1) / tile_rows);
   p.wp = nullptr; p.sp = p.bp = p.drop = p.gamma = p.beta = nullptr; p.x_res = nullptr; p.rows_per_drop = 1; p.eps = 0.f;
   if (C == 256) return launch_mlp<256, false>(p, G, (hipStream_t)stream);
