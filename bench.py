@@ -592,12 +592,14 @@ def time_loop_b_short(args, opt, steps, warmup):
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    host = time.perf_counter() - t0
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     pending.clear()
     del learner
     return {"metric": "text-line images/sec (fwd+bwd) at 32x256, TRBA+MRN 6 experts, REDUCED precision (not the headline)",
             "value": args.batch * steps / elapsed, "unit": "images/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": warmup,
+            "host_issue_ms_per_step": host / steps * 1e3,
             "dtype": "fp16" if ops.X3_PRODUCTS == 1 else "f32"}
 
 

@@ -6,6 +6,7 @@ import time
 import torch
 
 from .. import functional as Fn
+from .. import ops
 from ..tools.utils import Averager
 from .base import BaseLearner
 
@@ -23,7 +24,7 @@ class LwF(BaseLearner):
 
     def _old_stream(self):
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            self._side = ops.aux_stream(0, self.device)
         return self._side
 
     def kd_step(self, image, labels):

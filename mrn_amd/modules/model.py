@@ -223,7 +223,7 @@ class DERNet(Model):
         if plan is None or plan[2] is None or not (self.frozen_stream and image.is_cuda):
             return None
         if self._side is None:
-            self._side = torch.cuda.Stream(device=image.device)
+            self._side = ops.aux_stream(0, image.device)
         side = self._side
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -371,7 +371,7 @@ class MRNNet(nn.Module):
 
     def _streams(self, n, device):
         while len(self._stream_pool) < n:
-            self._stream_pool.append(torch.cuda.Stream(device=device))
+            self._stream_pool.append(ops.aux_stream(len(self._stream_pool), device))      # (process-wide: see ops.aux_stream)
         return self._stream_pool
 
     def _backbone_group(self):

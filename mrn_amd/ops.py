@@ -1966,6 +1966,24 @@ def side_stream():
     return st
 
 
+_AUX_STREAMS = {}
+
+
+def aux_stream(i, device=None):
+    """the i-th PROCESS-WIDE auxiliary stream of a device (lock-step sub-groups of the frozen experts, the heads, DER's frozen
+    extractors, LwF's previous network).  Every model takes the same streams instead of drawing fresh ones: torch hands streams out
+    of a pool round-robin and the runtime maps them onto a few hardware queues in creation order, so the third learner of a process
+    got streams that shared a queue -- SVTR x 6 (three concurrent sub-groups) ran 7 % slower as the last short line of a default
+    bench run than alone (21.5 vs 19.8 ms; host issue time equal), and the reduced-mode DER line 9 %."""
+    dev = torch.cuda.current_device() if device is None else (device.index if isinstance(device, torch.device) else int(device))
+    if dev is None:
+        dev = torch.cuda.current_device()
+    pool = _AUX_STREAMS.setdefault(dev, [])
+    while len(pool) <= i:
+        pool.append(torch.cuda.Stream(device=dev))
+    return pool[i]
+
+
 def join_side_stream():
     """the current stream waits for everything issued on the side stream (called once at the end of a backward pass)"""
     if _SIDE_PENDING[0]:
