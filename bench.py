@@ -31,8 +31,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0                         # MI355X_MICROARCH.md: de
 HBM_PEAK_GBS = 8000.0                                  # MI355X_MICROARCH.md: HBM3E peak (6.3 TB/s achievable on a float4 copy)
 
 
-PMC_SOURCE = ("static: profiles/r05_pmc.json -- separate rocprofv3 --pmc passes of this same command (tools/pmc_pass.sh), "
-              "FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE; counters cannot be read from inside the timed run")
+PMC_SOURCE = "profiles/r06_pmc.json (tools/pmc_pass.sh: separate rocprofv3 --pmc passes of this command; 2 x FETCH_SIZE + WRITE_SIZE)"
 
 
 def pmc_traffic(kernel_name, section="kernels"):
@@ -216,7 +215,7 @@ def power_probe(ops, R, launches=3):
     gflop = 2.0 * G * B * H * W * C * 9 * C / 1e9
     out.update({"shape": "G6 B256 4x65 512->512 3x3 (%s)" % ("Winograd F(%d,3)" % R if R else "direct"), "launches_each": launches,
                 "algorithmic_gflop_per_launch": gflop, "random_tflops": gflop / out["random_ms"], "zero_all_tflops": gflop / out["zero_all_ms"],
-                "measured": "live, after the timed region: HIP events around back-to-back launches of the same kernel on one stream"})
+                "measured": "live, behind the timed region: HIP events around back-to-back launches"})
     return out
 
 
@@ -239,9 +238,7 @@ def comm_telemetry(reducer, world, dev, step_ms):
         if exposed:
             out["exposed_ms_per_step"] = sum(exposed) / len(exposed)
             out["overlap_frac"] = max(0.0, 1.0 - out["exposed_ms_per_step"] / max(out["allreduce_ms_per_step"], 1e-9))
-        out["measured"] = ("allreduce_ms_per_step: the step's buckets all-reduced back to back on an otherwise idle GPU (HIP events); "
-                           "exposed_ms_per_step: HIP events on the compute stream around the wait for the outstanding buckets inside the timed "
-                           "steps; overlap_frac = 1 - exposed / standalone")
+        out["measured"] = "standalone: buckets back to back on an idle GPU; exposed: HIP events around the wait inside the timed steps"
     return out
 
 
@@ -436,8 +433,7 @@ def time_loop_a(args, opt, rank, world, steps, warmup, with_cpu_baseline=False):
         rl, hbm = roofline_entries(timer.summary(), steps, elapsed, pmc_section="kernels_loop_a" if args.model == "trba" else "none")
         if rl:
             res["roofline"] = rl[0]
-            res["roofline"]["measured"] = ("timed region: HIP events per launch on the launch stream (forward, data-gradient and weight-gradient "
-                                           "GEMMs of the trained convolutions run on this kernel family); rate over the union of the launch intervals")
+            res["roofline"]["measured"] = "timed region, HIP events per launch on the launch stream; rate over the union of the launch intervals"
             if len(rl) > 1 or hbm:
                 res["roofline_other_kernels"] = rl[1:4] + hbm
     if world > 1:
@@ -615,7 +611,7 @@ LINE_LIMIT = 4096            # the driver keeps an 8 KB tail of stdout: the line
 def _sig(x, digits=5):
     """numbers of the compact line at 5 significant digits (the detail file keeps them in full)"""
     if isinstance(x, float):
-        return float(f"{x:.{digits}g}")
+        return float(f"{x:.{digits}g}") if x == x and abs(x) != float("inf") else None      # (NaN / inf are not JSON)
     if isinstance(x, dict):
         return {k: _sig(v, digits) for k, v in x.items()}
     if isinstance(x, (list, tuple)):
@@ -884,10 +880,8 @@ def main():
                 res["roofline"]["power_probe"] = probe
             net = learner.model.module
             groups = net._half_groups(True) if hasattr(net, "_half_groups") else None
-            res["roofline"]["measured"] = ("timed region: HIP events per launch on the launch streams; %s and the router phase of the previous "
-                                           "batch share the GPU, so the rate is taken over the union of this kernel's launch intervals"
-                                           % ("one lock-step group of all experts (one side stream)" if groups is not None and len(groups) == 1 else
-                                              "%d lock-step sub-groups of the experts (one stream each)" % (len(groups) if groups else 1)))
+            res["roofline"]["measured"] = ("timed region, HIP events per launch on the launch stream(s), rate over the union of the launch "
+                                           "intervals; %d lock-step sub-group(s)" % (len(groups) if groups else 1))
             if isolated:
                 k = max((k for k in isolated if not k.startswith("hbm/")), key=lambda k: isolated[k]["total_ms"])
                 i_ = isolated[k]
@@ -897,8 +891,7 @@ def main():
                 res["roofline"]["isolated"] = {
                     "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "mfma_issue_frac": ach * per_flop / peak,
                     "avg_launch_ms": ms, "launches_per_step": i_["launches"] / 2, "kernel": kname.split(" (")[0],
-                    "measured": "2 extra steps after the timed region, one lock-step group of all experts on one stream, "
-                                "no look-ahead: each launch has the GPU to itself (python bench.py --serial reproduces it)"}
+                    "measured": "2 serialized steps behind the timed region (python bench.py --serial reproduces it)"}
             if len(rl) > 1 or hbm:
                 res["roofline_other_kernels"] = rl[1:] + hbm
         if comm is not None:
