@@ -227,6 +227,10 @@ int64_t mrn_conv3x3_patch_stats_blocks(int G, int B, int H, int W, int Cin);
 int mrn_conv3x3_patch_x3_hl32(const void* x_hl, const void* w_hl, const float* w_scale, const float* bias, const void* bn_gamma_ptrs,
                               float* y, float* stats, int G, int64_t x_group_stride_bytes, int B, int H, int W, int Cin, int Cout,
                               int act, int pool, void* stream);
+/* ... and with ONE fp16 product per term (hi x hi: the reduced-precision mode of BASELINE configs 2 / 5; same operands, the lo halves unread) */
+int mrn_conv3x3_patch_x1_hl32(const void* x_hl, const void* w_hl, const float* w_scale, const float* bias, const void* bn_gamma_ptrs,
+                              float* y, float* stats, int G, int64_t x_group_stride_bytes, int B, int H, int W, int Cin, int Cout,
+                              int act, int pool, void* stream);
 
 /* Elementwise passes between grouped convolutions (G frozen experts in lock-step).
  * mrn_bn_finalize_grouped_f32: train-mode BatchNorm2d statistics for G modules at once; partials [G][nblk][2][C] from

@@ -96,7 +96,8 @@ __device__ __forceinline__ float swap1(float v) {
 // The main loop of a pass is ONE basic block -- no branch on anything the launch decides at run time: the pooled form is a template
 // parameter, ReLU is a floor of 0 or -inf, invalid lanes store and fetch at an offset beyond their buffer descriptor (dropped / zeros)
 // -- because the scheduler interleaves the epilogue slices with the MFMAs only inside a block.
-template <int CB, int NCO, int NST, bool POOL>
+// NPROD: 3 = split-fp16 x3 (parity mode); 1 = hi * hi only (reduced-precision mode: the lo halves are neither held nor read)
+template <int CB, int NCO, int NST, bool POOL, int NPROD = 3>
 __global__ __launch_bounds__(256) void conv_patch_x3_kernel(const ConvPatchParams p) {
   using C = Cfg<CB, NCO, NST>;
   constexpr int PR = C::PR, PC = C::PC, TH = C::TH, STAGE = C::STAGE;
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256) void conv_patch_x3_kernel(const ConvPatchParam
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           Wh[cb][tap][ks] = *reinterpret_cast<const u32x4*>(wg + (cb * 9 + tap) * 128 + ks * 32);
-          Wl[cb][tap][ks] = *reinterpret_cast<const u32x4*>(wg + (cb * 9 + tap) * 128 + 64 + ks * 32);
+          if constexpr (NPROD == 3) Wl[cb][tap][ks] = *reinterpret_cast<const u32x4*>(wg + (cb * 9 + tap) * 128 + 64 + ks * 32);
         }
   }
   const float osc = p.w_scale[g * 2 + 1];
@@ -367,7 +368,7 @@ __global__ __launch_bounds__(256) void conv_patch_x3_kernel(const ConvPatchParam
 #pragma unroll
         for (int r = 0; r < RP; ++r) {
           const int imm = (cb * PR + ps * RP + r + dy) * PC * 128;
-          Xl[set][r] = *reinterpret_cast<const u32x4*>(lds + offv[dx][1][ks] + imm);
+          if constexpr (NPROD == 3) Xl[set][r] = *reinterpret_cast<const u32x4*>(lds + offv[dx][1][ks] + imm);
           Xh[set][r] = *reinterpret_cast<const u32x4*>(lds + offv[dx][0][ks] + imm);
         }
       };
@@ -385,17 +386,20 @@ __global__ __launch_bounds__(256) void conv_patch_x3_kernel(const ConvPatchParam
             if (i < C::NJ) issue_dma(i, nx, stage ^ 1, more);
         }
         if (PIPE && s >= EPI0 && s < EPI0 + 8) epilogue_slice(accp, s - EPI0);      // (nothing pending: every validity flag is 0)
+        if constexpr (NPROD == 3) {
 #pragma unroll
-        for (int r = 0; r < RP; ++r) acc[r] = mma(Wh[cb][tap][ks], Xl[set][r], acc[r]);
+          for (int r = 0; r < RP; ++r) acc[r] = mma(Wh[cb][tap][ks], Xl[set][r], acc[r]);
 #pragma unroll
-        for (int r = 0; r < RP; ++r) acc[r] = mma(Wl[cb][tap][ks], Xh[set][r], acc[r]);
+          for (int r = 0; r < RP; ++r) acc[r] = mma(Wl[cb][tap][ks], Xh[set][r], acc[r]);
+        }
 #pragma unroll
         for (int r = 0; r < RP; ++r) acc[r] = mma(Wh[cb][tap][ks], Xh[set][r], acc[r]);
         // one scheduling region per step (the scheduler otherwise hoists the reads of several steps: live fragments spill next to the
         // weights), ordered [MFMA, a few VALU operations of the pending epilogue, a fragment read] so that the fillers sit BETWEEN the MFMAs
 #define PATCH_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0);
 #define PATCH_INTERLEAVE PATCH_SGB(0x008, 1) PATCH_SGB(0x002, 6) PATCH_SGB(0x100, 1) PATCH_SGB(0x020, 1) PATCH_SGB(0x040, 1)
-        PATCH_INTERLEAVE PATCH_INTERLEAVE PATCH_INTERLEAVE PATCH_INTERLEAVE PATCH_INTERLEAVE PATCH_INTERLEAVE
+        PATCH_INTERLEAVE PATCH_INTERLEAVE
+        if constexpr (NPROD == 3) { PATCH_INTERLEAVE PATCH_INTERLEAVE PATCH_INTERLEAVE PATCH_INTERLEAVE }
         __builtin_amdgcn_sched_barrier(0);
       }
       if (ps == 0 && flush_row >= 0) {            // (the pending epilogue of the previous row's last tile ran under this pass)
@@ -484,9 +488,9 @@ MRN_EXPORT int64_t mrn_conv3x3_patch_stats_blocks(int G, int B, int H, int W, in
 // BatchNorm weight that follows (bn_gamma_ptrs: device table of G device addresses, NULL = no BatchNorm: all maxima) is >= 0 and
 // its MINIMUM where it is negative -- applying scale / shift / ReLU to that map equals max-pooling the applied full map bit for bit;
 // the statistics still cover the full map.
-MRN_EXPORT int mrn_conv3x3_patch_x3_hl32(const void* x_hl, const void* w_hl, const float* w_scale, const float* bias,
-                                         const void* bn_gamma_ptrs, float* y, float* stats, int G, int64_t x_group_stride_bytes, int B,
-                                         int H, int W, int Cin, int Cout, int act, int pool, void* stream) {
+static int patch_launch(const void* x_hl, const void* w_hl, const float* w_scale, const float* bias,
+                        const void* bn_gamma_ptrs, float* y, float* stats, int G, int64_t x_group_stride_bytes, int B,
+                        int H, int W, int Cin, int Cout, int act, int pool, int products, void* stream) {
   MRN_CHECK_ARG(x_hl && w_hl && w_scale && y && G >= 1 && mrn_conv3x3_patch_supported(Cin, Cout),
                 "mrn_conv3x3_patch_x3_hl32: bad operands (Cin=%d Cout=%d)", Cin, Cout);
   MRN_CHECK_ARG(!pool || (H % 2 == 0 && W % 2 == 0), "mrn_conv3x3_patch_x3_hl32: the pooled form needs even H, W (%d x %d)", H, W);
@@ -504,24 +508,39 @@ MRN_EXPORT int mrn_conv3x3_patch_x3_hl32(const void* x_hl, const void* w_hl, con
   p.rows = patch_rows(p.tiles);
   int wgs = patch_wgs(G, p.tiles, 1);
   if (wgs > p.rows) wgs = p.rows;
-#define PATCH_LAUNCH(CB_, NCO_, POOL_)                                                                                                   \
+#define PATCH_LAUNCH(CB_, NCO_, POOL_, NP_)                                                                                              \
   do {                                                                                                                                   \
     using C = Cfg<CB_, NCO_, 2>;                                                                                                          \
     static bool set = false;                                                                                                             \
     if (!set) {                                                                                                                          \
-      (void)hipFuncSetAttribute((const void*)conv_patch_x3_kernel<CB_, NCO_, 2, POOL_>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS); \
+      (void)hipFuncSetAttribute((const void*)conv_patch_x3_kernel<CB_, NCO_, 2, POOL_, NP_>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS); \
       set = true;                                                                                                                        \
     }                                                                                                                                    \
-    hipLaunchKernelGGL((conv_patch_x3_kernel<CB_, NCO_, 2, POOL_>), dim3(wgs, G), dim3(256), C::LDS, (hipStream_t)stream, p);           \
+    hipLaunchKernelGGL((conv_patch_x3_kernel<CB_, NCO_, 2, POOL_, NP_>), dim3(wgs, G), dim3(256), C::LDS, (hipStream_t)stream, p);      \
   } while (0)
+#define PATCH_LAUNCH_P(CB_, NCO_, POOL_) do { if (products == 1) PATCH_LAUNCH(CB_, NCO_, POOL_, 1); else PATCH_LAUNCH(CB_, NCO_, POOL_, 3); } while (0)
   if (Cin == 32) {
-    if (pool) PATCH_LAUNCH(1, 2, true);
-    else PATCH_LAUNCH(1, 2, false);
+    if (pool) PATCH_LAUNCH_P(1, 2, true);
+    else PATCH_LAUNCH_P(1, 2, false);
   } else {
-    if (pool) PATCH_LAUNCH(2, 4, true);
-    else PATCH_LAUNCH(2, 4, false);
+    if (pool) PATCH_LAUNCH_P(2, 4, true);
+    else PATCH_LAUNCH_P(2, 4, false);
   }
+#undef PATCH_LAUNCH_P
 #undef PATCH_LAUNCH
   MRN_LAUNCH_CHECK("conv3x3_patch_x3");
   return MRN_OK;
+}
+
+MRN_EXPORT int mrn_conv3x3_patch_x3_hl32(const void* x_hl, const void* w_hl, const float* w_scale, const float* bias,
+                                         const void* bn_gamma_ptrs, float* y, float* stats, int G, int64_t x_group_stride_bytes, int B,
+                                         int H, int W, int Cin, int Cout, int act, int pool, void* stream) {
+  return patch_launch(x_hl, w_hl, w_scale, bias, bn_gamma_ptrs, y, stats, G, x_group_stride_bytes, B, H, W, Cin, Cout, act, pool, 3, stream);
+}
+
+// the same convolution with ONE fp16 product per term (hi * hi; the lo halves of both operands stay unread): the reduced-precision mode
+MRN_EXPORT int mrn_conv3x3_patch_x1_hl32(const void* x_hl, const void* w_hl, const float* w_scale, const float* bias,
+                                         const void* bn_gamma_ptrs, float* y, float* stats, int G, int64_t x_group_stride_bytes, int B,
+                                         int H, int W, int Cin, int Cout, int act, int pool, void* stream) {
+  return patch_launch(x_hl, w_hl, w_scale, bias, bn_gamma_ptrs, y, stats, G, x_group_stride_bytes, B, H, W, Cin, Cout, act, pool, 1, stream);
 }

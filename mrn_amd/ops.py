@@ -1025,7 +1025,7 @@ PATCH_CONV = os.environ.get("MRN_PATCH_CONV", "1") == "1"       # A/B switch: th
 
 
 def patch_conv_supported(ksize, stride, padding, Cin, Cout):
-    return (PATCH_CONV and X3_PRODUCTS == 3 and tuple(ksize) == (3, 3) and tuple(stride) == (1, 1) and tuple(padding) == (1, 1)
+    return (PATCH_CONV and tuple(ksize) == (3, 3) and tuple(stride) == (1, 1) and tuple(padding) == (1, 1)
             and bool(call("mrn_conv3x3_patch_supported", Cin, Cout)))
 
 
@@ -1043,11 +1043,12 @@ def conv3x3_patch_x3(x_hl, G, shared_input, B, H, W, Cin, w_hl, w_scale, Cout, b
         stats = torch.empty(G, call("mrn_conv3x3_patch_stats_blocks", G, B, H, W, Cin), 2, Cout, device=dev, dtype=torch.float32)
     timed = CONV_TIMER is not None
     t0 = CONV_TIMER.begin() if timed else None
-    call("mrn_conv3x3_patch_x3_hl32", _p(x_hl), _p(w_hl), _p(w_scale), _p(bias), _p(gamma_ptrs), _p(y), _p(stats), G,
-         0 if shared_input else B * H * W * Cin * 4, B, H, W, Cin, Cout, act, int(bool(pool)), _stream())
+    one = X3_PRODUCTS == 1          # (reduced-precision mode: hi x hi only, same operands)
+    call("mrn_conv3x3_patch_x1_hl32" if one else "mrn_conv3x3_patch_x3_hl32", _p(x_hl), _p(w_hl), _p(w_scale), _p(bias), _p(gamma_ptrs), _p(y),
+         _p(stats), G, 0 if shared_input else B * H * W * Cin * 4, B, H, W, Cin, Cout, act, int(bool(pool)), _stream())
     if timed:
         nbytes = 4.0 * ((1 if shared_input else G) * B * H * W * Cin + G * Cout * 9 * Cin + G * B * Ho * Wo * Cout)
-        kind = "fp16x3/patch%d" % Cin + ("pool" if pool else "")
+        kind = ("fp16" if one else "fp16x3") + "/patch%d" % Cin + ("pool" if pool else "")
         if TIMER_SHAPES:
             kind += "|G%d B%d %dx%d %d->%d k3x3 s11" % (G, B, H, W, Cin, Cout)
         CONV_TIMER.end(t0, 2.0 * G * B * H * W * Cout * 9 * Cin, kind, nbytes)

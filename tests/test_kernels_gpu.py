@@ -863,6 +863,43 @@ def test_patch_resident_conv(ops, G, B, H, W, Cin, Cout, shared):
     assert torch.equal(torch.nan_to_num(ynp), torch.nan_to_num(refn))
 
 
+@pytest.mark.parametrize("G,B,H,W,Cin,Cout", [(3, 3, 32, 256, 32, 64), (2, 2, 16, 128, 64, 128), (1, 2, 12, 70, 64, 128)])
+def test_patch_resident_conv_one_product(ops, G, B, H, W, Cin, Cout):
+    """mrn_conv3x3_patch_x1_hl32 (the reduced-precision mode's form of the patch-resident kernel: hi x hi only) against float64 torch on
+    the operands' fp16 hi parts -- exact products, fp32 accumulation: 1e-5 of the output scale -- and its distance from the unquantised
+    convolution (a few 1e-3: the mode's accuracy); statistics and the pooled epilogue as in the x3 form"""
+    x = rnd(G, B, H, W, Cin, seed=330, scale=2.0)
+    w = [rnd(Cout, 3, 3, Cin, seed=331 + g, scale=0.1) for g in range(G)]
+    bias = rnd(G, Cout, seed=339)
+    x_hl = ops.split_hl32(cu(x))
+    w_hl, w_scale = ops.pack_weights_hl32([cu(t) for t in w])
+    saved = ops.X3_PRODUCTS
+    try:
+        ops.X3_PRODUCTS = 1
+        y, stats = ops.conv3x3_patch_x3(x_hl, G, False, B, H, W, Cin, w_hl, w_scale, Cout, bias=cu(bias), want_stats=True)
+        if H % 2 == 0 and W % 2 == 0:
+            yp, sp = ops.conv3x3_patch_x3(x_hl, G, False, B, H, W, Cin, w_hl, w_scale, Cout, bias=cu(bias), want_stats=True, pool=True)
+    finally:
+        ops.X3_PRODUCTS = saved
+    sc = w_scale.cpu().double()
+    for g in range(G):
+        xq = x[g].half().double().permute(0, 3, 1, 2)
+        wq = (w[g].double() * sc[g, 0]).half().double() * sc[g, 1]
+        ref_q = torch.nn.functional.conv2d(xq, wq.permute(0, 3, 1, 2), bias[g].double(), 1, 1).permute(0, 2, 3, 1)
+        ref = torch.nn.functional.conv2d(x[g].double().permute(0, 3, 1, 2), w[g].double().permute(0, 3, 1, 2), bias[g].double(), 1, 1).permute(0, 2, 3, 1)
+        scale = float(ref.abs().max())
+        got = y[g].double().cpu()
+        assert float((got - ref_q).abs().max()) <= 1e-5 * scale, (float((got - ref_q).abs().max()), scale)
+        err = float((got - ref).abs().max())
+        assert 1e-5 * scale < err <= 1e-2 * scale, (err, scale)
+        tot = stats[g].double().sum(0).cpu()
+        assert_close("sum", tot[0].float(), got.sum((0, 1, 2)).float(), atol=1e-5 * scale * B * H * W, rtol=0)
+    if H % 2 == 0 and W % 2 == 0:
+        assert torch.equal(sp, stats)
+        ref_p, _, _ = ops.maxpool_grouped(y, (2, 2), (2, 2), (0, 0), None, None, relu=False, want_f32=True, want_hl=False)
+        assert torch.equal(yp, ref_p)
+
+
 def test_sgd_and_adadelta_steps_vs_torch():
     """FlatSGD / FlatAdadelta (mrn_sgd_step_f32 / mrn_adadelta_step_f32) against torch.optim.SGD(momentum, weight_decay) and
     torch.optim.Adadelta(rho, eps) with clip_grad_norm_ in front -- the other two optimisers of il_modules/base.py:72-85"""
