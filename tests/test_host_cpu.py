@@ -424,3 +424,50 @@ def test_converter_encode_array_fill_equals_the_per_word_loop():
         c.encode(["a" * 26], 25)
     with pytest.raises(RuntimeError):
         a.encode(["a" * 26], 25)
+
+
+def test_bench_compact_line_is_bounded_and_strict_json():
+    """bench.compact_line (what the driver parses): headline + roofline numbers + cpu_baseline + {value, ms_per_step} per extra line, never
+    the detail record's prose; under 4 KB whatever the record holds (optional objects are dropped first), non-finite numbers as null"""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    res = {"metric": "m", "value": 3000.123456, "unit": "images/s", "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": 83.3333333,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "arithmetic": "x" * 500,
+           "config": {"workload": "w", "per_gpu_batch": 256, "global_batch": 256, "parallelism": "dp1", "classes": [1, 2], "parity": "p" * 900},
+           "roofline": {"bound": "mfma", "kernel": "wino_rows_kernel F(4,3)", "achieved": 750.0, "peak": 2500.0, "unit": "TFLOP/s", "frac": 0.3,
+                        "traffic": float("nan"), "measured": "prose " * 200, "power_probe": {"a": 1}, "isolated": {"achieved": 800.0, "frac": 0.32, "avg_launch_ms": 1.7, "measured": "z" * 300}},
+           "roofline_other_kernels": [{"kernel": "k" * 300}] * 20,
+           "cpu_baseline": {"value": 14.0, "unit": "images/s", "cores": 16, "kind": "port", "cpu": "c", "sample": "s", "index_agreement": {"greedy_index_agreement": 1.0}},
+           "extra": {"loop_a": {"value": 1.0, "ms_per_step": 2.0, "roofline": {"kernel": "y" * 2000}, "metric": "q" * 300}}}
+    line = bench.compact_line(res, "bench_detail.json")
+    assert len(line) < 1500 and "\n" not in line and "prose" not in line and "NaN" not in line
+    d = json.loads(line)
+    assert d["value"] == 3000.1 and d["roofline"]["frac"] == 0.3 and d["roofline"]["traffic"] is None and "measured" not in d["roofline"]
+    assert d["roofline"]["isolated"] == {"achieved": 800.0, "frac": 0.32, "avg_launch_ms": 1.7} and d["cpu_baseline"]["index_agreement"]["greedy_index_agreement"] == 1.0
+    assert d["extra"] == {"loop_a": {"value": 1.0, "ms_per_step": 2.0}} and d["detail"] == "bench_detail.json" and "roofline_other_kernels" not in d
+    # an oversized record sheds its optional objects instead of growing past the driver's tail
+    res["extra"] = {"line%d" % i: {"value": float(i), "ms_per_step": 1.0} for i in range(200)}
+    line = bench.compact_line(res, "bench_detail.json")
+    d = json.loads(line)
+    assert len(line) < bench.LINE_LIMIT and "extra" not in d and d["roofline"]["frac"] == 0.3 and d["cpu_baseline"]["value"] == 14.0
+
+
+def test_reduced_mode_winograd_eligibility():
+    """host logic of the reduced-precision mode's Winograd form (no kernel is launched): which layers take the plain-fp16 (d16) operands"""
+    from mrn_amd import ops
+    saved = (ops.X3_PRODUCTS, ops.WINO_DENSE)
+    try:
+        ops.X3_PRODUCTS = 3
+        assert not ops.wino_dense() and ops.wino_eligible((3, 3), (1, 1), (1, 1), 512, 512) and ops.wino_eligible((3, 3), (1, 1), (1, 1), 160, 96)
+        assert not ops.wino_eligible((3, 3), (1, 1), (1, 1), 64, 128) and not ops.wino_eligible((3, 3), (2, 1), (1, 1), 512, 512)      # narrow / strided
+        ops.X3_PRODUCTS = 1
+        assert ops.wino_dense() and ops.wino_eligible((3, 3), (1, 1), (1, 1), 512, 512)
+        assert not ops.wino_eligible((3, 3), (1, 1), (1, 1), 160, 96)                   # Cin % 64 != 0: no d16 form
+        assert ops.wino_eligible((3, 3), (1, 1), (1, 1), 160, 96, products=3)           # a trained layer of a parity-mode step asks for its own mode
+        assert ops.wino_dense(1) and not ops.wino_dense(3)
+        ops.WINO_DENSE = False
+        assert not ops.wino_dense() and not ops.wino_eligible((3, 3), (1, 1), (1, 1), 512, 512)      # MRN_WINO_DENSE=0: the round-5 form of the mode
+    finally:
+        ops.X3_PRODUCTS, ops.WINO_DENSE = saved
+
