@@ -458,6 +458,12 @@ __device__ __forceinline__ void wino_rows_tile(const WinoRowsParams& p, unsigned
 template <int DENSE>
 __global__ __launch_bounds__(256) void wino_rows_kernel(const WinoRowsParams p) {
   extern __shared__ __attribute__((aligned(128))) unsigned char lds[];
+#ifdef MRN_WPROBE_SKEW
+  // what-if probe: every other workgroup of the first round starts MRN_WPROBE_SKEW x 3.4 us late, so that the halves of the chip reach their
+  // store epilogues (a 64 MB burst per round when all 256 workgroups arrive together) at different times
+  if (blockIdx.x < 256u && ((blockIdx.x >> 3) & 1u))
+    for (int i = 0; i < MRN_WPROBE_SKEW; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
   // tile order: output-channel tile fastest, so the workgroups that share an XCD's L2 at one time read the same activation lines
   // (block b runs on XCD b % 8; xcd_remap makes consecutive logical tiles share an XCD)
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
