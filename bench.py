@@ -302,7 +302,7 @@ def train_dtype():
     """f32: every product is a 22-bit split-fp16 x3 MFMA term or exact fp32, fp32 accumulate and storage; fp16: ONE fp16 product per term
     (--precision fp16, the reduced mode of BASELINE configs 2 / 5)"""
     from mrn_amd import ops
-    return "fp16" if ops.TRAIN_PRODUCTS == 1 else "f32"
+    return ("bf16" if ops.REDUCED_BF16 else "fp16") if ops.TRAIN_PRODUCTS == 1 else "f32"
 
 
 def describe_kernel(kind):
@@ -694,11 +694,12 @@ def main():
     ap.add_argument("--timer-all", action="store_true", help="HIP events around EVERY timed launch inside the timed region (default: the dominant "
                     "kernel's launches only; the other kernels are measured in a short pass behind it)")
     ap.add_argument("--verbose", action="store_true")
-    ap.add_argument("--precision", default="auto", choices=["auto", "f32", "fp16x3", "fp16"],
+    ap.add_argument("--precision", default="auto", choices=["auto", "f32", "fp16x3", "fp16", "bf16"],
                     help="arithmetic of the frozen experts' convolutions / Linear layers: auto = split-fp16 x3 (22-bit products, keeps "
                          "the 1e-4 parity band: the headline); fp16 = ONE fp16 product per term on the same grouped kernels (the "
                          "reduced-precision mode of BASELINE configs 2 and 5: a separate line, never the headline); f32: "
-                         "the per-expert exact-fp32 MFMA kernel (mrn_amd/ops.py: CONV_PRECISION)")
+                         "the per-expert exact-fp32 MFMA kernel (mrn_amd/ops.py: CONV_PRECISION); bf16: the fp16 mode with the Winograd layers' 16-bit operands as "
+                         "bfloat16 (comparison line: BASELINE config 2 says \"bf16\")")
     ap.add_argument("--no-streams", action="store_true", help="run the experts sequentially on one stream")
     ap.add_argument("--no-pipeline", action="store_true", help="do not issue batch n+1's expert forward before batch n's router phase")
     ap.add_argument("--serial", action="store_true", help="one lock-step group on one stream, no look-ahead (every kernel runs alone)")
@@ -730,9 +731,10 @@ def main():
     torch.set_num_threads(max(1, host_cpu_budget() // max(1, world)))     # (PyTorch sizes its pools from the affinity mask, not the cgroup quota)
     torch.manual_seed(111)
 
-    if args.precision == "fp16":
+    if args.precision in ("fp16", "bf16"):
         ops.X3_PRODUCTS = 1
         ops.TRAIN_PRODUCTS = 1           # (--loop a / der / lwf / ewc: the trained convolutions too)
+        ops.REDUCED_BF16 = args.precision == "bf16"      # (the Winograd layers' 16-bit operands as bfloat16: comparison line of config 2's "bf16")
     else:
         ops.CONV_PRECISION = args.precision
     opt = make_opt(args.model, args.batch)
@@ -854,7 +856,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "host_issue_ms_per_step": host_elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "skipped_optimizer_steps": learner.optimizer.skipped_steps(),      # non-finite gradient norms (csrc/optim.hip): 0 or the line is suspect
-            "dtype": "fp16" if ops.X3_PRODUCTS == 1 else "f32",
+            "dtype": ("bf16" if ops.REDUCED_BF16 else "fp16") if ops.X3_PRODUCTS == 1 else "f32",
             "arithmetic": "one fp16 MFMA product per term, fp32 accumulate (reduced mode, not the headline)" if ops.X3_PRODUCTS == 1 else
             {"auto": "split-fp16 x3 MFMA products (22-bit), fp32 accumulate", "f32": "exact fp32 MFMA",
              "fp16x3": "split-fp16 x3 MFMA products (22-bit), fp32 accumulate"}[ops.CONV_PRECISION],

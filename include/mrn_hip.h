@@ -187,17 +187,19 @@ int mrn_conv2d_x3_wino_pool_hl32(const void* v_hl, const void* u_hl, const void*
  *   mrn_maxpool_wino_grouped_d16_f32    plain fp32 / HL32 by-products (identity-shortcut sources) keep full precision
  *   mrn_conv2d_x3_wino_d16              y, stats, out_scale, x_scale, v_group_stride_bytes as mrn_conv2d_x3_wino_hl32; pool != 0: the
  *                                       pooled epilogue of mrn_conv2d_x3_wino_pool_hl32.  H % 4 == 0 and Cin % 64 == 0, else
- *                                       MRN_ERR_UNSUPPORTED (there is no fallback kernel for this layout). */
-int mrn_pack_weight_wino_d16(const float* w_ohwi, void* out, int Cout, int Cin, const float* scale, void* stream);
+ *                                       MRN_ERR_UNSUPPORTED (there is no fallback kernel for this layout).
+ * bf16 != 0 (all four: producer and consumer must agree): the 16-bit operands are bfloat16 on v_mfma_f32_32x32x16_bf16 -- the literal "bf16" of
+ * BASELINE config 2, kept as a comparison instantiation (bench.py --precision bf16): same speed, 8 significand bits instead of fp16's 11. */
+int mrn_pack_weight_wino_d16(const float* w_ohwi, void* out, int Cout, int Cin, const float* scale, int bf16, void* stream);
 int mrn_bn_apply_wino_grouped_d16_f32(const float* y, const float* residual, const void* residual_hl32, const float* scale,
                                       const float* shift, float* out_f32, void* out_hl32, void* out_wino_d16, int G, int B, int H,
-                                      int W, int C, int relu, const float* prescale, void* stream);
+                                      int W, int C, int relu, const float* prescale, int bf16, void* stream);
 int mrn_maxpool_wino_grouped_d16_f32(const float* x, const float* scale, const float* shift, int relu, float* out_f32, void* out_hl32,
                                      void* out_wino_d16, int G, int B, int H, int W, int C, int kh, int kw, int sh, int sw, int ph,
-                                     int pw, void* stream);
+                                     int pw, int bf16, void* stream);
 int mrn_conv2d_x3_wino_d16(const void* v_d16, const void* u_d16, const float* bias, float* y, float* stats, const float* out_scale,
                            const float* x_scale, int G, int64_t v_group_stride_bytes, int B, int H, int W, int Cin, int Cout, int act,
-                           int pool, const void* bn_gamma_ptrs, void* stream);
+                           int pool, const void* bn_gamma_ptrs, int bf16, void* stream);
 
 /* First convolution of the frozen experts' stacks (3x3, stride 1, padding 1, Cin = 4, Cout = 32 or 64: VGG conv 0
  * feature_extraction.py:19, ResNet conv0_1 :214, TPS localisation conv 1 transformation.py:60), G experts in one launch on the

@@ -29,6 +29,7 @@
 namespace {
 
 typedef _Float16 f16v8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16v8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -45,6 +46,11 @@ __device__ __forceinline__ f32x16 mma(const u32x4 a, const u32x4 b, const f32x16
   return r;
 #endif
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16v8*>(&a), *reinterpret_cast<const f16v8*>(&b), c, 0, 0, 0);
+}
+
+// DENSE = 2: the plain 16-bit operands are bfloat16 (the literal "bf16" of BASELINE config 2: a comparison instantiation of the reduced mode)
+__device__ __forceinline__ f32x16 mma_bf16(const u32x4 a, const u32x4 b, const f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16v8*>(&a), *reinterpret_cast<const bf16v8*>(&b), c, 0, 0, 0);
 }
 
 // A^T of F(4,3) with the inverse row scales of the packed weight transform (conv_x3.hip: WinoAT<4>, pack_weight_wino_hl32_kernel)
@@ -174,12 +180,12 @@ __device__ __forceinline__ void wino_rows_tile(const WinoRowsParams& p, unsigned
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
         const int o = slot - ky;
-        if (o >= 0 && o <= 3) acc[o] = mma(Bh[ks][ky], Ah[par], acc[o]);
+        if (o >= 0 && o <= 3) acc[o] = DENSE == 2 ? mma_bf16(Bh[ks][ky], Ah[par], acc[o]) : mma(Bh[ks][ky], Ah[par], acc[o]);
       }
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
         const int o = slot - ky;
-        if (o >= 0 && o <= 3) acc[o] = mma(Bl[ks][ky], Al[par], acc[o]);
+        if (o >= 0 && o <= 3) acc[o] = DENSE == 2 ? mma_bf16(Bl[ks][ky], Al[par], acc[o]) : mma(Bl[ks][ky], Al[par], acc[o]);
       }
       return;
     }
@@ -511,9 +517,11 @@ int mrn_launch_wino_rows(const WinoRowsParams& p0, void* stream) {
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)wino_rows_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)wino_rows_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)wino_rows_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
   }
-  if (p.dense) hipLaunchKernelGGL(wino_rows_kernel<1>, dim3((unsigned)tiles), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
+  if (p.dense == 2) hipLaunchKernelGGL(wino_rows_kernel<2>, dim3((unsigned)tiles), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
+  else if (p.dense) hipLaunchKernelGGL(wino_rows_kernel<1>, dim3((unsigned)tiles), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(wino_rows_kernel<0>, dim3((unsigned)tiles), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
   MRN_LAUNCH_CHECK("conv2d_wino_rows");
   return MRN_OK;

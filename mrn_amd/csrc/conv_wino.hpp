@@ -14,7 +14,7 @@ struct WinoRowsParams {
   int v_bytes;                // bytes of one group's activation
   int G, B, H, W, Wq, Cb, N, act;
   int stats_blocks;           // row blocks the statistics buffer was sized for (mrn_conv2d_x3_wino_stats_floats)
-  int dense;                  // 1: operands are plain fp16, 64 channels per line (one product per term: the reduced-precision mode)
+  int dense;                  // 1 / 2: operands are plain fp16 / bfloat16, 64 channels per line (one product per term: the reduced-precision mode)
   int pool;                   // 1: y is [G][B][H/2][W/2][N], per 2x2 window the extreme chosen by the sign of the BatchNorm weight
   const long long* gamma;     // [G] device addresses of those BatchNorm weights, or null (all maxima)
   int tiles_p, row_blocks, tiles_n, tiles_m;   // filled by the launcher

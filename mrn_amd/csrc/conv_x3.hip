@@ -1539,8 +1539,23 @@ __global__ __launch_bounds__(256) void pack_weight_wino_hl32_kernel(const float*
       const _Float16 ll = (_Float16)(u - (double)hh);
       h[e] = hh; l[e] = ll;
     }
-    if (dense) {           // plain fp16, 64 channels per line: [Cout][NC][Cin/64][3][128 B]
-      *reinterpret_cast<f16v8*>(out + (((o_ * NC + m) * (Cin >> 6) + (c8 >> 3)) * 3 + ky) * 128 + (c8 & 7) * 16) = h;
+    if (dense) {           // plain fp16 (dense == 2: bfloat16), 64 channels per line: [Cout][NC][Cin/64][3][128 B]
+      unsigned char* dst = out + (((o_ * NC + m) * (Cin >> 6) + (c8 >> 3)) * 3 + ky) * 128 + (c8 & 7) * 16;
+      if (dense == 2) {
+        typedef unsigned short u16v8 __attribute__((ext_vector_type(8)));
+        u16v8 b;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          double u = 0.0;
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) u += wino_g(R, m, kx) * (double)src[kx * Cin + e];
+          const unsigned bits = __float_as_uint((float)(u * sc));
+          b[e] = (unsigned short)((bits + 0x7fffu + ((bits >> 16) & 1u)) >> 16);
+        }
+        *reinterpret_cast<u16v8*>(dst) = b;
+      } else {
+        *reinterpret_cast<f16v8*>(dst) = h;
+      }
       continue;
     }
     const int cb = c8 >> 2;
@@ -1567,14 +1582,14 @@ MRN_EXPORT int mrn_pack_weight_wino_hl32(const float* w_ohwi, void* out, int Cou
 
 // the same transform as PLAIN fp16 for the reduced-precision mode: w [Cout][3][3][Cin] fp32 -> [Cout][6][Cin/64][3][128 B] of
 // scale[0] * (G w), F(4,3), 64 channels per line (mrn_conv2d_x3_wino_d16's weight operand); Cin % 64 == 0
-MRN_EXPORT int mrn_pack_weight_wino_d16(const float* w_ohwi, void* out, int Cout, int Cin, const float* scale, void* stream) {
+MRN_EXPORT int mrn_pack_weight_wino_d16(const float* w_ohwi, void* out, int Cout, int Cin, const float* scale, int bf16, void* stream) {
   MRN_CHECK_ARG(w_ohwi && out && Cin % 64 == 0, "mrn_pack_weight_wino_d16: bad operands (Cin=%d)", Cin);
   const long n8 = (long)Cout * 6 * 3 * (Cin / 8);
   if (n8 == 0) return MRN_OK;
   long grid = (n8 + 255) / 256;
   if (grid > 8192) grid = 8192;
   hipLaunchKernelGGL(pack_weight_wino_hl32_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, w_ohwi, (unsigned char*)out,
-                     Cout, Cin, 4, scale, 1);
+                     Cout, Cin, 4, scale, bf16 ? 2 : 1);
   MRN_LAUNCH_CHECK("pack_weight_wino_d16");
   return MRN_OK;
 }
@@ -1682,9 +1697,9 @@ MRN_EXPORT int mrn_conv2d_x3_wino_hl32(const void* v_hl, const void* u_hl, const
 // MRN_ERR_UNSUPPORTED.  Statistics buffer: mrn_conv2d_x3_wino_stats_floats(G, B, H, W, Cout, 4).
 MRN_EXPORT int mrn_conv2d_x3_wino_d16(const void* v_d16, const void* u_d16, const float* bias, float* y, float* stats,
                                       const float* out_scale, const float* x_scale, int G, int64_t v_group_stride_bytes, int B, int H,
-                                      int W, int Cin, int Cout, int act, int pool, const void* bn_gamma_ptrs, void* stream) {
+                                      int W, int Cin, int Cout, int act, int pool, const void* bn_gamma_ptrs, int bf16, void* stream) {
   return wino_conv_launch(v_d16, u_d16, nullptr, bias, y, stats, out_scale, x_scale, G, v_group_stride_bytes, B, H, W, Cin, Cout, 4, act,
-                          pool, bn_gamma_ptrs, stream, 1);
+                          pool, bn_gamma_ptrs, stream, bf16 ? 2 : 1);
 }
 
 // mrn_conv2d_x3_wino_hl32 with the 2x2 / stride-2 max-pool that follows BatchNorm + ReLU taken in the epilogue (row-block kernel only:

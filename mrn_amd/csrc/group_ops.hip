@@ -44,14 +44,26 @@ __device__ __forceinline__ void store_hl(unsigned char* out, long row, int C, in
 }
 
 // the reduced-precision operand line: 64 channels of plain fp16 per 128 bytes (conv_wino.hip, DENSE), saturating like store_hl
-__device__ __forceinline__ void store_d16(unsigned char* out, long row, int C, int c8, const F8& v) {
+__device__ __forceinline__ void store_d16(unsigned char* out, long row, int C, int c8, const F8& v, int dense = 1) {
+  unsigned char* dst = out + (row * (C >> 6) + (c8 >> 3)) * 128 + (c8 & 7) * 16;
+  if (dense == 2) {            // bfloat16, round to nearest even (the comparison instantiation of the reduced mode)
+    typedef unsigned short u16v8 __attribute__((ext_vector_type(8)));
+    u16v8 h;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const unsigned u = __float_as_uint(e < 4 ? v.a[e] : v.b[e - 4]);
+      h[e] = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    }
+    *reinterpret_cast<u16v8*>(dst) = h;
+    return;
+  }
   f16v8 h;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     h[e] = (_Float16)fminf(fmaxf(v.a[e], -65504.f), 65504.f);
     h[4 + e] = (_Float16)fminf(fmaxf(v.b[e], -65504.f), 65504.f);
   }
-  *reinterpret_cast<f16v8*>(out + (row * (C >> 6) + (c8 >> 3)) * 128 + (c8 & 7) * 16) = h;
+  *reinterpret_cast<f16v8*>(dst) = h;
 }
 
 // a block = 32 channels x 32 row lanes of one group over ONE CHUNK of the partial rows (coalesced 128-byte reads, sums in double as
@@ -298,7 +310,7 @@ __global__ __launch_bounds__(256) void bn_apply_wino_grouped_kernel(const float*
     }
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
-      if (dense) store_d16(out_v, t * NC + k, C, c8, m[k]);
+      if (dense) store_d16(out_v, t * NC + k, C, c8, m[k], dense);
       else store_hl(out_v, t * NC + k, C, c8, m[k]);
     }
   }
@@ -458,7 +470,7 @@ __global__ __launch_bounds__(256) void maxpool_wino_grouped_kernel(const float* 
     }
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
-      if (dense) store_d16(out_v, t * NC + k, C, c8, m_[k]);
+      if (dense) store_d16(out_v, t * NC + k, C, c8, m_[k], dense);
       else store_hl(out_v, t * NC + k, C, c8, m_[k]);
     }
   }
@@ -644,8 +656,8 @@ MRN_EXPORT int mrn_bn_apply_wino_grouped_f32(const float* y, const float* residu
 // results (out_f32 / out_hl32: identity-shortcut sources) keep their full-precision forms.
 MRN_EXPORT int mrn_bn_apply_wino_grouped_d16_f32(const float* y, const float* residual, const void* residual_hl32, const float* scale,
                                                  const float* shift, float* out_f32, void* out_hl32, void* out_wino_d16, int G, int B, int H,
-                                                 int W, int C, int relu, const float* prescale, void* stream) {
-  return bn_apply_wino_launch(y, residual, residual_hl32, scale, shift, out_f32, out_hl32, out_wino_d16, G, B, H, W, C, 4, relu, prescale, 1, stream);
+                                                 int W, int C, int relu, const float* prescale, int bf16, void* stream) {
+  return bn_apply_wino_launch(y, residual, residual_hl32, scale, shift, out_f32, out_hl32, out_wino_d16, G, B, H, W, C, 4, relu, prescale, bf16 ? 2 : 1, stream);
 }
 
 // MaxPool2d over x [G][B][H][W][C] with the BatchNorm-apply (+ ReLU) of group g fused on the input (scale/shift [G][C] or NULL)
@@ -700,8 +712,8 @@ MRN_EXPORT int mrn_maxpool_wino_grouped_f32(const float* x, const float* scale, 
 // mrn_maxpool_wino_grouped_f32 for the reduced-precision mode: out_wino_d16 [G][B][Ho][ceil(Wo/4)][6][C/64][128 B] plain fp16 (C % 64 == 0)
 MRN_EXPORT int mrn_maxpool_wino_grouped_d16_f32(const float* x, const float* scale, const float* shift, int relu, float* out_f32,
                                                 void* out_hl32, void* out_wino_d16, int G, int B, int H, int W, int C, int kh, int kw, int sh,
-                                                int sw, int ph, int pw, void* stream) {
-  return maxpool_wino_launch(x, scale, shift, relu, out_f32, out_hl32, out_wino_d16, G, B, H, W, C, kh, kw, sh, sw, ph, pw, 4, 1, stream);
+                                                int sw, int ph, int pw, int bf16, void* stream) {
+  return maxpool_wino_launch(x, scale, shift, relu, out_f32, out_hl32, out_wino_d16, G, B, H, W, C, kh, kw, sh, sw, ph, pw, 4, bf16 ? 2 : 1, stream);
 }
 
 // t = x + drop[r / rows_per_drop] * branch (branch NULL: t = x; drop NULL: 1) -> sum_out (optional, may alias x);

@@ -119,7 +119,7 @@ class BackboneGroup(_GroupedLinear):
         return got[1]
 
     def _weights_wino(self, convs, R):
-        key = tuple((c.weight.data_ptr(), c.weight._version) for c in convs) + (R, ops.wino_dense())
+        key = tuple((c.weight.data_ptr(), c.weight._version) for c in convs) + (R, ops.wino_dense(), ops.REDUCED_BF16)
         got = self._wcache.get(("wino", id(convs[0])))
         if got is None or got[0] != key:
             got = (key, ops.pack_weights_wino([packed_weight(c).ohwi for c in convs], R))

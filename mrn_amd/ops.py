@@ -652,6 +652,9 @@ TRAIN_OPERAND_PEAK = 16384.0 / 16 if TRAIN_WINO else 16384.0
 # per 128-byte line ("d16": a third of the MFMAs on half the operand bytes; csrc/conv_wino.hip DENSE).  MRN_WINO_DENSE=0: the round-5 form of
 # the mode (no Winograd, direct one-product convolutions on HL32 lines whose lo halves are not read) -- the A/B partner.
 WINO_DENSE = os.environ.get("MRN_WINO_DENSE", "1") == "1"
+# the 16-bit type of those operands: fp16 (default: 11 significand bits) or bfloat16 (bench.py --precision bf16: the literal "bf16" of BASELINE
+# config 2 as a comparison instantiation -- same kernel, v_mfma_f32_32x32x16_bf16, 8 significand bits)
+REDUCED_BF16 = os.environ.get("MRN_REDUCED_BF16", "0") == "1"
 
 
 def wino_dense(products=None):
@@ -688,7 +691,7 @@ def pack_weights_wino(ws, R, scale=None, dense=None):
         if not known:
             call("mrn_pow2_scale_f32", _p(w), w.numel(), FP16_WEIGHT_PEAK, scale[g].data_ptr(), _pow2_ws(), _stream())
         if dense:
-            call("mrn_pack_weight_wino_d16", _p(w), out.data_ptr() + g * per, O, I, scale[g].data_ptr(), _stream())
+            call("mrn_pack_weight_wino_d16", _p(w), out.data_ptr() + g * per, O, I, scale[g].data_ptr(), int(REDUCED_BF16), _stream())
         else:
             call("mrn_pack_weight_wino_hl32", _p(w), out.data_ptr() + g * per, O, I, R, scale[g].data_ptr(), _stream())
     return out, scale
@@ -708,7 +711,7 @@ def bn_apply_wino_grouped(y, scale, shift, R, relu=True, residual=None, residual
     t0 = CONV_TIMER.begin("bnw") if CONV_TIMER is not None else None
     if dense:
         call("mrn_bn_apply_wino_grouped_d16_f32", _p(y), _p(residual), _p(residual_hl), _p(scale), _p(shift), _p(out), _p(out_hl), _p(v),
-             G, B, H, W, C, int(bool(relu)), _p(prescale), _stream())
+             G, B, H, W, C, int(bool(relu)), _p(prescale), int(REDUCED_BF16), _stream())
     else:
         call("mrn_bn_apply_wino_grouped_f32", _p(y), _p(residual), _p(residual_hl), _p(scale), _p(shift), _p(out), _p(out_hl), _p(v),
              G, B, H, W, C, R, int(bool(relu)), _p(prescale), _stream())
@@ -741,7 +744,7 @@ def conv2d_x3_wino(v_hl, G, shared_input, B, H, W, Cin, u_hl, u_scale, Cout, R, 
     t0 = CONV_TIMER.begin("wino") if timed else None
     if dense:           # (reduced-precision mode: plain fp16 operands, one product per term; row-block kernel only -- fails loudly otherwise)
         call("mrn_conv2d_x3_wino_d16", _p(v_hl), _p(u_hl), _p(bias), _p(y), _p(stats), _p(u_scale), _p(x_scale), G, gstride, B, H, W, Cin,
-             Cout, act, int(bool(pool)), _p(gamma_ptrs), _stream())
+             Cout, act, int(bool(pool)), _p(gamma_ptrs), int(REDUCED_BF16), _stream())
     elif pool:
         call("mrn_conv2d_x3_wino_pool_hl32", _p(v_hl), _p(u_hl), _p(_zero_page(dev)), _p(bias), _p(y), _p(stats), _p(u_scale), _p(x_scale), G,
              gstride, B, H, W, Cin, Cout, R, act, _p(gamma_ptrs), _stream())
@@ -837,7 +840,7 @@ def trained_weight_operand(w_ohwi, stride, padding, H=None):
     def build():
         w = w_ohwi.contiguous()
         return ("wino",) + tuple(pack_weights_wino([w], WINO_R, dense=dense)) if wino else ("hl32",) + tuple(pack_weights_hl32([w]))
-    return _memo(_wkey("op", w_ohwi, wino, WINO_R, dense), w_ohwi, build)
+    return _memo(_wkey("op", w_ohwi, wino, WINO_R, dense, REDUCED_BF16), w_ohwi, build)
 
 
 def trained_dgrad_weight(w_ohwi):
@@ -867,7 +870,7 @@ def prepack_trained():
                 dense = wino_dense(TRAIN_PRODUCTS)          # (H unknown here: a layer on a map the d16 form cannot take misses and packs in place)
                 wino = TRAIN_WINO and wino_eligible((kh, kw), stride, padding, Cin, Cout, TRAIN_PRODUCTS)
                 wc = w.contiguous()
-                new[_wkey("op", w, wino, WINO_R, dense)] = (("wino",) + tuple(pack_weights_wino([wc], WINO_R, dense=dense)) if wino
+                new[_wkey("op", w, wino, WINO_R, dense, REDUCED_BF16)] = (("wino",) + tuple(pack_weights_wino([wc], WINO_R, dense=dense)) if wino
                                                             else ("hl32",) + tuple(pack_weights_hl32([wc])), w)
             wt = pack_dgrad_weight(w)
             new[_wkey("dgrad", w)] = (wt, w)
@@ -875,7 +878,7 @@ def prepack_trained():
                 dpad = (kh - 1 - padding[0], kw - 1 - padding[1])
                 dense = wino_dense(TRAIN_PRODUCTS)
                 wino = TRAIN_WINO and wino_eligible((kh, kw), (1, 1), dpad, wt.ohwi.shape[-1], wt.ohwi.shape[0], TRAIN_PRODUCTS)
-                new[_wkey("op", wt.ohwi, wino, WINO_R, dense)] = (("wino",) + tuple(pack_weights_wino([wt.ohwi], WINO_R, dense=dense)) if wino
+                new[_wkey("op", wt.ohwi, wino, WINO_R, dense, REDUCED_BF16)] = (("wino",) + tuple(pack_weights_wino([wt.ohwi], WINO_R, dense=dense)) if wino
                                                                   else ("hl32",) + tuple(pack_weights_hl32([wt.ohwi])), wt.ohwi)
             ev = torch.cuda.Event()
             ev.record(side)
@@ -1130,7 +1133,7 @@ def maxpool_wino_grouped(x, kernel, stride, padding, R, scale=None, shift=None, 
     v = torch.empty(G * B * Ho * Wq * (R + 2) * C * (2 if dense else 4), device=x.device, dtype=torch.uint8)
     if dense:
         call("mrn_maxpool_wino_grouped_d16_f32", _p(x), _p(scale), _p(shift), int(bool(relu)), _p(out), _p(out_hl), _p(v), G, B, H, W, C,
-             kernel[0], kernel[1], stride[0], stride[1], padding[0], padding[1], _stream())
+             kernel[0], kernel[1], stride[0], stride[1], padding[0], padding[1], int(REDUCED_BF16), _stream())
     else:
         call("mrn_maxpool_wino_grouped_f32", _p(x), _p(scale), _p(shift), int(bool(relu)), _p(out), _p(out_hl), _p(v), G, B, H, W, C,
              kernel[0], kernel[1], stride[0], stride[1], padding[0], padding[1], R, _stream())

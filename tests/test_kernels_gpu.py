@@ -1177,6 +1177,43 @@ def test_winograd_d16_reduced_mode(ops, cfg):
         ops.conv2d_x3_wino(v, G, False, B * H // 2, 2, W, Cin, u, u_scale, Cout, R, dense=True)
 
 
+def test_winograd_d16_bf16_instantiation(ops):
+    """ops.REDUCED_BF16 (bench.py --precision bf16): the d16 operands as bfloat16 on v_mfma_f32_32x32x16_bf16 -- BASELINE config 2 says
+    "bf16"; the fp16 form is the mode that ships (11 significand bits against 8 at the same speed), this instantiation exists to compare.
+    Equal to float64 arithmetic on ITS quantised operands within 1e-5 of the output scale; against the unquantised convolution its error
+    is several times the fp16 form's (both asserted)."""
+    G, B, H, W, Cin, Cout, R = 2, 8, 4, 65, 128, 128, 4
+    yprev = rnd(G, B, H, W, Cin, seed=300)
+    scale, shift = rnd(G, Cin, seed=301) + 1.5, rnd(G, Cin, seed=302) * 0.5
+    ws = [rnd(Cout, Cin, 3, 3, seed=310 + g, scale=(2.0 / (Cin * 9)) ** 0.5) for g in range(G)]
+    a = (yprev.double() * scale.double()[:, None, None, None, :] + shift.double()[:, None, None, None, :]).clamp_min(0)
+    refs = torch.stack([F.conv2d(a[g].permute(0, 3, 1, 2), ws[g].double(), None, 1, 1).permute(0, 2, 3, 1) for g in range(G)])
+    sc = float(refs.abs().max())
+    AT = torch.tensor([[0.25, 0.5, 0.5, 0.5, 0.5, 0.0], [0.0, 0.5, -0.5, 1.0, -1.0, 0.0], [0.0, 0.5, 0.5, 2.0, 2.0, 0.0],
+                       [0.0, 0.5, -0.5, 4.0, -4.0, 1.0]], dtype=torch.float64)
+    Wq = (W + 3) // 4
+    errs = {}
+    saved = ops.REDUCED_BF16
+    try:
+        for bf16, dt in ((False, torch.float16), (True, torch.bfloat16)):
+            ops.REDUCED_BF16 = bf16
+            _, _, v = ops.bn_apply_wino_grouped(cu(yprev), cu(scale), cu(shift), R, relu=True, dense=True)
+            u, u_scale = ops.pack_weights_wino([cu(w.permute(0, 2, 3, 1).contiguous()) for w in ws], R, dense=True)
+            y, _ = ops.conv2d_x3_wino(v, G, False, B, H, W, Cin, u, u_scale, Cout, R, dense=True)
+            Vq = v.view(dt).view(G, B, H, Wq, 6, Cin).double().cpu()
+            Uq = u.view(dt).view(G, Cout, 6, Cin // 64, 3, 64).double().cpu().permute(0, 1, 2, 4, 3, 5).reshape(G, Cout, 6, 3, Cin)
+            Vp = torch.nn.functional.pad(Vq, (0, 0, 0, 0, 0, 0, 1, 1))
+            T = torch.zeros(G, B, H, Wq, 6, Cout, dtype=torch.float64)
+            for ky in range(3):
+                T += torch.einsum("gbhqmc,gomc->gbhqmo", Vp[:, :, ky:ky + H], Uq[:, :, :, ky])
+            yq = torch.einsum("rm,gbhqmo->gbhqro", AT, T).reshape(G, B, H, Wq * 4, Cout)[:, :, :, :W] * u_scale.double().cpu()[:, 1][:, None, None, None, None]
+            assert float((y.double().cpu() - yq).abs().max()) <= 1e-5 * sc, (bf16, float((y.double().cpu() - yq).abs().max()), sc)
+            errs[bf16] = float((y.double().cpu() - refs).pow(2).mean().sqrt()) / sc
+    finally:
+        ops.REDUCED_BF16 = saved
+    assert errs[False] < 2e-3 and 3 * errs[False] < errs[True] < 3e-2, errs
+
+
 def test_winograd_full_size_dominant_shape_properties(ops):
     """BASELINE-size check of the Winograd form of the dominant layer (6 experts x 256 images, 4x65 maps, 512 -> 512) against the
     direct split-fp16 x3 kernel on the same post-ReLU activations, and of the fused statistics"""
