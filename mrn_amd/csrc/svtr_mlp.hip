@@ -227,17 +227,22 @@ __global__ __launch_bounds__(C == 256 ? 256 : MRN_MLP_WAVES * 64, C == 256 ? 1 :
     const float ds = p.drop ? p.drop[(ok ? row : row0) / p.rows_per_drop] : 1.f;
     float* xr_ = p.x_res + row * C;
     float sum = 0.f;
-    // the residual row in batches of eight 16-byte pieces in flight (one load -> wait -> add -> store per piece was 32 serialized round trips)
+    // the residual row in batches of MRN_TAIL_BATCH 16-byte pieces in flight (one load -> wait -> add -> store per piece is 32 serialized
+    // round trips; but every piece in flight is four more live registers next to 128 accumulators + 128 fragment registers)
+#ifndef MRN_TAIL_BATCH
+#define MRN_TAIL_BATCH 8
+#endif
+    constexpr int XB = MRN_TAIL_BATCH;
 #pragma unroll
-    for (int o0 = 0; o0 < OC; o0 += 2) {
-      f32x4 xv[8];
+    for (int i0 = 0; i0 < OC * 4; i0 += XB) {
+      f32x4 xv[XB];
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        xv[i] = ok ? *reinterpret_cast<const f32x4*>(xr_ + (o0 + (i >> 2)) * 32 + 8 * (i & 3) + 4 * half) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < XB; ++i)
+        xv[i] = ok ? *reinterpret_cast<const f32x4*>(xr_ + ((i0 + i) >> 2) * 32 + 8 * ((i0 + i) & 3) + 4 * half) : f32x4{0.f, 0.f, 0.f, 0.f};
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int o = o0 + (i >> 2), k = i & 3;
+      for (int i = 0; i < XB; ++i) {
+        const int o = (i0 + i) >> 2, k = (i0 + i) & 3;
         const int c = o * 32 + 8 * k + 4 * half;
         const f32x4 bpv = *reinterpret_cast<const f32x4*>(ln_lds + 2 * C + c);
         f32x4 v;
