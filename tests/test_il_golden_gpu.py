@@ -417,6 +417,68 @@ def test_full_size_dernet_trba6_properties():
     assert float((net.aux_fc.weight.grad if net.aux_fc.weight.grad is not None else torch.zeros(1)).abs().max()) == 0.0
 
 
+def test_der6_batch32_full_class_counts_vs_oracle():
+    """BASELINE config 5 at the bench's size against the CPU ORACLE (not another HIP schedule): DERNet over SIX TRBA extractors, class
+    counts 2091 ... 5374, 32 smooth crops, DER's training configuration (five frozen extractors in eval mode on the lock-step path, the
+    newest one in train mode, main head over the 1536-wide concatenation, auxiliary head on the newest 256 channels).  Features, logits,
+    auxiliary logits and the classification loss within 1e-4 of the fp32 oracle -- or within 3 x the oracle's own distance from float64
+    arithmetic where that is larger (the TPS grid's conditioning) --, gradients of the heads within 5e-3, teacher-forced greedy indices
+    bit-exact wherever the float64 top-2 margin clears the band."""
+    from mrn_amd import functional as Fn
+    from oracle import mrn_oracle as O
+    from tests.helpers import oracle_dtype
+    opt = learner_opt("trba")
+    classes = (2091, 2311, 4039, 5199, 5272, 5374)
+    B, N = 32, len(classes)
+    net = build_dernet(opt, classes, seed=31)
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    for ext in list(net.model)[:-1]:
+        for p in ext.parameters():
+            p.requires_grad = False
+    net.train()
+    for ext in list(net.model)[:-1]:
+        ext.eval()
+    image = torch.from_numpy(W.smooth_image("b32_der", (B, 4, 32, 256), 7))
+    text = torch.from_numpy(W.randint("b32_der_text", (B, 27), 4, classes[-1], 7))
+    text[:, 0] = 2
+    cfg = O.Cfg("TPS", "ResNet", "BiLSTM", "Attn")
+    head_names = ["fc.weight", "fc.bias", "Prediction.attention_cell.i2h.weight", "Prediction.attention_cell.h2h.weight",
+                  "Prediction.attention_cell.rnn.weight_ih", "Prediction.attention_cell.rnn.weight_hh",
+                  f"model.{N - 1}.SequenceModeling.1.linear.weight"]
+    sd32 = {k: v.clone() for k, v in sd.items()}
+    for n in head_names:
+        sd32[n].requires_grad_(True)
+    ref = O.dernet_forward(sd32, cfg, N, image, text[:, :-1], True, training=True)
+    loss32 = O.attn_ce_loss(ref["logits"], text)
+    g32 = torch.autograd.grad(loss32, [sd32[n] for n in head_names])
+    with oracle_dtype(torch.float64) as od, torch.no_grad():
+        ref64 = O.dernet_forward(od.cast(sd), cfg, N, image.double(), text[:, :-1], True, training=True)
+    out = net(image.cuda(), text[:, :-1].cuda())
+    loss = Fn.cross_entropy(out["logits"], text[:, 1:].cuda(), 1)
+    loss.backward()
+    for key in ("features", "logits", "aux_logits"):
+        r32 = ref[key].detach()
+        band = float((r32.double() - ref64[key]).abs().max())
+        err = float((out[key].detach().cpu() - r32).abs().max())
+        scale = float(r32.abs().max())
+        assert err <= max(1e-4 * max(1.0, scale), 3 * band), (key, err, band, scale)
+    assert abs(float(loss.detach()) - float(loss32.detach())) <= 1e-4 * max(1.0, abs(float(loss32.detach())))
+    t2 = ref64["logits"].topk(2, dim=2)[0]
+    band_l = float((ref["logits"].detach().double() - ref64["logits"]).abs().max())
+    clear = (t2[..., 0] - t2[..., 1]) > 10 * max(band_l, 1e-5)
+    assert float(clear.float().mean()) > 0.9
+    assert torch.equal(out["logits"].detach().cpu().argmax(2)[clear], ref["logits"].detach().argmax(2)[clear])
+    for n, gr in zip(head_names, g32):
+        mine = net.get_parameter(n).grad.detach().cpu().double()
+        scale = max(float(gr.abs().max()), 1e-12)
+        rel = float((mine - gr.double()).norm() / max(float(gr.double().norm()), 1e-12))
+        assert rel <= 5e-3, (n, rel, scale)
+    # the frozen extractors took the eval path: their BatchNorm statistics did not move
+    after = net.state_dict()
+    for k in ("model.0.FeatureExtraction.ConvNet.bn0_1.running_mean", "model.4.FeatureExtraction.ConvNet.bn4_2.running_var"):
+        assert torch.equal(after[k].cpu(), sd[k]), k
+
+
 SEEDS2 = {"wa": (51, 52), "joint": (53, 54)}
 
 
