@@ -73,6 +73,22 @@ __device__ __forceinline__ void lstm_pointwise(const f32x4 (&acc)[4], const floa
   }
 }
 
+// (the form whose accumulators already hold the input projection)
+__device__ __forceinline__ void lstm_pointwise0(const f32x4 (&acc)[4], const float (&bh)[4], float (&c)[4], float (&h)[4], float (&act)[4][4]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float gi = acc[0][r] + bh[0];
+    const float gf = acc[1][r] + bh[1];
+    const float gg = acc[2][r] + bh[2];
+    const float go = acc[3][r] + bh[3];
+    const float ig = sigmoidf_acc(gi), fg = sigmoidf_acc(gf), og = sigmoidf_acc(go), cg = tanhf(gg);
+    const float cn = fg * c[r] + ig * cg;
+    c[r] = cn;
+    h[r] = og * tanhf(cn);
+    act[0][r] = ig; act[1][r] = fg; act[2][r] = cg; act[3][r] = og;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Bidirectional LSTM layer.  xproj[b][t][dir*4H + gate*H + j] holds W_ih x + b_ih.
 // grid = (ceil(B/16), ndir); out[b][t][dir*H + j].
@@ -221,9 +237,22 @@ struct LstmX3Group {
   int tiles, B, T, ndir, nsets, pinned;
 };
 
+// RB: 16-sample row blocks per workgroup.  A workgroup streams the whole W_hh of its (expert, direction) set through one CU every step
+// (1 MiB; 64 B / clk / CU from L2 = 7.8 us), with little MFMA work behind each fragment (96 MFMAs of 16 cycles per wave).  RB = 2 -- the same
+// stream for twice the samples, half as many workgroups per L2 -- was built and measured SLOWER (round 6, tools/bench_lstm.py, B = 256,
+// T = 65: G = 1 17.1 us / step against 11.8, G = 3 21.3 / 14.8, G = 6 22.9 / 15.3): with registers for the next hi fragments only, the
+// second row block's MFMAs wait on the lo fragments instead of hiding them.  RB = 1 is the product form; MRN_LSTM_RB=2 selects the other
+// for an A/B (bit-identical results).
+// The input projection is the accumulators' INITIAL value, scaled by the weights' power-of-two prescale (exact): no registers of its own.
+// Every global access is a buffer instruction (resource + scalar offset + a 32-bit lane offset).  Both changes are round 6's: the form
+// with 64-bit row and fragment pointers in vector registers ran at the 128-register cap; this one takes 100 and is 12-24 % faster
+// (G = 1 13.3 -> 11.8 us / step, G = 3 17.9 -> 14.8, G = 6 20.3 -> 15.3).
+template <int RB>
 __global__ __launch_bounds__(NTH) void lstm_layer_x3_kernel(const LstmX3Group grp) {
-  __shared__ __attribute__((aligned(16))) _Float16 h_hi[2][BT * LDH];
-  __shared__ __attribute__((aligned(16))) _Float16 h_lo[2][BT * LDH];
+  constexpr int BTX = BT * RB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lstm_lds[];
+  _Float16* const h_hi = reinterpret_cast<_Float16*>(lstm_lds);        // [2][BTX * LDH]
+  _Float16* const h_lo = h_hi + 2 * BTX * LDH;                         // [2][BTX * LDH]
   // pinned == 1: all tiles of a (expert, direction) set run on XCD (set % 8), whose L2 then holds that set's 1 MiB of W_hh.
   // pinned == 2: the (set, tile) pairs in set-major order are cut into eight equal runs, one per XCD (workgroup b runs on XCD b % 8): every
   // L2 serves the same number of workgroups and at most two or three sets' weights.  The step time follows the number of workgroups
@@ -247,57 +276,177 @@ __global__ __launch_bounds__(NTH) void lstm_layer_x3_kernel(const LstmX3Group gr
   float* __restrict__ c_out = grp.g[gi].c_out;
   const int B = grp.B, T = grp.T, ndir = grp.ndir;
   const int dir = set - gi * grp.ndir;
-  const int b0 = tile * BT;
+  const int b0 = tile * BTX;
   const int t_ = threadIdx.x, lane = t_ & 63, wave = t_ >> 6;
   const unsigned char* W = grp.g[gi].w_hh + (long)dir * 4 * HID * HID * 4;     // hi + lo fp16 = 4 bytes per weight
   const float inv = grp.g[gi].w_inv[dir];
+  const float pre = 1.f / inv;                                                 // the prescale itself (a power of two: exact)
   const int col = lane & 15, rbase = (lane >> 4) * 4;
   const int j = wave * 16 + col;
 
-  for (int i = t_; i < BT * LDH; i += NTH) {
-    h_hi[0][i] = (_Float16)0.f;
-    h_lo[0][i] = (_Float16)0.f;
+  for (int i = t_; i < BTX * LDH; i += NTH) {
+    h_hi[i] = (_Float16)0.f;
+    h_lo[i] = (_Float16)0.f;
   }
-  float c[4] = {0.f, 0.f, 0.f, 0.f}, bh[4];
+  float c[RB][4], bh[4];
+  // per-lane BYTE offsets of this lane's rows in xproj / the gate saves ([B][T][ndir][4H]); the (t, direction) part of an address is
+  // wave-uniform and goes into the scalar base, and the [B][T][ndir][H] arrays' offsets follow from the same registers -- eight
+  // loop-invariant registers instead of a 64-bit pointer per row and array (which the compiler hoisted and, at RB = 2, spilled).
+  // The launcher keeps B * T * ndir * 4H * 4 bytes below 2^32 (larger batches go in several launches)
+  unsigned xoff[RB][4];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int b = b0 + rb * BT + rbase + r;
+      c[rb][r] = 0.f;
+      xoff[rb][r] = ((unsigned)(b < B ? b : 0) * (unsigned)(T * ndir * 4 * HID) + (unsigned)j) * 4u;
+    }
 #pragma unroll
   for (int g = 0; g < 4; ++g) bh[g] = b_hh ? b_hh[dir * 4 * HID + g * HID + j] : 0.f;
   __syncthreads();
 
+  // fragment-major weight stream of this wave: [g][q][lane][hi 8 | lo 8 halves] (mma_rows_h's layout)
+  constexpr int Q = HID / 32;
+  // every global access is a buffer instruction -- resource + scalar offset + one 32-bit lane offset: no address lives in the vector file
+  // (as 64-bit pointers per gate / row the compiler hoisted them out of the step loop and, at RB = 2, spilled them)
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, 4 * HID * HID * 4, 0x00020000);
+  const int wwave = __builtin_amdgcn_readfirstlane(wave) * (4 * Q * 64 * 32);
+  const int wlane = lane * 32;
+  auto wfrag = [&](int g, int q, int plane) -> f16v8 {
+    return __builtin_bit_cast(f16v8, __builtin_amdgcn_raw_buffer_load_b128(rw, wlane, wwave + ((g * Q + q) * 128 + plane) * 16, 0));
+  };
+  const unsigned xbytes = (unsigned)B * (unsigned)(T * ndir * 4 * HID) * 4u;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)xproj, 0, xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, xbytes / 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)gates_out, 0, gates_out ? xbytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)c_out, 0, gates_out ? xbytes / 4 : 0, 0x00020000);
+  const int n = lane & 15, kg = lane >> 4;
+
   for (int step = 0; step < T; ++step) {
     const int t = dir == 0 ? step : T - 1 - step;
     const int cur = step & 1;
-    float xg[4][4];
+    f32x4 acc[RB][4];
+    const int tq = (t * ndir + dir) * HID * 4;                                     // (wave-uniform) byte offset in a [..][T][ndir][H] row
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int b = b0 + rbase + r;
-      const float* xp = xproj + ((long)(b < B ? b : 0) * T + t) * (ndir * 4 * HID) + dir * 4 * HID + j;
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) xg[g][r] = xp[g * HID];
-    }
-    f32x4 acc[4];
+      for (int r = 0; r < 4; ++r) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-    mma_rows_h<4>(acc, h_hi[cur], h_lo[cur], W, HID, wave, lane);
+        for (int g = 0; g < 4; ++g)
+          acc[rb][g][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (int)xoff[rb][r], 4 * tq + g * HID * 4, 0)) * pre;
+      }
+    {
+      const _Float16* ah = h_hi + cur * BTX * LDH + n * LDH + kg * 8;
+      const _Float16* al = h_lo + cur * BTX * LDH + n * LDH + kg * 8;
+      // RB = 1: the hi and lo fragments of k-step q + 1 are fetched before the MFMAs of step q issue.  RB = 2 has registers for the next hi
+      // fragments only: the lo fragments of step q are fetched at its top and used by its LAST product group
+      constexpr bool PF_LO = RB == 1;
+      f16v8 wh[4], wl[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g] *= inv;            // undo the power-of-two weight prescale (exact)
-    float h[4], act[4][4];
-    lstm_pointwise(acc, xg, bh, c, h, act);
+      for (int g = 0; g < 4; ++g) {
+        wh[g] = wfrag(g, 0, 0);
+        if (PF_LO) wl[g] = wfrag(g, 0, 1);
+      }
+#pragma unroll 1
+      for (int q = 0; q < Q; ++q) {
+        f16v8 nh[4], nl[4];
+        const int qn = (q + 1 < Q) ? q + 1 : q;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = rbase + r, b = b0 + row;
-      if (b < B) {
-        out[((long)b * T + t) * (ndir * HID) + dir * HID + j] = h[r];
-        if (gates_out) {
-          const long base = ((long)b * T + t) * ndir + dir;
+        for (int g = 0; g < 4; ++g) {
+          if (!PF_LO) wl[g] = wfrag(g, q, 1);
+          nh[g] = wfrag(g, qn, 0);
+          if (PF_LO) nl[g] = wfrag(g, qn, 1);
+        }
 #pragma unroll
-          for (int g = 0; g < 4; ++g) gates_out[base * 4 * HID + g * HID + j] = act[g][r];
-          c_out[base * HID + j] = c[r];
+        for (int rb = 0; rb < RB; ++rb) {
+          const f16v8 xh = *reinterpret_cast<const f16v8*>(ah + rb * BT * LDH + q * 32), xl = *reinterpret_cast<const f16v8*>(al + rb * BT * LDH + q * 32);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[rb][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, wh[g], acc[rb][g], 0, 0, 0);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[rb][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wh[g], acc[rb][g], 0, 0, 0);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[rb][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wl[g], acc[rb][g], 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          wh[g] = nh[g];
+          if (PF_LO) wl[g] = nl[g];
         }
       }
-      store_h_split(h_hi[cur ^ 1], h_lo[cur ^ 1], row * LDH + j, b < B ? h[r] : 0.f);
+    }
+    _Float16* const nhi = h_hi + (cur ^ 1) * BTX * LDH;
+    _Float16* const nlo = h_lo + (cur ^ 1) * BTX * LDH;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[rb][g] *= inv;        // undo the power-of-two weight prescale (exact): x-projection + W_hh . h
+      float h[4], act[4][4];
+      lstm_pointwise0(acc[rb], bh, c[rb], h, act);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rb * BT + rbase + r, b = b0 + row;
+        if (b < B) {
+          const int ooff = (int)(((xoff[rb][r] - 4u * (unsigned)j) >> 2) + 4u * (unsigned)j);       // the same row of a [B][T][ndir][H] array
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, h[r]), ro, ooff, tq, 0);
+          if (gates_out) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, act[g][r]), rg, (int)xoff[rb][r], 4 * tq + g * HID * 4, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, c[rb][r]), rc, ooff, tq, 0);
+          }
+        }
+        store_h_split(nhi, nlo, row * LDH + j, b < B ? h[r] : 0.f);
+      }
     }
     __syncthreads();
   }
+}
+
+// one launch of a filled group
+template <int RB>
+static int lstm_x3_launch_rb(LstmX3Group& grp, int n, bool may_pin, hipStream_t stream) {
+  constexpr size_t lds = (size_t)4 * BT * RB * LDH * sizeof(_Float16);
+  static bool once = false;
+  if (!once) {
+    (void)hipFuncSetAttribute((const void*)lstm_layer_x3_kernel<RB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    once = true;
+  }
+  grp.tiles = ceil_div(grp.B, BT * RB);
+  grp.nsets = n * grp.ndir;
+  grp.pinned = 0;
+  int blocks = grp.nsets * grp.tiles;
+  if (may_pin) {
+    grp.pinned = grp.nsets > 2 && grp.tiles * ceil_div(grp.nsets, 8) <= 32;
+    if (grp.pinned) blocks = 8 * ceil_div(grp.nsets, 8) * grp.tiles;
+    static const bool balance = !(getenv("MRN_LSTM_BALANCE") && atoi(getenv("MRN_LSTM_BALANCE")) == 0);     // (A/B switch, read once)
+    if (balance && grp.nsets > 2 && (grp.nsets * grp.tiles) % 8 == 0 && grp.nsets * grp.tiles <= 256) {
+      grp.pinned = 2;
+      blocks = grp.nsets * grp.tiles;
+    }
+  }
+  hipLaunchKernelGGL(lstm_layer_x3_kernel<RB>, dim3(blocks), dim3(NTH), lds, stream, grp);
+  return 0;
+}
+static int lstm_x3_launch(LstmX3Group& all, int n, bool may_pin, hipStream_t stream) {
+  static const int forced = getenv("MRN_LSTM_RB") ? atoi(getenv("MRN_LSTM_RB")) : 0;
+  // the kernel's row offsets are 32-bit byte offsets into [B][T][ndir][4H] floats: batches beyond that go in chunks of whole tiles
+  const long row_bytes = (long)all.T * all.ndir * 4 * HID * 4;
+  const long fit = 0xffffffffL / row_bytes / (2 * BT) * (2 * BT);
+  MRN_CHECK_ARG(fit >= 2 * BT, "lstm x3 layer: T=%d is beyond the kernel's 32-bit row offsets", all.T);
+  for (long s0 = 0; s0 < all.B; s0 += fit) {
+    LstmX3Group grp = all;
+    grp.B = (int)(all.B - s0 < fit ? all.B - s0 : fit);
+    for (int i = 0; i < n; ++i) {
+      LstmX3Params& q = grp.g[i];
+      q.xproj += s0 * (row_bytes / 4);
+      q.out += s0 * (row_bytes / 16);
+      if (q.gates_out) q.gates_out += s0 * (row_bytes / 4);
+      if (q.c_out) q.c_out += s0 * (row_bytes / 16);
+    }
+    const int rc = forced == 2 ? lstm_x3_launch_rb<2>(grp, n, may_pin, stream) : lstm_x3_launch_rb<1>(grp, n, may_pin, stream);
+    if (rc) return rc;
+  }
+  return 0;
 }
 
 // (A weight-stationary variant -- W_hh slices in the LDS of 16 workgroups per (expert, direction), h exchanged through L2 every step --
@@ -667,16 +816,9 @@ MRN_EXPORT int mrn_lstm_layer_fwd_x3_grouped(const void* const* xproj, const voi
       grp.g[i] = LstmX3Params{(const float*)xproj[g0 + i], (const unsigned char*)w_hh[g0 + i], (const float*)w_inv[g0 + i],
                               b_hh ? (const float*)b_hh[g0 + i] : nullptr, (float*)out[g0 + i]};
     }
-    grp.tiles = ceil_div(B, BT); grp.B = B; grp.T = T; grp.ndir = ndir;
-    grp.nsets = n * ndir;
-    grp.pinned = grp.nsets > 2 && grp.tiles * ceil_div(grp.nsets, 8) <= 32;
-    int blocks = grp.pinned ? 8 * ceil_div(grp.nsets, 8) * grp.tiles : grp.nsets * grp.tiles;
-    static const bool balance = !(getenv("MRN_LSTM_BALANCE") && atoi(getenv("MRN_LSTM_BALANCE")) == 0);     // (A/B switch, read once)
-    if (balance && grp.nsets > 2 && (grp.nsets * grp.tiles) % 8 == 0 && grp.nsets * grp.tiles <= 256) {
-      grp.pinned = 2;
-      blocks = grp.nsets * grp.tiles;
-    }
-    hipLaunchKernelGGL(lstm_layer_x3_kernel, dim3(blocks), dim3(NTH), 0, (hipStream_t)stream, grp);
+    grp.B = B; grp.T = T; grp.ndir = ndir;
+    const int rc = lstm_x3_launch(grp, n, true, (hipStream_t)stream);
+    if (rc) return rc;
     MRN_LAUNCH_CHECK("lstm_layer_x3");
   }
   return MRN_OK;
@@ -694,10 +836,9 @@ MRN_EXPORT int mrn_lstm_layer_fwd_x3_save(const float* xproj, const void* w_hh, 
   LstmX3Group grp;
   memset(&grp, 0, sizeof(grp));
   grp.g[0] = LstmX3Params{xproj, (const unsigned char*)w_hh, w_inv, b_hh, out, gates_out, c_out};
-  grp.tiles = ceil_div(B, BT); grp.B = B; grp.T = T; grp.ndir = ndir;
-  grp.nsets = ndir;
-  grp.pinned = 0;
-  hipLaunchKernelGGL(lstm_layer_x3_kernel, dim3(grp.nsets * grp.tiles), dim3(NTH), 0, (hipStream_t)stream, grp);
+  grp.B = B; grp.T = T; grp.ndir = ndir;
+  const int rc = lstm_x3_launch(grp, 1, false, (hipStream_t)stream);
+  if (rc) return rc;
   MRN_LAUNCH_CHECK("lstm_layer_x3_save");
   return MRN_OK;
 }

@@ -563,6 +563,25 @@ def test_lstm_recurrence_on_f16_mfma(ops):
     assert_close("lstm on the f16 MFMA", out, ref, atol=2e-6, rtol=1e-5)
 
 
+def test_lstm_x3_batch_beyond_the_32bit_row_offsets(ops):
+    """the x3 layer kernel addresses its rows with 32-bit byte offsets into [B][T][ndir][4H]; the launcher cuts a batch whose array is
+    beyond 4 GiB into chunks of whole tiles (rnn.hip: lstm_x3_launch).  T = 2048: 224 samples fit, B = 256 goes as 224 + 32 -- the same
+    bits as the two parts launched separately"""
+    G, B, T, Hd = 1, 256, 2048, 256
+    gen = torch.Generator(device="cuda").manual_seed(77)
+    xproj = torch.randn(G, B, T, 8 * Hd, device="cuda", generator=gen) * 0.7
+    ws = [cu(rnd(4 * Hd, Hd, seed=261 + d, scale=1 / 16.0)) for d in range(2)]
+    b_hh = cu(rnd(G, 8 * Hd, seed=263, scale=1 / 16.0))
+    packs = [ops.pack_fragment_major_h(w) for w in ws]
+    w_h = torch.stack([d[0] for d in packs]).unsqueeze(0).contiguous()
+    w_inv = torch.cat([d[1] for d in packs]).unsqueeze(0).contiguous()
+    out = ops.lstm_layer_x3_grouped(xproj, w_h, w_inv, b_hh, Hd, 2)
+    for lo, hi in ((0, 224), (224, 256)):
+        part = ops.lstm_layer_x3_grouped(xproj[:, lo:hi].contiguous(), w_h, w_inv, b_hh, Hd, 2)
+        assert torch.equal(out[:, lo:hi], part), (lo, hi)
+    assert torch.isfinite(out).all() and out.abs().max().item() > 0.1
+
+
 @pytest.mark.parametrize("B,T,mag", [(19, 29, 1.0), (256, 65, 1e-5), (37, 12, 300.0)])
 def test_lstm_training_kernels_on_f16_mfma(ops, B, T, mag):
     """mrn_lstm_layer_fwd_x3_save / mrn_lstm_layer_bwd_x3 (training forward with saves and backward through time, recurrent products as
