@@ -220,6 +220,50 @@ __device__ __forceinline__ void mma_rows_h(f32x4 (&acc)[NG], const _Float16* __r
   }
 }
 
+// mma_rows_h with the weight stream behind a buffer resource: scalar (wave, gate, k-step) offsets + one 32-bit lane offset, no 64-bit
+// fragment pointers in the vector file (the pointer form put the decoder kernel 60 registers over its 128)
+template <int NG>
+__device__ __forceinline__ void mma_rows_hb(f32x4 (&acc)[NG], const _Float16* __restrict__ a_hi, const _Float16* __restrict__ a_lo,
+                                            const __amdgpu_buffer_rsrc_t rw, int K, int wave, int lane, int ld = LDH) {
+  const int n = lane & 15, kg = lane >> 4;
+  const int Q = K / 32;
+  const int wwave = __builtin_amdgcn_readfirstlane(wave) * NG * Q * 2048;
+  const int wlane = lane * 32;
+  auto wfrag = [&](int g, int q, int plane) -> f16v8 {
+    return __builtin_bit_cast(f16v8, __builtin_amdgcn_raw_buffer_load_b128(rw, wlane, wwave + ((g * Q + q) * 128 + plane) * 16, 0));
+  };
+  const _Float16* ah = a_hi + n * ld + kg * 8;
+  const _Float16* al = a_lo + n * ld + kg * 8;
+  f16v8 wh[NG], wl[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    wh[g] = wfrag(g, 0, 0);
+    wl[g] = wfrag(g, 0, 1);
+  }
+#pragma unroll 1
+  for (int q = 0; q < Q; ++q) {
+    f16v8 nh[NG], nl[NG];
+    const int qn = (q + 1 < Q) ? q + 1 : q;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      nh[g] = wfrag(g, qn, 0);
+      nl[g] = wfrag(g, qn, 1);
+    }
+    const f16v8 xh = *reinterpret_cast<const f16v8*>(ah + q * 32), xl = *reinterpret_cast<const f16v8*>(al + q * 32);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, wh[g], acc[g], 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wl[g], acc[g], 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wh[g], acc[g], 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      wh[g] = nh[g];
+      wl[g] = nl[g];
+    }
+  }
+}
+
 __device__ __forceinline__ void store_h_split(_Float16* hi, _Float16* lo, int idx, float v) {
   _Float16 h, l;
   split_f16(v, h, l);
@@ -525,6 +569,10 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecGroup gr
   _Float16* c_hi = reinterpret_cast<_Float16*>(ctx_lds);
   _Float16* c_lo = c_hi + BT * CLDH;
   const float inv_h2h = X3 ? p.w_inv[0] : 1.f, inv_ih = X3 ? p.w_inv[1] : 1.f, inv_hh = X3 ? p.w_inv[2] : 1.f;
+  // x3: the three fp16 weight streams (4 bytes per weight) behind buffer resources
+  const __amdgpu_buffer_rsrc_t r_h2h = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_h2h, 0, X3 ? HID * HID * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_ih = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_ih, 0, X3 ? 4 * HID * D * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_hh = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_hh, 0, X3 ? 4 * HID * HID * 4 : 0, 0x00020000);
 
   // vb = samples per workgroup (16, or 8 / 4 when the batch would otherwise occupy less than half of the CUs: every step
   // re-reads the workgroup's Hproj / Hb slices (66 KB per sample each), so more, smaller workgroups shorten the step);
@@ -565,19 +613,10 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecGroup gr
   __syncthreads();
 
   for (int step = 0; step < p.S; ++step) {
-    // embedding half of the LSTMCell input projection for this step (lands during the phases below)
-    float xg[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int b = b0 + rbase + r;
-      const float* ep = p.eproj + (long)(b < Bend ? b : 0) * p.eproj_stride_b + (long)step * p.eproj_stride_s + j;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) xg[g][r] = ep[g * HID];
-    }
     // (1) hp = h2h(h) + bias
     {
       f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
-      if constexpr (X3) mma_rows_h<1>(acc, h_hi, h_lo, reinterpret_cast<const unsigned char*>(p.w_h2h), HID, wave, lane);
+      if constexpr (X3) mma_rows_hb<1>(acc, h_hi, h_lo, r_h2h, HID, wave, lane);
       else mma_rows<1>(acc, h_lds, HLD, p.w_h2h, HID, wave, lane);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -593,11 +632,12 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecGroup gr
     {
       const f32x4 wv = *reinterpret_cast<const f32x4*>(sw_lds + lane * 4);
       const int npair = vb * T;
-      for (int pr0 = wave * 4; pr0 < npair; pr0 += NW * 4) {
-        f32x4 hv[4];
-        int rows[4];
+      constexpr int U = 4;                 // pairs in flight per wave (8 measured the same, round 6)
+      for (int pr0 = wave * U; pr0 < npair; pr0 += NW * U) {
+        f32x4 hv[U];
+        int rows[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
           const int pr = pr0 + u;
           const int row = pr < npair ? pr / T : 0, t = pr < npair ? pr - row * T : 0;
           rows[u] = row;
@@ -605,9 +645,9 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecGroup gr
           hv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
           if (pr < npair && b < Bend) hv[u] = *reinterpret_cast<const f32x4*>(p.Hproj + ((long)b * T + t) * HID + lane * 4);
         }
-        float sacc[4];
+        float sacc[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
           const f32x4 pv = *reinterpret_cast<const f32x4*>(hp_lds + rows[u] * HLD + lane * 4);
           float s = 0.f;
 #pragma unroll
@@ -617,10 +657,12 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecGroup gr
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
 #pragma unroll
-          for (int u = 0; u < 4; ++u) sacc[u] += __shfl_xor(sacc[u], o);
+          for (int u = 0; u < U; ++u) sacc[u] += __shfl_xor(sacc[u], o);
         }
-        if (lane < 4 && pr0 + lane < npair) {
-          const float v = lane == 0 ? sacc[0] : lane == 1 ? sacc[1] : lane == 2 ? sacc[2] : sacc[3];
+        if (lane < U && pr0 + lane < npair) {
+          float v = sacc[0];
+#pragma unroll
+          for (int u = 1; u < U; ++u) v = lane == u ? sacc[u] : v;
           e_lds[pr0 + lane] = (b0 + (pr0 + lane) / T < p.B) ? v : 0.f;
         }
       }
@@ -648,6 +690,16 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecGroup gr
       }
     }
     __syncthreads();
+    // embedding half of the LSTMCell input projection for this step: issued here, it lands during phase (4) and becomes the INITIAL value
+    // of the gate accumulators (x the W_ih stream's power-of-two prescale: exact) -- sixteen registers live over one phase, not the step
+    f32x4 acc5[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int b = b0 + rbase + r;
+      const float* ep = p.eproj + (long)(b < Bend ? b : 0) * p.eproj_stride_b + (long)step * p.eproj_stride_s + j;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc5[g][r] = ep[g * HID];
+    }
     // (4) context[b][:] = sum_t alpha[b][t] * Hb[b][t][:]
     for (int it = t_; it < vb * (D / 4); it += NTH) {
       const int row = it / (D / 4), c4 = it - row * (D / 4);
@@ -657,7 +709,7 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecGroup gr
         const float* hb = p.Hb + (long)b * T * D + c4 * 4;
         int t = 0;
 #pragma unroll 1
-        for (; t + 4 <= T; t += 4) {                 // four independent loads in flight per lane, 16 waves per CU
+        for (; t + 4 <= T; t += 4) {                 // four independent loads in flight per lane, 16 waves per CU (eight: no faster)
           f32x4 v[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(hb + (long)(t + u) * D);
@@ -687,14 +739,15 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecGroup gr
     // (5) gates = eproj + ctx . W_ih[:, :D]^T + h . W_hh^T ; (6) LSTM cell
     {
       f32x4 acc[4];
+      const float pre_ih = 1.f / inv_ih;               // (a power of two)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int g = 0; g < 4; ++g) acc[g] = acc5[g] * pre_ih;
       if constexpr (X3) {
-        mma_rows_h<4>(acc, c_hi, c_lo, reinterpret_cast<const unsigned char*>(p.w_ih), D, wave, lane, CLDH);
+        mma_rows_hb<4>(acc, c_hi, c_lo, r_ih, D, wave, lane, CLDH);
         const float ratio = inv_ih / inv_hh;            // (powers of two: exact)
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] *= ratio;
-        mma_rows_h<4>(acc, h_hi, h_lo, reinterpret_cast<const unsigned char*>(p.w_hh), HID, wave, lane);
+        mma_rows_hb<4>(acc, h_hi, h_lo, r_hh, HID, wave, lane);
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] *= inv_hh;
       } else {
@@ -703,7 +756,7 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecGroup gr
       }
       __syncthreads();  // every wave has finished reading h_lds
       float h[4], act[4][4];
-      lstm_pointwise(acc, xg, bh, c, h, act);
+      lstm_pointwise0(acc, bh, c, h, act);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = rbase + r, b = b0 + row;
