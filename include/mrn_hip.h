@@ -391,14 +391,17 @@ int mrn_attn_decoder_fwd_grouped_f32(const void* const* Hb, const void* const* H
  * Saved by the forward: alpha [B][S][T], gates [B][S][4H] (post-activation), cseq [B][S][H], ctx [B][S][D], hp [B][S][H].
  * Weights transposed + fragment-major: w_h2hT (rows = input unit, K = H), w_ih_ctxT (rows = D index, K = 4H),
  * w_hhT (rows = hidden unit, K = 4H).  Outputs: dgates [B][S][4H] (gate pre-activations), dhp [B][S][H],
- * dHb [B][T][D] and dHproj [B][T][H] (must be zero-initialised; accumulated over the steps),
- * dwscore_part [mrn_attn_decoder_bwd_parts(B)][H] (one row per workgroup; the caller sums the rows).
+ * dHb [B][T][D] and dHproj [B][T][H] (written, not accumulated: no initialisation needed),
+ * dwscore_part [mrn_attn_decoder_bwd_parts(B)][H] (one row per workgroup; the caller sums the rows),
+ * dctx [B][S][D] (gradient of every step's context vector) and de [B][S][T] (gradient of every step's pre-softmax scores): the step
+ * loop writes them, and two small launches behind it form dHb = sum_s alpha[s] (x) dctx[s] and dHproj = sum_s de[s] * w * (1 - tanh^2)
+ * -- instead of a read-modify-write of both arrays in every step.
  * D must be a multiple of hidden (256). */
 int64_t mrn_attn_decoder_bwd_parts(int B);
 int mrn_attn_decoder_bwd_f32(const float* Hb, const float* Hproj, const float* alpha, const float* gates,
                              const float* cseq, const float* ctx, const float* hp, const float* dhid,
                              const float* w_score, const float* w_h2hT, const float* w_ih_ctxT, const float* w_hhT,
-                             float* dgates, float* dhp, float* dHb, float* dHproj, float* dwscore_part,
+                             float* dgates, float* dhp, float* dHb, float* dHproj, float* dwscore_part, float* dctx, float* de,
                              int B, int T, int D, int S, int hidden, void* stream);
 /* The same backward pass with its three transposed recurrent products (dgates . W_ih_ctx, dgates . W_hh, dhp . W_h2h) as split-fp16 x3:
  * w_h2hT / w_ih_ctxT / w_hhT = fragment-major fp16 hi / lo streams of the transposed weights (ops.pack_fragment_major_h), w_inv device
@@ -406,7 +409,8 @@ int mrn_attn_decoder_bwd_f32(const float* Hb, const float* Hproj, const float* a
 int mrn_attn_decoder_bwd_x3(const float* Hb, const float* Hproj, const float* alpha, const float* gates, const float* cseq,
                             const float* ctx, const float* hp, const float* dhid, const float* w_score, const void* w_h2hT,
                             const void* w_ih_ctxT, const void* w_hhT, const float* w_inv, const float* gscale, float* dgates, float* dhp,
-                            float* dHb, float* dHproj, float* dwscore_part, int B, int T, int D, int S, int hidden, void* stream);
+                            float* dHb, float* dHproj, float* dwscore_part, float* dctx, float* de, int B, int T, int D, int S, int hidden,
+                            void* stream);
 /* dtable[cut_unknown(idx[b][s])][:] += demb[b][s][:]  (nn.Embedding backward, modules/prediction.py:61) */
 int mrn_embed_scatter_add_f32(const int64_t* idx, int64_t idx_stride, const float* demb, float* dtable, int B, int S,
                               int E, int num_class, void* stream);

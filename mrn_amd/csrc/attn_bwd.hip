@@ -73,6 +73,7 @@ struct AttnBwdParams {
   const float *Hb, *Hproj, *alpha, *gates, *cseq, *ctx, *hp, *dhid, *w_score;
   const float *w_h2hT, *w_ih_ctxT, *w_hhT;
   float *dgates, *dhp, *dHb, *dHproj, *dws_part;
+  float *dctx, *de;       // [B][S][D] d context and [B][S][T] d score (pre-softmax) of every step: the operands of the two deferred passes below
   int B, T, D, S;
   int vb;      // samples per workgroup (16, 8 or 4): rows >= vb of the 16-row MFMA tile are treated like rows beyond the batch
   const float* w_inv;     // x3 form: device float[3] = 1 / prescale of W_h2h^T, W_ih_ctx^T, W_hh^T (then fp16 hi / lo fragment-major streams)
@@ -179,7 +180,9 @@ __global__ __launch_bounds__(NTH) void attn_decoder_bwd_kernel(const AttnBwdPara
     // (b) + (c), one 256-column block of the context at a time (D = 256 * G: DERNet's main head attends over the G
     // extractors' concatenated features, modules/model.py:289-291):
     //   dctx[:, blk] = dgates . W_ih[:, blk]   (block 0 shares its A fragments with dh_prev = dgates . W_hh, K = 4H)
-    //   dalpha[b][t] += dctx[b, blk] . Hb[b][t][blk] ;  dHb[b][t][blk] += alpha[b][t] * dctx[b, blk]   (wave per (b,t) pair)
+    //   dalpha[b][t] += dctx[b, blk] . Hb[b][t][blk]   (wave per (b,t) pair).  dHb = sum_s alpha[s] (x) dctx[s] is NOT accumulated here (a
+    //   read-modify-write of the workgroup's whole dHb slice every step, twice the bytes of everything else the step moves): the steps'
+    //   dctx go to p.dctx and attn_bwd_dhb_kernel forms the sum afterwards -- one small product per sample, dHb written once
     const int G = p.D / HID;
     for (int blk = 0; blk < G; ++blk) {
       if (blk == 0) {
@@ -193,7 +196,9 @@ __global__ __launch_bounds__(NTH) void attn_decoder_bwd_kernel(const AttnBwdPara
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          dctx_lds[(rbase + r) * HLD + j] = acc[0][r] * un_ih;
+          const float v = acc[0][r] * un_ih;
+          dctx_lds[(rbase + r) * HLD + j] = v;
+          if (b0 + rbase + r < Bend) p.dctx[((long)(b0 + rbase + r) * p.S + s) * p.D + j] = v;
           dh_rec[r] = acc[1][r] * un_hh;
         }
       } else {
@@ -206,7 +211,11 @@ __global__ __launch_bounds__(NTH) void attn_decoder_bwd_kernel(const AttnBwdPara
           mma_shared_a<1>(acc, dg_lds, GLD, wp, 4 * HID / 16, lane);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dctx_lds[(rbase + r) * HLD + j] = acc[0][r] * un_ih;
+        for (int r = 0; r < 4; ++r) {
+          const float v = acc[0][r] * un_ih;
+          dctx_lds[(rbase + r) * HLD + j] = v;
+          if (b0 + rbase + r < Bend) p.dctx[((long)(b0 + rbase + r) * p.S + s) * p.D + blk * HID + j] = v;
+        }
       }
       __syncthreads();
       for (int pr0 = wave * 4; pr0 < vb * T; pr0 += NW * 4) {
@@ -227,14 +236,6 @@ __global__ __launch_bounds__(NTH) void attn_decoder_bwd_kernel(const AttnBwdPara
         for (int u = 0; u < 4; ++u) {
           const f32x4 dv = *reinterpret_cast<const f32x4*>(dctx_lds + rows[u] * HLD + lane * 4);
           sacc[u] = hv[u][0] * dv[0] + hv[u][1] * dv[1] + hv[u][2] * dv[2] + hv[u][3] * dv[3];
-          if (ok[u]) {
-            const float a = al_lds[rows[u] * T + ts[u]];
-            f32x4* dst = reinterpret_cast<f32x4*>(p.dHb + ((long)(b0 + rows[u]) * T + ts[u]) * p.D + blk * HID + lane * 4);
-            f32x4 o = *dst;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = fmaf(a, dv[k], o[k]);
-            *dst = o;
-          }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -254,11 +255,16 @@ __global__ __launch_bounds__(NTH) void attn_decoder_bwd_kernel(const AttnBwdPara
       float dot = 0.f;
       for (int t = lane; t < T; t += 64) dot += al_lds[row * T + t] * de_lds[row * T + t];
       dot = wave_sum(dot);
-      for (int t = lane; t < T; t += 64) de_lds[row * T + t] = al_lds[row * T + t] * (de_lds[row * T + t] - dot);
+      for (int t = lane; t < T; t += 64) {
+        const float v = al_lds[row * T + t] * (de_lds[row * T + t] - dot);
+        de_lds[row * T + t] = v;
+        if (b0 + row < Bend) p.de[((long)(b0 + row) * p.S + s) * T + t] = v;
+      }
     }
     __syncthreads();
     // (e) through e = score . tanh(Hproj + hp): NW / vb waves per sample (each a contiguous slice of the T positions), lane = 4
-    //     channels; dhp accumulates in registers and the slices of one sample meet in LDS
+    //     channels; dhp accumulates in registers and the slices of one sample meet in LDS.  dHproj (the same terms summed over the steps
+    //     instead of over t) is formed afterwards by attn_bwd_dhproj_kernel from the steps' de -- no read-modify-write of dHproj here
     {
       const int wps = NW / vb;
       const int row = wave % vb, part = wave / vb, b = b0 + row;
@@ -277,33 +283,25 @@ __global__ __launch_bounds__(NTH) void attn_decoder_bwd_kernel(const AttnBwdPara
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const float de = de_lds[row * T + t + u];
-            f32x4* dst = reinterpret_cast<f32x4*>(p.dHproj + ((long)b * T + t + u) * HID + lane * 4);
-            f32x4 o = *dst;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
               const float uu = fast_tanh(hv[u][k] + pv[k]);
               const float dpre = de * wv[k] * (1.f - uu * uu);
               dws[k] = fmaf(de, uu, dws[k]);
               dhp[k] += dpre;
-              o[k] += dpre;
             }
-            *dst = o;
           }
         }
         for (; t < t_end; ++t) {
           const f32x4 hv = *reinterpret_cast<const f32x4*>(p.Hproj + ((long)b * T + t) * HID + lane * 4);
           const float de = de_lds[row * T + t];
-          f32x4* dst = reinterpret_cast<f32x4*>(p.dHproj + ((long)b * T + t) * HID + lane * 4);
-          f32x4 o = *dst;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const float uu = fast_tanh(hv[k] + pv[k]);
             const float dpre = de * wv[k] * (1.f - uu * uu);
             dws[k] = fmaf(de, uu, dws[k]);
             dhp[k] += dpre;
-            o[k] += dpre;
           }
-          *dst = o;
         }
       }
       if (wps > 1) {                      // (uniform across the workgroup)
@@ -452,13 +450,62 @@ __global__ __launch_bounds__(256) void tps_sample_bwd_kernel(const float* __rest
   }
 }
 
+// ---- the two deferred sums of the decoder backward (one workgroup of 256 threads per sample and 256-column block) ------------------
+// dHb[b][t][d] = sum_s alpha[b][s][t] * dctx[b][s][d]: thread = column d; alpha[b] and the block's dctx[b] staged in LDS
+__global__ __launch_bounds__(256) void attn_bwd_dhb_kernel(const float* __restrict__ alpha, const float* __restrict__ dctx,
+                                                           float* __restrict__ dHb, int T, int D, int S) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* al = sm;                 // [S][T]
+  float* dc = sm + S * T;         // [S][256]
+  const int b = blockIdx.x, d0 = blockIdx.y * 256, tid = threadIdx.x;
+  for (int i = tid; i < S * T; i += 256) al[i] = alpha[(long)b * S * T + i];
+  for (int s = 0; s < S; ++s) dc[s * 256 + tid] = dctx[((long)b * S + s) * D + d0 + tid];
+  __syncthreads();
+  float* out = dHb + (long)b * T * D + d0 + tid;
+  for (int t = 0; t < T; ++t) {
+    float a = 0.f;
+    for (int s = 0; s < S; ++s) a = fmaf(al[s * T + t], dc[s * 256 + tid], a);
+    out[(long)t * D] = a;
+  }
+}
+
+// dHproj[b][t][c] = sum_s de[b][s][t] * w_score[c] * (1 - tanh^2(Hproj[b][t][c] + hp[b][s][c])): thread = channel c, blockIdx.y = a slice
+// of the T positions; hp[b] and de[b] staged in LDS.  The terms are the main kernel's dpre (same expression, same fast_tanh).
+__global__ __launch_bounds__(256) void attn_bwd_dhproj_kernel(const float* __restrict__ Hproj, const float* __restrict__ hp,
+                                                              const float* __restrict__ de, const float* __restrict__ w_score,
+                                                              float* __restrict__ dHproj, int T, int S) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* hps = sm;                // [S][HID]
+  float* des = sm + S * HID;      // [S][T]
+  const int b = blockIdx.x, c = threadIdx.x;
+  for (int s = 0; s < S; ++s) hps[s * HID + c] = hp[((long)b * S + s) * HID + c];
+  for (int i = c; i < S * T; i += 256) des[i] = de[(long)b * S * T + i];
+  __syncthreads();
+  const float w = w_score[c];
+  const int per = (T + gridDim.y - 1) / gridDim.y;
+  const int t_end = min(T, (int)(blockIdx.y + 1) * per);
+  for (int t = blockIdx.y * per; t < t_end; ++t) {
+    const float x = Hproj[((long)b * T + t) * HID + c];
+    float a = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const float uu = fast_tanh(x + hps[s * HID + c]);
+      a += des[s * T + t] * w * (1.f - uu * uu);
+    }
+    dHproj[((long)b * T + t) * HID + c] = a;
+  }
+}
+
 }  // namespace
 
-// samples per workgroup of the decoder backward: the smallest of {4, 8, 16} that keeps the grid within 128 workgroups
+// samples per workgroup of the decoder backward: the smallest of {2, 4, 8, 16} that keeps the grid within one workgroup per CU (B = 256,
+// D = 256 / 1536, us per launch: 1150 / 3120 at 1, 1195 / 3360 at 2, 1440 / 4040 at 4, 1900 / 5420 at 8, 2840 / 8280 at 16; not 1 for the
+// reason given at the forward's rule, rnn.hip: attn_launch)
 static int attn_bwd_vb(int B) {
   static const int forced = getenv("MRN_ATTN_BWD_VB") ? atoi(getenv("MRN_ATTN_BWD_VB")) : 0;     // (A/B switch, read once)
   if (forced == 1 || forced == 2 || forced == 4 || forced == 8 || forced == 16) return forced;
-  return ceil_div(B, 4) <= 128 ? 4 : ceil_div(B, 8) <= 128 ? 8 : 16;
+  for (int v = 2; v < 16; v *= 2)
+    if (ceil_div(B, v) <= 256) return v;
+  return 16;
 }
 
 static int attn_bwd_launch(const AttnBwdParams& p, hipStream_t st) {
@@ -471,9 +518,15 @@ static int attn_bwd_launch(const AttnBwdParams& p, hipStream_t st) {
     hipFuncSetAttribute((const void*)attn_decoder_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
+  const size_t lds_b = sizeof(float) * (size_t)p.S * (p.T + 256), lds_p = sizeof(float) * (size_t)p.S * (HID + p.T);
+  MRN_CHECK_ARG(lds_b <= 64 * 1024 && lds_p <= 64 * 1024, "mrn_attn_decoder_bwd: S=%d, T=%d beyond the deferred sums' LDS staging", p.S, p.T);
   if (x3) hipLaunchKernelGGL(attn_decoder_bwd_kernel<true>, dim3(ceil_div(p.B, p.vb)), dim3(NTH), lds, st, p);
   else hipLaunchKernelGGL(attn_decoder_bwd_kernel<false>, dim3(ceil_div(p.B, p.vb)), dim3(NTH), lds, st, p);
   MRN_LAUNCH_CHECK("attn_decoder_bwd");
+  hipLaunchKernelGGL(attn_bwd_dhb_kernel, dim3(p.B, p.D / 256), dim3(256), lds_b, st, p.alpha, (const float*)p.dctx, p.dHb, p.T, p.D, p.S);
+  MRN_LAUNCH_CHECK("attn_bwd_dhb");
+  hipLaunchKernelGGL(attn_bwd_dhproj_kernel, dim3(p.B, 4), dim3(256), lds_p, st, p.Hproj, p.hp, (const float*)p.de, p.w_score, p.dHproj, p.T, p.S);
+  MRN_LAUNCH_CHECK("attn_bwd_dhproj");
   return MRN_OK;
 }
 
@@ -483,17 +536,17 @@ MRN_EXPORT int64_t mrn_attn_decoder_bwd_parts(int B) { return B > 0 ? ceil_div(B
 MRN_EXPORT int mrn_attn_decoder_bwd_f32(const float* Hb, const float* Hproj, const float* alpha, const float* gates,
                                         const float* cseq, const float* ctx, const float* hp, const float* dhid,
                                         const float* w_score, const float* w_h2hT, const float* w_ih_ctxT, const float* w_hhT,
-                                        float* dgates, float* dhp, float* dHb, float* dHproj, float* dwscore_part, int B, int T,
-                                        int D, int S, int hidden, void* stream) {
+                                        float* dgates, float* dhp, float* dHb, float* dHproj, float* dwscore_part, float* dctx,
+                                        float* de, int B, int T, int D, int S, int hidden, void* stream) {
   MRN_CHECK_ARG(Hb && Hproj && alpha && gates && cseq && ctx && hp && dhid && w_score && w_h2hT && w_ih_ctxT && w_hhT && dgates &&
-                    dhp && dHb && dHproj && dwscore_part, "mrn_attn_decoder_bwd_f32: null operand");
+                    dhp && dHb && dHproj && dwscore_part && dctx && de, "mrn_attn_decoder_bwd_f32: null operand");
   MRN_CHECK_ARG(hidden == HID && D >= HID && D % HID == 0,
                 "mrn_attn_decoder_bwd_f32: needs hidden == %d and D a multiple of it (got D=%d hidden=%d)", HID, D, hidden);
   if (B == 0 || S == 0) return MRN_OK;
   AttnBwdParams p;
   p.Hb = Hb; p.Hproj = Hproj; p.alpha = alpha; p.gates = gates; p.cseq = cseq; p.ctx = ctx; p.hp = hp; p.dhid = dhid;
   p.w_score = w_score; p.w_h2hT = w_h2hT; p.w_ih_ctxT = w_ih_ctxT; p.w_hhT = w_hhT;
-  p.dgates = dgates; p.dhp = dhp; p.dHb = dHb; p.dHproj = dHproj; p.dws_part = dwscore_part;
+  p.dgates = dgates; p.dhp = dhp; p.dHb = dHb; p.dHproj = dHproj; p.dws_part = dwscore_part; p.dctx = dctx; p.de = de;
   p.B = B; p.T = T; p.D = D; p.S = S;
   p.vb = attn_bwd_vb(B);
   p.w_inv = nullptr; p.gscale = nullptr;
@@ -507,17 +560,17 @@ MRN_EXPORT int mrn_attn_decoder_bwd_f32(const float* Hb, const float* Hproj, con
 MRN_EXPORT int mrn_attn_decoder_bwd_x3(const float* Hb, const float* Hproj, const float* alpha, const float* gates, const float* cseq,
                                        const float* ctx, const float* hp, const float* dhid, const float* w_score, const void* w_h2hT,
                                        const void* w_ih_ctxT, const void* w_hhT, const float* w_inv, const float* gscale, float* dgates,
-                                       float* dhp, float* dHb, float* dHproj, float* dwscore_part, int B, int T, int D, int S, int hidden,
-                                       void* stream) {
+                                       float* dhp, float* dHb, float* dHproj, float* dwscore_part, float* dctx, float* de, int B, int T,
+                                       int D, int S, int hidden, void* stream) {
   MRN_CHECK_ARG(Hb && Hproj && alpha && gates && cseq && ctx && hp && dhid && w_score && w_h2hT && w_ih_ctxT && w_hhT && w_inv && gscale &&
-                    dgates && dhp && dHb && dHproj && dwscore_part, "mrn_attn_decoder_bwd_x3: null operand");
+                    dgates && dhp && dHb && dHproj && dwscore_part && dctx && de, "mrn_attn_decoder_bwd_x3: null operand");
   MRN_CHECK_ARG(hidden == HID && D >= HID && D % HID == 0,
                 "mrn_attn_decoder_bwd_x3: needs hidden == %d and D a multiple of it (got D=%d hidden=%d)", HID, D, hidden);
   if (B == 0 || S == 0) return MRN_OK;
   AttnBwdParams p;
   p.Hb = Hb; p.Hproj = Hproj; p.alpha = alpha; p.gates = gates; p.cseq = cseq; p.ctx = ctx; p.hp = hp; p.dhid = dhid;
   p.w_score = w_score; p.w_h2hT = (const float*)w_h2hT; p.w_ih_ctxT = (const float*)w_ih_ctxT; p.w_hhT = (const float*)w_hhT;
-  p.dgates = dgates; p.dhp = dhp; p.dHb = dHb; p.dHproj = dHproj; p.dws_part = dwscore_part;
+  p.dgates = dgates; p.dhp = dhp; p.dHb = dHb; p.dHproj = dHproj; p.dws_part = dwscore_part; p.dctx = dctx; p.de = de;
   p.B = B; p.T = T; p.D = D; p.S = S;
   p.vb = attn_bwd_vb(B);
   p.w_inv = w_inv; p.gscale = gscale;

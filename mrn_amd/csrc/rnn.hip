@@ -574,7 +574,7 @@ __global__ __launch_bounds__(NTH) void attn_decoder_kernel(const AttnDecGroup gr
   const __amdgpu_buffer_rsrc_t r_ih = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_ih, 0, X3 ? 4 * HID * D * 4 : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_hh = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_hh, 0, X3 ? 4 * HID * HID * 4 : 0, 0x00020000);
 
-  // vb = samples per workgroup (16, or 8 / 4 when the batch would otherwise occupy less than half of the CUs: every step
+  // vb = samples per workgroup (2 ... 16, the fewest that keep the launch within 256 workgroups -- attn_launch: every step
   // re-reads the workgroup's Hproj / Hb slices (66 KB per sample each), so more, smaller workgroups shorten the step);
   // rows >= vb of the 16-row MFMA tile are treated like rows beyond the batch
   const int vb = grp.vb;
@@ -912,7 +912,14 @@ static int attn_fill(AttnDecParams& p, const float* Hb, const float* Hproj, cons
 static int attn_launch(AttnDecGroup& grp, int groups, int D, int T, hipStream_t st) {
   grp.groups = groups;
   const int B = grp.g[0].B;
-  grp.vb = (groups * ceil_div(B, 4) <= 128 && B > 4) ? 4 : (groups * ceil_div(B, BT) <= 128 && B > 8) ? 8 : BT;
+  // samples per workgroup: the fewest (from two) that keep the launch within one workgroup per CU.  The step is a chain of dependent
+  // phases whose length grows with the samples a workgroup walks through (B = 256, one expert, us per launch: 1100 at 1, 1130 at 2, 1315 at
+  // 4, 1700 at 8, 2580 at 16 -- tools/bench_decoder.py with MRN_ATTN_VB), and a second round of workgroups doubles it (three experts:
+  // 2330 at 2, 1380 at 4).  Not one: a trained network's launch then fills the chip, and the DER step, which runs its two heads'
+  // decoders side by side, loses 3 % (loop A gains 1.5 %: tools/probe/vb_sweep.sh)
+  grp.vb = BT;
+  for (int v = 2; v < BT; v *= 2)
+    if ((long)groups * ceil_div(B, v) <= 256) { grp.vb = v; break; }
   static const int forced_vb = getenv("MRN_ATTN_VB") ? atoi(getenv("MRN_ATTN_VB")) : 0;     // (A/B switch, read once)
   if (forced_vb == 1 || forced_vb == 2 || forced_vb == 4 || forced_vb == 8 || forced_vb == 16) grp.vb = forced_vb;
   grp.tiles = ceil_div(B, grp.vb);

@@ -2126,19 +2126,21 @@ def attn_decoder_bwd(Hb, Hproj, saves, dhid, w_score, w_h2hT, w_ih_ctxT, w_hhT, 
     dev = Hb.device
     dgates = torch.empty(B, S, 4 * hidden, device=dev, dtype=torch.float32)
     dhp = torch.empty(B, S, hidden, device=dev, dtype=torch.float32)
-    dHb = torch.zeros(B, T, D, device=dev, dtype=torch.float32)
-    dHproj = torch.zeros(B, T, hidden, device=dev, dtype=torch.float32)
+    dHb = torch.empty(B, T, D, device=dev, dtype=torch.float32)
+    dHproj = torch.empty(B, T, hidden, device=dev, dtype=torch.float32)
+    dctx = torch.empty(B, S, D, device=dev, dtype=torch.float32)          # per-step d context / d score: the step loop writes them, two
+    de = torch.empty(B, S, T, device=dev, dtype=torch.float32)            # launches behind it form dHb / dHproj (written once)
     nwg = call("mrn_attn_decoder_bwd_parts", B)
     dws = torch.empty(nwg, hidden, device=dev, dtype=torch.float32)
     dhid = dhid.contiguous()
     if w_inv is not None:
         gs = pow2_scale(dhid, 16.0)
         call("mrn_attn_decoder_bwd_x3", _p(Hb), _p(Hproj), _p(alpha), _p(gates), _p(cseq), _p(ctx), _p(hp), _p(dhid),
-             _p(w_score), _p(w_h2hT), _p(w_ih_ctxT), _p(w_hhT), _p(w_inv), _p(gs), _p(dgates), _p(dhp), _p(dHb), _p(dHproj), _p(dws), B, T, D, S,
+             _p(w_score), _p(w_h2hT), _p(w_ih_ctxT), _p(w_hhT), _p(w_inv), _p(gs), _p(dgates), _p(dhp), _p(dHb), _p(dHproj), _p(dws), _p(dctx), _p(de), B, T, D, S,
              hidden, _stream())
     else:
         call("mrn_attn_decoder_bwd_f32", _p(Hb), _p(Hproj), _p(alpha), _p(gates), _p(cseq), _p(ctx), _p(hp), _p(dhid),
-             _p(w_score), _p(w_h2hT), _p(w_ih_ctxT), _p(w_hhT), _p(dgates), _p(dhp), _p(dHb), _p(dHproj), _p(dws), B, T, D, S,
+             _p(w_score), _p(w_h2hT), _p(w_ih_ctxT), _p(w_hhT), _p(dgates), _p(dhp), _p(dHb), _p(dHproj), _p(dws), _p(dctx), _p(de), B, T, D, S,
              hidden, _stream())
     return dgates, dhp, dHb, dHproj, (colsum(dws) if nwg > 1 else dws[0])
 
