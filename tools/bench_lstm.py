@@ -27,3 +27,31 @@ for G, B in ((1, 256), (3, 256), (6, 256), (6, 64), (3, 32)):
     torch.cuda.synchronize()
     us = t0.elapsed_time(t1) / 10 * 1e3
     print(f"G {G} B {B:3d} T {T}: {us:7.1f} us / layer  {us / T:5.2f} us / step   checksum {fn().double().sum().item():.6f}")
+
+# one layer being TRAINED: forward with saves, backward through time (B = 256, T = 65, both directions)
+print("training forward (with saves) / backward")
+B, ndir = 256, 2
+torch.manual_seed(7)
+xproj = torch.randn(B, T, ndir * 4 * Hd, device=dev) * 0.7
+ws = [torch.randn(4 * Hd, Hd, device=dev) / 16.0 for _ in range(ndir)]
+b_hh = torch.randn(ndir * 4 * Hd, device=dev) / 16.0
+packs = [ops.pack_fragment_major_h(w) for w in ws]
+w_h, w_inv = torch.stack([p[0] for p in packs]).contiguous(), torch.cat([p[1] for p in packs]).contiguous()
+packsT = [ops.pack_fragment_major_h(w.t().contiguous()) for w in ws]
+wT_h, wT_inv = torch.stack([p[0] for p in packsT]).contiguous(), torch.cat([p[1] for p in packsT]).contiguous()
+fwd = lambda: ops.lstm_layer_x3_save(xproj, w_h, w_inv, b_hh, Hd, ndir)
+out, gates, cseq = fwd()
+dout = torch.randn(B, T, ndir * Hd, device=dev) * 1e-3
+bwd = lambda: ops.lstm_layer_bwd_x3(dout, gates, cseq, wT_h, wT_inv, Hd, ndir)
+for name, fn in (("forward ", fwd), ("backward", bwd)):
+    for _ in range(3):
+        fn()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(10):
+        fn()
+    t1.record()
+    torch.cuda.synchronize()
+    us = t0.elapsed_time(t1) / 10 * 1e3
+    print(f"{name}: {us:7.1f} us / layer  {us / T:5.2f} us / step")
+print("   checksum dgates %.8f" % bwd().double().sum().item())
