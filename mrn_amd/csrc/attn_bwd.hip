@@ -519,7 +519,15 @@ static int attn_bwd_launch(const AttnBwdParams& p, hipStream_t st) {
     attr = true;
   }
   const size_t lds_b = sizeof(float) * (size_t)p.S * (p.T + 256), lds_p = sizeof(float) * (size_t)p.S * (HID + p.T);
-  MRN_CHECK_ARG(lds_b <= 64 * 1024 && lds_p <= 64 * 1024, "mrn_attn_decoder_bwd: S=%d, T=%d beyond the deferred sums' LDS staging", p.S, p.T);
+  MRN_CHECK_ARG(lds_b <= 160 * 1024 && lds_p <= 160 * 1024, "mrn_attn_decoder_bwd: S=%d, T=%d beyond the deferred sums' LDS staging", p.S, p.T);
+  if (lds_b > 64 * 1024 || lds_p > 64 * 1024) {
+    static bool big = false;
+    if (!big) {
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dhb_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dhproj_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      big = true;
+    }
+  }
   if (x3) hipLaunchKernelGGL(attn_decoder_bwd_kernel<true>, dim3(ceil_div(p.B, p.vb)), dim3(NTH), lds, st, p);
   else hipLaunchKernelGGL(attn_decoder_bwd_kernel<false>, dim3(ceil_div(p.B, p.vb)), dim3(NTH), lds, st, p);
   MRN_LAUNCH_CHECK("attn_decoder_bwd");

@@ -204,29 +204,30 @@ def test_attention_decoder(ops, is_train):
     assert np.array_equal(out.argmax(2).cpu().numpy(), ref.argmax(2).numpy())
 
 
-@pytest.mark.parametrize("B,D", [(37, 256), (21, 512), (3, 256)])
-def test_attention_decoder_backward(ops, B, D):
+@pytest.mark.parametrize("B,D,T,S", [(37, 256, 65, 26), (21, 512, 65, 26), (3, 256, 65, 26), (5, 256, 150, 60)])
+def test_attention_decoder_backward(ops, B, D, T, S):
     """BPTT through the 26 teacher-forced steps (attn_decoder_bwd_kernel, several workgroups with a ragged last one, D = 256
-    and the DERNet-style wider context) against autograd through the oracle's step loop (reference prediction.py:58-68,102-118)"""
+    and the DERNet-style wider context) against autograd through the oracle's step loop (reference prediction.py:58-68,102-118); the
+    last case is a long line (150 positions, 60 steps: the deferred dHb / dHproj sums stage more than 64 KB in LDS)"""
     from oracle import mrn_oracle as O
     from mrn_amd.modules.prediction import Attention
     import torch.nn as nn
-    T, Hd, C = 65, 256, 97
+    Hd, C = 256, 97
     att = Attention(D, Hd, C, nn.Linear(Hd, C))
     sd = {k: rnd(*v.shape, seed=140 + i, scale=0.08) for i, (k, v) in enumerate(att.state_dict().items())}
     sd["char_embeddings.weight"] = rnd(C, 256, seed=177)
     att.load_state_dict(sd)
     Hb = rnd(B, T, D, seed=141)
-    text = torch.randint(0, C + 3, (B, 26), generator=torch.Generator().manual_seed(6))
+    text = torch.randint(0, C + 3, (B, S), generator=torch.Generator().manual_seed(6))
     text[:, 0] = 2
-    up = rnd(B, 26, C, seed=142)
+    up = rnd(B, S, C, seed=142)
     osd = {"P." + k: v.clone().requires_grad_(True) for k, v in sd.items()}
     Hr = Hb.clone().requires_grad_(True)
-    ref = O.attention_forward(osd, "P.", Hr, text, True, 25, osd["P.generator.weight"], osd["P.generator.bias"])
+    ref = O.attention_forward(osd, "P.", Hr, text, True, S - 1, osd["P.generator.weight"], osd["P.generator.bias"])
     (ref * up).sum().backward()
     att = att.cuda()
     Hc = cu(Hb).requires_grad_(True)
-    out = att(Hc, cu(text), True, 25)
+    out = att(Hc, cu(text), True, S - 1)
     (out * cu(up)).sum().backward()
     assert_close("decoder logits", out, ref, atol=1e-4)
     scale = Hr.grad.abs().max().item()
